@@ -1,0 +1,298 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own functions.
+
+TEST INFRASTRUCTURE ONLY.  Run in the authoring container only (it needs
+/root/reference, which never travels):
+
+    python -m oracle.gen_golden
+
+What is imported from the reference: ``manydepth.layers``,
+``manydepth.loss_utils`` (after registering an empty stand-in for the sibling module
+``manydepth.pareto``, which upstream never committed and only the ``opt.pareto`` branch
+uses) and ``dualrefine.layers``.  ``manydepth.trainer`` is not importable (cv2, wandb,
+detectron2, torchmetrics, absent vis.py), so the few lines of glue between the layers
+and the loss functions (trainer.py:573-629,1078-1207) are restated here, calling the
+reference's layer objects and loss functions for all arithmetic.
+
+The vectors are data: inputs (colours as uint8, disparities as fp16 so the stored
+values are exact), the CPU-generator noise, and the reference's outputs / gradients.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    stub = types.ModuleType("manydepth.pareto")
+
+    def pareto_fn(*a, **k):
+        raise NotImplementedError("manydepth/pareto.py is absent upstream")
+
+    stub.pareto_fn = pareto_fn
+    sys.modules["manydepth.pareto"] = stub
+    import manydepth.layers as ML
+    import manydepth.loss_utils as MLU
+    import dualrefine.layers as DL
+    return ML, MLU, DL
+
+
+def quantize_batch(batch):
+    """Make every stored input exactly representable in the on-disk dtype."""
+    q = dict(batch)
+    for k in ("color0", "color_m1", "color_p1"):
+        q[k] = torch.round(batch[k] * 255).clamp(0, 255) / 255
+    for k in ("disp_teacher", "disp_student", "lowest_cost"):
+        q[k] = batch[k].half().float()
+    for k in ("axisangle_m1", "translation_m1", "axisangle_p1", "translation_p1"):
+        q[k] = batch[k].clone()
+    return q
+
+
+def pack_inputs(q):
+    d = {}
+    for k in ("color0", "color_m1", "color_p1"):
+        d["in/" + k] = torch.round(q[k] * 255).to(torch.uint8).numpy()
+    for k in ("disp_teacher", "disp_student", "lowest_cost"):
+        d["in/" + k] = q[k].half().numpy()
+    for k in ("axisangle_m1", "translation_m1", "axisangle_p1", "translation_p1", "K", "inv_K"):
+        d["in/" + k] = q[k].numpy()
+    d["in/consistency_mask"] = q["consistency_mask"].to(torch.uint8).numpy()
+    d["in/augmentation_mask"] = q["augmentation_mask"].to(torch.uint8).numpy()
+    if "syn_rects" in q:
+        d["in/syn_rects"] = np.array(q["syn_rects"], dtype=np.int64)
+    return d
+
+
+def summarize(name, t, d, full):
+    """Full tensor for small cases; for big ones sums + an 8x8-strided subsample."""
+    a = t.detach().double()
+    if full:
+        d[name] = t.detach().numpy()
+        return
+    d[name + "#sum"] = np.float64(a.sum())
+    d[name + "#abs"] = np.float64(a.abs().sum())
+    d[name + "#sq"] = np.float64((a * a).sum())
+    if t.dim() >= 2 and t.shape[-1] >= 16 and t.shape[-2] >= 16:
+        d[name + "#sub"] = t.detach()[..., ::8, ::8].contiguous().numpy()
+    else:
+        d[name] = t.detach().numpy()
+
+
+def run_reference_step(ML, MLU, q, opt_kw, noise_seed, full, tag):
+    from mal_amd.synthetic import to_dicts, fake_image_synthesis
+    from oracle.mal_oracle import default_opt
+
+    B, _, H, W = q["color0"].shape
+    opt = default_opt(height=H, width=W, batch_size=B, **opt_kw)
+    inputs, mono_outputs, outputs, leaves = to_dicts(q, ML.transformation_from_parameters)
+    ssim = ML.SSIM()
+    backproject = ML.BackprojectDepth(B, H, W)
+    project = ML.Project3D(B, H, W)
+    synth = fake_image_synthesis(q["syn_rects"]) if "syn_rects" in q else None
+
+    def gen_pred(outs, is_multi):  # glue: trainer.py:1078-1170
+        disp = F.interpolate(outs[("disp", 0)], [H, W], mode="bilinear", align_corners=False)
+        _, depth = ML.disp_to_depth(disp, opt.min_depth, opt.max_depth)
+        outs[("depth", 0, 0)] = depth
+        for f in (-1, 1):
+            T = outs[("cam_T_cam", 0, f)]
+            if is_multi:
+                T = T.detach()
+            pts = backproject(depth, inputs[("inv_K", 0)])
+            grid = project(pts, inputs[("K", 0)], T)
+            outs[("sample", f, 0)] = grid
+            outs[("color", f, 0)] = F.grid_sample(inputs[("color", f, 0)], grid, padding_mode="border",
+                                                  align_corners=True)
+        has = False
+        if synth is not None and ((not is_multi and opt.temporal) or (is_multi and opt.main_temporal)):
+            has = synth(inputs, outs, 0)
+        return has
+
+    d = {}
+    shape = (B, 1, H, W)
+    torch.manual_seed(noise_seed)
+    noise_mono = torch.randn(shape)
+    noise_main = torch.randn(shape)
+    if full:
+        d["in/noise_mono"] = noise_mono.numpy()
+        d["in/noise_main"] = noise_main.numpy()
+    else:  # regenerated from the seed by the tests (torch.manual_seed; randn; randn), checked by sum
+        d["in/noise_mono#sum"] = np.float64(noise_mono.double().sum())
+        d["in/noise_main#sum"] = np.float64(noise_main.double().sum())
+    d["in/noise_seed"] = np.int64(noise_seed)
+
+    # pass A (teacher)
+    has_ins = gen_pred(mono_outputs, False) and opt.temporal
+    torch.manual_seed(noise_seed)
+    mono_losses, mono_reproj = MLU.compute_mono_losses(ssim, inputs, mono_outputs, opt.temporal, has_ins)
+    for key in list(mono_outputs.keys()):
+        if isinstance(key, tuple) and key[0] in ("depth", "disp"):
+            outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
+    # trainer.py:1066-1076 / :592-593
+    mono_d = outputs[("mono_depth", 0, 0)]
+    matching = 1 / outputs["lowest_cost"].unsqueeze(1)
+    mm = ((matching - mono_d) / mono_d) < 1.0
+    mm = mm * (((mono_d - matching) / matching) < 1.0)
+    d["matching_mask"] = mm[:, 0].to(torch.uint8).numpy() if full else np.int64(mm.sum())
+    outputs["consistency_mask"] = outputs["consistency_mask"] * mm[:, 0]
+    # pass B (ensemble): trainer.py:594-600,1172-1207
+    ensemble_reproj = None
+    if not opt.no_ens:
+        disp_e = (mono_outputs[("disp", 0)].detach() + outputs[("disp", 0)].detach()) / 2.0
+        disp_e = F.interpolate(disp_e, [H, W], mode="bilinear", align_corners=False)
+        _, depth_e = ML.disp_to_depth(disp_e, opt.min_depth, opt.max_depth)
+        rr = []
+        for f in (-1, 1):
+            pts = backproject(depth_e, inputs[("inv_K", 0)])
+            grid = project(pts, inputs[("K", 0)], outputs[("cam_T_cam", 0, f)].detach())
+            pred = F.grid_sample(inputs[("color", f, 0)], grid, padding_mode="border", align_corners=True)
+            rr.append(MLU.compute_reprojection_loss(ssim, pred, inputs[("color", 0, 0)]))
+        ensemble_reproj = torch.min(torch.cat(rr, 1), dim=1, keepdim=True)[0]
+    # pass C (student)
+    multi_has = gen_pred(outputs, True) and opt.main_temporal
+    w_list = [0.7, 0.3]
+    losses, w_out, loss_list = MLU.compute_main_losses(ssim, inputs, outputs, mono_reproj, ensemble_reproj, opt,
+                                                       None, w_list, multi_has)
+    main_only = {k: v.detach().clone() for k, v in losses.items()}
+    for k, v in mono_losses.items():
+        losses[k] = losses[k] + v
+    if opt.loss_blc:
+        loss_list[0] = loss_list[0] + mono_losses["loss"]
+        # loss_utils.py:303-318 (restated: .cuda() there): bs * sum_i w_i L_i
+        final = B * (w_list[0] * loss_list[0] + w_list[1] * loss_list[1])
+        d["loss_list0"] = np.float64(loss_list[0].item())
+        d["loss_list1"] = np.float64(loss_list[1].item())
+    else:
+        final = losses["loss"]
+    final.backward()
+
+    d["final_loss"] = np.float64(final.item())
+    for k, v in mono_losses.items():
+        d["mono_losses/" + k] = np.float64(v.item())
+    for k, v in main_only.items():
+        d["main_losses/" + k] = np.float64(v.item())
+    for k, v in losses.items():
+        d["losses/" + k] = np.float64(v.item())
+    summarize("mono_reproj", mono_reproj, d, full)
+    if ensemble_reproj is not None:
+        summarize("ensemble_reproj", ensemble_reproj, d, full)
+    summarize("mono/depth", mono_outputs[("depth", 0, 0)], d, full)
+    summarize("multi/depth", outputs[("depth", 0, 0)], d, full)
+    summarize("consistency_target", outputs["consistency_target/0"], d, full)
+    for f in (-1, 1):
+        fn = "m1" if f < 0 else "p1"
+        summarize("mono/color_" + fn, mono_outputs[("color", f, 0)], d, full)
+        summarize("multi/color_" + fn, outputs[("color", f, 0)], d, full)
+        summarize("mono/sample_" + fn, mono_outputs[("sample", f, 0)].permute(0, 3, 1, 2), d, full)
+        if ("syn", f, 0) in mono_outputs:
+            summarize("mono/syn_" + fn, mono_outputs[("syn", f, 0)], d, full)
+    for k, t in leaves.items():
+        g = t.grad if t.grad is not None else torch.zeros_like(t)
+        summarize("grad/" + k, g, d, full)
+    d.update(pack_inputs(q))
+    d["opt"] = np.array(repr(sorted(opt_kw.items())))
+    path = os.path.join(OUT, tag + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", "final_loss", d["final_loss"])
+
+
+def run_reference_layers(ML, MLU, DL, tag, B=2, H=24, W=40, seed=77):
+    from mal_amd.synthetic import make_batch
+    q = quantize_batch(make_batch(B, H, W, seed))
+    d = pack_inputs(q)
+    g = torch.Generator().manual_seed(seed + 1)
+    disp = q["disp_teacher"].clone().requires_grad_(True)
+    sd, depth = ML.disp_to_depth(disp, 0.1, 100.0)
+    d["scaled_disp"], d["depth"] = sd.detach().numpy(), depth.detach().numpy()
+    for inv in (False, True):
+        aa, tr = q["axisangle_m1"], q["translation_m1"]
+        d["T_inv%d" % inv] = ML.transformation_from_parameters(aa, tr, invert=inv).numpy()
+    d["rot"] = ML.rot_from_axisangle(q["axisangle_p1"]).numpy()
+    d["trans"] = ML.get_translation_matrix(q["translation_p1"]).numpy()
+    T = ML.transformation_from_parameters(q["axisangle_m1"], q["translation_m1"], invert=True).requires_grad_(True)
+    pts = ML.BackprojectDepth(B, H, W)(depth, q["inv_K"])
+    d["cam_points"] = pts.detach().numpy()
+    grid, zc = ML.Project3D(B, H, W, dc=True)(pts, q["K"], T)
+    d["grid_A"], d["proj_depth"] = grid.detach().numpy(), zc.detach().numpy()
+    warped = F.grid_sample(q["color_m1"], grid, padding_mode="border", align_corners=True)
+    d["warped_A"] = warped.detach().numpy()
+    gw = torch.randn(warped.shape, generator=g)
+    d["in/g_warped"] = gw.numpy()
+    (warped * gw).sum().backward()
+    d["grad_disp_A"], d["grad_T_A"] = disp.grad.numpy().copy(), T.grad.numpy().copy()
+    # DualRefine convention (dualrefine/layers.py:216-226 + align_corners=False)
+    disp2 = q["disp_teacher"].clone().requires_grad_(True)
+    T2 = T.detach().clone().requires_grad_(True)
+    _, depth2 = DL.disp_to_depth(disp2, 0.1, 100.0)
+    pts2 = DL.BackprojectDepth(B, H, W)(depth2, q["inv_K"])
+    grid2 = DL.Project3D(B, H, W)(pts2, q["K"], T2)
+    warped2 = F.grid_sample(q["color_m1"], grid2, padding_mode="border", align_corners=False)
+    d["grid_B"], d["warped_B"] = grid2.detach().numpy(), warped2.detach().numpy()
+    (warped2 * gw).sum().backward()
+    d["grad_disp_B"], d["grad_T_B"] = disp2.grad.numpy().copy(), T2.grad.numpy().copy()
+    # photometric primitives
+    x = warped.detach().clone().requires_grad_(True)
+    y = q["color0"].clone().requires_grad_(True)
+    ssim = ML.SSIM()
+    s = ssim(x, y)
+    d["ssim"] = s.detach().numpy()
+    gs = torch.randn(s.shape, generator=g)
+    d["in/g_ssim"] = gs.numpy()
+    (s * gs).sum().backward()
+    d["grad_ssim_x"], d["grad_ssim_y"] = x.grad.numpy().copy(), y.grad.numpy().copy()
+    x2 = warped.detach().clone().requires_grad_(True)
+    r = MLU.compute_reprojection_loss(ssim, x2, q["color0"])
+    d["reproj"] = r.detach().numpy()
+    gr = torch.randn(r.shape, generator=g)
+    d["in/g_reproj"] = gr.numpy()
+    (r * gr).sum().backward()
+    d["grad_reproj_pred"] = x2.grad.numpy().copy()
+    ident = MLU.compute_reprojection_loss(ssim, q["color_m1"], q["color0"])
+    d["identity_reproj"] = ident.numpy()
+    d["automask"] = MLU.compute_loss_masks(r.detach(), ident).numpy()
+    d["automask_none"] = MLU.compute_loss_masks(r.detach(), None).numpy()
+    disp3 = q["disp_student"].clone().requires_grad_(True)
+    sm = ML.get_smooth_loss(disp3, q["color0"])
+    sm.backward()
+    d["smooth"], d["grad_smooth"] = np.float64(sm.item()), disp3.grad.numpy().copy()
+    path = os.path.join(OUT, tag + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sys.path.insert(0, ROOT)
+    ML, MLU, DL = import_reference()
+    from mal_amd.synthetic import make_batch
+    torch.set_num_threads(8)
+    run_reference_layers(ML, MLU, DL, "layers_b2_24x40")
+    run_reference_layers(ML, MLU, DL, "layers_b1_19x33", B=1, H=19, W=33, seed=78)
+    small = quantize_batch(make_batch(2, 32, 64, seed=1234))
+    run_reference_step(ML, MLU, small, {}, 1000, True, "step_b2_32x64_distil")
+    run_reference_step(ML, MLU, small, {"no_ens": True}, 1001, True, "step_b2_32x64_noens")
+    run_reference_step(ML, MLU, small, {"loss_blc": True}, 1002, True, "step_b2_32x64_lossblc")
+    run_reference_step(ML, MLU, small, {"no_ens": True, "dual_distil": True}, 1003, True, "step_b2_32x64_dual")
+    syn = quantize_batch(make_batch(2, 32, 64, seed=1235, with_syn=True))
+    run_reference_step(ML, MLU, syn, {"temporal": True}, 1004, True, "step_b2_32x64_temporal")
+    run_reference_step(ML, MLU, syn, {"temporal": True, "main_temporal": True}, 1005, True,
+                       "step_b2_32x64_temporal_main")
+    ragged = quantize_batch(make_batch(3, 37, 50, seed=1236))
+    run_reference_step(ML, MLU, ragged, {}, 1006, True, "step_b3_37x50_distil")
+    big = quantize_batch(make_batch(2, 192, 640, seed=1234))
+    run_reference_step(ML, MLU, big, {}, 2000, False, "step_b2_192x640_distil")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""Load the committed golden vectors (tests/golden/*.npz, written by oracle/gen_golden.py
+from the reference's own functions) back into the batch layout of mal_amd.synthetic."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+STEP_CASES = [
+    "step_b2_32x64_distil", "step_b2_32x64_noens", "step_b2_32x64_lossblc", "step_b2_32x64_dual",
+    "step_b2_32x64_temporal", "step_b2_32x64_temporal_main", "step_b3_37x50_distil",
+]
+BIG_CASE = "step_b2_192x640_distil"
+LAYER_CASES = ["layers_b2_24x40", "layers_b1_19x33"]
+
+
+def load(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def batch_from_golden(z):
+    b = {}
+    for k in ("color0", "color_m1", "color_p1"):
+        b[k] = torch.from_numpy(z["in/" + k].astype(np.float32)) / 255
+    for k in ("disp_teacher", "disp_student", "lowest_cost"):
+        b[k] = torch.from_numpy(z["in/" + k].astype(np.float32))
+    for k in ("axisangle_m1", "translation_m1", "axisangle_p1", "translation_p1", "K", "inv_K"):
+        b[k] = torch.from_numpy(z["in/" + k].copy())
+    b["consistency_mask"] = torch.from_numpy(z["in/consistency_mask"].astype(np.float32))
+    b["augmentation_mask"] = torch.from_numpy(z["in/augmentation_mask"].astype(np.float32))
+    if "in/syn_rects" in z:
+        b["syn_rects"] = [tuple(int(v) for v in r) for r in z["in/syn_rects"]]
+    return b
+
+
+def opt_kwargs(z):
+    return dict(ast.literal_eval(str(z["opt"])))
+
+
+def noises(z, shape):
+    if "in/noise_mono" in z:
+        return torch.from_numpy(z["in/noise_mono"].copy()), torch.from_numpy(z["in/noise_main"].copy())
+    torch.manual_seed(int(z["in/noise_seed"]))
+    n0 = torch.randn(shape)
+    n1 = torch.randn(shape)
+    return n0, n1
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b) / np.maximum(np.abs(b), 1e-6)
+
+
+def assert_close(a, b, rtol, name="", floor=1e-6, max_bad_frac=0.0):
+    """|a-b| <= rtol*max(|b|, floor) elementwise; ``max_bad_frac`` of elements may miss
+    (used only for per-pixel maps at argmin ties / clamp boundaries, stated at call sites)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    bad = np.abs(a - b) > rtol * np.maximum(np.abs(b), floor)
+    frac = bad.mean() if bad.size else 0.0
+    assert frac <= max_bad_frac, "%s: %.3g of elements off (allowed %.3g), worst rel %.3g" % (
+        name, frac, max_bad_frac, (np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
