@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py -- MAL photometric-reprojection + motion-aware-loss path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one synthetic KITTI-shaped batch per GPU
+(B=12, 192x640, BASELINE.json configs[1]): process_batch's loss half --
+teacher pass (warp + SSIM/L1 + min + automask, forward+backward to disparity and poses),
+ensemble pass (no grad), student pass (+ consistency + distillation), the two smoothness
+terms, pose composition and the full backward to the four leaves
+(manydepth/trainer.py:573-642).  Inputs are resident in HBM before the timed region.
+The path shards by batch with no data-path collective (each DDP rank
+normalises over its own batch); ranks are replicas over disjoint batches -> weak scaling.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline:     the teacher-pass fused kernel, timed live with HIP events on its stream
+  cpu_baseline: the CPU oracle (PyTorch-CPU restatement == the reference's path) on the host.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+B, H, W = 12, 192, 640
+ALG_BYTES_PER_PX = 96      # fused warp+SSIM+min-reproj+automask fwd+bwd, fp32, F=2
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--graph", type=int, default=0, help="replay the step from a HIP graph (default eager)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+class Step:
+    """Everything a step needs, resident on the device."""
+
+    def __init__(self, dev, seed):
+        from mal_amd import config, layers, trainer
+        from mal_amd.synthetic import make_batch
+        config.noise_source = "cuda"       # device RNG: no host randn / H2D on the step
+        config.consistency_target = False  # logging-only map (loss_utils.py:212-215)
+        self.layers = layers
+        b = make_batch(B, H, W, seed=seed)
+        mv = lambda t: t.to(dev).contiguous()
+        self.inputs = {("color", 0, 0): mv(b["color0"]), ("color", -1, 0): mv(b["color_m1"]),
+                       ("color", 1, 0): mv(b["color_p1"]), ("K", 0): mv(b["K"]), ("inv_K", 0): mv(b["inv_K"])}
+        self.leaves = {k: mv(b[k]).requires_grad_(True) for k in
+                       ("disp_teacher", "disp_student", "axisangle_m1", "translation_m1", "axisangle_p1",
+                        "translation_p1")}
+        self.cmask, self.aug, self.lowest = mv(b["consistency_mask"]), mv(b["augmentation_mask"]), mv(b["lowest_cost"])
+        self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B), fuse=True)
+        self.batch_cpu = b
+
+    def __call__(self):
+        L, lv = self.layers, self.leaves
+        for t in lv.values():
+            t.grad = None
+        T_m1 = L.transformation_from_parameters(lv["axisangle_m1"], lv["translation_m1"], True)
+        T_p1 = L.transformation_from_parameters(lv["axisangle_p1"], lv["translation_p1"], False)
+        mono_outputs = {("disp", 0): lv["disp_teacher"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1}
+        outputs = {("disp", 0): lv["disp_student"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1,
+                   "consistency_mask": self.cmask, "augmentation_mask": self.aug, "lowest_cost": self.lowest}
+        _, losses, _ = self.lp.compute_batch_losses(self.inputs, mono_outputs, outputs)
+        losses["loss"].backward()
+        return losses["loss"]
+
+
+def cpu_baseline(batch, steps):
+    """The CPU oracle (oracle/mal_oracle.py, PyTorch-CPU ATen ops in the reference's order)
+    on the same workload: B=12 192x640, passes A+B+C forward+backward."""
+    from mal_amd.synthetic import to_dicts
+    from oracle import mal_oracle as O
+    opt = O.default_opt(height=H, width=W, batch_size=B)
+    threads = torch.get_num_threads()
+
+    def one():
+        inputs, mono_outputs, outputs, leaves = to_dicts(batch, O.transformation_from_parameters)
+        losses, *_ = O.mal_loss_step(opt, inputs, mono_outputs, outputs)
+        losses["loss"].backward()
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of the same B=12 192x640 loss step (passes A+B+C fwd+bwd) after 1 warm-up, "
+                      "torch CPU threads=%d" % (steps, threads), "ms_per_step": 1e3 * dt / steps}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the MAL loss path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from mal_amd import build, _lib
+    if rank == 0:
+        build.build(verbose=False)
+    if dist is not None:
+        dist.barrier()
+    lib = _lib.load()
+    step = Step(dev, 1234 + rank)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run = step
+    graph = None
+    if args.graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        run = graph.replay
+
+    for _ in range(args.warmup):
+        run()
+    # HIP events around the teacher-pass kernel (the first mal_pass_fused of a step), eager only
+    ev = []
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if graph is None:
+            a, b_ = lib.mal_event_create(), lib.mal_event_create()
+            lib.mal_profile_next_pass(a, b_)
+            ev.append((a, b_))
+        run()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if graph is not None:  # kernel timing needs eager launches: a few extra steps outside the timed region
+        for i in range(20):
+            a, b_ = lib.mal_event_create(), lib.mal_event_create()
+            lib.mal_profile_next_pass(a, b_)
+            ev.append((a, b_))
+            step()
+        torch.cuda.synchronize()
+    durs = []
+    for a, b_ in ev:
+        ms = ctypes.c_float(0)
+        if lib.mal_event_elapsed_ms(a, b_, ctypes.byref(ms)) == 0:
+            durs.append(ms.value)
+        lib.mal_event_destroy(a), lib.mal_event_destroy(b_)
+    kern_ms = sum(durs) / max(len(durs), 1)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    n_px = B * H * W
+    achieved = ALG_BYTES_PER_PX * n_px / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("pass_kernel_teacher_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "train images/sec at B=12 192x640 KITTI-shaped (MAL loss path: passes A+B+C fwd+bwd)",
+        "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ManyDepth+MAL loss step, B=12 per GPU, 192x640, --distil (teacher+ensemble+student "
+                               "passes, consistency+distillation+smoothness), fwd+bwd to disp/pose leaves; "
+                               "networks not included", "global_batch": B * world, "height": H, "width": W,
+                   "parallelism": "dp%d (replicas over disjoint batches, no data-path collective)" % world,
+                   "launch": "hip-graph" if graph is not None else "eager"},
+        "roofline": {"bound": "hbm", "kernel": "mal::pass_kernel<GRAD,AUTOMASK,POSE> (teacher pass: warp+SSIM+L1+"
+                                               "min+automask fwd+bwd, one launch)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "alg_bytes_per_px": ALG_BYTES_PER_PX, "pixels_per_launch": n_px,
+                     "kernel_ms": kern_ms, "launches_timed": len(durs)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(step.batch_cpu, args.cpu_steps)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

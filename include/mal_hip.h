@@ -1,0 +1,212 @@
+/*
+ * mal_hip.h -- C ABI of libmal_hip.so: the MI355X (gfx950) kernels for MAL's photometric
+ * reprojection + motion-aware loss hot path.
+ *
+ * The reference (YuejiangDong/MAL) has no FFI for this path: it sits behind plain Python
+ * imports of manydepth/layers.py, manydepth/loss_utils.py and three Trainer methods
+ * (manydepth/trainer.py:29-30,44).  These entry points are what a
+ * ctypes binding in those modules calls instead of the chain of ATen ops; each one cites
+ * the reference lines it replaces.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless the name says otherwise
+ *     (u8 = uint8_t, f64 = double); images are NCHW; 4x4 matrices are row-major [B][16].
+ *   - every function returns 0 (MAL_OK) or a negative MAL_E* code; nothing throws, nothing
+ *     allocates, nothing synchronises: work is enqueued on `stream` (a hipStream_t passed
+ *     as void*; NULL = the default stream) and scratch memory comes from the caller's
+ *     workspace (`mal_workspace_bytes`).
+ *   - `convention`: 0 = ManyDepth / DynamicDepth (grid = (u/(W-1)-0.5)*2 sampled with
+ *     align_corners=True, manydepth/layers.py:192-194 + trainer.py:1122-1125);
+ *     1 = DualRefine (grid = 2*(u+0.5)/W-1 sampled with align_corners=False,
+ *     dualrefine/layers.py:224-225 + dualrefine/trainer.py:444-447).
+ *   - F = number of source frames (2: frame ids -1, +1); arrays "[F]" are host arrays of F
+ *     device pointers, copied by value at launch (F <= MAL_MAX_FRAMES).
+ */
+#ifndef MAL_HIP_H
+#define MAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAL_VERSION 100 /* 0.1.0 */
+#define MAL_MAX_FRAMES 2
+#define MAL_MAX_CAND 4 /* warped -1,+1 and the temporal-hint "syn" -1,+1 (loss_utils.py:79-90) */
+
+enum {
+  MAL_OK = 0,
+  MAL_EINVAL = -1,    /* bad argument (null pointer, non-positive size, F/n_cand out of range) */
+  MAL_ESHAPE = -2,    /* image smaller than 2x2 (reflection pad needs >= 2) or too large for int32 indexing */
+  MAL_EWORKSPACE = -3,/* workspace too small: call mal_workspace_bytes */
+  MAL_ELAUNCH = -4,   /* hipLaunchKernel / hipGetLastError failed */
+  MAL_ENODEVICE = -5  /* no HIP device */
+};
+
+/* flags for mal_pass_fused / mal_photo_* */
+enum {
+  MAL_F_AUTOMASK = 1,   /* mask = argmin([min_c r_c, ident + 1e-5*noise]) == 0  (loss_utils.py:105-110) */
+  MAL_F_GRAD = 2,       /* also produce the (unnormalised) gradient maps */
+  MAL_F_POSE_GRAD = 4,  /* ... and d/dT (teacher pass; the student pass detaches T, trainer.py:1107-1109) */
+  MAL_F_NO_SSIM = 8,    /* --no_ssim: r = mean_c |t - p| (trainer.py:1217-1218) */
+  MAL_F_AVG = 16,       /* --avg_reprojection (dualrefine/trainer.py:579-583): mean over candidates */
+  MAL_F_EPILOGUE = 32,  /* student epilogue: consistency + distillation terms (loss_utils.py:193-254) */
+  MAL_F_DUAL_DISTIL = 64/* --dual_distil (loss_utils.py:232-234): the idx==0 target keeps its graph */
+};
+
+int mal_version(void);
+const char* mal_strerror(int code);
+/* 0 if a gfx950-class HIP device is present, else MAL_ENODEVICE. Never called by the loaders. */
+int mal_device_check(void);
+
+/* Scratch bytes the fused / warp-backward / photo entry points need for a (B,H,W) batch. */
+size_t mal_workspace_bytes(int B, int H, int W);
+
+/* ---- a1: manydepth/layers.py:14-23 ------------------------------------------------ */
+int mal_disp_to_depth(const float* disp, size_t n, float min_depth, float max_depth,
+                      float* scaled_out /*nullable*/, float* depth_out /*nullable*/, void* stream);
+/* g_disp = g_scaled*(1/min-1/max) - g_depth*depth^2*(1/min-1/max) */
+int mal_disp_to_depth_bwd(const float* disp, const float* g_scaled /*nullable*/, const float* g_depth /*nullable*/,
+                          size_t n, float min_depth, float max_depth, float* g_disp, void* stream);
+
+/* ---- a2: BackprojectDepth.forward, manydepth/layers.py:163-168 ---------------------- */
+int mal_backproject(const float* depth /*B,1,H,W*/, const float* inv_K /*B,16*/, int B, int H, int W,
+                    float* points /*B,4,HW*/, void* stream);
+int mal_backproject_bwd(const float* g_points /*B,4,HW*/, const float* inv_K, int B, int H, int W,
+                        float* g_depth /*B,1,H,W*/, void* stream);
+
+/* ---- a3: Project3D.forward, manydepth/layers.py:184-199; dualrefine/layers.py:216-226 -- */
+int mal_project3d(const float* points /*B,4,HW*/, const float* K, const float* T, int B, int H, int W,
+                  float eps, int convention, float* grid /*B,H,W,2*/, float* z_out /*nullable B,1,H,W*/,
+                  void* stream);
+/* g_points (B,4,HW) and g_T (B,16, = K^T [g_P;0]); g_z nullable. ws: mal_workspace_bytes. */
+int mal_project3d_bwd(const float* points, const float* K, const float* T, const float* g_grid,
+                      const float* g_z /*nullable*/, int B, int H, int W, float eps, int convention,
+                      float* g_points /*nullable*/, float* g_T /*nullable B,16*/, void* ws, size_t ws_bytes,
+                      void* stream);
+
+/* ---- a4: F.grid_sample(bilinear, border), trainer.py:1122-1125; dualrefine/trainer.py:444-447 */
+int mal_grid_sample(const float* src /*B,C,H,W*/, const float* grid /*B,Ho,Wo,2*/, int B, int C, int H, int W,
+                    int Ho, int Wo, int align_corners, float* out /*B,C,Ho,Wo*/, void* stream);
+/* gradient wrt the grid only (the reference's sources carry no gradient) */
+int mal_grid_sample_bwd(const float* src, const float* grid, const float* g_out, int B, int C, int H, int W,
+                        int Ho, int Wo, int align_corners, float* g_grid /*B,Ho,Wo,2*/, void* stream);
+
+/* ---- a7: SSIM.forward, manydepth/layers.py:243-257 ----------------------------------- */
+int mal_ssim(const float* x, const float* y, int B, int C, int H, int W, float* out /*B,C,H,W*/, void* stream);
+int mal_ssim_bwd(const float* x, const float* y, const float* g_out, int B, int C, int H, int W,
+                 float* g_x /*nullable*/, float* g_y /*nullable*/, void* stream);
+
+/* ---- a8: compute_reprojection_loss, manydepth/loss_utils.py:46-55 -------------------- */
+int mal_reprojection_loss(const float* pred, const float* target, int B, int C, int H, int W, int no_ssim,
+                          float* out /*B,1,H,W*/, void* stream);
+int mal_reprojection_loss_bwd(const float* pred, const float* target, const float* g_out /*B,1,H,W*/,
+                              int B, int C, int H, int W, int no_ssim,
+                              float* g_pred /*nullable*/, float* g_target /*nullable*/, void* stream);
+
+/* ---- a12: get_smooth_loss on mean-normalised disparity, layers.py:210-223 + loss_utils.py:119-121
+ * normalise != 0: disp is divided by (mean_HW disp + 1e-7) per sample first.
+ * loss_out[0] (f64, device) = mean_x-term + mean_y-term.  With g_disp != NULL also writes
+ * d loss / d disp (exact, including the mean-normalisation coupling).                      */
+int mal_smooth_loss(const float* disp /*B,1,H,W*/, const float* img /*B,C,H,W*/, int B, int C, int H, int W,
+                    int normalise, double* loss_out, float* g_disp /*nullable*/, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* ---- a5 (materialising): Trainer.generate_images_pred, manydepth/trainer.py:1093-1125 --
+ * depth = 1/(1/max + (1/min-1/max)*disp); for f<F: grid_f = Project3D(Backproject(depth), K, T_f);
+ * warped_f = grid_sample(src_f, grid_f).  Any of the outputs may be NULL.                  */
+int mal_warp_fwd(const float* disp /*B,1,H,W, full resolution*/, const float* K, const float* inv_K,
+                 const float* const* T /*[F] B,16*/, const float* const* src /*[F] B,3,H,W*/,
+                 int B, int H, int W, int F, float min_depth, float max_depth, float eps, int convention,
+                 float* depth_out, float* const* grid_out /*[F] B,H,W,2*/, float* const* warped_out /*[F] B,3,H,W*/,
+                 void* stream);
+/* Backward of the above.  g_warped[f] / g_grid[f] / g_depth may each be NULL (absent).
+ * g_disp (B,1,H,W) is overwritten; g_T[f] (B,16) nullable.                                */
+int mal_warp_bwd(const float* disp, const float* K, const float* inv_K, const float* const* T,
+                 const float* const* src, const float* const* g_warped, const float* const* g_grid,
+                 const float* g_depth, int B, int H, int W, int F, float min_depth, float max_depth, float eps,
+                 int convention, float* g_disp, float* const* g_T, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a8-a10 on materialised candidates: the per-pixel min / automask reduction --------
+ * cand[c] (B,3,H,W), c < n_cand <= MAL_MAX_CAND.  r_c = compute_reprojection_loss(cand_c, target);
+ * rp = min_c r_c (first minimum wins, as torch.min on CPU) or the mean with MAL_F_AVG;
+ * weight w = automask * ext_mask (each optional; ext_mask (B,1,H,W)).
+ * ident: (B,1,H,W) min over the identity losses (mal_photo_fwd on the raw sources with
+ *        flags=0 produces it); noise: (B,1,H,W) N(0,1) draws (CPU generator upstream).
+ * Outputs: min_reproj (B,1,H,W, nullable), argmin_u8 (B,1,H,W, nullable),
+ *          weight_out (B,1,H,W nullable), sums[0]=sum(rp*w), sums[1]=sum(w)  (f64, device).   */
+int mal_photo_fwd(const float* target, const float* const* cand, int n_cand, const float* ident /*nullable*/,
+                  const float* noise /*nullable*/, const float* ext_mask /*nullable*/, int B, int H, int W,
+                  int flags, float* min_reproj, uint8_t* argmin_u8, float* weight_out, double* sums,
+                  void* ws, size_t ws_bytes, void* stream);
+/* d(sum(rp*w))/d cand_c -> g_cand[c] (B,3,H,W), scaled by *scale (device f32 scalar, nullable = 1)
+ * divided by (sums[1] + 1e-7) when sums != NULL.  weight / argmin come from mal_photo_fwd.  */
+int mal_photo_bwd(const float* target, const float* const* cand, int n_cand, const uint8_t* argmin_u8,
+                  const float* weight, const float* scale, const double* sums, int B, int H, int W, int flags,
+                  float* const* g_cand, void* stream);
+
+/* ---- the fused pass: a2-a4 + a7-a10 (+ the a11 epilogue) in ONE launch ------------------
+ * Replaces generate_images_pred + compute_mono_losses / compute_main_losses /
+ * generate_images_pred_ensemble when the warped images need not be materialised
+ * (manydepth/trainer.py:573-612, loss_utils.py:57-254).
+ *
+ * Inputs: disp (full res), K, inv_K, T[F], src[F], target; ident/noise (automask), ext_mask
+ * (the student's consistency_mask*(1-augmentation_mask), expanded to B,1,H,W).
+ * Epilogue inputs (MAL_F_EPILOGUE): mono_depth, mono_reproj, ens_reproj (nullable -> 2-way argmin).
+ * Outputs:
+ *   min_reproj (B,1,H,W, nullable)         per-pixel min_c r_c
+ *   sums (f64[8], device): [0] sum(rp*w) [1] sum(w) [2] sum|d_multi-d_mono|*(1-w) [3] sum|distil-d_multi|*w
+ *   with MAL_F_GRAD:
+ *     g_reproj (B,1,H,W): d sum(rp*w) / d disp            (caller scales by g/(sums[1]+1e-7))
+ *     g_cons, g_distil (B,1,H,W, MAL_F_EPILOGUE): d sums[2] / d disp, d sums[3] / d disp
+ *     g_T[f] (B,16, MAL_F_POSE_GRAD): d sum(rp*w) / d T_f
+ *   consistency_target (B,1,H,W nullable): 1/(mono*cmask + multi*(1-cmask)), loss_utils.py:212-215
+ *   depth_out (B,1,H,W nullable)                                                               */
+int mal_pass_fused(const float* disp, const float* K, const float* inv_K, const float* const* T,
+                   const float* const* src, const float* target, const float* ident, const float* noise,
+                   const float* ext_mask, const float* mono_depth, const float* mono_reproj,
+                   const float* ens_reproj, int B, int H, int W, int F, float min_depth, float max_depth,
+                   float eps, int convention, int flags, float* min_reproj, double* sums, float* g_reproj,
+                   float* g_cons, float* g_distil, float* const* g_T, float* consistency_target,
+                   float* depth_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a11 epilogue on materialised depth (non-fused path): loss_utils.py:193-254 ---------
+ * w = ext_mask. sums[2], sums[3] as above; g_multi_cons / g_multi_distil are d/d multi_depth
+ * (unnormalised sums); g_mono_distil (nullable) is d sums[3] / d mono_depth for --dual_distil. */
+int mal_distil_epilogue(const float* multi_depth, const float* mono_depth, const float* multi_reproj,
+                        const float* mono_reproj, const float* ens_reproj /*nullable*/, const float* ext_mask,
+                        int B, int H, int W, int flags, double* sums /*f64[8]*/, float* g_multi_cons,
+                        float* g_multi_distil, float* g_mono_distil, float* consistency_target,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a13: Trainer.compute_matching_mask, manydepth/trainer.py:1066-1076 ----------------
+ * out = consistency_mask * [ (1/lowest_cost - mono)/mono < 1 ] * [ (mono - 1/lowest_cost)*lowest_cost < 1 ] */
+int mal_matching_mask(const float* lowest_cost /*B,H,W*/, const float* mono_depth /*B,1,H,W*/,
+                      const float* consistency_mask /*nullable B,H,W*/, size_t n, float* out, void* stream);
+
+/* ---- gradient assembly: out[i] = sum_k coef_k * maps[k][i], coef_k = (scale_k ? *scale_k : 1) *
+ * mult_k / (denom_k ? (*denom_k + denom_eps_k) : 1); all scalars are read on the device so the
+ * autograd backward needs no host sync.  n_terms <= 6.                                        */
+int mal_axpy_maps(int n_terms, const float* const* maps, const float* const* scale, const double* const* denom,
+                  const float* mult, const float* denom_eps, size_t n, float* out, int accumulate, void* stream);
+
+/* f64 device scalar -> f32 device scalars: out[k] = num[k] / (den ? den[k] + eps : 1) */
+int mal_finish_scalars(const double* num, const double* den /*nullable*/, float eps, float mult, int n,
+                       float* out, void* stream);
+
+/* sum of a float array into a f64 device scalar (the student's sum(m), known before the pass) */
+int mal_sum_f64(const float* x, size_t n, double* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- measurement hooks (bench.py): HIP events recorded immediately before / after the main
+ * kernel of the NEXT mal_pass_fused call, on its stream (one-shot; cleared by that call). */
+void* mal_event_create(void);
+int mal_event_destroy(void* ev);
+int mal_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int mal_profile_next_pass(void* start, void* stop);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAL_HIP_H */

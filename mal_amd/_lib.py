@@ -1,0 +1,100 @@
+"""ctypes binding of libmal_hip.so (include/mal_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.  The
+library is built in-tree by ``python -m mal_amd.build`` (``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmal_hip.so")
+
+c_fp = C.c_void_p      # device float*
+c_pp = C.c_void_p      # host array of device pointers (we pass a ctypes array)
+i32, f32, sz, vp = C.c_int, C.c_float, C.c_size_t, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/mal_hip.h one to one
+SIGNATURES = {
+    "mal_version": (i32, []),
+    "mal_strerror": (C.c_char_p, [i32]),
+    "mal_device_check": (i32, []),
+    "mal_workspace_bytes": (sz, [i32, i32, i32]),
+    "mal_disp_to_depth": (i32, [c_fp, sz, f32, f32, c_fp, c_fp, vp]),
+    "mal_disp_to_depth_bwd": (i32, [c_fp, c_fp, c_fp, sz, f32, f32, c_fp, vp]),
+    "mal_backproject": (i32, [c_fp, c_fp, i32, i32, i32, c_fp, vp]),
+    "mal_backproject_bwd": (i32, [c_fp, c_fp, i32, i32, i32, c_fp, vp]),
+    "mal_project3d": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, f32, i32, c_fp, c_fp, vp]),
+    "mal_project3d_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, f32, i32, c_fp, c_fp, vp, sz, vp]),
+    "mal_grid_sample": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, vp]),
+    "mal_grid_sample_bwd": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, vp]),
+    "mal_ssim": (i32, [c_fp, c_fp, i32, i32, i32, i32, c_fp, vp]),
+    "mal_ssim_bwd": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, vp]),
+    "mal_reprojection_loss": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, vp]),
+    "mal_reprojection_loss_bwd": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp, vp]),
+    "mal_smooth_loss": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp, vp, sz, vp]),
+    "mal_warp_fwd": (i32, [c_fp, c_fp, c_fp, c_pp, c_pp, i32, i32, i32, i32, f32, f32, f32, i32, c_fp, c_pp, c_pp, vp]),
+    "mal_warp_bwd": (i32, [c_fp, c_fp, c_fp, c_pp, c_pp, c_pp, c_pp, c_fp, i32, i32, i32, i32, f32, f32, f32, i32,
+                           c_fp, c_pp, vp, sz, vp]),
+    "mal_photo_fwd": (i32, [c_fp, c_pp, i32, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, vp, sz, vp]),
+    "mal_photo_bwd": (i32, [c_fp, c_pp, i32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_pp, vp]),
+    "mal_pass_fused": (i32, [c_fp, c_fp, c_fp, c_pp, c_pp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32,
+                             i32, f32, f32, f32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp, c_pp, c_fp, c_fp, vp, sz, vp]),
+    "mal_distil_epilogue": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp,
+                                  c_fp, vp, sz, vp]),
+    "mal_matching_mask": (i32, [c_fp, c_fp, c_fp, sz, c_fp, vp]),
+    "mal_axpy_maps": (i32, [i32, c_pp, c_pp, c_pp, C.POINTER(f32), C.POINTER(f32), sz, c_fp, i32, vp]),
+    "mal_finish_scalars": (i32, [c_fp, c_fp, f32, f32, i32, c_fp, vp]),
+    "mal_sum_f64": (i32, [c_fp, sz, c_fp, vp, sz, vp]),
+    "mal_event_create": (vp, []),
+    "mal_event_destroy": (i32, [vp]),
+    "mal_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
+    "mal_profile_next_pass": (i32, [vp, vp]),
+}
+
+# flags (include/mal_hip.h)
+F_AUTOMASK, F_GRAD, F_POSE_GRAD, F_NO_SSIM, F_AVG, F_EPILOGUE, F_DUAL_DISTIL = 1, 2, 4, 8, 16, 32, 64
+
+_lib = None
+
+
+class MalError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MalError("%s not found: build it with `python -m mal_amd.build` (hipcc, gfx950). "
+                       "There is no CPU fallback for the MAL loss path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MalError("%s failed: %s (%d)" % (what, load().mal_strerror(rc).decode(), rc))
+
+
+def ptr_array(ptrs):
+    """Host array of device pointers (None -> NULL)."""
+    arr = (C.c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p if p else None
+    return arr
+
+
+def f32_array(vals):
+    arr = (C.c_float * len(vals))()
+    for i, v in enumerate(vals):
+        arr[i] = float(v)
+    return arr

@@ -1,0 +1,74 @@
+"""Build libmal_hip.so (the C-ABI HIP library) in-tree for gfx950.
+
+    python -m mal_amd.build            # hipcc --offload-arch=gfx950 -> mal_amd/lib/libmal_hip.so
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box
+with the gpurun snapshot.  -ffp-contract=off: fused multiply-adds appear only where the
+kernels write them (mal_device.h states every rounding point).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmal_hip.so")
+SOURCES = ["mal_api.hip", "mal_pass.hip", "mal_warp.hip", "mal_photo.hip"]
+HEADERS = ["mal_common.h", "mal_device.h", os.path.join("..", "..", "include", "mal_hip.h")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _digest():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "libmal_hip.sha256")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (s, out))
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

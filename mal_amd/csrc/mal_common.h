@@ -1,0 +1,68 @@
+// Host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/mal_hip.h"
+
+namespace mal {
+
+// tile geometry of the fused / photometric kernels: 64x16 output pixels per 256-thread
+// workgroup; one wave owns one 64-pixel row segment per step, so every global access of the
+// (B,C,H,W) planes is a 256-byte coalesced row piece.
+constexpr int kTW = 64;
+constexpr int kTH = 16;
+constexpr int kThreads = 256;
+
+struct TileGrid {
+  int tiles_x, tiles_y, B;
+  int blocks() const { return tiles_x * tiles_y * B; }
+};
+
+inline TileGrid tile_grid(int B, int H, int W) {
+  TileGrid g;
+  g.tiles_x = (W + kTW - 1) / kTW;
+  g.tiles_y = (H + kTH - 1) / kTH;
+  g.B = B;
+  return g;
+}
+
+// workspace layout (all offsets 256-byte aligned):
+//   [0]            double block_sums[blocks][8]
+//   [..]           float  block_gP[blocks][2][12]
+//   [..]           double scratch[1024]         (generic two-stage reductions)
+struct Workspace {
+  double* block_sums;
+  float* block_gP;
+  double* scratch;
+  size_t bytes;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+inline Workspace carve(void* base, int B, int H, int W) {
+  TileGrid g = tile_grid(B, H, W);
+  size_t nb = (size_t)g.blocks();
+  size_t o = 0;
+  Workspace w;
+  char* p = (char*)base;
+  w.block_sums = (double*)(p + o); o += align256(nb * 8 * sizeof(double));
+  w.block_gP = (float*)(p + o);    o += align256(nb * 24 * sizeof(float));
+  w.scratch = (double*)(p + o);    o += align256(4096 * sizeof(double));
+  w.bytes = o;
+  return w;
+}
+
+inline int check_shape(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return MAL_EINVAL;
+  if (H < 2 || W < 2) return MAL_ESHAPE;
+  if ((double)B * 4.0 * (double)H * (double)W > 2.0e9) return MAL_ESHAPE;  // int32 indexing
+  return MAL_OK;
+}
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MAL_OK : MAL_ELAUNCH;
+}
+
+}  // namespace mal

@@ -1,0 +1,137 @@
+"""GPU parity of the module-level drop-ins (manydepth/layers.py names) against the golden
+vectors produced by the reference's own layer objects (tests/golden/layers_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_io as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    from mal_amd import build
+    build.build(verbose=False)
+
+
+def _c(a):
+    return torch.from_numpy(np.array(a)).to(DEV)
+
+
+def _l2rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+def _sample_ok(grid, H, W, ac, tol=1e-3):
+    """pixels whose sampling position is not within tol of an integer / the border clip"""
+    g = grid.astype(np.float64)
+    if ac:
+        ix, iy = (g[..., 0] + 1) / 2 * (W - 1), (g[..., 1] + 1) / 2 * (H - 1)
+    else:
+        ix, iy = ((g[..., 0] + 1) * W - 1) / 2, ((g[..., 1] + 1) * H - 1) / 2
+    ok = np.ones(ix.shape, bool)
+    for v, hi in ((ix, W - 1), (iy, H - 1)):
+        ok &= np.abs(v - np.round(v)) > tol
+        ok &= (v > tol) & (v < hi - tol) | (v < -tol) | (v > hi + tol)
+    return ok[:, None]
+
+
+@pytest.mark.parametrize("tag", G.LAYER_CASES)
+def test_geometry_modules(tag):
+    from mal_amd import layers
+    z = G.load(tag)
+    b = {k: v.to(DEV) for k, v in G.batch_from_golden(z).items() if torch.is_tensor(v)}
+    B, _, H, W = b["color0"].shape
+    disp = b["disp_teacher"].clone().requires_grad_(True)
+    sd, depth = layers.disp_to_depth(disp, 0.1, 100.0)
+    G.assert_close(sd.detach().cpu(), z["scaled_disp"], 1e-6), G.assert_close(depth.detach().cpu(), z["depth"], 1e-6)
+    for inv in (False, True):
+        T = layers.transformation_from_parameters(b["axisangle_m1"], b["translation_m1"], invert=inv)
+        G.assert_close(T.cpu(), z["T_inv%d" % inv], 1e-5, "T", floor=1e-3)
+    G.assert_close(layers.rot_from_axisangle(b["axisangle_p1"]).cpu(), z["rot"], 1e-5, floor=1e-3)
+    G.assert_close(layers.get_translation_matrix(b["translation_p1"]).cpu(), z["trans"], 0)
+    T = _c(z["T_inv1"]).requires_grad_(True)
+    pts = layers.BackprojectDepth(B, H, W)(depth, b["inv_K"])
+    G.assert_close(pts.detach().cpu(), z["cam_points"], 1e-6, "cam_points", floor=1e-4)
+    grid, zc = layers.Project3D(B, H, W, dc=True)(pts, b["K"], T)
+    G.assert_close(grid.detach().cpu(), z["grid_A"], 1e-5, "grid_A", floor=1e-1)
+    G.assert_close(zc.detach().cpu(), z["proj_depth"], 1e-5, "proj_depth", floor=1e-3)
+    warped = layers.grid_sample(b["color_m1"], grid, padding_mode="border", align_corners=True)
+    G.assert_close(warped.detach().cpu(), z["warped_A"], 1e-4, "warped_A", floor=1e-1)
+    (warped * _c(z["in/g_warped"])).sum().backward()
+    ok = _sample_ok(z["grid_A"], H, W, True)
+    sc = np.abs(z["grad_disp_A"]).max()
+    assert (np.abs(disp.grad.cpu().numpy() - z["grad_disp_A"])[ok] > 2e-4 * sc).mean() <= 1e-3
+    assert _l2rel(T.grad.cpu().numpy()[:, :3], z["grad_T_A"][:, :3]) <= 2e-3  # sums over clip/tap-switch pixels too
+    # DualRefine convention
+    disp2 = b["disp_teacher"].clone().requires_grad_(True)
+    T2 = _c(z["T_inv1"]).requires_grad_(True)
+    pts2 = layers.BackprojectDepth(B, H, W)(layers.disp_to_depth(disp2, 0.1, 100.0)[1], b["inv_K"])
+    grid2 = layers.Project3DDualRefine(B, H, W)(pts2, b["K"], T2)
+    G.assert_close(grid2.detach().cpu(), z["grid_B"], 1e-5, "grid_B", floor=1e-1)
+    warped2 = layers.grid_sample(b["color_m1"], grid2, padding_mode="border", align_corners=False)
+    G.assert_close(warped2.detach().cpu(), z["warped_B"], 1e-4, "warped_B", floor=1e-1)
+    (warped2 * _c(z["in/g_warped"])).sum().backward()
+    ok = _sample_ok(z["grid_B"], H, W, False)
+    sc = np.abs(z["grad_disp_B"]).max()
+    assert (np.abs(disp2.grad.cpu().numpy() - z["grad_disp_B"])[ok] > 2e-4 * sc).mean() <= 1e-3
+    assert _l2rel(T2.grad.cpu().numpy()[:, :3], z["grad_T_B"][:, :3]) <= 2e-3
+
+
+@pytest.mark.parametrize("tag", G.LAYER_CASES)
+def test_photometric_modules(tag):
+    from mal_amd import layers, loss_utils
+    z = G.load(tag)
+    b = {k: v.to(DEV) for k, v in G.batch_from_golden(z).items() if torch.is_tensor(v)}
+    x = _c(z["warped_A"]).requires_grad_(True)
+    y = b["color0"].clone().requires_grad_(True)
+    ssim = layers.SSIM()
+    s = ssim(x, y)
+    d = np.abs(s.detach().cpu().numpy() - z["ssim"])
+    assert d.max() <= 1e-4 and (d > 2e-5 + 1e-4 * z["ssim"]).mean() <= 1e-3
+    (s * _c(z["in/g_ssim"])).sum().backward()
+    # SSIM's gradient inherits the sigma cancellation: compare at the scale of the map
+    assert _l2rel(x.grad.cpu().numpy(), z["grad_ssim_x"]) <= 2e-4
+    assert _l2rel(y.grad.cpu().numpy(), z["grad_ssim_y"]) <= 2e-4
+    x2 = _c(z["warped_A"]).requires_grad_(True)
+    r = loss_utils.compute_reprojection_loss(ssim, x2, b["color0"])
+    d = np.abs(r.detach().cpu().numpy() - z["reproj"])
+    assert d.max() <= 1e-4
+    (r * _c(z["in/g_reproj"])).sum().backward()
+    assert _l2rel(x2.grad.cpu().numpy(), z["grad_reproj_pred"]) <= 2e-4
+    ident = loss_utils.compute_reprojection_loss(ssim, b["color_m1"], b["color0"])
+    assert np.abs(ident.cpu().numpy() - z["identity_reproj"]).max() <= 1e-4
+    m = loss_utils.compute_loss_masks(_c(z["reproj"]), _c(z["identity_reproj"]))
+    G.assert_close(m.cpu(), z["automask"], 0)
+    G.assert_close(loss_utils.compute_loss_masks(_c(z["reproj"]), None).cpu(), z["automask_none"], 0)
+    disp3 = b["disp_student"].clone().requires_grad_(True)
+    sm = layers.get_smooth_loss(disp3, b["color0"])
+    sm.backward()
+    assert abs(float(sm) - float(z["smooth"])) <= 1e-5 * abs(float(z["smooth"]))
+    g, r = disp3.grad.cpu().numpy(), z["grad_smooth"]
+    # |d_q - d_q'| has a kink at equality (fp16-quantised test disparities do tie): compare off the ties
+    assert (np.abs(g - r) > 1e-4 * np.abs(r).max()).mean() <= 2e-2
+    assert _l2rel(g, r) <= 0.2
+
+
+def test_identity_min_and_fused_ensemble_agree():
+    """generate_images_pred_ensemble (fused, no grad) == warp + reprojection + min on explicit images."""
+    from mal_amd import layers, loss_utils, trainer, ops
+    z = G.load("step_b3_37x50_distil")
+    b = {k: v.to(DEV) for k, v in G.batch_from_golden(z).items() if torch.is_tensor(v)}
+    B, _, H, W = b["color0"].shape
+    opt = trainer.default_options(height=H, width=W, batch_size=B)
+    lp = trainer.LossPath(opt)
+    inputs = {("color", 0, 0): b["color0"], ("color", -1, 0): b["color_m1"], ("color", 1, 0): b["color_p1"],
+              ("K", 0): b["K"], ("inv_K", 0): b["inv_K"]}
+    T0 = layers.transformation_from_parameters(b["axisangle_m1"], b["translation_m1"], True)
+    T1 = layers.transformation_from_parameters(b["axisangle_p1"], b["translation_p1"], False)
+    fused = lp.generate_images_pred_ensemble(inputs, T0, T1, b["disp_teacher"])
+    _, _, warped = ops.warp_fwd(b["disp_teacher"], b["K"], b["inv_K"], [T0, T1], [b["color_m1"], b["color_p1"]], 0.1,
+                                100.0, 1e-7, 0, want_depth=False, want_grid=False)
+    r = torch.minimum(loss_utils.compute_reprojection_loss(None, warped[0], b["color0"]),
+                      loss_utils.compute_reprojection_loss(None, warped[1], b["color0"]))
+    assert torch.equal(fused, r)

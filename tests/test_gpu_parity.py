@@ -1,0 +1,156 @@
+"""GPU parity: the HIP loss path (through the C ABI) against the CPU oracle and the golden
+vectors of the reference, on the same seeded inputs.
+
+Tolerances (north_star: 1e-4 rel, fp32).  The loss has genuine discontinuities -- the
+per-pixel argmin over candidates, the automask comparison, the 3-way distillation argmin,
+the bilinear tap switch when a sampling position crosses an integer, and the border clip --
+so two correct fp32 evaluations (e.g. ATen on two CPUs: the oracle re-run on the GPU box's
+host already differs from the golden file in the 7th digit) can take different branches at
+pixels that sit within rounding distance of a tie.  The tests therefore
+  * compare scalars at 1e-4 rel (the distillation mean gets the explicit allowance of its
+    near-tie pixels);
+  * compare per-pixel maps/gradients at 1e-4 of the map's scale OUTSIDE the pixels the
+    oracle itself marks as near-tie (listed by kind, their fraction bounded);
+  * bound summed gradients (poses) by 1e-4 or by the distance between the fp32 oracle and
+    the same oracle evaluated in fp64, whichever is larger: not further from the reference
+    than the reference is from exact arithmetic.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_io as G
+from tests import hip_harness as HH
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    from mal_amd import build
+    build.build(verbose=False)
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+
+
+def _l2rel(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+def _check_case(tag, fuse, full):
+    z = G.load(tag)
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    n0, n1 = G.noises(z, (B, 1, H, W))
+    kw = G.opt_kwargs(z)
+    o = HH.run_oracle(b, kw, n0, n1)
+    h = HH.run_hip(b, kw, n0, n1, fuse=fuse)
+    N = B * H * W
+
+    # ---- exact / elementwise things
+    G.assert_close(h["mono_depth"], o["mono_depth"], 1e-6, "mono depth")
+    G.assert_close(h["multi_depth"], o["multi_depth"], 1e-6, "multi depth")
+    assert (h["consistency_mask"] != o["consistency_mask"]).mean() <= 1e-5, "matching mask"
+    if "cons_target" in h:
+        G.assert_close(h["cons_target"], o["cons_target"], 1e-6, "consistency_target")
+
+    # ---- per-pixel minimum reprojection maps (SSIM's sigma = E[x^2]-mu^2 cancellation against
+    # C2 = 9e-4 turns a 1-ulp difference of a warped pixel into ~3e-5 relative)
+    for name in ("mono_reproj", "ens"):
+        if o[name] is None:
+            continue
+        d = np.abs(h[name] - o[name])
+        assert d.max() <= 1e-4, (name, d.max())
+        assert (d > 5e-5 + 1e-4 * np.abs(o[name])).mean() <= 1e-4, name
+
+    # ---- scalars
+    temporal = "syn_rects" in b
+    amb_distil = HH.near_tie(np.concatenate([m for m in (o["mono_reproj"], o["ens"], o["multi_cands"].min(1, keepdims=True))
+                                             if m is not None], 1), 2e-4)
+    allow_distil = float((np.abs(o["mono_depth"] - o["multi_depth"]) * amb_distil).sum() / N)
+    for k, v in o["losses"].items():
+        tol = 1e-4 * abs(v) + (allow_distil if ("distil" in k or k.startswith("loss")) else 0.0)
+        assert abs(h["losses"][k] - v) <= tol, (k, h["losses"][k], v, tol)
+        if not temporal:  # golden = the reference's own run in the authoring container
+            gv = float(z["losses/" + k])
+            assert abs(h["losses"][k] - gv) <= 2e-4 * abs(gv) + allow_distil, ("golden", k, h["losses"][k], gv)
+    assert abs(h["final"] - o["final"]) <= 1e-4 * abs(o["final"]) + B * allow_distil
+
+    # ---- per-pixel disparity gradients outside the near-tie pixels
+    idn = o["ident"] + n0.numpy() * np.float32(1e-5)
+    amb_t = HH.dilate3(HH.near_tie(o["mono_cands"], 2e-4) | (np.abs(o["mono_reproj"] - idn) <= 1e-4))
+    amb_t |= HH.sample_ambiguous(o["mono_sample"], H, W)
+    amb_s = HH.dilate3(HH.near_tie(o["multi_cands"], 2e-4)) | HH.sample_ambiguous(o["multi_sample"], H, W) | amb_distil
+    amb_s |= np.abs(o["mono_depth"] - o["multi_depth"]) <= 1e-6 * np.abs(o["mono_depth"])
+    if kw.get("dual_distil"):  # the teacher's depth then also receives the distillation gradient
+        amb_t |= amb_distil
+    if temporal:  # the synthesised candidates add their own ties; only aggregate checks below
+        amb_t[:] = True
+        if kw.get("main_temporal"):
+            amb_s[:] = True
+    for key, amb in (("disp_teacher", amb_t), ("disp_student", amb_s)):
+        g, r = h["grads"][key], o["grads"][key]
+        sc = np.abs(r).max()
+        good = ~amb
+        if good.any():
+            err = np.abs(g - r)[good]
+            assert (err > 2e-4 * sc).mean() <= 2e-5, (key, err.max() / sc, (err > 2e-4 * sc).mean())
+        assert amb.mean() <= 0.05 or temporal, (key, "near-tie fraction", amb.mean())
+
+    # ---- summed gradients: never further from the fp32 reference than it is from fp64
+    # (per-pixel leaves: over the pixels outside the near-tie set, where one flipped branch cannot
+    # dominate the norm of a small map)
+    o64 = HH.oracle_fp64_grads(b, kw, n0, n1)
+    for key in HH.LEAVES:
+        g, r, r64 = h["grads"][key], o["grads"][key], o64[key]
+        if key in ("disp_teacher", "disp_student"):
+            keep = ~(amb_t if key == "disp_teacher" else amb_s)
+            if not keep.any():
+                continue
+            g, r, r64 = g[keep], r[keep], r64[keep]
+        floor = _l2rel(r, r64)
+        assert _l2rel(g, r) <= max(1e-4, 1.5 * floor), (key, _l2rel(g, r), floor)
+
+
+@pytest.mark.parametrize("fuse", [True, False], ids=["fused", "explicit"])
+@pytest.mark.parametrize("tag", G.STEP_CASES)
+def test_step_parity(tag, fuse):
+    _check_case(tag, fuse, True)
+
+
+def test_step_parity_full_size():
+    """B=2 192x640 (the size BASELINE.json's metric is quoted on, per sample)."""
+    _check_case(G.BIG_CASE, True, False)
+
+
+def test_fused_equals_explicit_bitwise_losses():
+    """The fused kernel and the materialising kernels share their device arithmetic: the loss
+    scalars of the two routes agree to fp32 rounding of the final reductions."""
+    z = G.load("step_b3_37x50_distil")
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    n0, n1 = G.noises(z, (B, 1, H, W))
+    a = HH.run_hip(b, {}, n0, n1, fuse=True)
+    c = HH.run_hip(b, {}, n0, n1, fuse=False)
+    for k in a["losses"]:
+        assert abs(a["losses"][k] - c["losses"][k]) <= 2e-6 * abs(c["losses"][k]), k
+    for k in HH.LEAVES:
+        assert _l2rel(a["grads"][k], c["grads"][k]) <= 2e-5, k
+
+
+def test_determinism():
+    """Two runs on the same inputs are bitwise identical (no atomics anywhere)."""
+    z = G.load("step_b2_32x64_distil")
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    n0, n1 = G.noises(z, (B, 1, H, W))
+    a = HH.run_hip(b, {}, n0, n1, fuse=True)
+    c = HH.run_hip(b, {}, n0, n1, fuse=True)
+    assert a["final"] == c["final"]
+    for k in HH.LEAVES:
+        assert np.array_equal(a["grads"][k], c["grads"][k]), k
+
+
+def test_cpu_tensor_raises():
+    from mal_amd import layers, _lib
+    with pytest.raises(_lib.MalError):
+        layers.disp_to_depth(torch.rand(1, 1, 4, 4), 0.1, 100.0)

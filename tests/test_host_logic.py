@@ -1,0 +1,93 @@
+"""CPU: host-side logic of the package (no kernels): pose composition against the golden
+vectors, loss balancing against the oracle, mask rule, synthetic generator, option defaults,
+and that the product package never imports the oracle."""
+import os
+import re
+
+import numpy as np
+import torch
+
+from tests import golden_io as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pose_composition_matches_reference():
+    from mal_amd import layers
+    z = G.load("layers_b2_24x40")
+    b = G.batch_from_golden(z)
+    for inv in (False, True):
+        T = layers.transformation_from_parameters(b["axisangle_m1"], b["translation_m1"], invert=inv)
+        G.assert_close(T, z["T_inv%d" % inv], 1e-6, "T", floor=1e-3)
+    G.assert_close(layers.rot_from_axisangle(b["axisangle_p1"]), z["rot"], 1e-6, floor=1e-3)
+    G.assert_close(layers.get_translation_matrix(b["translation_p1"]), z["trans"], 0)
+
+
+def test_pose_composition_gradient_matches_oracle():
+    from mal_amd import layers
+    from oracle import mal_oracle as O
+    torch.manual_seed(0)
+    aa, tr = 0.01 * torch.randn(3, 1, 3), 0.05 * torch.randn(3, 1, 3)
+    w = torch.randn(3, 4, 4)
+    gs = []
+    for fn in (layers.transformation_from_parameters, O.transformation_from_parameters):
+        a, t = aa.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+        (fn(a, t, True) * w).sum().backward()
+        gs.append((a.grad, t.grad))
+    assert torch.allclose(gs[0][0], gs[1][0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(gs[0][1], gs[1][1], rtol=1e-5, atol=1e-6)
+
+
+def test_loss_masks_rule():
+    from mal_amd import loss_utils
+    from oracle import mal_oracle as O
+    torch.manual_seed(1)
+    r, i = torch.rand(2, 1, 5, 7), torch.rand(2, 1, 5, 7)
+    i[0, 0, 0, 0] = r[0, 0, 0, 0]  # tie -> index 0 wins -> mask 1
+    assert torch.equal(loss_utils.compute_loss_masks(r, i), O.compute_loss_masks(r, i))
+    assert torch.equal(loss_utils.compute_loss_masks(r, None), torch.ones_like(r))
+
+
+def test_loss_balancing_matches_oracle():
+    from mal_amd import loss_utils
+    from oracle import mal_oracle as O
+    a, b = loss_utils.LossBalancing(2, 10, 4), O.LossBalancing(2, 10, 4)
+    rng = np.random.RandomState(0)
+    for it in range(4):  # the last iteration runs off the end of the dataset (10 records, bs 4)
+        ll = [torch.tensor(float(rng.rand() + 0.5)), torch.tensor(float(rng.rand() + 0.1))]
+        la, lb = a.compute_loss(ll, it), b.compute_loss(ll, it)
+        assert abs(float(la) - float(lb)) < 1e-6
+        if it < 3:
+            wa, wb = a.update_weight(it, 3.0), b.update_weight(it, 3.0)
+            assert np.allclose(wa, wb)
+    assert np.allclose(a.train_scores, b.train_scores)
+
+
+def test_synthetic_batch_contract_and_determinism():
+    from mal_amd.synthetic import make_batch, kitti_intrinsics
+    a, b = make_batch(2, 16, 24, seed=5), make_batch(2, 16, 24, seed=5)
+    for k in a:
+        if torch.is_tensor(a[k]):
+            assert torch.equal(a[k], b[k]), k
+    assert a["color0"].shape == (2, 3, 16, 24) and a["color0"].min() >= 0 and a["color0"].max() <= 1
+    assert a["disp_teacher"].shape == (2, 1, 16, 24) and 0 < a["disp_teacher"].min() and a["disp_teacher"].max() < 1
+    K, iK = kitti_intrinsics(1, 192, 640)
+    assert abs(K[0, 0, 0] - 0.58 * 640) < 1e-3 and abs(K[0, 1, 1] - 1.92 * 192) < 1e-3
+    assert torch.allclose(K[0] @ iK[0], torch.eye(4), atol=1e-5)
+
+
+def test_option_defaults_follow_reference():
+    from mal_amd import trainer
+    o = trainer.default_options()
+    assert (o.height, o.width, o.batch_size, o.min_depth, o.max_depth) == (192, 640, 12, 0.1, 100.0)
+    assert o.frame_ids == [0, -1, 1] and o.sclm == 0 and o.disparity_smoothness == 1e-3
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under mal_amd/ may import or execute it."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle[./]", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mal_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), os.path.join(dirpath, f)
