@@ -164,9 +164,11 @@ int mal_photo_bwd(const float* target, const float* const* cand, int n_cand, con
  *     g_T[f] (B,16, MAL_F_POSE_GRAD): d sum(rp*w) / d T_f
  *   consistency_target (B,1,H,W nullable): 1/(mono*cmask + multi*(1-cmask)), loss_utils.py:212-215
  *   depth_out (B,1,H,W nullable)                                                               */
-int mal_pass_fused(const float* disp, const float* K, const float* inv_K, const float* const* T,
+int mal_pass_fused(const float* disp, const float* disp2 /*nullable: disparity = (disp+disp2)/2, trainer.py:598*/,
+                   const float* K, const float* inv_K, const float* const* T,
                    const float* const* src, const float* target, const float* ident, const float* noise,
-                   const float* ext_mask, const float* mono_depth, const float* mono_reproj,
+                   const float* ext_mask, const float* sample_scale /*nullable (B): w *= scale[b], e.g.
+                   1-augmentation_mask, loss_utils.py:194*/, const float* mono_depth, const float* mono_reproj,
                    const float* ens_reproj, int B, int H, int W, int F, float min_depth, float max_depth,
                    float eps, int convention, int flags, float* min_reproj, double* sums, float* g_reproj,
                    float* g_cons, float* g_distil, float* const* g_T, float* consistency_target,
@@ -198,6 +200,15 @@ int mal_finish_scalars(const double* num, const double* den /*nullable*/, float 
 
 /* sum of a float array into a f64 device scalar (the student's sum(m), known before the pass) */
 int mal_sum_f64(const float* x, size_t n, double* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a16: transformation_from_parameters, manydepth/layers.py:26-100 -----------------------
+ * axisangle[f], translation[f]: (B,3) (the reference's (B,1,3)); invert[f] (host ints): frame ids
+ * < 0 are inverted (networks/repdepth.py:159-160).  T[f]: (B,16).  One launch for all f, b. */
+int mal_pose_fwd(const float* const* axisangle, const float* const* translation, const int* invert,
+                 int B, int F, float* const* T, void* stream);
+int mal_pose_bwd(const float* const* axisangle, const float* const* translation, const int* invert,
+                 const float* const* g_T, int B, int F, float* const* g_axisangle /*[F] nullable each*/,
+                 float* const* g_translation /*[F] nullable each*/, void* stream);
 
 /* ---- measurement hooks (bench.py): HIP events recorded immediately before / after the main
  * kernel of the NEXT mal_pass_fused call, on its stream (one-shot; cleared by that call). */

@@ -39,7 +39,7 @@ SIGNATURES = {
                            c_fp, c_pp, vp, sz, vp]),
     "mal_photo_fwd": (i32, [c_fp, c_pp, i32, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, vp, sz, vp]),
     "mal_photo_bwd": (i32, [c_fp, c_pp, i32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_pp, vp]),
-    "mal_pass_fused": (i32, [c_fp, c_fp, c_fp, c_pp, c_pp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32,
+    "mal_pass_fused": (i32, [c_fp, c_fp, c_fp, c_fp, c_pp, c_pp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32,
                              i32, f32, f32, f32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp, c_pp, c_fp, c_fp, vp, sz, vp]),
     "mal_distil_epilogue": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp,
                                   c_fp, vp, sz, vp]),
@@ -47,6 +47,8 @@ SIGNATURES = {
     "mal_axpy_maps": (i32, [i32, c_pp, c_pp, c_pp, C.POINTER(f32), C.POINTER(f32), sz, c_fp, i32, vp]),
     "mal_finish_scalars": (i32, [c_fp, c_fp, f32, f32, i32, c_fp, vp]),
     "mal_sum_f64": (i32, [c_fp, sz, c_fp, vp, sz, vp]),
+    "mal_pose_fwd": (i32, [c_pp, c_pp, C.POINTER(i32), i32, i32, c_pp, vp]),
+    "mal_pose_bwd": (i32, [c_pp, c_pp, C.POINTER(i32), c_pp, i32, i32, c_pp, c_pp, vp]),
     "mal_event_create": (vp, []),
     "mal_event_destroy": (i32, [vp]),
     "mal_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),

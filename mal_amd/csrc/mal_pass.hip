@@ -40,9 +40,9 @@ constexpr int kHalo = RN - kTW * kTH;                    // 336
 constexpr int kRing = SN - kTW * kTH;                    // 164
 
 struct PassParams {
-  const float* disp; const float* K; const float* invK;
+  const float* disp; const float* disp2; const float* K; const float* invK;
   const float* T[2]; const float* src[2];
-  const float* target; const float* ident; const float* noise; const float* ext_mask;
+  const float* target; const float* ident; const float* noise; const float* ext_mask; const float* sample_scale;
   const float* mono_depth; const float* mono_reproj; const float* ens_reproj;
   int B, H, W; float min_disp, range, eps; int convention;
   float* min_reproj; float* g_reproj; float* g_cons; float* g_distil; float* cons_target; float* depth_out;
@@ -109,6 +109,9 @@ __global__ __launch_bounds__(kThreads, 2) void pass_kernel(PassParams p) {
 
   const float* tgt_b = p.target + (size_t)b * 3 * HW;
   const float* disp_b = p.disp + (size_t)b * HW;
+  const float* disp2_b = p.disp2 ? p.disp2 + (size_t)b * HW : nullptr;
+  // ensemble pass: the disparity is the mean of teacher and student (trainer.py:598)
+  auto disp_at = [&](int pix) { return disp2_b ? (disp_b[pix] + disp2_b[pix]) / 2.0f : disp_b[pix]; };
 
   // ---- phase 1: warp every in-image region position into LDS --------------------------
   Own own[4];
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kThreads, 2) void pass_kernel(PassParams p) {
     const int gy = y0 - 2 + ry, gx = x0 - 2 + rx;
     if (gy < 0 || gy >= H || gx < 0 || gx >= W) return;
     const int ridx = ry * RW + rx, pix = gy * W + gx;
-    const float depth = depth_of(disp_b[pix], p.min_disp, p.range);
+    const float depth = depth_of(disp_at(pix), p.min_disp, p.range);
     float ray[3], X[3];
     ray_of(s_ik, (float)gx, (float)gy, ray);
     X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(kThreads, 2) void pass_kernel(PassParams p) {
       w = (rp <= idn) ? 1.0f : 0.0f;
     }
     if (p.ext_mask) w *= p.ext_mask[(size_t)b * HW + pix];
+    if (p.sample_scale) w *= p.sample_scale[b];
     tag[slot] = win;
     if (owned) {
       wq[slot] = w;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(kThreads, 2) void pass_kernel(PassParams p) {
       if (gy >= H || gx >= W) continue;
       const int pix = gy * W + gx;
       const size_t gi = (size_t)b * HW + pix;
-      const float depth = depth_of(disp_b[pix], p.min_disp, p.range);
+      const float depth = depth_of(disp_at(pix), p.min_disp, p.range);
       const float ddepth = -(depth * depth) * p.range;  // d depth / d disp
       if (p.depth_out) p.depth_out[gi] = depth;
       if (GRAD) {
@@ -409,51 +413,48 @@ __global__ __launch_bounds__(kThreads, 2) void pass_kernel(PassParams p) {
   }
 }
 
-// sums[j] = sum over blocks; g_T[f][b] = K_b^T [gP_fb ; 0]
+// blocks 0..3: sums[j] = sum over workgroups (fixed order); blocks 4..4+B-1: g_T[f][b] = K_b^T [gP_fb ; 0]
 __global__ __launch_bounds__(256) void pass_finalize_kernel(const double* block_sums, const float* block_gP,
                                                             const float* K, int nblocks, int tiles, int B,
                                                             double* sums, float* gT0, float* gT1) {
   __shared__ double s_part[256];
   __shared__ double s_gP[24];
   const int tid = threadIdx.x;
-  if (blockIdx.x == 0) {
-    for (int j = 0; j < 4; ++j) {
-      double acc = 0.0;
-      for (int i = tid; i < nblocks; i += 256) acc += block_sums[(size_t)i * 8 + j];
-      s_part[tid] = acc;
-      __syncthreads();
-      for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) s_part[tid] += s_part[tid + s];
-        __syncthreads();
-      }
-      if (tid == 0) sums[j] = s_part[0];
-      __syncthreads();
-    }
-    return;
-  }
-  // blocks 1..B: pose gradient of sample b
-  if (!gT0) return;
-  const int b = blockIdx.x - 1;
-  if (b >= B) return;
-  for (int i = 0; i < 24; ++i) {
+  if (blockIdx.x < 4) {
+    const int j = blockIdx.x;
     double acc = 0.0;
-    for (int t = tid; t < tiles; t += 256) acc += (double)block_gP[((size_t)b * tiles + t) * 24 + i];
+    for (int i = tid; i < nblocks; i += 256) acc += block_sums[(size_t)i * 8 + j];
     s_part[tid] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
       if (tid < s) s_part[tid] += s_part[tid + s];
       __syncthreads();
     }
-    if (tid == 0) s_gP[i] = s_part[0];
-    __syncthreads();
+    if (tid == 0) { sums[j] = s_part[0]; sums[4 + j] = 0.0; }
+    return;
   }
+  const int b = blockIdx.x - 4;
+  if (!gT0 || b >= B) return;
+  // 24 sums of `tiles` partials: 8 lanes per value, then an 8-lane tree (fixed order)
+  const int v = tid >> 3, sub = tid & 7;
+  double acc = 0.0;
+  if (v < 24)
+    for (int t = sub; t < tiles; t += 8) acc += (double)block_gP[((size_t)b * tiles + t) * 24 + v];
+  s_part[tid] = acc;
+  __syncthreads();
+  if (v < 24 && sub == 0) {
+    double a = 0.0;
+    for (int k = 0; k < 8; ++k) a += s_part[tid + k];
+    s_gP[v] = a;
+  }
+  __syncthreads();
   if (tid < 32) {
     int f = tid >> 4, e = tid & 15, k = e >> 2, j = e & 3;
     const float* Kb = K + b * 16;
-    double acc = 0.0;
-    for (int i = 0; i < 3; ++i) acc += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
+    double a = 0.0;
+    for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
     float* out = f ? gT1 : gT0;
-    out[b * 16 + e] = (float)acc;
+    out[b * 16 + e] = (float)a;
   }
 }
 
@@ -461,9 +462,10 @@ __global__ __launch_bounds__(256) void pass_finalize_kernel(const double* block_
 
 using namespace mal;
 
-extern "C" int mal_pass_fused(const float* disp, const float* K, const float* inv_K, const float* const* T,
-                              const float* const* src, const float* target, const float* ident,
-                              const float* noise, const float* ext_mask, const float* mono_depth,
+extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float* K, const float* inv_K,
+                              const float* const* T, const float* const* src, const float* target,
+                              const float* ident, const float* noise, const float* ext_mask,
+                              const float* sample_scale, const float* mono_depth,
                               const float* mono_reproj, const float* ens_reproj, int B, int H, int W, int F,
                               float min_depth, float max_depth, float eps, int convention, int flags,
                               float* min_reproj, double* sums, float* g_reproj, float* g_cons, float* g_distil,
@@ -486,7 +488,7 @@ extern "C" int mal_pass_fused(const float* disp, const float* K, const float* in
 
   TileGrid tg = tile_grid(B, H, W);
   PassParams p;
-  p.disp = disp; p.K = K; p.invK = inv_K; p.T[0] = T[0]; p.T[1] = T[1]; p.src[0] = src[0]; p.src[1] = src[1];
+  p.disp = disp; p.disp2 = disp2; p.sample_scale = sample_scale; p.K = K; p.invK = inv_K; p.T[0] = T[0]; p.T[1] = T[1]; p.src[0] = src[0]; p.src[1] = src[1];
   p.target = target; p.ident = ident; p.noise = noise; p.ext_mask = ext_mask; p.mono_depth = mono_depth;
   p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj; p.B = B; p.H = H; p.W = W;
   p.min_disp = (float)(1.0 / (double)max_depth);
@@ -516,7 +518,7 @@ extern "C" int mal_pass_fused(const float* disp, const float* K, const float* in
   if (ev1) (void)hipEventRecord(ev1, st);
   rc = launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(pass_finalize_kernel, dim3(pose ? 1 + B : 1), dim3(256), 0, st, w.block_sums, w.block_gP, K,
+  hipLaunchKernelGGL(pass_finalize_kernel, dim3(pose ? 4 + B : 4), dim3(256), 0, st, w.block_sums, w.block_gP, K,
                      p.nblocks, tg.tiles_x * tg.tiles_y, B, sums, pose ? g_T[0] : nullptr, pose ? g_T[1] : nullptr);
   return launch_status();
 }

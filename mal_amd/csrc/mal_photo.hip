@@ -292,13 +292,37 @@ struct SmoothParams {
   const float* disp; const float* img; int B, C, H, W; int normalise; int chunks;
   const double* mean_partial;  // [B][chunks] sums of disp
   double* partial;             // [B*chunks][4]: sum_x, sum_y, dot(gn, disp)
+  double* stats;               // [2B]: mean_b, then corr_b = dot_b / (HW (mean_b+eps)^2)
   float* gn;                   // d loss / d normalised disp (nullable)
 };
 
-MAL_DEV float sample_mean(const SmoothParams& p, int b, int HW) {
-  double acc = 0.0;
-  for (int k = 0; k < p.chunks; ++k) acc += p.mean_partial[b * p.chunks + k];
-  return (float)(acc / (double)HW);
+MAL_DEV float sample_mean(const SmoothParams& p, int b, int HW) { return (float)p.stats[b]; }
+
+// one wave per sample.  stage 1: mean_b from the plane partials.  stage 2: corr_b, and (block B)
+// the loss = sum_x/Nx + sum_y/Ny from all smooth partials.
+__global__ __launch_bounds__(64) void smooth_mid_kernel(SmoothParams p, int stage, double* loss_out) {
+  const int b = blockIdx.x, lane = threadIdx.x, HW = p.H * p.W;
+  if (stage == 1) {
+    double acc = 0.0;
+    for (int k = lane; k < p.chunks; k += 64) acc += p.mean_partial[b * p.chunks + k];
+    acc = wave_sum_d(acc);
+    if (lane == 0) p.stats[b] = acc / (double)HW;
+    return;
+  }
+  if (b < p.B) {
+    double dot = 0.0;
+    for (int k = lane; k < p.chunks; k += 64) dot += p.partial[(size_t)(b * p.chunks + k) * 4 + 2];
+    dot = wave_sum_d(dot);
+    if (lane == 0) {
+      const double m = (double)((float)p.stats[b] + 1e-7f);
+      p.stats[p.B + b] = dot / ((double)HW * m * m);
+    }
+  } else {
+    double sx = 0.0, sy = 0.0;
+    for (int i = lane; i < p.B * p.chunks; i += 64) { sx += p.partial[(size_t)i * 4]; sy += p.partial[(size_t)i * 4 + 1]; }
+    sx = wave_sum_d(sx); sy = wave_sum_d(sy);
+    if (lane == 0) loss_out[0] = sx / ((double)p.B * p.H * (p.W - 1)) + sy / ((double)p.B * (p.H - 1) * p.W);
+  }
 }
 
 __global__ __launch_bounds__(256) void smooth_kernel(SmoothParams p) {
@@ -359,23 +383,14 @@ __global__ __launch_bounds__(256) void smooth_kernel(SmoothParams p) {
   }
 }
 
-// loss = sum_x/Nx + sum_y/Ny ; g_disp = gn/(mean+eps) - dot_b/(HW (mean+eps)^2)
-__global__ __launch_bounds__(256) void smooth_finish_kernel(SmoothParams p, double* loss_out, float* g_disp) {
+// g_disp = gn/(mean+eps) - corr_b
+__global__ __launch_bounds__(256) void smooth_finish_kernel(SmoothParams p, float* g_disp) {
   const int HW = p.H * p.W;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    double sx = 0.0, sy = 0.0;
-    for (int i = 0; i < p.B * p.chunks; ++i) { sx += p.partial[(size_t)i * 4]; sy += p.partial[(size_t)i * 4 + 1]; }
-    loss_out[0] = sx / ((double)p.B * p.H * (p.W - 1)) + sy / ((double)p.B * (p.H - 1) * p.W);
-  }
-  if (!g_disp) return;
   const int b = blockIdx.x / p.chunks, ck = blockIdx.x % p.chunks;
   float inv = 1.0f, corr = 0.0f;
   if (p.normalise) {
-    const float m = sample_mean(p, b, HW) + 1e-7f;
-    inv = div_(1.0f, m);
-    double dot = 0.0;
-    for (int k = 0; k < p.chunks; ++k) dot += p.partial[(size_t)(b * p.chunks + k) * 4 + 2];
-    corr = (float)(dot / ((double)HW * (double)m * (double)m));
+    inv = div_(1.0f, sample_mean(p, b, HW) + 1e-7f);
+    corr = (float)p.stats[p.B + b];
   }
   for (int pix = ck * 256 + threadIdx.x; pix < HW; pix += p.chunks * 256) {
     const size_t gi = (size_t)b * HW + pix;
@@ -567,20 +582,23 @@ extern "C" int mal_smooth_loss(const float* disp, const float* img, int B, int C
   Workspace w = carve(ws, B, H, W);
   if (ws_bytes < w.bytes) return MAL_EWORKSPACE;
   int chunks = (H * W + 1023) / 1024;
-  const int cap = 4096 / 5 / (B > 0 ? B : 1);  // scratch holds 4096 doubles: B*chunks*(1+4)
+  const int cap = (4096 - 2 * B) / 5 / B;  // scratch holds 4096 doubles: B*chunks*(1+4) + 2B
   if (chunks > cap) chunks = cap;
   if (chunks < 1) return MAL_ESHAPE;
-  SmoothParams p = {disp, img, B, C, H, W, normalise, chunks, w.scratch, w.scratch + (size_t)B * chunks, g_disp};
+  SmoothParams p = {disp, img, B, C, H, W, normalise, chunks, w.scratch, w.scratch + (size_t)B * chunks,
+                    w.scratch + (size_t)B * chunks * 5, g_disp};
   hipStream_t st = (hipStream_t)stream;
   if (normalise) {
     hipLaunchKernelGGL(plane_sum_kernel, dim3(B * chunks), dim3(256), 0, st, disp, H * W, chunks, w.scratch);
+    hipLaunchKernelGGL(smooth_mid_kernel, dim3(B), dim3(64), 0, st, p, 1, loss_out);
     rc = launch_status();
     if (rc) return rc;
   }
   hipLaunchKernelGGL(smooth_kernel, dim3(B * chunks), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(smooth_mid_kernel, dim3(B + 1), dim3(64), 0, st, p, 2, loss_out);
   rc = launch_status();
-  if (rc) return rc;
-  hipLaunchKernelGGL(smooth_finish_kernel, dim3(g_disp ? B * chunks : 1), dim3(256), 0, st, p, loss_out, g_disp);
+  if (rc || !g_disp) return rc;
+  if (normalise) hipLaunchKernelGGL(smooth_finish_kernel, dim3(B * chunks), dim3(256), 0, st, p, g_disp);
   return launch_status();
 }
 

@@ -35,6 +35,24 @@ class DispToDepthFn(Function):
         return ops.disp_to_depth_bwd(disp, g_scaled, g_depth, *ctx.rng), None, None
 
 
+class PoseFn(Function):
+    """transformation_from_parameters (manydepth/layers.py:26-42) for one frame, one launch."""
+
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert):
+        ctx.save_for_backward(axisangle, translation)
+        ctx.invert = bool(invert)
+        return ops.pose_fwd([axisangle], [translation], [invert])[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_T):
+        axisangle, translation = ctx.saved_tensors
+        g_aa, g_tr = ops.pose_bwd([axisangle], [translation], [ctx.invert], [g_T], [ctx.needs_input_grad[0]],
+                                  [ctx.needs_input_grad[1]])
+        return g_aa[0], g_tr[0], None
+
+
 class BackprojectFn(Function):
     @staticmethod
     def forward(ctx, depth, inv_K):
@@ -203,7 +221,7 @@ class FusedPassFn(Function):
 
     @staticmethod
     def forward(ctx, disp, T_m1, T_p1, K, inv_K, src_m1, src_p1, target, ident, noise, ext_mask, mono_depth,
-                mono_reproj, ens_reproj, cfg):
+                mono_reproj, ens_reproj, cfg, sample_scale=None):
         min_depth, max_depth, eps, convention, automask, epilogue, want_cons_target = cfg
         need_disp = disp.requires_grad
         need_T = T_m1.requires_grad or T_p1.requires_grad
@@ -218,7 +236,8 @@ class FusedPassFn(Function):
             flags |= L.F_POSE_GRAD
         out = ops.pass_fused(disp, K, inv_K, [T_m1, T_p1], [src_m1, src_p1], target, ident, noise, ext_mask,
                              mono_depth, mono_reproj, ens_reproj, min_depth, max_depth, eps, convention, flags,
-                             want_min=True, want_cons_target=bool(epilogue and want_cons_target), want_depth=False)
+                             want_min=True, want_cons_target=bool(epilogue and want_cons_target), want_depth=False,
+                             sample_scale=sample_scale)
         sums = out["sums"]
         B, _, H, W = disp.shape
         reproj = ops.finish_scalars(sums[0:1], sums[1:2], 1e-7).reshape(())
@@ -259,7 +278,7 @@ class FusedPassFn(Function):
                 g_T0 = ops.axpy_maps([gT0], [_scalar(g_reproj)], [sums[1:2]], [1.0], [1e-7])
             if ctx.needs_input_grad[2] and gT1.numel():
                 g_T1 = ops.axpy_maps([gT1], [_scalar(g_reproj)], [sums[1:2]], [1.0], [1e-7])
-        return (g_disp, g_T0, g_T1) + (None,) * 12
+        return (g_disp, g_T0, g_T1) + (None,) * 13
 
 
 class DistilFn(Function):

@@ -57,7 +57,11 @@ def get_translation_matrix(translation_vector):
 
 
 def transformation_from_parameters(axisangle, translation, invert=False):
-    """manydepth/layers.py:26-42."""
+    """manydepth/layers.py:26-42.  On the device: one HIP launch forward, one backward
+    (mal_pose_fwd/bwd) instead of ~40 tiny tensor ops each way; on CPU tensors (host-side
+    tools, tests) the same formulas as plain tensor ops."""
+    if axisangle.is_cuda and axisangle.dim() == 3 and axisangle.shape[1:] == (1, 3):
+        return Fn.PoseFn.apply(axisangle, translation, bool(invert))
     R = rot_from_axisangle(axisangle)
     t = translation.clone()
     if invert:

@@ -120,8 +120,9 @@ def compute_main_losses(ssim, inputs, outputs, mono_reproj, ensemble_reproj, opt
     B, _, H, W = target.shape
     if noise is None and config.noise_source == "cpu":
         torch.randn((B, 1, H, W))  # dead value upstream (:178,192); keeps the RNG stream aligned
-    m = outputs["consistency_mask"].unsqueeze(1) * (1 - outputs["augmentation_mask"][:opt.batch_size])
-    m = m.to(torch.float32).expand(B, 1, H, W).contiguous()
+    cmask = outputs["consistency_mask"].to(torch.float32).reshape(B, 1, H, W)
+    keep = (1 - outputs["augmentation_mask"][:opt.batch_size]).to(torch.float32).reshape(B)
+    m = None  # consistency_mask * (1 - augmentation_mask), (B,1,H,W): built only where a tensor is needed
     mono_depth = outputs[("mono_depth", 0, 0)]
     dual = bool(getattr(opt, "dual_distil", False)) and ensemble_reproj is None
     mono_reproj = mono_reproj.detach()
@@ -132,9 +133,10 @@ def compute_main_losses(ssim, inputs, outputs, mono_reproj, ensemble_reproj, opt
     if ctx is not None and not dual:
         cfg = (ctx.min_depth, ctx.max_depth, ctx.eps, ctx.convention, False, True, want_ct)
         reproj, cons, distil, multi_reproj, ct = Fn.FusedPassFn.apply(
-            ctx.disp, ctx.T[0], ctx.T[1], ctx.K, ctx.inv_K, sources[0], sources[1], target, None, None, m,
-            mono_depth.detach(), mono_reproj, ens, cfg)
+            ctx.disp, ctx.T[0], ctx.T[1], ctx.K, ctx.inv_K, sources[0], sources[1], target, None, None, cmask,
+            mono_depth.detach(), mono_reproj, ens, cfg, keep)
     else:
+        m = (cmask * keep.reshape(B, 1, 1, 1)).contiguous()
         if ctx is not None:
             cfg = (ctx.min_depth, ctx.max_depth, ctx.eps, ctx.convention, False, False, False)
             reproj, _, _, multi_reproj, _ = Fn.FusedPassFn.apply(

@@ -65,6 +65,35 @@ def disp_to_depth_bwd(disp, g_scaled, g_depth, min_depth, max_depth):
     return out
 
 
+# ------------------------------------------------------------------ a16
+def pose_fwd(axisangles, translations, inverts):
+    """[(B,1,3)]*F, [(B,1,3)]*F, [bool]*F -> [(B,4,4)]*F  (transformation_from_parameters)."""
+    import ctypes as C
+    aa = [_req(a, "axisangle") for a in axisangles]
+    tr = [_req(t, "translation") for t in translations]
+    B, F = aa[0].shape[0], len(aa)
+    Ts = [torch.empty(B, 4, 4, dtype=torch.float32, device=aa[0].device) for _ in range(F)]
+    inv = (C.c_int * F)(*[int(bool(i)) for i in inverts])
+    L.check(L.load().mal_pose_fwd(L.ptr_array([_p(a) for a in aa]), L.ptr_array([_p(t) for t in tr]), inv, B, F,
+                                  L.ptr_array([_p(t) for t in Ts]), _stream()), "mal_pose_fwd")
+    return Ts
+
+
+def pose_bwd(axisangles, translations, inverts, g_Ts, need_aa, need_tr):
+    import ctypes as C
+    aa = [_req(a, "axisangle") for a in axisangles]
+    tr = [_req(t, "translation") for t in translations]
+    g_Ts = [_req(g, "g_T") for g in g_Ts]
+    B, F = aa[0].shape[0], len(aa)
+    g_aa = [torch.empty_like(a) if n else None for a, n in zip(aa, need_aa)]
+    g_tr = [torch.empty_like(t) if n else None for t, n in zip(tr, need_tr)]
+    inv = (C.c_int * F)(*[int(bool(i)) for i in inverts])
+    L.check(L.load().mal_pose_bwd(L.ptr_array([_p(a) for a in aa]), L.ptr_array([_p(t) for t in tr]), inv,
+                                  L.ptr_array([_p(g) for g in g_Ts]), B, F, L.ptr_array([_p(g) for g in g_aa]),
+                                  L.ptr_array([_p(g) for g in g_tr]), _stream()), "mal_pose_bwd")
+    return g_aa, g_tr
+
+
 # ------------------------------------------------------------------ a2 / a3 / a4
 def backproject(depth, inv_K):
     depth = _req(depth, "depth")
@@ -251,8 +280,8 @@ def photo_bwd(target, cands, argmin, weight, scale, sums, flags, need):
 # ------------------------------------------------------------------ the fused pass
 def pass_fused(disp, K, inv_K, Ts, srcs, target, ident=None, noise=None, ext_mask=None, mono_depth=None,
                mono_reproj=None, ens_reproj=None, min_depth=0.1, max_depth=100.0, eps=1e-7, convention=0, flags=0,
-               want_min=True, want_cons_target=False, want_depth=False):
-    disp = _req(disp, "disp")
+               want_min=True, want_cons_target=False, want_depth=False, disp2=None, sample_scale=None):
+    disp, disp2, sample_scale = _req(disp, "disp"), _req(disp2, "disp2"), _req(sample_scale, "sample_scale")
     B, _, H, W = disp.shape
     K, inv_K = _mat(K, "K", B), _mat(inv_K, "inv_K", B)
     Ts = [_mat(t, "T", B) for t in Ts]
@@ -264,15 +293,15 @@ def pass_fused(disp, K, inv_K, Ts, srcs, target, ident=None, noise=None, ext_mas
     dev = disp.device
     new = lambda: torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
     grad, pose, epi = bool(flags & L.F_GRAD), bool(flags & L.F_POSE_GRAD), bool(flags & L.F_EPILOGUE)
-    out = dict(min_reproj=new() if want_min else None, sums=torch.zeros(8, dtype=torch.float64, device=dev),
+    out = dict(min_reproj=new() if want_min else None, sums=torch.empty(8, dtype=torch.float64, device=dev),
                g_reproj=new() if grad else None, g_cons=new() if (grad and epi) else None,
                g_distil=new() if (grad and epi) else None,
                g_T=[torch.empty(B, 4, 4, dtype=torch.float32, device=dev) if pose else None for _ in range(2)],
                cons_target=new() if (epi and want_cons_target) else None, depth=new() if want_depth else None)
     ws = workspace(dev, B, H, W)
     L.check(L.load().mal_pass_fused(
-        _p(disp), _p(K), _p(inv_K), L.ptr_array([_p(t) for t in Ts]), L.ptr_array([_p(s) for s in srcs]), _p(target),
-        _p(ident), _p(noise), _p(ext_mask), _p(mono_depth), _p(mono_reproj), _p(ens_reproj), B, H, W, 2, min_depth,
+        _p(disp), _p(disp2), _p(K), _p(inv_K), L.ptr_array([_p(t) for t in Ts]), L.ptr_array([_p(s) for s in srcs]),
+        _p(target), _p(ident), _p(noise), _p(ext_mask), _p(sample_scale), _p(mono_depth), _p(mono_reproj), _p(ens_reproj), B, H, W, 2, min_depth,
         max_depth, eps, convention, flags, _p(out["min_reproj"]), _p(out["sums"]), _p(out["g_reproj"]),
         _p(out["g_cons"]), _p(out["g_distil"]), L.ptr_array([_p(g) for g in out["g_T"]]), _p(out["cons_target"]),
         _p(out["depth"]), _p(ws), ws.numel(), _stream()), "mal_pass_fused")

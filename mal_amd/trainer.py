@@ -103,11 +103,16 @@ class MALLossPath:
         raise NotImplementedError("bind the temporal-hint producer (manydepth/dyn_utils.py:121-170) to "
                                   "self.image_synthesis; the Mask2Former segmenter is outside this package")
 
-    def generate_images_pred_ensemble(self, inputs, T_l, T_n, disp):
-        """manydepth/trainer.py:1172-1207 -> min_f r(warp_f, target), (B,1,H,W), no gradient."""
+    def generate_images_pred_ensemble(self, inputs, T_l, T_n, disp, disp2=None):
+        """manydepth/trainer.py:1172-1207 -> min_f r(warp_f, target), (B,1,H,W), no gradient.
+        ``disp2``: when given the disparity is (disp+disp2)/2, formed inside the kernel (:598)."""
         opt = self.opt
         if tuple(disp.shape[-2:]) != (opt.height, opt.width):
+            if disp2 is not None:
+                disp, disp2 = (disp + disp2) / 2.0, None
             disp = F.interpolate(disp, [opt.height, opt.width], mode="bilinear", align_corners=False)
+        if disp2 is not None and getattr(opt, "no_ssim", False):
+            disp, disp2 = (disp + disp2) / 2.0, None
         fids = opt.frame_ids[1:]
         srcs = [inputs[("color", f, 0)] for f in fids]
         with torch.no_grad():
@@ -121,7 +126,8 @@ class MALLossPath:
                 return mn
             out = ops.pass_fused(disp.detach(), inputs[("K", 0)], inputs[("inv_K", 0)], [T_l.detach(), T_n.detach()],
                                  srcs, inputs[("color", 0, 0)], min_depth=float(opt.min_depth),
-                                 max_depth=float(opt.max_depth), eps=1e-7, convention=self.convention, flags=0)
+                                 max_depth=float(opt.max_depth), eps=1e-7, convention=self.convention, flags=0,
+                                 disp2=None if disp2 is None else disp2.detach())
         return out["min_reproj"]
 
     # ---------------------------------------------------------------- small ops
@@ -226,11 +232,11 @@ class MALLossPath:
         ensemble_reproj = None
         if opt.distil and not opt.no_ens:
             if opt.learn_ens:
-                disp_ensemble = outputs["ens_disp"]
-            else:
-                disp_ensemble = (mono_outputs[("disp", 0)].detach() + outputs[("disp", 0)].detach()) / 2.0
+                d1, d2 = outputs["ens_disp"], None
+            else:  # (mono + multi) / 2 (:598), averaged inside the kernel
+                d1, d2 = mono_outputs[("disp", 0)].detach(), outputs[("disp", 0)].detach()
             ensemble_reproj = self.generate_images_pred_ensemble(inputs, outputs[("cam_T_cam", 0, -1)].detach(),
-                                                                 outputs[("cam_T_cam", 0, 1)].detach(), disp_ensemble)
+                                                                 outputs[("cam_T_cam", 0, 1)].detach(), d1, d2)
         self.generate_images_pred(inputs, outputs, is_multi=True)
         loss_list = None
         if opt.distil:

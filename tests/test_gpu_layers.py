@@ -117,6 +117,25 @@ def test_photometric_modules(tag):
     assert _l2rel(g, r) <= 0.2
 
 
+@pytest.mark.parametrize("invert", [False, True])
+def test_pose_kernel_forward_backward(invert):
+    """mal_pose_fwd/bwd (a16) against the oracle's tensor-op restatement of layers.py:26-100."""
+    from mal_amd import layers
+    from oracle import mal_oracle as O
+    torch.manual_seed(11)
+    aa, tr, w = 0.3 * torch.randn(5, 1, 3), 0.5 * torch.randn(5, 1, 3), torch.randn(5, 4, 4)
+    aa[0] = 0.01 * aa[0]  # the small-angle regime the pose decoder lives in (pose_decoder.py:47)
+    a0, t0 = aa.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+    Tc = O.transformation_from_parameters(a0, t0, invert)
+    (Tc * w).sum().backward()
+    a1, t1 = aa.to(DEV).requires_grad_(True), tr.to(DEV).requires_grad_(True)
+    Tg = layers.transformation_from_parameters(a1, t1, invert)
+    (Tg * w.to(DEV)).sum().backward()
+    assert torch.allclose(Tg.detach().cpu(), Tc.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(a1.grad.cpu(), a0.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(t1.grad.cpu(), t0.grad, rtol=1e-4, atol=1e-5)
+
+
 def test_identity_min_and_fused_ensemble_agree():
     """generate_images_pred_ensemble (fused, no grad) == warp + reprojection + min on explicit images."""
     from mal_amd import layers, loss_utils, trainer, ops
