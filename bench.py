@@ -57,6 +57,8 @@ class Step:
         config.noise_source = "cuda"       # device RNG: no host randn / H2D on the step
         config.consistency_target = False  # logging-only map (loss_utils.py:212-215)
         self.layers = layers
+        from mal_amd import ops
+        self.ops = ops
         b = make_batch(B, H, W, seed=seed)
         mv = lambda t: t.to(dev).contiguous()
         self.inputs = {("color", 0, 0): mv(b["color0"]), ("color", -1, 0): mv(b["color_m1"]),
@@ -70,6 +72,7 @@ class Step:
 
     def __call__(self):
         L, lv = self.layers, self.leaves
+        self.ops.clear_packed_sources()  # a real step sees new images: repack them every step
         for t in lv.values():
             t.grad = None
         T_m1 = L.transformation_from_parameters(lv["axisangle_m1"], lv["translation_m1"], True)

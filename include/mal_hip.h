@@ -53,7 +53,9 @@ enum {
   MAL_F_NO_SSIM = 8,    /* --no_ssim: r = mean_c |t - p| (trainer.py:1217-1218) */
   MAL_F_AVG = 16,       /* --avg_reprojection (dualrefine/trainer.py:579-583): mean over candidates */
   MAL_F_EPILOGUE = 32,  /* student epilogue: consistency + distillation terms (loss_utils.py:193-254) */
-  MAL_F_DUAL_DISTIL = 64/* --dual_distil (loss_utils.py:232-234): the idx==0 target keeps its graph */
+  MAL_F_DUAL_DISTIL = 64,/* --dual_distil (loss_utils.py:232-234): the idx==0 target keeps its graph */
+  MAL_F_SRC_PACKED = 128,/* mal_pass_fused: src[f] are (B,H,W,4) texel copies made by mal_pack_nhwc4 */
+  MAL_F_TGT_PACKED = 256 /* ... and so is target */
 };
 
 int mal_version(void);
@@ -183,6 +185,10 @@ int mal_distil_epilogue(const float* multi_depth, const float* mono_depth, const
                         float* g_multi_distil, float* g_mono_distil, float* consistency_target,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* (B,3,H,W) -> (B,H,W,4) texels (4th component 0): each bilinear tap of the fused pass becomes one
+ * 16-byte gather instead of three 4-byte ones.  Sources change per batch, not per pass: pack once. */
+int mal_pack_nhwc4(const float* src, int B, int H, int W, float* dst, void* stream);
+
 /* ---- a13: Trainer.compute_matching_mask, manydepth/trainer.py:1066-1076 ----------------
  * out = consistency_mask * [ (1/lowest_cost - mono)/mono < 1 ] * [ (mono - 1/lowest_cost)*lowest_cost < 1 ] */
 int mal_matching_mask(const float* lowest_cost /*B,H,W*/, const float* mono_depth /*B,1,H,W*/,
@@ -209,6 +215,11 @@ int mal_pose_fwd(const float* const* axisangle, const float* const* translation,
 int mal_pose_bwd(const float* const* axisangle, const float* const* translation, const int* invert,
                  const float* const* g_T, int B, int F, float* const* g_axisangle /*[F] nullable each*/,
                  float* const* g_translation /*[F] nullable each*/, void* stream);
+
+/* ---- library options: "pass_impl" selects the fused-pass formulation: 2 = LDS-tiled, 512 threads x
+ * 2 px (default); 1 = register-marching; 0 = LDS-tiled first version (both kept for A/B);
+ * "march_rows" = output rows per wavefront task of the marching kernel (default 16). */
+int mal_set_option(const char* name, int value);
 
 /* ---- measurement hooks (bench.py): HIP events recorded immediately before / after the main
  * kernel of the NEXT mal_pass_fused call, on its stream (one-shot; cleared by that call). */

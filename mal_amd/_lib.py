@@ -44,11 +44,13 @@ SIGNATURES = {
     "mal_distil_epilogue": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp,
                                   c_fp, vp, sz, vp]),
     "mal_matching_mask": (i32, [c_fp, c_fp, c_fp, sz, c_fp, vp]),
+    "mal_pack_nhwc4": (i32, [c_fp, i32, i32, i32, c_fp, vp]),
     "mal_axpy_maps": (i32, [i32, c_pp, c_pp, c_pp, C.POINTER(f32), C.POINTER(f32), sz, c_fp, i32, vp]),
     "mal_finish_scalars": (i32, [c_fp, c_fp, f32, f32, i32, c_fp, vp]),
     "mal_sum_f64": (i32, [c_fp, sz, c_fp, vp, sz, vp]),
     "mal_pose_fwd": (i32, [c_pp, c_pp, C.POINTER(i32), i32, i32, c_pp, vp]),
     "mal_pose_bwd": (i32, [c_pp, c_pp, C.POINTER(i32), c_pp, i32, i32, c_pp, c_pp, vp]),
+    "mal_set_option": (i32, [C.c_char_p, i32]),
     "mal_event_create": (vp, []),
     "mal_event_destroy": (i32, [vp]),
     "mal_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
@@ -56,7 +58,7 @@ SIGNATURES = {
 }
 
 # flags (include/mal_hip.h)
-F_AUTOMASK, F_GRAD, F_POSE_GRAD, F_NO_SSIM, F_AVG, F_EPILOGUE, F_DUAL_DISTIL = 1, 2, 4, 8, 16, 32, 64
+F_AUTOMASK, F_GRAD, F_POSE_GRAD, F_NO_SSIM, F_AVG, F_EPILOGUE, F_DUAL_DISTIL, F_SRC_PACKED, F_TGT_PACKED = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 _lib = None
 

@@ -40,9 +40,14 @@ struct Workspace {
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+// capacity of the per-workgroup partial arrays: the marching kernel's 60-column strips x 8-row
+// segments (>= the 64x16 tiles of the LDS-tiled kernel and the 1024-pixel chunks of the others)
+inline size_t ws_blocks(int B, int H, int W) {
+  return (size_t)B * (size_t)((W + 59) / 60) * (size_t)((H + 7) / 8);
+}
+
 inline Workspace carve(void* base, int B, int H, int W) {
-  TileGrid g = tile_grid(B, H, W);
-  size_t nb = (size_t)g.blocks();
+  size_t nb = ws_blocks(B, H, W);
   size_t o = 0;
   Workspace w;
   char* p = (char*)base;
@@ -59,6 +64,10 @@ inline int check_shape(int B, int H, int W) {
   if ((double)B * 4.0 * (double)H * (double)W > 2.0e9) return MAL_ESHAPE;  // int32 indexing
   return MAL_OK;
 }
+
+// mal_pass.hip: fixed-order second stage shared by both fused-pass formulations
+int launch_pass_finalize(const double* block_sums, const float* block_gP, const float* K, int nblocks,
+                         int blocks_per_sample, int B, double* sums, float* gT0, float* gT1, hipStream_t st);
 
 inline int launch_status() {
   hipError_t e = hipGetLastError();

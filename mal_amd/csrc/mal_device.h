@@ -181,6 +181,39 @@ MAL_DEV float blend(const Taps& t, float a, float b, float c, float d) {
   return fma_(d, t.se, o);
 }
 
+// the four bilinear taps of the three colour channels.  planar: (B,3,H,W), 12 dword gathers;
+// packed: (B,H,W,4) made by mal_pack_nhwc4, 4 x 16-byte gathers (the per-lane gather instruction
+// count, not the bytes, is what the texture-address path charges for)
+MAL_DEV void load_taps(const float* src, int packed, int b, int HW, const Taps& t, float* a, float* bb, float* c,
+                       float* d) {
+  if (packed) {
+    const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)b * HW;
+    const float4 A = sp[t.o00], Bv = sp[t.o01], C = sp[t.o10], D = sp[t.o11];
+    a[0] = A.x; a[1] = A.y; a[2] = A.z;
+    bb[0] = Bv.x; bb[1] = Bv.y; bb[2] = Bv.z;
+    c[0] = C.x; c[1] = C.y; c[2] = C.z;
+    d[0] = D.x; d[1] = D.y; d[2] = D.z;
+  } else {
+    const float* sb = src + (size_t)b * 3 * HW;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float* pl = sb + ch * HW;
+      a[ch] = pl[t.o00]; bb[ch] = pl[t.o01]; c[ch] = pl[t.o10]; d[ch] = pl[t.o11];
+    }
+  }
+}
+
+// the three colour channels of one pixel of a planar (B,3,H,W) or packed (B,H,W,4) image
+MAL_DEV void load_px3(const float* img, int packed, int b, int HW, int pix, float* out) {
+  if (packed) {
+    const float4 v = (reinterpret_cast<const float4*>(img) + (size_t)b * HW)[pix];
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+  } else {
+    const float* pl = img + (size_t)b * 3 * HW + pix;
+    out[0] = pl[0]; out[1] = pl[HW]; out[2] = pl[2 * (size_t)HW];
+  }
+}
+
 // d out / d ix and d out / d iy for one channel
 MAL_DEV void blend_grad(const Taps& t, float a, float b, float c, float d, float* dx, float* dy) {
   *dx = (b - a) * t.ey + (d - c) * t.ty;

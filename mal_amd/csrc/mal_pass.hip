@@ -48,6 +48,7 @@ struct PassParams {
   float* min_reproj; float* g_reproj; float* g_cons; float* g_distil; float* cons_target; float* depth_out;
   double* block_sums; float* block_gP;
   int tiles_x, tiles_y, nblocks, per_xcd;
+  int packed;  // src[f] are (B,H,W,4) copies made by mal_pack_nhwc4 (MAL_F_SRC_PACKED)
 };
 
 struct Own {          // what a tile pixel's owner keeps from phase 1 for the chain rule
@@ -107,7 +108,6 @@ __global__ __launch_bounds__(kThreads, 2) void pass_kernel(PassParams p) {
   }
   __syncthreads();
 
-  const float* tgt_b = p.target + (size_t)b * 3 * HW;
   const float* disp_b = p.disp + (size_t)b * HW;
   const float* disp2_b = p.disp2 ? p.disp2 + (size_t)b * HW : nullptr;
   // ensemble pass: the disparity is the mean of teacher and student (trainer.py:598)
@@ -123,17 +123,19 @@ __global__ __launch_bounds__(kThreads, 2) void pass_kernel(PassParams p) {
     float ray[3], X[3];
     ray_of(s_ik, (float)gx, (float)gy, ray);
     X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
+    float ty3[3];
+    load_px3(p.target, p.packed & 2, b, HW, pix, ty3);
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) s_tgt[ch][ridx] = tgt_b[ch * HW + pix];
+    for (int ch = 0; ch < 3; ++ch) s_tgt[ch][ridx] = ty3[ch];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       Sample s = project_pixel(s_P[f], X, p.eps, W, H, p.convention);
       Taps t = make_taps(s.ix, s.iy, W, H);
-      const float* sb = p.src[f] + (size_t)b * 3 * HW;
+      float ta[3], tb[3], tc[3], td[3];
+      load_taps(p.src[f], p.packed & 1, b, HW, t, ta, tb, tc, td);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        const float* pl = sb + ch * HW;
-        float a = pl[t.o00], bb = pl[t.o01], c = pl[t.o10], d = pl[t.o11];
+        float a = ta[ch], bb = tb[ch], c = tc[ch], d = td[ch];
         s_wp[f][ch][ridx] = blend(t, a, bb, c, d);
         if (GRAD && o) {
           float dx, dy;
@@ -458,11 +460,21 @@ __global__ __launch_bounds__(256) void pass_finalize_kernel(const double* block_
   }
 }
 
+int launch_pass_finalize(const double* block_sums, const float* block_gP, const float* K, int nblocks,
+                         int blocks_per_sample, int B, double* sums, float* gT0, float* gT1, hipStream_t st) {
+  hipLaunchKernelGGL(pass_finalize_kernel, dim3(gT0 ? 4 + B : 4), dim3(256), 0, st, block_sums, block_gP, K, nblocks,
+                     blocks_per_sample, B, sums, gT0, gT1);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MAL_OK : MAL_ELAUNCH;
+}
+
 }  // namespace mal
 
 using namespace mal;
 
-extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float* K, const float* inv_K,
+// The LDS-tiled formulation (first version); mal_pass_fused (mal_march.hip) dispatches here when
+// mal_set_option("pass_impl", 0).
+extern "C" int mal_pass_fused_tiled(const float* disp, const float* disp2, const float* K, const float* inv_K,
                               const float* const* T, const float* const* src, const float* target,
                               const float* ident, const float* noise, const float* ext_mask,
                               const float* sample_scale, const float* mono_depth,
@@ -497,6 +509,7 @@ extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float
   p.min_reproj = min_reproj; p.g_reproj = g_reproj; p.g_cons = g_cons; p.g_distil = g_distil;
   p.cons_target = consistency_target; p.depth_out = depth_out; p.block_sums = w.block_sums; p.block_gP = w.block_gP;
   p.tiles_x = tg.tiles_x; p.tiles_y = tg.tiles_y; p.nblocks = tg.blocks();
+  p.packed = ((flags & MAL_F_SRC_PACKED) ? 1 : 0) | ((flags & MAL_F_TGT_PACKED) ? 2 : 0);
   p.per_xcd = (p.nblocks + 7) / 8;
   dim3 grid(p.per_xcd * 8), block(kThreads);
   hipStream_t st = (hipStream_t)stream;
@@ -518,7 +531,6 @@ extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float
   if (ev1) (void)hipEventRecord(ev1, st);
   rc = launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(pass_finalize_kernel, dim3(pose ? 4 + B : 4), dim3(256), 0, st, w.block_sums, w.block_gP, K,
-                     p.nblocks, tg.tiles_x * tg.tiles_y, B, sums, pose ? g_T[0] : nullptr, pose ? g_T[1] : nullptr);
-  return launch_status();
+  return launch_pass_finalize(w.block_sums, w.block_gP, K, p.nblocks, tg.tiles_x * tg.tiles_y, B, sums,
+                              pose ? g_T[0] : nullptr, pose ? g_T[1] : nullptr, st);
 }

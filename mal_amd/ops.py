@@ -6,6 +6,8 @@ CPU path -- a CPU tensor raises.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -277,6 +279,32 @@ def photo_bwd(target, cands, argmin, weight, scale, sums, flags, need):
     return g
 
 
+# ------------------------------------------------------------------ texel packing of the sources
+_PACKED = {}
+pack_sources = True  # fused pass gathers 16-byte texels from (B,H,W,4) copies of the sources
+
+
+def packed_source(src):
+    """(B,3,H,W) -> (B,H,W,4) copy, cached per live tensor object and version: the sources of a
+    batch are shared by the teacher, ensemble and student passes (manydepth/trainer.py:573-612)."""
+    key = (id(src), _stream())
+    hit = _PACKED.get(key)
+    if hit is not None and hit[0]() is src and hit[1] == src._version:
+        return hit[2]
+    if len(_PACKED) > 16:
+        _PACKED.clear()
+    src_c = _req(src, "image")
+    B, _, H, W = src_c.shape
+    dst = torch.empty(B, H, W, 4, dtype=torch.float32, device=src_c.device)
+    L.check(L.load().mal_pack_nhwc4(_p(src_c), B, H, W, _p(dst), _stream()), "mal_pack_nhwc4")
+    _PACKED[key] = (weakref.ref(src), src._version, dst)
+    return dst
+
+
+def clear_packed_sources():
+    _PACKED.clear()
+
+
 # ------------------------------------------------------------------ the fused pass
 def pass_fused(disp, K, inv_K, Ts, srcs, target, ident=None, noise=None, ext_mask=None, mono_depth=None,
                mono_reproj=None, ens_reproj=None, min_depth=0.1, max_depth=100.0, eps=1e-7, convention=0, flags=0,
@@ -299,6 +327,10 @@ def pass_fused(disp, K, inv_K, Ts, srcs, target, ident=None, noise=None, ext_mas
                g_T=[torch.empty(B, 4, 4, dtype=torch.float32, device=dev) if pose else None for _ in range(2)],
                cons_target=new() if (epi and want_cons_target) else None, depth=new() if want_depth else None)
     ws = workspace(dev, B, H, W)
+    if pack_sources:
+        srcs = [packed_source(s) for s in srcs]
+        target = packed_source(target)
+        flags |= L.F_SRC_PACKED | L.F_TGT_PACKED
     L.check(L.load().mal_pass_fused(
         _p(disp), _p(disp2), _p(K), _p(inv_K), L.ptr_array([_p(t) for t in Ts]), L.ptr_array([_p(s) for s in srcs]),
         _p(target), _p(ident), _p(noise), _p(ext_mask), _p(sample_scale), _p(mono_depth), _p(mono_reproj), _p(ens_reproj), B, H, W, 2, min_depth,

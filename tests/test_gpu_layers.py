@@ -153,4 +153,15 @@ def test_identity_min_and_fused_ensemble_agree():
                                 100.0, 1e-7, 0, want_depth=False, want_grid=False)
     r = torch.minimum(loss_utils.compute_reprojection_loss(None, warped[0], b["color0"]),
                       loss_utils.compute_reprojection_loss(None, warped[1], b["color0"]))
-    assert torch.equal(fused, r)
+    # same arithmetic up to the association of the 3x3 window sums (the fused kernel sums
+    # horizontally then vertically); SSIM's sigma cancellation turns that into <= ~1e-4 abs
+    assert (fused - r).abs().max().item() <= 1e-4
+    from mal_amd import _lib
+    lib = _lib.load()
+    outs = []
+    for impl in (0, 1, 2):  # the three formulations of the fused pass agree with each other
+        assert lib.mal_set_option(b"pass_impl", impl) == 0
+        outs.append(lp.generate_images_pred_ensemble(inputs, T0, T1, b["disp_teacher"]))
+    lib.mal_set_option(b"pass_impl", 1)
+    assert (outs[0] - r).abs().max().item() <= 2e-6  # the LDS-tiled v1 keeps ATen's row-major sum order
+    assert (outs[1] - outs[0]).abs().max().item() <= 1e-4 and (outs[2] - outs[0]).abs().max().item() <= 1e-4
