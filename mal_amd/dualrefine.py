@@ -1,0 +1,217 @@
+"""DualRefine's warp / loss methods on the same kernels.
+
+Mirrors ``dualrefine/trainer.py``: ``generate_images_pred`` (:395-451),
+``pose_update_generate_images_pred`` (:457-480), ``compute_reprojection_loss`` (:487-499),
+``compute_losses`` (:530-697) and ``compute_pose_update_losses`` (:699-767) -- same method
+names, 4-tuple ``outputs`` keys ``(name, frame, scale, deq_iter)`` and loss-dict keys.
+Differences from the ManyDepth path that the kernels take as a flag: ``Project3D`` normalises
+``2*(u+0.5)/W-1`` and samples with ``align_corners=False`` (dualrefine/layers.py:224-225,
+trainer.py:444-447) -> ``convention=1``; the automask is multiplied by ``consistency_mask`` for
+deq_iter > 0 (:593-597); ``--avg_reprojection`` averages candidates instead of taking the min
+(:579-583), which runs on the explicit kernels.  The debug ``print``s and the ``exit(0)`` the
+shipped file carries (:452-455,481-484) are not behaviour and are not reproduced.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import config
+from . import functional as Fn
+from . import layers
+from . import loss_utils
+from . import ops
+from .trainer import WarpContext
+
+
+def default_options(**kw):
+    """The fields these methods read, with dualrefine/options.py defaults."""
+    o = dict(height=192, width=640, batch_size=8, min_depth=0.1, max_depth=100.0, frame_ids=[0, -1, 1], scales=[0],
+             n_losses=1, v1_multiscale=False, disable_automasking=False, no_ssim=False, disparity_smoothness=1e-3,
+             avg_reprojection=False, disable_motion_masking=False, Dstar_T0_pair=False, Tstar_D0_pair=False)
+    o.update(kw)
+    return SimpleNamespace(**o)
+
+
+class DualRefineLossPath:
+    convention = Fn.DUALREFINE
+    fuse = True
+    f_thres = 1  # compute_losses takes the per-deq-iteration branch when f_thres > 0 (:543)
+
+    def __init__(self, opt, fuse=True):
+        self.opt = opt
+        self.fuse = fuse
+        self.num_scales = len(opt.scales)
+        self.ssim = layers.SSIM()
+
+    # ------------------------------------------------------------------ warp
+    def _pose_for(self, outputs, frame_id, deq_iter):
+        """dualrefine/trainer.py:420-435."""
+        if frame_id == 1:
+            T = outputs[("cam_T_cam", 0, frame_id)]
+            return T.detach() if deq_iter > 0 else T
+        if deq_iter > 0:
+            if self.opt.Dstar_T0_pair:
+                return outputs[("cam_T_cam", 0, frame_id)].detach()
+            return outputs[("cam_T_cam", 0, frame_id, 1)]
+        return outputs[("cam_T_cam", 0, frame_id)]
+
+    def _iters(self, scale):
+        return self.opt.n_losses + 1 if scale in (0, 1, 2) else 1
+
+    def generate_images_pred(self, inputs, outputs):
+        """dualrefine/trainer.py:395-451."""
+        opt = self.opt
+        for scale in opt.scales:
+            for deq_iter in range(self._iters(scale)):
+                if scale == 1:
+                    continue
+                disp = outputs[("disp", scale, deq_iter)]
+                if not opt.v1_multiscale and tuple(disp.shape[-2:]) != (opt.height, opt.width):
+                    disp = F.interpolate(disp, [opt.height, opt.width], mode="bilinear", align_corners=False)
+                fids = opt.frame_ids[1:]
+                Ts = [self._pose_for(outputs, f, deq_iter) for f in fids]
+                K, inv_K = inputs[("K", 0)], inputs[("inv_K", 0)]
+                srcs = [inputs[("color", f, 0)] for f in fids]
+                cfg = (float(opt.min_depth), float(opt.max_depth), 1e-7, self.convention)
+                if self.fuse and not opt.avg_reprojection and not opt.no_ssim:
+                    _, depth = layers.disp_to_depth(disp, opt.min_depth, opt.max_depth)
+                    outputs[("depth", 0, scale, deq_iter)] = depth
+                    outputs[("mal_ctx", scale, deq_iter)] = WarpContext(
+                        disp=disp, T=Ts, K=K, inv_K=inv_K, min_depth=cfg[0], max_depth=cfg[1], eps=cfg[2],
+                        convention=cfg[3], srcs=srcs, fids=fids)
+                else:
+                    res = Fn.WarpFn.apply(disp, K, inv_K, cfg, len(fids), *Ts, *srcs)
+                    outputs[("depth", 0, scale, deq_iter)] = res[0]
+                    for i, f in enumerate(fids):
+                        outputs[("sample", f, scale, deq_iter)] = res[1 + i]
+                        outputs[("color", f, scale, deq_iter)] = res[1 + len(fids) + i]
+                if not opt.disable_automasking:
+                    for f in fids:
+                        outputs[("color_identity", f, scale, deq_iter)] = inputs[("color", f, 0)]
+
+    def pose_update_generate_images_pred(self, inputs, outputs):
+        """dualrefine/trainer.py:457-480: frame -1 re-warped with the refined pose."""
+        opt = self.opt
+        if opt.Tstar_D0_pair:
+            depth = outputs[("depth", 0, 0, 0)].clone().detach()
+        else:
+            depth = outputs[("depth", 0, 0, opt.n_losses)]
+        T = outputs[("cam_T_cam", 0, -1, 1)]
+        pts = layers.BackprojectDepth(opt.batch_size, opt.height, opt.width)(depth, inputs[("inv_K", 0)])
+        grid = layers.Project3DDualRefine(opt.batch_size, opt.height, opt.width)(pts, inputs[("K", 0)], T)
+        outputs[("color", -1, 0, 0, 1)] = layers.grid_sample(inputs[("color", -1, 0)], grid, padding_mode="border",
+                                                             align_corners=False)
+
+    # ------------------------------------------------------------------ losses
+    def compute_reprojection_loss(self, pred, target):
+        """dualrefine/trainer.py:487-499."""
+        return loss_utils.compute_reprojection_loss(None, pred, target, self.opt.no_ssim)
+
+    @staticmethod
+    def compute_loss_masks(reprojection_loss, identity_reprojection_loss):
+        return loss_utils.compute_loss_masks(reprojection_loss, identity_reprojection_loss)
+
+    def _reproj_term(self, inputs, outputs, key_tail, cands_keys, ext_mask, noise):
+        """masked min/avg reprojection for one (scale, deq_iter): the fused pass when the warp was
+        recorded lazily, else the explicit kernels.  -> (loss scalar, per-pixel map)."""
+        opt = self.opt
+        target = inputs[("color", 0, 0)]
+        fids = opt.frame_ids[1:]
+        sources = [inputs[("color", f, 0)] for f in fids]
+        B, _, H, W = target.shape
+        flags = (L.F_NO_SSIM if opt.no_ssim else 0) | (L.F_AVG if opt.avg_reprojection else 0)
+        ident = None
+        if not opt.disable_automasking:
+            # identity: min (or mean, :568-573) over the raw sources
+            ident, _, _, _ = ops.photo_fwd(target, [s.detach() for s in sources], None, None, None, flags,
+                                           want_argmin=False, want_weight=False)
+            flags |= L.F_AUTOMASK
+        ctx = outputs.get(("mal_ctx",) + key_tail) if cands_keys is None else None
+        if ctx is not None:
+            cfg = (ctx.min_depth, ctx.max_depth, ctx.eps, ctx.convention, ident is not None, False, False)
+            reproj, _, _, rp_map, _ = Fn.FusedPassFn.apply(ctx.disp, ctx.T[0], ctx.T[1], ctx.K, ctx.inv_K, sources[0],
+                                                           sources[1], target, ident, noise, ext_mask, None, None,
+                                                           None, cfg)
+        else:
+            keys = cands_keys if cands_keys is not None else [("color", f) + key_tail for f in fids]
+            reproj, rp_map, _ = Fn.PhotoLossFn.apply(target, ident, noise, ext_mask, flags,
+                                                     *[outputs[k] for k in keys])
+        return reproj, rp_map
+
+    def compute_losses(self, inputs, outputs, noises=None):
+        """dualrefine/trainer.py:530-633 (per scale, per deq iteration; losses accumulate across
+        the iterations of a scale exactly as upstream's running ``loss`` does)."""
+        opt = self.opt
+        losses = {}
+        total = 0
+        k = 0
+        for scale in opt.scales:
+            loss = 0
+            for it in range(self._iters(scale) if self.f_thres > 0 else 1):
+                if scale == 1 and self.f_thres > 0:
+                    continue
+                disp = outputs[("disp", scale, it)]
+                color = inputs[("color", 0, scale)]
+                ext = None
+                if it > 0 and not opt.disable_motion_masking:
+                    ext = outputs["consistency_mask"].to(torch.float32).contiguous()
+                noise = None
+                if not opt.disable_automasking:  # one draw per (scale, deq_iter), as :586-587
+                    target = inputs[("color", 0, 0)]
+                    noise = noises[k] if noises is not None else loss_utils.draw_noise(
+                        (target.shape[0], 1) + tuple(target.shape[-2:]), target.device)
+                k += 1
+                reproj, rp_map = self._reproj_term(inputs, outputs, (scale, it), None, ext, noise)
+                losses["reproj_loss/{}".format(scale)] = reproj
+                loss = loss + reproj
+                if it > 0:
+                    multi_depth = outputs[("depth", 0, scale, it)]
+                    mono_depth = outputs[("depth", 0, scale, 0)].detach()
+                    # consistency_mask = 1 - (automask * consistency_mask): needs the combined weight map
+                    wmap = self._weight_map(inputs, outputs, scale, it, ext, rp_map, noise)
+                    cons, _, ct = Fn.DistilFn.apply(multi_depth, mono_depth, rp_map, rp_map, None, wmap, False)
+                    if config.consistency_target:
+                        outputs["consistency_target/{}_{}".format(scale, it)] = ct
+                    losses["consistency_loss/{}_{}".format(scale, it)] = cons
+                    loss = loss + cons
+                loss = loss + opt.disparity_smoothness * loss_utils._smooth(disp, color) / (2 ** scale)
+                total = total + loss
+                losses["loss/{}_{}".format(scale, it)] = loss
+        losses["loss"] = total / self.num_scales
+        return losses
+
+    def _weight_map(self, inputs, outputs, scale, it, ext, rp_map, noise):
+        """reprojection_loss_mask of dualrefine/trainer.py:589-597 as a (B,1,H,W) map."""
+        opt = self.opt
+        w = torch.ones_like(rp_map)
+        if not opt.disable_automasking:
+            target = inputs[("color", 0, 0)]
+            sources = [inputs[("color", f, 0)] for f in opt.frame_ids[1:]]
+            flags = (L.F_NO_SSIM if opt.no_ssim else 0) | (L.F_AVG if opt.avg_reprojection else 0)
+            ident, _, _, _ = ops.photo_fwd(target, [s.detach() for s in sources], None, None, None, flags,
+                                           want_argmin=False, want_weight=False)
+            w = loss_utils.compute_loss_masks(rp_map.detach(), ident + noise * 0.00001 if noise is not None else ident)
+        if ext is not None:
+            w = w * ext
+        return w.contiguous()
+
+    def compute_pose_update_losses(self, inputs, outputs, noise=None):
+        """dualrefine/trainer.py:699-767."""
+        keys = [("color", -1, 0, 0, 1), ("color", 1, 0, 0)]
+        if keys[1] not in outputs:
+            ctx = outputs.get(("mal_ctx", 0, 0))
+            if ctx is None:
+                raise L.MalError("compute_pose_update_losses: call generate_images_pred first")
+            cfg = (ctx.min_depth, ctx.max_depth, ctx.eps, ctx.convention)
+            res = Fn.WarpFn.apply(ctx.disp, ctx.K, ctx.inv_K, cfg, 2, *ctx.T, *ctx.srcs)
+            outputs[keys[1]] = res[4]  # (depth, grid_-1, grid_+1, warped_-1, warped_+1)
+        if noise is None and not self.opt.disable_automasking:
+            target = inputs[("color", 0, 0)]
+            noise = loss_utils.draw_noise((target.shape[0], 1) + tuple(target.shape[-2:]), target.device)
+        reproj, _ = self._reproj_term(inputs, outputs, (0, 0), keys, None, noise)
+        losses = {"reproj_loss/pose_0": reproj, "loss/pose_0_0": reproj, "loss": reproj}
+        return losses

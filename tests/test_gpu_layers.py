@@ -165,3 +165,51 @@ def test_identity_min_and_fused_ensemble_agree():
     lib.mal_set_option(b"pass_impl", 1)
     assert (outs[0] - r).abs().max().item() <= 2e-6  # the LDS-tiled v1 keeps ATen's row-major sum order
     assert (outs[1] - outs[0]).abs().max().item() <= 1e-4 and (outs[2] - outs[0]).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("fuse,avg", [(True, False), (False, False), (False, True)],
+                         ids=["fused", "explicit", "explicit-avg"])
+def test_dualrefine_loss_path(fuse, avg):
+    """a17: DualRefine's per-(scale, deq_iter) loops (dualrefine/trainer.py:395-451,530-633) with the
+    align_corners=False convention, against the oracle's restatement of the same lines."""
+    from mal_amd import dualrefine, layers
+    from mal_amd.synthetic import make_batch
+    from oracle import mal_oracle as O
+    from tests import hip_harness as HH
+    B, H, W = 2, 40, 72
+    batch = make_batch(B, H, W, seed=321)
+    torch.manual_seed(5)
+    noises = [torch.randn(B, 1, H, W) for _ in range(2)]
+    kw = dict(height=H, width=W, batch_size=B, n_losses=1, avg_reprojection=avg)
+
+    def build(dev, pose_fn):
+        mv = lambda t: t.to(dev).contiguous()
+        inputs = {("color", f, 0): mv(batch[k]) for f, k in ((0, "color0"), (-1, "color_m1"), (1, "color_p1"))}
+        inputs[("K", 0)], inputs[("inv_K", 0)] = mv(batch["K"]), mv(batch["inv_K"])
+        leaves = {k: mv(batch[k]).clone().requires_grad_(True) for k in HH.LEAVES}
+        T_m1 = pose_fn(leaves["axisangle_m1"], leaves["translation_m1"], True)
+        T_p1 = pose_fn(leaves["axisangle_p1"], leaves["translation_p1"], False)
+        outputs = {("disp", 0, 0): leaves["disp_teacher"], ("disp", 0, 1): leaves["disp_student"],
+                   ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1, ("cam_T_cam", 0, -1, 1): T_m1 * 1.0,
+                   "consistency_mask": mv(batch["consistency_mask"]).unsqueeze(1)}
+        return inputs, outputs, leaves
+
+    inputs, outputs, leaves = build("cpu", O.transformation_from_parameters)
+    opt = O.dr_default_opt(**kw)
+    O.dr_generate_images_pred(opt, inputs, outputs)
+    ref = O.dr_compute_losses(opt, inputs, outputs, noises=[n.clone() for n in noises])
+    ref["loss"].backward()
+    inputs, outputs, gl = build(DEV, layers.transformation_from_parameters)
+    lp = dualrefine.DualRefineLossPath(dualrefine.default_options(**kw), fuse=fuse)
+    lp.generate_images_pred(inputs, outputs)
+    got = lp.compute_losses(inputs, outputs, noises=[n.to(DEV) for n in noises])
+    got["loss"].backward()
+    assert set(got) == set(ref)
+    for k, v in ref.items():
+        assert abs(float(got[k].detach()) - float(v)) <= 2e-4 * abs(float(v)) + 2e-5, (k, float(got[k].detach()), float(v))
+    for k in HH.LEAVES:
+        g, r = gl[k].grad.cpu().numpy(), leaves[k].grad.numpy()
+        if g.ndim == 4:
+            assert (np.abs(g - r) > 2e-4 * np.abs(r).max()).mean() <= 5e-3, k
+        else:
+            assert _l2rel(g, r) <= 2e-2, k  # 2880 pixels: one automask tie moves a pose sum by ~1e-2
