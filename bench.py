@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", type=int, default=0, help="replay the step from a HIP graph (default eager)")
+    ap.add_argument("--mode", choices=["step", "ops"], default="step",
+                    help="step: mal_loss_step (one C call per direction); ops: the operator-level API")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -51,8 +53,9 @@ def parse():
 class Step:
     """Everything a step needs, resident on the device."""
 
-    def __init__(self, dev, seed):
-        from mal_amd import config, layers, trainer
+    def __init__(self, dev, seed, mode="step"):
+        from mal_amd import config, layers, trainer, step as step_mod
+        self.mode, self.step_mod = mode, step_mod
         from mal_amd.synthetic import make_batch
         config.noise_source = "cuda"       # device RNG: no host randn / H2D on the step (DESIGN.md)
         config.consistency_target = False  # logging-only map (loss_utils.py:212-215)
@@ -72,9 +75,19 @@ class Step:
 
     def __call__(self):
         L, lv = self.layers, self.leaves
-        self.ops.clear_packed_sources()  # a real step sees new images: repack them every step
         for t in lv.values():
             t.grad = None
+        if self.mode == "step":  # one C call forward (incl. texel packing every step), one backward
+            mono_outputs = {("disp", 0): lv["disp_teacher"]}
+            for f, s in ((-1, "m1"), (1, "p1")):
+                mono_outputs[("axisangle", 0, f)] = lv["axisangle_" + s]
+                mono_outputs[("translation", 0, f)] = lv["translation_" + s]
+            outputs = {("disp", 0): lv["disp_student"], "consistency_mask": self.cmask,
+                       "augmentation_mask": self.aug, "lowest_cost": self.lowest}
+            losses, _, _ = self.step_mod.loss_step(self.lp.opt, self.inputs, mono_outputs, outputs, want_maps=False)
+            losses["loss"].backward()
+            return losses["loss"]
+        self.ops.clear_packed_sources()  # a real step sees new images: repack them every step
         T_m1 = L.transformation_from_parameters(lv["axisangle_m1"], lv["translation_m1"], True)
         T_p1 = L.transformation_from_parameters(lv["axisangle_p1"], lv["translation_p1"], False)
         mono_outputs = {("disp", 0): lv["disp_teacher"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1}
@@ -127,7 +140,7 @@ def main():
     if dist is not None:
         dist.barrier()
     lib = _lib.load()
-    step = Step(dev, 1234 + rank)
+    step = Step(dev, 1234 + rank, args.mode)
 
     def sync():
         if dist is not None:
@@ -204,7 +217,9 @@ def main():
                                "passes, consistency+distillation+smoothness), fwd+bwd to disp/pose leaves; "
                                "networks not included", "global_batch": B * world, "height": H, "width": W,
                    "parallelism": "dp%d (replicas over disjoint batches, no data-path collective)" % world,
-                   "launch": "hip-graph" if graph is not None else "eager"},
+                   "launch": "hip-graph" if graph is not None else "eager",
+                   "api": "mal_loss_step_fwd/_bwd (one host call per direction)" if args.mode == "step"
+                          else "operator-level (mal_amd.loss_utils / MALLossPath)"},
         "roofline": {"bound": "hbm", "kernel": "mal::pass_kernel<GRAD,AUTOMASK,POSE> (teacher pass: warp+SSIM+L1+"
                                                "min+automask fwd+bwd, one launch)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

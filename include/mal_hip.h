@@ -216,6 +216,42 @@ int mal_pose_bwd(const float* const* axisangle, const float* const* translation,
                  const float* const* g_T, int B, int F, float* const* g_axisangle /*[F] nullable each*/,
                  float* const* g_translation /*[F] nullable each*/, void* stream);
 
+/* ---- the whole loss half of process_batch (manydepth/trainer.py:573-642 with --distil) as one call.
+ * Forward enqueues ~18 kernels (pose composition, texel packing, identity term, teacher / ensemble /
+ * student passes with the matching mask and the consistency*(1-augmentation) mask formed in the
+ * kernel, both smoothness terms, reductions); backward enqueues 2 (gradient assembly, pose backward).
+ * losses[16] (device f32): 0 reproj_t 1 smooth_t 2 loss_t(=0+1e-3*1) 3 reproj_s 4 consistency 5 smooth_s
+ *   6 distil 7 loss_main(=3+4+1e-3*5) 8 total = w_main*(7+2) + w_distil*6   (what backward differentiates)
+ *   9 reproj_s+reproj_t ("reproj_loss/0") 10 (7+6)+2 ("loss" without --loss_blc) 11 7+2 (loss_list[0])
+ * Without --loss_blc pass w_main = w_distil = 1; with it w_main = bs*w0, w_distil = bs*w1
+ * (loss_utils.py:303-318).  All maps the step needs between kernels live in `ws`
+ * (mal_step_workspace_bytes); the same ws must be handed to _bwd. */
+enum { MAL_STEP_NO_ENS = 1 /* --no_ens: 2-way distillation argmin, no ensemble pass */ };
+typedef struct mal_step_args {
+  int B, H, W;
+  float min_depth, max_depth;
+  int flags;
+  float w_main, w_distil;
+  const float *color0, *color_m1, *color_p1;      /* (B,3,H,W) */
+  const float *K, *inv_K;                         /* (B,16) */
+  const float *disp_teacher, *disp_student;       /* (B,1,H,W), full resolution */
+  const float *axisangle_m1, *translation_m1, *axisangle_p1, *translation_p1; /* (B,3) */
+  const float *consistency_mask;                  /* (B,H,W), before the matching mask */
+  const float *augmentation_keep;                 /* (B): 1 - augmentation_mask */
+  const float *lowest_cost;                       /* (B,H,W) */
+  const float *noise;                             /* (B,1,H,W) N(0,1), nullable */
+  float *losses;                                  /* 16 */
+  float *mono_reproj, *ens_reproj, *multi_reproj; /* (B,1,H,W) nullable outputs */
+  float *consistency_mask_out;                    /* (B,H,W) nullable: mask * matching mask */
+  const float *g_total;                           /* backward: device scalar d(final)/d(total), nullable = 1 */
+  float *g_disp_teacher, *g_disp_student;         /* backward outputs, nullable */
+  float *g_axisangle_m1, *g_translation_m1, *g_axisangle_p1, *g_translation_p1;
+  void *ws; size_t ws_bytes; void *stream;
+} mal_step_args;
+size_t mal_step_workspace_bytes(int B, int H, int W);
+int mal_loss_step_fwd(const mal_step_args* args);
+int mal_loss_step_bwd(const mal_step_args* args);
+
 /* ---- library options: "pass_impl" selects the fused-pass formulation: 2 = LDS-tiled, 512 threads x
  * 2 px (default); 1 = register-marching; 0 = LDS-tiled first version (both kept for A/B);
  * "march_rows" = output rows per wavefront task of the marching kernel (default 16). */

@@ -50,12 +50,30 @@ SIGNATURES = {
     "mal_sum_f64": (i32, [c_fp, sz, c_fp, vp, sz, vp]),
     "mal_pose_fwd": (i32, [c_pp, c_pp, C.POINTER(i32), i32, i32, c_pp, vp]),
     "mal_pose_bwd": (i32, [c_pp, c_pp, C.POINTER(i32), c_pp, i32, i32, c_pp, c_pp, vp]),
+    "mal_step_workspace_bytes": (sz, [i32, i32, i32]),
+    "mal_loss_step_fwd": (i32, [vp]),
+    "mal_loss_step_bwd": (i32, [vp]),
     "mal_set_option": (i32, [C.c_char_p, i32]),
     "mal_event_create": (vp, []),
     "mal_event_destroy": (i32, [vp]),
     "mal_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
     "mal_profile_next_pass": (i32, [vp, vp]),
 }
+
+class StepArgs(C.Structure):
+    """mal_step_args (include/mal_hip.h)."""
+    _fields_ = ([("B", i32), ("H", i32), ("W", i32), ("min_depth", f32), ("max_depth", f32), ("flags", i32),
+                 ("w_main", f32), ("w_distil", f32)] +
+                [(n, vp) for n in ("color0", "color_m1", "color_p1", "K", "inv_K", "disp_teacher", "disp_student",
+                                   "axisangle_m1", "translation_m1", "axisangle_p1", "translation_p1",
+                                   "consistency_mask", "augmentation_keep", "lowest_cost", "noise", "losses",
+                                   "mono_reproj", "ens_reproj", "multi_reproj", "consistency_mask_out", "g_total",
+                                   "g_disp_teacher", "g_disp_student", "g_axisangle_m1", "g_translation_m1",
+                                   "g_axisangle_p1", "g_translation_p1", "ws")] +
+                [("ws_bytes", sz), ("stream", vp)])
+
+
+STEP_NO_ENS = 1
 
 # flags (include/mal_hip.h)
 F_AUTOMASK, F_GRAD, F_POSE_GRAD, F_NO_SSIM, F_AVG, F_EPILOGUE, F_DUAL_DISTIL, F_SRC_PACKED, F_TGT_PACKED = 1, 2, 4, 8, 16, 32, 64, 128, 256

@@ -1,0 +1,34 @@
+// Internal interface of the marching fused-pass kernels (mal_march.hip), shared with the
+// whole-step launch list (mal_step.hip).
+#pragma once
+#include "mal_common.h"
+
+namespace mal {
+
+struct MarchParams {
+  const float* disp; const float* disp2; const float* K; const float* invK;
+  const float* T[2]; const float* src[2];
+  const float* target; const float* ident; const float* noise; const float* ext_mask; const float* sample_scale;
+  const float* mono_depth; const float* mono_reproj; const float* ens_reproj;
+  // whole-step launch list (mal_step.hip): the teacher's depth is re-derived from its disparity and
+  // the matching mask (trainer.py:1066-1076) is formed in place, so neither map touches HBM
+  const float* mono_disp; const float* lowest_cost; float* cmask_out;
+  int B, H, W; float min_disp, range, eps; int convention;
+  float* min_reproj; float* g_reproj; float* g_cons; float* g_distil; float* cons_target; float* depth_out;
+  double* block_sums; float* block_gP;
+  int strips, segs, rows, ntasks, per_xcd;
+  int packed;
+  int debug;  // experiments only (mal_set_option("debug")): bit 0 = taps read the pixel's own address
+};
+
+// zero-initialised parameter block with the depth range / convention filled in
+MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, float eps, int convention);
+// fills the task decomposition for `flags` (MAL_F_*), launches the matching instantiation on `st`
+// (bracketed by the one-shot profile events if armed).  Partials go to p.block_sums / p.block_gP.
+int march_launch(MarchParams& p, int flags, hipStream_t st);
+// min_f r(src_f, target) on packed (B,H,W,4) images -> ident (B,1,H,W): the identity term of
+// manydepth/loss_utils.py:92-101, same marching structure without the warp
+int identity_launch(const float* target_packed, const float* src0_packed, const float* src1_packed, int B, int H,
+                    int W, float* ident, hipStream_t st);
+
+}  // namespace mal

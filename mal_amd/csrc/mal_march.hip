@@ -22,25 +22,12 @@
 // generate_images_pred (:1078-1125), the reprojection/min/automask part of compute_mono_losses
 // / compute_main_losses (loss_utils.py:57-113,131-199), generate_images_pred_ensemble
 // (:1172-1207) and the consistency/distillation terms (loss_utils.py:193-254).
-#include "mal_common.h"
+#include "mal_march.h"
 #include "mal_device.h"
 
 namespace mal {
 
 extern hipEvent_t g_prof_start, g_prof_stop;
-
-struct MarchParams {
-  const float* disp; const float* disp2; const float* K; const float* invK;
-  const float* T[2]; const float* src[2];
-  const float* target; const float* ident; const float* noise; const float* ext_mask; const float* sample_scale;
-  const float* mono_depth; const float* mono_reproj; const float* ens_reproj;
-  int B, H, W; float min_disp, range, eps; int convention;
-  float* min_reproj; float* g_reproj; float* g_cons; float* g_distil; float* cons_target; float* depth_out;
-  double* block_sums; float* block_gP;
-  int strips, segs, rows, ntasks, per_xcd;
-  int packed;
-  int debug;  // experiments only (mal_set_option("debug")): bit 0 = taps read the pixel's own address
-};
 
 MAL_DEV float dpp_shr1(float v) {  // lane i <- lane i-1 (lane 0 <- 0)
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
@@ -270,7 +257,17 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
         if (p.noise) idn += p.noise[gi] * 0.00001f;
         w = (pi0.rp <= idn) ? 1.0f : 0.0f;
       }
-      if (p.ext_mask) w *= p.ext_mask[gi];
+      if (p.ext_mask) {
+        float em = p.ext_mask[gi];
+        if (p.lowest_cost) {  // consistency_mask *= compute_matching_mask (trainer.py:592-593,1066-1076)
+          const float mono = depth_of(p.mono_disp[gi], p.min_disp, p.range);
+          const float matching = div_safe_(1.0f, p.lowest_cost[gi]);
+          const bool ok = (div_safe_(matching - mono, mono) < 1.0f) && (div_safe_(mono - matching, matching) < 1.0f);
+          em = ok ? em : em * 0.0f;
+          if (p.cmask_out && out_x && c >= y_lo && c < y_hi) p.cmask_out[gi] = em;
+        }
+        w *= em;
+      }
       w *= sscale;
       if (!in_x) w = 0.f;  // not a pixel: contributes nothing (its statistics only served as halo)
       pi0.w = w;
@@ -374,7 +371,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
         const size_t gi = map_b + (size_t)q * W + gxr;
         const float dm = depth_of(disp_b[q * W + gxr], p.min_disp, p.range);
         const float ddepth = -(dm * dm) * p.range;
-        const float dmono = p.mono_depth[gi];
+        const float dmono = p.mono_disp ? depth_of(p.mono_disp[gi], p.min_disp, p.range) : p.mono_depth[gi];
         const float m = pq.w, cm = 1.0f - m, mm = 1.0f - cm;
         const float dc = dm - dmono;
         acc_cons += (double)(fabsf(dc) * cm);
@@ -430,9 +427,136 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
   }
 }
 
+// ---- identity term: min over the two raw sources of r(src_f, target), forward only --------------
+struct IdentParams { const float* target; const float* src[2]; float* ident; int B, H, W, strips, segs, rows, ntasks, per_xcd; };
+
+__global__ __launch_bounds__(64, 4) void identity_kernel(IdentParams p) {
+  constexpr int HALO = 1, CW = 62;
+  const int id = blockIdx.x;
+  const int task = (id & 7) * p.per_xcd + (id >> 3);
+  if (task >= p.ntasks) return;
+  const int per_b = p.strips * p.segs;
+  const int b = task / per_b, tt = task - b * per_b;
+  const int seg = tt / p.strips, strip = tt - seg * p.strips;
+  const int H = p.H, W = p.W, HW = H * W, lane = threadIdx.x;
+  const int y_lo = seg * p.rows, y_hi = min(y_lo + p.rows, H);
+  const int gx = strip * CW - HALO + lane;
+  const bool in_x = gx >= 0 && gx < W;
+  const int gxr = min(max(reflect1(gx, W), 0), W - 1);
+  const bool out_x = in_x && lane >= HALO && lane < 64 - HALO;
+  float hsA[24], hsB[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) { hsA[i] = 0.f; hsB[i] = 0.f; }
+  float x1[2][3], y1[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) { x1[0][ch] = x1[1][ch] = 0.f; y1[ch] = 0.f; }
+  for (int r = max(y_lo - 1, -1); r <= y_hi; ++r) {
+    const int gyr = min(max(reflect1(r, H), 0), H - 1), pix = gyr * W + gxr;
+    float x0[2][3], y0[3];
+    load_px3(p.target, 1, b, HW, pix, y0);
+    load_px3(p.src[0], 1, b, HW, pix, x0[0]);
+    load_px3(p.src[1], 1, b, HW, pix, x0[1]);
+    float h[24];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float y = y0[ch];
+      h[18 + ch] = hsum3(y);
+      h[21 + ch] = hsum3(y * y);
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const float x = x0[f][ch];
+        h[f * 9 + ch * 3 + 0] = hsum3(x);
+        h[f * 9 + ch * 3 + 1] = hsum3(x * x);
+        h[f * 9 + ch * 3 + 2] = hsum3(x * y);
+      }
+    }
+    const int c = r - 1;
+    if (c >= y_lo && c < y_hi) {
+      float ssum[2], lsum[2];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float sy = hsA[18 + ch] + h[18 + ch], syy = hsA[21 + ch] + h[21 + ch];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const float sx = hsA[f * 9 + ch * 3] + h[f * 9 + ch * 3];
+          const float sxx = hsA[f * 9 + ch * 3 + 1] + h[f * 9 + ch * 3 + 1];
+          const float sxy = hsA[f * 9 + ch * 3 + 2] + h[f * 9 + ch * 3 + 2];
+          const float vc = clamp01(ssim_sums<false>(sx, sy, sxx, syy, sxy, nullptr, nullptr, nullptr));
+          ssum[f] = ch == 0 ? vc : ssum[f] + vc;
+          const float l1 = fabsf(y1[ch] - x1[f][ch]);
+          lsum[f] = ch == 0 ? l1 : lsum[f] + l1;
+        }
+      }
+      const float r0 = 0.85f * div3_(ssum[0]) + 0.15f * div3_(lsum[0]);
+      const float r1 = 0.85f * div3_(ssum[1]) + 0.15f * div3_(lsum[1]);
+      if (out_x) p.ident[(size_t)b * HW + (size_t)c * W + gxr] = fminf(r0, r1);
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { hsA[i] = hsB[i] + h[i]; hsB[i] = h[i]; }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { x1[0][ch] = x0[0][ch]; x1[1][ch] = x0[1][ch]; y1[ch] = y0[ch]; }
+  }
+}
+
 int g_pass_impl = 1;   // 1 = marching (this file, fastest); 0 = LDS-tiled v1 (mal_pass.hip); 2 = LDS-tiled, 512 threads (mal_tile2.hip)
 int g_march_rows = 16; // output rows per wave task
 int g_debug = 0;
+
+MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, float eps, int convention) {
+  MarchParams p = {};
+  p.B = B; p.H = H; p.W = W;
+  p.min_disp = (float)(1.0 / (double)max_depth);
+  p.range = (float)(1.0 / (double)min_depth - 1.0 / (double)max_depth);
+  p.eps = eps; p.convention = convention;
+  return p;
+}
+
+int march_launch(MarchParams& p, int flags, hipStream_t st) {
+  const bool grad = flags & MAL_F_GRAD, automask = flags & MAL_F_AUTOMASK, pose = flags & MAL_F_POSE_GRAD,
+             epi = flags & MAL_F_EPILOGUE;
+  const int cw = grad ? 60 : 62;
+  p.strips = (p.W + cw - 1) / cw;
+  int rows = g_march_rows;
+  if (rows < 8) rows = 8;  // workspace is sized for 8-row segments
+  p.rows = rows;
+  p.segs = (p.H + rows - 1) / rows;
+  p.ntasks = p.B * p.strips * p.segs;
+  p.debug = g_debug;
+  p.packed = ((flags & MAL_F_SRC_PACKED) ? 1 : 0) | ((flags & MAL_F_TGT_PACKED) ? 2 : 0);
+  p.per_xcd = (p.ntasks + 7) / 8;
+  dim3 grid(p.per_xcd * 8), block(64);
+  hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
+  g_prof_start = g_prof_stop = nullptr;
+  if (ev0) (void)hipEventRecord(ev0, st);
+#define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((march_kernel<G, A, P, E>), grid, block, 0, st, p)
+  if (!grad) {
+    if (automask) { if (epi) MAL_LAUNCH(false, true, false, true); else MAL_LAUNCH(false, true, false, false); }
+    else          { if (epi) MAL_LAUNCH(false, false, false, true); else MAL_LAUNCH(false, false, false, false); }
+  } else if (pose) {
+    if (automask) { if (epi) MAL_LAUNCH(true, true, true, true); else MAL_LAUNCH(true, true, true, false); }
+    else          { if (epi) MAL_LAUNCH(true, false, true, true); else MAL_LAUNCH(true, false, true, false); }
+  } else {
+    if (automask) { if (epi) MAL_LAUNCH(true, true, false, true); else MAL_LAUNCH(true, true, false, false); }
+    else          { if (epi) MAL_LAUNCH(true, false, false, true); else MAL_LAUNCH(true, false, false, false); }
+  }
+#undef MAL_LAUNCH
+  if (ev1) (void)hipEventRecord(ev1, st);
+  return launch_status();
+}
+
+int identity_launch(const float* target_packed, const float* src0_packed, const float* src1_packed, int B, int H,
+                    int W, float* ident, hipStream_t st) {
+  IdentParams p;
+  p.target = target_packed; p.src[0] = src0_packed; p.src[1] = src1_packed; p.ident = ident;
+  p.B = B; p.H = H; p.W = W;
+  p.strips = (W + 61) / 62;
+  p.rows = 16;
+  p.segs = (H + p.rows - 1) / p.rows;
+  p.ntasks = B * p.strips * p.segs;
+  p.per_xcd = (p.ntasks + 7) / 8;
+  hipLaunchKernelGGL(identity_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
+  return launch_status();
+}
 
 }  // namespace mal
 
@@ -500,45 +624,15 @@ extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float
   Workspace w = carve(ws, B, H, W);
   if (ws_bytes < w.bytes) return MAL_EWORKSPACE;
 
-  MarchParams p;
+  MarchParams p = march_params(B, H, W, min_depth, max_depth, eps, convention);
   p.disp = disp; p.disp2 = disp2; p.sample_scale = sample_scale; p.K = K; p.invK = inv_K;
   p.T[0] = T[0]; p.T[1] = T[1]; p.src[0] = src[0]; p.src[1] = src[1];
   p.target = target; p.ident = ident; p.noise = noise; p.ext_mask = ext_mask; p.mono_depth = mono_depth;
-  p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj; p.B = B; p.H = H; p.W = W;
-  p.min_disp = (float)(1.0 / (double)max_depth);
-  p.range = (float)(1.0 / (double)min_depth - 1.0 / (double)max_depth);
-  p.eps = eps; p.convention = convention;
+  p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj;
   p.min_reproj = min_reproj; p.g_reproj = g_reproj; p.g_cons = g_cons; p.g_distil = g_distil;
   p.cons_target = consistency_target; p.depth_out = depth_out; p.block_sums = w.block_sums; p.block_gP = w.block_gP;
-  const int cw = grad ? 60 : 62;
-  p.strips = (W + cw - 1) / cw;
-  int rows = g_march_rows;
-  if (rows < 8) rows = 8;  // workspace is sized for 8-row segments
-  p.rows = rows;
-  p.segs = (H + rows - 1) / rows;
-  p.ntasks = B * p.strips * p.segs;
-  p.debug = g_debug;
-  p.packed = ((flags & MAL_F_SRC_PACKED) ? 1 : 0) | ((flags & MAL_F_TGT_PACKED) ? 2 : 0);
-  p.per_xcd = (p.ntasks + 7) / 8;
-  dim3 grid(p.per_xcd * 8), block(64);
   hipStream_t st = (hipStream_t)stream;
-  hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
-  g_prof_start = g_prof_stop = nullptr;
-  if (ev0) (void)hipEventRecord(ev0, st);
-#define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((march_kernel<G, A, P, E>), grid, block, 0, st, p)
-  if (!grad) {
-    if (automask) { if (epi) MAL_LAUNCH(false, true, false, true); else MAL_LAUNCH(false, true, false, false); }
-    else          { if (epi) MAL_LAUNCH(false, false, false, true); else MAL_LAUNCH(false, false, false, false); }
-  } else if (pose) {
-    if (automask) { if (epi) MAL_LAUNCH(true, true, true, true); else MAL_LAUNCH(true, true, true, false); }
-    else          { if (epi) MAL_LAUNCH(true, false, true, true); else MAL_LAUNCH(true, false, true, false); }
-  } else {
-    if (automask) { if (epi) MAL_LAUNCH(true, true, false, true); else MAL_LAUNCH(true, true, false, false); }
-    else          { if (epi) MAL_LAUNCH(true, false, false, true); else MAL_LAUNCH(true, false, false, false); }
-  }
-#undef MAL_LAUNCH
-  if (ev1) (void)hipEventRecord(ev1, st);
-  rc = launch_status();
+  rc = march_launch(p, flags, st);
   if (rc) return rc;
   return launch_pass_finalize(w.block_sums, w.block_gP, K, p.ntasks, p.strips * p.segs, B, sums,
                               pose ? g_T[0] : nullptr, pose ? g_T[1] : nullptr, st);

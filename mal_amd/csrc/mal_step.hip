@@ -1,0 +1,360 @@
+// mal_loss_step_fwd / _bwd: the whole loss half of process_batch (manydepth/trainer.py:573-642,
+// --distil) as ONE host call that enqueues a fixed list of kernels on the caller's stream.
+//
+// The reference issues ~500 ATen launches for this (3 warp passes, 10 SSIM evaluations, masks,
+// reductions, pose composition, and the same again in autograd's backward); the operator-level
+// API of this library still needs ~60 launches plus Python glue between them.  Here:
+//
+//   forward  1 pose_fwd (both frames)            layers.py:26-100
+//            1 pack3 (target, src-1, src+1 -> 16-byte texels)
+//            1 identity (min_f r(src_f, target)) loss_utils.py:92-101
+//            2 disparity means (both maps)       loss_utils.py:119
+//            1 teacher pass  (warp+SSIM+L1+min+automask, fwd+bwd to disp and poses)   :573-581
+//            1 ensemble pass ((disp_t+disp_s)/2 formed in the kernel, no grad)        :594-600
+//            1 student pass  (matching mask, consistency*(1-augmentation) mask, mono depth from
+//                             the teacher's disparity, consistency + distillation epilogue) :592-612
+//            2 smoothness (both maps) + 4 fixed-order reductions + 1 scalar epilogue
+//   backward 1 gradient assembly (both disparity maps) + 1 pose_bwd
+//
+// All intermediate maps live in the caller's workspace; loss scalars stay on the device.
+#include "mal_march.h"
+#include "mal_device.h"
+
+namespace mal {
+
+constexpr int kLossSlots = 16;
+
+struct StepWs {
+  float* packed[3];   // target, src-1, src+1 as (B,H,W,4)
+  float* T[2]; float* gT[2]; float* gTs[2];
+  float* ident; float* mono_reproj; float* ens_reproj; float* multi_reproj;
+  float* G_r_t; float* G_r_s; float* G_c; float* G_d; float* gn_t; float* gn_s;
+  double* sums_t; double* sums_s; double* sums_e;      // 8 each
+  double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
+  double* sm_plane; double* sm_part; double* sm_stats;  // smoothness: [2B*chunks], [2B*chunks][4], [4*2B]
+  float* coefs;       // 16 device scalars for the backward
+  int chunks;
+  size_t bytes;
+};
+
+static StepWs carve_step(void* base, int B, int H, int W) {
+  StepWs w;
+  char* p = (char*)base;
+  size_t o = 0;
+  const size_t HW = (size_t)H * W, map = align256(B * HW * sizeof(float)), nb = ws_blocks(B, H, W);
+  auto take = [&](size_t bytes) { char* r = p + o; o += align256(bytes); return r; };
+  for (int i = 0; i < 3; ++i) w.packed[i] = (float*)take(B * HW * 4 * sizeof(float));
+  for (int f = 0; f < 2; ++f) { w.T[f] = (float*)take(B * 16 * 4); w.gT[f] = (float*)take(B * 16 * 4); w.gTs[f] = (float*)take(B * 16 * 4); }
+  float** maps[] = {&w.ident, &w.mono_reproj, &w.ens_reproj, &w.multi_reproj, &w.G_r_t, &w.G_r_s, &w.G_c, &w.G_d,
+                    &w.gn_t, &w.gn_s};
+  for (auto m : maps) *m = (float*)take(map);
+  w.sums_t = (double*)take(8 * 8); w.sums_s = (double*)take(8 * 8); w.sums_e = (double*)take(8 * 8);
+  w.bs_t = (double*)take(nb * 8 * 8); w.bs_s = (double*)take(nb * 8 * 8); w.bs_e = (double*)take(nb * 8 * 8);
+  w.bgP = (float*)take(nb * 24 * 4);
+  int chunks = (int)((HW + 1023) / 1024);
+  if (chunks > 64) chunks = 64;
+  w.chunks = chunks;
+  w.sm_plane = (double*)take((size_t)2 * B * chunks * 8);
+  w.sm_part = (double*)take((size_t)2 * B * chunks * 4 * 8);
+  w.sm_stats = (double*)take((size_t)8 * B * 8);
+  w.coefs = (float*)take(16 * 4);
+  w.bytes = o;
+  return w;
+}
+
+// ---------------------------------------------------------------- small kernels
+__global__ void pack3_kernel(const float* a, const float* b, const float* c, int B, int HW, float4* da, float4* db,
+                             float4* dc) {
+  const float* src = blockIdx.y == 0 ? a : (blockIdx.y == 1 ? b : c);
+  float4* dst = blockIdx.y == 0 ? da : (blockIdx.y == 1 ? db : dc);
+  const size_t n = (size_t)B * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bb = i / HW, pix = i - bb * HW;
+    const float* s = src + bb * 3 * HW + pix;
+    dst[i] = make_float4(s[0], s[HW], s[2 * (size_t)HW], 0.f);
+  }
+}
+
+// sample s of the 2B "samples": the teacher's disparity maps first, then the student's
+MAL_DEV const float* disp_of(const float* dt, const float* ds, int s, int B, int HW) {
+  return s < B ? dt + (size_t)s * HW : ds + (size_t)(s - B) * HW;
+}
+
+__global__ __launch_bounds__(256) void step_plane_sum_kernel(const float* dt, const float* ds, int B, int HW, int chunks,
+                                                             double* partial) {
+  __shared__ double sh[4];
+  const int s = blockIdx.x / chunks, ck = blockIdx.x % chunks;
+  const float* d = disp_of(dt, ds, s, B, HW);
+  double acc = 0.0;
+  for (int i = ck * 256 + threadIdx.x; i < HW; i += chunks * 256) acc += (double)d[i];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// stage 1: stats[s] = mean of sample s.  stage 2: stats[2B+s] = corr_s = dot_s / (HW (mean+eps)^2);
+// block 2B: stats[4B + {0,1}] = smoothness loss of the teacher / student map
+__global__ __launch_bounds__(64) void step_smooth_mid_kernel(const double* plane, const double* part, int B, int H, int W,
+                                                             int chunks, int stage, double* stats) {
+  const int s = blockIdx.x, lane = threadIdx.x, HW = H * W;
+  if (stage == 1) {
+    double acc = 0.0;
+    for (int k = lane; k < chunks; k += 64) acc += plane[s * chunks + k];
+    acc = wave_sum_d(acc);
+    if (lane == 0) stats[s] = acc / (double)HW;
+    return;
+  }
+  if (s < 2 * B) {
+    double dot = 0.0;
+    for (int k = lane; k < chunks; k += 64) dot += part[(size_t)(s * chunks + k) * 4 + 2];
+    dot = wave_sum_d(dot);
+    if (lane == 0) {
+      const double m = (double)((float)stats[s] + 1e-7f);
+      stats[2 * B + s] = dot / ((double)HW * m * m);
+    }
+  } else {
+    for (int which = 0; which < 2; ++which) {
+      double sx = 0.0, sy = 0.0;
+      for (int i = lane; i < B * chunks; i += 64) {
+        sx += part[(size_t)(which * B * chunks + i) * 4];
+        sy += part[(size_t)(which * B * chunks + i) * 4 + 1];
+      }
+      sx = wave_sum_d(sx); sy = wave_sum_d(sy);
+      if (lane == 0) stats[4 * B + which] = sx / ((double)B * H * (W - 1)) + sy / ((double)B * (H - 1) * W);
+    }
+  }
+}
+
+// get_smooth_loss on disp/(mean+1e-7) for both maps (layers.py:210-223, loss_utils.py:119-121):
+// loss partials, d loss / d normalised-disp map, and the per-sample dot(gn, disp) of the mean coupling
+__global__ __launch_bounds__(256) void step_smooth_kernel(const float* dt, const float* ds, const float* img_packed,
+                                                          int B, int H, int W, int chunks, const double* stats,
+                                                          double* part, float* gn_t, float* gn_s) {
+  __shared__ double sh[4][3];
+  const int HW = H * W;
+  const int s = blockIdx.x / chunks, ck = blockIdx.x % chunks;
+  const int b = s < B ? s : s - B;
+  const float* d = disp_of(dt, ds, s, B, HW);
+  float* gn = (s < B ? gn_t : gn_s) + (size_t)b * HW;
+  const float4* im = reinterpret_cast<const float4*>(img_packed) + (size_t)b * HW;
+  const float inv = div_(1.0f, (float)stats[s] + 1e-7f);
+  const float nx = 1.0f / ((float)B * (float)H * (float)(W - 1));
+  const float ny = 1.0f / ((float)B * (float)(H - 1) * (float)W);
+  double ax = 0.0, ay = 0.0, adot = 0.0;
+  auto sg = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+  for (int pix = ck * 256 + threadIdx.x; pix < HW; pix += chunks * 256) {
+    const int gy = pix / W, gx = pix - gy * W;
+    const float dq = d[pix], nq = dq * inv;
+    const float4 cq = im[pix];
+    auto edge = [&](int other) {
+      const float4 co = im[other];
+      const float e = (fabsf(cq.x - co.x) + fabsf(cq.y - co.y)) + fabsf(cq.z - co.z);
+      return expf(-(e * (1.0f / 3.0f)));
+    };
+    float g = 0.f;
+    if (gx + 1 < W) {
+      const float w = edge(pix + 1), df = nq - d[pix + 1] * inv;
+      ax += (double)(fabsf(df) * w);
+      g += sg(df) * w * nx;
+    }
+    if (gx > 0) g -= sg(d[pix - 1] * inv - nq) * edge(pix - 1) * nx;
+    if (gy + 1 < H) {
+      const float w = edge(pix + W), df = nq - d[pix + W] * inv;
+      ay += (double)(fabsf(df) * w);
+      g += sg(df) * w * ny;
+    }
+    if (gy > 0) g -= sg(d[pix - W] * inv - nq) * edge(pix - W) * ny;
+    gn[pix] = g;
+    adot += (double)g * (double)dq;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  ax = wave_sum_d(ax); ay = wave_sum_d(ay); adot = wave_sum_d(adot);
+  if (lane == 0) { sh[wv][0] = ax; sh[wv][1] = ay; sh[wv][2] = adot; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int j = threadIdx.x;
+    part[(size_t)blockIdx.x * 4 + j] = (sh[0][j] + sh[1][j]) + (sh[2][j] + sh[3][j]);
+  }
+}
+
+// loss scalars (loss_utils.py:112-127,198-279; trainer.py:625-629) and the coefficients of the backward
+__global__ void step_scalars_kernel(const double* sums_t, const double* sums_s, const double* stats, int B, int HW,
+                                    float w_main, float w_distil, float* losses, float* coefs) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double N = (double)B * HW;
+  const double reproj_t = sums_t[0] / (sums_t[1] + 1e-7), reproj_s = sums_s[0] / (sums_s[1] + 1e-7);
+  const double cons = sums_s[2] / N, distil = sums_s[3] / N;
+  const double smooth_t = stats[4 * B], smooth_s = stats[4 * B + 1];
+  const float loss_t = (float)reproj_t + 1e-3f * (float)smooth_t;
+  const float loss_m = ((float)reproj_s + (float)cons) + 1e-3f * (float)smooth_s;
+  losses[0] = (float)reproj_t; losses[1] = (float)smooth_t; losses[2] = loss_t;
+  losses[3] = (float)reproj_s; losses[4] = (float)cons; losses[5] = (float)smooth_s; losses[6] = (float)distil;
+  losses[7] = loss_m;
+  losses[8] = w_main * (loss_m + loss_t) + w_distil * (float)distil;
+  losses[9] = (float)reproj_s + (float)reproj_t;            // "reproj_loss/0" after the mono losses are added in
+  losses[10] = (loss_m + (float)distil) + loss_t;           // "loss/0" / "loss" without loss balancing
+  losses[11] = loss_m + loss_t;                             // loss_list[0] with loss balancing
+  for (int i = 12; i < kLossSlots; ++i) losses[i] = 0.f;
+  coefs[0] = (float)((double)w_main / (sums_t[1] + 1e-7));  // teacher reprojection map
+  coefs[1] = (float)((double)w_main / (sums_s[1] + 1e-7));  // student reprojection map
+  coefs[2] = (float)((double)w_main / N);                   // consistency map
+  coefs[3] = (float)((double)w_distil / N);                 // distillation map
+  coefs[4] = w_main * 1e-3f;                                // smoothness
+}
+
+// d total / d disp for both maps, and the pose gradients scaled for pose_bwd
+__global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, const float* G_r_s, const float* G_c,
+                                                            const float* G_d, const float* gn_t, const float* gn_s,
+                                                            const float* coefs, const double* stats, const float* g_total,
+                                                            int B, int HW, const float* gT0, const float* gT1,
+                                                            float* gTs0, float* gTs1, float* g_disp_t, float* g_disp_s) {
+  const float g = g_total ? *g_total : 1.0f;
+  const float cRt = coefs[0] * g, cRs = coefs[1] * g, cC = coefs[2] * g, cD = coefs[3] * g, cS = coefs[4] * g;
+  const size_t n = (size_t)B * HW;
+  if (blockIdx.x == 0 && threadIdx.x < 32) {
+    for (int i = threadIdx.x; i < B * 16; i += 32) { gTs0[i] = gT0[i] * cRt; gTs1[i] = gT1[i] * cRt; }
+  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW);
+    const float inv_t = div_(1.0f, (float)stats[b] + 1e-7f), inv_s = div_(1.0f, (float)stats[B + b] + 1e-7f);
+    const float corr_t = (float)stats[2 * B + b], corr_s = (float)stats[3 * B + b];
+    if (g_disp_t) g_disp_t[i] = fma_(cRt, G_r_t[i], cS * (gn_t[i] * inv_t - corr_t));
+    if (g_disp_s) g_disp_s[i] = fma_(cRs, G_r_s[i], fma_(cC, G_c[i], fma_(cD, G_d[i], cS * (gn_s[i] * inv_s - corr_s))));
+  }
+}
+
+}  // namespace mal
+
+using namespace mal;
+
+extern "C" size_t mal_step_workspace_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return carve_step(nullptr, B, H, W).bytes;
+}
+
+extern "C" int mal_pose_fwd(const float* const*, const float* const*, const int*, int, int, float* const*, void*);
+extern "C" int mal_pose_bwd(const float* const*, const float* const*, const int*, const float* const*, int, int,
+                            float* const*, float* const*, void*);
+
+static int step_check(const mal_step_args* a) {
+  if (!a) return MAL_EINVAL;
+  int rc = check_shape(a->B, a->H, a->W);
+  if (rc) return rc;
+  if (!a->color0 || !a->color_m1 || !a->color_p1 || !a->K || !a->inv_K || !a->disp_teacher || !a->disp_student ||
+      !a->axisangle_m1 || !a->translation_m1 || !a->axisangle_p1 || !a->translation_p1 || !a->consistency_mask ||
+      !a->augmentation_keep || !a->lowest_cost || !a->losses || !a->ws)
+    return MAL_EINVAL;
+  if (a->ws_bytes < carve_step(nullptr, a->B, a->H, a->W).bytes) return MAL_EWORKSPACE;
+  return MAL_OK;
+}
+
+extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
+  int rc = step_check(a);
+  if (rc) return rc;
+  const int B = a->B, H = a->H, W = a->W, HW = H * W;
+  StepWs w = carve_step(a->ws, B, H, W);
+  hipStream_t st = (hipStream_t)a->stream;
+  const bool no_ens = a->flags & MAL_STEP_NO_ENS;
+  float* mono_reproj = a->mono_reproj ? a->mono_reproj : w.mono_reproj;
+  float* ens_reproj = no_ens ? nullptr : (a->ens_reproj ? a->ens_reproj : w.ens_reproj);
+  float* multi_reproj = a->multi_reproj ? a->multi_reproj : w.multi_reproj;
+
+  // 1. poses (frame -1 is inverted, networks/repdepth.py:159-160)
+  {
+    const float* aa[2] = {a->axisangle_m1, a->axisangle_p1};
+    const float* tr[2] = {a->translation_m1, a->translation_p1};
+    const int inv[2] = {1, 0};
+    float* T[2] = {w.T[0], w.T[1]};
+    rc = mal_pose_fwd(aa, tr, inv, B, 2, T, a->stream);
+    if (rc) return rc;
+  }
+  // 2. texel packing of the three images
+  {
+    size_t g = ((size_t)B * HW + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(pack3_kernel, dim3((unsigned)g, 3), dim3(256), 0, st, a->color0, a->color_m1, a->color_p1, B, HW,
+                       (float4*)w.packed[0], (float4*)w.packed[1], (float4*)w.packed[2]);
+  }
+  // 3. identity term
+  rc = identity_launch(w.packed[0], w.packed[1], w.packed[2], B, H, W, w.ident, st);
+  if (rc) return rc;
+  // 4. disparity means of both maps
+  hipLaunchKernelGGL(step_plane_sum_kernel, dim3(2 * B * w.chunks), dim3(256), 0, st, a->disp_teacher, a->disp_student,
+                     B, HW, w.chunks, w.sm_plane);
+  hipLaunchKernelGGL(step_smooth_mid_kernel, dim3(2 * B), dim3(64), 0, st, w.sm_plane, w.sm_part, B, H, W, w.chunks, 1,
+                     w.sm_stats);
+  rc = launch_status();
+  if (rc) return rc;
+  const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
+  // 5. teacher pass
+  {
+    MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
+    p.disp = a->disp_teacher; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+    p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+    p.ident = w.ident; p.noise = a->noise; p.min_reproj = mono_reproj; p.g_reproj = w.G_r_t;
+    p.block_sums = w.bs_t; p.block_gP = w.bgP;
+    rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
+    if (rc) return rc;
+    rc = launch_pass_finalize(w.bs_t, w.bgP, a->K, p.ntasks, p.strips * p.segs, B, w.sums_t, w.gT[0], w.gT[1], st);
+    if (rc) return rc;
+  }
+  // 6. ensemble pass (no gradient)
+  if (!no_ens) {
+    MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
+    p.disp = a->disp_teacher; p.disp2 = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+    p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+    p.min_reproj = ens_reproj; p.block_sums = w.bs_e; p.block_gP = w.bgP;
+    rc = march_launch(p, packed, st);
+    if (rc) return rc;
+  }
+  // 7. student pass with the consistency / distillation epilogue
+  {
+    MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
+    p.disp = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+    p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+    p.ext_mask = a->consistency_mask; p.sample_scale = a->augmentation_keep;
+    p.mono_disp = a->disp_teacher; p.lowest_cost = a->lowest_cost; p.cmask_out = a->consistency_mask_out;
+    p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj;
+    p.min_reproj = multi_reproj; p.g_reproj = w.G_r_s; p.g_cons = w.G_c; p.g_distil = w.G_d;
+    p.block_sums = w.bs_s; p.block_gP = w.bgP;
+    rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
+    if (rc) return rc;
+    rc = launch_pass_finalize(w.bs_s, w.bgP, a->K, p.ntasks, p.strips * p.segs, B, w.sums_s, nullptr, nullptr, st);
+    if (rc) return rc;
+  }
+  // 8. smoothness of both maps
+  hipLaunchKernelGGL(step_smooth_kernel, dim3(2 * B * w.chunks), dim3(256), 0, st, a->disp_teacher, a->disp_student,
+                     w.packed[0], B, H, W, w.chunks, w.sm_stats, w.sm_part, w.gn_t, w.gn_s);
+  hipLaunchKernelGGL(step_smooth_mid_kernel, dim3(2 * B + 1), dim3(64), 0, st, w.sm_plane, w.sm_part, B, H, W, w.chunks,
+                     2, w.sm_stats);
+  // 9. scalars
+  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, st, w.sums_t, w.sums_s, w.sm_stats, B, HW, a->w_main,
+                     a->w_distil, a->losses, w.coefs);
+  return launch_status();
+}
+
+extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
+  int rc = step_check(a);
+  if (rc) return rc;
+  const int B = a->B, H = a->H, W = a->W, HW = H * W;
+  StepWs w = carve_step(a->ws, B, H, W);
+  hipStream_t st = (hipStream_t)a->stream;
+  size_t g = ((size_t)B * HW + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.G_d, w.gn_t,
+                     w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
+                     a->g_disp_teacher, a->g_disp_student);
+  rc = launch_status();
+  if (rc) return rc;
+  if (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) {
+    const float* aa[2] = {a->axisangle_m1, a->axisangle_p1};
+    const float* tr[2] = {a->translation_m1, a->translation_p1};
+    const int inv[2] = {1, 0};
+    const float* gT[2] = {w.gTs[0], w.gTs[1]};
+    float* gaa[2] = {a->g_axisangle_m1, a->g_axisangle_p1};
+    float* gtr[2] = {a->g_translation_m1, a->g_translation_p1};
+    rc = mal_pose_bwd(aa, tr, inv, gT, B, 2, gaa, gtr, a->stream);
+  }
+  return rc;
+}

@@ -1,0 +1,141 @@
+"""The whole loss half of ``Trainer.process_batch`` (manydepth/trainer.py:573-642, ``--distil``)
+as one C call forward (``mal_loss_step_fwd``, ~18 kernels) and one backward
+(``mal_loss_step_bwd``, 2 kernels): no Python between the kernels, no per-op autograd nodes.
+
+``loss_step(...)`` returns the same ``losses`` dict keys as the reference's ``process_batch``
+(views of one 16-float device vector, so reading them launches nothing) plus the per-pixel maps.
+The operator-level API (``mal_amd.loss_utils`` / ``MALLossPath``) computes the same thing op by
+op; ``tests/test_gpu_step.py`` holds the two against each other and against the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+from . import ops
+
+_WS = {}
+
+
+def _workspace(dev, B, H, W):
+    need = L.load().mal_step_workspace_bytes(B, H, W)
+    key = (dev.index, ops._stream(), B, H, W)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _WS[key] = ws
+    return ws
+
+
+class LossStepFn(Function):
+    """leaves: disp_teacher, disp_student, axisangle_m1, translation_m1, axisangle_p1, translation_p1."""
+
+    @staticmethod
+    def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg):
+        color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise = consts
+        min_depth, max_depth, no_ens, w_main, w_distil, want_maps = cfg
+        req = ops._req
+        tens = [req(t, n) for t, n in ((disp_t, "disp_teacher"), (disp_s, "disp_student"), (aa_m1, "axisangle"),
+                                       (tr_m1, "translation"), (aa_p1, "axisangle"), (tr_p1, "translation"))]
+        cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise)]
+        B, _, H, W = tens[0].shape
+        dev = tens[0].device
+        a = L.StepArgs()
+        a.B, a.H, a.W = B, H, W
+        a.min_depth, a.max_depth = float(min_depth), float(max_depth)
+        a.flags = L.STEP_NO_ENS if no_ens else 0
+        a.w_main, a.w_distil = float(w_main), float(w_distil)
+        p = ops._p
+        a.disp_teacher, a.disp_student = p(tens[0]), p(tens[1])
+        a.axisangle_m1, a.translation_m1, a.axisangle_p1, a.translation_p1 = (p(t) for t in tens[2:])
+        (a.color0, a.color_m1, a.color_p1, a.K, a.inv_K, a.consistency_mask, a.augmentation_keep, a.lowest_cost,
+         a.noise) = (p(t) for t in cons)
+        losses = torch.empty(16, dtype=torch.float32, device=dev)
+        a.losses = p(losses)
+        maps = {}
+        if want_maps:
+            new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            maps = dict(mono_reproj=new((B, 1, H, W)), multi_reproj=new((B, 1, H, W)),
+                        consistency_mask=new((B, H, W)))
+            if not no_ens:
+                maps["ens_reproj"] = new((B, 1, H, W))
+            a.mono_reproj, a.multi_reproj = p(maps["mono_reproj"]), p(maps["multi_reproj"])
+            a.consistency_mask_out = p(maps["consistency_mask"])
+            a.ens_reproj = p(maps.get("ens_reproj"))
+        ws = _workspace(dev, B, H, W)
+        a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
+        L.check(L.load().mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
+        ctx.args = a
+        ctx.keep = (tens, cons, ws, losses)  # the C struct holds raw pointers: keep the tensors alive
+        ctx.set_materialize_grads(False)
+        outs = [losses] + [maps[k] for k in ("mono_reproj", "multi_reproj", "consistency_mask", "ens_reproj")
+                           if k in maps]
+        ctx.mark_non_differentiable(*outs[1:])
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_losses, *_):
+        tens = ctx.keep[0]
+        if g_losses is None:
+            return (None,) * 8
+        # only slot 8 ("total") is differentiable through this node: the other slots are its terms
+        g_total = g_losses[8:9].contiguous()
+        a = ctx.args
+        grads = [torch.empty_like(t) if ctx.needs_input_grad[i] else None for i, t in enumerate(tens)]
+        a.g_total = ops._p(g_total)
+        (a.g_disp_teacher, a.g_disp_student, a.g_axisangle_m1, a.g_translation_m1, a.g_axisangle_p1,
+         a.g_translation_p1) = (ops._p(g) for g in grads)
+        L.check(L.load().mal_loss_step_bwd(C.byref(a)), "mal_loss_step_bwd")
+        return (*grads, None, None)
+
+
+def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=None, noise=None, want_maps=True):
+    """process_batch's loss half in one call.  Reads the same dict entries as the reference:
+    ``inputs[("color", f, 0)]``, ``("K", 0)``, ``("inv_K", 0)``; ``mono_outputs[("disp", 0)]``,
+    ``("axisangle", 0, f)`` / ``("translation", 0, f)`` (networks/repdepth.py:155-156);
+    ``outputs[("disp", 0)]``, ``"consistency_mask"``, ``"augmentation_mask"``, ``"lowest_cost"``.
+    Writes ``outputs["consistency_mask"]`` (x matching mask, trainer.py:592-593) when ``want_maps``.
+    Returns (losses dict, loss_list or None, maps dict)."""
+    from . import config, loss_utils
+    if getattr(opt, "temporal", False) or getattr(opt, "main_temporal", False) or getattr(opt, "dual_distil", False) \
+            or getattr(opt, "learn_ens", False) or getattr(opt, "no_ssim", False) or not getattr(opt, "distil", True) \
+            or getattr(opt, "sclm", 0) != 0:
+        raise L.MalError("loss_step covers the --distil single-scale configuration; use MALLossPath."
+                         "compute_batch_losses for temporal / dual_distil / learn_ens / no_ssim / non-distil runs")
+    color0 = inputs[("color", 0, 0)]
+    B, _, H, W = color0.shape
+    dev = color0.device
+    aa = {f: mono_outputs[("axisangle", 0, f)] for f in (-1, 1)}
+    tr = {f: mono_outputs[("translation", 0, f)] for f in (-1, 1)}
+    fix = lambda t: t[:, 0] if t.dim() == 4 else t  # the pose decoder emits (B,2,1,3); frame 0 of it is used
+    if noise is None and not getattr(opt, "disable_automasking", False):
+        noise = loss_utils.draw_noise((B, 1, H, W), dev)
+        if config.noise_source == "cpu":
+            torch.randn((B, 1, H, W))  # compute_main_losses' dead draw (loss_utils.py:178)
+    keep = (1 - outputs["augmentation_mask"][:opt.batch_size]).to(torch.float32).reshape(B)
+    blc = bool(getattr(opt, "loss_blc", False))
+    w_main, w_distil = 1.0, 1.0
+    if blc:
+        scale = float(batch_size_scale if batch_size_scale is not None else opt.batch_size)
+        w_main, w_distil = scale * float(w_list[0]), scale * float(w_list[1])
+    consts = (color0, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)],
+              outputs["consistency_mask"].to(torch.float32), keep, outputs["lowest_cost"], noise)
+    cfg = (opt.min_depth, opt.max_depth, bool(getattr(opt, "no_ens", False)), w_main, w_distil, bool(want_maps))
+    res = LossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
+                           fix(tr[1]), consts, cfg)
+    v = res[0]
+    maps = {}
+    if want_maps:
+        names = ["mono_reproj", "multi_reproj", "consistency_mask"] + ([] if cfg[2] else ["ens_reproj"])
+        maps = dict(zip(names, res[1:]))
+        outputs["consistency_mask"] = maps["consistency_mask"]
+    losses = {"reproj_loss/0": v[9], "consistency_loss/0": v[4], "distil_loss": v[6], "loss/0": v[11] if blc else v[10],
+              "loss": v[8], "mono/reproj_loss/0": v[0], "mono/loss": v[2], "smooth_loss/mono": v[1],
+              "smooth_loss/multi": v[5], "main/reproj_loss/0": v[3]}
+    loss_list = [v[11], v[6]] if blc else None
+    return losses, loss_list, maps

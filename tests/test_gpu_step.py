@@ -1,0 +1,105 @@
+"""GPU parity of the whole-step entry point (mal_loss_step_fwd/_bwd through mal_amd.step.loss_step)
+against the CPU oracle and against the operator-level route of the same library."""
+import numpy as np
+import pytest
+import torch
+
+from mal_amd.synthetic import to_dicts
+from tests import golden_io as G
+from tests import hip_harness as HH
+
+pytestmark = pytest.mark.gpu
+CASES = ["step_b2_32x64_distil", "step_b2_32x64_noens", "step_b2_32x64_lossblc", "step_b3_37x50_distil"]
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    from mal_amd import build
+    build.build(verbose=False)
+
+
+def _l2rel(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+def run_step(batch, opt_kw, n0, w_list=(0.7, 0.3), device="cuda:0"):
+    from mal_amd import step, trainer
+    B, _, H, W = batch["color0"].shape
+    dev = torch.device(device)
+    opt = trainer.default_options(height=H, width=W, batch_size=B, **opt_kw)
+    inputs, mono_outputs, outputs, leaves = to_dicts(batch, lambda a, t, inv: None, device=dev)
+    for f, s in ((-1, "m1"), (1, "p1")):
+        mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + s]
+        mono_outputs[("translation", 0, f)] = leaves["translation_" + s]
+    losses, loss_list, maps = step.loss_step(opt, inputs, mono_outputs, outputs, w_list=list(w_list), noise=n0.to(dev))
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    return dict(losses={k: float(v.detach()) for k, v in losses.items()}, maps={k: v.cpu().numpy() for k, v in maps.items()},
+                loss_list=None if loss_list is None else [float(l.detach()) for l in loss_list],
+                grads={k: (t.grad if t.grad is not None else torch.zeros_like(t)).cpu().numpy() for k, t in leaves.items()})
+
+
+@pytest.mark.parametrize("tag", CASES + [G.BIG_CASE])
+def test_loss_step_against_oracle(tag):
+    z = G.load(tag)
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    n0, n1 = G.noises(z, (B, 1, H, W))
+    kw = G.opt_kwargs(z)
+    o = HH.run_oracle(b, kw, n0, n1)
+    h = run_step(b, kw, n0)
+    N = B * H * W
+    amb_distil = HH.near_tie(np.concatenate([m for m in (o["mono_reproj"], o["ens"], o["multi_cands"].min(1, keepdims=True))
+                                             if m is not None], 1), 2e-4)
+    allow = float((np.abs(o["mono_depth"] - o["multi_depth"]) * amb_distil).sum() / N)
+    pairs = [("reproj_loss/0", o["losses"]["reproj_loss/0"]), ("consistency_loss/0", o["losses"]["consistency_loss/0"]),
+             ("distil_loss", o["losses"]["distil_loss"]), ("mono/loss", o["mono_losses"]["loss"]),
+             ("mono/reproj_loss/0", o["mono_losses"]["reproj_loss/0"])]
+    for k, v in pairs:
+        tol = 1e-4 * abs(v) + (allow if "distil" in k else 0.0)
+        assert abs(h["losses"][k] - v) <= tol, (k, h["losses"][k], v)
+    scale = B if kw.get("loss_blc") else 1
+    assert abs(h["losses"]["loss"] - o["final"]) <= 1e-4 * abs(o["final"]) + scale * allow, (h["losses"]["loss"], o["final"])
+    if kw.get("loss_blc"):
+        assert abs(h["loss_list"][0] - o["loss_list"][0]) <= 1e-4 * abs(o["loss_list"][0])
+    assert np.abs(h["maps"]["mono_reproj"] - o["mono_reproj"]).max() <= 1e-4
+    if o["ens"] is not None:
+        assert np.abs(h["maps"]["ens_reproj"] - o["ens"]).max() <= 1e-4
+    assert (h["maps"]["consistency_mask"] != o["consistency_mask"]).mean() <= 1e-5
+    # gradients: per-pixel maps off the near-tie pixels, summed (pose) gradients against the fp64 floor
+    idn = o["ident"] + n0.numpy() * np.float32(1e-5)
+    amb_t = HH.dilate3(HH.near_tie(o["mono_cands"], 2e-4) | (np.abs(o["mono_reproj"] - idn) <= 1e-4))
+    amb_t |= HH.sample_ambiguous(o["mono_sample"], H, W)
+    amb_s = HH.dilate3(HH.near_tie(o["multi_cands"], 2e-4)) | HH.sample_ambiguous(o["multi_sample"], H, W) | amb_distil
+    amb_s |= np.abs(o["mono_depth"] - o["multi_depth"]) <= 1e-6 * np.abs(o["mono_depth"])
+    o64 = HH.oracle_fp64_grads(b, kw, n0, n1)
+    for key in HH.LEAVES:
+        g, r, r64 = h["grads"][key], o["grads"][key], o64[key]
+        if key.startswith("disp"):
+            keep = ~(amb_t if key == "disp_teacher" else amb_s)
+            err = np.abs(g - r)[keep]
+            assert (err > 2e-4 * np.abs(r).max()).mean() <= 2e-5, (key, err.max() / np.abs(r).max())
+            g, r, r64 = g[keep], r[keep], r64[keep]
+        floor = _l2rel(r, r64)
+        assert _l2rel(g, r) <= max(1e-4, 1.5 * floor), (key, _l2rel(g, r), floor)
+
+
+def test_loss_step_equals_operator_route():
+    """one C call vs ~60 operator launches: same kernels underneath, same numbers."""
+    z = G.load("step_b3_37x50_distil")
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    n0, n1 = G.noises(z, (B, 1, H, W))
+    a = run_step(b, {}, n0)
+    c = HH.run_hip(b, {}, n0, n1, fuse=True)
+    assert abs(a["losses"]["loss"] - c["final"]) <= 2e-6 * abs(c["final"])
+    for k in HH.LEAVES:
+        ga, gc = a["grads"][k], c["grads"][k]
+        assert np.abs(ga - gc).max() <= 2e-5 * np.abs(gc).max(), k
+
+
+def test_loss_step_rejects_unsupported_options():
+    from mal_amd import step, trainer, _lib
+    opt = trainer.default_options(temporal=True)
+    with pytest.raises(_lib.MalError):
+        step.loss_step(opt, {("color", 0, 0): torch.zeros(1, 3, 4, 4, device="cuda")}, {}, {})
