@@ -254,7 +254,7 @@ int mal_loss_step_bwd(const mal_step_args* args);
 
 /* ---- library options: "pass_impl" selects the fused-pass formulation: 2 = LDS-tiled, 512 threads x
  * 2 px (default); 1 = register-marching; 0 = LDS-tiled first version (both kept for A/B);
- * "march_rows" = output rows per wavefront task of the marching kernel (default 16). */
+ * "march_rows" = output rows per wavefront task of the marching kernel (0 = automatic, default). */
 int mal_set_option(const char* name, int value);
 
 /* ---- measurement hooks (bench.py): HIP events recorded immediately before / after the main

@@ -193,16 +193,35 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
 
   // rows r = y_lo-HALO .. y_hi-1+HALO are warped (reflected when outside the image; row -2 is never
   // needed); the statistics row is c = r-1, the gradient row q = r-2
+  // what the gradient row (two iterations behind the warped row) needs of its pixel -- the warped
+  // values, the target and the chain-rule numbers -- waits in a 3-slot per-lane LDS ring (no bank
+  // conflicts: lane-private dwords; no barrier: one wavefront) instead of ~50 registers or a re-warp
+  constexpr int RING = GRAD ? (POSE ? 21 : 15) : 1;
+  __shared__ float s_ring[GRAD ? 3 : 1][RING][64];
+  int it = 0;
   const int r_first = max(y_lo - HALO, -1), r_last = y_hi - 1 + HALO;
-  for (int r = r_first; r <= r_last; ++r) {
+  for (int r = r_first; r <= r_last; ++r, ++it) {
     // ================= stage W: warp row r (reflected if outside the image) ==================
     const int gyr = min(max(reflect1(r, H), 0), H - 1);
     WarpRow w0;
     {
       float dv_ = disp_b[gyr * W + gxr];
       if (disp2_b) dv_ = (dv_ + disp2_b[gyr * W + gxr]) / 2.0f;
-      DerivRow unused;
-      warp_px<false, false>(p, P, ik, b, gyr, gxr, dv_, w0, unused);
+      DerivRow d0;
+      warp_px<GRAD, POSE>(p, P, ik, b, gyr, gxr, dv_, w0, d0);
+      if (GRAD) {
+        float (*slot)[64] = s_ring[it % 3];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            slot[f * 3 + ch][lane] = w0.x[f][ch];
+            if (POSE) { slot[9 + f * 3 + ch][lane] = d0.du[f][ch]; slot[15 + f * 3 + ch][lane] = d0.dv[f][ch]; }
+            else slot[9 + f * 3 + ch][lane] = d0.e[f][ch];
+          }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) slot[6 + ch][lane] = w0.y[ch];
+      }
     }
 
     // ================= stage H: horizontal 3-sums of row r ====================================
@@ -312,11 +331,39 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
       // ================= stage G: output row q = c-1 = r-2 ======================================
       const int q = r - 2;
       if (q >= y_lo && q < y_hi) {  // wave-uniform; q is always inside the image
-        // re-warp the pixel with its chain-rule data (taps are cache-hot; costs less than carrying
-        // ~50 registers per lane across two rows: carrying them spills at 256 VGPRs)
         WarpRow wq;
         DerivRow dq;
-        warp_px<true, POSE>(p, P, ik, b, q, gxr, disp_b[q * W + gxr], wq, dq);
+        {
+          float (*slot)[64] = s_ring[(it + 1) % 3];  // written two iterations ago
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+              wq.x[f][ch] = slot[f * 3 + ch][lane];
+              if (POSE) { dq.du[f][ch] = slot[9 + f * 3 + ch][lane]; dq.dv[f][ch] = slot[15 + f * 3 + ch][lane]; }
+              else dq.e[f][ch] = slot[9 + f * 3 + ch][lane];
+            }
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) wq.y[ch] = slot[6 + ch][lane];
+        }
+        float alq[2] = {0.f, 0.f}, beq[2] = {0.f, 0.f};
+        if (POSE) {  // the projection of row q re-derived from its disparity (no gathers)
+          const float depth = depth_of(disp_b[q * W + gxr], p.min_disp, p.range);
+          const float ddepth = -(depth * depth) * p.range;
+          float ray[3];
+          ray_of(ik, (float)gxr, (float)q, ray);
+          dq.X[0] = depth * ray[0]; dq.X[1] = depth * ray[1]; dq.X[2] = depth * ray[2];
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const Sample sm = project_pixel(P[f], dq.X, p.eps, W, H, p.convention);
+            dq.rz[f] = sm.rz; dq.u[f] = sm.u; dq.v[f] = sm.v;
+            const float c0 = P[f][0] * ray[0] + P[f][1] * ray[1] + P[f][2] * ray[2];
+            const float c1 = P[f][4] * ray[0] + P[f][5] * ray[1] + P[f][6] * ray[2];
+            const float c2 = P[f][8] * ray[0] + P[f][9] * ray[1] + P[f][10] * ray[2];
+            alq[f] = (c0 - sm.u * c2) * sm.rz * ddepth;  // d u / d disp (the clip gate is inside du, dv)
+            beq[f] = (c1 - sm.v * c2) * sm.rz * ddepth;
+          }
+        }
         const float wyd = (q == H - 2) ? 2.0f : 1.0f;  // row q+1 = c is the bottom border row
         float gdisp = 0.f, gu[2] = {0.f, 0.f}, gv[2] = {0.f, 0.f};
 #pragma unroll
@@ -332,9 +379,10 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
               const float df = xq - yq;
               g += pi1.w * (0.15f / 3.0f) * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
             }
-            gdisp = fma_(g, dq.e[f][ch], gdisp);
             if (POSE) { gu[f] = fma_(g, dq.du[f][ch], gu[f]); gv[f] = fma_(g, dq.dv[f][ch], gv[f]); }
+            else gdisp = fma_(g, dq.e[f][ch], gdisp);
           }
+        if (POSE) gdisp = (gu[0] * alq[0] + gv[0] * beq[0]) + (gu[1] * alq[1] + gv[1] * beq[1]);
         const size_t gi = map_b + (size_t)q * W + gxr;
         if (out_x) p.g_reproj[gi] = gdisp;
         if (POSE && out_x) {
@@ -499,7 +547,7 @@ __global__ __launch_bounds__(64, 4) void identity_kernel(IdentParams p) {
 }
 
 int g_pass_impl = 1;   // 1 = marching (this file, fastest); 0 = LDS-tiled v1 (mal_pass.hip); 2 = LDS-tiled, 512 threads (mal_tile2.hip)
-int g_march_rows = 16; // output rows per wave task
+int g_march_rows = 0;  // output rows per wave task; 0 = pick so that one round of tasks fills the chip
 int g_debug = 0;
 
 MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, float eps, int convention) {
@@ -517,6 +565,20 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   const int cw = grad ? 60 : 62;
   p.strips = (p.W + cw - 1) / cw;
   int rows = g_march_rows;
+  if (rows <= 0) {
+    // Every task is one wavefront that lives for (rows + 2*halo) iterations and the kernel runs at two
+    // waves per SIMD (<= 256 VGPRs): the shortest makespan is the smallest `rows` whose task count still
+    // fits in ONE resident round (CUs x 4 SIMDs x 2).  Measured on MI355X at B=12 192x640: rows 13
+    // (1980 tasks <= 2048) 124 us vs rows 16 135 us vs rows 12 (2112 tasks, two rounds) 164 us.
+    static int slots = 0;
+    if (slots == 0) {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      slots = cus * 8;
+    }
+    rows = 8;
+    while (rows < p.H && (long long)p.B * p.strips * ((p.H + rows - 1) / rows) > slots) ++rows;
+  }
   if (rows < 8) rows = 8;  // workspace is sized for 8-row segments
   p.rows = rows;
   p.segs = (p.H + rows - 1) / rows;
@@ -550,7 +612,7 @@ int identity_launch(const float* target_packed, const float* src0_packed, const 
   p.target = target_packed; p.src[0] = src0_packed; p.src[1] = src1_packed; p.ident = ident;
   p.B = B; p.H = H; p.W = W;
   p.strips = (W + 61) / 62;
-  p.rows = 16;
+  p.rows = 12;  // 4 waves per SIMD fit (launch bounds): 16 segments x 11 strips x 12 samples = 2112 <= 4096
   p.segs = (H + p.rows - 1) / p.rows;
   p.ntasks = B * p.strips * p.segs;
   p.per_xcd = (p.ntasks + 7) / 8;
@@ -567,7 +629,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   auto eq = [&](const char* s) { const char* a = name; while (*a && *a == *s) { ++a; ++s; } return *a == *s; };
   if (eq("pass_impl")) { if (value < 0 || value > 2) return MAL_EINVAL; g_pass_impl = value; return MAL_OK; }
   if (eq("debug")) { g_debug = value; return MAL_OK; }
-  if (eq("march_rows")) { if (value < 4 || value > 4096) return MAL_EINVAL; g_march_rows = value; return MAL_OK; }
+  if (eq("march_rows")) { if (value < 0 || value > 4096) return MAL_EINVAL; g_march_rows = value; return MAL_OK; }
   return MAL_EINVAL;
 }
 
