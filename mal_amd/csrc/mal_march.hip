@@ -201,6 +201,24 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
   int it = 0;
   const int r_first = max(y_lo - HALO, -1), r_last = y_hi - 1 + HALO;
   for (int r = r_first; r <= r_last; ++r, ++it) {
+    // ---- the small per-pixel operands of this iteration's later stages are requested first, so their
+    // latency overlaps the warp (loads sitting behind a wave-uniform branch are not hoisted by the compiler)
+    const size_t gic = map_b + (size_t)min(max(r - 1, 0), H - 1) * W + gxr;  // statistics row c = r-1
+    float ld_ident = 0.f, ld_noise = 0.f, ld_ext = 1.f, ld_mono = 0.f, ld_cost = 1.f;
+    if (AUTOMASK) { ld_ident = p.ident[gic]; if (p.noise) ld_noise = p.noise[gic]; }
+    if (p.ext_mask) {
+      ld_ext = p.ext_mask[gic];
+      if (p.lowest_cost) { ld_mono = p.mono_disp[gic]; ld_cost = p.lowest_cost[gic]; }
+    }
+    const int qe = GRAD ? r - 2 : r - 1;                                     // epilogue row
+    const size_t giq = map_b + (size_t)min(max(qe, 0), H - 1) * W + gxr;
+    float le_disp = 0.f, le_mono = 0.f, le_mr = 0.f, le_er = 0.f;
+    if (EPI) {
+      le_disp = disp_b[giq - map_b];
+      le_mono = p.mono_disp ? p.mono_disp[giq] : p.mono_depth[giq];
+      le_mr = p.mono_reproj[giq];
+      if (p.ens_reproj) le_er = p.ens_reproj[giq];
+    }
     // ================= stage W: warp row r (reflected if outside the image) ==================
     const int gyr = min(max(reflect1(r, H), 0), H - 1);
     WarpRow w0;
@@ -272,15 +290,15 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
       float w = 1.0f;
       const size_t gi = map_b + (size_t)c * W + gxr;
       if (AUTOMASK) {
-        float idn = p.ident[gi];
-        if (p.noise) idn += p.noise[gi] * 0.00001f;
+        float idn = ld_ident;
+        if (p.noise) idn += ld_noise * 0.00001f;
         w = (pi0.rp <= idn) ? 1.0f : 0.0f;
       }
       if (p.ext_mask) {
-        float em = p.ext_mask[gi];
+        float em = ld_ext;
         if (p.lowest_cost) {  // consistency_mask *= compute_matching_mask (trainer.py:592-593,1066-1076)
-          const float mono = depth_of(p.mono_disp[gi], p.min_disp, p.range);
-          const float matching = div_safe_(1.0f, p.lowest_cost[gi]);
+          const float mono = depth_of(ld_mono, p.min_disp, p.range);
+          const float matching = div_safe_(1.0f, ld_cost);
           const bool ok = (div_safe_(matching - mono, mono) < 1.0f) && (div_safe_(mono - matching, matching) < 1.0f);
           em = ok ? em : em * 0.0f;
           if (p.cmask_out && out_x && c >= y_lo && c < y_hi) p.cmask_out[gi] = em;
@@ -417,16 +435,16 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
       const PixInfo& pq = GRAD ? pi1 : pi0;
       if (q >= y_lo && q < y_hi && out_x) {
         const size_t gi = map_b + (size_t)q * W + gxr;
-        const float dm = depth_of(disp_b[q * W + gxr], p.min_disp, p.range);
+        const float dm = depth_of(le_disp, p.min_disp, p.range);
         const float ddepth = -(dm * dm) * p.range;
-        const float dmono = p.mono_disp ? depth_of(p.mono_disp[gi], p.min_disp, p.range) : p.mono_depth[gi];
+        const float dmono = p.mono_disp ? depth_of(le_mono, p.min_disp, p.range) : le_mono;
         const float m = pq.w, cm = 1.0f - m, mm = 1.0f - cm;
         const float dc = dm - dmono;
         acc_cons += (double)(fabsf(dc) * cm);
         int idx = 0;
-        float best = p.mono_reproj[gi];
+        float best = le_mr;
         if (p.ens_reproj) {
-          const float r_ens = p.ens_reproj[gi];
+          const float r_ens = le_er;
           if (r_ens < best) { best = r_ens; idx = 1; }
         }
         if (pq.rp < best) idx = 2;
