@@ -5,7 +5,7 @@ as one C call forward (``mal_loss_step_fwd``, ~18 kernels) and one backward
 ``loss_step(...)`` returns the same ``losses`` dict keys as the reference's ``process_batch``
 (views of one 16-float device vector, so reading them launches nothing) plus the per-pixel maps.
 The operator-level API (``mal_amd.loss_utils`` / ``MALLossPath``) computes the same thing op by
-op; ``tests/test_gpu_step.py`` holds the two against each other and against the oracle.
+op; ``tests/test_gpu_step.py`` holds the two against each other and against the CPU checker.
 """
 from __future__ import annotations
 
