@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--graph", type=int, default=0, help="replay the step from a HIP graph (default eager)")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a HIP graph (default); 0: eager launches")
     ap.add_argument("--mode", choices=["step", "ops"], default="step",
                     help="step: mal_loss_step (one C call per direction); ops: the operator-level API")
     ap.add_argument("--no-cpu-baseline", action="store_true")

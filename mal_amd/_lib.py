@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmal_hip.so")
+# MAL_HIP_LIB points at another build of the same ABI (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("MAL_HIP_LIB") or os.path.join(_HERE, "lib", "libmal_hip.so")
 
 c_fp = C.c_void_p      # device float*
 c_pp = C.c_void_p      # host array of device pointers (we pass a ctypes array)

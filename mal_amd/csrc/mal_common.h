@@ -30,11 +30,13 @@ inline TileGrid tile_grid(int B, int H, int W) {
 // workspace layout (all offsets 256-byte aligned):
 //   [0]            double block_sums[blocks][8]
 //   [..]           float  block_gP[blocks][2][12]
-//   [..]           double scratch[1024]         (generic two-stage reductions)
+//   [..]           double scratch[4096]         (generic two-stage reductions)
+//   [..]           float  cam[B][40]            (marching kernel: P of both frames + inv_K per sample)
 struct Workspace {
   double* block_sums;
   float* block_gP;
   double* scratch;
+  float* cam;
   size_t bytes;
 };
 
@@ -54,6 +56,7 @@ inline Workspace carve(void* base, int B, int H, int W) {
   w.block_sums = (double*)(p + o); o += align256(nb * 8 * sizeof(double));
   w.block_gP = (float*)(p + o);    o += align256(nb * 24 * sizeof(float));
   w.scratch = (double*)(p + o);    o += align256(4096 * sizeof(double));
+  w.cam = (float*)(p + o);         o += align256((size_t)B * 40 * sizeof(float));
   w.bytes = o;
   return w;
 }
@@ -67,7 +70,8 @@ inline int check_shape(int B, int H, int W) {
 
 // mal_pass.hip: fixed-order second stage shared by both fused-pass formulations
 int launch_pass_finalize(const double* block_sums, const float* block_gP, const float* K, int nblocks,
-                         int blocks_per_sample, int B, double* sums, float* gT0, float* gT1, hipStream_t st);
+                         int blocks_per_sample, int B, double* sums, float* gT0, float* gT1, hipStream_t st,
+                         int nsums = 4);
 
 inline int launch_status() {
   hipError_t e = hipGetLastError();

@@ -62,6 +62,38 @@ MAL_DEV float ssim_sums(float sx, float sy, float sxx, float syy, float sxy, flo
   return (1.0f - S) * 0.5f;
 }
 
+typedef __attribute__((address_space(4))) const float cfloat;  // constant address space: uniform loads are s_load
+constexpr int kCamFloats = 40;  // P[2][12], inv_K 3x3, 7 pad
+
+// the pointer is made opaque per call so the loads stay where they are written (not hoisted out of the
+// row loop and spilled)
+MAL_DEV void load_cam(const cfloat* cam, float (&P)[2][12], float (&ik)[9]) {
+  asm volatile("" : "+s"(cam));
+#pragma unroll
+  for (int e = 0; e < 24; ++e) P[e / 12][e % 12] = cam[e];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) ik[e] = cam[24 + e];
+}
+
+// one block per sample: P_f = (K T_f)[:3,:] with ATen's bmm association, inv_K[:3,:3]
+__global__ void cam_setup_kernel(const float* K, const float* T0, const float* T1, const float* invK, float* cam) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float mine = 0.f;
+  if (lane < 24) {
+    const int f = lane / 12, e = lane % 12, i = e >> 2, j = e & 3;
+    const float* Kb = K + b * 16;
+    const float* T = (f ? T1 : T0) + b * 16;
+    float acc = Kb[i * 4 + 0] * T[0 * 4 + j];
+    acc = fma_(Kb[i * 4 + 1], T[1 * 4 + j], acc);
+    acc = fma_(Kb[i * 4 + 2], T[2 * 4 + j], acc);
+    mine = fma_(Kb[i * 4 + 3], T[3 * 4 + j], acc);
+  } else if (lane < 33) {
+    const int e = lane - 24;
+    mine = invK[b * 16 + (e / 3) * 4 + (e % 3)];
+  }
+  if (lane < kCamFloats) cam[b * kCamFloats + lane] = mine;
+}
+
 struct WarpRow {        // one pixel of a warped row
   float x[2][3];        // warped candidates
   float y[3];           // target
@@ -75,8 +107,8 @@ struct DerivRow {       // chain-rule data of that pixel
 struct PixInfo { float rp, w; int win; };
 
 // warp one pixel (both frames); DERIV also returns the chain-rule data
-template <bool DERIV, bool POSE>
-MAL_DEV void warp_px(const MarchParams& p, const float (&P)[2][12], const float (&ik)[9], int b,
+template <bool DERIV, bool POSE, class PT>
+MAL_DEV void warp_px(const PT& p, const float (&P)[2][12], const float (&ik)[9], int b,
                      int gyr, int gxr, float dispv, WarpRow& w, DerivRow& d) {
   const int W = p.W, H = p.H, HW = H * W, pix = gyr * W + gxr;
   const float depth = depth_of(dispv, p.min_disp, p.range);
@@ -118,9 +150,15 @@ MAL_DEV void warp_px(const MarchParams& p, const float (&P)[2][12], const float 
 }
 
 template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI>
-__global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
+__global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   constexpr int HALO = GRAD ? 2 : 1;
   constexpr int CW = 64 - 2 * HALO;
+  // The ~30 pointers and sizes of the parameter block do not fit in scalar registers next to the loop
+  // state; rather than let them spill (v_readlane reloads in the row loop) every iteration re-reads the
+  // fields it uses from the kernarg segment with scalar loads, through a pointer made opaque per iteration.
+  typedef __attribute__((address_space(4))) const MarchParams CParams;
+  CParams* const kp0 = (CParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  CParams& p = *kp0;
 
   const int id = blockIdx.x;
   const int task = (id & 7) * p.per_xcd + (id >> 3);
@@ -133,29 +171,11 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
   const int lane = threadIdx.x;
   const int y_lo = seg * p.rows, y_hi = min(y_lo + p.rows, H);
 
-  // P = (K T)[:3,:] for both frames and inv_K[:3,:3]: each entry is computed by one lane and
-  // broadcast into scalar registers (wave-uniform operands cost no VGPRs and no LDS)
-  float P[2][12], ik[9];
-  {
-    float mine = 0.f;
-    if (lane < 24) {
-      const int f = lane / 12, e = lane % 12, i = e >> 2, j = e & 3;
-      const float* K = p.K + b * 16;
-      const float* T = p.T[f] + b * 16;
-      float acc = K[i * 4 + 0] * T[0 * 4 + j];
-      acc = fma_(K[i * 4 + 1], T[1 * 4 + j], acc);
-      acc = fma_(K[i * 4 + 2], T[2 * 4 + j], acc);
-      mine = fma_(K[i * 4 + 3], T[3 * 4 + j], acc);
-    } else if (lane >= 32 && lane < 41) {
-      const int e = lane - 32;
-      mine = p.invK[b * 16 + (e / 3) * 4 + (e % 3)];
-    }
-    const int bits = __builtin_bit_cast(int, mine);
-#pragma unroll
-    for (int e = 0; e < 24; ++e) P[e / 12][e % 12] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, e));
-#pragma unroll
-    for (int e = 0; e < 9; ++e) ik[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 32 + e));
-  }
+  // P = (K T)[:3,:] of both frames and inv_K[:3,:3] (cam_setup_kernel wrote them, 40 floats per sample).
+  // They are fetched with scalar loads where they are used, every iteration, rather than held across
+  // the loop: 33 resident scalars overflowed the SGPR file and the spill traffic (v_readlane + hazard
+  // nops, ~230 instructions per row) cost more than five s_load per row through the scalar cache.
+  const cfloat* cam_b = (const cfloat*)(p.cam + (size_t)b * kCamFloats);
 
   // ---- lane geometry
   const int gx = strip * CW - HALO + lane;
@@ -178,7 +198,13 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
   WarpRow w1;                    // row r-1 (raw values, for the L1 term of the centre row)
   PixInfo pi1;                   // row c-1 = r-2 (decided one iteration ago)
   float gP[POSE ? 24 : 1];
-  double acc_rw = 0.0, acc_w = 0.0, acc_cons = 0.0, acc_dist = 0.0;
+  float acc_rw = 0.f, acc_w = 0.f, acc_cons = 0.f, acc_dist = 0.f;  // per-lane partials (<= rows terms each)
+  // in-sweep smoothness state: normalised / raw disparity of the previous row, its pending gradient
+  const bool smooth = GRAD && p.smooth_mean != nullptr;
+  const float sm_inv = smooth ? div_(1.0f, (float)p.smooth_mean[b] + 1e-7f) : 0.f;
+  const float sm_nx = 1.0f / ((float)p.B * (float)H * (float)(W - 1)), sm_ny = 1.0f / ((float)p.B * (float)(H - 1) * (float)W);
+  float sm_n1 = 0.f, sm_d1 = 0.f, sm_g1 = 0.f;
+  float acc_sx = 0.f, acc_sy = 0.f, acc_sd = 0.f;  // per-lane partials over <= rows pixels: fp32, widened at the wave sum
 #pragma unroll
   for (int i = 0; i < 24; ++i) { hsA[i] = 0.f; hsB[i] = 0.f; }
   if (GRAD)
@@ -201,6 +227,9 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
   int it = 0;
   const int r_first = max(y_lo - HALO, -1), r_last = y_hi - 1 + HALO;
   for (int r = r_first; r <= r_last; ++r, ++it) {
+    CParams* kp = kp0;
+    asm volatile("" : "+s"(kp));
+    CParams& p = *kp;
     // ---- the small per-pixel operands of this iteration's later stages are requested first, so their
     // latency overlaps the warp (loads sitting behind a wave-uniform branch are not hoisted by the compiler)
     const size_t gic = map_b + (size_t)min(max(r - 1, 0), H - 1) * W + gxr;  // statistics row c = r-1
@@ -222,10 +251,12 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
     // ================= stage W: warp row r (reflected if outside the image) ==================
     const int gyr = min(max(reflect1(r, H), 0), H - 1);
     WarpRow w0;
+    float dv_ = disp_b[gyr * W + gxr];
     {
-      float dv_ = disp_b[gyr * W + gxr];
       if (disp2_b) dv_ = (dv_ + disp2_b[gyr * W + gxr]) / 2.0f;
       DerivRow d0;
+      float P[2][12], ik[9];
+      load_cam(cam_b, P, ik);
       warp_px<GRAD, POSE>(p, P, ik, b, gyr, gxr, dv_, w0, d0);
       if (GRAD) {
         float (*slot)[64] = s_ring[it % 3];
@@ -240,6 +271,38 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) slot[6 + ch][lane] = w0.y[ch];
       }
+    }
+
+    // ================= smoothness of row r (edges to the right and up), finishing row r-1 ======
+    if (smooth) {
+      auto sgnf = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+      const bool row_ok = r >= 0 && r < H;
+      const float n0 = dv_ * sm_inv;
+      // right edge (r,x)-(r,x+1): exists for in-image x with x+1 < W
+      const float nR = dpp_shl1(n0);
+      const float eR = (fabsf(w0.y[0] - dpp_shl1(w0.y[0])) + fabsf(w0.y[1] - dpp_shl1(w0.y[1]))) +
+                       fabsf(w0.y[2] - dpp_shl1(w0.y[2]));
+      const bool hx = row_ok && in_x && gx + 1 < W;
+      const float wxr = hx ? expf(-(eR * (1.0f / 3.0f))) : 0.f;
+      const float dfx = n0 - nR;
+      const float sx = sgnf(dfx) * wxr * sm_nx;
+      // up edge (r-1,x)-(r,x): exists when both rows are image rows
+      const bool vy = row_ok && r >= 1 && in_x;
+      const float eU = (fabsf(w1.y[0] - w0.y[0]) + fabsf(w1.y[1] - w0.y[1])) + fabsf(w1.y[2] - w0.y[2]);
+      const float wyu_ = vy ? expf(-(eU * (1.0f / 3.0f))) : 0.f;
+      const float dfy = sm_n1 - n0;
+      const float sy = sgnf(dfy) * wyu_ * sm_ny;
+      const int qs = r - 1;  // row finished now: its down edge is this up edge
+      if (qs >= y_lo && qs < y_hi && out_x) {
+        const float g = sm_g1 + sy;
+        p.smooth_gn[map_b + (size_t)qs * W + gxr] = g;
+        acc_sy += fabsf(dfy) * wyu_;
+        acc_sd += g * sm_d1;
+      }
+      if (r >= y_lo && r < y_hi && out_x) acc_sx += fabsf(dfx) * wxr;
+      sm_g1 = (sx - dpp_shr1(sx)) - sy;
+      sm_n1 = n0;
+      sm_d1 = dv_;
     }
 
     // ================= stage H: horizontal 3-sums of row r ====================================
@@ -310,8 +373,8 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
       pi0.w = w;
       if (out_x && c >= y_lo && c < y_hi) {
         if (p.min_reproj) p.min_reproj[gi] = pi0.rp;
-        acc_rw += (double)(pi0.rp * w);
-        acc_w += (double)w;
+        acc_rw += pi0.rp * w;
+        acc_w += w;
       }
       if (GRAD) {
         // partials of the WINNING candidate only (its window sums are re-formed from the running sums)
@@ -368,7 +431,8 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
         if (POSE) {  // the projection of row q re-derived from its disparity (no gathers)
           const float depth = depth_of(disp_b[q * W + gxr], p.min_disp, p.range);
           const float ddepth = -(depth * depth) * p.range;
-          float ray[3];
+          float ray[3], P[2][12], ik[9];
+          load_cam(cam_b, P, ik);
           ray_of(ik, (float)gxr, (float)q, ray);
           dq.X[0] = depth * ray[0]; dq.X[1] = depth * ray[1]; dq.X[2] = depth * ray[2];
 #pragma unroll
@@ -440,7 +504,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
         const float dmono = p.mono_disp ? depth_of(le_mono, p.min_disp, p.range) : le_mono;
         const float m = pq.w, cm = 1.0f - m, mm = 1.0f - cm;
         const float dc = dm - dmono;
-        acc_cons += (double)(fabsf(dc) * cm);
+        acc_cons += fabsf(dc) * cm;
         int idx = 0;
         float best = le_mr;
         if (p.ens_reproj) {
@@ -451,7 +515,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
         const float ens = (dmono + dm) / 2.0f;
         const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
         const float dd = target - dm;
-        acc_dist += (double)(fabsf(dd) * mm);
+        acc_dist += fabsf(dd) * mm;
         if (p.cons_target) p.cons_target[gi] = div_(1.0f, dmono * cm + dm * (1.0f - cm));
         if (GRAD) {
           const float sc = dc > 0.f ? 1.f : (dc < 0.f ? -1.f : 0.f);
@@ -478,11 +542,15 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p) {
   }
 
   // ---- per-task partials (fixed-order second stage in pass_finalize_kernel)
-  const double r0 = wave_sum_d(acc_rw), r1 = wave_sum_d(acc_w);
-  const double r2 = EPI ? wave_sum_d(acc_cons) : 0.0, r3 = EPI ? wave_sum_d(acc_dist) : 0.0;
+  const double r0 = wave_sum_d((double)acc_rw), r1 = wave_sum_d((double)acc_w);
+  const double r2 = EPI ? wave_sum_d((double)acc_cons) : 0.0, r3 = EPI ? wave_sum_d((double)acc_dist) : 0.0;
   if (lane == 0) {
     double* o = p.block_sums + (size_t)task * 8;
     o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
+  }
+  if (GRAD) {  // smoothness partials (zeros when the term is not folded in)
+    const double q0 = wave_sum_d((double)acc_sx), q1 = wave_sum_d((double)acc_sy), q2 = wave_sum_d((double)acc_sd);
+    if (lane == 0) { double* o = p.block_sums + (size_t)task * 8; o[4] = q0; o[5] = q1; o[6] = q2; o[7] = 0.0; }
   }
   if (POSE) {
 #pragma unroll
@@ -605,6 +673,11 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   p.packed = ((flags & MAL_F_SRC_PACKED) ? 1 : 0) | ((flags & MAL_F_TGT_PACKED) ? 2 : 0);
   p.per_xcd = (p.ntasks + 7) / 8;
   dim3 grid(p.per_xcd * 8), block(64);
+  if (!p.cam) return MAL_EINVAL;
+  if (!p.cam_ready) {
+    hipLaunchKernelGGL(cam_setup_kernel, dim3(p.B), dim3(64), 0, st, p.K, p.T[0], p.T[1], p.invK, p.cam);
+    p.cam_ready = 1;
+  }
   hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
   g_prof_start = g_prof_stop = nullptr;
   if (ev0) (void)hipEventRecord(ev0, st);
@@ -711,6 +784,7 @@ extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float
   p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj;
   p.min_reproj = min_reproj; p.g_reproj = g_reproj; p.g_cons = g_cons; p.g_distil = g_distil;
   p.cons_target = consistency_target; p.depth_out = depth_out; p.block_sums = w.block_sums; p.block_gP = w.block_gP;
+  p.cam = w.cam;
   hipStream_t st = (hipStream_t)stream;
   rc = march_launch(p, flags, st);
   if (rc) return rc;

@@ -415,27 +415,28 @@ __global__ __launch_bounds__(kThreads, 2) void pass_kernel(PassParams p) {
   }
 }
 
-// blocks 0..3: sums[j] = sum over workgroups (fixed order); blocks 4..4+B-1: g_T[f][b] = K_b^T [gP_fb ; 0]
+// blocks 0..7: sums[j] = sum over workgroups (fixed order; j >= nsums -> 0); blocks 8..8+B-1: g_T[f][b] = K_b^T [gP_fb ; 0]
 __global__ __launch_bounds__(256) void pass_finalize_kernel(const double* block_sums, const float* block_gP,
                                                             const float* K, int nblocks, int tiles, int B,
-                                                            double* sums, float* gT0, float* gT1) {
+                                                            double* sums, float* gT0, float* gT1, int nsums) {
   __shared__ double s_part[256];
   __shared__ double s_gP[24];
   const int tid = threadIdx.x;
-  if (blockIdx.x < 4) {
+  if (blockIdx.x < 8) {
     const int j = blockIdx.x;
     double acc = 0.0;
-    for (int i = tid; i < nblocks; i += 256) acc += block_sums[(size_t)i * 8 + j];
+    if (j < nsums)
+      for (int i = tid; i < nblocks; i += 256) acc += block_sums[(size_t)i * 8 + j];
     s_part[tid] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
       if (tid < s) s_part[tid] += s_part[tid + s];
       __syncthreads();
     }
-    if (tid == 0) { sums[j] = s_part[0]; sums[4 + j] = 0.0; }
+    if (tid == 0) sums[j] = s_part[0];
     return;
   }
-  const int b = blockIdx.x - 4;
+  const int b = blockIdx.x - 8;
   if (!gT0 || b >= B) return;
   // 24 sums of `tiles` partials: 8 lanes per value, then an 8-lane tree (fixed order)
   const int v = tid >> 3, sub = tid & 7;
@@ -461,9 +462,10 @@ __global__ __launch_bounds__(256) void pass_finalize_kernel(const double* block_
 }
 
 int launch_pass_finalize(const double* block_sums, const float* block_gP, const float* K, int nblocks,
-                         int blocks_per_sample, int B, double* sums, float* gT0, float* gT1, hipStream_t st) {
-  hipLaunchKernelGGL(pass_finalize_kernel, dim3(gT0 ? 4 + B : 4), dim3(256), 0, st, block_sums, block_gP, K, nblocks,
-                     blocks_per_sample, B, sums, gT0, gT1);
+                         int blocks_per_sample, int B, double* sums, float* gT0, float* gT1, hipStream_t st,
+                         int nsums) {
+  hipLaunchKernelGGL(pass_finalize_kernel, dim3(gT0 ? 8 + B : 8), dim3(256), 0, st, block_sums, block_gP, K, nblocks,
+                     blocks_per_sample, B, sums, gT0, gT1, nsums);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MAL_OK : MAL_ELAUNCH;
 }

@@ -33,6 +33,7 @@ struct StepWs {
   double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
   double* sm_plane; double* sm_part; double* sm_stats;  // smoothness: [2B*chunks], [2B*chunks][4], [4*2B]
   float* coefs;       // 16 device scalars for the backward
+  float* cam;         // [B][40] camera block of the marching kernels
   int chunks;
   size_t bytes;
 };
@@ -58,6 +59,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   w.sm_part = (double*)take((size_t)2 * B * chunks * 4 * 8);
   w.sm_stats = (double*)take((size_t)8 * B * 8);
   w.coefs = (float*)take(16 * 4);
+  w.cam = (float*)take((size_t)B * 40 * 4);
   w.bytes = o;
   return w;
 }
@@ -126,6 +128,22 @@ __global__ __launch_bounds__(64) void step_smooth_mid_kernel(const double* plane
   }
 }
 
+// per-sample mean-coupling term of the in-sweep smoothness: corr_s = dot_s / (HW (mean_s+eps)^2), the dot
+// summed over the marching tasks of sample s (contiguous in task order); which = 0 teacher, 1 student
+__global__ __launch_bounds__(64) void step_smooth_corr_kernel(const double* bs_t, const double* bs_s, int per_sample,
+                                                              int B, int HW, double* stats) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const double* bs = s < B ? bs_t : bs_s;
+  const int b = s < B ? s : s - B;
+  double dot = 0.0;
+  for (int k = lane; k < per_sample; k += 64) dot += bs[((size_t)b * per_sample + k) * 8 + 6];
+  dot = wave_sum_d(dot);
+  if (lane == 0) {
+    const double m = (double)((float)stats[s] + 1e-7f);
+    stats[2 * B + s] = dot / ((double)HW * m * m);
+  }
+}
+
 // get_smooth_loss on disp/(mean+1e-7) for both maps (layers.py:210-223, loss_utils.py:119-121):
 // loss partials, d loss / d normalised-disp map, and the per-sample dot(gn, disp) of the mean coupling
 __global__ __launch_bounds__(256) void step_smooth_kernel(const float* dt, const float* ds, const float* img_packed,
@@ -179,13 +197,16 @@ __global__ __launch_bounds__(256) void step_smooth_kernel(const float* dt, const
 }
 
 // loss scalars (loss_utils.py:112-127,198-279; trainer.py:625-629) and the coefficients of the backward
-__global__ void step_scalars_kernel(const double* sums_t, const double* sums_s, const double* stats, int B, int HW,
+__global__ void step_scalars_kernel(const double* sums_t, const double* sums_s, const double* stats, int B, int H, int W,
                                     float w_main, float w_distil, float* losses, float* coefs) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int HW = H * W;
   const double N = (double)B * HW;
   const double reproj_t = sums_t[0] / (sums_t[1] + 1e-7), reproj_s = sums_s[0] / (sums_s[1] + 1e-7);
   const double cons = sums_s[2] / N, distil = sums_s[3] / N;
-  const double smooth_t = stats[4 * B], smooth_s = stats[4 * B + 1];
+  // smoothness sums come with the pass sums (slots 4, 5: sum Tx, sum Ty of the in-sweep term)
+  const double Nx = (double)B * H * (W - 1), Ny = (double)B * (H - 1) * W;
+  const double smooth_t = sums_t[4] / Nx + sums_t[5] / Ny, smooth_s = sums_s[4] / Nx + sums_s[5] / Ny;
   const float loss_t = (float)reproj_t + 1e-3f * (float)smooth_t;
   const float loss_m = ((float)reproj_s + (float)cons) + 1e-3f * (float)smooth_s;
   losses[0] = (float)reproj_t; losses[1] = (float)smooth_t; losses[2] = loss_t;
@@ -287,6 +308,8 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   rc = launch_status();
   if (rc) return rc;
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
+  int per_sample = 1;
+  int cam_ready = 0;  // the first pass fills the camera block, the others reuse it
   // 5. teacher pass
   {
     MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
@@ -294,9 +317,13 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
     p.ident = w.ident; p.noise = a->noise; p.min_reproj = mono_reproj; p.g_reproj = w.G_r_t;
     p.block_sums = w.bs_t; p.block_gP = w.bgP;
+    p.smooth_mean = w.sm_stats; p.smooth_gn = w.gn_t;
+    p.cam = w.cam; p.cam_ready = cam_ready;
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
     if (rc) return rc;
-    rc = launch_pass_finalize(w.bs_t, w.bgP, a->K, p.ntasks, p.strips * p.segs, B, w.sums_t, w.gT[0], w.gT[1], st);
+    per_sample = p.strips * p.segs;
+    cam_ready = p.cam_ready;
+    rc = launch_pass_finalize(w.bs_t, w.bgP, a->K, p.ntasks, per_sample, B, w.sums_t, w.gT[0], w.gT[1], st, 8);
     if (rc) return rc;
   }
   // 6. ensemble pass (no gradient)
@@ -305,6 +332,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.disp = a->disp_teacher; p.disp2 = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
     p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
     p.min_reproj = ens_reproj; p.block_sums = w.bs_e; p.block_gP = w.bgP;
+    p.cam = w.cam; p.cam_ready = cam_ready;
     rc = march_launch(p, packed, st);
     if (rc) return rc;
   }
@@ -318,18 +346,18 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj;
     p.min_reproj = multi_reproj; p.g_reproj = w.G_r_s; p.g_cons = w.G_c; p.g_distil = w.G_d;
     p.block_sums = w.bs_s; p.block_gP = w.bgP;
+    p.smooth_mean = w.sm_stats + B; p.smooth_gn = w.gn_s;
+    p.cam = w.cam; p.cam_ready = cam_ready;
     rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
     if (rc) return rc;
-    rc = launch_pass_finalize(w.bs_s, w.bgP, a->K, p.ntasks, p.strips * p.segs, B, w.sums_s, nullptr, nullptr, st);
+    rc = launch_pass_finalize(w.bs_s, w.bgP, a->K, p.ntasks, p.strips * p.segs, B, w.sums_s, nullptr, nullptr, st, 8);
     if (rc) return rc;
   }
-  // 8. smoothness of both maps
-  hipLaunchKernelGGL(step_smooth_kernel, dim3(2 * B * w.chunks), dim3(256), 0, st, a->disp_teacher, a->disp_student,
-                     w.packed[0], B, H, W, w.chunks, w.sm_stats, w.sm_part, w.gn_t, w.gn_s);
-  hipLaunchKernelGGL(step_smooth_mid_kernel, dim3(2 * B + 1), dim3(64), 0, st, w.sm_plane, w.sm_part, B, H, W, w.chunks,
-                     2, w.sm_stats);
+  // 8. mean-coupling term of both smoothness gradients (the terms themselves were folded into the passes)
+  hipLaunchKernelGGL(step_smooth_corr_kernel, dim3(2 * B), dim3(64), 0, st, w.bs_t, w.bs_s, per_sample, B, HW,
+                     w.sm_stats);
   // 9. scalars
-  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, st, w.sums_t, w.sums_s, w.sm_stats, B, HW, a->w_main,
+  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, st, w.sums_t, w.sums_s, w.sm_stats, B, H, W, a->w_main,
                      a->w_distil, a->losses, w.coefs);
   return launch_status();
 }
