@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--mode", choices=["step", "ops"], default="step",
                     help="step: mal_loss_step (one C call per direction); ops: the operator-level API")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
+                    help="mal_set_option before the run (kernel experiments, e.g. march_rows=16)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
 
@@ -140,6 +142,9 @@ def main():
     if dist is not None:
         dist.barrier()
     lib = _lib.load()
+    for kv in args.opt:
+        name, val = kv.split("=")
+        _lib.check(lib.mal_set_option(name.encode(), int(val)), "mal_set_option(%s)" % kv)
     step = Step(dev, 1234 + rank, args.mode)
 
     def sync():

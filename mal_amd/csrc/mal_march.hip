@@ -1,4 +1,4 @@
-// The fused pass, second formulation: register-resident marching (no LDS, no barriers).
+// The fused pass, second formulation: register-resident marching (no barriers).
 //
 // One wavefront owns a 64-column strip of one sample and walks down a segment of rows.
 //   * lane <-> image column: every plane access (disp, target, masks, outputs) is one coalesced
@@ -13,6 +13,12 @@
 //     reflected pixel; its adjoint = border neighbours count twice.
 //   * strips overlap by the halo (2 columns each side with gradients, 1 without): 60 (62) useful
 //     columns per wave; segments overlap by 2 (1) rows each side.
+//   * the kernel is bound by VALU issue (a wave64 op takes 4 cycles on the 16-lane SIMD), so the
+//     six colour values of a pixel (2 candidates x 3 channels) live as three register PAIRS and the
+//     arithmetic on them is packed fp32 (v_pk_fma/mul/add_f32: two values per lane per issue):
+//         pair 0 = (r, g) of candidate 0,  pair 1 = (r, g) of candidate 1,  pair 2 = (b0, b1)
+//     (r, g) is how a 16-byte texel arrives from the gather, so no shuffles are needed; everything
+//     per candidate (projection, tap weights, pose terms) is a pair over the two candidates.
 // The SSIM is evaluated on window SUMS (numerator and denominator scaled by 81^2) so no
 // division by 9 is needed; with the separable association this differs from ATen's row-major
 // order by fp32 reassociation only (tests bound it).
@@ -40,37 +46,103 @@ MAL_DEV float hsum3(float v) { return (dpp_shr1(v) + v) + dpp_shl1(v); }
 constexpr float kC1s = 81.0f * 0.0001f;  // 81 * C1
 constexpr float kC2s = 81.0f * 0.0009f;  // 81 * C2
 
-// SSIM from 3x3 window sums; returns the un-clamped (1 - S)/2 and the partials of S wrt the
-// window sums of x (the candidate): dS/d(sum x), dS/d(sum x^2), dS/d(sum xy).
-template <bool GRAD>
-MAL_DEV float ssim_sums(float sx, float sy, float sxx, float syy, float sxy, float* dsx, float* dsxx, float* dsxy) {
+// SSIM from 3x3 window sums (scalar form, used by the identity kernel); returns the un-clamped (1 - S)/2
+MAL_DEV float ssim_sums(float sx, float sy, float sxx, float syy, float sxy) {
   const float pxy = sx * sy;
-  const float n1 = 2.0f * pxy + kC1s;
-  const float n2 = 2.0f * (9.0f * sxy - pxy) + kC2s;
-  const float sx2 = sx * sx, sy2 = sy * sy;
-  const float d1 = sx2 + sy2 + kC1s;
-  const float d2 = (9.0f * sxx - sx2) + (9.0f * syy - sy2) + kC2s;
+  const float n1 = fma_(2.0f, pxy, kC1s);
+  const float n2 = fma_(2.0f, fma_(9.0f, sxy, -pxy), kC2s);
+  const float d1 = fma_(sx, sx, fma_(sy, sy, kC1s));
+  const float d2 = (fma_(-sx, sx, 9.0f * sxx) + fma_(-sy, sy, 9.0f * syy)) + kC2s;
   const float n = n1 * n2, d = d1 * d2;
   float rd = __builtin_amdgcn_rcpf(d);
   rd = fma_(fma_(-d, rd, 1.0f), rd, rd);
-  const float S = n * rd;
-  if (GRAD) {
-    *dsx = (2.0f * sy * (n2 - n1) - S * (2.0f * sx * (d2 - d1))) * rd;
-    *dsxx = -9.0f * S * d1 * rd;
-    *dsxy = 18.0f * n1 * rd;
+  return fma_(n * rd, -0.5f, 0.5f);
+}
+
+// ---------------------------------------------------------------- packed fp32 (two values per lane)
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+MAL_DEV f2 bc(float v) { return (f2){v, v}; }
+MAL_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+MAL_DEV f2 rcp2(f2 a) { return (f2){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+MAL_DEV f2 hsum3(f2 v) { return (f2){hsum3(v.x), hsum3(v.y)}; }
+// div_ / div_safe_ / div3_ of mal_device.h, element for element
+MAL_DEV f2 div2_(f2 a, f2 b) {
+  f2 y = rcp2(b);
+  y = fma2(fma2(-b, y, bc(1.0f)), y, y);
+  const f2 q = a * y;
+  const f2 r = fma2(-b, q, a);
+  return fma2(r, y, q);
+}
+MAL_DEV f2 div_safe2_(f2 a, f2 b) {
+  const f2 y0 = rcp2(b);
+  const f2 y = fma2(fma2(-b, y0, bc(1.0f)), y0, y0);
+  const f2 q = a * y;
+  const f2 r = fma2(-b, q, a);
+  const f2 q1 = fma2(r, y, q);
+  const f2 alt = a * y0;
+  return (f2){__builtin_isfinite(q1.x) ? q1.x : alt.x, __builtin_isfinite(q1.y) ? q1.y : alt.y};
+}
+MAL_DEV f2 div3_2(f2 a) {
+  const f2 q = a * bc(0.333333333333333333f);
+  const f2 r = fma2(bc(-3.0f), q, a);
+  return fma2(r, bc(0.333333333333333333f), q);
+}
+// Global accesses as (wave-uniform base) + (32-bit per-lane BYTE offset): the saddr form of global_load/
+// global_store.  One offset register serves every map that is read at the same pixel and no 64-bit vector
+// address arithmetic is needed (check_shape bounds every tensor below 2^31 bytes).
+MAL_DEV float ldf(const float* base, unsigned boff) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+}
+MAL_DEV f4 ldf4(const float* base, unsigned boff) {
+  return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(base) + boff);
+}
+MAL_DEV void stf(float* base, unsigned boff, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v; }
+// the three colour channels of pixel `pix` of sample b: planar (B,3,H,W) or packed (B,H,W,4)
+MAL_DEV void load_rgb(const float* img, int packed, int b, int HW, unsigned pix, float* out) {
+  if (packed) {
+    const f4 v = ldf4(img + (size_t)b * HW * 4, pix * 16u);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+  } else {
+    const float* pl = img + (size_t)b * 3 * HW;
+    out[0] = ldf(pl, pix * 4u); out[1] = ldf(pl + HW, pix * 4u); out[2] = ldf(pl + 2 * (size_t)HW, pix * 4u);
   }
-  return (1.0f - S) * 0.5f;
+}
+MAL_DEV float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// SSIM of two windows at once from their sums; un-clamped (1 - S)/2 and, with GRAD, the partials of S
+// wrt the window sums of x: dS/d(sum x), 2 dS/d(sum x^2) (the 2 of d x^2/dx folded in), dS/d(sum xy)
+template <bool GRAD>
+MAL_DEV f2 ssim_sums2(f2 sx, f2 sy, f2 sxx, f2 vy /* 9 syy - sy^2 */, f2 d1y /* sy^2 + 81 C1 */, f2 sxy, f2* dsx,
+                      f2* dsxx2, f2* dsxy) {
+  const f2 pxy = sx * sy;
+  const f2 n1 = fma2(bc(2.0f), pxy, bc(kC1s));
+  const f2 n2 = fma2(bc(2.0f), fma2(bc(9.0f), sxy, -pxy), bc(kC2s));
+  const f2 d1 = fma2(sx, sx, d1y);
+  const f2 d2 = (fma2(-sx, sx, bc(9.0f) * sxx) + vy) + bc(kC2s);
+  const f2 n = n1 * n2, d = d1 * d2;
+  f2 rd = rcp2(d);
+  rd = fma2(fma2(-d, rd, bc(1.0f)), rd, rd);
+  const f2 S = n * rd;
+  if (GRAD) {
+    const f2 t1 = sy * (n2 - n1);
+    const f2 t2 = (S * sx) * (d2 - d1);
+    *dsx = (bc(2.0f) * (t1 - t2)) * rd;
+    *dsxx2 = (bc(-18.0f) * S) * (d1 * rd);
+    *dsxy = (bc(18.0f) * n1) * rd;
+  }
+  return fma2(S, bc(-0.5f), bc(0.5f));
 }
 
 typedef __attribute__((address_space(4))) const float cfloat;  // constant address space: uniform loads are s_load
-constexpr int kCamFloats = 40;  // P[2][12], inv_K 3x3, 7 pad
+constexpr int kCamFloats = 40;  // P interleaved over the two frames [12][2], inv_K 3x3, 7 pad
 
 // the pointer is made opaque per call so the loads stay where they are written (not hoisted out of the
-// row loop and spilled)
-MAL_DEV void load_cam(const cfloat* cam, float (&P)[2][12], float (&ik)[9]) {
+// row loop and spilled); P[e] = (P_frame0[e], P_frame1[e]) lands in an aligned scalar register pair
+MAL_DEV void load_cam(const cfloat* cam, f2 (&P)[12], float (&ik)[9]) {
   asm volatile("" : "+s"(cam));
 #pragma unroll
-  for (int e = 0; e < 24; ++e) P[e / 12][e % 12] = cam[e];
+  for (int e = 0; e < 12; ++e) P[e] = (f2){cam[2 * e], cam[2 * e + 1]};
 #pragma unroll
   for (int e = 0; e < 9; ++e) ik[e] = cam[24 + e];
 }
@@ -80,7 +152,7 @@ __global__ void cam_setup_kernel(const float* K, const float* T0, const float* T
   const int b = blockIdx.x, lane = threadIdx.x;
   float mine = 0.f;
   if (lane < 24) {
-    const int f = lane / 12, e = lane % 12, i = e >> 2, j = e & 3;
+    const int f = lane & 1, e = lane >> 1, i = e >> 2, j = e & 3;
     const float* Kb = K + b * 16;
     const float* T = (f ? T1 : T0) + b * 16;
     float acc = Kb[i * 4 + 0] * T[0 * 4 + j];
@@ -94,59 +166,172 @@ __global__ void cam_setup_kernel(const float* K, const float* T0, const float* T
   if (lane < kCamFloats) cam[b * kCamFloats + lane] = mine;
 }
 
-struct WarpRow {        // one pixel of a warped row
-  float x[2][3];        // warped candidates
-  float y[3];           // target
+// Colour pairs of one pixel: x[0] = (r,g) of candidate 0, x[1] = (r,g) of candidate 1, x[2] = (b0, b1)
+struct WarpRow {
+  f2 x[3];
+  f2 yrg; float yb;     // target
 };
-struct DerivRow {       // chain-rule data of that pixel
-  float e[2][3];        // d x[f][ch] / d disp  (through u, v, depth; border clip folded in)
-  float du[2][3], dv[2][3];  // POSE only: d x / d u, d x / d v
-  float rz[2], u[2], v[2];   // POSE only
-  float X[3];                // POSE only
+struct DerivRow {       // chain-rule data of that pixel, same pairing
+  f2 e[3];              // d x / d disp  (through u, v, depth; border clip folded in)
+  f2 du[3], dv[3];      // POSE only: d x / d u, d x / d v
 };
 struct PixInfo { float rp, w; int win; };
 
-// warp one pixel (both frames); DERIV also returns the chain-rule data
-template <bool DERIV, bool POSE, class PT>
-MAL_DEV void warp_px(const PT& p, const float (&P)[2][12], const float (&ik)[9], int b,
-                     int gyr, int gxr, float dispv, WarpRow& w, DerivRow& d) {
+// Project3D + unnormalise + border clip of mal_device.h::project_pixel for both frames at once
+struct Sample2 { f2 ix, iy, mx, my, u, v, rz; };
+
+// a / c with y = the refined reciprocal of c that div_ would form (wave-uniform, made once per wave)
+MAL_DEV f2 divc2_(f2 a, float c, float y) {
+  const f2 q = a * bc(y);
+  const f2 r = fma2(bc(-c), q, a);
+  return fma2(r, bc(y), q);
+}
+MAL_DEV float refined_rcp(float b) {
+  const float y = __builtin_amdgcn_rcpf(b);
+  return fma_(fma_(-b, y, 1.0f), y, y);
+}
+
+// rw, rh: refined reciprocals of the grid normalisation's divisors (W-1, H-1 for convention 0; W, H for 1)
+MAL_DEV Sample2 project2(const f2 (&P)[12], const float (&X)[3], float eps, int W, int H, int convention, float rw,
+                         float rh) {
+  Sample2 s;
+  f2 c[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f2 acc = P[4 * i] * bc(X[0]);
+    acc = fma2(P[4 * i + 1], bc(X[1]), acc);
+    acc = fma2(P[4 * i + 2], bc(X[2]), acc);
+    c[i] = acc + P[4 * i + 3];  // == fma(P, 1, acc)
+  }
+  const f2 zp = c[2] + bc(eps);
+  s.u = div_safe2_(c[0], zp);
+  s.v = div_safe2_(c[1], zp);
+  s.rz = rcp2(zp);
+  f2 ix, iy;
+  if (convention == 0) {
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    const f2 gx = (divc2_(s.u, wm1, rw) - bc(0.5f)) * bc(2.0f);
+    const f2 gy = (divc2_(s.v, hm1, rh) - bc(0.5f)) * bc(2.0f);
+    ix = (gx + bc(1.0f)) * bc(wm1 * 0.5f);
+    iy = (gy + bc(1.0f)) * bc(hm1 * 0.5f);
+  } else {
+    const float wf = (float)W, hf = (float)H;
+    const f2 gx = divc2_(bc(2.0f) * (s.u + bc(0.5f)), wf, rw) - bc(1.0f);
+    const f2 gy = divc2_(bc(2.0f) * (s.v + bc(0.5f)), hf, rh) - bc(1.0f);
+    ix = fma2(gx + bc(1.0f), bc(wf * 0.5f), bc(-0.5f));
+    iy = fma2(gy + bc(1.0f), bc(hf * 0.5f), bc(-0.5f));
+  }
+  const float xmax = (float)(W - 1), ymax = (float)(H - 1);
+  // fmaxf/fminf drop NaNs, so a degenerate projection still yields an in-range index
+  s.ix = (f2){fminf(fmaxf(ix.x, 0.0f), xmax), fminf(fmaxf(ix.y, 0.0f), xmax)};
+  s.iy = (f2){fminf(fmaxf(iy.x, 0.0f), ymax), fminf(fmaxf(iy.y, 0.0f), ymax)};
+  // the border itself counts as clipped (ATen)
+  s.mx = (f2){(s.ix.x != 0.0f && s.ix.x != xmax) ? 1.0f : 0.0f, (s.ix.y != 0.0f && s.ix.y != xmax) ? 1.0f : 0.0f};
+  s.my = (f2){(s.iy.x != 0.0f && s.iy.x != ymax) ? 1.0f : 0.0f, (s.iy.y != 0.0f && s.iy.y != ymax) ? 1.0f : 0.0f};
+  return s;
+}
+
+// The warp of one pixel (both frames) in two halves, so that work that does not need the gathered
+// texels can be placed between the gather instructions and their first use.
+struct PendingWarp {
+  f4 t[2][4];                  // the four taps of both frames: (r, g, b, -)
+  f2 nw, ne, sw, se;           // tap weights, pairs over the two frames
+  f2 ex, ey, tx, ty;           // DERIV
+  f2 mx, my, du_ddisp, dv_ddisp;
+  f2 u, v, rz;                 // POSE: the projection, kept for the pose terms of the gradient row
+};
+
+// the parameter-block fields the warp needs, read together at the top of an iteration (one scalar-load wait)
+struct WarpConsts { const float* src[2]; int packed, debug, W, H, convention; float min_disp, range, eps, rw, rh; };
+
+// projection, tap weights and the eight gathers
+template <bool DERIV, bool POSE, class BeforeGathers>
+MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik)[9], int b, int gyr, int gxr,
+                        float dispv, PendingWarp& w, BeforeGathers before_gathers) {
   const int W = p.W, H = p.H, HW = H * W, pix = gyr * W + gxr;
   const float depth = depth_of(dispv, p.min_disp, p.range);
   float ray[3], X[3];
   ray_of(ik, (float)gxr, (float)gyr, ray);
   X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
-  const float ddepth = -(depth * depth) * p.range;
-  load_px3(p.target, p.packed & 2, b, HW, pix, w.y);
+  const Sample2 s = project2(P, X, p.eps, W, H, p.convention, p.rw, p.rh);
+  // make_taps of mal_device.h for both frames
+  const f2 x0f = (f2){floorf(s.ix.x), floorf(s.ix.y)}, y0f = (f2){floorf(s.iy.x), floorf(s.iy.y)};
+  int oo[2][4];
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    Sample s = project_pixel(P[f], X, p.eps, W, H, p.convention);
-    Taps t = make_taps(s.ix, s.iy, W, H);
-    if (p.debug & 1) { t.o00 = t.o01 = t.o10 = t.o11 = pix; }
-    float ta[3], tb[3], tc[3], td[3];
-    load_taps(p.src[f], p.packed & 1, b, HW, t, ta, tb, tc, td);
-    float du_ddisp = 0.f, dv_ddisp = 0.f;
-    if (DERIV) {
-      // d c_i / d depth = P_i[:3] . ray ;  u = c0/z', v = c1/z'
-      const float c0 = P[f][0] * ray[0] + P[f][1] * ray[1] + P[f][2] * ray[2];
-      const float c1 = P[f][4] * ray[0] + P[f][5] * ray[1] + P[f][6] * ray[2];
-      const float c2 = P[f][8] * ray[0] + P[f][9] * ray[1] + P[f][10] * ray[2];
-      du_ddisp = (c0 - s.u * c2) * s.rz * ddepth * s.mx;
-      dv_ddisp = (c1 - s.v * c2) * s.rz * ddepth * s.my;
-    }
+    const int x0 = (int)x0f[f], y0 = (int)y0f[f];
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);  // x0+1 == W only with weight 0
+    oo[f][0] = y0 * W + x0; oo[f][1] = y0 * W + x1; oo[f][2] = y1 * W + x0; oo[f][3] = y1 * W + x1;
+    if (p.debug & 1) { oo[f][0] = oo[f][1] = oo[f][2] = oo[f][3] = pix; }
+  }
+  before_gathers();
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      const float a = ta[ch], bb = tb[ch], c = tc[ch], dd = td[ch];
-      w.x[f][ch] = blend(t, a, bb, c, dd);
-      if (DERIV) {
-        float dx, dy;
-        blend_grad(t, a, bb, c, dd, &dx, &dy);
-        d.e[f][ch] = dx * du_ddisp + dy * dv_ddisp;
-        if (POSE) { d.du[f][ch] = dx * s.mx; d.dv[f][ch] = dy * s.my; }
+  for (int f = 0; f < 2; ++f) {
+    const int (&o)[4] = oo[f];
+    if (p.packed & 1) {
+      const float* sp = p.src[f] + (size_t)b * HW * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w.t[f][k] = ldf4(sp, (unsigned)o[k] * 16u);
+    } else {
+      const float* p0 = p.src[f] + (size_t)b * 3 * HW;
+      const float* p1 = p0 + HW;
+      const float* p2 = p1 + HW;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned bo = (unsigned)o[k] * 4u;
+        w.t[f][k] = (f4){ldf(p0, bo), ldf(p1, bo), ldf(p2, bo), 0.f};
       }
     }
-    if (DERIV && POSE) { d.rz[f] = s.rz; d.u[f] = s.u; d.v[f] = s.v; }
   }
-  if (DERIV && POSE) { d.X[0] = X[0]; d.X[1] = X[1]; d.X[2] = X[2]; }
+  w.tx = s.ix - x0f; w.ex = bc(1.0f) - w.tx; w.ty = s.iy - y0f; w.ey = bc(1.0f) - w.ty;
+  w.nw = w.ey * w.ex; w.ne = w.ey * w.tx; w.sw = w.ty * w.ex; w.se = w.ty * w.tx;
+  w.mx = s.mx; w.my = s.my;
+  if (POSE) { w.u = s.u; w.v = s.v; w.rz = s.rz; }
+  if (DERIV && !POSE) {
+    // d c_i / d depth = P_i[:3] . ray ;  u = c0/z', v = c1/z'
+    const float ddepth = -(depth * depth) * p.range;
+    const f2 c0 = P[0] * bc(ray[0]) + P[1] * bc(ray[1]) + P[2] * bc(ray[2]);
+    const f2 c1 = P[4] * bc(ray[0]) + P[5] * bc(ray[1]) + P[6] * bc(ray[2]);
+    const f2 c2 = P[8] * bc(ray[0]) + P[9] * bc(ray[1]) + P[10] * bc(ray[2]);
+    w.du_ddisp = (c0 - s.u * c2) * s.rz * bc(ddepth) * s.mx;
+    w.dv_ddisp = (c1 - s.v * c2) * s.rz * bc(ddepth) * s.my;
+  }
+}
+
+// blend (and its derivatives) once the texels are there
+template <bool DERIV, bool POSE>
+MAL_DEV void warp_finish(PendingWarp& pw, f2 (&x)[3], DerivRow& d) {
+  f2 dxb, dyb;  // b channel of both frames
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm("" : "+v"(pw.t[f][k]));  // whole 16-byte texels: one gather each, not 8+4 bytes
+    const f4 A = pw.t[f][0], Bv = pw.t[f][1], C = pw.t[f][2], D = pw.t[f][3];
+    const f2 a = (f2){A.x, A.y}, bb = (f2){Bv.x, Bv.y}, c = (f2){C.x, C.y}, dd = (f2){D.x, D.y};
+    const float nw_ = pw.nw[f], ne_ = pw.ne[f], sw_ = pw.sw[f], se_ = pw.se[f];
+    // blend (mal_device.h): nw*a, then fma for ne, sw, se
+    f2 o = a * bc(nw_);
+    o = fma2(bb, bc(ne_), o);
+    o = fma2(c, bc(sw_), o);
+    x[f] = fma2(dd, bc(se_), o);
+    float oz = A.z * nw_;
+    oz = fma_(Bv.z, ne_, oz);
+    oz = fma_(C.z, sw_, oz);
+    x[2][f] = fma_(D.z, se_, oz);
+    if (DERIV) {
+      const float ex_ = pw.ex[f], ey_ = pw.ey[f], tx_ = pw.tx[f], ty_ = pw.ty[f];
+      const f2 dx = (bb - a) * bc(ey_) + (dd - c) * bc(ty_);
+      const f2 dy = (c - a) * bc(ex_) + (dd - bb) * bc(tx_);
+      dxb[f] = (Bv.z - A.z) * ey_ + (D.z - C.z) * ty_;
+      dyb[f] = (C.z - A.z) * ex_ + (D.z - Bv.z) * tx_;
+      if (POSE) { d.du[f] = dx * bc(pw.mx[f]); d.dv[f] = dy * bc(pw.my[f]); }
+      else d.e[f] = dx * bc(pw.du_ddisp[f]) + dy * bc(pw.dv_ddisp[f]);
+    }
+  }
+  if (DERIV) {
+    if (POSE) { d.du[2] = dxb * pw.mx; d.dv[2] = dyb * pw.my; }
+    else d.e[2] = dxb * pw.du_ddisp + dyb * pw.dv_ddisp;
+  }
 }
 
 template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI>
@@ -174,7 +359,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   // P = (K T)[:3,:] of both frames and inv_K[:3,:3] (cam_setup_kernel wrote them, 40 floats per sample).
   // They are fetched with scalar loads where they are used, every iteration, rather than held across
   // the loop: 33 resident scalars overflowed the SGPR file and the spill traffic (v_readlane + hazard
-  // nops, ~230 instructions per row) cost more than five s_load per row through the scalar cache.
+  // nops, ~230 instructions per row) cost more than a few s_load per row through the scalar cache.
   const cfloat* cam_b = (const cfloat*)(p.cam + (size_t)b * kCamFloats);
 
   // ---- lane geometry
@@ -185,19 +370,20 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   // adjoint of the horizontal reflection: what this lane's partials count for when they are
   // shifted to the right neighbour (it is column 0 feeding column 1) / to the left neighbour
   const float sL = gx == 0 ? 2.0f : 1.0f, sR = gx == W - 1 ? 2.0f : 1.0f;
-  const bool strip_border = (strip == 0) || (strip * CW - HALO + 63 >= W - 1);  // wave-uniform
 
   const float* disp_b = p.disp + (size_t)b * HW;
   const float* disp2_b = p.disp2 ? p.disp2 + (size_t)b * HW : nullptr;
   const size_t map_b = (size_t)b * HW;
   const float sscale = p.sample_scale ? p.sample_scale[b] : 1.0f;
 
-  // ---- running state
-  float hsA[24], hsB[24];        // partial vertical sums of the horizontal sums: centre r-1 (top+mid), centre r (top)
-  float hcA[GRAD ? 18 : 1], hcB[GRAD ? 18 : 1];  // same for the 18 partial planes: output row c-1, c
+  // ---- running state (pairs as in WarpRow: index k*3 + {x, x^2, xy} for the colour pairs k)
+  f2 hsA[9], hsB[9];             // partial vertical sums of the horizontal sums: centre r-1 (top+mid), centre r (top)
+  f2 hyA[2], hyB[2];             // same for the target's (r,g): sum y, sum y^2
+  float hzA[2], hzB[2];          // and its b channel
+  f2 hcA[GRAD ? 9 : 1], hcB[GRAD ? 9 : 1];  // same for the 18 partial planes: output row c-1, c
   WarpRow w1;                    // row r-1 (raw values, for the L1 term of the centre row)
   PixInfo pi1;                   // row c-1 = r-2 (decided one iteration ago)
-  float gP[POSE ? 24 : 1];
+  f2 gP[POSE ? 12 : 1];          // d loss / d P of both frames
   float acc_rw = 0.f, acc_w = 0.f, acc_cons = 0.f, acc_dist = 0.f;  // per-lane partials (<= rows terms each)
   // in-sweep smoothness state: normalised / raw disparity of the previous row, its pending gradient
   const bool smooth = GRAD && p.smooth_mean != nullptr;
@@ -206,96 +392,162 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   float sm_n1 = 0.f, sm_d1 = 0.f, sm_g1 = 0.f;
   float acc_sx = 0.f, acc_sy = 0.f, acc_sd = 0.f;  // per-lane partials over <= rows pixels: fp32, widened at the wave sum
 #pragma unroll
-  for (int i = 0; i < 24; ++i) { hsA[i] = 0.f; hsB[i] = 0.f; }
+  for (int i = 0; i < 9; ++i) { hsA[i] = bc(0.f); hsB[i] = bc(0.f); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { hyA[i] = bc(0.f); hyB[i] = bc(0.f); hzA[i] = 0.f; hzB[i] = 0.f; }
   if (GRAD)
 #pragma unroll
-    for (int i = 0; i < 18; ++i) { hcA[i] = 0.f; hcB[i] = 0.f; }
+    for (int i = 0; i < 9; ++i) { hcA[i] = bc(0.f); hcB[i] = bc(0.f); }
   if (POSE)
 #pragma unroll
-    for (int i = 0; i < 24; ++i) gP[i] = 0.f;
+    for (int i = 0; i < 12; ++i) gP[i] = bc(0.f);
   pi1.rp = 0.f; pi1.w = 0.f; pi1.win = 0;
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) { w1.x[0][ch] = w1.x[1][ch] = 0.f; w1.y[ch] = 0.f; }
+  for (int k = 0; k < 3; ++k) w1.x[k] = bc(0.f);
+  w1.yrg = bc(0.f); w1.yb = 0.f;
 
   // rows r = y_lo-HALO .. y_hi-1+HALO are warped (reflected when outside the image; row -2 is never
   // needed); the statistics row is c = r-1, the gradient row q = r-2
   // what the gradient row (two iterations behind the warped row) needs of its pixel -- the warped
   // values, the target and the chain-rule numbers -- waits in a 3-slot per-lane LDS ring (no bank
   // conflicts: lane-private dwords; no barrier: one wavefront) instead of ~50 registers or a re-warp
-  constexpr int RING = GRAD ? (POSE ? 21 : 15) : 1;
+  constexpr int RING = GRAD ? (POSE ? 24 : 12) : 1;  // x, then (du, dv, u/v/rz) or e; the target row is re-read from memory
   __shared__ float s_ring[GRAD ? 3 : 1][RING][64];
   int it = 0;
   const int r_first = max(y_lo - HALO, -1), r_last = y_hi - 1 + HALO;
+  // A wave runs its stages in order and the vector-memory counter retires in order, so a load that is
+  // waited for soon after it was issued exposes a full memory round trip (two waves per SIMD hide little),
+  // and so does any wait that follows younger loads.  Hence EVERY per-pixel operand except the gathers is
+  // requested one iteration ahead (struct Ahead): the only wait for them sits at the top of the next
+  // iteration, when they have had a whole iteration to arrive.  The gathers are issued as soon as the
+  // projection allows; the work that does not need them sits between their issue and the blend.
+  struct Ahead {
+    float disp, disp2, y[3];                      // the row to warp
+    float ident, noise, ext, mono, cost;          // statistics row c
+    float e_mono, e_mr, e_er;                     // epilogue row
+  };
+  auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
+  // everything iteration `rr` will need, from the parameter block `pp`
+  auto request = [&](CParams& pp, int rr, Ahead& a) {
+    const int packed_t = pp.packed & 2;
+    const unsigned pix = (unsigned)(row_of(rr) * W + gxr);
+    a.disp = ldf(disp_b, pix * 4u);
+    a.disp2 = disp2_b ? ldf(disp2_b, pix * 4u) : 0.f;
+    load_rgb(pp.target, packed_t, b, HW, pix, a.y);
+    const unsigned oc = (unsigned)(min(max(rr - 1, 0), H - 1) * W + gxr) * 4u;  // statistics row c = rr-1
+    a.ident = 0.f; a.noise = 0.f; a.ext = 1.f; a.mono = 0.f; a.cost = 1.f;
+    if (AUTOMASK) { a.ident = ldf(pp.ident + map_b, oc); if (pp.noise) a.noise = ldf(pp.noise + map_b, oc); }
+    if (pp.ext_mask) {
+      a.ext = ldf(pp.ext_mask + map_b, oc);
+      if (pp.lowest_cost) { a.mono = ldf(pp.mono_disp + map_b, oc); a.cost = ldf(pp.lowest_cost + map_b, oc); }
+    }
+    const unsigned oq = (unsigned)(min(max(GRAD ? rr - 2 : rr - 1, 0), H - 1) * W + gxr) * 4u;  // epilogue row
+    a.e_mono = 0.f; a.e_mr = 0.f; a.e_er = 0.f;
+    if (EPI) {
+      a.e_mono = pp.mono_disp ? ldf(pp.mono_disp + map_b, oq) : ldf(pp.mono_depth + map_b, oq);
+      a.e_mr = ldf(pp.mono_reproj + map_b, oq);
+      if (pp.ens_reproj) a.e_er = ldf(pp.ens_reproj + map_b, oq);
+    }
+  };
+  Ahead nxt;
+  request(p, r_first, nxt);
+  // reciprocals of the grid normalisation's divisors, once per wave (scalar registers)
+  const float norm_rw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
+      int, refined_rcp(p.convention == 0 ? (float)(W - 1) : (float)W))));
+  const float norm_rh = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
+      int, refined_rcp(p.convention == 0 ? (float)(H - 1) : (float)H))));
+  // experiments (mal_set_option("debug", 64)): cycles per stage of this wave, written over min_reproj[task*8..]
+#ifdef MAL_STAGE_TIMERS  // build with -DMAL_STAGE_TIMERS for scripts/gpu_stage_times.py
+  unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = clock64();
+#endif
+  f2 y2rg = bc(0.f);
+  float y2b = 0.f;  // target pixel of row r-2
+  float dv_1 = 0.f, dv_2 = 0.f;  // disparity of rows r-1, r-2 (the pose terms of the gradient row re-project it)
   for (int r = r_first; r <= r_last; ++r, ++it) {
     CParams* kp = kp0;
     asm volatile("" : "+s"(kp));
     CParams& p = *kp;
-    // ---- the small per-pixel operands of this iteration's later stages are requested first, so their
-    // latency overlaps the warp (loads sitting behind a wave-uniform branch are not hoisted by the compiler)
-    const size_t gic = map_b + (size_t)min(max(r - 1, 0), H - 1) * W + gxr;  // statistics row c = r-1
-    float ld_ident = 0.f, ld_noise = 0.f, ld_ext = 1.f, ld_mono = 0.f, ld_cost = 1.f;
-    if (AUTOMASK) { ld_ident = p.ident[gic]; if (p.noise) ld_noise = p.noise[gic]; }
-    if (p.ext_mask) {
-      ld_ext = p.ext_mask[gic];
-      if (p.lowest_cost) { ld_mono = p.mono_disp[gic]; ld_cost = p.lowest_cost[gic]; }
-    }
-    const int qe = GRAD ? r - 2 : r - 1;                                     // epilogue row
-    const size_t giq = map_b + (size_t)min(max(qe, 0), H - 1) * W + gxr;
-    float le_disp = 0.f, le_mono = 0.f, le_mr = 0.f, le_er = 0.f;
-    if (EPI) {
-      le_disp = disp_b[giq - map_b];
-      le_mono = p.mono_disp ? p.mono_disp[giq] : p.mono_depth[giq];
-      le_mr = p.mono_reproj[giq];
-      if (p.ens_reproj) le_er = p.ens_reproj[giq];
-    }
+    PixInfo pi0;  // what stage S decides for the centre row c = r-1
+    pi0.rp = 0.f; pi0.w = 0.f; pi0.win = 0;
+    const bool has_noise = AUTOMASK && p.noise != nullptr, has_ext = p.ext_mask != nullptr,
+               has_cost = p.lowest_cost != nullptr, has_mdisp = p.mono_disp != nullptr,
+               has_er = EPI && p.ens_reproj != nullptr;
+    WarpConsts wc;
+    wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = p.packed; wc.debug = p.debug; wc.W = W; wc.H = H;
+    wc.convention = p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
+    wc.rw = norm_rw; wc.rh = norm_rh;
+#ifdef MAL_STAGE_TIMERS
+    auto tick = [&](int i) {
+      if (wc.debug & 64) { const unsigned long long t = clock64(); tacc[i] += (unsigned)(t - tprev); tprev = t; }
+    };
+#else
+    auto tick = [](int) {};
+#endif
+    tick(0);  // loop overhead + parameter loads
+    // ---- what the previous iteration requested for this one
+    const Ahead cur = nxt;
+    const float ld_ident = cur.ident, ld_noise = cur.noise, ld_ext = cur.ext, ld_mono = cur.mono, ld_cost = cur.cost;
+    const float le_disp = GRAD ? dv_2 : dv_1;  // the epilogue row's own disparity (rows r-2 / r-1 of this sweep)
+    const float le_mono = cur.e_mono, le_mr = cur.e_mr, le_er = cur.e_er;
     // ================= stage W: warp row r (reflected if outside the image) ==================
-    const int gyr = min(max(reflect1(r, H), 0), H - 1);
+    const int gyr = row_of(r);
     WarpRow w0;
-    float dv_ = disp_b[gyr * W + gxr];
+    const float dv_ = disp2_b ? (cur.disp + cur.disp2) / 2.0f : cur.disp;
+    w0.yrg = (f2){cur.y[0], cur.y[1]}; w0.yb = cur.y[2];
+    PendingWarp pw;
     {
-      if (disp2_b) dv_ = (dv_ + disp2_b[gyr * W + gxr]) / 2.0f;
-      DerivRow d0;
-      float P[2][12], ik[9];
+      f2 P[12];
+      float ik[9];
       load_cam(cam_b, P, ik);
-      warp_px<GRAD, POSE>(p, P, ik, b, gyr, gxr, dv_, w0, d0);
-      if (GRAD) {
+      // the next iteration's operands go out between the projection and the gathers (older in the queue)
+      warp_issue<GRAD, POSE>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(p, r + 1, nxt); });
+    }
+    tick(1);  // small loads, prefetch, projection, gathers issued
+    auto finish_warp = [&]() {
+      DerivRow d0;
+      warp_finish<GRAD, POSE>(pw, w0.x, d0);
+      if (GRAD && !(wc.debug & 2)) {
         float (*slot)[64] = s_ring[it % 3];
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            slot[f * 3 + ch][lane] = w0.x[f][ch];
-            if (POSE) { slot[9 + f * 3 + ch][lane] = d0.du[f][ch]; slot[15 + f * 3 + ch][lane] = d0.dv[f][ch]; }
-            else slot[9 + f * 3 + ch][lane] = d0.e[f][ch];
+        for (int k = 0; k < 3; ++k) {
+          slot[2 * k][lane] = w0.x[k].x; slot[2 * k + 1][lane] = w0.x[k].y;
+          if (POSE) {
+            slot[6 + 2 * k][lane] = d0.du[k].x; slot[6 + 2 * k + 1][lane] = d0.du[k].y;
+            slot[12 + 2 * k][lane] = d0.dv[k].x; slot[12 + 2 * k + 1][lane] = d0.dv[k].y;
+          } else {
+            slot[6 + 2 * k][lane] = d0.e[k].x; slot[6 + 2 * k + 1][lane] = d0.e[k].y;
           }
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) slot[6 + ch][lane] = w0.y[ch];
+        }
+        if (POSE) {
+          slot[18][lane] = pw.u.x; slot[19][lane] = pw.u.y; slot[20][lane] = pw.v.x; slot[21][lane] = pw.v.y;
+          slot[22][lane] = pw.rz.x; slot[23][lane] = pw.rz.y;
+        }
       }
-    }
+    };
 
     // ================= smoothness of row r (edges to the right and up), finishing row r-1 ======
-    if (smooth) {
-      auto sgnf = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+    if (smooth && !(wc.debug & 16)) {
       const bool row_ok = r >= 0 && r < H;
       const float n0 = dv_ * sm_inv;
       // right edge (r,x)-(r,x+1): exists for in-image x with x+1 < W
       const float nR = dpp_shl1(n0);
-      const float eR = (fabsf(w0.y[0] - dpp_shl1(w0.y[0])) + fabsf(w0.y[1] - dpp_shl1(w0.y[1]))) +
-                       fabsf(w0.y[2] - dpp_shl1(w0.y[2]));
+      const float eR = (fabsf(w0.yrg.x - dpp_shl1(w0.yrg.x)) + fabsf(w0.yrg.y - dpp_shl1(w0.yrg.y))) +
+                       fabsf(w0.yb - dpp_shl1(w0.yb));
       const bool hx = row_ok && in_x && gx + 1 < W;
-      const float wxr = hx ? expf(-(eR * (1.0f / 3.0f))) : 0.f;
+      const float wxr = hx ? __expf(-(eR * (1.0f / 3.0f))) : 0.f;
       const float dfx = n0 - nR;
       const float sx = sgnf(dfx) * wxr * sm_nx;
       // up edge (r-1,x)-(r,x): exists when both rows are image rows
       const bool vy = row_ok && r >= 1 && in_x;
-      const float eU = (fabsf(w1.y[0] - w0.y[0]) + fabsf(w1.y[1] - w0.y[1])) + fabsf(w1.y[2] - w0.y[2]);
-      const float wyu_ = vy ? expf(-(eU * (1.0f / 3.0f))) : 0.f;
+      const float eU = (fabsf(w1.yrg.x - w0.yrg.x) + fabsf(w1.yrg.y - w0.yrg.y)) + fabsf(w1.yb - w0.yb);
+      const float wyu_ = vy ? __expf(-(eU * (1.0f / 3.0f))) : 0.f;
       const float dfy = sm_n1 - n0;
       const float sy = sgnf(dfy) * wyu_ * sm_ny;
       const int qs = r - 1;  // row finished now: its down edge is this up edge
       if (qs >= y_lo && qs < y_hi && out_x) {
         const float g = sm_g1 + sy;
-        p.smooth_gn[map_b + (size_t)qs * W + gxr] = g;
+        stf(p.smooth_gn + map_b, (unsigned)(qs * W + gxr) * 4u, g);
         acc_sy += fabsf(dfy) * wyu_;
         acc_sd += g * sm_d1;
       }
@@ -305,209 +557,21 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       sm_d1 = dv_;
     }
 
-    // ================= stage H: horizontal 3-sums of row r ====================================
-    float h[24];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      const float y = w0.y[ch];
-      h[18 + ch] = hsum3(y);
-      h[21 + ch] = hsum3(y * y);
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const float x = w0.x[f][ch];
-        h[f * 9 + ch * 3 + 0] = hsum3(x);
-        h[f * 9 + ch * 3 + 1] = hsum3(x * x);
-        h[f * 9 + ch * 3 + 2] = hsum3(x * y);
-      }
-    }
-
-    // ================= stage S: statistics of centre row c = r-1 ==============================
-    const int c = r - 1;
-    const bool c_valid = c >= 0 && c < H && c >= y_lo - (HALO - 1) && c <= y_hi - 1 + (HALO - 1);
-    PixInfo pi0;
-    pi0.rp = 0.f; pi0.w = 0.f; pi0.win = 0;
-    float coef[GRAD ? 9 : 1];
-    if (GRAD)
-#pragma unroll
-      for (int i = 0; i < 9; ++i) coef[i] = 0.f;
-    if (c_valid) {  // wave-uniform
-      float ssum[2], lsum[2];
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float sy = hsA[18 + ch] + h[18 + ch], syy = hsA[21 + ch] + h[21 + ch];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          const float sx = hsA[f * 9 + ch * 3] + h[f * 9 + ch * 3];
-          const float sxx = hsA[f * 9 + ch * 3 + 1] + h[f * 9 + ch * 3 + 1];
-          const float sxy = hsA[f * 9 + ch * 3 + 2] + h[f * 9 + ch * 3 + 2];
-          const float vc = clamp01(ssim_sums<false>(sx, sy, sxx, syy, sxy, nullptr, nullptr, nullptr));
-          ssum[f] = ch == 0 ? vc : ssum[f] + vc;
-          const float l1 = fabsf(w1.y[ch] - w1.x[f][ch]);
-          lsum[f] = ch == 0 ? l1 : lsum[f] + l1;
-        }
-      }
-      const float r0 = 0.85f * div3_(ssum[0]) + 0.15f * div3_(lsum[0]);
-      const float r1 = 0.85f * div3_(ssum[1]) + 0.15f * div3_(lsum[1]);
-      pi0.win = (r1 < r0) ? 1 : 0;
-      pi0.rp = pi0.win ? r1 : r0;
-      float w = 1.0f;
-      const size_t gi = map_b + (size_t)c * W + gxr;
-      if (AUTOMASK) {
-        float idn = ld_ident;
-        if (p.noise) idn += ld_noise * 0.00001f;
-        w = (pi0.rp <= idn) ? 1.0f : 0.0f;
-      }
-      if (p.ext_mask) {
-        float em = ld_ext;
-        if (p.lowest_cost) {  // consistency_mask *= compute_matching_mask (trainer.py:592-593,1066-1076)
-          const float mono = depth_of(ld_mono, p.min_disp, p.range);
-          const float matching = div_safe_(1.0f, ld_cost);
-          const bool ok = (div_safe_(matching - mono, mono) < 1.0f) && (div_safe_(mono - matching, matching) < 1.0f);
-          em = ok ? em : em * 0.0f;
-          if (p.cmask_out && out_x && c >= y_lo && c < y_hi) p.cmask_out[gi] = em;
-        }
-        w *= em;
-      }
-      w *= sscale;
-      if (!in_x) w = 0.f;  // not a pixel: contributes nothing (its statistics only served as halo)
-      pi0.w = w;
-      if (out_x && c >= y_lo && c < y_hi) {
-        if (p.min_reproj) p.min_reproj[gi] = pi0.rp;
-        acc_rw += pi0.rp * w;
-        acc_w += w;
-      }
-      if (GRAD) {
-        // partials of the WINNING candidate only (its window sums are re-formed from the running sums)
-        // w * 0.85/3 (channel mean) * -1/2 (v = (1-S)/2); the box mean's 1/9 lives in the sums
-        const float kk = -w * (0.85f / 3.0f) * 0.5f;
-        const bool w1_ = pi0.win != 0;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const float sy = hsA[18 + ch] + h[18 + ch], syy = hsA[21 + ch] + h[21 + ch];
-          const float sx = (w1_ ? hsA[9 + ch * 3] : hsA[ch * 3]) + (w1_ ? h[9 + ch * 3] : h[ch * 3]);
-          const float sxx = (w1_ ? hsA[9 + ch * 3 + 1] : hsA[ch * 3 + 1]) + (w1_ ? h[9 + ch * 3 + 1] : h[ch * 3 + 1]);
-          const float sxy = (w1_ ? hsA[9 + ch * 3 + 2] : hsA[ch * 3 + 2]) + (w1_ ? h[9 + ch * 3 + 2] : h[ch * 3 + 2]);
-          float a, bq, cq;
-          const float v = ssim_sums<true>(sx, sy, sxx, syy, sxy, &a, &bq, &cq);
-          const float g = (v >= 0.0f && v <= 1.0f) ? kk : 0.0f;
-          coef[ch * 3 + 0] = g * a;
-          coef[ch * 3 + 1] = g * 2.0f * bq;  // d(sum x^2)/dx = 2x
-          coef[ch * 3 + 2] = g * cq;
-        }
-      }
-    }
-
-    if (GRAD) {
-      // ================= stage HC: horizontal sums of the partial planes of row c ==============
-      float hc[18];
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          const float v = (pi0.win == f) ? coef[i] : 0.f;
-          float l = v, rr = v;
-          if (strip_border) { l = v * sL; rr = v * sR; }
-          hc[f * 9 + i] = (dpp_shr1(l) + v) + dpp_shl1(rr);
-        }
-      // ================= stage G: output row q = c-1 = r-2 ======================================
-      const int q = r - 2;
-      if (q >= y_lo && q < y_hi) {  // wave-uniform; q is always inside the image
-        WarpRow wq;
-        DerivRow dq;
-        {
-          float (*slot)[64] = s_ring[(it + 1) % 3];  // written two iterations ago
-#pragma unroll
-          for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-              wq.x[f][ch] = slot[f * 3 + ch][lane];
-              if (POSE) { dq.du[f][ch] = slot[9 + f * 3 + ch][lane]; dq.dv[f][ch] = slot[15 + f * 3 + ch][lane]; }
-              else dq.e[f][ch] = slot[9 + f * 3 + ch][lane];
-            }
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) wq.y[ch] = slot[6 + ch][lane];
-        }
-        float alq[2] = {0.f, 0.f}, beq[2] = {0.f, 0.f};
-        if (POSE) {  // the projection of row q re-derived from its disparity (no gathers)
-          const float depth = depth_of(disp_b[q * W + gxr], p.min_disp, p.range);
-          const float ddepth = -(depth * depth) * p.range;
-          float ray[3], P[2][12], ik[9];
-          load_cam(cam_b, P, ik);
-          ray_of(ik, (float)gxr, (float)q, ray);
-          dq.X[0] = depth * ray[0]; dq.X[1] = depth * ray[1]; dq.X[2] = depth * ray[2];
-#pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            const Sample sm = project_pixel(P[f], dq.X, p.eps, W, H, p.convention);
-            dq.rz[f] = sm.rz; dq.u[f] = sm.u; dq.v[f] = sm.v;
-            const float c0 = P[f][0] * ray[0] + P[f][1] * ray[1] + P[f][2] * ray[2];
-            const float c1 = P[f][4] * ray[0] + P[f][5] * ray[1] + P[f][6] * ray[2];
-            const float c2 = P[f][8] * ray[0] + P[f][9] * ray[1] + P[f][10] * ray[2];
-            alq[f] = (c0 - sm.u * c2) * sm.rz * ddepth;  // d u / d disp (the clip gate is inside du, dv)
-            beq[f] = (c1 - sm.v * c2) * sm.rz * ddepth;
-          }
-        }
-        const float wyd = (q == H - 2) ? 2.0f : 1.0f;  // row q+1 = c is the bottom border row
-        float gdisp = 0.f, gu[2] = {0.f, 0.f}, gv[2] = {0.f, 0.f};
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            const float SA = fma_(wyd, hc[f * 9 + ch * 3], hcA[f * 9 + ch * 3]);
-            const float SB = fma_(wyd, hc[f * 9 + ch * 3 + 1], hcA[f * 9 + ch * 3 + 1]);
-            const float SC = fma_(wyd, hc[f * 9 + ch * 3 + 2], hcA[f * 9 + ch * 3 + 2]);
-            const float xq = wq.x[f][ch], yq = wq.y[ch];
-            float g = SA + SB * xq + SC * yq;
-            if (pi1.win == f) {
-              const float df = xq - yq;
-              g += pi1.w * (0.15f / 3.0f) * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
-            }
-            if (POSE) { gu[f] = fma_(g, dq.du[f][ch], gu[f]); gv[f] = fma_(g, dq.dv[f][ch], gv[f]); }
-            else gdisp = fma_(g, dq.e[f][ch], gdisp);
-          }
-        if (POSE) gdisp = (gu[0] * alq[0] + gv[0] * beq[0]) + (gu[1] * alq[1] + gv[1] * beq[1]);
-        const size_t gi = map_b + (size_t)q * W + gxr;
-        if (out_x) p.g_reproj[gi] = gdisp;
-        if (POSE && out_x) {
-#pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            const float a0 = gu[f] * dq.rz[f], a1 = gv[f] * dq.rz[f];
-            const float a2 = -(gu[f] * dq.u[f] + gv[f] * dq.v[f]) * dq.rz[f];
-            const float a[3] = {a0, a1, a2};
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-              for (int j = 0; j < 3; ++j) gP[f * 12 + i * 4 + j] = fma_(a[i], dq.X[j], gP[f * 12 + i * 4 + j]);
-              gP[f * 12 + i * 4 + 3] += a[i];
-            }
-          }
-        }
-      }
-      // roll the partial-plane sums: (row c: top+mid) <- (row c: top) + hc(c) ; (row c+1: top) <- hc(c)
-      {
-        const float wyu = (c == 0) ? 2.0f : 1.0f;  // hc(c) as the TOP neighbour of row c+1: doubled if c is row 0
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {
-          hcA[i] = hcB[i] + hc[i];
-          hcB[i] = wyu * hc[i];
-        }
-      }
-    }
-
     // ================= epilogue terms of output row (EPI): row q = r-2 with GRAD, c without ===
-    if (EPI) {
+    auto epilogue = [&]() {
       const int q = GRAD ? r - 2 : r - 1;
       const PixInfo& pq = GRAD ? pi1 : pi0;
       if (q >= y_lo && q < y_hi && out_x) {
-        const size_t gi = map_b + (size_t)q * W + gxr;
-        const float dm = depth_of(le_disp, p.min_disp, p.range);
-        const float ddepth = -(dm * dm) * p.range;
-        const float dmono = p.mono_disp ? depth_of(le_mono, p.min_disp, p.range) : le_mono;
+        const unsigned go = (unsigned)(q * W + gxr) * 4u;
+        const float dm = depth_of(le_disp, wc.min_disp, wc.range);
+        const float ddepth = -(dm * dm) * wc.range;
+        const float dmono = has_mdisp ? depth_of(le_mono, wc.min_disp, wc.range) : le_mono;
         const float m = pq.w, cm = 1.0f - m, mm = 1.0f - cm;
         const float dc = dm - dmono;
         acc_cons += fabsf(dc) * cm;
         int idx = 0;
         float best = le_mr;
-        if (p.ens_reproj) {
+        if (has_er) {
           const float r_ens = le_er;
           if (r_ens < best) { best = r_ens; idx = 1; }
         }
@@ -516,30 +580,229 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
         const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
         const float dd = target - dm;
         acc_dist += fabsf(dd) * mm;
-        if (p.cons_target) p.cons_target[gi] = div_(1.0f, dmono * cm + dm * (1.0f - cm));
+        if (p.cons_target) stf(p.cons_target + map_b, go, div_(1.0f, dmono * cm + dm * (1.0f - cm)));
         if (GRAD) {
-          const float sc = dc > 0.f ? 1.f : (dc < 0.f ? -1.f : 0.f);
-          const float sd = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
-          p.g_cons[gi] = sc * cm * ddepth;
-          p.g_distil[gi] = sd * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : -0.5f)) * mm * ddepth;
+          stf(p.g_cons + map_b, go, sgnf(dc) * cm * ddepth);
+          stf(p.g_distil + map_b, go, sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : -0.5f)) * mm * ddepth);
+        }
+      }
+    };
+    if (EPI && GRAD) epilogue();
+    tick(2);  // smoothness, epilogue terms
+    finish_warp();
+    tick(3);  // gather wait, blend, ring write
+
+    // ================= stage H: horizontal 3-sums of row r ====================================
+    f2 h[9], hy[2];
+    float hz[2];
+    hy[0] = hsum3(w0.yrg); hy[1] = hsum3(w0.yrg * w0.yrg);
+    hz[0] = hsum3(w0.yb);  hz[1] = hsum3(w0.yb * w0.yb);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f2 x = w0.x[k], y = k < 2 ? w0.yrg : bc(w0.yb);
+      h[k * 3 + 0] = hsum3(x);
+      h[k * 3 + 1] = hsum3(x * x);
+      h[k * 3 + 2] = hsum3(x * y);
+    }
+
+    tick(4);  // horizontal sums
+    // ================= stage S: statistics of centre row c = r-1 ==============================
+    const int c = r - 1;
+    const bool c_valid = c >= 0 && c < H && c >= y_lo - (HALO - 1) && c <= y_hi - 1 + (HALO - 1);
+    f2 coef[GRAD ? 9 : 1];
+    if (GRAD)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) coef[i] = bc(0.f);
+    if (c_valid && !(wc.debug & 8)) {  // wave-uniform
+      // the target's side of the statistics, shared by the two candidates
+      const f2 syq = hyA[0] + hy[0], syyq = hyA[1] + hy[1];
+      const float syz = hzA[0] + hz[0], syyz = hzA[1] + hz[1];
+      const f2 vyq = fma2(-syq, syq, bc(9.0f) * syyq), d1yq = fma2(syq, syq, bc(kC1s));
+      const float vyz = fma_(-syz, syz, 9.0f * syyz), d1yz = fma_(syz, syz, kC1s);
+      f2 v[3], vc[3], pa[GRAD ? 3 : 1], pb[GRAD ? 3 : 1], pcq[GRAD ? 3 : 1];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f2 sx = hsA[k * 3] + h[k * 3], sxx = hsA[k * 3 + 1] + h[k * 3 + 1], sxy = hsA[k * 3 + 2] + h[k * 3 + 2];
+        v[k] = ssim_sums2<GRAD>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
+                                &pa[GRAD ? k : 0], &pb[GRAD ? k : 0], &pcq[GRAD ? k : 0]);
+        vc[k] = (f2){clamp01(v[k].x), clamp01(v[k].y)};
+      }
+      const f2 ssum = (f2){(vc[0].x + vc[0].y) + vc[2].x, (vc[1].x + vc[1].y) + vc[2].y};
+      const f2 l0 = w1.yrg - w1.x[0], l1 = w1.yrg - w1.x[1], l2 = bc(w1.yb) - w1.x[2];
+      const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
+      const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
+      pi0.win = (rr.y < rr.x) ? 1 : 0;
+      pi0.rp = pi0.win ? rr.y : rr.x;
+      float w = 1.0f;
+      const unsigned go = (unsigned)(c * W + gxr) * 4u;
+      if (AUTOMASK) {
+        float idn = ld_ident;
+        if (has_noise) idn += ld_noise * 0.00001f;
+        w = (pi0.rp <= idn) ? 1.0f : 0.0f;
+      }
+      if (has_ext) {
+        float em = ld_ext;
+        if (has_cost) {  // consistency_mask *= compute_matching_mask (trainer.py:592-593,1066-1076)
+          const float mono = depth_of(ld_mono, wc.min_disp, wc.range);
+          const float matching = div_safe_(1.0f, ld_cost);
+          const bool ok = (div_safe_(matching - mono, mono) < 1.0f) && (div_safe_(mono - matching, matching) < 1.0f);
+          em = ok ? em : em * 0.0f;
+          if (p.cmask_out && out_x && c >= y_lo && c < y_hi) stf(p.cmask_out + map_b, go, em);
+        }
+        w *= em;
+      }
+      w *= sscale;
+      if (!in_x) w = 0.f;  // not a pixel: contributes nothing (its statistics only served as halo)
+      pi0.w = w;
+      if (out_x && c >= y_lo && c < y_hi) {
+        if (p.min_reproj) stf(p.min_reproj + map_b, go, pi0.rp);
+        acc_rw += pi0.rp * w;
+        acc_w += w;
+      }
+      if (GRAD) {
+        // partials of the WINNING candidate only: w * 0.85/3 (channel mean) * -1/2 (v = (1-S)/2); the box
+        // mean's 1/9 lives in the sums; torch.clamp passes gradient on [0,1] inclusive (clamped == raw)
+        const float kk = -w * (0.85f / 3.0f) * 0.5f;
+        const float kk0 = pi0.win == 0 ? kk : 0.f, kk1 = pi0.win != 0 ? kk : 0.f;
+        const f2 g0 = (f2){vc[0].x == v[0].x ? kk0 : 0.f, vc[0].y == v[0].y ? kk0 : 0.f};
+        const f2 g1 = (f2){vc[1].x == v[1].x ? kk1 : 0.f, vc[1].y == v[1].y ? kk1 : 0.f};
+        const f2 g2 = (f2){vc[2].x == v[2].x ? kk0 : 0.f, vc[2].y == v[2].y ? kk1 : 0.f};
+        const f2 gk[3] = {g0, g1, g2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          coef[k * 3 + 0] = gk[k] * pa[k];
+          coef[k * 3 + 1] = gk[k] * pb[k];
+          coef[k * 3 + 2] = gk[k] * pcq[k];
         }
       }
     }
+
+    tick(5);  // statistics, SSIM, masks
+    if (GRAD) {
+      // ================= stage HC: horizontal sums of the partial planes of row c ==============
+      f2 hc[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const f2 vv = coef[i], l = vv * bc(sL), rr = vv * bc(sR);
+        hc[i] = (f2){(dpp_shr1(l.x) + vv.x) + dpp_shl1(rr.x), (dpp_shr1(l.y) + vv.y) + dpp_shl1(rr.y)};
+      }
+      // ================= stage G: output row q = c-1 = r-2 ======================================
+      const int q = r - 2;
+      if (q >= y_lo && q < y_hi && !(wc.debug & 4)) {  // wave-uniform; q is always inside the image
+        WarpRow wq;
+        DerivRow dq;
+        f2 pq_u = bc(0.f), pq_v = bc(0.f), pq_rz = bc(0.f);
+        {
+          float (*slot)[64] = s_ring[(it + 1) % 3];  // written two iterations ago
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            wq.x[k] = (f2){slot[2 * k][lane], slot[2 * k + 1][lane]};
+            if (POSE) {
+              dq.du[k] = (f2){slot[6 + 2 * k][lane], slot[6 + 2 * k + 1][lane]};
+              dq.dv[k] = (f2){slot[12 + 2 * k][lane], slot[12 + 2 * k + 1][lane]};
+            } else {
+              dq.e[k] = (f2){slot[6 + 2 * k][lane], slot[6 + 2 * k + 1][lane]};
+            }
+          }
+          if (POSE) {
+            pq_u = (f2){slot[18][lane], slot[19][lane]}; pq_v = (f2){slot[20][lane], slot[21][lane]};
+            pq_rz = (f2){slot[22][lane], slot[23][lane]};
+          }
+          wq.yrg = y2rg; wq.yb = y2b;  // target of row q = r-2, kept from its own iteration
+        }
+        const float wyd = (q == H - 2) ? 2.0f : 1.0f;  // row q+1 = c is the bottom border row
+        // L1 term of the winner: w * 0.15/3 * sign(x - y)
+        const float lw = pi1.w * (0.15f / 3.0f);
+        const float lw0 = pi1.win == 0 ? lw : 0.f, lw1 = pi1.win != 0 ? lw : 0.f;
+        const f2 lwk[3] = {bc(lw0), bc(lw1), (f2){lw0, lw1}};
+        f2 g[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const f2 SA = fma2(bc(wyd), hc[k * 3], hcA[k * 3]);
+          const f2 SB = fma2(bc(wyd), hc[k * 3 + 1], hcA[k * 3 + 1]);
+          const f2 SC = fma2(bc(wyd), hc[k * 3 + 2], hcA[k * 3 + 2]);
+          const f2 xq = wq.x[k], yq = k < 2 ? wq.yrg : bc(wq.yb);
+          const f2 df = xq - yq;
+          const f2 sg = (f2){sgnf(df.x), sgnf(df.y)};
+          g[k] = fma2(lwk[k], sg, fma2(SC, yq, fma2(SB, xq, SA)));
+        }
+        float gdisp;
+        if (POSE) {
+          // u, v, 1/z of row q come back from the ring; its point and the depth derivatives are re-derived
+          const float depth = depth_of(dv_2, wc.min_disp, wc.range);
+          const float ddepth = -(depth * depth) * wc.range;
+          float ray[3], ik[9], X[3];
+          f2 P[12];
+          load_cam(cam_b, P, ik);
+          ray_of(ik, (float)gxr, (float)q, ray);
+          X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
+          const f2 c0 = P[0] * bc(ray[0]) + P[1] * bc(ray[1]) + P[2] * bc(ray[2]);
+          const f2 c1 = P[4] * bc(ray[0]) + P[5] * bc(ray[1]) + P[6] * bc(ray[2]);
+          const f2 c2 = P[8] * bc(ray[0]) + P[9] * bc(ray[1]) + P[10] * bc(ray[2]);
+          const f2 alq = (c0 - pq_u * c2) * pq_rz * bc(ddepth);  // d u / d disp (the clip gate is inside du, dv)
+          const f2 beq = (c1 - pq_v * c2) * pq_rz * bc(ddepth);
+          const f2 tu0 = g[0] * dq.du[0], tu1 = g[1] * dq.du[1], tu2 = g[2] * dq.du[2];
+          const f2 tv0 = g[0] * dq.dv[0], tv1 = g[1] * dq.dv[1], tv2 = g[2] * dq.dv[2];
+          const f2 gu = (f2){(tu0.x + tu0.y) + tu2.x, (tu1.x + tu1.y) + tu2.y};
+          const f2 gv = (f2){(tv0.x + tv0.y) + tv2.x, (tv1.x + tv1.y) + tv2.y};
+          const f2 gd = gu * alq + gv * beq;
+          gdisp = gd.x + gd.y;
+          if (out_x) {
+            const f2 a0 = gu * pq_rz, a1 = gv * pq_rz, a2 = -(gu * pq_u + gv * pq_v) * pq_rz;
+            const f2 a[3] = {a0, a1, a2};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+              for (int j = 0; j < 3; ++j) gP[i * 4 + j] = fma2(a[i], bc(X[j]), gP[i * 4 + j]);
+              gP[i * 4 + 3] += a[i];
+            }
+          }
+        } else {
+          const f2 t0 = g[0] * dq.e[0], t1 = g[1] * dq.e[1], t2 = g[2] * dq.e[2];
+          const f2 ts = (t0 + t1) + t2;
+          gdisp = ts.x + ts.y;
+        }
+        if (out_x) stf(p.g_reproj + map_b, (unsigned)(q * W + gxr) * 4u, gdisp);
+      }
+      // roll the partial-plane sums: (row c: top+mid) <- (row c: top) + hc(c) ; (row c+1: top) <- hc(c)
+      {
+        const float wyu = (c == 0) ? 2.0f : 1.0f;  // hc(c) as the TOP neighbour of row c+1: doubled if c is row 0
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          hcA[i] = hcB[i] + hc[i];
+          hcB[i] = bc(wyu) * hc[i];
+        }
+      }
+    }
+
+    tick(6);  // partial-plane sums, gradient row
+    if (EPI && !GRAD) epilogue();
     if (p.depth_out) {
       const int q = r - 1;
       if (q >= y_lo && q < y_hi && out_x)
-        p.depth_out[map_b + (size_t)q * W + gxr] = depth_of(disp_b[q * W + gxr], p.min_disp, p.range);
+        stf(p.depth_out + map_b, (unsigned)(q * W + gxr) * 4u, depth_of(ldf(disp_b, (unsigned)(q * W + gxr) * 4u), wc.min_disp, wc.range));
     }
 
     // ================= roll the row state =====================================================
 #pragma unroll
-    for (int i = 0; i < 24; ++i) {
+    for (int i = 0; i < 9; ++i) {
       hsA[i] = hsB[i] + h[i];
       hsB[i] = h[i];
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      hyA[i] = hyB[i] + hy[i]; hyB[i] = hy[i];
+      hzA[i] = hzB[i] + hz[i]; hzB[i] = hz[i];
+    }
+    if (GRAD) { y2rg = w1.yrg; y2b = w1.yb; }
     w1 = w0;
     if (GRAD) pi1 = pi0;
+    dv_2 = dv_1; dv_1 = dv_;
+    tick(7);  // rolls
   }
+#ifdef MAL_STAGE_TIMERS
+  if ((p.debug & 64) && lane < 8 && p.min_reproj) p.min_reproj[(size_t)task * 8 + lane] = (float)tacc[lane];
+#endif
 
   // ---- per-task partials (fixed-order second stage in pass_finalize_kernel)
   const double r0 = wave_sum_d((double)acc_rw), r1 = wave_sum_d((double)acc_w);
@@ -552,11 +815,11 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     const double q0 = wave_sum_d((double)acc_sx), q1 = wave_sum_d((double)acc_sy), q2 = wave_sum_d((double)acc_sd);
     if (lane == 0) { double* o = p.block_sums + (size_t)task * 8; o[4] = q0; o[5] = q1; o[6] = q2; o[7] = 0.0; }
   }
-  if (POSE) {
+  if (POSE) {  // block_gP[task][f][12]
 #pragma unroll
-    for (int i = 0; i < 24; ++i) {
-      const float v = wave_sum(gP[i]);
-      if (lane == 0) p.block_gP[(size_t)task * 24 + i] = v;
+    for (int i = 0; i < 12; ++i) {
+      const float v0 = wave_sum(gP[i].x), v1 = wave_sum(gP[i].y);
+      if (lane == 0) { p.block_gP[(size_t)task * 24 + i] = v0; p.block_gP[(size_t)task * 24 + 12 + i] = v1; }
     }
   }
 }
@@ -615,7 +878,7 @@ __global__ __launch_bounds__(64, 4) void identity_kernel(IdentParams p) {
           const float sx = hsA[f * 9 + ch * 3] + h[f * 9 + ch * 3];
           const float sxx = hsA[f * 9 + ch * 3 + 1] + h[f * 9 + ch * 3 + 1];
           const float sxy = hsA[f * 9 + ch * 3 + 2] + h[f * 9 + ch * 3 + 2];
-          const float vc = clamp01(ssim_sums<false>(sx, sy, sxx, syy, sxy, nullptr, nullptr, nullptr));
+          const float vc = clamp01(ssim_sums(sx, sy, sxx, syy, sxy));
           ssum[f] = ch == 0 ? vc : ssum[f] + vc;
           const float l1 = fabsf(y1[ch] - x1[f][ch]);
           lsum[f] = ch == 0 ? l1 : lsum[f] + l1;

@@ -55,13 +55,20 @@ def test_loss_step_against_oracle(tag):
     pairs = [("reproj_loss/0", o["losses"]["reproj_loss/0"]), ("consistency_loss/0", o["losses"]["consistency_loss/0"]),
              ("distil_loss", o["losses"]["distil_loss"]), ("mono/loss", o["mono_losses"]["loss"]),
              ("mono/reproj_loss/0", o["mono_losses"]["reproj_loss/0"])]
+    # the automask `rp <= identity + 1e-5*noise` (loss_utils.py:27-44) is a comparison of two fp32 values: a pixel
+    # within rounding distance of the threshold may fall on either side; flipping pixel i moves the masked mean
+    # sum(rp*m)/sum(m) by at most (rp_i + mean)/sum(m)
+    idn_ = o["ident"] + n0.numpy() * np.float32(1e-5)
+    amb_auto = np.abs(o["mono_reproj"] - idn_) <= 3e-5 * np.maximum(np.abs(idn_), 1e-3)
+    m_t = o["mono_reproj"] <= idn_
+    allow_auto = float(((o["mono_reproj"] + o["mono_losses"]["reproj_loss/0"]) * amb_auto).sum() / max(m_t.sum(), 1))
     for k, v in pairs:
-        tol = 1e-4 * abs(v) + (allow if "distil" in k else 0.0)
-        assert abs(h["losses"][k] - v) <= tol, (k, h["losses"][k], v)
+        tol = 1e-4 * abs(v) + (allow if "distil" in k else 0.0) + (allow_auto if "distil" not in k and "consistency" not in k else 0.0)
+        assert abs(h["losses"][k] - v) <= tol, (k, h["losses"][k], v, allow_auto)
     scale = B if kw.get("loss_blc") else 1
-    assert abs(h["losses"]["loss"] - o["final"]) <= 1e-4 * abs(o["final"]) + scale * allow, (h["losses"]["loss"], o["final"])
+    assert abs(h["losses"]["loss"] - o["final"]) <= 1e-4 * abs(o["final"]) + scale * (allow + allow_auto), (h["losses"]["loss"], o["final"])
     if kw.get("loss_blc"):
-        assert abs(h["loss_list"][0] - o["loss_list"][0]) <= 1e-4 * abs(o["loss_list"][0])
+        assert abs(h["loss_list"][0] - o["loss_list"][0]) <= 1e-4 * abs(o["loss_list"][0]) + allow_auto
     assert np.abs(h["maps"]["mono_reproj"] - o["mono_reproj"]).max() <= 1e-4
     if o["ens"] is not None:
         assert np.abs(h["maps"]["ens_reproj"] - o["ens"]).max() <= 1e-4
@@ -73,15 +80,21 @@ def test_loss_step_against_oracle(tag):
     amb_s = HH.dilate3(HH.near_tie(o["multi_cands"], 2e-4)) | HH.sample_ambiguous(o["multi_sample"], H, W) | amb_distil
     amb_s |= np.abs(o["mono_depth"] - o["multi_depth"]) <= 1e-6 * np.abs(o["mono_depth"])
     o64 = HH.oracle_fp64_grads(b, kw, n0, n1)
+    # an automask pixel on the other side of its threshold also rescales every teacher-pass gradient by
+    # 1/sum(mask) -> 1/(sum(mask) +- 1)
+    renorm = float(amb_auto.sum()) / max(int(m_t.sum()), 1)
     for key in HH.LEAVES:
         g, r, r64 = h["grads"][key], o["grads"][key], o64[key]
+        extra = 0.0 if key == "disp_student" else renorm
         if key.startswith("disp"):
             keep = ~(amb_t if key == "disp_teacher" else amb_s)
             err = np.abs(g - r)[keep]
-            assert (err > 2e-4 * np.abs(r).max()).mean() <= 2e-5, (key, err.max() / np.abs(r).max())
+            assert (err > (2e-4 + extra) * np.abs(r).max()).mean() <= 2e-5, (key, err.max() / np.abs(r).max())
             g, r, r64 = g[keep], r[keep], r64[keep]
+        elif amb_auto.any():
+            extra += 2e-2  # the summed (pose) gradients gain or lose that pixel's whole contribution
         floor = _l2rel(r, r64)
-        assert _l2rel(g, r) <= max(1e-4, 1.5 * floor), (key, _l2rel(g, r), floor)
+        assert _l2rel(g, r) <= max(1e-4, 1.5 * floor) + extra, (key, _l2rel(g, r), floor)
 
 
 def test_loss_step_equals_operator_route():
