@@ -226,7 +226,10 @@ int mal_pose_bwd(const float* const* axisangle, const float* const* translation,
  * Without --loss_blc pass w_main = w_distil = 1; with it w_main = bs*w0, w_distil = bs*w1
  * (loss_utils.py:303-318).  All maps the step needs between kernels live in `ws`
  * (mal_step_workspace_bytes); the same ws must be handed to _bwd. */
-enum { MAL_STEP_NO_ENS = 1 /* --no_ens: 2-way distillation argmin, no ensemble pass */ };
+enum {
+  MAL_STEP_NO_ENS = 1,   /* --no_ens: 2-way distillation argmin, no ensemble pass */
+  MAL_STEP_AUG_MASK = 2  /* `augmentation_keep` holds augmentation_mask itself; 1 - mask is formed on the device */
+};
 typedef struct mal_step_args {
   int B, H, W;
   float min_depth, max_depth;
@@ -237,10 +240,11 @@ typedef struct mal_step_args {
   const float *disp_teacher, *disp_student;       /* (B,1,H,W), full resolution */
   const float *axisangle_m1, *translation_m1, *axisangle_p1, *translation_p1; /* (B,3) */
   const float *consistency_mask;                  /* (B,H,W), before the matching mask */
-  const float *augmentation_keep;                 /* (B): 1 - augmentation_mask */
+  const float *augmentation_keep;                 /* (B): 1 - augmentation_mask (or the mask, MAL_STEP_AUG_MASK) */
   const float *lowest_cost;                       /* (B,H,W) */
   const float *noise;                             /* (B,1,H,W) N(0,1), nullable */
   float *losses;                                  /* 16 */
+  float *loss_total;                              /* nullable: receives losses[8], the differentiable total */
   float *mono_reproj, *ens_reproj, *multi_reproj; /* (B,1,H,W) nullable outputs */
   float *consistency_mask_out;                    /* (B,H,W) nullable: mask * matching mask */
   const float *g_total;                           /* backward: device scalar d(final)/d(total), nullable = 1 */

@@ -67,14 +67,14 @@ class StepArgs(C.Structure):
                  ("w_main", f32), ("w_distil", f32)] +
                 [(n, vp) for n in ("color0", "color_m1", "color_p1", "K", "inv_K", "disp_teacher", "disp_student",
                                    "axisangle_m1", "translation_m1", "axisangle_p1", "translation_p1",
-                                   "consistency_mask", "augmentation_keep", "lowest_cost", "noise", "losses",
+                                   "consistency_mask", "augmentation_keep", "lowest_cost", "noise", "losses", "loss_total",
                                    "mono_reproj", "ens_reproj", "multi_reproj", "consistency_mask_out", "g_total",
                                    "g_disp_teacher", "g_disp_student", "g_axisangle_m1", "g_translation_m1",
                                    "g_axisangle_p1", "g_translation_p1", "ws")] +
                 [("ws_bytes", sz), ("stream", vp)])
 
 
-STEP_NO_ENS = 1
+STEP_NO_ENS, STEP_AUG_MASK = 1, 2
 
 # flags (include/mal_hip.h)
 F_AUTOMASK, F_GRAD, F_POSE_GRAD, F_NO_SSIM, F_AVG, F_EPILOGUE, F_DUAL_DISTIL, F_SRC_PACKED, F_TGT_PACKED = 1, 2, 4, 8, 16, 32, 64, 128, 256

@@ -13,12 +13,14 @@ struct MarchParams {
   // whole-step launch list (mal_step.hip): the teacher's depth is re-derived from its disparity and
   // the matching mask (trainer.py:1066-1076) is formed in place, so neither map touches HBM
   const float* mono_disp; const float* lowest_cost; float* cmask_out;
-  // smoothness of this pass's disparity folded into the sweep (GRAD passes of the whole-step list):
-  // per-sample means (f64, already offset to this map), d loss/d normalised-disp map out; partial sums
-  // go to block_sums[task][4..6] = sum Tx, sum Ty, sum gn*disp  (layers.py:210-223, loss_utils.py:119-121)
-  const double* smooth_mean; float* smooth_gn;
+  // smoothness of this pass's disparity folded into the sweep (GRAD passes of the whole-step list): d loss /
+  // d normalised-disp map out; per-task partials block_sums[task][4..7] = sum |dx d| w, sum |dy d| w, sum gn*disp,
+  // sum disp -- the 1/(mean+1e-7) of the mean normalisation is applied per sample afterwards
+  // (layers.py:210-223, loss_utils.py:119-121)
+  float* smooth_gn;
   // per-sample camera block [B][40]: P_f = (K T_f)[:3,:], inv_K[:3,:3]; march_launch fills it unless cam_ready
   float* cam; int cam_ready;
+  int sample_scale_is_mask;  // sample_scale holds the augmentation mask: the scale is 1 - mask
   int B, H, W; float min_disp, range, eps; int convention;
   float* min_reproj; float* g_reproj; float* g_cons; float* g_distil; float* cons_target; float* depth_out;
   double* block_sums; float* block_gP;

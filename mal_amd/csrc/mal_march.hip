@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   const float* disp_b = p.disp + (size_t)b * HW;
   const float* disp2_b = p.disp2 ? p.disp2 + (size_t)b * HW : nullptr;
   const size_t map_b = (size_t)b * HW;
-  const float sscale = p.sample_scale ? p.sample_scale[b] : 1.0f;
+  const float sscale = p.sample_scale ? (p.sample_scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
 
   // ---- running state (pairs as in WarpRow: index k*3 + {x, x^2, xy} for the colour pairs k)
   f2 hsA[9], hsB[9];             // partial vertical sums of the horizontal sums: centre r-1 (top+mid), centre r (top)
@@ -386,11 +386,13 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   f2 gP[POSE ? 12 : 1];          // d loss / d P of both frames
   float acc_rw = 0.f, acc_w = 0.f, acc_cons = 0.f, acc_dist = 0.f;  // per-lane partials (<= rows terms each)
   // in-sweep smoothness state: normalised / raw disparity of the previous row, its pending gradient
-  const bool smooth = GRAD && p.smooth_mean != nullptr;
-  const float sm_inv = smooth ? div_(1.0f, (float)p.smooth_mean[b] + 1e-7f) : 0.f;
+  // (the per-sample 1/(mean+1e-7) of the normalised disparity is a positive constant of the sample: it is
+  // factored out of |d n| and applied to the per-sample sums afterwards; the sample mean itself comes from
+  // the sum of the disparity over the task's pixels, partial slot 7)
+  const bool smooth = GRAD && p.smooth_gn != nullptr;
   const float sm_nx = 1.0f / ((float)p.B * (float)H * (float)(W - 1)), sm_ny = 1.0f / ((float)p.B * (float)(H - 1) * (float)W);
   float sm_n1 = 0.f, sm_d1 = 0.f, sm_g1 = 0.f;
-  float acc_sx = 0.f, acc_sy = 0.f, acc_sd = 0.f;  // per-lane partials over <= rows pixels: fp32, widened at the wave sum
+  float acc_sx = 0.f, acc_sy = 0.f, acc_sd = 0.f, acc_d = 0.f;  // per-lane partials over <= rows pixels: fp32, widened at the wave sum
 #pragma unroll
   for (int i = 0; i < 9; ++i) { hsA[i] = bc(0.f); hsB[i] = bc(0.f); }
 #pragma unroll
@@ -426,9 +428,19 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     float ident, noise, ext, mono, cost;          // statistics row c
     float e_mono, e_mr, e_er;                     // epilogue row
   };
+  // the map pointers of the parameter block, read together (one scalar-load wait per iteration)
+  struct Maps { const float *ident, *noise, *ext_mask, *lowest_cost, *mono_disp, *mono_depth, *mono_reproj, *ens_reproj, *target; int packed; };
+  auto maps_of = [&](CParams& pp) {
+    Maps m;
+    m.ident = AUTOMASK ? pp.ident : nullptr; m.noise = AUTOMASK ? pp.noise : nullptr;
+    m.ext_mask = pp.ext_mask; m.lowest_cost = pp.lowest_cost; m.mono_disp = pp.mono_disp;
+    m.mono_depth = EPI ? pp.mono_depth : nullptr; m.mono_reproj = EPI ? pp.mono_reproj : nullptr;
+    m.ens_reproj = EPI ? pp.ens_reproj : nullptr; m.target = pp.target; m.packed = pp.packed;
+    return m;
+  };
   auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
-  // everything iteration `rr` will need, from the parameter block `pp`
-  auto request = [&](CParams& pp, int rr, Ahead& a) {
+  // everything iteration `rr` will need
+  auto request = [&](const Maps& pp, int rr, Ahead& a) {
     const int packed_t = pp.packed & 2;
     const unsigned pix = (unsigned)(row_of(rr) * W + gxr);
     a.disp = ldf(disp_b, pix * 4u);
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     }
   };
   Ahead nxt;
-  request(p, r_first, nxt);
+  request(maps_of(p), r_first, nxt);
   // reciprocals of the grid normalisation's divisors, once per wave (scalar registers)
   const float norm_rw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
       int, refined_rcp(p.convention == 0 ? (float)(W - 1) : (float)W))));
@@ -470,11 +482,11 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     CParams& p = *kp;
     PixInfo pi0;  // what stage S decides for the centre row c = r-1
     pi0.rp = 0.f; pi0.w = 0.f; pi0.win = 0;
-    const bool has_noise = AUTOMASK && p.noise != nullptr, has_ext = p.ext_mask != nullptr,
-               has_cost = p.lowest_cost != nullptr, has_mdisp = p.mono_disp != nullptr,
-               has_er = EPI && p.ens_reproj != nullptr;
+    const Maps mp = maps_of(p);
+    const bool has_noise = mp.noise != nullptr, has_ext = mp.ext_mask != nullptr, has_cost = mp.lowest_cost != nullptr,
+               has_mdisp = mp.mono_disp != nullptr, has_er = mp.ens_reproj != nullptr;
     WarpConsts wc;
-    wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = p.packed; wc.debug = p.debug; wc.W = W; wc.H = H;
+    wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = mp.packed; wc.debug = p.debug; wc.W = W; wc.H = H;
     wc.convention = p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
     wc.rw = norm_rw; wc.rh = norm_rh;
 #ifdef MAL_STAGE_TIMERS
@@ -501,7 +513,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       float ik[9];
       load_cam(cam_b, P, ik);
       // the next iteration's operands go out between the projection and the gathers (older in the queue)
-      warp_issue<GRAD, POSE>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(p, r + 1, nxt); });
+      warp_issue<GRAD, POSE>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
     }
     tick(1);  // small loads, prefetch, projection, gathers issued
     auto finish_warp = [&]() {
@@ -529,7 +541,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     // ================= smoothness of row r (edges to the right and up), finishing row r-1 ======
     if (smooth && !(wc.debug & 16)) {
       const bool row_ok = r >= 0 && r < H;
-      const float n0 = dv_ * sm_inv;
+      const float n0 = dv_;
       // right edge (r,x)-(r,x+1): exists for in-image x with x+1 < W
       const float nR = dpp_shl1(n0);
       const float eR = (fabsf(w0.yrg.x - dpp_shl1(w0.yrg.x)) + fabsf(w0.yrg.y - dpp_shl1(w0.yrg.y))) +
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
         acc_sy += fabsf(dfy) * wyu_;
         acc_sd += g * sm_d1;
       }
-      if (r >= y_lo && r < y_hi && out_x) acc_sx += fabsf(dfx) * wxr;
+      if (r >= y_lo && r < y_hi && out_x) { acc_sx += fabsf(dfx) * wxr; acc_d += dv_; }
       sm_g1 = (sx - dpp_shr1(sx)) - sy;
       sm_n1 = n0;
       sm_d1 = dv_;
@@ -813,7 +825,8 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   }
   if (GRAD) {  // smoothness partials (zeros when the term is not folded in)
     const double q0 = wave_sum_d((double)acc_sx), q1 = wave_sum_d((double)acc_sy), q2 = wave_sum_d((double)acc_sd);
-    if (lane == 0) { double* o = p.block_sums + (size_t)task * 8; o[4] = q0; o[5] = q1; o[6] = q2; o[7] = 0.0; }
+    const double q3 = wave_sum_d((double)acc_d);
+    if (lane == 0) { double* o = p.block_sums + (size_t)task * 8; o[4] = q0; o[5] = q1; o[6] = q2; o[7] = q3; }
   }
   if (POSE) {  // block_gP[task][f][12]
 #pragma unroll

@@ -8,12 +8,12 @@
 //   forward  1 pose_fwd (both frames)            layers.py:26-100
 //            1 pack3 (target, src-1, src+1 -> 16-byte texels)
 //            1 identity (min_f r(src_f, target)) loss_utils.py:92-101
-//            2 disparity means (both maps)       loss_utils.py:119
-//            1 teacher pass  (warp+SSIM+L1+min+automask, fwd+bwd to disp and poses)   :573-581
-//            1 ensemble pass ((disp_t+disp_s)/2 formed in the kernel, no grad)        :594-600
-//            1 student pass  (matching mask, consistency*(1-augmentation) mask, mono depth from
-//                             the teacher's disparity, consistency + distillation epilogue) :592-612
-//            2 smoothness (both maps) + 4 fixed-order reductions + 1 scalar epilogue
+//            1 camera block (P = K T of both frames per sample)
+//            1 teacher pass  (warp+SSIM+L1+min+automask+smoothness, fwd+bwd to disp and poses)   :573-581
+//            1 ensemble pass ((disp_t+disp_s)/2 formed in the kernel, no grad)                   :594-600
+//            1 student pass  (matching mask, consistency*(1-augmentation) mask, mono depth from the teacher's
+//                             disparity, consistency + distillation epilogue, smoothness)       :592-612
+//            1 per-sample reduction of the passes' partials + 1 scalar epilogue (fixed order, no atomics)
 //   backward 1 gradient assembly (both disparity maps) + 1 pose_bwd
 //
 // All intermediate maps live in the caller's workspace; loss scalars stay on the device.
@@ -29,12 +29,11 @@ struct StepWs {
   float* T[2]; float* gT[2]; float* gTs[2];
   float* ident; float* mono_reproj; float* ens_reproj; float* multi_reproj;
   float* G_r_t; float* G_r_s; float* G_c; float* G_d; float* gn_t; float* gn_s;
-  double* sums_t; double* sums_s; double* sums_e;      // 8 each
   double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
-  double* sm_plane; double* sm_part; double* sm_stats;  // smoothness: [2B*chunks], [2B*chunks][4], [4*2B]
+  double* ps;         // per-sample sums of the teacher's, then the student's partials: [2][B][8]
+  double* sm_stats;   // [4B]: mean_t[b], mean_s[b], corr_t[b], corr_s[b] of the mean-normalised smoothness
   float* coefs;       // 16 device scalars for the backward
   float* cam;         // [B][40] camera block of the marching kernels
-  int chunks;
   size_t bytes;
 };
 
@@ -49,15 +48,10 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   float** maps[] = {&w.ident, &w.mono_reproj, &w.ens_reproj, &w.multi_reproj, &w.G_r_t, &w.G_r_s, &w.G_c, &w.G_d,
                     &w.gn_t, &w.gn_s};
   for (auto m : maps) *m = (float*)take(map);
-  w.sums_t = (double*)take(8 * 8); w.sums_s = (double*)take(8 * 8); w.sums_e = (double*)take(8 * 8);
   w.bs_t = (double*)take(nb * 8 * 8); w.bs_s = (double*)take(nb * 8 * 8); w.bs_e = (double*)take(nb * 8 * 8);
   w.bgP = (float*)take(nb * 24 * 4);
-  int chunks = (int)((HW + 1023) / 1024);
-  if (chunks > 64) chunks = 64;
-  w.chunks = chunks;
-  w.sm_plane = (double*)take((size_t)2 * B * chunks * 8);
-  w.sm_part = (double*)take((size_t)2 * B * chunks * 4 * 8);
-  w.sm_stats = (double*)take((size_t)8 * B * 8);
+  w.ps = (double*)take((size_t)2 * B * 8 * 8);
+  w.sm_stats = (double*)take((size_t)4 * B * 8);
   w.coefs = (float*)take(16 * 4);
   w.cam = (float*)take((size_t)B * 40 * 4);
   w.bytes = o;
@@ -77,148 +71,107 @@ __global__ void pack3_kernel(const float* a, const float* b, const float* c, int
   }
 }
 
-// sample s of the 2B "samples": the teacher's disparity maps first, then the student's
-MAL_DEV const float* disp_of(const float* dt, const float* ds, int s, int B, int HW) {
-  return s < B ? dt + (size_t)s * HW : ds + (size_t)(s - B) * HW;
-}
-
-__global__ __launch_bounds__(256) void step_plane_sum_kernel(const float* dt, const float* ds, int B, int HW, int chunks,
-                                                             double* partial) {
-  __shared__ double sh[4];
-  const int s = blockIdx.x / chunks, ck = blockIdx.x % chunks;
-  const float* d = disp_of(dt, ds, s, B, HW);
-  double acc = 0.0;
-  for (int i = ck * 256 + threadIdx.x; i < HW; i += chunks * 256) acc += (double)d[i];
-  acc = wave_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
-
-// stage 1: stats[s] = mean of sample s.  stage 2: stats[2B+s] = corr_s = dot_s / (HW (mean+eps)^2);
-// block 2B: stats[4B + {0,1}] = smoothness loss of the teacher / student map
-__global__ __launch_bounds__(64) void step_smooth_mid_kernel(const double* plane, const double* part, int B, int H, int W,
-                                                             int chunks, int stage, double* stats) {
-  const int s = blockIdx.x, lane = threadIdx.x, HW = H * W;
-  if (stage == 1) {
+// Second stage of the passes' reductions, one block per (pass, sample) and one per sample for the pose terms;
+// the marching tasks of a sample are contiguous.  Fixed summation order, no atomics.
+//   blocks [0, 2B):  ps[pass][b][j] = sum over the sample's tasks of block_sums[task][j]
+//   blocks [2B, 3B): g_T[f][b] = K_b^T [gP_fb ; 0]  from the teacher's per-task pose partials
+__global__ __launch_bounds__(256) void step_reduce_kernel(const double* bs_t, const double* bs_s, const float* bgP,
+                                                          const float* K, int per_sample, int B, double* ps,
+                                                          float* gT0, float* gT1) {
+  __shared__ double s_part[256];
+  __shared__ double s_gP[24];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < 2 * B) {
+    const int pass = blockIdx.x / B, b = blockIdx.x - pass * B;
+    const double* bs = (pass ? bs_s : bs_t) + (size_t)b * per_sample * 8;
+    const int j = tid & 7, sub = tid >> 3;  // 32 strided partial sums per quantity
     double acc = 0.0;
-    for (int k = lane; k < chunks; k += 64) acc += plane[s * chunks + k];
-    acc = wave_sum_d(acc);
-    if (lane == 0) stats[s] = acc / (double)HW;
+    for (int t = sub; t < per_sample; t += 32) acc += bs[(size_t)t * 8 + j];
+    s_part[tid] = acc;
+    __syncthreads();
+    if (tid < 8) {
+      double a = 0.0;
+      for (int k = 0; k < 32; ++k) a += s_part[k * 8 + tid];
+      ps[((size_t)pass * B + b) * 8 + tid] = a;
+    }
     return;
   }
-  if (s < 2 * B) {
-    double dot = 0.0;
-    for (int k = lane; k < chunks; k += 64) dot += part[(size_t)(s * chunks + k) * 4 + 2];
-    dot = wave_sum_d(dot);
-    if (lane == 0) {
-      const double m = (double)((float)stats[s] + 1e-7f);
-      stats[2 * B + s] = dot / ((double)HW * m * m);
-    }
-  } else {
-    for (int which = 0; which < 2; ++which) {
-      double sx = 0.0, sy = 0.0;
-      for (int i = lane; i < B * chunks; i += 64) {
-        sx += part[(size_t)(which * B * chunks + i) * 4];
-        sy += part[(size_t)(which * B * chunks + i) * 4 + 1];
-      }
-      sx = wave_sum_d(sx); sy = wave_sum_d(sy);
-      if (lane == 0) stats[4 * B + which] = sx / ((double)B * H * (W - 1)) + sy / ((double)B * (H - 1) * W);
-    }
-  }
-}
-
-// per-sample mean-coupling term of the in-sweep smoothness: corr_s = dot_s / (HW (mean_s+eps)^2), the dot
-// summed over the marching tasks of sample s (contiguous in task order); which = 0 teacher, 1 student
-__global__ __launch_bounds__(64) void step_smooth_corr_kernel(const double* bs_t, const double* bs_s, int per_sample,
-                                                              int B, int HW, double* stats) {
-  const int s = blockIdx.x, lane = threadIdx.x;
-  const double* bs = s < B ? bs_t : bs_s;
-  const int b = s < B ? s : s - B;
-  double dot = 0.0;
-  for (int k = lane; k < per_sample; k += 64) dot += bs[((size_t)b * per_sample + k) * 8 + 6];
-  dot = wave_sum_d(dot);
-  if (lane == 0) {
-    const double m = (double)((float)stats[s] + 1e-7f);
-    stats[2 * B + s] = dot / ((double)HW * m * m);
-  }
-}
-
-// get_smooth_loss on disp/(mean+1e-7) for both maps (layers.py:210-223, loss_utils.py:119-121):
-// loss partials, d loss / d normalised-disp map, and the per-sample dot(gn, disp) of the mean coupling
-__global__ __launch_bounds__(256) void step_smooth_kernel(const float* dt, const float* ds, const float* img_packed,
-                                                          int B, int H, int W, int chunks, const double* stats,
-                                                          double* part, float* gn_t, float* gn_s) {
-  __shared__ double sh[4][3];
-  const int HW = H * W;
-  const int s = blockIdx.x / chunks, ck = blockIdx.x % chunks;
-  const int b = s < B ? s : s - B;
-  const float* d = disp_of(dt, ds, s, B, HW);
-  float* gn = (s < B ? gn_t : gn_s) + (size_t)b * HW;
-  const float4* im = reinterpret_cast<const float4*>(img_packed) + (size_t)b * HW;
-  const float inv = div_(1.0f, (float)stats[s] + 1e-7f);
-  const float nx = 1.0f / ((float)B * (float)H * (float)(W - 1));
-  const float ny = 1.0f / ((float)B * (float)(H - 1) * (float)W);
-  double ax = 0.0, ay = 0.0, adot = 0.0;
-  auto sg = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
-  for (int pix = ck * 256 + threadIdx.x; pix < HW; pix += chunks * 256) {
-    const int gy = pix / W, gx = pix - gy * W;
-    const float dq = d[pix], nq = dq * inv;
-    const float4 cq = im[pix];
-    auto edge = [&](int other) {
-      const float4 co = im[other];
-      const float e = (fabsf(cq.x - co.x) + fabsf(cq.y - co.y)) + fabsf(cq.z - co.z);
-      return expf(-(e * (1.0f / 3.0f)));
-    };
-    float g = 0.f;
-    if (gx + 1 < W) {
-      const float w = edge(pix + 1), df = nq - d[pix + 1] * inv;
-      ax += (double)(fabsf(df) * w);
-      g += sg(df) * w * nx;
-    }
-    if (gx > 0) g -= sg(d[pix - 1] * inv - nq) * edge(pix - 1) * nx;
-    if (gy + 1 < H) {
-      const float w = edge(pix + W), df = nq - d[pix + W] * inv;
-      ay += (double)(fabsf(df) * w);
-      g += sg(df) * w * ny;
-    }
-    if (gy > 0) g -= sg(d[pix - W] * inv - nq) * edge(pix - W) * ny;
-    gn[pix] = g;
-    adot += (double)g * (double)dq;
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  ax = wave_sum_d(ax); ay = wave_sum_d(ay); adot = wave_sum_d(adot);
-  if (lane == 0) { sh[wv][0] = ax; sh[wv][1] = ay; sh[wv][2] = adot; }
+  const int b = blockIdx.x - 2 * B;
+  // 24 sums of per_sample partials: 8 lanes per value, then an 8-term sum (fixed order)
+  const int v = tid >> 3, sub = tid & 7;
+  double acc = 0.0;
+  if (v < 24)
+    for (int t = sub; t < per_sample; t += 8) acc += (double)bgP[((size_t)b * per_sample + t) * 24 + v];
+  s_part[tid] = acc;
   __syncthreads();
-  if (threadIdx.x < 3) {
-    const int j = threadIdx.x;
-    part[(size_t)blockIdx.x * 4 + j] = (sh[0][j] + sh[1][j]) + (sh[2][j] + sh[3][j]);
+  if (v < 24 && sub == 0) {
+    double a = 0.0;
+    for (int k = 0; k < 8; ++k) a += s_part[tid + k];
+    s_gP[v] = a;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int f = tid >> 4, e = tid & 15, k = e >> 2, j = e & 3;
+    const float* Kb = K + b * 16;
+    double a = 0.0;
+    for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
+    (f ? gT1 : gT0)[b * 16 + e] = (float)a;
   }
 }
 
-// loss scalars (loss_utils.py:112-127,198-279; trainer.py:625-629) and the coefficients of the backward
-__global__ void step_scalars_kernel(const double* sums_t, const double* sums_s, const double* stats, int B, int H, int W,
-                                    float w_main, float w_distil, float* losses, float* coefs) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int HW = H * W;
-  const double N = (double)B * HW;
-  const double reproj_t = sums_t[0] / (sums_t[1] + 1e-7), reproj_s = sums_s[0] / (sums_s[1] + 1e-7);
-  const double cons = sums_s[2] / N, distil = sums_s[3] / N;
-  // smoothness sums come with the pass sums (slots 4, 5: sum Tx, sum Ty of the in-sweep term)
+// loss scalars (loss_utils.py:112-127,198-279; trainer.py:625-629), the smoothness of the mean-normalised
+// disparities (layers.py:210-223, loss_utils.py:119-121) from the per-sample sums, and the coefficients of
+// the backward.  One wavefront; lane b owns sample b, sums over samples run in sample order.
+__global__ __launch_bounds__(64) void step_scalars_kernel(const double* ps, int B, int H, int W, float w_main,
+                                                          float w_distil, double* stats, float* losses, float* coefs,
+                                                          float* loss_total) {
+  __shared__ double sh[2][8];
+  const int lane = threadIdx.x, HW = H * W;
   const double Nx = (double)B * H * (W - 1), Ny = (double)B * (H - 1) * W;
-  const double smooth_t = sums_t[4] / Nx + sums_t[5] / Ny, smooth_s = sums_s[4] / Nx + sums_s[5] / Ny;
+  // sums over samples, fixed order; slots 4, 5 (smoothness) are weighted by the sample's 1/(mean+1e-7)
+  if (lane < 16) {
+    const int pass = lane >> 3, j = lane & 7;
+    double a = 0.0;
+    for (int b = 0; b < B; ++b) {
+      const double* q = ps + ((size_t)pass * B + b) * 8;
+      double v = q[j];
+      if (j == 4 || j == 5) {
+        const float m = (float)(q[7] / (double)HW) + 1e-7f;
+        v = v * (double)div_(1.0f, m);
+      }
+      a += v;
+    }
+    sh[pass][j] = a;
+  }
+  // per-sample statistics of the smoothness gradient: mean and the mean-coupling term dot/(HW (mean+eps)^2)
+  for (int s = lane; s < 2 * B; s += 64) {
+    const double* q = ps + (size_t)s * 8;
+    const double mean = q[7] / (double)HW;
+    const double m = (double)((float)mean + 1e-7f);
+    stats[s] = mean;
+    stats[2 * B + s] = q[6] / ((double)HW * m * m);
+  }
+  __syncthreads();
+  if (lane != 0) return;
+  const double* st = sh[0];
+  const double* ss = sh[1];
+  const double N = (double)B * HW;
+  const double reproj_t = st[0] / (st[1] + 1e-7), reproj_s = ss[0] / (ss[1] + 1e-7);
+  const double cons = ss[2] / N, distil = ss[3] / N;
+  const double smooth_t = st[4] / Nx + st[5] / Ny, smooth_s = ss[4] / Nx + ss[5] / Ny;
   const float loss_t = (float)reproj_t + 1e-3f * (float)smooth_t;
   const float loss_m = ((float)reproj_s + (float)cons) + 1e-3f * (float)smooth_s;
   losses[0] = (float)reproj_t; losses[1] = (float)smooth_t; losses[2] = loss_t;
   losses[3] = (float)reproj_s; losses[4] = (float)cons; losses[5] = (float)smooth_s; losses[6] = (float)distil;
   losses[7] = loss_m;
   losses[8] = w_main * (loss_m + loss_t) + w_distil * (float)distil;
+  if (loss_total) *loss_total = losses[8];
   losses[9] = (float)reproj_s + (float)reproj_t;            // "reproj_loss/0" after the mono losses are added in
   losses[10] = (loss_m + (float)distil) + loss_t;           // "loss/0" / "loss" without loss balancing
   losses[11] = loss_m + loss_t;                             // loss_list[0] with loss balancing
   for (int i = 12; i < kLossSlots; ++i) losses[i] = 0.f;
-  coefs[0] = (float)((double)w_main / (sums_t[1] + 1e-7));  // teacher reprojection map
-  coefs[1] = (float)((double)w_main / (sums_s[1] + 1e-7));  // student reprojection map
+  coefs[0] = (float)((double)w_main / (st[1] + 1e-7));      // teacher reprojection map
+  coefs[1] = (float)((double)w_main / (ss[1] + 1e-7));      // student reprojection map
   coefs[2] = (float)((double)w_main / N);                   // consistency map
   coefs[3] = (float)((double)w_distil / N);                 // distillation map
   coefs[4] = w_main * 1e-3f;                                // smoothness
@@ -300,13 +253,6 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   // 3. identity term
   rc = identity_launch(w.packed[0], w.packed[1], w.packed[2], B, H, W, w.ident, st);
   if (rc) return rc;
-  // 4. disparity means of both maps
-  hipLaunchKernelGGL(step_plane_sum_kernel, dim3(2 * B * w.chunks), dim3(256), 0, st, a->disp_teacher, a->disp_student,
-                     B, HW, w.chunks, w.sm_plane);
-  hipLaunchKernelGGL(step_smooth_mid_kernel, dim3(2 * B), dim3(64), 0, st, w.sm_plane, w.sm_part, B, H, W, w.chunks, 1,
-                     w.sm_stats);
-  rc = launch_status();
-  if (rc) return rc;
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
   int per_sample = 1;
   int cam_ready = 0;  // the first pass fills the camera block, the others reuse it
@@ -317,14 +263,12 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
     p.ident = w.ident; p.noise = a->noise; p.min_reproj = mono_reproj; p.g_reproj = w.G_r_t;
     p.block_sums = w.bs_t; p.block_gP = w.bgP;
-    p.smooth_mean = w.sm_stats; p.smooth_gn = w.gn_t;
+    p.smooth_gn = w.gn_t;
     p.cam = w.cam; p.cam_ready = cam_ready;
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
     if (rc) return rc;
     per_sample = p.strips * p.segs;
     cam_ready = p.cam_ready;
-    rc = launch_pass_finalize(w.bs_t, w.bgP, a->K, p.ntasks, per_sample, B, w.sums_t, w.gT[0], w.gT[1], st, 8);
-    if (rc) return rc;
   }
   // 6. ensemble pass (no gradient)
   if (!no_ens) {
@@ -342,23 +286,21 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.disp = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
     p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
     p.ext_mask = a->consistency_mask; p.sample_scale = a->augmentation_keep;
+    p.sample_scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0;
     p.mono_disp = a->disp_teacher; p.lowest_cost = a->lowest_cost; p.cmask_out = a->consistency_mask_out;
     p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj;
     p.min_reproj = multi_reproj; p.g_reproj = w.G_r_s; p.g_cons = w.G_c; p.g_distil = w.G_d;
     p.block_sums = w.bs_s; p.block_gP = w.bgP;
-    p.smooth_mean = w.sm_stats + B; p.smooth_gn = w.gn_s;
+    p.smooth_gn = w.gn_s;
     p.cam = w.cam; p.cam_ready = cam_ready;
     rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
     if (rc) return rc;
-    rc = launch_pass_finalize(w.bs_s, w.bgP, a->K, p.ntasks, p.strips * p.segs, B, w.sums_s, nullptr, nullptr, st, 8);
-    if (rc) return rc;
   }
-  // 8. mean-coupling term of both smoothness gradients (the terms themselves were folded into the passes)
-  hipLaunchKernelGGL(step_smooth_corr_kernel, dim3(2 * B), dim3(64), 0, st, w.bs_t, w.bs_s, per_sample, B, HW,
-                     w.sm_stats);
-  // 9. scalars
-  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, st, w.sums_t, w.sums_s, w.sm_stats, B, H, W, a->w_main,
-                     a->w_distil, a->losses, w.coefs);
+  // 8. per-sample sums of both gradient passes + pose gradients, then the scalars
+  hipLaunchKernelGGL(step_reduce_kernel, dim3(3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, w.bgP, a->K, per_sample, B,
+                     w.ps, w.gT[0], w.gT[1]);
+  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(64), 0, st, w.ps, B, H, W, a->w_main, a->w_distil, w.sm_stats,
+                     a->losses, w.coefs, a->loss_total);
   return launch_status();
 }
 

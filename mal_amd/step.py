@@ -1,5 +1,5 @@
 """The whole loss half of ``Trainer.process_batch`` (manydepth/trainer.py:573-642, ``--distil``)
-as one C call forward (``mal_loss_step_fwd``, ~18 kernels) and one backward
+as one C call forward (``mal_loss_step_fwd``, 9 kernels) and one backward
 (``mal_loss_step_bwd``, 2 kernels): no Python between the kernels, no per-op autograd nodes.
 
 ``loss_step(...)`` returns the same ``losses`` dict keys as the reference's ``process_batch``
@@ -37,7 +37,7 @@ class LossStepFn(Function):
     @staticmethod
     def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg):
         color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise = consts
-        min_depth, max_depth, no_ens, w_main, w_distil, want_maps = cfg
+        min_depth, max_depth, no_ens, w_main, w_distil, want_maps, aug_is_mask = cfg
         req = ops._req
         tens = [req(t, n) for t, n in ((disp_t, "disp_teacher"), (disp_s, "disp_student"), (aa_m1, "axisangle"),
                                        (tr_m1, "translation"), (aa_p1, "axisangle"), (tr_p1, "translation"))]
@@ -47,7 +47,7 @@ class LossStepFn(Function):
         a = L.StepArgs()
         a.B, a.H, a.W = B, H, W
         a.min_depth, a.max_depth = float(min_depth), float(max_depth)
-        a.flags = L.STEP_NO_ENS if no_ens else 0
+        a.flags = (L.STEP_NO_ENS if no_ens else 0) | (L.STEP_AUG_MASK if aug_is_mask else 0)
         a.w_main, a.w_distil = float(w_main), float(w_distil)
         p = ops._p
         a.disp_teacher, a.disp_student = p(tens[0]), p(tens[1])
@@ -55,7 +55,8 @@ class LossStepFn(Function):
         (a.color0, a.color_m1, a.color_p1, a.K, a.inv_K, a.consistency_mask, a.augmentation_keep, a.lowest_cost,
          a.noise) = (p(t) for t in cons)
         losses = torch.empty(16, dtype=torch.float32, device=dev)
-        a.losses = p(losses)
+        total = torch.empty(1, dtype=torch.float32, device=dev)  # its own tensor: no select/copy nodes in the backward
+        a.losses, a.loss_total = p(losses), p(total)
         maps = {}
         if want_maps:
             new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -70,21 +71,21 @@ class LossStepFn(Function):
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
         L.check(L.load().mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
         ctx.args = a
-        ctx.keep = (tens, cons, ws, losses)  # the C struct holds raw pointers: keep the tensors alive
+        ctx.keep = (tens, cons, ws, losses, total)  # the C struct holds raw pointers: keep the tensors alive
         ctx.set_materialize_grads(False)
-        outs = [losses] + [maps[k] for k in ("mono_reproj", "multi_reproj", "consistency_mask", "ens_reproj")
-                           if k in maps]
+        outs = [total, losses] + [maps[k] for k in ("mono_reproj", "multi_reproj", "consistency_mask", "ens_reproj")
+                                  if k in maps]
         ctx.mark_non_differentiable(*outs[1:])
         return tuple(outs)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_losses, *_):
+    def backward(ctx, g_total, *_):
         tens = ctx.keep[0]
-        if g_losses is None:
+        if g_total is None:
             return (None,) * 8
-        # only slot 8 ("total") is differentiable through this node: the other slots are its terms
-        g_total = g_losses[8:9].contiguous()
+        # only the total is differentiable through this node: the 16 slots are its terms, for logging
+        g_total = g_total.reshape(1).contiguous()
         a = ctx.args
         grads = [torch.empty_like(t) if ctx.needs_input_grad[i] else None for i, t in enumerate(tens)]
         a.g_total = ops._p(g_total)
@@ -117,7 +118,9 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
         noise = loss_utils.draw_noise((B, 1, H, W), dev)
         if config.noise_source == "cpu":
             torch.randn((B, 1, H, W))  # compute_main_losses' dead draw (loss_utils.py:178)
-    keep = (1 - outputs["augmentation_mask"][:opt.batch_size]).to(torch.float32).reshape(B)
+    aug = outputs["augmentation_mask"][:opt.batch_size]
+    aug_is_mask = aug.dtype == torch.float32 and aug.is_contiguous()  # then 1 - mask is formed on the device
+    keep = aug.reshape(B) if aug_is_mask else (1 - aug).to(torch.float32).reshape(B)
     blc = bool(getattr(opt, "loss_blc", False))
     w_main, w_distil = 1.0, 1.0
     if blc:
@@ -125,17 +128,18 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
         w_main, w_distil = scale * float(w_list[0]), scale * float(w_list[1])
     consts = (color0, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)],
               outputs["consistency_mask"].to(torch.float32), keep, outputs["lowest_cost"], noise)
-    cfg = (opt.min_depth, opt.max_depth, bool(getattr(opt, "no_ens", False)), w_main, w_distil, bool(want_maps))
+    cfg = (opt.min_depth, opt.max_depth, bool(getattr(opt, "no_ens", False)), w_main, w_distil, bool(want_maps),
+           aug_is_mask)
     res = LossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
                            fix(tr[1]), consts, cfg)
-    v = res[0]
+    total, v = res[0].reshape(()), res[1]
     maps = {}
     if want_maps:
         names = ["mono_reproj", "multi_reproj", "consistency_mask"] + ([] if cfg[2] else ["ens_reproj"])
-        maps = dict(zip(names, res[1:]))
+        maps = dict(zip(names, res[2:]))
         outputs["consistency_mask"] = maps["consistency_mask"]
     losses = {"reproj_loss/0": v[9], "consistency_loss/0": v[4], "distil_loss": v[6], "loss/0": v[11] if blc else v[10],
-              "loss": v[8], "mono/reproj_loss/0": v[0], "mono/loss": v[2], "smooth_loss/mono": v[1],
+              "loss": total, "mono/reproj_loss/0": v[0], "mono/loss": v[2], "smooth_loss/mono": v[1],
               "smooth_loss/multi": v[5], "main/reproj_loss/0": v[3]}
     loss_list = [v[11], v[6]] if blc else None
     return losses, loss_list, maps
