@@ -34,9 +34,10 @@ MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, 
 // fills the task decomposition for `flags` (MAL_F_*), launches the matching instantiation on `st`
 // (bracketed by the one-shot profile events if armed).  Partials go to p.block_sums / p.block_gP.
 int march_launch(MarchParams& p, int flags, hipStream_t st);
-// min_f r(src_f, target) on packed (B,H,W,4) images -> ident (B,1,H,W): the identity term of
-// manydepth/loss_utils.py:92-101, same marching structure without the warp
-int identity_launch(const float* target_packed, const float* src0_packed, const float* src1_packed, int B, int H,
-                    int W, float* ident, hipStream_t st);
+// min_f r(src_f, target) of the RAW sources -> ident (B,1,H,W) (the identity term of
+// manydepth/loss_utils.py:92-101), and in the same sweep the two planar sources repacked as (B,H,W,4) texels
+// (packed0/1 nullable together), optionally the target too
+int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
+                         float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st);
 
 }  // namespace mal

@@ -46,19 +46,6 @@ MAL_DEV float hsum3(float v) { return (dpp_shr1(v) + v) + dpp_shl1(v); }
 constexpr float kC1s = 81.0f * 0.0001f;  // 81 * C1
 constexpr float kC2s = 81.0f * 0.0009f;  // 81 * C2
 
-// SSIM from 3x3 window sums (scalar form, used by the identity kernel); returns the un-clamped (1 - S)/2
-MAL_DEV float ssim_sums(float sx, float sy, float sxx, float syy, float sxy) {
-  const float pxy = sx * sy;
-  const float n1 = fma_(2.0f, pxy, kC1s);
-  const float n2 = fma_(2.0f, fma_(9.0f, sxy, -pxy), kC2s);
-  const float d1 = fma_(sx, sx, fma_(sy, sy, kC1s));
-  const float d2 = (fma_(-sx, sx, 9.0f * sxx) + fma_(-sy, sy, 9.0f * syy)) + kC2s;
-  const float n = n1 * n2, d = d1 * d2;
-  float rd = __builtin_amdgcn_rcpf(d);
-  rd = fma_(fma_(-d, rd, 1.0f), rd, rd);
-  return fma_(n * rd, -0.5f, 0.5f);
-}
-
 // ---------------------------------------------------------------- packed fp32 (two values per lane)
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -837,10 +824,19 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   }
 }
 
-// ---- identity term: min over the two raw sources of r(src_f, target), forward only --------------
-struct IdentParams { const float* target; const float* src[2]; float* ident; int B, H, W, strips, segs, rows, ntasks, per_xcd; };
+// ---- identity term + texel packing: min over the two raw sources of r(src_f, target)
+// (manydepth/loss_utils.py:92-101, forward only) in the same sweep that turns the two planar (B,3,H,W)
+// sources into the 16-byte texels (B,H,W,4) the warp gathers from.  Same marching structure and the same
+// colour pairs as march_kernel: x[0] = (r,g) of source 0, x[1] = (r,g) of source 1, x[2] = (b0, b1).
+struct IdentParams {
+  const float* target; const float* src[2];   // planar (B,3,H,W)
+  float* packed[2];                           // the sources as (B,H,W,4) out, nullable
+  float* packed_target;                       // the target as (B,H,W,4) out, nullable
+  float* ident;                               // (B,1,H,W) out
+  int B, H, W, strips, segs, rows, ntasks, per_xcd;
+};
 
-__global__ __launch_bounds__(64, 4) void identity_kernel(IdentParams p) {
+__global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
   constexpr int HALO = 1, CW = 62;
   const int id = blockIdx.x;
   const int task = (id & 7) * p.per_xcd + (id >> 3);
@@ -854,57 +850,81 @@ __global__ __launch_bounds__(64, 4) void identity_kernel(IdentParams p) {
   const bool in_x = gx >= 0 && gx < W;
   const int gxr = min(max(reflect1(gx, W), 0), W - 1);
   const bool out_x = in_x && lane >= HALO && lane < 64 - HALO;
-  float hsA[24], hsB[24];
+  const float* tb = p.target + (size_t)b * 3 * HW;
+  const float* s0 = p.src[0] + (size_t)b * 3 * HW;
+  const float* s1 = p.src[1] + (size_t)b * 3 * HW;
+  f2 hsA[9], hsB[9], hyA[2], hyB[2];
+  float hzA[2], hzB[2];
 #pragma unroll
-  for (int i = 0; i < 24; ++i) { hsA[i] = 0.f; hsB[i] = 0.f; }
-  float x1[2][3], y1[3];
+  for (int i = 0; i < 9; ++i) { hsA[i] = bc(0.f); hsB[i] = bc(0.f); }
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) { x1[0][ch] = x1[1][ch] = 0.f; y1[ch] = 0.f; }
-  for (int r = max(y_lo - 1, -1); r <= y_hi; ++r) {
-    const int gyr = min(max(reflect1(r, H), 0), H - 1), pix = gyr * W + gxr;
-    float x0[2][3], y0[3];
-    load_px3(p.target, 1, b, HW, pix, y0);
-    load_px3(p.src[0], 1, b, HW, pix, x0[0]);
-    load_px3(p.src[1], 1, b, HW, pix, x0[1]);
-    float h[24];
+  for (int i = 0; i < 2; ++i) { hyA[i] = bc(0.f); hyB[i] = bc(0.f); hzA[i] = 0.f; hzB[i] = 0.f; }
+  f2 x1[3] = {bc(0.f), bc(0.f), bc(0.f)}, y1rg = bc(0.f);
+  float y1b = 0.f;
+  auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
+  // the nine planes of a pixel, requested one iteration ahead (see march_kernel)
+  struct Px { float t[3], a[3], c[3]; };
+  auto request = [&](int rr, Px& q) {
+    const unsigned bo = (unsigned)(row_of(rr) * W + gxr) * 4u;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const float y = y0[ch];
-      h[18 + ch] = hsum3(y);
-      h[21 + ch] = hsum3(y * y);
+      q.t[ch] = ldf(tb + (size_t)ch * HW, bo); q.a[ch] = ldf(s0 + (size_t)ch * HW, bo); q.c[ch] = ldf(s1 + (size_t)ch * HW, bo);
+    }
+  };
+  const int r_first = max(y_lo - 1, -1);
+  Px nxt;
+  request(r_first, nxt);
+  for (int r = r_first; r <= y_hi; ++r) {
+    const Px cur = nxt;
+    request(r + 1, nxt);
+    if (r >= y_lo && r < y_hi && out_x && p.packed[0]) {  // an image row owned by this task: emit its texels
+      const unsigned bo = (unsigned)(r * W + gxr) * 16u;
+      *reinterpret_cast<f4*>(reinterpret_cast<char*>(p.packed[0] + (size_t)b * HW * 4) + bo) = (f4){cur.a[0], cur.a[1], cur.a[2], 0.f};
+      *reinterpret_cast<f4*>(reinterpret_cast<char*>(p.packed[1] + (size_t)b * HW * 4) + bo) = (f4){cur.c[0], cur.c[1], cur.c[2], 0.f};
+      if (p.packed_target)
+        *reinterpret_cast<f4*>(reinterpret_cast<char*>(p.packed_target + (size_t)b * HW * 4) + bo) = (f4){cur.t[0], cur.t[1], cur.t[2], 0.f};
+    }
+    const f2 x0[3] = {(f2){cur.a[0], cur.a[1]}, (f2){cur.c[0], cur.c[1]}, (f2){cur.a[2], cur.c[2]}};
+    const f2 y0rg = (f2){cur.t[0], cur.t[1]};
+    const float y0b = cur.t[2];
+    f2 h[9], hy[2];
+    float hz[2];
+    hy[0] = hsum3(y0rg); hy[1] = hsum3(y0rg * y0rg);
+    hz[0] = hsum3(y0b);  hz[1] = hsum3(y0b * y0b);
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const float x = x0[f][ch];
-        h[f * 9 + ch * 3 + 0] = hsum3(x);
-        h[f * 9 + ch * 3 + 1] = hsum3(x * x);
-        h[f * 9 + ch * 3 + 2] = hsum3(x * y);
-      }
+    for (int k = 0; k < 3; ++k) {
+      const f2 x = x0[k], y = k < 2 ? y0rg : bc(y0b);
+      h[k * 3 + 0] = hsum3(x);
+      h[k * 3 + 1] = hsum3(x * x);
+      h[k * 3 + 2] = hsum3(x * y);
     }
     const int c = r - 1;
     if (c >= y_lo && c < y_hi) {
-      float ssum[2], lsum[2];
+      const f2 syq = hyA[0] + hy[0], syyq = hyA[1] + hy[1];
+      const float syz = hzA[0] + hz[0], syyz = hzA[1] + hz[1];
+      const f2 vyq = fma2(-syq, syq, bc(9.0f) * syyq), d1yq = fma2(syq, syq, bc(kC1s));
+      const float vyz = fma_(-syz, syz, 9.0f * syyz), d1yz = fma_(syz, syz, kC1s);
+      f2 vc[3];
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float sy = hsA[18 + ch] + h[18 + ch], syy = hsA[21 + ch] + h[21 + ch];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          const float sx = hsA[f * 9 + ch * 3] + h[f * 9 + ch * 3];
-          const float sxx = hsA[f * 9 + ch * 3 + 1] + h[f * 9 + ch * 3 + 1];
-          const float sxy = hsA[f * 9 + ch * 3 + 2] + h[f * 9 + ch * 3 + 2];
-          const float vc = clamp01(ssim_sums(sx, sy, sxx, syy, sxy));
-          ssum[f] = ch == 0 ? vc : ssum[f] + vc;
-          const float l1 = fabsf(y1[ch] - x1[f][ch]);
-          lsum[f] = ch == 0 ? l1 : lsum[f] + l1;
-        }
+      for (int k = 0; k < 3; ++k) {
+        const f2 sx = hsA[k * 3] + h[k * 3], sxx = hsA[k * 3 + 1] + h[k * 3 + 1], sxy = hsA[k * 3 + 2] + h[k * 3 + 2];
+        const f2 v = ssim_sums2<false>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
+                                       nullptr, nullptr, nullptr);
+        vc[k] = (f2){clamp01(v.x), clamp01(v.y)};
       }
-      const float r0 = 0.85f * div3_(ssum[0]) + 0.15f * div3_(lsum[0]);
-      const float r1 = 0.85f * div3_(ssum[1]) + 0.15f * div3_(lsum[1]);
-      if (out_x) p.ident[(size_t)b * HW + (size_t)c * W + gxr] = fminf(r0, r1);
+      const f2 ssum = (f2){(vc[0].x + vc[0].y) + vc[2].x, (vc[1].x + vc[1].y) + vc[2].y};
+      const f2 l0 = y1rg - x1[0], l1 = y1rg - x1[1], l2 = bc(y1b) - x1[2];
+      const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
+      const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
+      if (out_x) stf(p.ident + (size_t)b * HW, (unsigned)(c * W + gxr) * 4u, fminf(rr.x, rr.y));
     }
 #pragma unroll
-    for (int i = 0; i < 24; ++i) { hsA[i] = hsB[i] + h[i]; hsB[i] = h[i]; }
+    for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i] + h[i]; hsB[i] = h[i]; }
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) { x1[0][ch] = x0[0][ch]; x1[1][ch] = x0[1][ch]; y1[ch] = y0[ch]; }
+    for (int i = 0; i < 2; ++i) { hyA[i] = hyB[i] + hy[i]; hyB[i] = hy[i]; hzA[i] = hzB[i] + hz[i]; hzB[i] = hz[i]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x1[k] = x0[k];
+    y1rg = y0rg; y1b = y0b;
   }
 }
 
@@ -973,17 +993,17 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   return launch_status();
 }
 
-int identity_launch(const float* target_packed, const float* src0_packed, const float* src1_packed, int B, int H,
-                    int W, float* ident, hipStream_t st) {
+int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
+                         float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st) {
   IdentParams p;
-  p.target = target_packed; p.src[0] = src0_packed; p.src[1] = src1_packed; p.ident = ident;
+  p.target = target; p.src[0] = src0; p.src[1] = src1; p.packed[0] = packed0; p.packed[1] = packed1; p.packed_target = packed_target; p.ident = ident;
   p.B = B; p.H = H; p.W = W;
   p.strips = (W + 61) / 62;
   p.rows = 12;  // 4 waves per SIMD fit (launch bounds): 16 segments x 11 strips x 12 samples = 2112 <= 4096
   p.segs = (H + p.rows - 1) / p.rows;
   p.ntasks = B * p.strips * p.segs;
   p.per_xcd = (p.ntasks + 7) / 8;
-  hipLaunchKernelGGL(identity_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(pack_identity_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
   return launch_status();
 }
 

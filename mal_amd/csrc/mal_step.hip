@@ -6,8 +6,7 @@
 // API of this library still needs ~60 launches plus Python glue between them.  Here:
 //
 //   forward  1 pose_fwd (both frames)            layers.py:26-100
-//            1 pack3 (target, src-1, src+1 -> 16-byte texels)
-//            1 identity (min_f r(src_f, target)) loss_utils.py:92-101
+//            1 identity term min_f r(src_f, target) (loss_utils.py:92-101) + packing of the sources into 16-byte texels
 //            1 camera block (P = K T of both frames per sample)
 //            1 teacher pass  (warp+SSIM+L1+min+automask+smoothness, fwd+bwd to disp and poses)   :573-581
 //            1 ensemble pass ((disp_t+disp_s)/2 formed in the kernel, no grad)                   :594-600
@@ -25,7 +24,7 @@ namespace mal {
 constexpr int kLossSlots = 16;
 
 struct StepWs {
-  float* packed[3];   // target, src-1, src+1 as (B,H,W,4)
+  float* packed[3];   // target, src-1, src+1 as (B,H,W,4) texels
   float* T[2]; float* gT[2]; float* gTs[2];
   float* ident; float* mono_reproj; float* ens_reproj; float* multi_reproj;
   float* G_r_t; float* G_r_s; float* G_c; float* G_d; float* gn_t; float* gn_s;
@@ -59,18 +58,6 @@ static StepWs carve_step(void* base, int B, int H, int W) {
 }
 
 // ---------------------------------------------------------------- small kernels
-__global__ void pack3_kernel(const float* a, const float* b, const float* c, int B, int HW, float4* da, float4* db,
-                             float4* dc) {
-  const float* src = blockIdx.y == 0 ? a : (blockIdx.y == 1 ? b : c);
-  float4* dst = blockIdx.y == 0 ? da : (blockIdx.y == 1 ? db : dc);
-  const size_t n = (size_t)B * HW;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t bb = i / HW, pix = i - bb * HW;
-    const float* s = src + bb * 3 * HW + pix;
-    dst[i] = make_float4(s[0], s[HW], s[2 * (size_t)HW], 0.f);
-  }
-}
-
 // Second stage of the passes' reductions, one block per (pass, sample) and one per sample for the pose terms;
 // the marching tasks of a sample are contiguous.  Fixed summation order, no atomics.
 //   blocks [0, 2B):  ps[pass][b][j] = sum over the sample's tasks of block_sums[task][j]
@@ -226,7 +213,7 @@ static int step_check(const mal_step_args* a) {
 extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   int rc = step_check(a);
   if (rc) return rc;
-  const int B = a->B, H = a->H, W = a->W, HW = H * W;
+  const int B = a->B, H = a->H, W = a->W;
   StepWs w = carve_step(a->ws, B, H, W);
   hipStream_t st = (hipStream_t)a->stream;
   const bool no_ens = a->flags & MAL_STEP_NO_ENS;
@@ -243,15 +230,8 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     rc = mal_pose_fwd(aa, tr, inv, B, 2, T, a->stream);
     if (rc) return rc;
   }
-  // 2. texel packing of the three images
-  {
-    size_t g = ((size_t)B * HW + 255) / 256;
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(pack3_kernel, dim3((unsigned)g, 3), dim3(256), 0, st, a->color0, a->color_m1, a->color_p1, B, HW,
-                       (float4*)w.packed[0], (float4*)w.packed[1], (float4*)w.packed[2]);
-  }
-  // 3. identity term
-  rc = identity_launch(w.packed[0], w.packed[1], w.packed[2], B, H, W, w.ident, st);
+  // 2. identity term + texel packing of the three images (one 16-byte load per pixel in the passes)
+  rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st);
   if (rc) return rc;
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
   int per_sample = 1;
