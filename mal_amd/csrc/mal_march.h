@@ -2,6 +2,7 @@
 // whole-step launch list (mal_step.hip).
 #pragma once
 #include "mal_common.h"
+#include "mal_device.h"
 
 namespace mal {
 
@@ -28,6 +29,26 @@ struct MarchParams {
   int packed;
   int debug;  // experiments only (mal_set_option("debug")): bit 0 = taps read the pixel's own address
 };
+
+constexpr int kCamFloats = 40;  // P interleaved over the two frames [12][2], inv_K 3x3, 7 pad
+
+// entry `lane` (< kCamFloats) of sample b's camera block: P_f = (K T_f)[:3,:] with ATen's bmm association, inv_K[:3,:3]
+MAL_DEV void cam_fill(const float* K, const float* T0, const float* T1, const float* invK, float* cam, int b, int lane) {
+  float mine = 0.f;
+  if (lane < 24) {
+    const int f = lane & 1, e = lane >> 1, i = e >> 2, j = e & 3;
+    const float* Kb = K + b * 16;
+    const float* T = (f ? T1 : T0) + b * 16;
+    float acc = Kb[i * 4 + 0] * T[0 * 4 + j];
+    acc = fma_(Kb[i * 4 + 1], T[1 * 4 + j], acc);
+    acc = fma_(Kb[i * 4 + 2], T[2 * 4 + j], acc);
+    mine = fma_(Kb[i * 4 + 3], T[3 * 4 + j], acc);
+  } else if (lane < 33) {
+    const int e = lane - 24;
+    mine = invK[b * 16 + (e / 3) * 4 + (e % 3)];
+  }
+  if (lane < kCamFloats) cam[b * kCamFloats + lane] = mine;
+}
 
 // zero-initialised parameter block with the depth range / convention filled in
 MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, float eps, int convention);

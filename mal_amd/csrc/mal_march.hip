@@ -122,7 +122,6 @@ MAL_DEV f2 ssim_sums2(f2 sx, f2 sy, f2 sxx, f2 vy /* 9 syy - sy^2 */, f2 d1y /* 
 }
 
 typedef __attribute__((address_space(4))) const float cfloat;  // constant address space: uniform loads are s_load
-constexpr int kCamFloats = 40;  // P interleaved over the two frames [12][2], inv_K 3x3, 7 pad
 
 // the pointer is made opaque per call so the loads stay where they are written (not hoisted out of the
 // row loop and spilled); P[e] = (P_frame0[e], P_frame1[e]) lands in an aligned scalar register pair
@@ -134,23 +133,9 @@ MAL_DEV void load_cam(const cfloat* cam, f2 (&P)[12], float (&ik)[9]) {
   for (int e = 0; e < 9; ++e) ik[e] = cam[24 + e];
 }
 
-// one block per sample: P_f = (K T_f)[:3,:] with ATen's bmm association, inv_K[:3,:3]
+// one block per sample
 __global__ void cam_setup_kernel(const float* K, const float* T0, const float* T1, const float* invK, float* cam) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  float mine = 0.f;
-  if (lane < 24) {
-    const int f = lane & 1, e = lane >> 1, i = e >> 2, j = e & 3;
-    const float* Kb = K + b * 16;
-    const float* T = (f ? T1 : T0) + b * 16;
-    float acc = Kb[i * 4 + 0] * T[0 * 4 + j];
-    acc = fma_(Kb[i * 4 + 1], T[1 * 4 + j], acc);
-    acc = fma_(Kb[i * 4 + 2], T[2 * 4 + j], acc);
-    mine = fma_(Kb[i * 4 + 3], T[3 * 4 + j], acc);
-  } else if (lane < 33) {
-    const int e = lane - 24;
-    mine = invK[b * 16 + (e / 3) * 4 + (e % 3)];
-  }
-  if (lane < kCamFloats) cam[b * kCamFloats + lane] = mine;
+  cam_fill(K, T0, T1, invK, cam, blockIdx.x, threadIdx.x);
 }
 
 // Colour pairs of one pixel: x[0] = (r,g) of candidate 0, x[1] = (r,g) of candidate 1, x[2] = (b0, b1)

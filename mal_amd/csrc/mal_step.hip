@@ -5,19 +5,19 @@
 // reductions, pose composition, and the same again in autograd's backward); the operator-level
 // API of this library still needs ~60 launches plus Python glue between them.  Here:
 //
-//   forward  1 pose_fwd (both frames)            layers.py:26-100
+//   forward  1 poses of both frames (layers.py:26-100) + the camera block P = K T of the passes
 //            1 identity term min_f r(src_f, target) (loss_utils.py:92-101) + packing of the sources into 16-byte texels
-//            1 camera block (P = K T of both frames per sample)
 //            1 teacher pass  (warp+SSIM+L1+min+automask+smoothness, fwd+bwd to disp and poses)   :573-581
 //            1 ensemble pass ((disp_t+disp_s)/2 formed in the kernel, no grad)                   :594-600
 //            1 student pass  (matching mask, consistency*(1-augmentation) mask, mono depth from the teacher's
 //                             disparity, consistency + distillation epilogue, smoothness)       :592-612
-//            1 per-sample reduction of the passes' partials + 1 scalar epilogue (fixed order, no atomics)
-//   backward 1 gradient assembly (both disparity maps) + 1 pose_bwd
+//            1 reduction of the passes' partials + pose gradients + loss scalars (fixed order, no atomics)
+//   backward 1 gradient assembly (both disparity maps) with the pose backward in its first block
 //
 // All intermediate maps live in the caller's workspace; loss scalars stay on the device.
 #include "mal_march.h"
 #include "mal_device.h"
+#include "mal_pose.h"
 
 namespace mal {
 
@@ -30,6 +30,7 @@ struct StepWs {
   float* G_r_t; float* G_r_s; float* G_c; float* G_d; float* gn_t; float* gn_s;
   double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
   double* ps;         // per-sample sums of the teacher's, then the student's partials: [2][B][8]
+  unsigned* ticket;   // completion counter of step_final_kernel
   double* sm_stats;   // [4B]: mean_t[b], mean_s[b], corr_t[b], corr_s[b] of the mean-normalised smoothness
   float* coefs;       // 16 device scalars for the backward
   float* cam;         // [B][40] camera block of the marching kernels
@@ -50,6 +51,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   w.bs_t = (double*)take(nb * 8 * 8); w.bs_s = (double*)take(nb * 8 * 8); w.bs_e = (double*)take(nb * 8 * 8);
   w.bgP = (float*)take(nb * 24 * 4);
   w.ps = (double*)take((size_t)2 * B * 8 * 8);
+  w.ticket = (unsigned*)take(4);
   w.sm_stats = (double*)take((size_t)4 * B * 8);
   w.coefs = (float*)take(16 * 4);
   w.cam = (float*)take((size_t)B * 40 * 4);
@@ -58,16 +60,33 @@ static StepWs carve_step(void* base, int B, int H, int W) {
 }
 
 // ---------------------------------------------------------------- small kernels
-// Second stage of the passes' reductions, one block per (pass, sample) and one per sample for the pose terms;
-// the marching tasks of a sample are contiguous.  Fixed summation order, no atomics.
-//   blocks [0, 2B):  ps[pass][b][j] = sum over the sample's tasks of block_sums[task][j]
+// poses of both frames (layers.py:26-100) and the camera block of the marching kernels, one block per sample
+__global__ __launch_bounds__(64) void step_pose_cam_kernel(PoseParams p, const float* K, const float* invK, float* cam,
+                                                           unsigned* ticket) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b == 0 && tid == 0) *ticket = 0u;  // step_final_kernel's completion counter, first kernel of every step
+  if (tid < 2) pose_fwd_one(p, tid, b);
+  __syncthreads();  // T of this sample, written by threads 0/1 to global memory, is visible to the block
+  cam_fill(K, p.T[0], p.T[1], invK, cam, b, tid);
+}
+
+// Everything after the three passes, fixed summation order, no floating-point atomics.  3B blocks:
+//   blocks [0, 2B):  ps[pass][b][j] = sum over the sample's marching tasks (contiguous) of block_sums[task][j]
 //   blocks [2B, 3B): g_T[f][b] = K_b^T [gP_fb ; 0]  from the teacher's per-task pose partials
-__global__ __launch_bounds__(256) void step_reduce_kernel(const double* bs_t, const double* bs_s, const float* bgP,
-                                                          const float* K, int per_sample, int B, double* ps,
-                                                          float* gT0, float* gT1) {
+// and the block that finishes last (a ticket counter, reset by step_pose_cam_kernel at the start of every
+// step) turns the per-sample sums into the smoothness of the mean-normalised disparities (layers.py:210-223,
+// loss_utils.py:119-121), the loss scalars (loss_utils.py:112-127,198-279; trainer.py:625-629) and the
+// coefficients of the backward.
+__global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, const double* bs_s, const float* bgP,
+                                                         const float* K, int per_sample, int B, int H, int W,
+                                                         float w_main, float w_distil, double* ps, float* gT0, float* gT1,
+                                                         double* stats, float* losses, float* coefs, float* loss_total,
+                                                         unsigned* ticket) {
   __shared__ double s_part[256];
   __shared__ double s_gP[24];
-  const int tid = threadIdx.x;
+  __shared__ double sh_tot[2][8];
+  __shared__ unsigned s_last;
+  const int tid = threadIdx.x, HW = H * W;
   if ((int)blockIdx.x < 2 * B) {
     const int pass = blockIdx.x / B, b = blockIdx.x - pass * B;
     const double* bs = (pass ? bs_s : bs_t) + (size_t)b * per_sample * 8;
@@ -81,46 +100,43 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const double* bs_t, co
       for (int k = 0; k < 32; ++k) a += s_part[k * 8 + tid];
       ps[((size_t)pass * B + b) * 8 + tid] = a;
     }
-    return;
+  } else {
+    const int b = blockIdx.x - 2 * B;
+    // 24 sums of per_sample partials: 8 lanes per value, then an 8-term sum (fixed order)
+    const int v = tid >> 3, sub = tid & 7;
+    double acc = 0.0;
+    if (v < 24)
+      for (int t = sub; t < per_sample; t += 8) acc += (double)bgP[((size_t)b * per_sample + t) * 24 + v];
+    s_part[tid] = acc;
+    __syncthreads();
+    if (v < 24 && sub == 0) {
+      double a = 0.0;
+      for (int k = 0; k < 8; ++k) a += s_part[tid + k];
+      s_gP[v] = a;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int f = tid >> 4, e = tid & 15, k = e >> 2, j = e & 3;
+      const float* Kb = K + b * 16;
+      double a = 0.0;
+      for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
+      (f ? gT1 : gT0)[b * 16 + e] = (float)a;
+    }
   }
-  const int b = blockIdx.x - 2 * B;
-  // 24 sums of per_sample partials: 8 lanes per value, then an 8-term sum (fixed order)
-  const int v = tid >> 3, sub = tid & 7;
-  double acc = 0.0;
-  if (v < 24)
-    for (int t = sub; t < per_sample; t += 8) acc += (double)bgP[((size_t)b * per_sample + t) * 24 + v];
-  s_part[tid] = acc;
+  // ---- the last block to get here does the scalar epilogue
+  __threadfence();
   __syncthreads();
-  if (v < 24 && sub == 0) {
-    double a = 0.0;
-    for (int k = 0; k < 8; ++k) a += s_part[tid + k];
-    s_gP[v] = a;
-  }
+  if (tid == 0) s_last = atomicAdd(ticket, 1u);
   __syncthreads();
-  if (tid < 32) {
-    const int f = tid >> 4, e = tid & 15, k = e >> 2, j = e & 3;
-    const float* Kb = K + b * 16;
-    double a = 0.0;
-    for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
-    (f ? gT1 : gT0)[b * 16 + e] = (float)a;
-  }
-}
-
-// loss scalars (loss_utils.py:112-127,198-279; trainer.py:625-629), the smoothness of the mean-normalised
-// disparities (layers.py:210-223, loss_utils.py:119-121) from the per-sample sums, and the coefficients of
-// the backward.  One wavefront; lane b owns sample b, sums over samples run in sample order.
-__global__ __launch_bounds__(64) void step_scalars_kernel(const double* ps, int B, int H, int W, float w_main,
-                                                          float w_distil, double* stats, float* losses, float* coefs,
-                                                          float* loss_total) {
-  __shared__ double sh[2][8];
-  const int lane = threadIdx.x, HW = H * W;
-  const double Nx = (double)B * H * (W - 1), Ny = (double)B * (H - 1) * W;
+  if (s_last != gridDim.x - 1) return;
+  __threadfence();
+  const volatile double* vps = ps;
   // sums over samples, fixed order; slots 4, 5 (smoothness) are weighted by the sample's 1/(mean+1e-7)
-  if (lane < 16) {
-    const int pass = lane >> 3, j = lane & 7;
+  if (tid < 16) {
+    const int pass = tid >> 3, j = tid & 7;
     double a = 0.0;
     for (int b = 0; b < B; ++b) {
-      const double* q = ps + ((size_t)pass * B + b) * 8;
+      const volatile double* q = vps + ((size_t)pass * B + b) * 8;
       double v = q[j];
       if (j == 4 || j == 5) {
         const float m = (float)(q[7] / (double)HW) + 1e-7f;
@@ -128,21 +144,21 @@ __global__ __launch_bounds__(64) void step_scalars_kernel(const double* ps, int 
       }
       a += v;
     }
-    sh[pass][j] = a;
+    sh_tot[pass][j] = a;
   }
   // per-sample statistics of the smoothness gradient: mean and the mean-coupling term dot/(HW (mean+eps)^2)
-  for (int s = lane; s < 2 * B; s += 64) {
-    const double* q = ps + (size_t)s * 8;
+  for (int s = tid; s < 2 * B; s += 256) {
+    const volatile double* q = vps + (size_t)s * 8;
     const double mean = q[7] / (double)HW;
     const double m = (double)((float)mean + 1e-7f);
     stats[s] = mean;
     stats[2 * B + s] = q[6] / ((double)HW * m * m);
   }
   __syncthreads();
-  if (lane != 0) return;
-  const double* st = sh[0];
-  const double* ss = sh[1];
-  const double N = (double)B * HW;
+  if (tid != 0) return;
+  const double* st = sh_tot[0];
+  const double* ss = sh_tot[1];
+  const double N = (double)B * HW, Nx = (double)B * H * (W - 1), Ny = (double)B * (H - 1) * W;
   const double reproj_t = st[0] / (st[1] + 1e-7), reproj_s = ss[0] / (ss[1] + 1e-7);
   const double cons = ss[2] / N, distil = ss[3] / N;
   const double smooth_t = st[4] / Nx + st[5] / Ny, smooth_s = ss[4] / Nx + ss[5] / Ny;
@@ -164,17 +180,22 @@ __global__ __launch_bounds__(64) void step_scalars_kernel(const double* ps, int 
   coefs[4] = w_main * 1e-3f;                                // smoothness
 }
 
-// d total / d disp for both maps, and the pose gradients scaled for pose_bwd
+// d total / d disp for both maps; block 0 also scales the pose gradients and runs the backward of
+// transformation_from_parameters (pp.gT = the scaled gradients, pp.g_axisangle / g_translation nullable)
 __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, const float* G_r_s, const float* G_c,
                                                             const float* G_d, const float* gn_t, const float* gn_s,
                                                             const float* coefs, const double* stats, const float* g_total,
                                                             int B, int HW, const float* gT0, const float* gT1,
-                                                            float* gTs0, float* gTs1, float* g_disp_t, float* g_disp_s) {
+                                                            float* gTs0, float* gTs1, float* g_disp_t, float* g_disp_s,
+                                                            PoseParams pp, int pose_bwd) {
   const float g = g_total ? *g_total : 1.0f;
   const float cRt = coefs[0] * g, cRs = coefs[1] * g, cC = coefs[2] * g, cD = coefs[3] * g, cS = coefs[4] * g;
   const size_t n = (size_t)B * HW;
-  if (blockIdx.x == 0 && threadIdx.x < 32) {
-    for (int i = threadIdx.x; i < B * 16; i += 32) { gTs0[i] = gT0[i] * cRt; gTs1[i] = gT1[i] * cRt; }
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < B * 16; i += 256) { gTs0[i] = gT0[i] * cRt; gTs1[i] = gT1[i] * cRt; }
+    __syncthreads();
+    if (pose_bwd)
+      for (int i = threadIdx.x; i < B * 2; i += 256) pose_bwd_one(pp, i / B, i % B);
   }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / HW);
@@ -193,10 +214,6 @@ extern "C" size_t mal_step_workspace_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   return carve_step(nullptr, B, H, W).bytes;
 }
-
-extern "C" int mal_pose_fwd(const float* const*, const float* const*, const int*, int, int, float* const*, void*);
-extern "C" int mal_pose_bwd(const float* const*, const float* const*, const int*, const float* const*, int, int,
-                            float* const*, float* const*, void*);
 
 static int step_check(const mal_step_args* a) {
   if (!a) return MAL_EINVAL;
@@ -221,21 +238,22 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   float* ens_reproj = no_ens ? nullptr : (a->ens_reproj ? a->ens_reproj : w.ens_reproj);
   float* multi_reproj = a->multi_reproj ? a->multi_reproj : w.multi_reproj;
 
-  // 1. poses (frame -1 is inverted, networks/repdepth.py:159-160)
+  // 1. poses (frame -1 is inverted, networks/repdepth.py:159-160) + the camera block of the passes
   {
-    const float* aa[2] = {a->axisangle_m1, a->axisangle_p1};
-    const float* tr[2] = {a->translation_m1, a->translation_p1};
-    const int inv[2] = {1, 0};
-    float* T[2] = {w.T[0], w.T[1]};
-    rc = mal_pose_fwd(aa, tr, inv, B, 2, T, a->stream);
-    if (rc) return rc;
+    PoseParams pp = {};
+    pp.B = B; pp.F = 2;
+    pp.axisangle[0] = a->axisangle_m1; pp.axisangle[1] = a->axisangle_p1;
+    pp.translation[0] = a->translation_m1; pp.translation[1] = a->translation_p1;
+    pp.invert[0] = 1; pp.invert[1] = 0;
+    pp.T[0] = w.T[0]; pp.T[1] = w.T[1];
+    hipLaunchKernelGGL(step_pose_cam_kernel, dim3(B), dim3(64), 0, st, pp, a->K, a->inv_K, w.cam, w.ticket);
   }
   // 2. identity term + texel packing of the three images (one 16-byte load per pixel in the passes)
   rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st);
   if (rc) return rc;
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
   int per_sample = 1;
-  int cam_ready = 0;  // the first pass fills the camera block, the others reuse it
+  int cam_ready = 1;  // step_pose_cam_kernel filled the camera block
   // 5. teacher pass
   {
     MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
@@ -276,11 +294,10 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
     if (rc) return rc;
   }
-  // 8. per-sample sums of both gradient passes + pose gradients, then the scalars
-  hipLaunchKernelGGL(step_reduce_kernel, dim3(3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, w.bgP, a->K, per_sample, B,
-                     w.ps, w.gT[0], w.gT[1]);
-  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(64), 0, st, w.ps, B, H, W, a->w_main, a->w_distil, w.sm_stats,
-                     a->losses, w.coefs, a->loss_total);
+  // 8. per-sample sums of both gradient passes, pose gradients, scalars
+  hipLaunchKernelGGL(step_final_kernel, dim3(3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, w.bgP, a->K, per_sample, B, H, W,
+                     a->w_main, a->w_distil, w.ps, w.gT[0], w.gT[1], w.sm_stats, a->losses, w.coefs, a->loss_total,
+                     w.ticket);
   return launch_status();
 }
 
@@ -292,19 +309,18 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   hipStream_t st = (hipStream_t)a->stream;
   size_t g = ((size_t)B * HW + 255) / 256;
   if (g > 2048) g = 2048;
+  PoseParams pp = {};
+  pp.B = B; pp.F = 2;
+  pp.axisangle[0] = a->axisangle_m1; pp.axisangle[1] = a->axisangle_p1;
+  pp.translation[0] = a->translation_m1; pp.translation[1] = a->translation_p1;
+  pp.invert[0] = 1; pp.invert[1] = 0;
+  pp.gT[0] = w.gTs[0]; pp.gT[1] = w.gTs[1];
+  pp.g_axisangle[0] = a->g_axisangle_m1; pp.g_axisangle[1] = a->g_axisangle_p1;
+  pp.g_translation[0] = a->g_translation_m1; pp.g_translation[1] = a->g_translation_p1;
+  const int pose_bwd = (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) ? 1 : 0;
   hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.G_d, w.gn_t,
                      w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
-                     a->g_disp_teacher, a->g_disp_student);
+                     a->g_disp_teacher, a->g_disp_student, pp, pose_bwd);
   rc = launch_status();
-  if (rc) return rc;
-  if (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) {
-    const float* aa[2] = {a->axisangle_m1, a->axisangle_p1};
-    const float* tr[2] = {a->translation_m1, a->translation_p1};
-    const int inv[2] = {1, 0};
-    const float* gT[2] = {w.gTs[0], w.gTs[1]};
-    float* gaa[2] = {a->g_axisangle_m1, a->g_axisangle_p1};
-    float* gtr[2] = {a->g_translation_m1, a->g_translation_p1};
-    rc = mal_pose_bwd(aa, tr, inv, gT, B, 2, gaa, gtr, a->stream);
-  }
   return rc;
 }
