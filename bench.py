@@ -225,8 +225,8 @@ def main():
                    "launch": "hip-graph" if graph is not None else "eager",
                    "api": "mal_loss_step_fwd/_bwd (one host call per direction)" if args.mode == "step"
                           else "operator-level (mal_amd.loss_utils / MALLossPath)"},
-        "roofline": {"bound": "hbm", "kernel": "mal::pass_kernel<GRAD,AUTOMASK,POSE> (teacher pass: warp+SSIM+L1+"
-                                               "min+automask fwd+bwd, one launch)",
+        "roofline": {"bound": "hbm", "kernel": "mal::march_kernel<true,true,true,false> (teacher pass: warp+SSIM+L1+"
+                                               "min+automask+smoothness fwd+bwd, one launch)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "alg_bytes_per_px": ALG_BYTES_PER_PX, "pixels_per_launch": n_px,
                      "kernel_ms": kern_ms, "launches_timed": len(durs)},
