@@ -167,16 +167,18 @@ def test_identity_min_and_fused_ensemble_agree():
     assert (outs[1] - outs[0]).abs().max().item() <= 1e-4 and (outs[2] - outs[0]).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("fuse,avg", [(True, False), (False, False), (False, True)],
-                         ids=["fused", "explicit", "explicit-avg"])
-def test_dualrefine_loss_path(fuse, avg):
+@pytest.mark.parametrize("fuse,avg,shape", [(True, False, (2, 40, 72)), (False, False, (2, 40, 72)),
+                                            (False, True, (2, 40, 72)), (True, False, (8, 192, 640))],
+                         ids=["fused", "explicit", "explicit-avg", "fused-b8_192x640"])
+def test_dualrefine_loss_path(fuse, avg, shape):
     """a17: DualRefine's per-(scale, deq_iter) loops (dualrefine/trainer.py:395-451,530-633) with the
-    align_corners=False convention, against the oracle's restatement of the same lines."""
+    align_corners=False convention, against the oracle's restatement of the same lines; the last case is
+    BASELINE.json configs[4] (B=8 192x640)."""
     from mal_amd import dualrefine, layers
     from mal_amd.synthetic import make_batch
     from oracle import mal_oracle as O
     from tests import hip_harness as HH
-    B, H, W = 2, 40, 72
+    B, H, W = shape
     batch = make_batch(B, H, W, seed=321)
     torch.manual_seed(5)
     noises = [torch.randn(B, 1, H, W) for _ in range(2)]

@@ -45,7 +45,22 @@ def test_loss_step_against_oracle(tag):
     b = G.batch_from_golden(z)
     B, _, H, W = b["color0"].shape
     n0, n1 = G.noises(z, (B, 1, H, W))
-    kw = G.opt_kwargs(z)
+    _check_step(b, G.opt_kwargs(z), n0, n1)
+
+
+@pytest.mark.parametrize("B,H,W", [(12, 192, 640), (12, 192, 512)], ids=["kitti_b12_192x640", "cityscapes_b12_192x512"])
+def test_loss_step_at_baseline_sizes(B, H, W):
+    """BASELINE.json configs[1] / configs[3] shapes on the synthetic batch bench.py uses: the oracle still
+    finishes in seconds there, so the full-size step is held against it directly."""
+    from mal_amd.synthetic import make_batch
+    b = make_batch(B, H, W, seed=77)
+    g = torch.Generator().manual_seed(5)
+    n0, n1 = torch.randn(B, 1, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
+    _check_step(b, {}, n0, n1)
+
+
+def _check_step(b, kw, n0, n1):
+    B, _, H, W = b["color0"].shape
     o = HH.run_oracle(b, kw, n0, n1)
     h = run_step(b, kw, n0)
     N = B * H * W
