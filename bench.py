@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a HIP graph (default); 0: eager launches")
-    ap.add_argument("--mode", choices=["step", "ops"], default="step",
+    ap.add_argument("--mode", choices=["step", "ops", "temporal"], default="step",
                     help="step: mal_loss_step (one C call per direction); ops: the operator-level API")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
@@ -64,7 +64,7 @@ class Step:
         self.layers = layers
         from mal_amd import ops
         self.ops = ops
-        b = make_batch(B, H, W, seed=seed)
+        b = make_batch(B, H, W, seed=seed, with_syn=(mode == "temporal"))
         mv = lambda t: t.to(dev).contiguous()
         self.inputs = {("color", 0, 0): mv(b["color0"]), ("color", -1, 0): mv(b["color_m1"]),
                        ("color", 1, 0): mv(b["color_p1"]), ("K", 0): mv(b["K"]), ("inv_K", 0): mv(b["inv_K"])}
@@ -72,7 +72,12 @@ class Step:
                        ("disp_teacher", "disp_student", "axisangle_m1", "translation_m1", "axisangle_p1",
                         "translation_p1")}
         self.cmask, self.aug, self.lowest = mv(b["consistency_mask"]), mv(b["augmentation_mask"]), mv(b["lowest_cost"])
-        self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B), fuse=True)
+        if mode == "temporal":  # --temporal --distil: the producer (Mask2Former + patch shifts) is stood in for
+            from mal_amd.synthetic import fake_image_synthesis
+            self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, temporal=True), fuse=True,
+                                       image_synthesis=fake_image_synthesis(b["syn_rects"]))
+        else:
+            self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B), fuse=True)
         self.batch_cpu = b
 
     def __call__(self):

@@ -256,9 +256,13 @@ size_t mal_step_workspace_bytes(int B, int H, int W);
 int mal_loss_step_fwd(const mal_step_args* args);
 int mal_loss_step_bwd(const mal_step_args* args);
 
-/* ---- library options: "pass_impl" selects the fused-pass formulation: 2 = LDS-tiled, 512 threads x
- * 2 px (default); 1 = register-marching; 0 = LDS-tiled first version (both kept for A/B);
- * "march_rows" = output rows per wavefront task of the marching kernel (0 = automatic, default). */
+/* ---- library options:
+ * "pass_impl"   formulation of the fused pass: 1 = register-marching (default); 0 / 2 = the LDS-tiled first
+ *               versions (256 threads x 4 px, 512 threads x 2 px), kept for A/B;
+ * "march_rows"  output rows per wavefront task of the marching kernels (0 = automatic, default);
+ * "photo_impl"  mal_photo_fwd/bwd: 1 = marching kernels, two candidates per launch (default for SSIM + min);
+ *               0 = one pixel per thread (ATen's summation order; always used for MAL_F_NO_SSIM / MAL_F_AVG);
+ * "fwd_waves", "debug": kernel experiments. */
 int mal_set_option(const char* name, int value);
 
 /* ---- measurement hooks (bench.py): HIP events recorded immediately before / after the main

@@ -1,0 +1,94 @@
+// Device-side helpers of the marching kernels (mal_march.hip, mal_photo_march.hip): DPP horizontal sums,
+// packed fp32 pairs (two values per lane per issue), uniform-base global accesses, SSIM on window sums.
+#pragma once
+#include "mal_device.h"
+
+namespace mal {
+
+MAL_DEV float dpp_shr1(float v) {  // lane i <- lane i-1 (lane 0 <- 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+MAL_DEV float dpp_shl1(float v) {  // lane i <- lane i+1 (lane 63 <- 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+MAL_DEV float hsum3(float v) { return (dpp_shr1(v) + v) + dpp_shl1(v); }
+
+constexpr float kC1s = 81.0f * 0.0001f;  // 81 * C1
+constexpr float kC2s = 81.0f * 0.0009f;  // 81 * C2
+
+// ---------------------------------------------------------------- packed fp32 (two values per lane)
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+MAL_DEV f2 bc(float v) { return (f2){v, v}; }
+MAL_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+MAL_DEV f2 rcp2(f2 a) { return (f2){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+MAL_DEV f2 hsum3(f2 v) { return (f2){hsum3(v.x), hsum3(v.y)}; }
+// div_ / div_safe_ / div3_ of mal_device.h, element for element
+MAL_DEV f2 div2_(f2 a, f2 b) {
+  f2 y = rcp2(b);
+  y = fma2(fma2(-b, y, bc(1.0f)), y, y);
+  const f2 q = a * y;
+  const f2 r = fma2(-b, q, a);
+  return fma2(r, y, q);
+}
+MAL_DEV f2 div_safe2_(f2 a, f2 b) {
+  const f2 y0 = rcp2(b);
+  const f2 y = fma2(fma2(-b, y0, bc(1.0f)), y0, y0);
+  const f2 q = a * y;
+  const f2 r = fma2(-b, q, a);
+  const f2 q1 = fma2(r, y, q);
+  const f2 alt = a * y0;
+  return (f2){__builtin_isfinite(q1.x) ? q1.x : alt.x, __builtin_isfinite(q1.y) ? q1.y : alt.y};
+}
+MAL_DEV f2 div3_2(f2 a) {
+  const f2 q = a * bc(0.333333333333333333f);
+  const f2 r = fma2(bc(-3.0f), q, a);
+  return fma2(r, bc(0.333333333333333333f), q);
+}
+// Global accesses as (wave-uniform base) + (32-bit per-lane BYTE offset): the saddr form of global_load/
+// global_store.  One offset register serves every map that is read at the same pixel and no 64-bit vector
+// address arithmetic is needed (check_shape bounds every tensor below 2^31 bytes).
+MAL_DEV float ldf(const float* base, unsigned boff) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+}
+MAL_DEV f4 ldf4(const float* base, unsigned boff) {
+  return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(base) + boff);
+}
+MAL_DEV void stf(float* base, unsigned boff, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v; }
+// the three colour channels of pixel `pix` of sample b: planar (B,3,H,W) or packed (B,H,W,4)
+MAL_DEV void load_rgb(const float* img, int packed, int b, int HW, unsigned pix, float* out) {
+  if (packed) {
+    const f4 v = ldf4(img + (size_t)b * HW * 4, pix * 16u);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+  } else {
+    const float* pl = img + (size_t)b * 3 * HW;
+    out[0] = ldf(pl, pix * 4u); out[1] = ldf(pl + HW, pix * 4u); out[2] = ldf(pl + 2 * (size_t)HW, pix * 4u);
+  }
+}
+MAL_DEV float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// SSIM of two windows at once from their sums; un-clamped (1 - S)/2 and, with GRAD, the partials of S
+// wrt the window sums of x: dS/d(sum x), 2 dS/d(sum x^2) (the 2 of d x^2/dx folded in), dS/d(sum xy)
+template <bool GRAD>
+MAL_DEV f2 ssim_sums2(f2 sx, f2 sy, f2 sxx, f2 vy /* 9 syy - sy^2 */, f2 d1y /* sy^2 + 81 C1 */, f2 sxy, f2* dsx,
+                      f2* dsxx2, f2* dsxy) {
+  const f2 pxy = sx * sy;
+  const f2 n1 = fma2(bc(2.0f), pxy, bc(kC1s));
+  const f2 n2 = fma2(bc(2.0f), fma2(bc(9.0f), sxy, -pxy), bc(kC2s));
+  const f2 d1 = fma2(sx, sx, d1y);
+  const f2 d2 = (fma2(-sx, sx, bc(9.0f) * sxx) + vy) + bc(kC2s);
+  const f2 n = n1 * n2, d = d1 * d2;
+  f2 rd = rcp2(d);
+  rd = fma2(fma2(-d, rd, bc(1.0f)), rd, rd);
+  const f2 S = n * rd;
+  if (GRAD) {
+    const f2 t1 = sy * (n2 - n1);
+    const f2 t2 = (S * sx) * (d2 - d1);
+    *dsx = (bc(2.0f) * (t1 - t2)) * rd;
+    *dsxx2 = (bc(-18.0f) * S) * (d1 * rd);
+    *dsxy = (bc(18.0f) * n1) * rd;
+  }
+  return fma2(S, bc(-0.5f), bc(0.5f));
+}
+
+}  // namespace mal

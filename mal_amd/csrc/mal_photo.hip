@@ -160,6 +160,14 @@ __global__ __launch_bounds__(256) void reproj_bwd_kernel(const float* pred, cons
 }
 
 // ---------------------------------------------------------------- photo fwd / bwd
+// marching formulation (mal_photo_march.hip), the default for SSIM + min
+extern int g_photo_impl;
+int photo_march_fwd(const float* target, const float* const* cand, int n_cand, const float* ident, const float* noise,
+                    const float* ext_mask, int B, int H, int W, int automask, float* min_reproj, uint8_t* argmin,
+                    float* weight_out, double* block_sums, int* ntasks_out, hipStream_t st);
+int photo_march_bwd(const float* target, const float* const* cand, int n_cand, const uint8_t* argmin, const float* weight,
+                    const float* scale, const double* sums, int B, int H, int W, float* const* g_cand, hipStream_t st);
+
 struct PhotoParams {
   const float* target; const float* cand[MAL_MAX_CAND]; int n_cand;
   const float* ident; const float* noise; const float* ext_mask;
@@ -545,9 +553,18 @@ extern "C" int mal_photo_fwd(const float* target, const float* const* cand, int 
   if ((flags & MAL_F_AUTOMASK) && !ident) return MAL_EINVAL;
   Workspace w = carve(ws, B, H, W);
   if (ws_bytes < w.bytes) return MAL_EWORKSPACE;
+  for (int c = 0; c < n_cand; ++c) if (!cand[c]) return MAL_EINVAL;
+  if (g_photo_impl == 1 && !(flags & (MAL_F_NO_SSIM | MAL_F_AVG)) && (n_cand <= 2 || (min_reproj && argmin_u8))) {
+    int ntasks = 0;  // marching kernels (mal_photo_march.hip), two candidates per launch
+    rc = photo_march_fwd(target, cand, n_cand, ident, noise, ext_mask, B, H, W, (flags & MAL_F_AUTOMASK) ? 1 : 0,
+                         min_reproj, argmin_u8, weight_out, w.block_sums, &ntasks, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w.block_sums, ntasks, 2, 2, sums);
+    return launch_status();
+  }
   PhotoParams p = {};
   p.target = target; p.n_cand = n_cand;
-  for (int c = 0; c < n_cand; ++c) { if (!cand[c]) return MAL_EINVAL; p.cand[c] = cand[c]; }
+  for (int c = 0; c < n_cand; ++c) p.cand[c] = cand[c];
   p.ident = ident; p.noise = noise; p.ext_mask = ext_mask; p.B = B; p.H = H; p.W = W; p.flags = flags;
   p.min_reproj = min_reproj; p.argmin_u8 = argmin_u8; p.weight_out = weight_out; p.block_sums = w.scratch;
   const int grid = ew_grid2((size_t)B * H * W, 2048);
@@ -565,6 +582,9 @@ extern "C" int mal_photo_bwd(const float* target, const float* const* cand, int 
   int rc = check_shape(B, H, W);
   if (rc) return rc;
   if (!target || !cand || n_cand < 1 || n_cand > MAL_MAX_CAND || !argmin_u8 || !weight || !g_cand) return MAL_EINVAL;
+  for (int c = 0; c < n_cand; ++c) if (!cand[c]) return MAL_EINVAL;
+  if (g_photo_impl == 1 && !(flags & (MAL_F_NO_SSIM | MAL_F_AVG)))
+    return photo_march_bwd(target, cand, n_cand, argmin_u8, weight, scale, sums, B, H, W, g_cand, (hipStream_t)stream);
   PhotoParams p = {};
   p.target = target; p.n_cand = n_cand;
   for (int c = 0; c < n_cand; ++c) { if (!cand[c]) return MAL_EINVAL; p.cand[c] = cand[c]; p.g_cand[c] = g_cand[c]; }

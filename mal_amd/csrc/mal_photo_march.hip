@@ -1,0 +1,358 @@
+// The min-reprojection / automask reduction over MATERIALISED candidate images and its backward, in the
+// marching form of mal_march.hip (one wavefront per 64-column strip walking rows, DPP horizontal sums,
+// running vertical sums, packed fp32 over colour pairs) -- the consumer side of the temporal hint
+// (manydepth/loss_utils.py:84-101,152-160: the candidates are the warped sources plus ("syn", f, s)) and of
+// every `fuse=False` route.  Candidates are processed two at a time (the pair structure of the fused pass):
+//
+//   forward   one launch per pair; a later pair continues the running min / argmin of the earlier ones
+//             (first minimum wins, as torch.min), the last one forms the weight (automask x ext_mask),
+//             the outputs and the per-task partial sums
+//   backward  one launch per pair: d sum(rp*w) / d candidate for the pair's two images, from the argmin and
+//             weight maps of the forward.  Only the winner of a pixel has SSIM/L1 partials, but a pixel
+//             collects them from its 3x3 neighbours, whose winners differ: 18 partial planes per pair.
+//
+// Same numerics as march_kernel (SSIM on window sums scaled by 81^2; reassociation <= 1e-5 against the
+// one-pixel-per-thread kernels of mal_photo.hip, which keep ATen's summation order and stay available:
+// mal_set_option("photo_impl", 0); they also serve MAL_F_NO_SSIM / MAL_F_AVG).
+#include "mal_common.h"
+#include "mal_device.h"
+#include "mal_pairs.h"
+
+namespace mal {
+
+struct PhotoMarchParams {
+  const float* target; const float* cand[2];   // planar (B,3,H,W)
+  int idx[2];                                   // the candidates' indices in the caller's list; idx[1] < 0: single candidate
+  const float* ident; const float* noise; const float* ext_mask;
+  const float* prev_min; const uint8_t* prev_arg;   // running min / argmin of earlier pairs (nullable)
+  int last, automask;
+  float* min_reproj; uint8_t* argmin; float* weight_out; double* block_sums;  // [task][2]
+  // backward
+  const uint8_t* argmin_in; const float* weight_in; const float* scale; const double* sums;
+  float* g_cand[2];                              // (B,3,H,W) each, [1] nullable
+  int B, H, W, strips, segs, rows, ntasks, per_xcd;
+};
+
+struct Px9 { float t[3], a[3], c[3]; };
+
+// the nine planes of pixel (row rr reflected, column gxr) of sample b
+MAL_DEV void request9(const PhotoMarchParams& p, const float* tb, const float* ab, const float* cb, int HW, int row,
+                      int gxr, Px9& q) {
+  const unsigned bo = (unsigned)(row * p.W + gxr) * 4u;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    q.t[ch] = ldf(tb + (size_t)ch * HW, bo); q.a[ch] = ldf(ab + (size_t)ch * HW, bo); q.c[ch] = ldf(cb + (size_t)ch * HW, bo);
+  }
+}
+
+__global__ __launch_bounds__(64, 4) void photo_march_fwd_kernel(PhotoMarchParams p) {
+  constexpr int HALO = 1, CW = 62;
+  const int id = blockIdx.x;
+  const int task = (id & 7) * p.per_xcd + (id >> 3);
+  if (task >= p.ntasks) return;
+  const int per_b = p.strips * p.segs;
+  const int b = task / per_b, tt = task - b * per_b;
+  const int seg = tt / p.strips, strip = tt - seg * p.strips;
+  const int H = p.H, W = p.W, HW = H * W, lane = threadIdx.x;
+  const int y_lo = seg * p.rows, y_hi = min(y_lo + p.rows, H);
+  const int gx = strip * CW - HALO + lane;
+  const bool in_x = gx >= 0 && gx < W;
+  const int gxr = min(max(reflect1(gx, W), 0), W - 1);
+  const bool out_x = in_x && lane >= HALO && lane < 64 - HALO;
+  const float* tb = p.target + (size_t)b * 3 * HW;
+  const float* ab = p.cand[0] + (size_t)b * 3 * HW;
+  const float* cb = p.cand[1] + (size_t)b * 3 * HW;
+  const size_t map_b = (size_t)b * HW;
+  const bool single = p.idx[1] < 0;
+  f2 hsA[9], hsB[9], hyA[2], hyB[2];
+  float hzA[2], hzB[2];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { hsA[i] = bc(0.f); hsB[i] = bc(0.f); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { hyA[i] = bc(0.f); hyB[i] = bc(0.f); hzA[i] = 0.f; hzB[i] = 0.f; }
+  f2 x1[3] = {bc(0.f), bc(0.f), bc(0.f)}, y1rg = bc(0.f);
+  float y1b = 0.f, acc_rw = 0.f, acc_w = 0.f;
+  auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
+  const int r_first = max(y_lo - 1, -1);
+  Px9 nxt;
+  request9(p, tb, ab, cb, HW, row_of(r_first), gxr, nxt);
+  for (int r = r_first; r <= y_hi; ++r) {
+    const Px9 cur = nxt;
+    request9(p, tb, ab, cb, HW, row_of(r + 1), gxr, nxt);
+    const int c = r - 1;
+    const bool c_own = c >= y_lo && c < y_hi;
+    // the maps of the centre row, requested before the arithmetic of this row
+    const unsigned go = (unsigned)(min(max(c, 0), H - 1) * W + gxr) * 4u;
+    float pm = 0.f, idn = 0.f, nz = 0.f, em = 1.f;
+    int pa = 0;
+    if (c_own) {
+      if (p.prev_min) { pm = ldf(p.prev_min + map_b, go); pa = p.prev_arg[map_b + (go >> 2)]; }
+      if (p.last) {
+        if (p.automask) { idn = ldf(p.ident + map_b, go); if (p.noise) nz = ldf(p.noise + map_b, go); }
+        if (p.ext_mask) em = ldf(p.ext_mask + map_b, go);
+      }
+    }
+    const f2 x0[3] = {(f2){cur.a[0], cur.a[1]}, (f2){cur.c[0], cur.c[1]}, (f2){cur.a[2], cur.c[2]}};
+    const f2 y0rg = (f2){cur.t[0], cur.t[1]};
+    const float y0b = cur.t[2];
+    f2 h[9], hy[2];
+    float hz[2];
+    hy[0] = hsum3(y0rg); hy[1] = hsum3(y0rg * y0rg);
+    hz[0] = hsum3(y0b);  hz[1] = hsum3(y0b * y0b);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f2 x = x0[k], y = k < 2 ? y0rg : bc(y0b);
+      h[k * 3 + 0] = hsum3(x);
+      h[k * 3 + 1] = hsum3(x * x);
+      h[k * 3 + 2] = hsum3(x * y);
+    }
+    if (c_own) {  // wave-uniform
+      const f2 syq = hyA[0] + hy[0], syyq = hyA[1] + hy[1];
+      const float syz = hzA[0] + hz[0], syyz = hzA[1] + hz[1];
+      const f2 vyq = fma2(-syq, syq, bc(9.0f) * syyq), d1yq = fma2(syq, syq, bc(kC1s));
+      const float vyz = fma_(-syz, syz, 9.0f * syyz), d1yz = fma_(syz, syz, kC1s);
+      f2 vc[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f2 sx = hsA[k * 3] + h[k * 3], sxx = hsA[k * 3 + 1] + h[k * 3 + 1], sxy = hsA[k * 3 + 2] + h[k * 3 + 2];
+        const f2 v = ssim_sums2<false>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
+                                       nullptr, nullptr, nullptr);
+        vc[k] = (f2){clamp01(v.x), clamp01(v.y)};
+      }
+      const f2 ssum = (f2){(vc[0].x + vc[0].y) + vc[2].x, (vc[1].x + vc[1].y) + vc[2].y};
+      const f2 l0 = y1rg - x1[0], l1 = y1rg - x1[1], l2 = bc(y1b) - x1[2];
+      const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
+      const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
+      // running min, first minimum wins (torch.min)
+      float rp = rr.x;
+      int win = p.idx[0];
+      if (p.prev_min) { rp = pm; win = pa; if (rr.x < rp) { rp = rr.x; win = p.idx[0]; } }
+      if (!single && rr.y < rp) { rp = rr.y; win = p.idx[1]; }
+      if (out_x) {
+        if (p.min_reproj) stf(p.min_reproj + map_b, go, rp);
+        if (p.argmin) p.argmin[map_b + (go >> 2)] = (uint8_t)win;
+        if (p.last) {
+          float w = 1.0f;
+          if (p.automask) w = (rp <= idn + nz * 0.00001f) ? 1.0f : 0.0f;
+          w *= em;
+          if (p.weight_out) stf(p.weight_out + map_b, go, w);
+          acc_rw += rp * w;
+          acc_w += w;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i] + h[i]; hsB[i] = h[i]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { hyA[i] = hyB[i] + hy[i]; hyB[i] = hy[i]; hzA[i] = hzB[i] + hz[i]; hzB[i] = hz[i]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x1[k] = x0[k];
+    y1rg = y0rg; y1b = y0b;
+  }
+  if (p.last) {
+    const double r0 = wave_sum_d((double)acc_rw), r1 = wave_sum_d((double)acc_w);
+    if (lane == 0) { p.block_sums[(size_t)task * 2] = r0; p.block_sums[(size_t)task * 2 + 1] = r1; }
+  }
+}
+
+__global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams p) {
+  constexpr int HALO = 2, CW = 60;
+  const int id = blockIdx.x;
+  const int task = (id & 7) * p.per_xcd + (id >> 3);
+  if (task >= p.ntasks) return;
+  const int per_b = p.strips * p.segs;
+  const int b = task / per_b, tt = task - b * per_b;
+  const int seg = tt / p.strips, strip = tt - seg * p.strips;
+  const int H = p.H, W = p.W, HW = H * W, lane = threadIdx.x;
+  const int y_lo = seg * p.rows, y_hi = min(y_lo + p.rows, H);
+  const int gx = strip * CW - HALO + lane;
+  const bool in_x = gx >= 0 && gx < W;
+  const int gxr = min(max(reflect1(gx, W), 0), W - 1);
+  const bool out_x = in_x && lane >= HALO && lane < 64 - HALO;
+  const float sL = gx == 0 ? 2.0f : 1.0f, sR = gx == W - 1 ? 2.0f : 1.0f;
+  const float* tb = p.target + (size_t)b * 3 * HW;
+  const float* ab = p.cand[0] + (size_t)b * 3 * HW;
+  const float* cb = p.cand[1] + (size_t)b * 3 * HW;
+  float* ga = p.g_cand[0] + (size_t)b * 3 * HW;
+  float* gb = p.g_cand[1] ? p.g_cand[1] + (size_t)b * 3 * HW : nullptr;
+  const size_t map_b = (size_t)b * HW;
+  float sc = p.scale ? *p.scale : 1.0f;
+  if (p.sums) sc = (float)((double)sc / (p.sums[1] + 1e-7));
+  f2 hsA[9], hsB[9], hyA[2], hyB[2], hcA[9], hcB[9];
+  float hzA[2], hzB[2];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { hsA[i] = bc(0.f); hsB[i] = bc(0.f); hcA[i] = bc(0.f); hcB[i] = bc(0.f); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { hyA[i] = bc(0.f); hyB[i] = bc(0.f); hzA[i] = 0.f; hzB[i] = 0.f; }
+  // raw values of rows r-1 and r-2 (L1 term of the centre row; own pixel of the gradient row)
+  f2 x1[3] = {bc(0.f), bc(0.f), bc(0.f)}, x2[3] = {bc(0.f), bc(0.f), bc(0.f)}, y1rg = bc(0.f), y2rg = bc(0.f);
+  float y1b = 0.f, y2b = 0.f;
+  float w1 = 0.f;  // weight and winner of row c-1 = r-2
+  int win1 = 255;
+  auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
+  const int r_first = max(y_lo - HALO, -1), r_last = y_hi - 1 + HALO;
+  Px9 nxt;
+  request9(p, tb, ab, cb, HW, row_of(r_first), gxr, nxt);
+  for (int r = r_first; r <= r_last; ++r) {
+    const Px9 cur = nxt;
+    request9(p, tb, ab, cb, HW, row_of(r + 1), gxr, nxt);
+    const int c = r - 1;
+    const bool c_valid = c >= 0 && c < H && c >= y_lo - 1 && c <= y_hi;
+    float w0 = 0.f;
+    int win0 = 255;
+    if (c_valid) {
+      const unsigned go = (unsigned)(c * W + gxr);
+      w0 = in_x ? ldf(p.weight_in + map_b, go * 4u) : 0.f;  // not a pixel: contributes nothing
+      win0 = p.argmin_in[map_b + go];
+    }
+    const f2 x0[3] = {(f2){cur.a[0], cur.a[1]}, (f2){cur.c[0], cur.c[1]}, (f2){cur.a[2], cur.c[2]}};
+    const f2 y0rg = (f2){cur.t[0], cur.t[1]};
+    const float y0b = cur.t[2];
+    f2 h[9], hy[2];
+    float hz[2];
+    hy[0] = hsum3(y0rg); hy[1] = hsum3(y0rg * y0rg);
+    hz[0] = hsum3(y0b);  hz[1] = hsum3(y0b * y0b);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f2 x = x0[k], y = k < 2 ? y0rg : bc(y0b);
+      h[k * 3 + 0] = hsum3(x);
+      h[k * 3 + 1] = hsum3(x * x);
+      h[k * 3 + 2] = hsum3(x * y);
+    }
+    // ---- SSIM partials of the centre row c for the candidate that won there (if it is one of this pair)
+    f2 coef[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) coef[i] = bc(0.f);
+    if (c_valid) {  // wave-uniform
+      const f2 syq = hyA[0] + hy[0], syyq = hyA[1] + hy[1];
+      const float syz = hzA[0] + hz[0], syyz = hzA[1] + hz[1];
+      const f2 vyq = fma2(-syq, syq, bc(9.0f) * syyq), d1yq = fma2(syq, syq, bc(kC1s));
+      const float vyz = fma_(-syz, syz, 9.0f * syyz), d1yz = fma_(syz, syz, kC1s);
+      const float kk = -w0 * (0.85f / 3.0f) * 0.5f;
+      const float kk0 = win0 == p.idx[0] ? kk : 0.f, kk1 = win0 == p.idx[1] ? kk : 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f2 sx = hsA[k * 3] + h[k * 3], sxx = hsA[k * 3 + 1] + h[k * 3 + 1], sxy = hsA[k * 3 + 2] + h[k * 3 + 2];
+        f2 pa, pb, pc;
+        const f2 v = ssim_sums2<true>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
+                                      &pa, &pb, &pc);
+        // torch.clamp passes gradient on [0,1] inclusive (clamped == raw)
+        const float ka = k == 1 ? kk1 : kk0, kb = k == 0 ? kk0 : kk1;
+        const f2 g = (f2){clamp01(v.x) == v.x ? ka : 0.f, clamp01(v.y) == v.y ? kb : 0.f};
+        coef[k * 3 + 0] = g * pa; coef[k * 3 + 1] = g * pb; coef[k * 3 + 2] = g * pc;
+      }
+    }
+    // ---- horizontal sums of the partial planes of row c
+    f2 hc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const f2 vv = coef[i], l = vv * bc(sL), rr = vv * bc(sR);
+      hc[i] = (f2){(dpp_shr1(l.x) + vv.x) + dpp_shl1(rr.x), (dpp_shr1(l.y) + vv.y) + dpp_shl1(rr.y)};
+    }
+    // ---- gradient row q = r-2
+    const int q = r - 2;
+    if (q >= y_lo && q < y_hi) {  // wave-uniform
+      const float wyd = (q == H - 2) ? 2.0f : 1.0f;
+      const float lw = w1 * (0.15f / 3.0f);
+      const float lw0 = win1 == p.idx[0] ? lw : 0.f, lw1 = win1 == p.idx[1] ? lw : 0.f;
+      const f2 lwk[3] = {bc(lw0), bc(lw1), (f2){lw0, lw1}};
+      f2 g[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f2 SA = fma2(bc(wyd), hc[k * 3], hcA[k * 3]);
+        const f2 SB = fma2(bc(wyd), hc[k * 3 + 1], hcA[k * 3 + 1]);
+        const f2 SC = fma2(bc(wyd), hc[k * 3 + 2], hcA[k * 3 + 2]);
+        const f2 xq = x2[k], yq = k < 2 ? y2rg : bc(y2b);
+        const f2 df = xq - yq;
+        const f2 sg = (f2){sgnf(df.x), sgnf(df.y)};
+        g[k] = fma2(lwk[k], sg, fma2(SC, yq, fma2(SB, xq, SA))) * bc(sc);
+      }
+      if (out_x) {
+        const unsigned bo = (unsigned)(q * W + gxr) * 4u;
+        stf(ga, bo, g[0].x); stf(ga + HW, bo, g[0].y); stf(ga + 2 * (size_t)HW, bo, g[2].x);
+        if (gb) { stf(gb, bo, g[1].x); stf(gb + HW, bo, g[1].y); stf(gb + 2 * (size_t)HW, bo, g[2].y); }
+      }
+    }
+    // ---- rolls
+    {
+      const float wyu = (c == 0) ? 2.0f : 1.0f;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { hcA[i] = hcB[i] + hc[i]; hcB[i] = bc(wyu) * hc[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i] + h[i]; hsB[i] = h[i]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { hyA[i] = hyB[i] + hy[i]; hyB[i] = hy[i]; hzA[i] = hzB[i] + hz[i]; hzB[i] = hz[i]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { x2[k] = x1[k]; x1[k] = x0[k]; }
+    y2rg = y1rg; y2b = y1b; y1rg = y0rg; y1b = y0b;
+    w1 = w0; win1 = win0;
+  }
+}
+
+int g_photo_impl = 1;  // 1 = marching kernels of this file; 0 = one-pixel-per-thread kernels of mal_photo.hip
+
+static int device_slots() {
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = cus * 4;  // SIMDs
+  }
+  return slots;
+}
+
+static void decompose(PhotoMarchParams& p, int cw, int waves_per_simd) {
+  p.strips = (p.W + cw - 1) / cw;
+  int rows = 8;
+  const long long cap = (long long)device_slots() * waves_per_simd;
+  while (rows < p.H && (long long)p.B * p.strips * ((p.H + rows - 1) / rows) > cap) ++rows;
+  p.rows = rows;
+  p.segs = (p.H + rows - 1) / rows;
+  p.ntasks = p.B * p.strips * p.segs;
+  p.per_xcd = (p.ntasks + 7) / 8;
+}
+
+// forward over n_cand candidates; tmp_min / tmp_arg: scratch maps for the running min when the caller does
+// not want min_reproj / argmin.  block_sums: [>= ntasks][2].  *ntasks_out tasks of the last launch.
+int photo_march_fwd(const float* target, const float* const* cand, int n_cand, const float* ident, const float* noise,
+                    const float* ext_mask, int B, int H, int W, int automask, float* min_reproj, uint8_t* argmin,
+                    float* weight_out, double* block_sums, int* ntasks_out, hipStream_t st) {
+  const int npairs = (n_cand + 1) / 2;
+  if (npairs > 1 && (!min_reproj || !argmin)) return MAL_EINVAL;  // the running min travels in the output maps
+  for (int pr = 0; pr < npairs; ++pr) {
+    PhotoMarchParams p = {};
+    p.target = target; p.B = B; p.H = H; p.W = W;
+    p.cand[0] = cand[2 * pr]; p.idx[0] = 2 * pr;
+    const bool has2 = 2 * pr + 1 < n_cand;
+    p.cand[1] = has2 ? cand[2 * pr + 1] : cand[2 * pr]; p.idx[1] = has2 ? 2 * pr + 1 : -1;
+    p.prev_min = pr ? min_reproj : nullptr; p.prev_arg = pr ? argmin : nullptr;
+    p.last = pr == npairs - 1; p.automask = automask;
+    p.ident = ident; p.noise = noise; p.ext_mask = ext_mask;
+    p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;
+    decompose(p, 62, 4);
+    *ntasks_out = p.ntasks;
+    hipLaunchKernelGGL(photo_march_fwd_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
+  }
+  return launch_status();
+}
+
+int photo_march_bwd(const float* target, const float* const* cand, int n_cand, const uint8_t* argmin, const float* weight,
+                    const float* scale, const double* sums, int B, int H, int W, float* const* g_cand, hipStream_t st) {
+  for (int pr = 0; pr < (n_cand + 1) / 2; ++pr) {
+    PhotoMarchParams p = {};
+    p.target = target; p.B = B; p.H = H; p.W = W;
+    const bool has2 = 2 * pr + 1 < n_cand;
+    int i0 = 2 * pr, i1 = has2 ? 2 * pr + 1 : -1;
+    if (!g_cand[i0] && i1 >= 0 && g_cand[i1]) { const int t = i0; i0 = i1; i1 = t; }  // slot 0 always writes
+    if (!g_cand[i0]) continue;
+    p.cand[0] = cand[i0]; p.idx[0] = i0; p.g_cand[0] = g_cand[i0];
+    p.cand[1] = i1 >= 0 ? cand[i1] : cand[i0]; p.idx[1] = i1; p.g_cand[1] = i1 >= 0 ? g_cand[i1] : nullptr;
+    p.argmin_in = argmin; p.weight_in = weight; p.scale = scale; p.sums = sums;
+    decompose(p, 60, 2);
+    hipLaunchKernelGGL(photo_march_bwd_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
+  }
+  return launch_status();
+}
+
+}  // namespace mal

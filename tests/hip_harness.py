@@ -105,6 +105,20 @@ def dilate3(mask):
     return out
 
 
+def automask_tie_allowance(o, n0, rel=3e-5):
+    """The automask `rp <= identity + 1e-5*noise` (loss_utils.py:27-44) compares two fp32 values: a pixel within
+    rounding distance of the threshold may fall on either side.  Returns (allow, renorm, any): flipping pixel i
+    moves the masked mean sum(rp*m)/sum(m) by at most (rp_i + mean)/sum(m) [allow, summed over such pixels],
+    rescales every teacher-pass gradient by 1/sum(m) -> 1/(sum(m) +- 1) [renorm], and adds or removes that
+    pixel's whole contribution to the summed (pose) gradients [any]."""
+    idn = o["ident"] + n0.numpy() * np.float32(1e-5)
+    amb = np.abs(o["mono_reproj"] - idn) <= rel * np.maximum(np.abs(idn), 1e-3)
+    m = o["mono_reproj"] <= idn
+    mean = float((o["mono_reproj"] * m).sum() / max(int(m.sum()), 1))
+    allow = float(((o["mono_reproj"] + mean) * amb).sum() / max(int(m.sum()), 1))
+    return allow, float(amb.sum()) / max(int(m.sum()), 1), bool(amb.any())
+
+
 def near_tie(maps, tol):
     """pixels where the smallest two of the stacked (B,K,H,W) maps are within tol (relative)."""
     s = np.sort(maps, axis=1)

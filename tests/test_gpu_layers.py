@@ -215,3 +215,40 @@ def test_dualrefine_loss_path(fuse, avg, shape):
             assert (np.abs(g - r) > 2e-4 * np.abs(r).max()).mean() <= 5e-3, k
         else:
             assert _l2rel(g, r) <= 2e-2, k  # 2880 pixels: one automask tie moves a pose sum by ~1e-2
+
+
+@pytest.mark.parametrize("n_cand", [1, 2, 3, 4])
+def test_photo_marching_kernels_match_the_pixel_kernels(n_cand):
+    """min-reprojection / automask over materialised candidates (loss_utils.py:84-113) and its backward:
+    the marching formulation (two candidates per launch, running min across launches) against the
+    one-pixel-per-thread kernels that keep ATen's summation order."""
+    from mal_amd import ops, _lib
+    from mal_amd.synthetic import make_batch
+    lib = _lib.load()
+    B, H, W = 3, 45, 139  # ragged against the 62/60-column strips and the row segments
+    bt = make_batch(B, H, W, seed=11)
+    tgt = bt["color0"].to(DEV)
+    g = torch.Generator().manual_seed(3)
+    cands = [(bt["color_m1"] if i % 2 == 0 else bt["color_p1"]).clone() for i in range(n_cand)]
+    cands = [(c + 0.02 * i * torch.rand(c.shape, generator=g)).clamp(0, 1).to(DEV) for i, c in enumerate(cands)]
+    ident = (0.25 * torch.rand(B, 1, H, W, generator=g)).to(DEV)
+    noise = torch.randn(B, 1, H, W, generator=g).to(DEV)
+    ext = (torch.rand(B, 1, H, W, generator=g) > 0.2).float().to(DEV)
+    scale = torch.tensor([0.7], device=DEV)
+    res = []
+    for impl in (0, 1):
+        assert lib.mal_set_option(b"photo_impl", impl) == 0
+        mn, am, wt, sums = ops.photo_fwd(tgt, cands, ident=ident, noise=noise, ext_mask=ext, flags=_lib.F_AUTOMASK)
+        gr = ops.photo_bwd(tgt, cands, am, wt, scale, sums, 0, [True] * n_cand)
+        res.append((mn, am, wt, sums.clone(), gr))
+    lib.mal_set_option(b"photo_impl", 1)
+    (mn0, am0, wt0, s0, g0), (mn1, am1, wt1, s1, g1) = res
+    assert (mn0 - mn1).abs().max().item() <= 1e-4
+    flip = (am0 != am1) | (wt0 != wt1)  # candidates / automask at rounding distance of each other
+    assert flip.float().mean().item() <= 2e-3
+    for k in range(2):
+        assert abs(float(s0[k]) - float(s1[k])) <= 1e-4 * abs(float(s0[k])) + 2.0 * float(flip.sum())
+    near = torch.nn.functional.max_pool2d(flip.float(), 5, 1, 2) > 0  # a flipped pixel moves its neighbours' gradients
+    for a, c in zip(g0, g1):
+        d = (a - c).abs()[~near.expand_as(a)]
+        assert d.max().item() <= 2e-4 * a.abs().max().item() * (1 + 4 * float(flip.sum()))

@@ -67,13 +67,15 @@ def _check_case(tag, fuse, full):
     amb_distil = HH.near_tie(np.concatenate([m for m in (o["mono_reproj"], o["ens"], o["multi_cands"].min(1, keepdims=True))
                                              if m is not None], 1), 2e-4)
     allow_distil = float((np.abs(o["mono_depth"] - o["multi_depth"]) * amb_distil).sum() / N)
+    allow_auto, renorm, any_auto = HH.automask_tie_allowance(o, n0)  # automask pixels at rounding distance of the threshold
     for k, v in o["losses"].items():
         tol = 1e-4 * abs(v) + (allow_distil if ("distil" in k or k.startswith("loss")) else 0.0)
+        tol += 0.0 if ("distil" in k or "consistency" in k) else allow_auto
         assert abs(h["losses"][k] - v) <= tol, (k, h["losses"][k], v, tol)
         if not temporal:  # golden = the reference's own run in the authoring container
             gv = float(z["losses/" + k])
-            assert abs(h["losses"][k] - gv) <= 2e-4 * abs(gv) + allow_distil, ("golden", k, h["losses"][k], gv)
-    assert abs(h["final"] - o["final"]) <= 1e-4 * abs(o["final"]) + B * allow_distil
+            assert abs(h["losses"][k] - gv) <= 2e-4 * abs(gv) + allow_distil + allow_auto, ("golden", k, h["losses"][k], gv)
+    assert abs(h["final"] - o["final"]) <= 1e-4 * abs(o["final"]) + B * (allow_distil + allow_auto)
 
     # ---- per-pixel disparity gradients outside the near-tie pixels
     idn = o["ident"] + n0.numpy() * np.float32(1e-5)
@@ -93,7 +95,8 @@ def _check_case(tag, fuse, full):
         good = ~amb
         if good.any():
             err = np.abs(g - r)[good]
-            assert (err > 2e-4 * sc).mean() <= 2e-5, (key, err.max() / sc, (err > 2e-4 * sc).mean())
+            tol = 2e-4 + (renorm if key == "disp_teacher" else 0.0)
+            assert (err > tol * sc).mean() <= 2e-5, (key, err.max() / sc, (err > tol * sc).mean())
         assert amb.mean() <= 0.05 or temporal, (key, "near-tie fraction", amb.mean())
 
     # ---- summed gradients: never further from the fp32 reference than it is from fp64
@@ -108,7 +111,8 @@ def _check_case(tag, fuse, full):
                 continue
             g, r, r64 = g[keep], r[keep], r64[keep]
         floor = _l2rel(r, r64)
-        assert _l2rel(g, r) <= max(1e-4, 1.5 * floor), (key, _l2rel(g, r), floor)
+        extra = 0.0 if key == "disp_student" else renorm + (2e-2 if (any_auto and g.ndim != 4 and g.size <= 64) else 0.0)
+        assert _l2rel(g, r) <= max(1e-4, 1.5 * floor) + extra, (key, _l2rel(g, r), floor)
 
 
 @pytest.mark.parametrize("fuse", [True, False], ids=["fused", "explicit"])

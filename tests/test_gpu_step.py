@@ -70,13 +70,7 @@ def _check_step(b, kw, n0, n1):
     pairs = [("reproj_loss/0", o["losses"]["reproj_loss/0"]), ("consistency_loss/0", o["losses"]["consistency_loss/0"]),
              ("distil_loss", o["losses"]["distil_loss"]), ("mono/loss", o["mono_losses"]["loss"]),
              ("mono/reproj_loss/0", o["mono_losses"]["reproj_loss/0"])]
-    # the automask `rp <= identity + 1e-5*noise` (loss_utils.py:27-44) is a comparison of two fp32 values: a pixel
-    # within rounding distance of the threshold may fall on either side; flipping pixel i moves the masked mean
-    # sum(rp*m)/sum(m) by at most (rp_i + mean)/sum(m)
-    idn_ = o["ident"] + n0.numpy() * np.float32(1e-5)
-    amb_auto = np.abs(o["mono_reproj"] - idn_) <= 3e-5 * np.maximum(np.abs(idn_), 1e-3)
-    m_t = o["mono_reproj"] <= idn_
-    allow_auto = float(((o["mono_reproj"] + o["mono_losses"]["reproj_loss/0"]) * amb_auto).sum() / max(m_t.sum(), 1))
+    allow_auto, renorm, any_auto = HH.automask_tie_allowance(o, n0)  # automask pixels at rounding distance of the threshold
     for k, v in pairs:
         tol = 1e-4 * abs(v) + (allow if "distil" in k else 0.0) + (allow_auto if "distil" not in k and "consistency" not in k else 0.0)
         assert abs(h["losses"][k] - v) <= tol, (k, h["losses"][k], v, allow_auto)
@@ -95,9 +89,6 @@ def _check_step(b, kw, n0, n1):
     amb_s = HH.dilate3(HH.near_tie(o["multi_cands"], 2e-4)) | HH.sample_ambiguous(o["multi_sample"], H, W) | amb_distil
     amb_s |= np.abs(o["mono_depth"] - o["multi_depth"]) <= 1e-6 * np.abs(o["mono_depth"])
     o64 = HH.oracle_fp64_grads(b, kw, n0, n1)
-    # an automask pixel on the other side of its threshold also rescales every teacher-pass gradient by
-    # 1/sum(mask) -> 1/(sum(mask) +- 1)
-    renorm = float(amb_auto.sum()) / max(int(m_t.sum()), 1)
     for key in HH.LEAVES:
         g, r, r64 = h["grads"][key], o["grads"][key], o64[key]
         extra = 0.0 if key == "disp_student" else renorm
@@ -106,7 +97,7 @@ def _check_step(b, kw, n0, n1):
             err = np.abs(g - r)[keep]
             assert (err > (2e-4 + extra) * np.abs(r).max()).mean() <= 2e-5, (key, err.max() / np.abs(r).max())
             g, r, r64 = g[keep], r[keep], r64[keep]
-        elif amb_auto.any():
+        elif any_auto:
             extra += 2e-2  # the summed (pose) gradients gain or lose that pixel's whole contribution
         floor = _l2rel(r, r64)
         assert _l2rel(g, r) <= max(1e-4, 1.5 * floor) + extra, (key, _l2rel(g, r), floor)
