@@ -338,13 +338,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       const float v = ldf(disp2_b ? disp2_b : disp_b, pix * 4u);
       a.disp2 = disp2_b ? v : 0.f;
     }
-    {  // target pixel: one 16-byte texel (packed) or three planes; the other form reads the sample's first bytes
-      const float* t0 = packed_t ? pp.target + (size_t)b * HW * 4 : pp.target + (size_t)b * 3 * HW;
-      const f4 t4 = ldf4(t0, packed_t ? pix * 16u : 0u);
-      const unsigned bo = packed_t ? 0u : pix * 4u;
-      const float p0 = ldf(t0, bo), p1 = ldf(t0 + HW, bo), p2 = ldf(t0 + 2 * (size_t)HW, bo);
-      a.y[0] = packed_t ? t4.x : p0; a.y[1] = packed_t ? t4.y : p1; a.y[2] = packed_t ? t4.z : p2;
-    }
+    load_rgb(pp.target, packed_t, b, HW, pix, a.y);  // one 16-byte texel (packed) or three planes
     const unsigned oc = (unsigned)(min(max(rr - 1, 0), H - 1) * W + gxr) * 4u;  // statistics row c = rr-1
     auto opt = [&](const float* m, unsigned off, float absent) {
       const float v = ldf(m ? m + map_b : disp_b, off);
