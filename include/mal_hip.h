@@ -35,6 +35,7 @@ extern "C" {
 #define MAL_VERSION 100 /* 0.1.0 */
 #define MAL_MAX_FRAMES 2
 #define MAL_MAX_CAND 4 /* warped -1,+1 and the temporal-hint "syn" -1,+1 (loss_utils.py:79-90) */
+#define MAL_MAX_INSTANCES 64 /* matched instance masks per sample of the temporal-hint producer */
 
 enum {
   MAL_OK = 0,
@@ -255,6 +256,23 @@ typedef struct mal_step_args {
 size_t mal_step_workspace_bytes(int B, int H, int W);
 int mal_loss_step_fwd(const mal_step_args* args);
 int mal_loss_step_bwd(const mal_step_args* args);
+
+/* ---- N2: the temporal-hint producer's per-sample arithmetic, manydepth/dyn_utils.py:6-119 --------
+ * (fill_dynamic_obj + generate_dynamic_instance), given the matched instance masks of the two warped frames
+ * (num,H,W as bytes, non-zero = set; Mask2Former and the matcher stay outside).  Per instance the displacement
+ * is half the larger-magnitude difference of the bounding-box edges between the frames (rows: low/top, columns:
+ * right/left; index 0 is invisible to the extents, as upstream; half-to-even; replace=1 zeroes |d| < 3); "last"
+ * patches move by +d, "next" by -d, overlapping copies add, pixels vacated by an instance show the other frame.
+ * Outputs: ori_last / ori_next (C,H,W) = the reference's return values; delta [num][2] (row, column) and
+ * flags [H*W] are what mal_dyn_instance_bwd needs.  C <= 4, num <= MAL_MAX_INSTANCES.                     */
+size_t mal_dyn_workspace_bytes(int num);
+int mal_dyn_instance_fwd(const uint8_t* mask_last, const uint8_t* mask_next, int num, const float* img_last,
+                         const float* img_next, int C, int H, int W, int replace, float* ori_last, float* ori_next,
+                         int32_t* delta, uint8_t* flags, void* ws, size_t ws_bytes, void* stream);
+/* cotangents of (ori_last, ori_next) -> gradients w.r.t. (img_last, img_next), either nullable */
+int mal_dyn_instance_bwd(const uint8_t* mask_last, const uint8_t* mask_next, int num, const int32_t* delta,
+                         const uint8_t* flags, const float* g_ori_last, const float* g_ori_next, int C, int H, int W,
+                         float* g_img_last, float* g_img_next, void* stream);
 
 /* ---- library options:
  * "pass_impl"   formulation of the fused pass: 1 = register-marching (default); 0 / 2 = the LDS-tiled first

@@ -1,0 +1,217 @@
+// N2: the temporal-hint producer's per-sample arithmetic -- manydepth/dyn_utils.py:6-119,
+// `fill_dynamic_obj` + `generate_dynamic_instance` -- given the matched instance masks of the two warped
+// frames.  (Mask2Former and the Hungarian matcher that produce the masks stay outside this library.)
+//
+// Upstream this is a TorchScript loop over instances with (num, 3, H, W) temporaries per call and per
+// sample; here it is three launches per sample and no temporaries:
+//   dyn_extents_kernel   per (instance, frame): which rows / columns >= 1 hold mask pixels (the reference
+//                        weighs the mask by the row / column index, so index 0 is invisible) -> low, top,
+//                        right, left; then, per instance, the displacement: of (low_next-low_last,
+//                        top_next-top_last) the one of larger magnitude (the first on a tie), halved and rounded
+//                        half-to-even; columns alike; replace=1 zeroes magnitudes < 3   (dyn_utils.py:53-103)
+//   dyn_synth_fwd_kernel per pixel p:
+//        A(p)   = sum_i [p - d_i inside and mask_last_i(p - d_i)] img_last(p - d_i),  any(p) = or_i [...]
+//        bg(p)  = or_i (mask_last_i & ~mask_next_i)(p) ? img_next(p) : img_last(p)
+//        ori_last(p) = or_i (mask_last_i | mask_next_i)(p) ? (any(p) ? A(p) : bg(p)) : img_last(p)
+//      and symmetrically ori_next with -d_i; the five predicates are kept as a flag byte per pixel (:6-36,106-119)
+//   dyn_synth_bwd_kernel the adjoint in gather form: what p receives directly, plus, for every instance whose
+//                        mask holds p, the cotangent at the pixel p was copied to.
+#include "mal_common.h"
+#include "mal_device.h"
+
+namespace mal {
+
+struct DynParams {
+  const uint8_t* mask_last; const uint8_t* mask_next;  // (num,H,W) bytes, non-zero = set
+  int num, C, H, W, replace;
+  const float* img_last; const float* img_next;         // (C,H,W)
+  float* ori_last; float* ori_next;
+  int* ext;       // [num][2][4]: low, top, right, left of (last, next)
+  int* delta;     // [num][2]: row, column displacement of the "last" copy
+  uint8_t* flags; // [H*W]: bit0 region, bit1 any_last, bit2 any_next, bit3 last's background is img_next, bit4 next's is img_last
+  const float* g_ori_last; const float* g_ori_next; float* g_img_last; float* g_img_next;
+};
+
+__global__ __launch_bounds__(1024) void dyn_extents_kernel(DynParams p) {
+  extern __shared__ int sh[];  // row flags [H], column flags [W], then 4 results
+  const int i = blockIdx.x, which = blockIdx.y, tid = threadIdx.x, H = p.H, W = p.W, HW = H * W;
+  int* rowf = sh;
+  int* colf = sh + H;
+  int* res = sh + H + W;
+  for (int k = tid; k < H + W; k += 1024) sh[k] = 0;
+  if (tid < 4) res[tid] = (tid & 1) ? 0x7fffffff : 0;  // low, top, right, left: max / min
+  __syncthreads();
+  const uint8_t* m = (which ? p.mask_next : p.mask_last) + (size_t)i * HW;
+  auto mark = [&](int k) { rowf[k / W] = 1; colf[k % W] = 1; };  // same-value stores: benign races
+  if ((HW & 15) == 0 && (reinterpret_cast<size_t>(m) & 15) == 0) {
+    // masks are mostly empty: scan 16 bytes per load, look at the bytes only where a word is non-zero
+    const uint4* m16 = reinterpret_cast<const uint4*>(m);
+    for (int k = tid; k < HW / 16; k += 1024) {
+      const uint4 v = m16[k];
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (w4[j])
+          for (int t = 0; t < 4; ++t)
+            if ((w4[j] >> (8 * t)) & 0xffu) mark(k * 16 + j * 4 + t);
+    }
+  } else {
+    for (int k = tid; k < HW; k += 1024)
+      if (m[k]) mark(k);
+  }
+  __syncthreads();
+  for (int r = 1 + tid; r < H; r += 1024)
+    if (rowf[r]) { atomicMax(&res[0], r); atomicMin(&res[1], r); }
+  for (int c = 1 + tid; c < W; c += 1024)
+    if (colf[c]) { atomicMax(&res[2], c); atomicMin(&res[3], c); }
+  __syncthreads();
+  if (tid < 4) {
+    int v = res[tid];
+    if (v == 0x7fffffff) v = 0;  // nothing present: argmin over an all-"inf" row returns index 0
+    p.ext[(i * 2 + which) * 4 + tid] = v;
+  }
+}
+
+__global__ void dyn_delta_kernel(DynParams p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.num) return;
+  const int* el = p.ext + (i * 2 + 0) * 4;
+  const int* en = p.ext + (i * 2 + 1) * 4;
+  auto pick = [](int a, int b) {  // larger magnitude, the first on a tie; half, rounded half-to-even
+    const int s = abs(b) > abs(a) ? b : a;
+    return (int)rintf((float)s * 0.5f);
+  };
+  int dx = pick(en[0] - el[0], en[1] - el[1]);
+  int dy = pick(en[2] - el[2], en[3] - el[3]);
+  if (p.replace) { if (abs(dx) < 3) dx = 0; if (abs(dy) < 3) dy = 0; }
+  p.delta[i * 2] = dx; p.delta[i * 2 + 1] = dy;
+}
+
+__global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynParams p) {
+  extern __shared__ int s_delta[];  // [num][2]
+  for (int k = threadIdx.x; k < p.num * 2; k += 256) s_delta[k] = p.delta[k];
+  __syncthreads();
+  const int H = p.H, W = p.W, HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= HW) return;
+  const int r = pix / W, c = pix - r * W;
+  bool region = false, any_l = false, any_n = false, bg_l = false, bg_n = false;
+  float accl[4] = {0.f, 0.f, 0.f, 0.f}, accn[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < p.num; ++i) {
+    const uint8_t* ml = p.mask_last + (size_t)i * HW;
+    const uint8_t* mn = p.mask_next + (size_t)i * HW;
+    const bool a = ml[pix] != 0, b = mn[pix] != 0;
+    region |= a | b; bg_l |= a & !b; bg_n |= b & !a;
+    const int dx = s_delta[2 * i], dy = s_delta[2 * i + 1];
+    {  // "last" moves by +d: destination p takes source p - d
+      const int rs = r - dx, cs = c - dy;
+      if (rs >= 0 && rs < H && cs >= 0 && cs < W && ml[rs * W + cs]) {
+        any_l = true;
+        for (int ch = 0; ch < p.C; ++ch) accl[ch] += p.img_last[(size_t)ch * HW + rs * W + cs];
+      }
+    }
+    {  // "next" moves by -d
+      const int rs = r + dx, cs = c + dy;
+      if (rs >= 0 && rs < H && cs >= 0 && cs < W && mn[rs * W + cs]) {
+        any_n = true;
+        for (int ch = 0; ch < p.C; ++ch) accn[ch] += p.img_next[(size_t)ch * HW + rs * W + cs];
+      }
+    }
+  }
+  p.flags[pix] = (uint8_t)((region ? 1 : 0) | (any_l ? 2 : 0) | (any_n ? 4 : 0) | (bg_l ? 8 : 0) | (bg_n ? 16 : 0));
+  for (int ch = 0; ch < p.C; ++ch) {
+    const float il = p.img_last[(size_t)ch * HW + pix], in = p.img_next[(size_t)ch * HW + pix];
+    p.ori_last[(size_t)ch * HW + pix] = region ? (any_l ? accl[ch] : (bg_l ? in : il)) : il;
+    p.ori_next[(size_t)ch * HW + pix] = region ? (any_n ? accn[ch] : (bg_n ? il : in)) : in;
+  }
+}
+
+__global__ __launch_bounds__(256) void dyn_synth_bwd_kernel(DynParams p) {
+  extern __shared__ int s_delta[];
+  for (int k = threadIdx.x; k < p.num * 2; k += 256) s_delta[k] = p.delta[k];
+  __syncthreads();
+  const int H = p.H, W = p.W, HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= HW) return;
+  const int r = pix / W, c = pix - r * W;
+  const int f = p.flags[pix];
+  // where the two outputs at p read the two images AT p
+  const bool ol_from_l = !(f & 1) || (!(f & 2) && !(f & 8)), ol_from_n = (f & 1) && !(f & 2) && (f & 8);
+  const bool on_from_n = !(f & 1) || (!(f & 4) && !(f & 16)), on_from_l = (f & 1) && !(f & 4) && (f & 16);
+  float gl[4] = {0.f, 0.f, 0.f, 0.f}, gn[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int ch = 0; ch < p.C; ++ch) {
+    const float a = p.g_ori_last[(size_t)ch * HW + pix], b = p.g_ori_next[(size_t)ch * HW + pix];
+    if (ol_from_l) gl[ch] += a;
+    if (on_from_l) gl[ch] += b;
+    if (on_from_n) gn[ch] += b;
+    if (ol_from_n) gn[ch] += a;
+  }
+  // where p was copied to: instance i took img_last(p) to p + d_i (if that lies in the replaced region)
+  for (int i = 0; i < p.num; ++i) {
+    const int dx = s_delta[2 * i], dy = s_delta[2 * i + 1];
+    if (p.mask_last[(size_t)i * HW + pix]) {
+      const int rd = r + dx, cd = c + dy;
+      if (rd >= 0 && rd < H && cd >= 0 && cd < W && (p.flags[rd * W + cd] & 1))
+        for (int ch = 0; ch < p.C; ++ch) gl[ch] += p.g_ori_last[(size_t)ch * HW + rd * W + cd];
+    }
+    if (p.mask_next[(size_t)i * HW + pix]) {
+      const int rd = r - dx, cd = c - dy;
+      if (rd >= 0 && rd < H && cd >= 0 && cd < W && (p.flags[rd * W + cd] & 1))
+        for (int ch = 0; ch < p.C; ++ch) gn[ch] += p.g_ori_next[(size_t)ch * HW + rd * W + cd];
+    }
+  }
+  for (int ch = 0; ch < p.C; ++ch) {
+    if (p.g_img_last) p.g_img_last[(size_t)ch * HW + pix] = gl[ch];
+    if (p.g_img_next) p.g_img_next[(size_t)ch * HW + pix] = gn[ch];
+  }
+}
+
+}  // namespace mal
+
+using namespace mal;
+
+static int dyn_check(int num, int C, int H, int W) {
+  if (num < 1 || num > MAL_MAX_INSTANCES || C < 1 || C > 4) return MAL_EINVAL;
+  if (H < 2 || W < 2 || (double)H * W > 2.0e9 / 4) return MAL_ESHAPE;
+  return MAL_OK;
+}
+
+extern "C" size_t mal_dyn_workspace_bytes(int num) {
+  return num > 0 ? align256((size_t)num * 8 * sizeof(int)) : 0;
+}
+
+extern "C" int mal_dyn_instance_fwd(const uint8_t* mask_last, const uint8_t* mask_next, int num, const float* img_last,
+                                    const float* img_next, int C, int H, int W, int replace, float* ori_last,
+                                    float* ori_next, int32_t* delta, uint8_t* flags, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  int rc = dyn_check(num, C, H, W);
+  if (rc) return rc;
+  if (!mask_last || !mask_next || !img_last || !img_next || !ori_last || !ori_next || !delta || !flags || !ws)
+    return MAL_EINVAL;
+  if (ws_bytes < mal_dyn_workspace_bytes(num)) return MAL_EWORKSPACE;
+  DynParams p = {};
+  p.mask_last = mask_last; p.mask_next = mask_next; p.num = num; p.C = C; p.H = H; p.W = W; p.replace = replace;
+  p.img_last = img_last; p.img_next = img_next; p.ori_last = ori_last; p.ori_next = ori_next;
+  p.ext = (int*)ws; p.delta = delta; p.flags = flags;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dyn_extents_kernel, dim3(num, 2), dim3(1024), (size_t)(H + W + 4) * sizeof(int), st, p);
+  hipLaunchKernelGGL(dyn_delta_kernel, dim3(1), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(dyn_synth_fwd_kernel, dim3((H * W + 255) / 256), dim3(256), (size_t)num * 2 * sizeof(int), st, p);
+  return launch_status();
+}
+
+extern "C" int mal_dyn_instance_bwd(const uint8_t* mask_last, const uint8_t* mask_next, int num, const int32_t* delta,
+                                    const uint8_t* flags, const float* g_ori_last, const float* g_ori_next, int C, int H,
+                                    int W, float* g_img_last, float* g_img_next, void* stream) {
+  int rc = dyn_check(num, C, H, W);
+  if (rc) return rc;
+  if (!mask_last || !mask_next || !delta || !flags || !g_ori_last || !g_ori_next || (!g_img_last && !g_img_next))
+    return MAL_EINVAL;
+  DynParams p = {};
+  p.mask_last = mask_last; p.mask_next = mask_next; p.num = num; p.C = C; p.H = H; p.W = W;
+  p.delta = const_cast<int*>(delta); p.flags = const_cast<uint8_t*>(flags);
+  p.g_ori_last = g_ori_last; p.g_ori_next = g_ori_next; p.g_img_last = g_img_last; p.g_img_next = g_img_next;
+  hipLaunchKernelGGL(dyn_synth_bwd_kernel, dim3((H * W + 255) / 256), dim3(256), (size_t)num * 2 * sizeof(int),
+                     (hipStream_t)stream, p);
+  return launch_status();
+}

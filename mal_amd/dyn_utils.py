@@ -1,0 +1,107 @@
+"""Temporal-hint producer: ``manydepth/dyn_utils.py`` with the per-sample arithmetic
+(``generate_dynamic_instance`` / ``fill_dynamic_obj``, :6-119) on the device as three HIP launches instead of a
+TorchScript loop over instances with (num,3,H,W) temporaries.  Same names and signatures as the reference, so
+``from manydepth.dyn_utils import image_synthesis`` can point here; the instance segmenter (Mask2Former through
+``generate_instances``) and the Hungarian matcher stay external and are passed in exactly as upstream.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+from . import ops
+
+
+class DynamicInstanceFn(Function):
+    """(mask_last, mask_next, img_last, img_next, replace) -> (ori_last, ori_next); differentiable w.r.t. the images."""
+
+    @staticmethod
+    def forward(ctx, mask_last, mask_next, img_last, img_next, replace):
+        if mask_last.shape != mask_next.shape or mask_last.dim() != 3:
+            raise L.MalError("generate_dynamic_instance: masks must be two (num,H,W) tensors of the same shape")
+        num, H, W = mask_last.shape
+        il, inx = ops._req(img_last, "img_last"), ops._req(img_next, "img_next")
+        C = il.shape[0]
+        if il.shape != (C, H, W) or inx.shape != (C, H, W):
+            raise L.MalError("generate_dynamic_instance: images must be (C,H,W) matching the masks")
+        dev = il.device
+        ml = mask_last.to(device=dev, dtype=torch.uint8).contiguous()
+        mn = mask_next.to(device=dev, dtype=torch.uint8).contiguous()
+        ol, on = torch.empty_like(il), torch.empty_like(inx)
+        delta = torch.empty(num, 2, dtype=torch.int32, device=dev)
+        flags = torch.empty(H, W, dtype=torch.uint8, device=dev)
+        lib = L.load()
+        ws = torch.empty(lib.mal_dyn_workspace_bytes(num), dtype=torch.uint8, device=dev)
+        p = ops._p
+        L.check(lib.mal_dyn_instance_fwd(p(ml), p(mn), num, p(il), p(inx), C, H, W, 1 if replace else 0, p(ol), p(on),
+                                         p(delta), p(flags), p(ws), ws.numel(), ops._stream()), "mal_dyn_instance_fwd")
+        ctx.save_for_backward(ml, mn, delta, flags)
+        ctx.shape = (num, C, H, W)
+        return ol, on
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_last, g_next):
+        ml, mn, delta, flags = ctx.saved_tensors
+        num, C, H, W = ctx.shape
+        dev = ml.device
+        zeros = lambda: torch.zeros(C, H, W, dtype=torch.float32, device=dev)
+        g_last = zeros() if g_last is None else g_last.contiguous()
+        g_next = zeros() if g_next is None else g_next.contiguous()
+        gl = torch.empty_like(g_last) if ctx.needs_input_grad[2] else None
+        gn = torch.empty_like(g_next) if ctx.needs_input_grad[3] else None
+        if gl is None and gn is None:
+            return None, None, None, None, None
+        p = ops._p
+        L.check(L.load().mal_dyn_instance_bwd(p(ml), p(mn), num, p(delta), p(flags), p(g_last), p(g_next), C, H, W, p(gl),
+                                              p(gn), ops._stream()), "mal_dyn_instance_bwd")
+        return None, None, gl, gn, None
+
+
+def generate_dynamic_instance(grid_h, grid_w, mask_last, mask_next, img_last, img_next, replace: bool):
+    """Signature of manydepth/dyn_utils.py:38 (``grid_h`` / ``grid_w`` are the reference's index grids; the kernels
+    derive row / column indices from the thread id and do not read them)."""
+    return DynamicInstanceFn.apply(mask_last, mask_next, img_last, img_next, bool(replace))
+
+
+def generate_instances(images, ins_model):
+    """manydepth/dyn_utils.py:172-190 runs the Mask2Former predictor on BGR uint8 copies of the images; the
+    segmenter is not part of this package: pass a callable ``ins_model(images) -> list of {"instances": ...}``."""
+    if not callable(ins_model):
+        raise NotImplementedError("bind an instance segmenter: generate_instances(images, ins_model) calls "
+                                  "ins_model(images) (upstream: Mask2Former through detectron2, dyn_utils.py:172-190)")
+    return ins_model(images)
+
+
+def image_synthesis(inputs, outputs, scale, thres, ins_model, matcher):
+    """manydepth/dyn_utils.py:121-170, unchanged control flow; the per-sample synthesis runs in the HIP kernels.
+    Writes ``outputs[("syn", -1, scale)]`` / ``("syn", 1, scale)`` when any sample has matched instances."""
+    bs = inputs[("color", 0, 0)].shape[0]
+    instances = generate_instances(inputs[("color", 0, 0)], ins_model)
+    syn_last = outputs[("color", -1, scale)].clone()
+    syn_next = outputs[("color", 1, scale)].clone()
+    has_ins = False
+    for b in range(bs):
+        cur = instances[b]["instances"]
+        instances_cur = cur[cur.scores > thres]
+        if len(instances_cur) == 0:
+            continue
+        img_last = outputs[("color", -1, scale)][b]
+        img_next = outputs[("color", 1, scale)][b]
+        both = generate_instances(torch.stack([img_last, img_next], dim=0), ins_model)
+        ins_last, ins_next = both[0]["instances"], both[1]["instances"]
+        slice_last, slice_next = matcher(ins_last, ins_next, instances_cur)
+        if len(slice_last) + len(slice_next) == 0:
+            continue
+        has_ins = True
+        mask_last = ins_last.pred_masks[slice_last].bool()
+        mask_next = ins_next.pred_masks[slice_next].bool()
+        tmp_last, tmp_next = generate_dynamic_instance(None, None, mask_last, mask_next, img_last, img_next, replace=False)
+        syn_last[b] = tmp_last
+        syn_next[b] = tmp_next
+    if has_ins:
+        outputs[("syn", -1, scale)] = syn_last
+        outputs[("syn", 1, scale)] = syn_next
+    return has_ins
