@@ -274,6 +274,19 @@ int mal_dyn_instance_bwd(const uint8_t* mask_last, const uint8_t* mask_next, int
                          const uint8_t* flags, const float* g_ori_last, const float* g_ori_next, int C, int H, int W,
                          float* g_img_last, float* g_img_next, void* stream);
 
+/* ---- N3: ManyDepth's cost volume as MAL's student encoder builds it (forward only; upstream runs it under
+ * no_grad): manydepth/networks/resnet_encoder.py:152-233 match_features + :296-312 of the encoder's forward.
+ * current_feats (B,h,w,C) and lookup_feats (B,F,h,w,C) CHANNEL-LAST, C = 64; poses (B,F,16) relative poses (an
+ * all-zero pose = missing frame, skipped); K / inv_K (B,16) at the matching resolution; depth_bins (D <= 256).
+ * cost_volume (B,D,h,w) = match_features' first return value (mean |warped - current| x border masks, averaged
+ * over the frames that hit, missing bins set to the pixel's maximum when set_missing_to_max); nullable outputs:
+ * missing_mask (B,D,h,w) = its second return value; masked_cost_volume = cost_volume x confidence (:311);
+ * lowest_cost (B,h,w) = 1 / depth of the first minimum, zeros read as 100 (:303-307); confidence_mask (B,h,w). */
+int mal_cost_volume(const float* current_feats, const float* lookup_feats, const float* poses, const float* K,
+                    const float* inv_K, const float* depth_bins, int B, int F, int C, int D, int h, int w, float eps,
+                    int set_missing_to_max, float* cost_volume, float* missing_mask, float* masked_cost_volume,
+                    float* lowest_cost, float* confidence_mask, void* stream);
+
 /* ---- library options:
  * "pass_impl"   formulation of the fused pass: 1 = register-marching (default); 0 / 2 = the LDS-tiled first
  *               versions (256 threads x 4 px, 512 threads x 2 px), kept for A/B;

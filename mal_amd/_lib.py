@@ -51,6 +51,8 @@ SIGNATURES = {
     "mal_sum_f64": (i32, [c_fp, sz, c_fp, vp, sz, vp]),
     "mal_pose_fwd": (i32, [c_pp, c_pp, C.POINTER(i32), i32, i32, c_pp, vp]),
     "mal_pose_bwd": (i32, [c_pp, c_pp, C.POINTER(i32), c_pp, i32, i32, c_pp, c_pp, vp]),
+    "mal_cost_volume": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, f32, i32, c_fp, c_fp, c_fp,
+                              c_fp, c_fp, vp]),
     "mal_dyn_workspace_bytes": (sz, [i32]),
     "mal_dyn_instance_fwd": (i32, [vp, vp, i32, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, vp, vp, vp, sz, vp]),
     "mal_dyn_instance_bwd": (i32, [vp, vp, i32, vp, vp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, vp]),

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmal_hip.so")
-SOURCES = ["mal_api.hip", "mal_pass.hip", "mal_warp.hip", "mal_photo.hip", "mal_photo_march.hip", "mal_dyn.hip", "mal_pose.hip", "mal_march.hip", "mal_tile2.hip", "mal_step.hip"]
+SOURCES = ["mal_api.hip", "mal_pass.hip", "mal_warp.hip", "mal_photo.hip", "mal_photo_march.hip", "mal_dyn.hip", "mal_costvol.hip", "mal_pose.hip", "mal_march.hip", "mal_tile2.hip", "mal_step.hip"]
 HEADERS = ["mal_common.h", "mal_device.h", "mal_march.h", "mal_pose.h", "mal_pairs.h", os.path.join("..", "..", "include", "mal_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
