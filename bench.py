@@ -43,13 +43,33 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a HIP graph (default); 0: eager launches")
-    ap.add_argument("--mode", choices=["step", "ops", "temporal"], default="step",
-                    help="step: mal_loss_step (one C call per direction); ops: the operator-level API")
+    ap.add_argument("--mode", choices=["step", "ops", "temporal", "train"], default="step",
+                    help="step: mal_loss_step (one C call per direction, the headline); ops: the operator-level API; "
+                         "temporal: --temporal --distil through the operator-level API; train: the whole training step "
+                         "of the harness (RepDepth networks + loss step + flat-bucket all-reduce + Adam, eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mal_set_option before the run (kernel experiments, e.g. march_rows=16)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
+
+
+class TrainStep:
+    """--mode train: mal_amd.harness.TrainHarness on a synthetic batch (next row N1; not the headline metric)."""
+
+    def __init__(self, dev, seed):
+        import random
+        from mal_amd import config, harness
+        config.noise_source = "cuda"
+        random.seed(seed)
+        torch.manual_seed(seed)
+        self.opt = harness.default_options(batch_size=B, height=H, width=W)
+        self.h = harness.TrainHarness(self.opt, dev)
+        self.inputs = harness.synthetic_inputs(self.opt, dev, seed=seed)
+        self.batch_cpu = None
+
+    def __call__(self):
+        return self.h.train_step(self.inputs)["loss"]
 
 
 class Step:
@@ -150,7 +170,12 @@ def main():
     for kv in args.opt:
         name, val = kv.split("=")
         _lib.check(lib.mal_set_option(name.encode(), int(val)), "mal_set_option(%s)" % kv)
-    step = Step(dev, 1234 + rank, args.mode)
+    if args.mode == "train":
+        step = TrainStep(dev, 1234 + rank)
+        args.graph = 0  # host-side RNG, optimizer and collective in the step
+        args.no_cpu_baseline = True
+    else:
+        step = Step(dev, 1234 + rank, args.mode)
 
     def sync():
         if dist is not None:
@@ -236,6 +261,15 @@ def main():
                      "traffic": traffic, "alg_bytes_per_px": ALG_BYTES_PER_PX, "pixels_per_launch": n_px,
                      "kernel_ms": kern_ms, "launches_timed": len(durs)},
     }
+    if args.mode == "train":
+        out["metric"] = "train images/sec at B=12 192x640 KITTI-shaped (whole training step of the harness)"
+        out["config"]["workload"] = ("RepDepth (ResNet-18 x3 + decoders + pose, cost volume) forward+backward through torch.nn/MIOpen, "
+                                     "MAL loss step (7 HIP kernels), one flat-bucket gradient all-reduce (165 MB fp32), Adam; "
+                                     "B=12 per GPU, 192x640, --distil, synthetic batch, random-init weights")
+        out["config"]["parallelism"] = "dp%d (one RCCL all-reduce of the flat gradient bucket per step)" % world
+        out["config"]["api"] = "mal_amd.harness.TrainHarness.train_step"
+    elif args.mode != "step":
+        out["config"]["workload"] += " [mode %s]" % args.mode
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(step.batch_cpu, args.cpu_steps)
     print(json.dumps(out), flush=True)
