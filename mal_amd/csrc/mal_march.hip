@@ -403,6 +403,9 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     WarpRow w0;
     const float dv_ = disp2_b ? (cur.disp + cur.disp2) / 2.0f : cur.disp;
     w0.yrg = (f2){cur.y[0], cur.y[1]}; w0.yb = cur.y[2];
+    // the issue phase (projection, operand requests, gathers) is what the rest of the iteration waits for:
+    // run it at raised wave priority so the sibling wave's arithmetic does not delay it (measured -1.7 %)
+    __builtin_amdgcn_s_setprio(3);
     PendingWarp pw;
     {
       f2 P[12];
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       // gathers is 5 % slower even when the blend then waits for the gathers only)
       warp_issue<GRAD, POSE>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
     }
+    __builtin_amdgcn_s_setprio(0);
     tick(1);  // small loads, prefetch, projection, gathers issued
     auto finish_warp = [&]() {
       DerivRow d0;
@@ -625,14 +629,21 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
         const float lw0 = pi1.win == 0 ? lw : 0.f, lw1 = pi1.win != 0 ? lw : 0.f;
         const f2 lwk[3] = {bc(lw0), bc(lw1), (f2){lw0, lw1}};
         f2 g[3];
+        // only the winner's L1 term is non-zero: take the sign of the winner's differences and let the zero
+        // weight of the other candidate discard it
+        const bool w1_ = pi1.win != 0;
+        const f2 dwin = (w1_ ? wq.x[1] : wq.x[0]) - wq.yrg;
+        const float dwb = (w1_ ? wq.x[2].y : wq.x[2].x) - wq.yb;
+        const f2 sgrg = (f2){sgnf(dwin.x), sgnf(dwin.y)};
+        const float sgb = sgnf(dwb);
+        const f2 sgk[3] = {sgrg, sgrg, bc(sgb)};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const f2 SA = fma2(bc(wyd), hc[k * 3], hcA[k * 3]);
           const f2 SB = fma2(bc(wyd), hc[k * 3 + 1], hcA[k * 3 + 1]);
           const f2 SC = fma2(bc(wyd), hc[k * 3 + 2], hcA[k * 3 + 2]);
           const f2 xq = wq.x[k], yq = k < 2 ? wq.yrg : bc(wq.yb);
-          const f2 df = xq - yq;
-          const f2 sg = (f2){sgnf(df.x), sgnf(df.y)};
+          const f2 sg = sgk[k];
           g[k] = fma2(lwk[k], sg, fma2(SC, yq, fma2(SB, xq, SA)));
         }
         float gdisp;
