@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
     const double* bs = (pass ? bs_s : bs_t) + (size_t)b * per_sample * 8;
     const int j = tid & 7, sub = tid >> 3;  // 32 strided partial sums per quantity
     double acc = 0.0;
-    for (int t = sub; t < per_sample; t += 32) acc += bs[(size_t)t * 8 + j];
+#pragma unroll 8
+    for (int t = sub; t < per_sample; t += 32) acc += bs[(size_t)t * 8 + j];  // independent loads: issue them together
     s_part[tid] = acc;
     __syncthreads();
     if (tid < 8) {
@@ -102,17 +103,19 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
     }
   } else {
     const int b = blockIdx.x - 2 * B;
-    // 24 sums of per_sample partials: 8 lanes per value, then an 8-term sum (fixed order)
-    const int v = tid >> 3, sub = tid & 7;
+    // 24 sums of per_sample partials: 10 threads per value (240 of 256), then a 10-term sum (fixed order)
+    const int v = tid % 24, sub = tid / 24;
     double acc = 0.0;
-    if (v < 24)
-      for (int t = sub; t < per_sample; t += 8) acc += (double)bgP[((size_t)b * per_sample + t) * 24 + v];
+    if (sub < 10) {
+#pragma unroll 8
+      for (int t = sub; t < per_sample; t += 10) acc += (double)bgP[((size_t)b * per_sample + t) * 24 + v];
+    }
     s_part[tid] = acc;
     __syncthreads();
-    if (v < 24 && sub == 0) {
+    if (tid < 24) {
       double a = 0.0;
-      for (int k = 0; k < 8; ++k) a += s_part[tid + k];
-      s_gP[v] = a;
+      for (int k = 0; k < 10; ++k) a += s_part[k * 24 + tid];
+      s_gP[tid] = a;
     }
     __syncthreads();
     if (tid < 32) {
