@@ -270,7 +270,7 @@ def main():
     if args.mode == "train":
         out["metric"] = "train images/sec at B=12 192x640 KITTI-shaped (whole training step of the harness)"
         out["config"]["workload"] = ("RepDepth (ResNet-18 x3 + decoders + pose, cost volume) forward+backward through torch.nn/MIOpen, "
-                                     "MAL loss step (7 HIP kernels), one flat-bucket gradient all-reduce (165 MB fp32), Adam; "
+                                     "MAL loss step (6 HIP kernels), one flat-bucket gradient all-reduce (165 MB fp32), Adam; "
                                      "B=12 per GPU, 192x640, --distil, synthetic batch, random-init weights")
         out["config"]["parallelism"] = "dp%d (one RCCL all-reduce of the flat gradient bucket per step)" % world
         out["config"]["api"] = "mal_amd.harness.TrainHarness.train_step"

@@ -3,6 +3,7 @@
 #pragma once
 #include "mal_common.h"
 #include "mal_device.h"
+#include "mal_pose.h"
 
 namespace mal {
 
@@ -57,8 +58,12 @@ MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, 
 int march_launch(MarchParams& p, int flags, hipStream_t st);
 // min_f r(src_f, target) of the RAW sources -> ident (B,1,H,W) (the identity term of
 // manydepth/loss_utils.py:92-101), and in the same sweep the two planar sources repacked as (B,H,W,4) texels
-// (packed0/1 nullable together), optionally the target too
+// (packed0/1 nullable together), optionally the target too.  With `poses` (the whole-step launch list) B extra
+// workgroups of the same launch compose the poses of both frames (layers.py:26-100), fill the camera block of
+// the marching passes and reset the completion counter of the step's last kernel.
+struct StepPoses { PoseParams pose; const float* K; const float* invK; float* cam; unsigned* ticket; };
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
-                         float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st);
+                         float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
+                         const StepPoses* poses = nullptr);
 
 }  // namespace mal

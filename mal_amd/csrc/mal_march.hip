@@ -755,11 +755,20 @@ struct IdentParams {
   float* packed_target;                       // the target as (B,H,W,4) out, nullable
   float* ident;                               // (B,1,H,W) out
   int B, H, W, strips, segs, rows, ntasks, per_xcd;
+  int pose_blocks; StepPoses sp;              // the last pose_blocks workgroups: poses + camera block of sample b
 };
 
 __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
   constexpr int HALO = 1, CW = 62;
   const int id = blockIdx.x;
+  if (id >= p.per_xcd * 8) {  // whole-step list: poses of both frames and the camera block of sample b
+    const int b = id - p.per_xcd * 8, tid = threadIdx.x;
+    if (b == 0 && tid == 0) *p.sp.ticket = 0u;  // completion counter of step_final_kernel
+    if (tid < 2) pose_fwd_one(p.sp.pose, tid, b);
+    __syncthreads();  // T of this sample, written by threads 0/1 to global memory, is visible to the block
+    cam_fill(p.sp.K, p.sp.pose.T[0], p.sp.pose.T[1], p.sp.invK, p.sp.cam, b, tid);
+    return;
+  }
   const int task = (id & 7) * p.per_xcd + (id >> 3);
   if (task >= p.ntasks) return;
   const int per_b = p.strips * p.segs;
@@ -916,8 +925,11 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
 }
 
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
-                         float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st) {
-  IdentParams p;
+                         float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
+                         const StepPoses* poses) {
+  IdentParams p = {};
+  p.pose_blocks = poses ? B : 0;
+  if (poses) p.sp = *poses;
   p.target = target; p.src[0] = src0; p.src[1] = src1; p.packed[0] = packed0; p.packed[1] = packed1; p.packed_target = packed_target; p.ident = ident;
   p.B = B; p.H = H; p.W = W;
   p.strips = (W + 61) / 62;
@@ -925,7 +937,7 @@ int pack_identity_launch(const float* target, const float* src0, const float* sr
   p.segs = (H + p.rows - 1) / p.rows;
   p.ntasks = B * p.strips * p.segs;
   p.per_xcd = (p.ntasks + 7) / 8;
-  hipLaunchKernelGGL(pack_identity_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(pack_identity_kernel, dim3(p.per_xcd * 8 + p.pose_blocks), dim3(64), 0, st, p);
   return launch_status();
 }
 

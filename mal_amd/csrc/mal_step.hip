@@ -5,8 +5,8 @@
 // reductions, pose composition, and the same again in autograd's backward); the operator-level
 // API of this library still needs ~60 launches plus Python glue between them.  Here:
 //
-//   forward  1 poses of both frames (layers.py:26-100) + the camera block P = K T of the passes
-//            1 identity term min_f r(src_f, target) (loss_utils.py:92-101) + packing of the sources into 16-byte texels
+//   forward  1 identity term min_f r(src_f, target) (loss_utils.py:92-101) + packing of the images into 16-byte
+//              texels; B extra workgroups: poses of both frames (layers.py:26-100) + camera block P = K T
 //            1 teacher pass  (warp+SSIM+L1+min+automask+smoothness, fwd+bwd to disp and poses)   :573-581
 //            1 ensemble pass ((disp_t+disp_s)/2 formed in the kernel, no grad)                   :594-600
 //            1 student pass  (matching mask, consistency*(1-augmentation) mask, mono depth from the teacher's
@@ -60,21 +60,10 @@ static StepWs carve_step(void* base, int B, int H, int W) {
 }
 
 // ---------------------------------------------------------------- small kernels
-// poses of both frames (layers.py:26-100) and the camera block of the marching kernels, one block per sample
-__global__ __launch_bounds__(64) void step_pose_cam_kernel(PoseParams p, const float* K, const float* invK, float* cam,
-                                                           unsigned* ticket) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (b == 0 && tid == 0) *ticket = 0u;  // step_final_kernel's completion counter, first kernel of every step
-  if (tid < 2) pose_fwd_one(p, tid, b);
-  __syncthreads();  // T of this sample, written by threads 0/1 to global memory, is visible to the block
-  cam_fill(K, p.T[0], p.T[1], invK, cam, b, tid);
-}
-
 // Everything after the three passes, fixed summation order, no floating-point atomics.  3B blocks:
 //   blocks [0, 2B):  ps[pass][b][j] = sum over the sample's marching tasks (contiguous) of block_sums[task][j]
 //   blocks [2B, 3B): g_T[f][b] = K_b^T [gP_fb ; 0]  from the teacher's per-task pose partials
-// and the block that finishes last (a ticket counter, reset by step_pose_cam_kernel at the start of every
-// step) turns the per-sample sums into the smoothness of the mean-normalised disparities (layers.py:210-223,
+// and the block that finishes last (a ticket counter, reset by the step's first launch) turns the per-sample sums into the smoothness of the mean-normalised disparities (layers.py:210-223,
 // loss_utils.py:119-121), the loss scalars (loss_utils.py:112-127,198-279; trainer.py:625-629) and the
 // coefficients of the backward.
 __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, const double* bs_s, const float* bgP,
@@ -241,22 +230,23 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   float* ens_reproj = no_ens ? nullptr : (a->ens_reproj ? a->ens_reproj : w.ens_reproj);
   float* multi_reproj = a->multi_reproj ? a->multi_reproj : w.multi_reproj;
 
-  // 1. poses (frame -1 is inverted, networks/repdepth.py:159-160) + the camera block of the passes
+  // 1. identity term + texel packing of the three images (one 16-byte load per pixel in the passes); B extra
+  //    workgroups of the same launch: poses (frame -1 is inverted, networks/repdepth.py:159-160) + camera block
   {
-    PoseParams pp = {};
-    pp.B = B; pp.F = 2;
-    pp.axisangle[0] = a->axisangle_m1; pp.axisangle[1] = a->axisangle_p1;
-    pp.translation[0] = a->translation_m1; pp.translation[1] = a->translation_p1;
-    pp.invert[0] = 1; pp.invert[1] = 0;
-    pp.T[0] = w.T[0]; pp.T[1] = w.T[1];
-    hipLaunchKernelGGL(step_pose_cam_kernel, dim3(B), dim3(64), 0, st, pp, a->K, a->inv_K, w.cam, w.ticket);
+    StepPoses sp = {};
+    sp.pose.B = B; sp.pose.F = 2;
+    sp.pose.axisangle[0] = a->axisangle_m1; sp.pose.axisangle[1] = a->axisangle_p1;
+    sp.pose.translation[0] = a->translation_m1; sp.pose.translation[1] = a->translation_p1;
+    sp.pose.invert[0] = 1; sp.pose.invert[1] = 0;
+    sp.pose.T[0] = w.T[0]; sp.pose.T[1] = w.T[1];
+    sp.K = a->K; sp.invK = a->inv_K; sp.cam = w.cam; sp.ticket = w.ticket;
+    rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
+                              &sp);
+    if (rc) return rc;
   }
-  // 2. identity term + texel packing of the three images (one 16-byte load per pixel in the passes)
-  rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st);
-  if (rc) return rc;
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
   int per_sample = 1;
-  int cam_ready = 1;  // step_pose_cam_kernel filled the camera block
+  int cam_ready = 1;  // the first launch filled the camera block
   // 5. teacher pass
   {
     MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);

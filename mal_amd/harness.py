@@ -5,7 +5,7 @@ tracker (:75-99), ``LossBalancing`` (:640-642), Adam + StepLR / ``WarmupStepLRSc
 1667-1730) and the data-parallel exchange: ONE flat-bucket all-reduce of the parameter gradients per step over
 RCCL (mal_amd.dp.FlatGradBucket) instead of accelerate's DDP + per-step barrier.
 
-The loss half of ``process_batch`` is ``mal_amd.step.loss_step`` (7 HIP kernels); the networks run through
+The loss half of ``process_batch`` is ``mal_amd.step.loss_step`` (6 HIP kernels); the networks run through
 torch.nn (MIOpen).  Options follow manydepth/options.py names.
 """
 from __future__ import annotations

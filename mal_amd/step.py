@@ -1,5 +1,5 @@
 """The whole loss half of ``Trainer.process_batch`` (manydepth/trainer.py:573-642, ``--distil``)
-as one C call forward (``mal_loss_step_fwd``, 9 kernels) and one backward
+as one C call forward (``mal_loss_step_fwd``, 5 kernels) and one backward
 (``mal_loss_step_bwd``, 2 kernels): no Python between the kernels, no per-op autograd nodes.
 
 ``loss_step(...)`` returns the same ``losses`` dict keys as the reference's ``process_batch``
