@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void costvol_match_kernel(CostVolParams p) {
       const TapSet t = taps_for(P, ray, p.bins[min(dmine, p.D - 1)], p.eps, w, h);  // phase 1: lane = bin
       const int nb = min(64, p.D - k * 64);
       for (int j = 0; j < nb; ++j) {                                                   // phase 2: lane = channel
+        if (bcast(t.edge, j) == 0.f) continue;  // masked out (wave-uniform): the difference would be multiplied by 0
         const int o0 = bcasti(t.o[0], j), o1 = bcasti(t.o[1], j), o2 = bcasti(t.o[2], j), o3 = bcasti(t.o[3], j);
         const float w0 = bcast(t.w[0], j), w1 = bcast(t.w[1], j), w2 = bcast(t.w[2], j), w3 = bcast(t.w[3], j);
         const float a = lf[(size_t)o0 * kCvC], bb = lf[(size_t)o1 * kCvC], c = lf[(size_t)o2 * kCvC], d = lf[(size_t)o3 * kCvC];
