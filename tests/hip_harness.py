@@ -119,6 +119,24 @@ def automask_tie_allowance(o, n0, rel=3e-5):
     return allow, float(amb.sum()) / max(int(m.sum()), 1), bool(amb.any())
 
 
+def smooth_sign_ambiguous(disp, rel=4e-7):
+    """(B,1,H,W) bool: a neighbour's disparity is within a few ulp -- the sign of d(mean-normalised disp) in
+    get_smooth_loss's gradient (layers.py:210-223) then depends on how the normalisation rounds (upstream divides
+    each pixel by mean+1e-7 first; the kernels take the difference of the raw values and scale afterwards)."""
+    d = disp.astype(np.float64)
+    amb = np.zeros(d.shape, dtype=bool)
+    tol = rel * np.abs(d)
+    dx = np.abs(d[..., :, 1:] - d[..., :, :-1])
+    dy = np.abs(d[..., 1:, :] - d[..., :-1, :])
+    ex = (dx <= np.maximum(tol[..., :, 1:], tol[..., :, :-1])) & (dx > 0)
+    ey = (dy <= np.maximum(tol[..., 1:, :], tol[..., :-1, :])) & (dy > 0)
+    amb[..., :, 1:] |= ex
+    amb[..., :, :-1] |= ex
+    amb[..., 1:, :] |= ey
+    amb[..., :-1, :] |= ey
+    return amb
+
+
 def near_tie(maps, tol):
     """pixels where the smallest two of the stacked (B,K,H,W) maps are within tol (relative)."""
     s = np.sort(maps, axis=1)

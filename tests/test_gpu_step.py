@@ -59,6 +59,18 @@ def test_loss_step_at_baseline_sizes(B, H, W):
     _check_step(b, {}, n0, n1)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 8, 72), (1, 16, 61), (2, 10, 121), (1, 24, 8)],
+                         ids=["two_strips", "strip_edge_61", "three_strips_ragged", "narrow_8"])
+def test_loss_step_small_and_ragged_shapes(B, H, W):
+    """strip / segment boundaries of the marching kernels: widths just past a 60-column strip, a few rows only,
+    images narrower than one wavefront"""
+    from mal_amd.synthetic import make_batch
+    b = make_batch(B, H, W, seed=31)
+    g = torch.Generator().manual_seed(6)
+    n0, n1 = torch.randn(B, 1, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
+    _check_step(b, {}, n0, n1)
+
+
 def _check_step(b, kw, n0, n1):
     B, _, H, W = b["color0"].shape
     o = HH.run_oracle(b, kw, n0, n1)
@@ -88,6 +100,8 @@ def _check_step(b, kw, n0, n1):
     amb_t |= HH.sample_ambiguous(o["mono_sample"], H, W)
     amb_s = HH.dilate3(HH.near_tie(o["multi_cands"], 2e-4)) | HH.sample_ambiguous(o["multi_sample"], H, W) | amb_distil
     amb_s |= np.abs(o["mono_depth"] - o["multi_depth"]) <= 1e-6 * np.abs(o["mono_depth"])
+    amb_t |= HH.smooth_sign_ambiguous(b["disp_teacher"].numpy())   # neighbours equal to a few ulp: sign of the
+    amb_s |= HH.smooth_sign_ambiguous(b["disp_student"].numpy())   # smoothness difference is a rounding matter
     o64 = HH.oracle_fp64_grads(b, kw, n0, n1)
     for key in HH.LEAVES:
         g, r, r64 = h["grads"][key], o["grads"][key], o64[key]
