@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch first: the process must hold ONE HIP runtime, the one PyTorch-ROCm loads.  If libmal_hip.so were loaded
+# before torch, the system libamdhip64 would come in first and kernels registered with it fail to launch on
+# torch's streams ("HIP kernel launch failed").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MAL_HIP_LIB points at another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("MAL_HIP_LIB") or os.path.join(_HERE, "lib", "libmal_hip.so")
