@@ -125,6 +125,21 @@ class Step:
         return losses["loss"]
 
 
+def measured_copy_ceiling(dev, mib=1024, reps=5):
+    """device-to-device copy rate of this box (read + write bytes / time): the practical HBM ceiling next to the
+    8 TB/s spec the roofline fraction is quoted against (SURVEY.md 8d asks for both)."""
+    n = mib * (1 << 20) // 4
+    a, b = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(batch, steps):
     """The CPU oracle (oracle/mal_oracle.py, PyTorch-CPU ATen ops in the reference's order)
     on the same workload: B=12 192x640, passes A+B+C forward+backward."""
@@ -242,6 +257,7 @@ def main():
         return
     n_px = B * H * W
     achieved = ALG_BYTES_PER_PX * n_px / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    copy_gbs = measured_copy_ceiling(dev)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -265,7 +281,8 @@ def main():
                                                "min+automask+smoothness fwd+bwd, one launch)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "alg_bytes_per_px": ALG_BYTES_PER_PX, "pixels_per_launch": n_px,
-                     "kernel_ms": kern_ms, "launches_timed": len(durs)},
+                     "kernel_ms": kern_ms, "launches_timed": len(durs),
+                     "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None},
     }
     if args.mode == "train":
         out["metric"] = "train images/sec at B=12 192x640 KITTI-shaped (whole training step of the harness)"
