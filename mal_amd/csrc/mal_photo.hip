@@ -296,6 +296,9 @@ __global__ __launch_bounds__(256) void plane_sum_kernel(const float* x, int HW, 
   if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
+int smooth_march(const float* disp, const float* img, int B, int H, int W, int normalise, float* gn, double* partial,
+                 double* stats, double* sums, double* loss_out, hipStream_t st);
+
 struct SmoothParams {
   const float* disp; const float* img; int B, C, H, W; int normalise; int chunks;
   const double* mean_partial;  // [B][chunks] sums of disp
@@ -601,6 +604,17 @@ extern "C" int mal_smooth_loss(const float* disp, const float* img, int B, int C
   if (!disp || !img || !loss_out || !ws || C <= 0) return MAL_EINVAL;
   Workspace w = carve(ws, B, H, W);
   if (ws_bytes < w.bytes) return MAL_EWORKSPACE;
+  if (g_photo_impl == 1 && C == 3 && 4 * B <= 4096) {
+    // marching sweep (mal_photo_march.hip): 2-3 launches instead of 5.  scratch: stats [2B], sums [2B]
+    double* stats = w.scratch;
+    double* sums = w.scratch + 2 * B;
+    hipStream_t st = (hipStream_t)stream;
+    rc = smooth_march(disp, img, B, H, W, normalise, g_disp, w.block_sums, stats, sums, loss_out, st);
+    if (rc || !g_disp || !normalise) return rc;
+    SmoothParams q = {disp, img, B, C, H, W, normalise, 64, nullptr, nullptr, stats, g_disp};
+    hipLaunchKernelGGL(smooth_finish_kernel, dim3(B * 64), dim3(256), 0, st, q, g_disp);  // g = gn/(mean+eps) - corr
+    return launch_status();
+  }
   int chunks = (H * W + 1023) / 1024;
   const int cap = (4096 - 2 * B) / 5 / B;  // scratch holds 4096 doubles: B*chunks*(1+4) + 2B
   if (chunks > cap) chunks = cap;

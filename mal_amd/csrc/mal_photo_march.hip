@@ -290,6 +290,115 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
   }
 }
 
+// ---- get_smooth_loss (manydepth/layers.py:210-223) on the mean-normalised disparity (loss_utils.py:119-121) in one
+// sweep: lane = column, the right edge comes from the neighbouring lane (DPP), the up edge from the previous
+// row in registers.  The per-sample 1/(mean+1e-7) is a positive constant, so it is factored out of |d n|: the
+// sweep accumulates sum|dx d| w, sum|dy d| w, sum gn*d and sum d per task and writes the gradient w.r.t. the
+// normalised map; a second small kernel forms the means, the loss and the mean-coupling term.
+struct SmoothMarchParams {
+  const float* disp; const float* img;  // (B,1,H,W), (B,3,H,W)
+  float* gn;                            // (B,1,H,W) nullable
+  double* partial;                      // [task][4]
+  int B, H, W, strips, segs, rows, ntasks, per_xcd;
+};
+
+__global__ __launch_bounds__(64, 4) void smooth_march_kernel(SmoothMarchParams p) {
+  constexpr int HALO = 1, CW = 62;
+  const int id = blockIdx.x;
+  const int task = (id & 7) * p.per_xcd + (id >> 3);
+  if (task >= p.ntasks) return;
+  const int per_b = p.strips * p.segs;
+  const int b = task / per_b, tt = task - b * per_b;
+  const int seg = tt / p.strips, strip = tt - seg * p.strips;
+  const int H = p.H, W = p.W, HW = H * W, lane = threadIdx.x;
+  const int y_lo = seg * p.rows, y_hi = min(y_lo + p.rows, H);
+  const int gx = strip * CW - HALO + lane;
+  const bool in_x = gx >= 0 && gx < W;
+  const int gxr = min(max(gx, 0), W - 1);
+  const bool out_x = in_x && lane >= HALO && lane < 64 - HALO;
+  const float* d = p.disp + (size_t)b * HW;
+  const float* im = p.img + (size_t)b * 3 * HW;
+  const float nx = 1.0f / ((float)p.B * (float)H * (float)(W - 1)), ny = 1.0f / ((float)p.B * (float)(H - 1) * (float)W);
+  float d1 = 0.f, c1[3] = {0.f, 0.f, 0.f}, g1 = 0.f;  // previous row: disparity, colour, pending gradient
+  float acc_x = 0.f, acc_y = 0.f, acc_g = 0.f, acc_d = 0.f;
+  // rows y_lo-1 (context for the up edge of y_lo) .. y_hi (finishes row y_hi-1 through its down edge; row H is
+  // virtual: no edges)
+  const int r0 = max(y_lo - 1, 0);
+  for (int r = r0; r <= y_hi; ++r) {
+    const bool row_ok = r < H;
+    const unsigned bo = (unsigned)(min(r, H - 1) * W + gxr) * 4u;
+    const float d0 = ldf(d, bo);
+    const float c0[3] = {ldf(im, bo), ldf(im + HW, bo), ldf(im + 2 * (size_t)HW, bo)};
+    // right edge (r,x)-(r,x+1)
+    const float eR = (fabsf(c0[0] - dpp_shl1(c0[0])) + fabsf(c0[1] - dpp_shl1(c0[1]))) + fabsf(c0[2] - dpp_shl1(c0[2]));
+    const float wx = (row_ok && in_x && gx + 1 < W) ? __expf(-(eR * (1.0f / 3.0f))) : 0.f;
+    const float dfx = d0 - dpp_shl1(d0);
+    const float sx = sgnf(dfx) * wx * nx;
+    // up edge (r-1,x)-(r,x)
+    const float eU = (fabsf(c1[0] - c0[0]) + fabsf(c1[1] - c0[1])) + fabsf(c1[2] - c0[2]);
+    const bool have_up = r > r0;  // the first row of the sweep has no previous row in registers (and row 0 has none)
+    const float wyu = (row_ok && have_up && in_x) ? __expf(-(eU * (1.0f / 3.0f))) : 0.f;
+    const float dfy = d1 - d0;
+    const float sy = sgnf(dfy) * wyu * ny;
+    const int q = r - 1;  // row finished now
+    if (q >= y_lo && q < y_hi && out_x) {
+      const float g = g1 + sy;
+      if (p.gn) stf(p.gn + (size_t)b * HW, (unsigned)(q * W + gxr) * 4u, g);
+      acc_y += fabsf(dfy) * wyu;
+      acc_g += g * d1;
+    }
+    if (r >= y_lo && r < y_hi && out_x) { acc_x += fabsf(dfx) * wx; acc_d += d0; }
+    g1 = (sx - dpp_shr1(sx)) - sy;
+    d1 = d0; c1[0] = c0[0]; c1[1] = c0[1]; c1[2] = c0[2];
+  }
+  const double s0 = wave_sum_d((double)acc_x), s1 = wave_sum_d((double)acc_y), s2 = wave_sum_d((double)acc_g),
+               s3 = wave_sum_d((double)acc_d);
+  if (lane == 0) { double* o = p.partial + (size_t)task * 4; o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; }
+}
+
+// per-sample sums over the tasks (contiguous), then loss, means, coupling terms: one workgroup, one wave per sample
+// (16 at a time), the loss summed over the samples in sample order
+__global__ __launch_bounds__(1024) void smooth_march_finish_kernel(const double* partial, int per_sample, int B, int H, int W,
+                                                                   int normalise, double* stats, double* sums,
+                                                                   double* loss_out) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, HW = H * W;
+  for (int b = wv; b < B; b += 16) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t = lane; t < per_sample; t += 64)
+      for (int j = 0; j < 4; ++j) a[j] += partial[((size_t)b * per_sample + t) * 4 + j];
+    for (int j = 0; j < 4; ++j) a[j] = wave_sum_d(a[j]);
+    if (lane == 0) {
+      const double mean = a[3] / (double)HW;
+      const float m = normalise ? (float)mean + 1e-7f : 1.0f;
+      const double inv = normalise ? (double)div_(1.0f, m) : 1.0;
+      stats[b] = mean;
+      stats[B + b] = normalise ? a[2] / ((double)HW * (double)m * (double)m) : 0.0;
+      sums[2 * b] = a[0] * inv; sums[2 * b + 1] = a[1] * inv;
+    }
+  }
+  __syncthreads();  // the per-sample sums, written to global memory by this workgroup, are visible to it
+  if (threadIdx.x != 0) return;
+  double sx = 0.0, sy = 0.0;
+  for (int k = 0; k < B; ++k) { sx += sums[2 * k]; sy += sums[2 * k + 1]; }
+  loss_out[0] = sx / ((double)B * H * (W - 1)) + sy / ((double)B * (H - 1) * W);
+}
+
+// partial: [>= B*tasks][4]; stats [2B]; sums [2B]
+int smooth_march(const float* disp, const float* img, int B, int H, int W, int normalise, float* gn, double* partial,
+                 double* stats, double* sums, double* loss_out, hipStream_t st) {
+  SmoothMarchParams p = {};
+  p.disp = disp; p.img = img; p.gn = gn; p.partial = partial; p.B = B; p.H = H; p.W = W;
+  p.strips = (W + 61) / 62;
+  p.rows = 12;
+  p.segs = (H + p.rows - 1) / p.rows;
+  p.ntasks = B * p.strips * p.segs;
+  p.per_xcd = (p.ntasks + 7) / 8;
+  hipLaunchKernelGGL(smooth_march_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(smooth_march_finish_kernel, dim3(1), dim3(1024), 0, st, partial, p.strips * p.segs, B, H, W, normalise,
+                     stats, sums, loss_out);
+  return launch_status();
+}
+
 int g_photo_impl = 1;  // 1 = marching kernels of this file; 0 = one-pixel-per-thread kernels of mal_photo.hip
 
 static int device_slots() {
