@@ -52,3 +52,18 @@ def test_process_batch_keys_match_upstream():
     assert outputs["lowest_cost"].shape == (2, 96, 160) and outputs[("disp", 0)].shape == (2, 1, 96, 160)
     for k in ("loss", "reproj_loss/0", "consistency_loss/0", "distil_loss", "mono/loss"):
         assert k in losses and torch.isfinite(losses[k]).all()
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    """end to end: networks -> HIP loss step -> backward through the flat bucket -> Adam; overfitting one batch
+    must drive the total loss down (gradients of the HIP path are descent directions for the networks)"""
+    import random
+    from mal_amd import harness
+    torch.manual_seed(1)
+    random.seed(1)
+    opt = harness.default_options(batch_size=2, height=96, width=160, no_matching_augmentation=True, learning_rate=2e-4)
+    h = harness.TrainHarness(opt, DEV)
+    inputs = harness.synthetic_inputs(opt, DEV, seed=5)
+    losses = [float(h.train_step(inputs)["loss"].detach()) for _ in range(25)]
+    head, tail = sum(losses[:3]) / 3, sum(losses[-3:]) / 3
+    assert tail < 0.95 * head, losses
