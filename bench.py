@@ -71,6 +71,17 @@ class TrainStep:
     def __call__(self):
         return self.h.train_step(self.inputs)["loss"]
 
+    def breakdown_ms(self, steps=5):
+        """mean device time per stage over a few extra steps outside the timed region"""
+        from mal_amd.harness import StageTimer
+        acc = {}
+        for _ in range(steps):
+            t = StageTimer()
+            self.h.train_step(self.inputs, t)
+            for k, v in t.result_ms().items():
+                acc[k] = acc.get(k, 0.0) + v / steps
+        return acc
+
 
 class Step:
     """Everything a step needs, resident on the device."""
@@ -291,6 +302,8 @@ def main():
                                      "B=12 per GPU, 192x640, --distil, synthetic batch, random-init weights")
         out["config"]["parallelism"] = "dp%d (one RCCL all-reduce of the flat gradient bucket per step)" % world
         out["config"]["api"] = "mal_amd.harness.TrainHarness.train_step"
+        out["breakdown_ms"] = step.breakdown_ms()
+        out.pop("roofline")  # the kernel line belongs to the default mode
     elif args.mode != "step":
         out["config"]["workload"] += " [mode %s]" % args.mode
     if world == 1 and not args.no_cpu_baseline:

@@ -82,6 +82,23 @@ class WarmupStepLRScheduler:
         return [self.lr]
 
 
+class StageTimer:
+    """device-side stage marks of one training step (network, loss-path, all-reduce and optimizer time
+    reported separately); events on the current stream, read back after a synchronize"""
+
+    def __init__(self):
+        self.marks = []
+
+    def mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append((name, e))
+
+    def result_ms(self):
+        torch.cuda.synchronize()
+        return {n: self.marks[i - 1][1].elapsed_time(e) for i, (n, e) in enumerate(self.marks) if i}
+
+
 class TrainHarness:
     def __init__(self, opt, device, process_group=None):
         self.opt, self.device = opt, torch.device(device)
@@ -99,12 +116,16 @@ class TrainHarness:
         self.step_count = 0
 
     # ---- trainer.py:555-644, --distil
-    def process_batch(self, inputs, index_iter=0):
+    def process_batch(self, inputs, index_iter=0, timer=None):
         min_depth, max_depth = self.tracker.compute()
         mono_outputs, outputs = self.model(inputs, min_depth, max_depth)
+        if timer is not None:
+            timer.mark("networks_fwd")
         # with --loss_blc the total is bs * sum_i w_i L_i (loss_utils.py:303-318), formed on the device
         w_list = list(self.loss_blc.w_list) if self.loss_blc is not None else None
         losses, loss_list, maps = loss_step(self.opt, inputs, mono_outputs, outputs, w_list=w_list)
+        if timer is not None:
+            timer.mark("loss_path_fwd")
         if not self.opt.notadabins and not self.model.freeze_tp:
             # ("mono_depth", 0, 0) of generate_images_pred: 1 / (1/max + (1/min - 1/max) * disp)   (layers.py:14-23)
             lo, hi = 1.0 / self.opt.max_depth, 1.0 / self.opt.min_depth
@@ -114,13 +135,18 @@ class TrainHarness:
             losses["w_ori"], losses["w_distil"] = self.loss_blc.update_weight(index_iter, 0.0)
         return outputs, losses
 
-    def train_step(self, inputs):
+    def train_step(self, inputs, timer=None):
+        mark = timer.mark if timer is not None else (lambda name: None)
         self.model.train()
+        mark("start")
         self.bucket.zero_()
-        outputs, losses = self.process_batch(inputs, self.step_count)
+        outputs, losses = self.process_batch(inputs, self.step_count, timer)
         losses["loss"].backward()
+        mark("loss_path_bwd+networks_bwd")
         self.bucket.all_reduce_mean()
+        mark("grad_all_reduce")
         self.optimizer.step()
+        mark("adam")
         self.step_count += 1
         return losses
 
