@@ -291,6 +291,8 @@ int mal_cost_volume(const float* current_feats, const float* lookup_feats, const
  * "pass_impl"   formulation of the fused pass: 1 = register-marching (default); 0 / 2 = the LDS-tiled first
  *               versions (256 threads x 4 px, 512 threads x 2 px), kept for A/B;
  * "march_rows"  output rows per wavefront task of the marching kernels (0 = automatic, default);
+ * "march_flip"  1 (default): odd row segments of the marching kernels walk bottom-up, so the two tasks sharing a
+ *               segment boundary reach it together and the halo rows are served by the L2; 0 = all top-down;
  * "photo_impl"  mal_photo_fwd/bwd: 1 = marching kernels, two candidates per launch (default for SSIM + min);
  *               0 = one pixel per thread (ATen's summation order; always used for MAL_F_NO_SSIM / MAL_F_AVG);
  * "fwd_waves", "debug": kernel experiments. */

@@ -28,6 +28,7 @@ struct MarchParams {
   double* block_sums; float* block_gP;
   int strips, segs, rows, ntasks, per_xcd;
   int packed;
+  int flip_odd;  // odd row segments walk bottom-up: both tasks that share a segment boundary reach it together (L2 serves the halo)
   int debug;  // experiments only (mal_set_option("debug")): bit 0 = taps read the pixel's own address
 };
 

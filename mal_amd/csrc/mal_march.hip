@@ -241,7 +241,15 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   const int seg = tt / p.strips, strip = tt - seg * p.strips;  // strips of one segment are consecutive tasks
   const int H = p.H, W = p.W, HW = H * W;
   const int lane = threadIdx.x;
-  const int y_lo = seg * p.rows, y_hi = min(y_lo + p.rows, H);
+  // Rows are LOGICAL rows of this task: odd segments see the sample upside down (physical row = H-1 - logical), so
+  // they walk bottom-up and a segment boundary is reached by both of its tasks at the same time -- the halo rows one
+  // of them re-reads are then still in the XCD's L2.  Box filter, reflection padding and the smoothness stencil are
+  // symmetric under the flip; only addresses and the ray's row use the physical row (prow).
+  const int ph_lo = seg * p.rows, ph_hi = min(ph_lo + p.rows, H);
+  const bool flip = (seg & 1) != 0 && p.flip_odd != 0;
+  const int y_lo = flip ? H - ph_hi : ph_lo, y_hi = flip ? H - ph_lo : ph_hi;
+  const int yf = flip ? H - 1 : 0;
+  auto prow = [&](int y) { return abs(y - yf); };  // y in [0, H-1]
 
   // P = (K T)[:3,:] of both frames and inv_K[:3,:3] (cam_setup_kernel wrote them, 40 floats per sample).
   // They are fetched with scalar loads where they are used, every iteration, rather than held across
@@ -332,14 +340,14 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     // gathers (the blend then waits for the gathers only).  A map that is absent is read from the disparity map
     // of the sample instead (a valid address, L2-resident) and the value is dropped.
     const bool packed_t = (pp.packed & 2) != 0;
-    const unsigned pix = (unsigned)(row_of(rr) * W + gxr);
+    const unsigned pix = (unsigned)(prow(row_of(rr)) * W + gxr);
     a.disp = ldf(disp_b, pix * 4u);
     {
       const float v = ldf(disp2_b ? disp2_b : disp_b, pix * 4u);
       a.disp2 = disp2_b ? v : 0.f;
     }
     load_rgb(pp.target, packed_t, b, HW, pix, a.y);  // one 16-byte texel (packed) or three planes
-    const unsigned oc = (unsigned)(min(max(rr - 1, 0), H - 1) * W + gxr) * 4u;  // statistics row c = rr-1
+    const unsigned oc = (unsigned)(prow(min(max(rr - 1, 0), H - 1)) * W + gxr) * 4u;  // statistics row c = rr-1
     auto opt = [&](const float* m, unsigned off, float absent) {
       const float v = ldf(m ? m + map_b : disp_b, off);
       return m ? v : absent;
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     a.ext = opt(pp.ext_mask, oc, 1.f);
     a.mono = opt(pp.lowest_cost ? pp.mono_disp : nullptr, oc, 0.f);
     a.cost = opt(pp.lowest_cost, oc, 1.f);
-    const unsigned oq = (unsigned)(min(max(GRAD ? rr - 2 : rr - 1, 0), H - 1) * W + gxr) * 4u;  // epilogue row
+    const unsigned oq = (unsigned)(prow(min(max(GRAD ? rr - 2 : rr - 1, 0), H - 1)) * W + gxr) * 4u;  // epilogue row
     a.e_mono = 0.f; a.e_mr = 0.f; a.e_er = 0.f;
     if (EPI) {
       a.e_mono = ldf((pp.mono_disp ? pp.mono_disp : pp.mono_depth) + map_b, oq);
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     const float le_disp = GRAD ? dv_2 : dv_1;  // the epilogue row's own disparity (rows r-2 / r-1 of this sweep)
     const float le_mono = cur.e_mono, le_mr = cur.e_mr, le_er = cur.e_er;
     // ================= stage W: warp row r (reflected if outside the image) ==================
-    const int gyr = row_of(r);
+    const int gyr = prow(row_of(r));  // physical row: addresses and the ray
     WarpRow w0;
     const float dv_ = disp2_b ? (cur.disp + cur.disp2) / 2.0f : cur.disp;
     w0.yrg = (f2){cur.y[0], cur.y[1]}; w0.yb = cur.y[2];
@@ -460,10 +468,11 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       const int qs = r - 1;  // row finished now: its down edge is this up edge
       if (qs >= y_lo && qs < y_hi && out_x) {
         const float g = sm_g1 + sy;
-        stf(p.smooth_gn + map_b, (unsigned)(qs * W + gxr) * 4u, g);
-        acc_sy += fabsf(dfy) * wyu_;
+        stf(p.smooth_gn + map_b, (unsigned)(prow(qs) * W + gxr) * 4u, g);
         acc_sd += g * sm_d1;
       }
+      // every vertical edge is summed once: by the task that owns its physically upper row
+      if ((flip ? r : qs) >= y_lo && (flip ? r : qs) < y_hi && out_x) acc_sy += fabsf(dfy) * wyu_;
       if (r >= y_lo && r < y_hi && out_x) { acc_sx += fabsf(dfx) * wxr; acc_d += dv_; }
       sm_g1 = (sx - dpp_shr1(sx)) - sy;
       sm_n1 = n0;
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       const int q = GRAD ? r - 2 : r - 1;
       const PixInfo& pq = GRAD ? pi1 : pi0;
       if (q >= y_lo && q < y_hi && out_x) {
-        const unsigned go = (unsigned)(q * W + gxr) * 4u;
+        const unsigned go = (unsigned)(prow(q) * W + gxr) * 4u;
         const float dm = depth_of(le_disp, wc.min_disp, wc.range);
         const float ddepth = -(dm * dm) * wc.range;
         const float dmono = has_mdisp ? depth_of(le_mono, wc.min_disp, wc.range) : le_mono;
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       pi0.win = (rr.y < rr.x) ? 1 : 0;
       pi0.rp = pi0.win ? rr.y : rr.x;
       float w = 1.0f;
-      const unsigned go = (unsigned)(c * W + gxr) * 4u;
+      const unsigned go = (unsigned)(prow(min(max(c, 0), H - 1)) * W + gxr) * 4u;
       if (AUTOMASK) {
         float idn = ld_ident;
         if (has_noise) idn += ld_noise * 0.00001f;
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
           float ray[3], ik[9], X[3];
           f2 P[12];
           load_cam(cam_b, P, ik);
-          ray_of(ik, (float)gxr, (float)q, ray);
+          ray_of(ik, (float)gxr, (float)prow(q), ray);
           X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
           const f2 c0 = P[0] * bc(ray[0]) + P[1] * bc(ray[1]) + P[2] * bc(ray[2]);
           const f2 c1 = P[4] * bc(ray[0]) + P[5] * bc(ray[1]) + P[6] * bc(ray[2]);
@@ -682,7 +691,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
           const f2 ts = (t0 + t1) + t2;
           gdisp = ts.x + ts.y;
         }
-        if (out_x) stf(p.g_reproj + map_b, (unsigned)(q * W + gxr) * 4u, gdisp);
+        if (out_x) stf(p.g_reproj + map_b, (unsigned)(prow(q) * W + gxr) * 4u, gdisp);
       }
       // roll the partial-plane sums: (row c: top+mid) <- (row c: top) + hc(c) ; (row c+1: top) <- hc(c)
       {
@@ -700,7 +709,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     if (p.depth_out) {
       const int q = r - 1;
       if (q >= y_lo && q < y_hi && out_x)
-        stf(p.depth_out + map_b, (unsigned)(q * W + gxr) * 4u, depth_of(ldf(disp_b, (unsigned)(q * W + gxr) * 4u), wc.min_disp, wc.range));
+        stf(p.depth_out + map_b, (unsigned)(prow(q) * W + gxr) * 4u, depth_of(ldf(disp_b, (unsigned)(prow(q) * W + gxr) * 4u), wc.min_disp, wc.range));
     }
 
     // ================= roll the row state =====================================================
@@ -859,6 +868,7 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
 }
 
 int g_pass_impl = 1;   // 1 = marching (this file, fastest); 0 = LDS-tiled v1 (mal_pass.hip); 2 = LDS-tiled, 512 threads (mal_tile2.hip)
+int g_march_flip = 1;  // odd segments bottom-up (mal_set_option("march_flip", 0|1))
 int g_march_rows = 0;  // output rows per wave task; 0 = pick so that one round of tasks fills the chip
 int g_debug = 0;
 extern int g_photo_impl;  // mal_photo_march.hip
@@ -897,6 +907,7 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   p.segs = (p.H + rows - 1) / rows;
   p.ntasks = p.B * p.strips * p.segs;
   p.debug = g_debug;
+  p.flip_odd = g_march_flip;
   p.packed = ((flags & MAL_F_SRC_PACKED) ? 1 : 0) | ((flags & MAL_F_TGT_PACKED) ? 2 : 0);
   p.per_xcd = (p.ntasks + 7) / 8;
   dim3 grid(p.per_xcd * 8), block(64);
@@ -951,6 +962,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("pass_impl")) { if (value < 0 || value > 2) return MAL_EINVAL; g_pass_impl = value; return MAL_OK; }
   if (eq("debug")) { g_debug = value; return MAL_OK; }
   if (eq("photo_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_photo_impl = value; return MAL_OK; }
+  if (eq("march_flip")) { g_march_flip = value != 0; return MAL_OK; }
   if (eq("march_rows")) { if (value < 0 || value > 4096) return MAL_EINVAL; g_march_rows = value; return MAL_OK; }
   return MAL_EINVAL;
 }
