@@ -55,7 +55,7 @@ enum {
   MAL_F_AVG = 16,       /* --avg_reprojection (dualrefine/trainer.py:579-583): mean over candidates */
   MAL_F_EPILOGUE = 32,  /* student epilogue: consistency + distillation terms (loss_utils.py:193-254) */
   MAL_F_DUAL_DISTIL = 64,/* --dual_distil (loss_utils.py:232-234): the idx==0 target keeps its graph */
-  MAL_F_SRC_PACKED = 128,/* mal_pass_fused: src[f] are (B,H,W,4) texel copies made by mal_pack_nhwc4 */
+  MAL_F_SRC_PACKED = 128,/* mal_pass_fused: src[f] are texel copies made by mal_pack_texels */
   MAL_F_TGT_PACKED = 256 /* ... and so is target */
 };
 
@@ -186,9 +186,11 @@ int mal_distil_epilogue(const float* multi_depth, const float* mono_depth, const
                         float* g_multi_distil, float* g_mono_distil, float* consistency_target,
                         void* ws, size_t ws_bytes, void* stream);
 
-/* (B,3,H,W) -> (B,H,W,4) texels (4th component 0): each bilinear tap of the fused pass becomes one
- * 16-byte gather instead of three 4-byte ones.  Sources change per batch, not per pass: pack once. */
-int mal_pack_nhwc4(const float* src, int B, int H, int W, float* dst, void* stream);
+/* (B,3,H,W) -> (B,H,W,n) texels, n = mal_texel_floats() (3: r,g,b 12 bytes apart): each bilinear tap of the fused
+ * pass becomes one per-lane gather instead of three 4-byte ones.  Sources change per batch, not per pass: pack once.
+ * dst holds B*H*W*n floats. */
+int mal_texel_floats(void);
+int mal_pack_texels(const float* src, int B, int H, int W, float* dst, void* stream);
 
 /* ---- a13: Trainer.compute_matching_mask, manydepth/trainer.py:1066-1076 ----------------
  * out = consistency_mask * [ (1/lowest_cost - mono)/mono < 1 ] * [ (mono - 1/lowest_cost)*lowest_cost < 1 ] */

@@ -58,7 +58,7 @@ MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, 
 // (bracketed by the one-shot profile events if armed).  Partials go to p.block_sums / p.block_gP.
 int march_launch(MarchParams& p, int flags, hipStream_t st);
 // min_f r(src_f, target) of the RAW sources -> ident (B,1,H,W) (the identity term of
-// manydepth/loss_utils.py:92-101), and in the same sweep the two planar sources repacked as (B,H,W,4) texels
+// manydepth/loss_utils.py:92-101), and in the same sweep the two planar sources repacked as (B,H,W,kTexel) texels
 // (packed0/1 nullable together), optionally the target too.  With `poses` (the whole-step launch list) B extra
 // workgroups of the same launch compose the poses of both frames (layers.py:26-100), fill the camera block of
 // the marching passes and reset the completion counter of the step's last kernel.

@@ -17,7 +17,7 @@
 //     six colour values of a pixel (2 candidates x 3 channels) live as three register PAIRS and the
 //     arithmetic on them is packed fp32 (v_pk_fma/mul/add_f32: two values per lane per issue):
 //         pair 0 = (r, g) of candidate 0,  pair 1 = (r, g) of candidate 1,  pair 2 = (b0, b1)
-//     (r, g) is how a 16-byte texel arrives from the gather, so no shuffles are needed; everything
+//     (r, g) is how a texel arrives from the gather, so no shuffles are needed; everything
 //     per candidate (projection, tap weights, pose terms) is a pair over the two candidates.
 // The SSIM is evaluated on window SUMS (numerator and denominator scaled by 81^2) so no
 // division by 9 is needed; with the separable association this differs from ATen's row-major
@@ -121,7 +121,7 @@ MAL_DEV Sample2 project2(const f2 (&P)[12], const float (&X)[3], float eps, int 
 // The warp of one pixel (both frames) in two halves, so that work that does not need the gathered
 // texels can be placed between the gather instructions and their first use.
 struct PendingWarp {
-  f4 t[2][4];                  // the four taps of both frames: (r, g, b, -)
+  texel_t t[2][4];             // the four taps of both frames: (r, g, b[, -])
   f2 nw, ne, sw, se;           // tap weights, pairs over the two frames
   f2 ex, ey, tx, ty;           // DERIV
   f2 mx, my, du_ddisp, dv_ddisp;
@@ -156,9 +156,9 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
   for (int f = 0; f < 2; ++f) {
     const int (&o)[4] = oo[f];
     if (p.packed & 1) {
-      const float* sp = p.src[f] + (size_t)b * HW * 4;
+      const float* sp = p.src[f] + (size_t)b * HW * kTexel;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) w.t[f][k] = ldf4(sp, (unsigned)o[k] * 16u);
+      for (int k = 0; k < 4; ++k) w.t[f][k] = ldt(sp, (unsigned)o[k] * (unsigned)(kTexel * 4));
     } else {
       const float* p0 = p.src[f] + (size_t)b * 3 * HW;
       const float* p1 = p0 + HW;
@@ -166,7 +166,7 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const unsigned bo = (unsigned)o[k] * 4u;
-        w.t[f][k] = (f4){ldf(p0, bo), ldf(p1, bo), ldf(p2, bo), 0.f};
+        w.t[f][k] = make_texel(ldf(p0, bo), ldf(p1, bo), ldf(p2, bo));
       }
     }
   }
@@ -192,8 +192,8 @@ MAL_DEV void warp_finish(PendingWarp& pw, f2 (&x)[3], DerivRow& d) {
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm("" : "+v"(pw.t[f][k]));  // whole 16-byte texels: one gather each, not 8+4 bytes
-    const f4 A = pw.t[f][0], Bv = pw.t[f][1], C = pw.t[f][2], D = pw.t[f][3];
+    for (int k = 0; k < 4; ++k) asm("" : "+v"(pw.t[f][k]));  // whole texels: one gather each, not 8+4 bytes
+    const texel_t A = pw.t[f][0], Bv = pw.t[f][1], C = pw.t[f][2], D = pw.t[f][3];
     const f2 a = (f2){A.x, A.y}, bb = (f2){Bv.x, Bv.y}, c = (f2){C.x, C.y}, dd = (f2){D.x, D.y};
     const float nw_ = pw.nw[f], ne_ = pw.ne[f], sw_ = pw.sw[f], se_ = pw.se[f];
     // blend (mal_device.h): nw*a, then fma for ne, sw, se
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       const float v = ldf(disp2_b ? disp2_b : disp_b, pix * 4u);
       a.disp2 = disp2_b ? v : 0.f;
     }
-    load_rgb(pp.target, packed_t, b, HW, pix, a.y);  // one 16-byte texel (packed) or three planes
+    load_rgb(pp.target, packed_t, b, HW, pix, a.y);  // one texel (packed) or three planes
     const unsigned oc = (unsigned)(prow(min(max(rr - 1, 0), H - 1)) * W + gxr) * 4u;  // statistics row c = rr-1
     auto opt = [&](const float* m, unsigned off, float absent) {
       const float v = ldf(m ? m + map_b : disp_b, off);
@@ -756,12 +756,12 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
 
 // ---- identity term + texel packing: min over the two raw sources of r(src_f, target)
 // (manydepth/loss_utils.py:92-101, forward only) in the same sweep that turns the two planar (B,3,H,W)
-// sources into the 16-byte texels (B,H,W,4) the warp gathers from.  Same marching structure and the same
+// sources into the texels (B,H,W,kTexel) the warp gathers from.  Same marching structure and the same
 // colour pairs as march_kernel: x[0] = (r,g) of source 0, x[1] = (r,g) of source 1, x[2] = (b0, b1).
 struct IdentParams {
   const float* target; const float* src[2];   // planar (B,3,H,W)
-  float* packed[2];                           // the sources as (B,H,W,4) out, nullable
-  float* packed_target;                       // the target as (B,H,W,4) out, nullable
+  float* packed[2];                           // the sources as (B,H,W,kTexel) out, nullable
+  float* packed_target;                       // the target as (B,H,W,kTexel) out, nullable
   float* ident;                               // (B,1,H,W) out
   int B, H, W, strips, segs, rows, ntasks, per_xcd;
   int pose_blocks; StepPoses sp;              // the last pose_blocks workgroups: poses + camera block of sample b
@@ -817,11 +817,11 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
     const Px cur = nxt;
     request(r + 1, nxt);
     if (r >= y_lo && r < y_hi && out_x && p.packed[0]) {  // an image row owned by this task: emit its texels
-      const unsigned bo = (unsigned)(r * W + gxr) * 16u;
-      *reinterpret_cast<f4*>(reinterpret_cast<char*>(p.packed[0] + (size_t)b * HW * 4) + bo) = (f4){cur.a[0], cur.a[1], cur.a[2], 0.f};
-      *reinterpret_cast<f4*>(reinterpret_cast<char*>(p.packed[1] + (size_t)b * HW * 4) + bo) = (f4){cur.c[0], cur.c[1], cur.c[2], 0.f};
+      const size_t bo = (size_t)(r * W + gxr);
+      st_texel(p.packed[0] + (size_t)b * HW * kTexel, bo, make_texel(cur.a[0], cur.a[1], cur.a[2]));
+      st_texel(p.packed[1] + (size_t)b * HW * kTexel, bo, make_texel(cur.c[0], cur.c[1], cur.c[2]));
       if (p.packed_target)
-        *reinterpret_cast<f4*>(reinterpret_cast<char*>(p.packed_target + (size_t)b * HW * 4) + bo) = (f4){cur.t[0], cur.t[1], cur.t[2], 0.f};
+        st_texel(p.packed_target + (size_t)b * HW * kTexel, bo, make_texel(cur.t[0], cur.t[1], cur.t[2]));
     }
     const f2 x0[3] = {(f2){cur.a[0], cur.a[1]}, (f2){cur.c[0], cur.c[1]}, (f2){cur.a[2], cur.c[2]}};
     const f2 y0rg = (f2){cur.t[0], cur.t[1]};

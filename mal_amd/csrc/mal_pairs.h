@@ -54,11 +54,14 @@ MAL_DEV float ldf(const float* base, unsigned boff) {
 MAL_DEV f4 ldf4(const float* base, unsigned boff) {
   return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(base) + boff);
 }
+MAL_DEV texel_t ldt(const float* base, unsigned boff) {
+  return *reinterpret_cast<const texel_t*>(reinterpret_cast<const char*>(base) + boff);
+}
 MAL_DEV void stf(float* base, unsigned boff, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v; }
-// the three colour channels of pixel `pix` of sample b: planar (B,3,H,W) or packed (B,H,W,4)
+// the three colour channels of pixel `pix` of sample b: planar (B,3,H,W) or packed (B,H,W,kTexel)
 MAL_DEV void load_rgb(const float* img, int packed, int b, int HW, unsigned pix, float* out) {
   if (packed) {
-    const f4 v = ldf4(img + (size_t)b * HW * 4, pix * 16u);
+    const texel_t v = ldt(img + (size_t)b * HW * kTexel, pix * (unsigned)(kTexel * 4));
     out[0] = v.x; out[1] = v.y; out[2] = v.z;
   } else {
     const float* pl = img + (size_t)b * 3 * HW;

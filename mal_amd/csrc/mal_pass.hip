@@ -48,7 +48,7 @@ struct PassParams {
   float* min_reproj; float* g_reproj; float* g_cons; float* g_distil; float* cons_target; float* depth_out;
   double* block_sums; float* block_gP;
   int tiles_x, tiles_y, nblocks, per_xcd;
-  int packed;  // src[f] are (B,H,W,4) copies made by mal_pack_nhwc4 (MAL_F_SRC_PACKED)
+  int packed;  // src[f] are (B,H,W,kTexel) copies made by mal_pack_texels (MAL_F_SRC_PACKED)
 };
 
 struct Own {          // what a tile pixel's owner keeps from phase 1 for the chain rule

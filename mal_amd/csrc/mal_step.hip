@@ -5,7 +5,7 @@
 // reductions, pose composition, and the same again in autograd's backward); the operator-level
 // API of this library still needs ~60 launches plus Python glue between them.  Here:
 //
-//   forward  1 identity term min_f r(src_f, target) (loss_utils.py:92-101) + packing of the images into 16-byte
+//   forward  1 identity term min_f r(src_f, target) (loss_utils.py:92-101) + packing of the images into 12-byte
 //              texels; B extra workgroups: poses of both frames (layers.py:26-100) + camera block P = K T
 //            1 teacher pass  (warp+SSIM+L1+min+automask+smoothness, fwd+bwd to disp and poses)   :573-581
 //            1 ensemble pass ((disp_t+disp_s)/2 formed in the kernel, no grad)                   :594-600
@@ -24,7 +24,7 @@ namespace mal {
 constexpr int kLossSlots = 16;
 
 struct StepWs {
-  float* packed[3];   // target, src-1, src+1 as (B,H,W,4) texels
+  float* packed[3];   // target, src-1, src+1 as (B,H,W,kTexel) texels
   float* T[2]; float* gT[2]; float* gTs[2];
   float* ident; float* mono_reproj; float* ens_reproj; float* multi_reproj;
   float* G_r_t; float* G_r_s; float* G_c; float* G_d; float* gn_t; float* gn_s;
@@ -43,7 +43,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   size_t o = 0;
   const size_t HW = (size_t)H * W, map = align256(B * HW * sizeof(float)), nb = ws_blocks(B, H, W);
   auto take = [&](size_t bytes) { char* r = p + o; o += align256(bytes); return r; };
-  for (int i = 0; i < 3; ++i) w.packed[i] = (float*)take(B * HW * 4 * sizeof(float));
+  for (int i = 0; i < 3; ++i) w.packed[i] = (float*)take(B * HW * kTexel * sizeof(float));
   for (int f = 0; f < 2; ++f) { w.T[f] = (float*)take(B * 16 * 4); w.gT[f] = (float*)take(B * 16 * 4); w.gTs[f] = (float*)take(B * 16 * 4); }
   float** maps[] = {&w.ident, &w.mono_reproj, &w.ens_reproj, &w.multi_reproj, &w.G_r_t, &w.G_r_s, &w.G_c, &w.G_d,
                     &w.gn_t, &w.gn_s};
@@ -230,7 +230,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   float* ens_reproj = no_ens ? nullptr : (a->ens_reproj ? a->ens_reproj : w.ens_reproj);
   float* multi_reproj = a->multi_reproj ? a->multi_reproj : w.multi_reproj;
 
-  // 1. identity term + texel packing of the three images (one 16-byte load per pixel in the passes); B extra
+  // 1. identity term + texel packing of the three images (one texel load per pixel in the passes); B extra
   //    workgroups of the same launch: poses (frame -1 is inverted, networks/repdepth.py:159-160) + camera block
   {
     StepPoses sp = {};

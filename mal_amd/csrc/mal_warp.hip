@@ -373,13 +373,13 @@ __global__ void matching_mask_kernel(const float* lowest_cost, const float* mono
   }
 }
 
-// (B,3,H,W) -> (B,H,W,4): one 16-byte texel per pixel (4th component 0)
-__global__ void pack_nhwc4_kernel(const float* src, int B, int HW, float4* dst) {
+// (B,3,H,W) -> (B,H,W,kTexel): one texel (r, g, b) per pixel
+__global__ void pack_texels_kernel(const float* src, int B, int HW, float* dst) {
   const size_t n = (size_t)B * HW;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t b = i / HW, pix = i - b * HW;
     const float* s = src + b * 3 * HW + pix;
-    dst[i] = make_float4(s[0], s[HW], s[2 * (size_t)HW], 0.f);
+    st_texel(dst, i, make_texel(s[0], s[HW], s[2 * (size_t)HW]));
   }
 }
 
@@ -546,12 +546,14 @@ extern "C" int mal_grid_sample_bwd(const float* src, const float* grid, const fl
   return launch_status();
 }
 
-extern "C" int mal_pack_nhwc4(const float* src, int B, int H, int W, float* dst, void* stream) {
+extern "C" int mal_texel_floats(void) { return kTexel; }
+
+extern "C" int mal_pack_texels(const float* src, int B, int H, int W, float* dst, void* stream) {
   int rc = check_shape(B, H, W);
   if (rc) return rc;
   if (!src || !dst) return MAL_EINVAL;
-  hipLaunchKernelGGL(pack_nhwc4_kernel, dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, src, B,
-                     H * W, reinterpret_cast<float4*>(dst));
+  hipLaunchKernelGGL(pack_texels_kernel, dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, src, B,
+                     H * W, dst);
   return launch_status();
 }
 

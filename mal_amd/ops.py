@@ -281,11 +281,11 @@ def photo_bwd(target, cands, argmin, weight, scale, sums, flags, need):
 
 # ------------------------------------------------------------------ texel packing of the sources
 _PACKED = {}
-pack_sources = True  # fused pass gathers 16-byte texels from (B,H,W,4) copies of the sources
+pack_sources = True  # fused pass gathers whole texels from (B,H,W,n) copies of the sources (n = mal_texel_floats())
 
 
 def packed_source(src):
-    """(B,3,H,W) -> (B,H,W,4) copy, cached per live tensor object and version: the sources of a
+    """(B,3,H,W) -> (B,H,W,n) texel copy, cached per live tensor object and version: the sources of a
     batch are shared by the teacher, ensemble and student passes (manydepth/trainer.py:573-612)."""
     key = (id(src), _stream())
     hit = _PACKED.get(key)
@@ -295,8 +295,8 @@ def packed_source(src):
         _PACKED.clear()
     src_c = _req(src, "image")
     B, _, H, W = src_c.shape
-    dst = torch.empty(B, H, W, 4, dtype=torch.float32, device=src_c.device)
-    L.check(L.load().mal_pack_nhwc4(_p(src_c), B, H, W, _p(dst), _stream()), "mal_pack_nhwc4")
+    dst = torch.empty(B, H, W, L.load().mal_texel_floats(), dtype=torch.float32, device=src_c.device)
+    L.check(L.load().mal_pack_texels(_p(src_c), B, H, W, _p(dst), _stream()), "mal_pack_texels")
     _PACKED[key] = (weakref.ref(src), src._version, dst)
     return dst
 
