@@ -122,29 +122,45 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
   __syncthreads();
   if (s_last != gridDim.x - 1) return;
   __threadfence();
-  const volatile double* vps = ps;
-  // sums over samples, fixed order; slots 4, 5 (smoothness) are weighted by the sample's 1/(mean+1e-7)
-  if (tid < 16) {
-    const int pass = tid >> 3, j = tid & 7;
-    double a = 0.0;
-    for (int b = 0; b < B; ++b) {
-      const volatile double* q = vps + ((size_t)pass * B + b) * 8;
-      double v = q[j];
-      if (j == 4 || j == 5) {
-        const float m = (float)(q[7] / (double)HW) + 1e-7f;
-        v = v * (double)div_(1.0f, m);
-      }
-      a += v;
+  // sums over samples, fixed order; slots 4, 5 (smoothness) are weighted by the sample's 1/(mean+1e-7).  One
+  // thread per (pass, sample, slot) fetches and weighs its term (a single round trip for all of them), 16 threads
+  // then add the B terms in sample order.
+  constexpr int kMaxStepB = 64;  // beyond this the terms are re-fetched by the summing threads instead of staged in LDS
+  __shared__ double s_term[2 * kMaxStepB * 8];
+  const bool staged = B <= kMaxStepB;
+  for (int i = tid; staged && i < 2 * B * 8; i += 256) {
+    const int j = i & 7;
+    const double* q = ps + (size_t)(i >> 3) * 8;
+    double v = q[j];
+    if (j == 4 || j == 5) {
+      const float m = (float)(q[7] / (double)HW) + 1e-7f;
+      v = v * (double)div_(1.0f, m);
     }
-    sh_tot[pass][j] = a;
+    s_term[i] = v;
   }
   // per-sample statistics of the smoothness gradient: mean and the mean-coupling term dot/(HW (mean+eps)^2)
   for (int s = tid; s < 2 * B; s += 256) {
-    const volatile double* q = vps + (size_t)s * 8;
+    const double* q = ps + (size_t)s * 8;
     const double mean = q[7] / (double)HW;
     const double m = (double)((float)mean + 1e-7f);
     stats[s] = mean;
     stats[2 * B + s] = q[6] / ((double)HW * m * m);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int pass = tid >> 3, j = tid & 7;
+    double a = 0.0;
+    for (int b = 0; b < B; ++b) {
+      double v;
+      if (staged) v = s_term[((size_t)pass * B + b) * 8 + j];
+      else {
+        const double* q = ps + ((size_t)pass * B + b) * 8;
+        v = q[j];
+        if (j == 4 || j == 5) v = v * (double)div_(1.0f, (float)(q[7] / (double)HW) + 1e-7f);
+      }
+      a += v;
+    }
+    sh_tot[pass][j] = a;
   }
   __syncthreads();
   if (tid != 0) return;
