@@ -20,6 +20,9 @@ struct MarchParams {
   // sum disp -- the 1/(mean+1e-7) of the mean normalisation is applied per sample afterwards
   // (layers.py:210-223, loss_utils.py:119-121)
   float* smooth_gn;
+  // whole-step list: with g_distil == nullptr the two epilogue gradients leave as ONE map,
+  // merge_cons * d cons + merge_distil * d distil (their loss weights do not depend on the data)
+  float merge_cons, merge_distil;
   // per-sample camera block [B][40]: P_f = (K T_f)[:3,:], inv_K[:3,:3]; march_launch fills it unless cam_ready
   float* cam; int cam_ready;
   int sample_scale_is_mask;  // sample_scale holds the augmentation mask: the scale is 1 - mask

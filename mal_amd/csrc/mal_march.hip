@@ -504,8 +504,14 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
         acc_dist += fabsf(dd) * mm;
         if (p.cons_target) stf(p.cons_target + map_b, go, div_(1.0f, dmono * cm + dm * (1.0f - cm)));
         if (GRAD) {
-          stf(p.g_cons + map_b, go, sgnf(dc) * cm * ddepth);
-          stf(p.g_distil + map_b, go, sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : -0.5f)) * mm * ddepth);
+          const float gc = sgnf(dc) * cm * ddepth;
+          const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : -0.5f)) * mm * ddepth;
+          if (p.g_distil) {
+            stf(p.g_cons + map_b, go, gc);
+            stf(p.g_distil + map_b, go, gd);
+          } else {
+            stf(p.g_cons + map_b, go, fma_(p.merge_cons, gc, p.merge_distil * gd));
+          }
         }
       }
     };

@@ -27,7 +27,7 @@ struct StepWs {
   float* packed[3];   // target, src-1, src+1 as (B,H,W,kTexel) texels
   float* T[2]; float* gT[2]; float* gTs[2];
   float* ident; float* mono_reproj; float* ens_reproj; float* multi_reproj;
-  float* G_r_t; float* G_r_s; float* G_c; float* G_d; float* gn_t; float* gn_s;
+  float* G_r_t; float* G_r_s; float* G_c; float* gn_t; float* gn_s;
   double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
   double* ps;         // per-sample sums of the teacher's, then the student's partials: [2][B][8]
   unsigned* ticket;   // completion counter of step_final_kernel
@@ -45,7 +45,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   auto take = [&](size_t bytes) { char* r = p + o; o += align256(bytes); return r; };
   for (int i = 0; i < 3; ++i) w.packed[i] = (float*)take(B * HW * kTexel * sizeof(float));
   for (int f = 0; f < 2; ++f) { w.T[f] = (float*)take(B * 16 * 4); w.gT[f] = (float*)take(B * 16 * 4); w.gTs[f] = (float*)take(B * 16 * 4); }
-  float** maps[] = {&w.ident, &w.mono_reproj, &w.ens_reproj, &w.multi_reproj, &w.G_r_t, &w.G_r_s, &w.G_c, &w.G_d,
+  float** maps[] = {&w.ident, &w.mono_reproj, &w.ens_reproj, &w.multi_reproj, &w.G_r_t, &w.G_r_s, &w.G_c,
                     &w.gn_t, &w.gn_s};
   for (auto m : maps) *m = (float*)take(map);
   w.bs_t = (double*)take(nb * 8 * 8); w.bs_s = (double*)take(nb * 8 * 8); w.bs_e = (double*)take(nb * 8 * 8);
@@ -190,14 +190,14 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
 
 // d total / d disp for both maps; block 0 also scales the pose gradients and runs the backward of
 // transformation_from_parameters (pp.gT = the scaled gradients, pp.g_axisangle / g_translation nullable)
-__global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, const float* G_r_s, const float* G_c,
-                                                            const float* G_d, const float* gn_t, const float* gn_s,
+__global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, const float* G_r_s, const float* G_cd,
+                                                            const float* gn_t, const float* gn_s,
                                                             const float* coefs, const double* stats, const float* g_total,
                                                             int B, int HW, const float* gT0, const float* gT1,
                                                             float* gTs0, float* gTs1, float* g_disp_t, float* g_disp_s,
                                                             PoseParams pp, int pose_bwd) {
   const float g = g_total ? *g_total : 1.0f;
-  const float cRt = coefs[0] * g, cRs = coefs[1] * g, cC = coefs[2] * g, cD = coefs[3] * g, cS = coefs[4] * g;
+  const float cRt = coefs[0] * g, cRs = coefs[1] * g, cS = coefs[4] * g;  // coefs[2], [3] are already inside G_cd
   const size_t n = (size_t)B * HW;
   if (blockIdx.x == 0) {
     for (int i = threadIdx.x; i < B * 16; i += 256) { gTs0[i] = gT0[i] * cRt; gTs1[i] = gT1[i] * cRt; }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
     const float inv_t = div_(1.0f, (float)stats[b] + 1e-7f), inv_s = div_(1.0f, (float)stats[B + b] + 1e-7f);
     const float corr_t = (float)stats[2 * B + b], corr_s = (float)stats[3 * B + b];
     if (g_disp_t) g_disp_t[i] = fma_(cRt, G_r_t[i], cS * (gn_t[i] * inv_t - corr_t));
-    if (g_disp_s) g_disp_s[i] = fma_(cRs, G_r_s[i], fma_(cC, G_c[i], fma_(cD, G_d[i], cS * (gn_s[i] * inv_s - corr_s))));
+    if (g_disp_s) g_disp_s[i] = fma_(cRs, G_r_s[i], fma_(g, G_cd[i], cS * (gn_s[i] * inv_s - corr_s)));
   }
 }
 
@@ -296,7 +296,9 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.sample_scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0;
     p.mono_disp = a->disp_teacher; p.lowest_cost = a->lowest_cost; p.cmask_out = a->consistency_mask_out;
     p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj;
-    p.min_reproj = multi_reproj; p.g_reproj = w.G_r_s; p.g_cons = w.G_c; p.g_distil = w.G_d;
+    p.min_reproj = multi_reproj; p.g_reproj = w.G_r_s;
+    p.g_cons = w.G_c; p.g_distil = nullptr;  // one merged map: weights as coefs[2], coefs[3] of step_final_kernel
+    p.merge_cons = (float)((double)a->w_main / ((double)B * H * W)); p.merge_distil = (float)((double)a->w_distil / ((double)B * H * W));
     p.block_sums = w.bs_s; p.block_gP = w.bgP;
     p.smooth_gn = w.gn_s;
     p.cam = w.cam; p.cam_ready = cam_ready;
@@ -327,7 +329,7 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   pp.g_axisangle[0] = a->g_axisangle_m1; pp.g_axisangle[1] = a->g_axisangle_p1;
   pp.g_translation[0] = a->g_translation_m1; pp.g_translation[1] = a->g_translation_p1;
   const int pose_bwd = (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) ? 1 : 0;
-  hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.G_d, w.gn_t,
+  hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.gn_t,
                      w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
                      a->g_disp_teacher, a->g_disp_student, pp, pose_bwd);
   rc = launch_status();
