@@ -26,7 +26,7 @@ constexpr int kLossSlots = 16;
 struct StepWs {
   float* packed[3];   // target, src-1, src+1 as (B,H,W,kTexel) texels
   float* T[2]; float* gT[2]; float* gTs[2];
-  float* ident; float* mono_reproj; float* ens_reproj; float* multi_reproj;
+  float* ident; float* mono_reproj; float* ens_reproj;
   float* G_r_t; float* G_r_s; float* G_c; float* gn_t; float* gn_s;
   double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
   double* ps;         // per-sample sums of the teacher's, then the student's partials: [2][B][8]
@@ -45,7 +45,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   auto take = [&](size_t bytes) { char* r = p + o; o += align256(bytes); return r; };
   for (int i = 0; i < 3; ++i) w.packed[i] = (float*)take(B * HW * kTexel * sizeof(float));
   for (int f = 0; f < 2; ++f) { w.T[f] = (float*)take(B * 16 * 4); w.gT[f] = (float*)take(B * 16 * 4); w.gTs[f] = (float*)take(B * 16 * 4); }
-  float** maps[] = {&w.ident, &w.mono_reproj, &w.ens_reproj, &w.multi_reproj, &w.G_r_t, &w.G_r_s, &w.G_c,
+  float** maps[] = {&w.ident, &w.mono_reproj, &w.ens_reproj, &w.G_r_t, &w.G_r_s, &w.G_c,
                     &w.gn_t, &w.gn_s};
   for (auto m : maps) *m = (float*)take(map);
   w.bs_t = (double*)take(nb * 8 * 8); w.bs_s = (double*)take(nb * 8 * 8); w.bs_e = (double*)take(nb * 8 * 8);
@@ -244,7 +244,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   const bool no_ens = a->flags & MAL_STEP_NO_ENS;
   float* mono_reproj = a->mono_reproj ? a->mono_reproj : w.mono_reproj;
   float* ens_reproj = no_ens ? nullptr : (a->ens_reproj ? a->ens_reproj : w.ens_reproj);
-  float* multi_reproj = a->multi_reproj ? a->multi_reproj : w.multi_reproj;
+  float* multi_reproj = a->multi_reproj;  // only written when the caller wants the map
 
   // 1. identity term + texel packing of the three images (one texel load per pixel in the passes); B extra
   //    workgroups of the same launch: poses (frame -1 is inverted, networks/repdepth.py:159-160) + camera block
