@@ -169,9 +169,17 @@ def cpu_baseline(batch, steps):
     for _ in range(steps):
         one()
     dt = time.perf_counter() - t0
-    return {"value": B * steps / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "%d steps of the same B=12 192x640 loss step (passes A+B+C fwd+bwd) after 1 warm-up, "
-                      "torch CPU threads=%d" % (steps, threads), "ms_per_step": 1e3 * dt / steps}
+    out = {"value": B * steps / dt, "unit": "images/s", "cores": threads, "kind": "port",
+           "sample": "%d steps of the same B=12 192x640 loss step (passes A+B+C fwd+bwd) after 1 warm-up, "
+                     "torch CPU threads=%d" % (steps, threads), "ms_per_step": 1e3 * dt / steps}
+    # what the reference's OMP_NUM_THREADS=1 (manydepth/trainer.py:8-10) would give: one thread, one step
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    one()
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(threads)
+    out["single_thread"] = {"value": B / dt1, "unit": "images/s", "cores": 1, "sample": "1 step, no warm-up", "ms_per_step": 1e3 * dt1}
+    return out
 
 
 def main():
