@@ -157,7 +157,11 @@ def cpu_baseline(batch, steps):
     from mal_amd.synthetic import to_dicts
     from oracle import mal_oracle as O
     opt = O.default_opt(height=H, width=W, batch_size=B)
-    threads = torch.get_num_threads()
+    # a one-GPU box's CPU share is 16 cores: more torch threads than that oversubscribe it (128 threads measured no
+    # faster than 1)
+    all_threads = torch.get_num_threads()
+    threads = min(all_threads, 16)
+    torch.set_num_threads(threads)
 
     def one():
         inputs, mono_outputs, outputs, leaves = to_dicts(batch, O.transformation_from_parameters)
@@ -177,7 +181,7 @@ def cpu_baseline(batch, steps):
     t0 = time.perf_counter()
     one()
     dt1 = time.perf_counter() - t0
-    torch.set_num_threads(threads)
+    torch.set_num_threads(all_threads)
     out["single_thread"] = {"value": B / dt1, "unit": "images/s", "cores": 1, "sample": "1 step, no warm-up", "ms_per_step": 1e3 * dt1}
     return out
 
