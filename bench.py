@@ -95,7 +95,7 @@ class Step:
         self.layers = layers
         from mal_amd import ops
         self.ops = ops
-        b = make_batch(B, H, W, seed=seed, with_syn=(mode == "temporal"))
+        b = make_batch(B, H, W, seed=seed)
         mv = lambda t: t.to(dev).contiguous()
         self.inputs = {("color", 0, 0): mv(b["color0"]), ("color", -1, 0): mv(b["color_m1"]),
                        ("color", 1, 0): mv(b["color_p1"]), ("K", 0): mv(b["K"]), ("inv_K", 0): mv(b["inv_K"])}
@@ -103,10 +103,15 @@ class Step:
                        ("disp_teacher", "disp_student", "axisangle_m1", "translation_m1", "axisangle_p1",
                         "translation_p1")}
         self.cmask, self.aug, self.lowest = mv(b["consistency_mask"]), mv(b["augmentation_mask"]), mv(b["lowest_cost"])
-        if mode == "temporal":  # --temporal --distil: the producer (Mask2Former + patch shifts) is stood in for
-            from mal_amd.synthetic import fake_image_synthesis
+        if mode == "temporal":
+            # --temporal --distil: dyn_utils.image_synthesis itself (N2: the patch shifts in HIP) with stand-ins for its
+            # two external models, three matched instances per sample
+            from mal_amd import dyn_utils
+            from mal_amd.synthetic import instance_stub
+            ins_model, matcher = instance_stub(B, H, W, n_inst=3, seed=seed, device=dev)
+            synth = lambda inputs, outputs, scale: dyn_utils.image_synthesis(inputs, outputs, scale, 0.5, ins_model, matcher)
             self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, temporal=True), fuse=True,
-                                       image_synthesis=fake_image_synthesis(b["syn_rects"]))
+                                       image_synthesis=synth)
         else:
             self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B), fuse=True)
         self.batch_cpu = b

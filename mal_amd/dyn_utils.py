@@ -27,8 +27,10 @@ class DynamicInstanceFn(Function):
         if il.shape != (C, H, W) or inx.shape != (C, H, W):
             raise L.MalError("generate_dynamic_instance: images must be (C,H,W) matching the masks")
         dev = il.device
-        ml = mask_last.to(device=dev, dtype=torch.uint8).contiguous()
-        mn = mask_next.to(device=dev, dtype=torch.uint8).contiguous()
+        # bool masks are one byte per element already: reinterpret, do not convert
+        as_u8 = lambda m: (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8))
+        ml = as_u8(mask_last.to(dev).contiguous())
+        mn = as_u8(mask_next.to(dev).contiguous())
         ol, on = torch.empty_like(il), torch.empty_like(inx)
         delta = torch.empty(num, 2, dtype=torch.int32, device=dev)
         flags = torch.empty(H, W, dtype=torch.uint8, device=dev)

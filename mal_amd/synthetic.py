@@ -128,6 +128,60 @@ def fake_image_synthesis(rects):
     return synth
 
 
+class _Instances:
+    """the slice of detectron2's ``Instances`` that ``image_synthesis`` touches (scores, pred_masks, len, indexing)"""
+
+    def __init__(self, scores, masks):
+        self.scores, self.pred_masks = scores, masks
+
+    def __len__(self):
+        return len(self.scores)
+    def __getitem__(self, sel):
+        if torch.is_tensor(sel) and sel.dtype == torch.bool and not sel.is_cuda and bool(sel.all()):
+            return self  # every instance kept: no device-side selection (a step stays capturable in a HIP graph)
+        return _Instances(self.scores[sel], self.pred_masks[sel])
+
+
+def instance_stub(B, H, W, n_inst=3, seed=0, device="cpu"):
+    """Stand-ins for the two external models of the temporal-hint producer -- the Mask2Former segmenter and the
+    Hungarian matcher (manydepth/dyn_utils.py:172-190, matcher.py:89-173) -- so that ``dyn_utils.image_synthesis``
+    itself can be driven on synthetic data: every sample has ``n_inst`` confident instances (elliptic blobs) that
+    moved by a few pixels between the two warped frames and are all matched.  Returns ``(ins_model, matcher)``.
+    All tensors live on ``device`` already (nothing is copied from the host inside a step)."""
+    g = torch.Generator().manual_seed(int(seed))
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    masks = []
+    for b in range(B):
+        pair = [[], []]
+        for _ in range(n_inst):
+            cy = float(torch.randint(H // 5, max(4 * H // 5, H // 5 + 1), (1,), generator=g))
+            cx = float(torch.randint(W // 8, max(7 * W // 8, W // 8 + 1), (1,), generator=g))
+            ry = float(torch.randint(max(H // 16, 2), max(H // 6, 3), (1,), generator=g))
+            rx = float(torch.randint(max(W // 32, 2), max(W // 10, 3), (1,), generator=g))
+            sx = float(torch.randint(-8, 9, (1,), generator=g))
+            sy = float(torch.randint(-3, 4, (1,), generator=g))
+            for f, sgn in ((0, -0.5), (1, 0.5)):
+                pair[f].append((((yy - cy - sgn * sy) / ry) ** 2 + ((xx - cx - sgn * sx) / rx) ** 2) <= 1.0)
+        masks.append((torch.stack(pair[0]).to(device), torch.stack(pair[1]).to(device)))
+    scores = torch.full((n_inst,), 0.9)  # host side, as the thresholding of dyn_utils.py:133 is a host decision
+    empty = torch.zeros(n_inst, H, W, dtype=torch.bool, device=device)
+    every = torch.arange(n_inst, device=device)
+    state = {"b": 0}
+
+    def ins_model(images):
+        if images.shape[0] != 2:  # the target frames: only the scores are read (dyn_utils.py:131-133)
+            state["b"] = 0
+            return [{"instances": _Instances(scores, empty)} for _ in range(images.shape[0])]
+        b = state["b"] % B        # the (warped last, warped next) pair of the next sample, in batch order
+        state["b"] += 1
+        return [{"instances": _Instances(scores, masks[b][0])}, {"instances": _Instances(scores, masks[b][1])}]
+
+    def matcher(ins_last, ins_next, cur):
+        return every, every
+
+    return ins_model, matcher
+
+
 def to_dicts(batch, pose_fn, device=None, requires_grad=True):
     """Arrange a ``make_batch`` result into the reference's dict contract.
 
