@@ -233,6 +233,7 @@ def main():
 
     run = step
     graph = None
+    graph_note = None
     if args.graph:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -240,10 +241,16 @@ def main():
             for _ in range(3):
                 step()
         torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
-        run = graph.replay
+        try:
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: other threads of the process (the RCCL watchdog at N>1) may touch the runtime during capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                step()
+            run = graph.replay
+        except Exception as e:  # keep the measurement alive: eager launches (host-bound, slower), and say so
+            graph, run = None, step
+            graph_note = "graph capture failed (%s: %s); eager launches" % (type(e).__name__, str(e).splitlines()[0][:120])
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         run()
@@ -302,7 +309,7 @@ def main():
                                "passes, consistency+distillation+smoothness), fwd+bwd to disp/pose leaves; "
                                "networks not included", "global_batch": B * world, "height": H, "width": W,
                    "parallelism": "dp%d (replicas over disjoint batches, no data-path collective)" % world,
-                   "launch": "hip-graph" if graph is not None else "eager",
+                   "launch": "hip-graph" if graph is not None else (graph_note or "eager"),
                    "api": "mal_loss_step_fwd/_bwd (one host call per direction)" if args.mode == "step"
                           else "operator-level (mal_amd.loss_utils / MALLossPath)"},
         "roofline": {"bound": "hbm", "kernel": "mal::march_kernel<true,true,true,false> (teacher pass: warp+SSIM+L1+"
