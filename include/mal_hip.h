@@ -278,12 +278,14 @@ int mal_dyn_instance_bwd(const uint8_t* mask_last, const uint8_t* mask_next, int
 
 /* ---- N3: ManyDepth's cost volume as MAL's student encoder builds it (forward only; upstream runs it under
  * no_grad): manydepth/networks/resnet_encoder.py:152-233 match_features + :296-312 of the encoder's forward.
- * current_feats (B,h,w,C) and lookup_feats (B,F,h,w,C) CHANNEL-LAST, C = 64; poses (B,F,16) relative poses (an
+ * current_feats (B,C,h,w) and lookup_feats (B,F,C,h,w) planar as the encoder produces them, C = 64 (with option
+ * "costvol_impl" 0, the first formulation, both CHANNEL-LAST instead: mal_costvol_channel_last() says which); poses (B,F,16) relative poses (an
  * all-zero pose = missing frame, skipped); K / inv_K (B,16) at the matching resolution; depth_bins (D <= 256).
  * cost_volume (B,D,h,w) = match_features' first return value (mean |warped - current| x border masks, averaged
  * over the frames that hit, missing bins set to the pixel's maximum when set_missing_to_max); nullable outputs:
  * missing_mask (B,D,h,w) = its second return value; masked_cost_volume = cost_volume x confidence (:311);
  * lowest_cost (B,h,w) = 1 / depth of the first minimum, zeros read as 100 (:303-307); confidence_mask (B,h,w). */
+int mal_costvol_channel_last(void);
 int mal_cost_volume(const float* current_feats, const float* lookup_feats, const float* poses, const float* K,
                     const float* inv_K, const float* depth_bins, int B, int F, int C, int D, int h, int w, float eps,
                     int set_missing_to_max, float* cost_volume, float* missing_mask, float* masked_cost_volume,
@@ -295,6 +297,7 @@ int mal_cost_volume(const float* current_feats, const float* lookup_feats, const
  * "march_rows"  output rows per wavefront task of the marching kernels (0 = automatic, default);
  * "march_flip"  1 (default): odd row segments of the marching kernels walk bottom-up, so the two tasks sharing a
  *               segment boundary reach it together and the halo rows are served by the L2; 0 = all top-down;
+ * "costvol_impl" 1 (default): cost volume with planar features, lane = pixel; 0: channel-last, lane = channel;
  * "photo_impl"  mal_photo_fwd/bwd: 1 = marching kernels, two candidates per launch (default for SSIM + min);
  *               0 = one pixel per thread (ATen's summation order; always used for MAL_F_NO_SSIM / MAL_F_AVG);
  * "fwd_waves", "debug": kernel experiments. */

@@ -51,6 +51,7 @@ SIGNATURES = {
                                   c_fp, vp, sz, vp]),
     "mal_matching_mask": (i32, [c_fp, c_fp, c_fp, sz, c_fp, vp]),
     "mal_texel_floats": (i32, []),
+    "mal_costvol_channel_last": (i32, []),
     "mal_pack_texels": (i32, [c_fp, i32, i32, i32, c_fp, vp]),
     "mal_axpy_maps": (i32, [i32, c_pp, c_pp, c_pp, C.POINTER(f32), C.POINTER(f32), sz, c_fp, i32, vp]),
     "mal_finish_scalars": (i32, [c_fp, c_fp, f32, f32, i32, c_fp, vp]),

@@ -2,8 +2,7 @@
 ``ResnetEncoderMatching.match_features`` (manydepth/networks/resnet_encoder.py:152-233) and the lines of its
 ``forward`` that turn the volume into ``lowest_cost`` / ``confidence_mask`` (:296-312), as two HIP launches
 (``mal_cost_volume``) instead of a Python loop over the batch with 96-fold feature replication.  Forward only,
-as upstream (``torch.no_grad()``).  The NCHW -> channel-last relayout of the two feature maps is plumbing done
-with torch; everything else runs in the kernels.
+as upstream (``torch.no_grad()``).  The kernels read the encoder's own NCHW feature maps.
 """
 from __future__ import annotations
 
@@ -23,8 +22,11 @@ def _run(current_feats, lookup_feats, relative_poses, K, invK, depth_bins, set_m
     dev = cur.device
     bins = torch.as_tensor(depth_bins, dtype=torch.float32).to(dev).contiguous().reshape(-1)
     D = bins.numel()
-    cl = cur.permute(0, 2, 3, 1).contiguous()
-    ll = look.permute(0, 1, 3, 4, 2).contiguous()
+    if L.load().mal_costvol_channel_last():  # first formulation (mal_set_option("costvol_impl", 0)): relayout
+        cl = cur.permute(0, 2, 3, 1).contiguous()
+        ll = look.permute(0, 1, 3, 4, 2).contiguous()
+    else:                                    # default: the kernels read the encoder's own (B,C,h,w) layout
+        cl, ll = cur, ops._req(look, "lookup_feats")
     poses = ops._req(relative_poses.detach().reshape(B, F_, 16).contiguous(), "relative_poses")
     Kc, iKc = ops._req(K.detach().reshape(B, 16).contiguous(), "K"), ops._req(invK.detach().reshape(B, 16).contiguous(), "invK")
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)

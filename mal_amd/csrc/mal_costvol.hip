@@ -147,6 +147,83 @@ __global__ __launch_bounds__(256) void costvol_match_kernel(CostVolParams p) {
     if (k < rounds && k * 64 + lane < p.D) out[(size_t)(k * 64 + lane) * hw] = div_(acc[k], cnt[k] + 1e-7f);
 }
 
+// Second formulation (default): features stay PLANAR (B,C,h,w) as the encoder produces them -- no relayout -- and
+// lane = pixel: a wavefront owns 64 consecutive pixels and kCvG consecutive depth bins.  Per lookup frame every lane
+// derives its taps for its bins once (phase 1 of the first formulation, without the broadcast), then walks the 64
+// channel planes: per (bin, channel) four dword loads whose lanes fall in adjacent addresses (neighbouring pixels
+// sample neighbouring positions) and that move only a little from bin to bin (the epipolar line), so they hit the
+// L1 -- and 6 VALU operations, with no cross-lane reduction at all (the channel sum is a per-lane running sum).
+// bins per wavefront, (4 offsets + 4 weights) registers each.  Measured at B=12 48x160 D=96: 2..6 bins 0.50 ms, 8 0.52,
+// 12 0.88, 16 1.28 (spills); forcing three or four waves per SIMD through the launch bounds is slower (0.65-0.74 ms:
+// the compiler's wide version keeps more loads in flight); loading a row's two taps as one unaligned 8-byte pair is
+// slower too (0.58 ms).
+constexpr int kCvG = 6;
+
+__global__ __launch_bounds__(256) void costvol_match_px_kernel(CostVolParams p) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = p.h, w = p.w, hw = h * w;
+  const int pix0 = (blockIdx.x * 4 + wv) * 64, grp = blockIdx.y, b = blockIdx.z;
+  if (pix0 >= hw) return;
+  const bool live = pix0 + lane < hw;
+  const int pix = min(pix0 + lane, hw - 1);
+  const int y = pix / w, x = pix - y * w;
+  const bool inner = y >= 2 && y < h - 2 && x >= 2 && x < w - 2;  // resnet_encoder.py:208-210
+  const int d0 = grp * kCvG;
+  float ray[3], ik[9];
+  for (int e = 0; e < 9; ++e) ik[e] = p.invK[b * 16 + (e / 3) * 4 + (e % 3)];
+  ray_of(ik, (float)x, (float)y, ray);
+  float acc[kCvG], cnt[kCvG];
+#pragma unroll
+  for (int j = 0; j < kCvG; ++j) { acc[j] = 0.f; cnt[j] = 0.f; }
+  const float* cf = p.cur + (size_t)b * kCvC * hw;
+  for (int f = 0; f < p.F; ++f) {
+    const float* T = p.poses + ((size_t)b * p.F + f) * 16;
+    float tsum = 0.f;
+    for (int i = 0; i < 16; ++i) tsum += T[i];
+    if (tsum == 0.f) continue;  // a missing lookup frame (:176-178); wave-uniform
+    float P[12];
+    compose_P(p.K + b * 16, T, P);
+    unsigned off[kCvG][4];
+    float wt[kCvG][4], edge[kCvG], sum[kCvG];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < kCvG; ++j) {
+      const TapSet t = taps_for(P, ray, p.bins[min(d0 + j, p.D - 1)], p.eps, w, h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { off[j][k] = (unsigned)t.o[k] * 4u; wt[j][k] = t.w[k]; }
+      edge[j] = inner ? t.edge : 0.f;
+      sum[j] = 0.f;
+      any = any || edge[j] != 0.f;
+    }
+    if (__ballot(any) == 0ull) continue;  // every (pixel, bin) of this wave is masked out: all differences are x 0
+    const float* lf = p.look + ((size_t)b * p.F + f) * kCvC * hw;
+    for (int ch = 0; ch < kCvC; ++ch) {
+      const char* pl = reinterpret_cast<const char*>(lf + (size_t)ch * hw);
+      const float cv = cf[(size_t)ch * hw + pix];
+#pragma unroll
+      for (int j = 0; j < kCvG; ++j) {
+        const float a = *reinterpret_cast<const float*>(pl + off[j][0]), bb = *reinterpret_cast<const float*>(pl + off[j][1]);
+        const float c = *reinterpret_cast<const float*>(pl + off[j][2]), d = *reinterpret_cast<const float*>(pl + off[j][3]);
+        float o = a * wt[j][0];
+        o = fma_(bb, wt[j][1], o);
+        o = fma_(c, wt[j][2], o);
+        o = fma_(d, wt[j][3], o);
+        sum[j] += fabsf(o - cv);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kCvG; ++j) {
+      const float diff = sum[j] * (1.0f / (float)kCvC) * edge[j];
+      acc[j] += diff;
+      cnt[j] += diff > 0.f ? 1.0f : 0.f;
+    }
+  }
+  float* out = p.cost + (size_t)b * p.D * hw + pix;
+#pragma unroll
+  for (int j = 0; j < kCvG; ++j)
+    if (live && d0 + j < p.D) out[(size_t)(d0 + j) * hw] = div_(acc[j], cnt[j] + 1e-7f);  // 0 / 1e-7 = 0 outside the inner region
+}
+
 __global__ __launch_bounds__(256) void costvol_finish_kernel(CostVolParams p) {
   const int hw = p.h * p.w;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -182,6 +259,10 @@ __global__ __launch_bounds__(256) void costvol_finish_kernel(CostVolParams p) {
 
 using namespace mal;
 
+namespace mal { int g_costvol_impl = 1; }  // 1 = planar features, lane = pixel (default); 0 = channel-last, lane = channel
+
+extern "C" int mal_costvol_channel_last(void) { return g_costvol_impl == 0; }
+
 extern "C" int mal_cost_volume(const float* current_feats, const float* lookup_feats, const float* poses, const float* K,
                                const float* inv_K, const float* depth_bins, int B, int F, int C, int D, int h, int w,
                                float eps, int set_missing_to_max, float* cost_volume, float* missing_mask,
@@ -196,7 +277,10 @@ extern "C" int mal_cost_volume(const float* current_feats, const float* lookup_f
   p.cost = cost_volume; p.missing = missing_mask; p.masked = masked_cost_volume; p.lowest_cost = lowest_cost;
   p.confidence = confidence_mask;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(costvol_match_kernel, dim3((w + 3) / 4, h, B), dim3(256), 0, st, p);
+  if (g_costvol_impl == 0)
+    hipLaunchKernelGGL(costvol_match_kernel, dim3((w + 3) / 4, h, B), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(costvol_match_px_kernel, dim3((h * w + 255) / 256, (D + kCvG - 1) / kCvG, B), dim3(256), 0, st, p);
   hipLaunchKernelGGL(costvol_finish_kernel, dim3((B * h * w + 255) / 256), dim3(256), 0, st, p);
   return launch_status();
 }

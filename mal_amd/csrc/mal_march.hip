@@ -874,6 +874,7 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
 }
 
 int g_pass_impl = 1;   // 1 = marching (this file, fastest); 0 = LDS-tiled v1 (mal_pass.hip); 2 = LDS-tiled, 512 threads (mal_tile2.hip)
+extern int g_costvol_impl;  // mal_costvol.hip
 int g_march_flip = 1;  // odd segments bottom-up (mal_set_option("march_flip", 0|1))
 int g_march_rows = 0;  // output rows per wave task; 0 = pick so that one round of tasks fills the chip
 int g_debug = 0;
@@ -968,6 +969,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("pass_impl")) { if (value < 0 || value > 2) return MAL_EINVAL; g_pass_impl = value; return MAL_OK; }
   if (eq("debug")) { g_debug = value; return MAL_OK; }
   if (eq("photo_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_photo_impl = value; return MAL_OK; }
+  if (eq("costvol_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_costvol_impl = value; return MAL_OK; }
   if (eq("march_flip")) { g_march_flip = value != 0; return MAL_OK; }
   if (eq("march_rows")) { if (value < 0 || value > 4096) return MAL_EINVAL; g_march_rows = value; return MAL_OK; }
   return MAL_EINVAL;

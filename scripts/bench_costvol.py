@@ -1,5 +1,5 @@
 """Cost volume (N3) at MAL's size: B=12, one lookup frame, 64 channels, 96 bins, 48x160 (192x640 / 4).
-HIP kernels (mal_cost_volume, incl. the channel-last relayout) vs the reference's formulation run with torch on the
+HIP kernels (mal_cost_volume; argv[1] = costvol_impl, default 1) vs the reference's formulation run with torch on the
 same GPU (the oracle's code moved to the device) and on the host CPU."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +13,9 @@ poses[:, :, :3, 3] *= 0.25
 bins = CO.depth_bins(0.5, 20.0, D, "linear")
 dev = torch.device("cuda:0")
 g = [t.to(dev) for t in (cur, look, poses, K, invK)]
+from mal_amd import _lib
+if len(sys.argv) > 1:
+    _lib.check(_lib.load().mal_set_option(b"costvol_impl", int(sys.argv[1])), "costvol_impl")
 def hip():
     return costvol.cost_volume_outputs(*g, bins, True)
 for _ in range(3): hip()
