@@ -58,12 +58,21 @@ def check(cur, look, poses, K, invK, bins, ref):
     assert ((a - bq).abs() <= 2e-4 * bq.abs().clamp(min=1.0))[~amb_px].all()
 
 
+@pytest.mark.parametrize("impl", [1, 0], ids=["lane_pixel", "lane_channel"])
 @pytest.mark.parametrize("tag", CASES)
-def test_golden(tag):
+def test_golden(tag, impl):
+    """both formulations of the match kernel (mal_set_option("costvol_impl"): 1 = planar features, lane = pixel, the
+    default; 0 = channel-last, lane = channel) against the golden run"""
+    from mal_amd import _lib
     t = torch.from_numpy
     z, cur, look, poses, K, invK, bins = load(tag)
-    check(cur, look, poses, K, invK, bins, (t(z["out/cost_volume"]), t(z["out/missing"]), t(z["out/masked_cost_volume"]),
-                                            t(z["out/lowest_cost"]), t(z["out/confidence"])))
+    lib = _lib.load()
+    _lib.check(lib.mal_set_option(b"costvol_impl", impl), "costvol_impl")
+    try:
+        check(cur, look, poses, K, invK, bins, (t(z["out/cost_volume"]), t(z["out/missing"]), t(z["out/masked_cost_volume"]),
+                                                t(z["out/lowest_cost"]), t(z["out/confidence"])))
+    finally:
+        lib.mal_set_option(b"costvol_impl", 1)
 
 
 def test_mal_size_against_the_cpu_checker():

@@ -71,6 +71,28 @@ def test_loss_step_small_and_ragged_shapes(B, H, W):
     _check_step(b, {}, n0, n1)
 
 
+def test_march_direction_option():
+    """mal_set_option("march_flip"): odd row segments walking bottom-up (default) or top-down is a scheduling choice --
+    same losses and gradients up to the fp32 order of the vertical window sums"""
+    from mal_amd import _lib
+    from mal_amd.synthetic import make_batch
+    b = make_batch(2, 40, 130, seed=41)
+    g = torch.Generator().manual_seed(9)
+    n0 = torch.randn(2, 1, 40, 130, generator=g)
+    lib = _lib.load()
+    res = {}
+    try:
+        for flip in (0, 1):
+            _lib.check(lib.mal_set_option(b"march_flip", flip), "march_flip")
+            res[flip] = run_step(b, {}, n0)
+    finally:
+        lib.mal_set_option(b"march_flip", 1)
+    for k, v in res[1]["losses"].items():
+        assert abs(res[0]["losses"][k] - v) <= 2e-6 * max(abs(v), 1e-3), k
+    for k, gq in res[1]["grads"].items():
+        assert _l2rel(res[0]["grads"][k], gq) <= 2e-4, k  # a handful of near-tie pixels may take the other branch
+
+
 def _check_step(b, kw, n0, n1):
     B, _, H, W = b["color0"].shape
     o = HH.run_oracle(b, kw, n0, n1)
