@@ -224,35 +224,55 @@ __global__ __launch_bounds__(256) void costvol_match_px_kernel(CostVolParams p) 
     if (live && d0 + j < p.D) out[(size_t)(d0 + j) * hw] = div_(acc[j], cnt[j] + 1e-7f);  // 0 / 1e-7 = 0 outside the inner region
 }
 
+// 64 pixels per workgroup, the bins split over its four wavefronts (lane = pixel: every access is a coalesced row
+// piece of one bin plane); the pixel's maximum / hit count / first minimum are combined through LDS in bin order
 __global__ __launch_bounds__(256) void costvol_finish_kernel(CostVolParams p) {
-  const int hw = p.h * p.w;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.B * hw) return;
-  const int b = i / hw, pix = i - b * hw;
+  __shared__ float s_mx[4][64], s_best[4][64];
+  __shared__ int s_seen[4][64], s_arg[4][64];
+  const int hw = p.h * p.w, lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const bool live = i < p.B * hw;
+  const int ii = live ? i : p.B * hw - 1;
+  const int b = ii / hw, pix = ii - b * hw;
+  const int per = (p.D + 3) / 4, d_lo = min(part * per, p.D), d_hi = min(d_lo + per, p.D);
   float* c = p.cost + (size_t)b * p.D * hw + pix;
   float mx = -INFINITY;
   int seen = 0;
-  for (int d = 0; d < p.D; ++d) {
+#pragma unroll 8
+  for (int d = d_lo; d < d_hi; ++d) {
     const float v = c[(size_t)d * hw];
     mx = fmaxf(mx, v);
     seen += v > 0.f ? 1 : 0;  // (cost * (1 - missing) > 0): a missing bin is exactly 0
   }
+  s_mx[part][lane] = mx; s_seen[part][lane] = seen;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_mx[0][lane], s_mx[1][lane]), fmaxf(s_mx[2][lane], s_mx[3][lane]));
+  seen = (s_seen[0][lane] + s_seen[1][lane]) + (s_seen[2][lane] + s_seen[3][lane]);
   const float conf = seen == p.D ? 1.0f : 0.0f;
   float best = INFINITY;
   int arg = 0;
-  for (int d = 0; d < p.D; ++d) {
+#pragma unroll 4
+  for (int d = d_lo; d < d_hi; ++d) {
     const float v = c[(size_t)d * hw];
     const float miss = v == 0.f ? 1.0f : 0.0f;
     const float filled = p.set_missing_to_max ? v * (1.0f - miss) + mx * miss : v;
     const float viz = filled == 0.f ? 100.0f : filled;
     if (viz < best) { best = viz; arg = d; }  // first minimum, as torch.min
-    const size_t o = (size_t)b * p.D * hw + (size_t)d * hw + pix;
-    c[(size_t)d * hw] = filled;
-    if (p.missing) p.missing[o] = miss;
-    if (p.masked) p.masked[o] = filled * conf;
+    if (live) {
+      const size_t o = (size_t)b * p.D * hw + (size_t)d * hw + pix;
+      c[(size_t)d * hw] = filled;
+      if (p.missing) p.missing[o] = miss;
+      if (p.masked) p.masked[o] = filled * conf;
+    }
   }
-  if (p.confidence) p.confidence[i] = conf;
-  if (p.lowest_cost) p.lowest_cost[i] = div_(1.0f, p.bins[arg]);
+  s_best[part][lane] = best; s_arg[part][lane] = arg;
+  __syncthreads();
+  if (part == 0 && live) {
+    for (int k = 1; k < 4; ++k)
+      if (s_best[k][lane] < best) { best = s_best[k][lane]; arg = s_arg[k][lane]; }  // strict: the earlier bin wins a tie
+    if (p.confidence) p.confidence[i] = conf;
+    if (p.lowest_cost) p.lowest_cost[i] = div_(1.0f, p.bins[arg]);
+  }
 }
 
 }  // namespace mal
@@ -281,6 +301,6 @@ extern "C" int mal_cost_volume(const float* current_feats, const float* lookup_f
     hipLaunchKernelGGL(costvol_match_kernel, dim3((w + 3) / 4, h, B), dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL(costvol_match_px_kernel, dim3((h * w + 255) / 256, (D + kCvG - 1) / kCvG, B), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(costvol_finish_kernel, dim3((B * h * w + 255) / 256), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(costvol_finish_kernel, dim3((B * h * w + 63) / 64), dim3(256), 0, st, p);
   return launch_status();
 }
