@@ -43,10 +43,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a HIP graph (default); 0: eager launches")
-    ap.add_argument("--mode", choices=["step", "ops", "temporal", "train"], default="step",
+    ap.add_argument("--mode", choices=["step", "ops", "temporal", "train", "multiscale"], default="step",
                     help="step: mal_loss_step (one C call per direction, the headline); ops: the operator-level API; "
                          "temporal: --temporal --distil through the operator-level API; train: the whole training step "
-                         "of the harness (RepDepth networks + loss step + flat-bucket all-reduce + Adam, eager)")
+                         "of the harness (RepDepth networks + loss step + flat-bucket all-reduce + Adam, eager); "
+                         "multiscale: the non-distil compute_losses with sclm=3 (four disparity scales, "
+                         "manydepth/trainer.py:1248-1475) through the operator-level API")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mal_set_option before the run (kernel experiments, e.g. march_rows=16)")
@@ -112,6 +114,15 @@ class Step:
             synth = lambda inputs, outputs, scale: dyn_utils.image_synthesis(inputs, outputs, scale, 0.5, ins_model, matcher)
             self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, temporal=True), fuse=True,
                                        image_synthesis=synth)
+        elif mode == "multiscale":
+            # --scales 0..3 semantics (sclm=3): per-scale disparities upsampled to full resolution, loss
+            # / 2**scale, total / (sclm+1); the shipped decoder only feeds scale 0, so the lower scales are pooled copies
+            self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, sclm=3, distil=False), fuse=True)
+            for sc in (1, 2, 3):
+                k = 2 ** sc
+                self.inputs[("color", 0, sc)] = torch.nn.functional.avg_pool2d(self.inputs[("color", 0, 0)], k)
+                for name in ("disp_teacher", "disp_student"):
+                    self.leaves["%s_s%d" % (name, sc)] = torch.nn.functional.avg_pool2d(mv(b[name]), k).clone().requires_grad_(True)
         else:
             self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B), fuse=True)
         self.batch_cpu = b
@@ -136,6 +147,21 @@ class Step:
         mono_outputs = {("disp", 0): lv["disp_teacher"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1}
         outputs = {("disp", 0): lv["disp_student"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1,
                    "consistency_mask": self.cmask, "augmentation_mask": self.aug, "lowest_cost": self.lowest}
+        if self.mode == "multiscale":  # trainer.py:573-612 with not opt.distil: compute_losses for both nets
+            for sc in (1, 2, 3):
+                mono_outputs[("disp", sc)] = lv["disp_teacher_s%d" % sc]
+                outputs[("disp", sc)] = lv["disp_student_s%d" % sc]
+            lp = self.lp
+            lp.generate_images_pred(self.inputs, mono_outputs)
+            mono_losses, _ = lp.compute_losses(self.inputs, mono_outputs, is_multi=False)
+            for key in list(mono_outputs.keys()):
+                if isinstance(key, tuple) and key[0] in ("depth", "disp"):
+                    outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
+            lp.generate_images_pred(self.inputs, outputs, is_multi=True)
+            losses, _ = lp.compute_losses(self.inputs, outputs, is_multi=True)
+            total = losses["loss"] + mono_losses["loss"]
+            total.backward()
+            return total
         _, losses, _ = self.lp.compute_batch_losses(self.inputs, mono_outputs, outputs)
         losses["loss"].backward()
         return losses["loss"]
