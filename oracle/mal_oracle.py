@@ -23,7 +23,6 @@ resulting vectors are committed under ``tests/golden/`` and re-checked by
 """
 from __future__ import annotations
 
-import math
 from types import SimpleNamespace
 
 import numpy as np

@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from mal_amd import build, _lib, ops, layers
+from mal_amd import _lib, ops, layers
 from mal_amd.synthetic import make_batch
 lib = _lib.load()
 dev = torch.device("cuda:0")

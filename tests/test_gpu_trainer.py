@@ -7,7 +7,6 @@ import torch
 
 from mal_amd.synthetic import make_batch, to_dicts
 from oracle import mal_oracle as O
-from tests import hip_harness as HH
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -39,7 +38,7 @@ def _two_scale(batch, dev, pose_fn):
 @pytest.mark.parametrize("fuse,no_ssim", [(True, False), (False, False), (False, True)],
                          ids=["fused", "explicit", "explicit-no_ssim"])
 def test_non_distil_losses_two_scales(fuse, no_ssim):
-    from mal_amd import layers, trainer, loss_utils, config
+    from mal_amd import layers, trainer, config
     B, H, W = 2, 48, 80
     batch = make_batch(B, H, W, seed=77)
     torch.manual_seed(9)
