@@ -266,9 +266,12 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   // shifted to the right neighbour (it is column 0 feeding column 1) / to the left neighbour
   const float sL = gx == 0 ? 2.0f : 1.0f, sR = gx == W - 1 ? 2.0f : 1.0f;
 
-  const float* disp_b = p.disp + (size_t)b * HW;
-  const float* disp2_b = p.disp2 ? p.disp2 + (size_t)b * HW : nullptr;
-  const size_t map_b = (size_t)b * HW;
+  // (B,1,H,W) maps are addressed as (kernel-argument pointer) + (32-bit per-lane byte offset that already holds the
+  // sample's base): no 64-bit pointer arithmetic per map and row (check_shape bounds a map below 2^31 bytes)
+  const float* disp_b = p.disp;
+  const float* disp2_b = p.disp2;
+  const unsigned lane_off = (unsigned)gxr * 4u + (unsigned)b * (unsigned)HW * 4u;
+  auto moff = [&](int row) { return (unsigned)(prow(row) * W) * 4u + lane_off; };  // row in [0, H-1] (logical)
   const float sscale = p.sample_scale ? (p.sample_scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
 
   // ---- running state (pairs as in WarpRow: index k*3 + {x, x^2, xy} for the colour pairs k)
@@ -341,27 +344,28 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     // of the sample instead (a valid address, L2-resident) and the value is dropped.
     const bool packed_t = (pp.packed & 2) != 0;
     const unsigned pix = (unsigned)(prow(row_of(rr)) * W + gxr);
-    a.disp = ldf(disp_b, pix * 4u);
+    const unsigned od = moff(row_of(rr));
+    a.disp = ldf(disp_b, od);
     {
-      const float v = ldf(disp2_b ? disp2_b : disp_b, pix * 4u);
+      const float v = ldf(disp2_b ? disp2_b : disp_b, od);
       a.disp2 = disp2_b ? v : 0.f;
     }
     load_rgb(pp.target, packed_t, b, HW, pix, a.y);  // one texel (packed) or three planes
-    const unsigned oc = (unsigned)(prow(min(max(rr - 1, 0), H - 1)) * W + gxr) * 4u;  // statistics row c = rr-1
+    const unsigned oc = moff(min(max(rr - 1, 0), H - 1));  // statistics row c = rr-1
     auto opt = [&](const float* m, unsigned off, float absent) {
-      const float v = ldf(m ? m + map_b : disp_b, off);
+      const float v = ldf(m ? m : disp_b, off);
       return m ? v : absent;
     };
     a.ident = 0.f; a.noise = 0.f;
-    if (AUTOMASK) { a.ident = ldf(pp.ident + map_b, oc); a.noise = opt(pp.noise, oc, 0.f); }
+    if (AUTOMASK) { a.ident = ldf(pp.ident, oc); a.noise = opt(pp.noise, oc, 0.f); }
     a.ext = opt(pp.ext_mask, oc, 1.f);
     a.mono = opt(pp.lowest_cost ? pp.mono_disp : nullptr, oc, 0.f);
     a.cost = opt(pp.lowest_cost, oc, 1.f);
-    const unsigned oq = (unsigned)(prow(min(max(GRAD ? rr - 2 : rr - 1, 0), H - 1)) * W + gxr) * 4u;  // epilogue row
+    const unsigned oq = GRAD ? moff(min(max(rr - 2, 0), H - 1)) : oc;  // epilogue row
     a.e_mono = 0.f; a.e_mr = 0.f; a.e_er = 0.f;
     if (EPI) {
-      a.e_mono = ldf((pp.mono_disp ? pp.mono_disp : pp.mono_depth) + map_b, oq);
-      a.e_mr = ldf(pp.mono_reproj + map_b, oq);
+      a.e_mono = ldf(pp.mono_disp ? pp.mono_disp : pp.mono_depth, oq);
+      a.e_mr = ldf(pp.mono_reproj, oq);
       a.e_er = opt(pp.ens_reproj, oq, 0.f);
     }
   };
@@ -401,6 +405,8 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     auto tick = [](int) {};
 #endif
     tick(0);  // loop overhead + parameter loads
+    // byte offsets (sample base included) of this lane's pixel in the rows this iteration writes: c = r-1 and q = r-2
+    const unsigned so_c = moff(min(max(r - 1, 0), H - 1)), so_q = GRAD ? moff(min(max(r - 2, 0), H - 1)) : so_c;
     // ---- what the previous iteration requested for this one
     const Ahead cur = nxt;
     const float ld_ident = cur.ident, ld_noise = cur.noise, ld_ext = cur.ext, ld_mono = cur.mono, ld_cost = cur.cost;
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       const int qs = r - 1;  // row finished now: its down edge is this up edge
       if (qs >= y_lo && qs < y_hi && out_x) {
         const float g = sm_g1 + sy;
-        stf(p.smooth_gn + map_b, (unsigned)(prow(qs) * W + gxr) * 4u, g);
+        stf(p.smooth_gn, so_c, g);
         acc_sd += g * sm_d1;
       }
       // every vertical edge is summed once: by the task that owns its physically upper row
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       const int q = GRAD ? r - 2 : r - 1;
       const PixInfo& pq = GRAD ? pi1 : pi0;
       if (q >= y_lo && q < y_hi && out_x) {
-        const unsigned go = (unsigned)(prow(q) * W + gxr) * 4u;
+        const unsigned go = GRAD ? so_q : so_c;
         const float dm = depth_of(le_disp, wc.min_disp, wc.range);
         const float ddepth = -(dm * dm) * wc.range;
         const float dmono = has_mdisp ? depth_of(le_mono, wc.min_disp, wc.range) : le_mono;
@@ -502,15 +508,15 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
         const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
         const float dd = target - dm;
         acc_dist += fabsf(dd) * mm;
-        if (p.cons_target) stf(p.cons_target + map_b, go, div_(1.0f, dmono * cm + dm * (1.0f - cm)));
+        if (p.cons_target) stf(p.cons_target, go, div_(1.0f, dmono * cm + dm * (1.0f - cm)));
         if (GRAD) {
           const float gc = sgnf(dc) * cm * ddepth;
           const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : -0.5f)) * mm * ddepth;
           if (p.g_distil) {
-            stf(p.g_cons + map_b, go, gc);
-            stf(p.g_distil + map_b, go, gd);
+            stf(p.g_cons, go, gc);
+            stf(p.g_distil, go, gd);
           } else {
-            stf(p.g_cons + map_b, go, fma_(p.merge_cons, gc, p.merge_distil * gd));
+            stf(p.g_cons, go, fma_(p.merge_cons, gc, p.merge_distil * gd));
           }
         }
       }
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       pi0.win = (rr.y < rr.x) ? 1 : 0;
       pi0.rp = pi0.win ? rr.y : rr.x;
       float w = 1.0f;
-      const unsigned go = (unsigned)(prow(min(max(c, 0), H - 1)) * W + gxr) * 4u;
+      const unsigned go = so_c;
       if (AUTOMASK) {
         float idn = ld_ident;
         if (has_noise) idn += ld_noise * 0.00001f;
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
           const float matching = div_safe_(1.0f, ld_cost);
           const bool ok = (div_safe_(matching - mono, mono) < 1.0f) && (div_safe_(mono - matching, matching) < 1.0f);
           em = ok ? em : em * 0.0f;
-          if (p.cmask_out && out_x && c >= y_lo && c < y_hi) stf(p.cmask_out + map_b, go, em);
+          if (p.cmask_out && out_x && c >= y_lo && c < y_hi) stf(p.cmask_out, go, em);
         }
         w *= em;
       }
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       if (!in_x) w = 0.f;  // not a pixel: contributes nothing (its statistics only served as halo)
       pi0.w = w;
       if (out_x && c >= y_lo && c < y_hi) {
-        if (p.min_reproj) stf(p.min_reproj + map_b, go, pi0.rp);
+        if (p.min_reproj) stf(p.min_reproj, go, pi0.rp);
         acc_rw += pi0.rp * w;
         acc_w += w;
       }
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
           const f2 ts = (t0 + t1) + t2;
           gdisp = ts.x + ts.y;
         }
-        if (out_x) stf(p.g_reproj + map_b, (unsigned)(prow(q) * W + gxr) * 4u, gdisp);
+        if (out_x) stf(p.g_reproj, so_q, gdisp);
       }
       // roll the partial-plane sums: (row c: top+mid) <- (row c: top) + hc(c) ; (row c+1: top) <- hc(c)
       {
@@ -715,7 +721,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     if (p.depth_out) {
       const int q = r - 1;
       if (q >= y_lo && q < y_hi && out_x)
-        stf(p.depth_out + map_b, (unsigned)(prow(q) * W + gxr) * 4u, depth_of(ldf(disp_b, (unsigned)(prow(q) * W + gxr) * 4u), wc.min_disp, wc.range));
+        stf(p.depth_out, so_c, depth_of(ldf(disp_b, so_c), wc.min_disp, wc.range));
     }
 
     // ================= roll the row state =====================================================
