@@ -120,6 +120,9 @@ int mal_smooth_loss(const float* disp /*B,1,H,W*/, const float* img /*B,C,H,W*/,
 /* ---- a5 (materialising): Trainer.generate_images_pred, manydepth/trainer.py:1093-1125 --
  * depth = 1/(1/max + (1/min-1/max)*disp); for f<F: grid_f = Project3D(Backproject(depth), K, T_f);
  * warped_f = grid_sample(src_f, grid_f).  Any of the outputs may be NULL.                  */
+/* `convention` of mal_warp_fwd/bwd may be OR'ed with MAL_WARP_TEXELS: src[f] are then the texel copies made by
+ * mal_pack_texels (one gather per bilinear tap instead of three); results are bit-identical. */
+#define MAL_WARP_TEXELS 256
 int mal_warp_fwd(const float* disp /*B,1,H,W, full resolution*/, const float* K, const float* inv_K,
                  const float* const* T /*[F] B,16*/, const float* const* src /*[F] B,3,H,W*/,
                  int B, int H, int W, int F, float min_depth, float max_depth, float eps, int convention,

@@ -26,6 +26,7 @@ struct WarpParams {
   float* depth_out; float* grid_out[2]; float* warped_out[2];
   float* g_disp; float* block_gP;
   int B, H, W, F; float min_disp, range, eps; int convention; int bps;  // blocks per sample
+  int packed;  // src[f] are texel copies made by mal_pack_texels (MAL_WARP_TEXELS): one gather per tap instead of three
 };
 
 __device__ inline void load_cam(const WarpParams& p, int b, float (*sP)[12], float* sik) {
@@ -67,13 +68,11 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpParams p) {
       if (p.grid_out[f]) { p.grid_out[f][gi * 2] = s.gx; p.grid_out[f][gi * 2 + 1] = s.gy; }
       if (p.warped_out[f]) {
         Taps t = make_taps(s.ix, s.iy, p.W, p.H);
-        const float* sb = p.src[f] + (size_t)b * 3 * HW;
         float* ob = p.warped_out[f] + (size_t)b * 3 * HW;
+        float ta[3], tb[3], tc[3], td[3];
+        load_taps(p.src[f], p.packed, b, HW, t, ta, tb, tc, td);
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const float* pl = sb + ch * HW;
-          ob[ch * HW + pix] = blend(t, pl[t.o00], pl[t.o01], pl[t.o10], pl[t.o11]);
-        }
+        for (int ch = 0; ch < 3; ++ch) ob[ch * HW + pix] = blend(t, ta[ch], tb[ch], tc[ch], td[ch]);
       }
     }
   }
@@ -111,14 +110,14 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpParams p) {
       float gu = 0.f, gv = 0.f;
       if (p.g_warped[f]) {
         Taps t = make_taps(s.ix, s.iy, p.W, p.H);
-        const float* sb = p.src[f] + (size_t)b * 3 * HW;
         const float* gb = p.g_warped[f] + (size_t)b * 3 * HW;
         float gix = 0.f, giy = 0.f;
+        float ta[3], tb[3], tc[3], td[3];
+        load_taps(p.src[f], p.packed, b, HW, t, ta, tb, tc, td);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float* pl = sb + ch * HW;
           float dx, dy;
-          blend_grad(t, pl[t.o00], pl[t.o01], pl[t.o10], pl[t.o11], &dx, &dy);
+          blend_grad(t, ta[ch], tb[ch], tc[ch], td[ch], &dx, &dy);
           const float g = gb[ch * HW + pix];
           gix = fma_(g, dx, gix);
           giy = fma_(g, dy, giy);
@@ -417,9 +416,12 @@ extern "C" int mal_warp_fwd(const float* disp, const float* K, const float* inv_
   int rc = check_shape(B, H, W);
   if (rc) return rc;
   if (F < 1 || F > MAL_MAX_FRAMES || !disp || !K || !inv_K || !T) return MAL_EINVAL;
+  const int texels = (convention & MAL_WARP_TEXELS) ? 1 : 0;
+  convention &= ~MAL_WARP_TEXELS;
   if (convention != 0 && convention != 1) return MAL_EINVAL;
   WarpParams p;
   fill_warp_params(p, disp, K, inv_K, T, src, B, H, W, F, min_depth, max_depth, eps, convention);
+  p.packed = texels;
   p.depth_out = depth_out;
   for (int f = 0; f < F; ++f) {
     if (!T[f]) return MAL_EINVAL;
@@ -439,11 +441,14 @@ extern "C" int mal_warp_bwd(const float* disp, const float* K, const float* inv_
   int rc = check_shape(B, H, W);
   if (rc) return rc;
   if (F < 1 || F > MAL_MAX_FRAMES || !disp || !K || !inv_K || !T || !g_disp || !ws) return MAL_EINVAL;
+  const int texels = (convention & MAL_WARP_TEXELS) ? 1 : 0;
+  convention &= ~MAL_WARP_TEXELS;
   if (convention != 0 && convention != 1) return MAL_EINVAL;
   Workspace w = carve(ws, B, H, W);
   if (ws_bytes < w.bytes) return MAL_EWORKSPACE;
   WarpParams p;
   fill_warp_params(p, disp, K, inv_K, T, src, B, H, W, F, min_depth, max_depth, eps, convention);
+  p.packed = texels;
   for (int f = 0; f < F; ++f) {
     if (!T[f]) return MAL_EINVAL;
     p.g_warped[f] = g_warped ? g_warped[f] : nullptr;

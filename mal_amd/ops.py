@@ -208,6 +208,9 @@ def smooth_loss(disp, img, normalise, need_grad):
 
 
 # ------------------------------------------------------------------ a5 materialising warp
+WARP_TEXELS = 256  # MAL_WARP_TEXELS of include/mal_hip.h
+
+
 def warp_fwd(disp, K, inv_K, Ts, srcs, min_depth, max_depth, eps, convention, want_depth=True, want_grid=True,
              want_warped=True):
     disp = _req(disp, "disp")
@@ -216,6 +219,8 @@ def warp_fwd(disp, K, inv_K, Ts, srcs, min_depth, max_depth, eps, convention, wa
     K, inv_K = _mat(K, "K", B), _mat(inv_K, "inv_K", B)
     Ts = [_mat(t, "T", B) for t in Ts]
     srcs = [_req(s, "src") for s in srcs]
+    if pack_sources and want_warped:  # texel copies (cached per source tensor, shared with the fused passes)
+        srcs, convention = [packed_source(s) for s in srcs], convention | WARP_TEXELS
     dev = disp.device
     depth = torch.empty_like(disp) if want_depth else None
     grids = [torch.empty(B, H, W, 2, dtype=torch.float32, device=dev) if want_grid else None for _ in range(F)]
@@ -234,6 +239,8 @@ def warp_bwd(disp, K, inv_K, Ts, srcs, g_warped, g_grid, g_depth, min_depth, max
     K, inv_K = _mat(K, "K", B), _mat(inv_K, "inv_K", B)
     Ts = [_mat(t, "T", B) for t in Ts]
     srcs = [_req(s, "src") for s in srcs]
+    if pack_sources and any(g is not None for g in g_warped):
+        srcs, convention = [packed_source(s) for s in srcs], convention | WARP_TEXELS
     g_warped = [_req(g, "g_warped") for g in g_warped]
     g_grid = [_req(g, "g_grid") for g in g_grid]
     g_depth = _req(g_depth, "g_depth")
