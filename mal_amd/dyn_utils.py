@@ -27,10 +27,7 @@ class DynamicInstanceFn(Function):
         if il.shape != (C, H, W) or inx.shape != (C, H, W):
             raise L.MalError("generate_dynamic_instance: images must be (C,H,W) matching the masks")
         dev = il.device
-        # bool masks are one byte per element already: reinterpret, do not convert
-        as_u8 = lambda m: (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8))
-        ml = as_u8(mask_last.to(dev).contiguous())
-        mn = as_u8(mask_next.to(dev).contiguous())
+        ml, mn = _as_u8(mask_last, dev), _as_u8(mask_next, dev)
         ol, on = torch.empty_like(il), torch.empty_like(inx)
         delta = torch.empty(num, 2, dtype=torch.int32, device=dev)
         flags = torch.empty(H, W, dtype=torch.uint8, device=dev)
@@ -77,33 +74,75 @@ def generate_instances(images, ins_model):
     return ins_model(images)
 
 
+def _as_u8(mask, dev):
+    """(n,H,W) instance masks as bytes on the device; bool is one byte per element already: reinterpret, do not convert"""
+    m = mask.to(dev).contiguous()
+    return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+
+
+class BatchSynthesisFn(Function):
+    """``image_synthesis``'s tensor work for the whole batch as ONE autograd node: (color_last, color_next) (B,C,H,W) and
+    ``items`` = [(b, mask_last, mask_next)] for the samples with matched instances -> (syn_last, syn_next).  Samples
+    not listed keep their warped images (and pass their gradient through), exactly as the reference's
+    ``clone`` + per-sample assignment (dyn_utils.py:127-128,163-168) -- without one select / copy / zero-fill / add
+    node per sample in the autograd graph."""
+
+    @staticmethod
+    def forward(ctx, color_last, color_next, items, replace):
+        cl, cn = ops._req(color_last, "color_last"), ops._req(color_next, "color_next")
+        B, C, H, W = cl.shape
+        dev = cl.device
+        syn_last, syn_next = cl.clone(), cn.clone()
+        lib, p = L.load(), ops._p
+        saved = []
+        for b, mask_last, mask_next in items:
+            if mask_last.shape != mask_next.shape or mask_last.dim() != 3 or tuple(mask_last.shape[1:]) != (H, W):
+                raise L.MalError("image_synthesis: masks must be two (num,H,W) tensors matching the images")
+            num = mask_last.shape[0]
+            ml, mn = _as_u8(mask_last, dev), _as_u8(mask_next, dev)
+            delta = torch.empty(num, 2, dtype=torch.int32, device=dev)
+            flags = torch.empty(H, W, dtype=torch.uint8, device=dev)
+            ws = torch.empty(lib.mal_dyn_workspace_bytes(num), dtype=torch.uint8, device=dev)
+            L.check(lib.mal_dyn_instance_fwd(p(ml), p(mn), num, p(cl[b]), p(cn[b]), C, H, W, 1 if replace else 0,
+                                             p(syn_last[b]), p(syn_next[b]), p(delta), p(flags), p(ws), ws.numel(),
+                                             ops._stream()), "mal_dyn_instance_fwd")
+            saved.append((b, ml, mn, num, delta, flags))
+        ctx.saved, ctx.dims = saved, (C, H, W)
+        return syn_last, syn_next
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_last, g_next):
+        C, H, W = ctx.dims
+        g_last, g_next = g_last.contiguous(), g_next.contiguous()
+        gl, gn = g_last.clone(), g_next.clone()  # samples without instances: the identity
+        lib, p = L.load(), ops._p
+        for b, ml, mn, num, delta, flags in ctx.saved:
+            L.check(lib.mal_dyn_instance_bwd(p(ml), p(mn), num, p(delta), p(flags), p(g_last[b]), p(g_next[b]), C, H, W,
+                                             p(gl[b]), p(gn[b]), ops._stream()), "mal_dyn_instance_bwd")
+        return gl, gn, None, None
+
+
 def image_synthesis(inputs, outputs, scale, thres, ins_model, matcher):
-    """manydepth/dyn_utils.py:121-170, unchanged control flow; the per-sample synthesis runs in the HIP kernels.
+    """manydepth/dyn_utils.py:121-170: same control flow and calls to the two external models, sample by sample; the
+    tensor work of all samples with matched instances then runs as one autograd node (``BatchSynthesisFn``).
     Writes ``outputs[("syn", -1, scale)]`` / ``("syn", 1, scale)`` when any sample has matched instances."""
     bs = inputs[("color", 0, 0)].shape[0]
     instances = generate_instances(inputs[("color", 0, 0)], ins_model)
-    syn_last = outputs[("color", -1, scale)].clone()
-    syn_next = outputs[("color", 1, scale)].clone()
-    has_ins = False
+    color_last, color_next = outputs[("color", -1, scale)], outputs[("color", 1, scale)]
+    items = []
     for b in range(bs):
         cur = instances[b]["instances"]
         instances_cur = cur[cur.scores > thres]
         if len(instances_cur) == 0:
             continue
-        img_last = outputs[("color", -1, scale)][b]
-        img_next = outputs[("color", 1, scale)][b]
-        both = generate_instances(torch.stack([img_last, img_next], dim=0), ins_model)
+        both = generate_instances(torch.stack([color_last[b].detach(), color_next[b].detach()], dim=0), ins_model)
         ins_last, ins_next = both[0]["instances"], both[1]["instances"]
         slice_last, slice_next = matcher(ins_last, ins_next, instances_cur)
         if len(slice_last) + len(slice_next) == 0:
             continue
-        has_ins = True
-        mask_last = ins_last.pred_masks[slice_last].bool()
-        mask_next = ins_next.pred_masks[slice_next].bool()
-        tmp_last, tmp_next = generate_dynamic_instance(None, None, mask_last, mask_next, img_last, img_next, replace=False)
-        syn_last[b] = tmp_last
-        syn_next[b] = tmp_next
-    if has_ins:
-        outputs[("syn", -1, scale)] = syn_last
-        outputs[("syn", 1, scale)] = syn_next
-    return has_ins
+        items.append((b, ins_last.pred_masks[slice_last].bool(), ins_next.pred_masks[slice_next].bool()))
+    if not items:
+        return False
+    outputs[("syn", -1, scale)], outputs[("syn", 1, scale)] = BatchSynthesisFn.apply(color_last, color_next, items, False)
+    return True

@@ -101,16 +101,27 @@ def test_image_synthesis_control_flow():
         return orig(images, model)
 
     dyn_utils.generate_instances = tracking
+    leaves = {f: color[f].clone().requires_grad_(True) for f in (-1, 1)}
     try:
         inputs = {("color", 0, 0): color[0]}
-        outputs = {("color", -1, 0): color[-1], ("color", 1, 0): color[1]}
+        outputs = {("color", -1, 0): leaves[-1], ("color", 1, 0): leaves[1]}
         has = dyn_utils.image_synthesis(inputs, outputs, 0, 0.5, ins_model, matcher)
     finally:
         dyn_utils.generate_instances = orig
     assert has is True
-    sl, sn = outputs[("syn", -1, 0)].cpu(), outputs[("syn", 1, 0)].cpu()
+    sl, sn = outputs[("syn", -1, 0)].detach().cpu(), outputs[("syn", 1, 0)].detach().cpu()
     for b in (1, 2):
         assert torch.equal(sl[b], color[-1][b].cpu()) and torch.equal(sn[b], color[1][b].cpu())
     ml, mn = masks[0][0][[0, 2]], masks[0][1][[0, 2]]
-    ol, on = D.generate_dynamic_instance(ml, mn, color[-1][0].cpu(), color[1][0].cpu(), False)
-    assert torch.equal(sl[0], ol) and torch.equal(sn[0], on)
+    rl, rn = color[-1][0].cpu().clone().requires_grad_(True), color[1][0].cpu().clone().requires_grad_(True)
+    ol, on = D.generate_dynamic_instance(ml, mn, rl, rn, False)
+    assert torch.equal(sl[0], ol.detach()) and torch.equal(sn[0], on.detach())
+    # the whole batch is one autograd node: samples without instances pass their cotangent through, sample 0 gets
+    # the adjoint of its synthesis (bit-exact against the oracle's)
+    wl, wn = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    ((outputs[("syn", -1, 0)] * wl.to(DEV)).sum() + (outputs[("syn", 1, 0)] * wn.to(DEV)).sum()).backward()
+    ((ol * wl[0]).sum() + (on * wn[0]).sum()).backward()
+    gl, gn = leaves[-1].grad.cpu(), leaves[1].grad.cpu()
+    assert torch.equal(gl[0], rl.grad) and torch.equal(gn[0], rn.grad)
+    for b in (1, 2):
+        assert torch.equal(gl[b], wl[b]) and torch.equal(gn[b], wn[b])
