@@ -279,6 +279,19 @@ int mal_dyn_instance_bwd(const uint8_t* mask_last, const uint8_t* mask_next, int
                          const uint8_t* flags, const float* g_ori_last, const float* g_ori_next, int C, int H, int W,
                          float* g_img_last, float* g_img_next, void* stream);
 
+/* The same for several samples of a batch in one call (three launches forward, one backward for up to 16 samples; more
+ * are chunked): one item per sample with matched instances; the fields are the arguments of the two functions above. */
+typedef struct mal_dyn_item {
+  const uint8_t* mask_last; const uint8_t* mask_next; int num;
+  const float* img_last; const float* img_next;  /* forward in */
+  float* ori_last; float* ori_next;              /* forward out */
+  int32_t* delta; uint8_t* flags;                /* forward out, backward in */
+  void* ws; size_t ws_bytes;                     /* forward scratch: mal_dyn_workspace_bytes(num) */
+  const float* g_ori_last; const float* g_ori_next; float* g_img_last; float* g_img_next;  /* backward */
+} mal_dyn_item;
+int mal_dyn_batch_fwd(const mal_dyn_item* items, int n_items, int C, int H, int W, int replace, void* stream);
+int mal_dyn_batch_bwd(const mal_dyn_item* items, int n_items, int C, int H, int W, void* stream);
+
 /* ---- N3: ManyDepth's cost volume as MAL's student encoder builds it (forward only; upstream runs it under
  * no_grad): manydepth/networks/resnet_encoder.py:152-233 match_features + :296-312 of the encoder's forward.
  * current_feats (B,C,h,w) and lookup_feats (B,F,C,h,w) planar as the encoder produces them, C = 64 (with option

@@ -63,6 +63,8 @@ SIGNATURES = {
     "mal_dyn_workspace_bytes": (sz, [i32]),
     "mal_dyn_instance_fwd": (i32, [vp, vp, i32, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, vp, vp, vp, sz, vp]),
     "mal_dyn_instance_bwd": (i32, [vp, vp, i32, vp, vp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, vp]),
+    "mal_dyn_batch_fwd": (i32, [vp, i32, i32, i32, i32, i32, vp]),
+    "mal_dyn_batch_bwd": (i32, [vp, i32, i32, i32, i32, vp]),
     "mal_step_workspace_bytes": (sz, [i32, i32, i32]),
     "mal_loss_step_fwd": (i32, [vp]),
     "mal_loss_step_bwd": (i32, [vp]),
@@ -72,6 +74,13 @@ SIGNATURES = {
     "mal_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
     "mal_profile_next_pass": (i32, [vp, vp]),
 }
+
+class DynItem(C.Structure):
+    """mal_dyn_item (include/mal_hip.h)."""
+    _fields_ = [("mask_last", vp), ("mask_next", vp), ("num", i32), ("img_last", vp), ("img_next", vp),
+                ("ori_last", vp), ("ori_next", vp), ("delta", vp), ("flags", vp), ("ws", vp), ("ws_bytes", sz),
+                ("g_ori_last", vp), ("g_ori_next", vp), ("g_img_last", vp), ("g_img_next", vp)]
+
 
 class StepArgs(C.Structure):
     """mal_step_args (include/mal_hip.h)."""

@@ -32,8 +32,15 @@ struct DynParams {
   const float* g_ori_last; const float* g_ori_next; float* g_img_last; float* g_img_next;
 };
 
-__global__ __launch_bounds__(1024) void dyn_extents_kernel(DynParams p) {
+// Up to kDynBatch samples per launch (blockIdx.z = sample): a step's temporal hint is 12 samples x 3 kernels of a few
+// microseconds each when launched one by one
+constexpr int kDynBatch = 16;
+struct DynBatch { DynParams s[kDynBatch]; };
+
+__global__ __launch_bounds__(1024) void dyn_extents_kernel(DynBatch bt) {
   extern __shared__ int sh[];  // row flags [H], column flags [W], then 4 results
+  const DynParams& p = bt.s[blockIdx.z];
+  if ((int)blockIdx.x >= p.num) return;  // the grid is as wide as the sample with the most instances
   const int i = blockIdx.x, which = blockIdx.y, tid = threadIdx.x, H = p.H, W = p.W, HW = H * W;
   int* rowf = sh;
   int* colf = sh + H;
@@ -72,7 +79,8 @@ __global__ __launch_bounds__(1024) void dyn_extents_kernel(DynParams p) {
   }
 }
 
-__global__ void dyn_delta_kernel(DynParams p) {
+__global__ void dyn_delta_kernel(DynBatch bt) {
+  const DynParams& p = bt.s[blockIdx.z];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.num) return;
   const int* el = p.ext + (i * 2 + 0) * 4;
@@ -87,8 +95,9 @@ __global__ void dyn_delta_kernel(DynParams p) {
   p.delta[i * 2] = dx; p.delta[i * 2 + 1] = dy;
 }
 
-__global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynParams p) {
+__global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynBatch bt) {
   extern __shared__ int s_delta[];  // [num][2]
+  const DynParams& p = bt.s[blockIdx.z];
   for (int k = threadIdx.x; k < p.num * 2; k += 256) s_delta[k] = p.delta[k];
   __syncthreads();
   const int H = p.H, W = p.W, HW = H * W;
@@ -126,8 +135,9 @@ __global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynParams p) {
   }
 }
 
-__global__ __launch_bounds__(256) void dyn_synth_bwd_kernel(DynParams p) {
+__global__ __launch_bounds__(256) void dyn_synth_bwd_kernel(DynBatch bt) {
   extern __shared__ int s_delta[];
+  const DynParams& p = bt.s[blockIdx.z];
   for (int k = threadIdx.x; k < p.num * 2; k += 256) s_delta[k] = p.delta[k];
   __syncthreads();
   const int H = p.H, W = p.W, HW = H * W;
@@ -180,38 +190,83 @@ extern "C" size_t mal_dyn_workspace_bytes(int num) {
   return num > 0 ? align256((size_t)num * 8 * sizeof(int)) : 0;
 }
 
+static int dyn_fwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, int replace, hipStream_t st) {
+  DynBatch bt = {};
+  int max_num = 0;
+  for (int k = 0; k < n; ++k) {
+    const mal_dyn_item& a = it[k];
+    int rc = dyn_check(a.num, C, H, W);
+    if (rc) return rc;
+    if (!a.mask_last || !a.mask_next || !a.img_last || !a.img_next || !a.ori_last || !a.ori_next || !a.delta || !a.flags ||
+        !a.ws)
+      return MAL_EINVAL;
+    if (a.ws_bytes < mal_dyn_workspace_bytes(a.num)) return MAL_EWORKSPACE;
+    DynParams& p = bt.s[k];
+    p.mask_last = a.mask_last; p.mask_next = a.mask_next; p.num = a.num; p.C = C; p.H = H; p.W = W; p.replace = replace;
+    p.img_last = a.img_last; p.img_next = a.img_next; p.ori_last = a.ori_last; p.ori_next = a.ori_next;
+    p.ext = (int*)a.ws; p.delta = a.delta; p.flags = a.flags;
+    max_num = a.num > max_num ? a.num : max_num;
+  }
+  hipLaunchKernelGGL(dyn_extents_kernel, dim3(max_num, 2, n), dim3(1024), (size_t)(H + W + 4) * sizeof(int), st, bt);
+  hipLaunchKernelGGL(dyn_delta_kernel, dim3(1, 1, n), dim3(64), 0, st, bt);
+  hipLaunchKernelGGL(dyn_synth_fwd_kernel, dim3((H * W + 255) / 256, 1, n), dim3(256), (size_t)max_num * 2 * sizeof(int), st, bt);
+  return launch_status();
+}
+
+static int dyn_bwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, hipStream_t st) {
+  DynBatch bt = {};
+  int max_num = 0;
+  for (int k = 0; k < n; ++k) {
+    const mal_dyn_item& a = it[k];
+    int rc = dyn_check(a.num, C, H, W);
+    if (rc) return rc;
+    if (!a.mask_last || !a.mask_next || !a.delta || !a.flags || !a.g_ori_last || !a.g_ori_next ||
+        (!a.g_img_last && !a.g_img_next))
+      return MAL_EINVAL;
+    DynParams& p = bt.s[k];
+    p.mask_last = a.mask_last; p.mask_next = a.mask_next; p.num = a.num; p.C = C; p.H = H; p.W = W;
+    p.delta = a.delta; p.flags = a.flags;
+    p.g_ori_last = a.g_ori_last; p.g_ori_next = a.g_ori_next; p.g_img_last = a.g_img_last; p.g_img_next = a.g_img_next;
+    max_num = a.num > max_num ? a.num : max_num;
+  }
+  hipLaunchKernelGGL(dyn_synth_bwd_kernel, dim3((H * W + 255) / 256, 1, n), dim3(256), (size_t)max_num * 2 * sizeof(int), st, bt);
+  return launch_status();
+}
+
+extern "C" int mal_dyn_batch_fwd(const mal_dyn_item* items, int n_items, int C, int H, int W, int replace, void* stream) {
+  if (!items || n_items < 1) return MAL_EINVAL;
+  for (int o = 0; o < n_items; o += kDynBatch) {
+    int rc = dyn_fwd_chunk(items + o, n_items - o < kDynBatch ? n_items - o : kDynBatch, C, H, W, replace, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return MAL_OK;
+}
+
+extern "C" int mal_dyn_batch_bwd(const mal_dyn_item* items, int n_items, int C, int H, int W, void* stream) {
+  if (!items || n_items < 1) return MAL_EINVAL;
+  for (int o = 0; o < n_items; o += kDynBatch) {
+    int rc = dyn_bwd_chunk(items + o, n_items - o < kDynBatch ? n_items - o : kDynBatch, C, H, W, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return MAL_OK;
+}
+
 extern "C" int mal_dyn_instance_fwd(const uint8_t* mask_last, const uint8_t* mask_next, int num, const float* img_last,
                                     const float* img_next, int C, int H, int W, int replace, float* ori_last,
                                     float* ori_next, int32_t* delta, uint8_t* flags, void* ws, size_t ws_bytes,
                                     void* stream) {
-  int rc = dyn_check(num, C, H, W);
-  if (rc) return rc;
-  if (!mask_last || !mask_next || !img_last || !img_next || !ori_last || !ori_next || !delta || !flags || !ws)
-    return MAL_EINVAL;
-  if (ws_bytes < mal_dyn_workspace_bytes(num)) return MAL_EWORKSPACE;
-  DynParams p = {};
-  p.mask_last = mask_last; p.mask_next = mask_next; p.num = num; p.C = C; p.H = H; p.W = W; p.replace = replace;
-  p.img_last = img_last; p.img_next = img_next; p.ori_last = ori_last; p.ori_next = ori_next;
-  p.ext = (int*)ws; p.delta = delta; p.flags = flags;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(dyn_extents_kernel, dim3(num, 2), dim3(1024), (size_t)(H + W + 4) * sizeof(int), st, p);
-  hipLaunchKernelGGL(dyn_delta_kernel, dim3(1), dim3(64), 0, st, p);
-  hipLaunchKernelGGL(dyn_synth_fwd_kernel, dim3((H * W + 255) / 256), dim3(256), (size_t)num * 2 * sizeof(int), st, p);
-  return launch_status();
+  mal_dyn_item a = {};
+  a.mask_last = mask_last; a.mask_next = mask_next; a.num = num; a.img_last = img_last; a.img_next = img_next;
+  a.ori_last = ori_last; a.ori_next = ori_next; a.delta = delta; a.flags = flags; a.ws = ws; a.ws_bytes = ws_bytes;
+  return dyn_fwd_chunk(&a, 1, C, H, W, replace, (hipStream_t)stream);
 }
 
 extern "C" int mal_dyn_instance_bwd(const uint8_t* mask_last, const uint8_t* mask_next, int num, const int32_t* delta,
                                     const uint8_t* flags, const float* g_ori_last, const float* g_ori_next, int C, int H,
                                     int W, float* g_img_last, float* g_img_next, void* stream) {
-  int rc = dyn_check(num, C, H, W);
-  if (rc) return rc;
-  if (!mask_last || !mask_next || !delta || !flags || !g_ori_last || !g_ori_next || (!g_img_last && !g_img_next))
-    return MAL_EINVAL;
-  DynParams p = {};
-  p.mask_last = mask_last; p.mask_next = mask_next; p.num = num; p.C = C; p.H = H; p.W = W;
-  p.delta = const_cast<int*>(delta); p.flags = const_cast<uint8_t*>(flags);
-  p.g_ori_last = g_ori_last; p.g_ori_next = g_ori_next; p.g_img_last = g_img_last; p.g_img_next = g_img_next;
-  hipLaunchKernelGGL(dyn_synth_bwd_kernel, dim3((H * W + 255) / 256), dim3(256), (size_t)num * 2 * sizeof(int),
-                     (hipStream_t)stream, p);
-  return launch_status();
+  mal_dyn_item a = {};
+  a.mask_last = mask_last; a.mask_next = mask_next; a.num = num; a.delta = const_cast<int32_t*>(delta);
+  a.flags = const_cast<uint8_t*>(flags); a.g_ori_last = g_ori_last; a.g_ori_next = g_ori_next;
+  a.g_img_last = g_img_last; a.g_img_next = g_img_next;
+  return dyn_bwd_chunk(&a, 1, C, H, W, (hipStream_t)stream);
 }

@@ -94,8 +94,12 @@ class BatchSynthesisFn(Function):
         dev = cl.device
         syn_last, syn_next = cl.clone(), cn.clone()
         lib, p = L.load(), ops._p
+        if not items:
+            ctx.saved, ctx.dims = [], (C, H, W)
+            return syn_last, syn_next
+        arr = (L.DynItem * len(items))()
         saved = []
-        for b, mask_last, mask_next in items:
+        for k, (b, mask_last, mask_next) in enumerate(items):
             if mask_last.shape != mask_next.shape or mask_last.dim() != 3 or tuple(mask_last.shape[1:]) != (H, W):
                 raise L.MalError("image_synthesis: masks must be two (num,H,W) tensors matching the images")
             num = mask_last.shape[0]
@@ -103,10 +107,13 @@ class BatchSynthesisFn(Function):
             delta = torch.empty(num, 2, dtype=torch.int32, device=dev)
             flags = torch.empty(H, W, dtype=torch.uint8, device=dev)
             ws = torch.empty(lib.mal_dyn_workspace_bytes(num), dtype=torch.uint8, device=dev)
-            L.check(lib.mal_dyn_instance_fwd(p(ml), p(mn), num, p(cl[b]), p(cn[b]), C, H, W, 1 if replace else 0,
-                                             p(syn_last[b]), p(syn_next[b]), p(delta), p(flags), p(ws), ws.numel(),
-                                             ops._stream()), "mal_dyn_instance_fwd")
-            saved.append((b, ml, mn, num, delta, flags))
+            a = arr[k]
+            a.mask_last, a.mask_next, a.num = p(ml), p(mn), num
+            a.img_last, a.img_next, a.ori_last, a.ori_next = p(cl[b]), p(cn[b]), p(syn_last[b]), p(syn_next[b])
+            a.delta, a.flags, a.ws, a.ws_bytes = p(delta), p(flags), p(ws), ws.numel()
+            saved.append((b, ml, mn, num, delta, flags, ws))
+        # all samples in one call: three launches (extents, displacements, synthesis) for up to 16 samples
+        L.check(lib.mal_dyn_batch_fwd(arr, len(items), C, H, W, 1 if replace else 0, ops._stream()), "mal_dyn_batch_fwd")
         ctx.saved, ctx.dims = saved, (C, H, W)
         return syn_last, syn_next
 
@@ -116,10 +123,15 @@ class BatchSynthesisFn(Function):
         C, H, W = ctx.dims
         g_last, g_next = g_last.contiguous(), g_next.contiguous()
         gl, gn = g_last.clone(), g_next.clone()  # samples without instances: the identity
+        if not ctx.saved:
+            return gl, gn, None, None
         lib, p = L.load(), ops._p
-        for b, ml, mn, num, delta, flags in ctx.saved:
-            L.check(lib.mal_dyn_instance_bwd(p(ml), p(mn), num, p(delta), p(flags), p(g_last[b]), p(g_next[b]), C, H, W,
-                                             p(gl[b]), p(gn[b]), ops._stream()), "mal_dyn_instance_bwd")
+        arr = (L.DynItem * len(ctx.saved))()
+        for k, (b, ml, mn, num, delta, flags, ws) in enumerate(ctx.saved):
+            a = arr[k]
+            a.mask_last, a.mask_next, a.num, a.delta, a.flags = p(ml), p(mn), num, p(delta), p(flags)
+            a.g_ori_last, a.g_ori_next, a.g_img_last, a.g_img_next = p(g_last[b]), p(g_next[b]), p(gl[b]), p(gn[b])
+        L.check(lib.mal_dyn_batch_bwd(arr, len(ctx.saved), C, H, W, ops._stream()), "mal_dyn_batch_bwd")
         return gl, gn, None, None
 
 
