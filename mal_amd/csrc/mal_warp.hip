@@ -160,13 +160,23 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpParams p) {
 }
 
 // g_T[f][b] = K_b^T [sum_blocks gP_fb ; 0]
-__global__ __launch_bounds__(64) void pose_grad_finalize_kernel(const float* block_gP, const float* K, int bps, int F,
-                                                                float* gT0, float* gT1) {
+__global__ __launch_bounds__(256) void pose_grad_finalize_kernel(const float* block_gP, const float* K, int bps, int F,
+                                                                 float* gT0, float* gT1) {
   __shared__ double s_gP[24];
+  __shared__ double s_part[240];
   const int b = blockIdx.x, tid = threadIdx.x;
+  // 24 sums of bps partials: 10 threads per value (independent loads issued together), then a 10-term sum, fixed order
+  if (tid < 240) {
+    const int v = tid % 24, sub = tid / 24;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int t = sub; t < bps; t += 10) acc += (double)block_gP[((size_t)b * bps + t) * 24 + v];
+    s_part[tid] = acc;
+  }
+  __syncthreads();
   if (tid < 24) {
     double acc = 0.0;
-    for (int t = 0; t < bps; ++t) acc += (double)block_gP[((size_t)b * bps + t) * 24 + tid];
+    for (int k = 0; k < 10; ++k) acc += s_part[k * 24 + tid];
     s_gP[tid] = acc;
   }
   __syncthreads();
@@ -462,7 +472,7 @@ extern "C" int mal_warp_bwd(const float* disp, const float* K, const float* inv_
   else hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3(p.bps * B), dim3(256), 0, st, p);
   rc = launch_status();
   if (rc || !pose) return rc;
-  hipLaunchKernelGGL(pose_grad_finalize_kernel, dim3(B), dim3(64), 0, st, w.block_gP, K, p.bps, F, g_T[0],
+  hipLaunchKernelGGL(pose_grad_finalize_kernel, dim3(B), dim3(256), 0, st, w.block_gP, K, p.bps, F, g_T[0],
                      F > 1 ? g_T[1] : nullptr);
   return launch_status();
 }
@@ -530,7 +540,7 @@ extern "C" int mal_project3d_bwd(const float* points, const float* K, const floa
   hipLaunchKernelGGL(project_kernel<true>, dim3(p.bps * B), dim3(256), 0, st, p);
   rc = launch_status();
   if (rc || !g_T) return rc;
-  hipLaunchKernelGGL(pose_grad_finalize_kernel, dim3(B), dim3(64), 0, st, w.block_gP, K, p.bps, 1, g_T, nullptr);
+  hipLaunchKernelGGL(pose_grad_finalize_kernel, dim3(B), dim3(256), 0, st, w.block_gP, K, p.bps, 1, g_T, nullptr);
   return launch_status();
 }
 
