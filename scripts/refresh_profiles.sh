@@ -11,4 +11,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o p -- python3 $R/scripts/gpu_step_target.py > $O/fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o p -- python3 $R/scripts/gpu_step_target.py > $O/write.log 2>&1 || exit 1
 cd $R && python scripts/make_traffic.py $O/fetch/p_counter_collection.csv $O/write/p_counter_collection.csv $O/traffic.json > /dev/null
+# bench.py read profiles/traffic.json of the PREVIOUS refresh: put this run's counter value into this run's line
+python - "$O" <<'PY'
+import json, sys
+o = sys.argv[1]
+d = json.loads(open(o + "/bench.json").read().strip().splitlines()[-1])
+d["roofline"]["traffic"] = json.load(open(o + "/traffic.json"))["pass_kernel_teacher_bytes_per_launch"]
+json.dump(d, open(o + "/bench.json", "w"))
+PY
 cat $O/bench.json
