@@ -1,0 +1,82 @@
+"""TEST INFRASTRUCTURE (authoring container only): golden vectors of DualRefine's epipolar correlation lookup from the
+REFERENCE's own classes -> tests/golden/epi_*.npz.
+
+``dualrefine/networks/__init__.py`` imports the never-committed ``networks/lib``, so the package is
+registered as a bare namespace and the two module files that hold this path -- ``networks/utils/utils.py``
+(``Reprojections``) and ``networks/corr.py`` (``CoordSampler``) -- are imported on their own; nothing of them is
+modified or stood in for.  Run: python -m oracle.gen_golden_epi
+"""
+import importlib
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def reference_modules():
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import dualrefine  # noqa: F401
+    if "dualrefine.networks" not in sys.modules:
+        pkg = types.ModuleType("dualrefine.networks")
+        pkg.__path__ = [os.path.join(REF, "dualrefine", "networks")]
+        sys.modules["dualrefine.networks"] = pkg
+    return (importlib.import_module("dualrefine.networks.utils.utils"), importlib.import_module("dualrefine.networks.corr"))
+
+
+def make_case(B, C, h, w, seed, trans=0.15):
+    g = torch.Generator().manual_seed(seed)
+    K = torch.eye(4).repeat(B, 1, 1)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = 0.58 * w, 1.92 * h, 0.5 * w, 0.5 * h
+    low = torch.nn.functional.interpolate(torch.rand(B, 1, max(h // 4, 2), max(w // 4, 2), generator=g), size=(h, w),
+                                          mode="bilinear", align_corners=False)
+    depth = (1.0 + 8.0 * low).contiguous()
+    poses = torch.eye(4).repeat(B, 1, 1)
+    poses[:, :3, 3] = trans * torch.randn(B, 3, generator=g)
+    ang = 0.02 * torch.randn(B, generator=g)
+    poses[:, 0, 0], poses[:, 0, 2], poses[:, 2, 0], poses[:, 2, 2] = torch.cos(ang), torch.sin(ang), -torch.sin(ang), torch.cos(ang)
+    # features quantised to fp16-representable values so the fixture stores them exactly in half the bytes
+    f1 = torch.randn(B, C, h, w, generator=g).half().float()
+    f2 = torch.randn(B, C, h, w, generator=g).half().float()
+    return K, depth, poses, f1, f2
+
+
+CASES = {  # tag: (B, C, h, w, r, levels, heads, gap_factor, seed)
+    "epi_b2_c16_12x20_r4_l3": (2, 16, 12, 20, 4, 3, 1, "depth", 11),
+    "epi_b1_c8_9x13_r2_l2_h2": (1, 8, 9, 13, 2, 2, 2, "depth", 12),
+}
+
+
+def main():
+    U, Cn = reference_modules()
+    os.makedirs(OUT, exist_ok=True)
+    for tag, (B, C, h, w, r, L, heads, gf, seed) in CASES.items():
+        K, depth, poses, f1, f2 = make_case(B, C, h, w, seed)
+        args = SimpleNamespace(corr_radius=r, disable_pose_updates=True, gap_factor=gf, gap_factor_depth_ratio=8, num_levels=L,
+                               min_depth=0.1, max_depth=100.0, use_depth_bins_for_masking=False)
+        R = U.Reprojections(args)
+        with torch.no_grad():
+            R.delta.fill_(0.7)
+        R._reg_intrinsics(K)
+        R.update_depth_bins(9.0, 1.0, 4.0, 4.0)
+        S = Cn.CoordSampler(args)
+        with torch.no_grad():
+            c, max_dx, ds = R.depth2epipolarcoords(poses, depth)
+            S.register(f1, f2, num_levels=L)
+            corr = S(c, L, heads)
+        np.savez_compressed(os.path.join(OUT, tag + ".npz"), **{
+            "in/K": K.numpy(), "in/depth": depth.numpy(), "in/poses": poses.numpy(), "in/f1": f1.half().numpy(),
+            "in/f2": f2.half().numpy(), "in/meta": np.array([r, L, heads, 1 if gf == "minmax" else 0], dtype=np.int64),
+            "in/delta": np.float32(0.7), "in/minmax": np.array([9.0, 1.0], dtype=np.float32),
+            "out/coords": c.numpy(), "out/max_dx": max_dx.numpy(), "out/depths": ds.numpy(), "out/corr": corr.numpy()})
+        print(tag, tuple(c.shape), tuple(corr.shape), float(corr.mean()))
+
+
+if __name__ == "__main__":
+    main()

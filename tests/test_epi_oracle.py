@@ -1,0 +1,28 @@
+"""The N4 oracle (oracle/epi_oracle.py: DualRefine's epipolar correlation lookup, forward) reproduces the golden vectors
+made by the reference's own Reprojections / CoordSampler (oracle/gen_golden_epi.py) bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import epi_oracle as E
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["epi_b2_c16_12x20_r4_l3", "epi_b1_c8_9x13_r2_l2_h2"]
+
+
+def load(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    t = lambda k: torch.from_numpy(z[k].astype(np.float32))
+    r, L, heads, _ = (int(v) for v in z["in/meta"])
+    return z, t("in/K"), t("in/depth"), t("in/poses"), t("in/f1"), t("in/f2"), r, L, heads, torch.tensor([float(z["in/delta"])])
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_oracle_reproduces_reference(tag):
+    z, K, depth, poses, f1, f2, r, L, heads, delta = load(tag)
+    c, max_dx, ds = E.depth2epipolarcoords(poses, depth, K, delta, r=r, num_levels=L)
+    corr = E.coord_sample(f1, E.pyramid(f2, L), c, L, heads)
+    for got, key in ((c, "out/coords"), (max_dx, "out/max_dx"), (ds, "out/depths"), (corr, "out/corr")):
+        assert np.array_equal(got.numpy(), z[key]), key
