@@ -307,6 +307,19 @@ int mal_cost_volume(const float* current_feats, const float* lookup_feats, const
                     int set_missing_to_max, float* cost_volume, float* missing_mask, float* masked_cost_volume,
                     float* lowest_cost, float* confidence_mask, void* stream);
 
+/* ---- N4 (forward): DualRefine's epipolar correlation lookup, dualrefine/networks/depth_pose.py:433-435.
+ * mal_epipolar_coords = Reprojections.depth2epipolarcoords (dualrefine/networks/utils/utils.py:180-217, --gap_factor
+ * depth): depth (B,1,h,w), poses (B,16) relative poses, K (B,16) at that resolution, r = --corr_radius, L = --num_levels
+ * (<= 4), softplus_delta = softplus of the module's learnable delta, ratio = --gap_factor_depth_ratio ->
+ * coords (B,2,L,2r+1,h,w) pixel coordinates in the other view, max_dx (B,1,h,w), depths (B,1,L*(2r+1),h,w).
+ * mal_coord_sample_l1 = CoordSampler.__call__ (dualrefine/networks/corr.py:25-50): fmap1 (B,C,h,w), f2_pyramid[l]
+ * (B,C,h>>l,w>>l) (avg_pool2d(2,2) levels, corr.py:19-23), coords as above with d1 hypotheses per level ->
+ * out (B, L*heads*d1, h, w): per level and channel group (heads) the mean of |fmap1 - bilinear zero-padded sample|. */
+int mal_epipolar_coords(const float* depth, const float* poses, const float* K, int B, int h, int w, int r, int L,
+                        float softplus_delta, float ratio, float* coords, float* max_dx, float* depths, void* stream);
+int mal_coord_sample_l1(const float* fmap1, const float* const* f2_pyramid, const float* coords, int B, int C, int h, int w,
+                        int L, int d1, int heads, float* out, void* stream);
+
 /* ---- library options:
  * "pass_impl"   formulation of the fused pass: 1 = register-marching (default); 0 / 2 = the LDS-tiled first
  *               versions (256 threads x 4 px, 512 threads x 2 px), kept for A/B;

@@ -1,0 +1,35 @@
+"""Epipolar correlation lookup (N4, forward) at DualRefine's size: B=8, 128 channels, 48x160 (192x640 / 4), radius 8,
+3 levels = 51 hypotheses per pixel.  HIP (mal_epipolar_coords + mal_coord_sample_l1 through mal_amd.epipolar) vs the CPU
+checker (the reference's formulation, oracle/epi_oracle.py)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from types import SimpleNamespace
+import torch
+from mal_amd import epipolar
+from oracle import epi_oracle as E
+from oracle.gen_golden_epi import make_case
+B, C, h, w, r, L = 8, 128, 48, 160, 8, 3
+K, depth, poses, f1, f2 = make_case(B, C, h, w, seed=3)
+dev = torch.device("cuda:0")
+args = SimpleNamespace(corr_radius=r, disable_pose_updates=True, gap_factor="depth", gap_factor_depth_ratio=8, num_levels=L)
+R = epipolar.Reprojections(args).to(dev)
+S = epipolar.CoordSampler(args)
+g = [t.to(dev) for t in (K, depth, poses, f1, f2)]
+with torch.no_grad():
+    R._reg_intrinsics(g[0])
+    S.register(g[3], g[4], num_levels=L)
+    def hip():
+        c, max_dx, ds = R.depth2epipolarcoords(g[2], g[1])
+        return S(c, L, 1)
+    for _ in range(3): hip()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20): hip()
+    torch.cuda.synchronize(); th = (time.perf_counter() - t) / 20
+    t = time.perf_counter()
+    rc, _, _ = E.depth2epipolarcoords(poses, depth, K, torch.tensor([1.0]), r=r, num_levels=L)
+    E.coord_sample(f1, E.pyramid(f2, L), rc, L, 1)
+    tc = time.perf_counter() - t
+D = L * (2 * r + 1)
+alg = B * h * w * (2 * C * 4 + D * 4 + 2 * D * 4 + 4)  # both feature maps once, the correlation, the coordinates
+print("HIP %.0f us (%.1f GB/s algorithmic; %d (pixel,hypothesis) pairs -> %.1f G pair-channels/s)   CPU checker %.2f s (%d threads)" %
+      (th * 1e6, alg / th / 1e9, B * h * w * D, B * h * w * D * C / th / 1e9, tc, torch.get_num_threads()))
