@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void epi_sample_kernel(EpiSampleParams p) {
     float sum[kEpiG];
 #pragma unroll
     for (int g = 0; g < kEpiG; ++g) sum[g] = 0.f;
-#pragma unroll 2
+#pragma unroll 4  // more planes' taps in flight (the channel count is a run-time value: no automatic unrolling)
     for (int c = head * cg; c < (head + 1) * cg; ++c) {
       const float f1 = p.fmap1[((size_t)b * p.C + c) * hw + pix];
       const char* pl = reinterpret_cast<const char*>(f2l + ((size_t)b * p.C + c) * hwl);
