@@ -86,3 +86,81 @@ def coord_sample(fmap1, f2_pyramid, coords, num_levels=1, num_head=1):
         corr = torch.abs(f1 - f2).view(batch, num_head, -1, h1, w1, d1).mean(2)
         outs.append(corr.permute(0, 2, 3, 1, 4).reshape(batch, h1, w1, -1))
     return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+
+
+# ---------------------------------------------------------------- pose refinement step (forward)
+def depth2gradcoords(poses, depths, K):
+    """utils.py:219-236 -> (c1 (B,2,1,5,h,w): the projection and its +-1 px neighbours in x and y, X1 (B,4,h*w))"""
+    bsz, _, ht, wd = depths.shape
+    X0 = iproj(depths[:, None], K)
+    X1 = poses.type(X0.dtype) @ X0.reshape(bsz, 4, -1)
+    c1 = proj(X1, K).reshape(bsz, 2, 1, 1, ht, wd)
+    p_dx = torch.tensor([1., 0.]).reshape(1, 2, 1, 1, 1, 1)
+    p_dy = torch.tensor([0., 1.]).reshape(1, 2, 1, 1, 1, 1)
+    return torch.cat([c1, c1 + torch.cat([p_dx, -p_dx, p_dy, -p_dy], 3)], 3), X1
+
+
+def se3_exp(vec):
+    """dualrefine/layers.py:29-55"""
+    rho, phi = vec[:, :3], vec[:, 3:]
+    theta = torch.norm(phi, 2, 1, keepdim=True)
+    a = phi / theta
+    a_skew = torch.zeros((vec.shape[0], 3, 3))
+    a_skew[:, 0, 1] = -a[:, 2, 0]
+    a_skew[:, 0, 2] = a[:, 1, 0]
+    a_skew[:, 1, 0] = a[:, 2, 0]
+    a_skew[:, 1, 2] = -a[:, 0, 0]
+    a_skew[:, 2, 0] = -a[:, 1, 0]
+    a_skew[:, 2, 1] = a[:, 0, 0]
+    eye = torch.eye(3).unsqueeze(0)
+    aat = torch.bmm(a, a.permute(0, 2, 1))
+    R = torch.cos(theta) * eye + (1 - torch.cos(theta)) * aat + torch.sin(theta) * a_skew
+    J = (torch.sin(theta) / theta) * eye + (1 - (torch.sin(theta) / theta)) * aat + (1 - torch.cos(theta)) / theta * a_skew
+    T = torch.eye(4).unsqueeze(0).repeat(vec.shape[0], 1, 1)
+    T[:, :3, :3] = R
+    T[:, :3, -1:] = torch.bmm(J, rho.type(J.dtype))
+    return T
+
+
+def sample_tgt(tgt_feat, tgt_w, p2):
+    """utils.py:370-392 -> (warped features (B,C,h,w), their central-difference gradients (B,C,h,w,2), warped weight)"""
+    batch, _, n1, d1, h1, w1 = p2.shape
+    p2 = p2.permute(2, 0, 4, 5, 3, 1).reshape(batch, h1 * w1, d1, 2)
+    xg, yg = p2.split([1, 1], dim=-1)
+    grid = torch.cat([2 * (xg + 0.5) / w1 - 1, 2 * (yg + 0.5) / h1 - 1], dim=-1)
+    f = F.grid_sample(tgt_feat, grid, align_corners=False).view(batch, -1, h1, w1, d1)
+    grads = torch.stack([(f[..., 1] - f[..., 2]) / 2, (f[..., 3] - f[..., 4]) / 2], dim=-1)
+    w = F.grid_sample(tgt_w, grid[:, :, :1], align_corners=False).reshape(batch, 1, h1, w1)
+    return f[..., 0], grads, w
+
+
+def normal_equations(src_feat, tgt_feat, src_w, tgt_w, K, p2, P2, weight=None):
+    """utils.py:303-355 up to the solve (without --robust_pose_loss, the default): H (B,6,6), b (B,6)"""
+    batch_size, channels, height, width = src_feat.shape
+    warped, grads, warped_w = sample_tgt(tgt_feat, tgt_w, p2)
+    X, Y, Z = P2[:, 0], P2[:, 1], P2[:, 2]
+    fx, fy = K[:, 0, 0].reshape(-1, 1), K[:, 1, 1].reshape(-1, 1)
+    fxz, fyz = fx / Z, fy / Z
+    fxxz2, fyyz2 = fxz * X / Z, fyz * Y / Z
+    zeros = torch.zeros(fxxz2.shape)
+    J_pixel_xi = torch.stack((torch.stack((fxz, zeros, -fxxz2, -fxxz2 * Y, fx + fxxz2 * X, -fxz * Y), 1),
+                              torch.stack((zeros, fyz, -fyyz2, -fy - fyyz2 * Y, fyyz2 * X, fyz * X), 1)), 1)
+    J_pixel_xi = J_pixel_xi.permute(0, 3, 1, 2)
+    J_img_pixel = grads.reshape(batch_size, channels, height * width, 2).permute(0, 2, 1, 3)
+    J = -J_img_pixel @ J_pixel_xi
+    res = (src_feat - warped).permute(0, 2, 3, 1).reshape(-1, height * width, channels, 1)
+    w = src_w * warped_w
+    if weight is not None:
+        w = w * weight
+    JW = J * w.reshape(batch_size, height * width, 1, 1)
+    H = (JW.transpose(2, 3) @ J).sum(1)
+    b = (-res * JW).sum(2).sum(1)
+    return H, b
+
+
+def direct_align(poses, src_feat, tgt_feat, src_w, tgt_w, K, p2, P2, weight=None):
+    """utils.py:303-368: one Gauss-Newton step on the feature-metric error -> (new poses (B,4,4), update (B,6,1))"""
+    H, b = normal_equations(src_feat, tgt_feat, src_w, tgt_w, K, p2, P2, weight)
+    L = torch.linalg.cholesky(H)
+    update = torch.cholesky_solve(b[..., None], L)
+    return torch.bmm(se3_exp(update).type(poses.dtype), poses), update

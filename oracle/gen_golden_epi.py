@@ -76,6 +76,23 @@ def main():
             "in/delta": np.float32(0.7), "in/minmax": np.array([9.0, 1.0], dtype=np.float32),
             "out/coords": c.numpy(), "out/max_dx": max_dx.numpy(), "out/depths": ds.numpy(), "out/corr": corr.numpy()})
         print(tag, tuple(c.shape), tuple(corr.shape), float(corr.mean()))
+        # pose refinement step (utils.py:219-236, 303-368): PoseUpdate.direct_align without --robust_pose_loss
+        g2 = torch.Generator().manual_seed(seed + 100)
+        f2s = (0.8 * f1 + 0.2 * f2).half().float()  # a target that resembles the source, so the step is well conditioned
+        src_w, tgt_w = 0.5 + torch.rand(B, 1, h, w, generator=g2), 0.5 + torch.rand(B, 1, h, w, generator=g2)
+        weight = 0.5 + torch.rand(B, 1, h, w, generator=g2)
+        args.disable_fixed_pose_weight, args.robust_pose_loss, args.mixed_precision = True, False, False
+        P = U.PoseUpdate(args, C, norm_fn="none")
+        with torch.no_grad():
+            c_p, P2 = R.depth2gradcoords(poses, depth, K)
+            P.compute_feat(f1, f2s)
+            P.src_w, P.tgt_w = src_w.clone(), tgt_w.clone()
+            new_poses, update = P.direct_align(poses, K, c_p, P2, weight.clone())
+        np.savez_compressed(os.path.join(OUT, tag.replace("epi_", "epi_align_") + ".npz"), **{
+            "in/K": K.numpy(), "in/depth": depth.numpy(), "in/poses": poses.numpy(), "in/f1": f1.half().numpy(),
+            "in/f2": f2s.half().numpy(), "in/src_w": src_w.numpy(), "in/tgt_w": tgt_w.numpy(), "in/weight": weight.numpy(),
+            "out/c_p": c_p.numpy(), "out/P2": P2.numpy(), "out/new_poses": new_poses.numpy(), "out/update": update.numpy()})
+        print("  align", tuple(c_p.shape), update.flatten()[:3].tolist())
 
 
 if __name__ == "__main__":

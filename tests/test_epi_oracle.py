@@ -26,3 +26,22 @@ def test_oracle_reproduces_reference(tag):
     corr = E.coord_sample(f1, E.pyramid(f2, L), c, L, heads)
     for got, key in ((c, "out/coords"), (max_dx, "out/max_dx"), (ds, "out/depths"), (corr, "out/corr")):
         assert np.array_equal(got.numpy(), z[key]), key
+
+
+ALIGN_CASES = ["epi_align_b2_c16_12x20_r4_l3", "epi_align_b1_c8_9x13_r2_l2_h2"]
+
+
+def load_align(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    t = lambda k: torch.from_numpy(z[k].astype(np.float32))
+    return z, {k[3:]: t(k) for k in z.files if k.startswith("in/")}
+
+
+@pytest.mark.parametrize("tag", ALIGN_CASES)
+def test_direct_align_oracle_reproduces_reference(tag):
+    """PoseUpdate.direct_align (utils.py:303-368) through depth2gradcoords (:219-236): bit for bit"""
+    z, i = load_align(tag)
+    c_p, P2 = E.depth2gradcoords(i["poses"], i["depth"], i["K"])
+    new_poses, update = E.direct_align(i["poses"], i["f1"], i["f2"], i["src_w"], i["tgt_w"], i["K"], c_p, P2, i["weight"])
+    for got, key in ((c_p, "out/c_p"), (P2, "out/P2"), (update, "out/update"), (new_poses, "out/new_poses")):
+        assert np.array_equal(got.numpy(), z[key]), key
