@@ -319,6 +319,20 @@ int mal_epipolar_coords(const float* depth, const float* poses, const float* K, 
                         float softplus_delta, float ratio, float* coords, float* max_dx, float* depths, void* stream);
 int mal_coord_sample_l1(const float* fmap1, const float* const* f2_pyramid, const float* coords, int B, int C, int h, int w,
                         int L, int d1, int heads, float* out, void* stream);
+/* The pose refinement step of the same loop (depth_pose.py:450-455), forward:
+ * mal_epipolar_gradcoords = Reprojections.depth2gradcoords (utils.py:219-236): c_p (B,2,1,5,h,w) = the projection and its
+ * +-1 px neighbours in x and y, P2 (B,4,h*w) = the transformed points.
+ * mal_direct_align_normal_eq = PoseUpdate.direct_align up to the solve (utils.py:303-355, without --robust_pose_loss):
+ * src_feat / tgt_feat (B,C,h,w), src_w / tgt_w (B,1,h,w) (tgt_w is sampled at the projection as :388-390), weight (B,1,h,w)
+ * nullable, K (B,16), p2 = c_p, P2 as above -> H (B,6,6) = sum_px w J^T J and b (B,6) = sum_px -res w J of the
+ * feature-metric Gauss-Newton step; ws: mal_direct_align_workspace_bytes(B,h,w).  The 6x6 solve and the se3 update are
+ * the caller's (torch.linalg on the device in mal_amd/epipolar.py). */
+int mal_epipolar_gradcoords(const float* depth, const float* poses, const float* K, int B, int h, int w, float* c_p, float* P2,
+                            void* stream);
+size_t mal_direct_align_workspace_bytes(int B, int h, int w);
+int mal_direct_align_normal_eq(const float* src_feat, const float* tgt_feat, const float* src_w, const float* tgt_w,
+                               const float* weight, const float* K, const float* p2, const float* P2, int B, int C, int h, int w,
+                               float* H, float* b, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- library options:
  * "pass_impl"   formulation of the fused pass: 1 = register-marching (default); 0 / 2 = the LDS-tiled first

@@ -137,9 +137,190 @@ __global__ __launch_bounds__(256) void epi_sample_kernel(EpiSampleParams p) {
   }
 }
 
+// ---------------------------------------------------------------- pose refinement step (forward)
+struct EpiGradCoordParams {
+  const float* depth; const float* poses; const float* K;
+  int B, h, w;
+  float* c_p;  // (B,2,1,5,h,w): projection, +x, -x, +y, -y
+  float* P2;   // (B,4,h*w): the transformed points
+};
+
+// Reprojections.depth2gradcoords, utils.py:219-236
+__global__ __launch_bounds__(256) void epi_gradcoords_kernel(EpiGradCoordParams p) {
+  const int hw = p.h * p.w;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * hw) return;
+  const int b = i / hw, pix = i - b * hw, y = pix / p.w, x = pix - y * p.w;
+  const float* Kb = p.K + b * 16;
+  const float* T = p.poses + b * 16;
+  const float fx = Kb[0], fy = Kb[5], cx = Kb[2], cy = Kb[6];
+  const float Z = p.depth[i];
+  const float X = div_((float)x - cx, fx), Y = div_((float)y - cy, fy);
+  const float X0[4] = {Z * X, Z * Y, Z, 1.0f};
+  float X1[4];
+  for (int r_ = 0; r_ < 4; ++r_) {
+    float acc = T[r_ * 4] * X0[0];
+    acc = fma_(T[r_ * 4 + 1], X0[1], acc);
+    acc = fma_(T[r_ * 4 + 2], X0[2], acc);
+    X1[r_] = fma_(T[r_ * 4 + 3], X0[3], acc);
+    p.P2[((size_t)b * 4 + r_) * hw + pix] = X1[r_];
+  }
+  const float inv = div_(1.0f, X1[2]);
+  const float d = inv > 100.0f ? 100.0f : inv;
+  const float u = fx * (X1[0] * d) + cx, v = fy * (X1[1] * d) + cy;
+  const float du[5] = {0.f, 1.f, -1.f, 0.f, 0.f}, dv[5] = {0.f, 0.f, 0.f, 1.f, -1.f};
+  for (int k = 0; k < 5; ++k) {
+    p.c_p[(((size_t)b * 2 + 0) * 5 + k) * hw + pix] = u + du[k];
+    p.c_p[(((size_t)b * 2 + 1) * 5 + k) * hw + pix] = v + dv[k];
+  }
+}
+
+struct EpiAlignParams {
+  const float* src; const float* tgt;      // (B,C,h,w)
+  const float* src_w; const float* tgt_w;  // (B,1,h,w)
+  const float* weight;                     // (B,1,h,w) nullable
+  const float* K; const float* p2; const float* P2;
+  int B, C, h, w, nblk;                    // nblk = workgroups per sample
+  double* partial;                         // [B][nblk][27]
+  float* H; float* bvec;                   // (B,36), (B,6)
+};
+
+struct Tap4 { unsigned o[4]; float w[4]; };
+
+// bilinear, zero-padded, align_corners=False sample position (u, v) in pixels of an (h,w) map (corr.py:38-39 /
+// utils.py:374-379 + grid_sample's unnormalise)
+MAL_DEV Tap4 taps_at(float u, float v, int h, int w) {
+  Tap4 t;
+  const float gx = div_(2.0f * (u + 0.5f), (float)w) - 1.0f, gy = div_(2.0f * (v + 0.5f), (float)h) - 1.0f;
+  const float ix = ((gx + 1.0f) * (float)w - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)h - 1.0f) / 2.0f;
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float xc = fminf(fmaxf(x0f, -2.0f), (float)w + 1.0f), yc = fminf(fmaxf(y0f, -2.0f), (float)h + 1.0f);
+  const bool wild = !(x0f == xc && y0f == yc);
+  const int x0 = (int)xc, y0 = (int)yc, x1 = x0 + 1, y1 = y0 + 1;
+  const float tx = ix - x0f, ty = iy - y0f, ex = (x0f + 1.0f) - ix, ey = (y0f + 1.0f) - iy;
+  const bool vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w, vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
+  const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1), cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
+  t.o[0] = (unsigned)(cy0 * w + cx0) * 4u; t.o[1] = (unsigned)(cy0 * w + cx1) * 4u;
+  t.o[2] = (unsigned)(cy1 * w + cx0) * 4u; t.o[3] = (unsigned)(cy1 * w + cx1) * 4u;
+  t.w[0] = (!wild && vx0 && vy0) ? ex * ey : 0.f;
+  t.w[1] = (!wild && vx1 && vy0) ? tx * ey : 0.f;
+  t.w[2] = (!wild && vx0 && vy1) ? ex * ty : 0.f;
+  t.w[3] = (!wild && vx1 && vy1) ? tx * ty : 0.f;
+  return t;
+}
+MAL_DEV float sample4(const char* plane, const Tap4& t) {
+  float o = *reinterpret_cast<const float*>(plane + t.o[0]) * t.w[0];
+  o = fma_(*reinterpret_cast<const float*>(plane + t.o[1]), t.w[1], o);
+  o = fma_(*reinterpret_cast<const float*>(plane + t.o[2]), t.w[2], o);
+  return fma_(*reinterpret_cast<const float*>(plane + t.o[3]), t.w[3], o);
+}
+
+// PoseUpdate.direct_align up to the solve (utils.py:303-355, without --robust_pose_loss).  The reference materialises
+// J = -J_img J_pix (B,hw,C,6) and a 6x6 matrix per pixel; with J_c = -(gx_c a + gy_c b) (a, b: the two rows of the
+// projection Jacobian, gx_c, gy_c: the sampled central differences of channel c) the per-pixel sums over the channels are
+//   sum_c J_c J_c^T = Sxx a a^T + Sxy (a b^T + b a^T) + Syy b b^T,   sum_c r_c J_c = -(Srx a + Sry b)
+// so five channel sums per pixel suffice (lane = pixel, the channel loop gathers 5 positions x 4 taps), the 27 numbers
+// of the weighted normal equations are formed once per pixel and reduced over the sample in fixed order.
+__global__ __launch_bounds__(256) void epi_align_kernel(EpiAlignParams p) {
+  __shared__ double s_red[4][27];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hw = p.h * p.w, b = blockIdx.y;
+  const int pix_raw = blockIdx.x * 256 + threadIdx.x;
+  const bool live = pix_raw < hw;
+  const int pix = min(pix_raw, hw - 1);
+  Tap4 t[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    t[k] = taps_at(p.p2[(((size_t)b * 2 + 0) * 5 + k) * hw + pix], p.p2[(((size_t)b * 2 + 1) * 5 + k) * hw + pix], p.h, p.w);
+  float Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Srx = 0.f, Sry = 0.f;
+#pragma unroll 2
+  for (int c = 0; c < p.C; ++c) {
+    const char* pl = reinterpret_cast<const char*>(p.tgt + ((size_t)b * p.C + c) * hw);
+    const float f0 = sample4(pl, t[0]);
+    const float gx = (sample4(pl, t[1]) - sample4(pl, t[2])) / 2.0f, gy = (sample4(pl, t[3]) - sample4(pl, t[4])) / 2.0f;
+    const float r = p.src[((size_t)b * p.C + c) * hw + pix] - f0;
+    Sxx = fma_(gx, gx, Sxx); Sxy = fma_(gx, gy, Sxy); Syy = fma_(gy, gy, Syy);
+    Srx = fma_(r, gx, Srx); Sry = fma_(r, gy, Sry);
+  }
+  float wgt = p.src_w[(size_t)b * hw + pix] * sample4(reinterpret_cast<const char*>(p.tgt_w + (size_t)b * hw), t[0]);
+  if (p.weight) wgt *= p.weight[(size_t)b * hw + pix];
+  if (!live) wgt = 0.f;
+  const float X = p.P2[((size_t)b * 4 + 0) * hw + pix], Y = p.P2[((size_t)b * 4 + 1) * hw + pix], Z = p.P2[((size_t)b * 4 + 2) * hw + pix];
+  const float fx = p.K[b * 16], fy = p.K[b * 16 + 5];
+  const float fxz = div_(fx, Z), fyz = div_(fy, Z);
+  const float fxxz2 = div_(fxz * X, Z), fyyz2 = div_(fyz * Y, Z);
+  const float a[6] = {fxz, 0.f, -fxxz2, -fxxz2 * Y, fx + fxxz2 * X, -fxz * Y};
+  const float q[6] = {0.f, fyz, -fyyz2, -fy - fyyz2 * Y, fyyz2 * X, fyz * X};
+  float v27[27];
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j)
+      v27[n++] = wgt * (Sxx * (a[i] * a[j]) + Sxy * (a[i] * q[j] + q[i] * a[j]) + Syy * (q[i] * q[j]));
+#pragma unroll
+  for (int i = 0; i < 6; ++i) v27[21 + i] = wgt * (Srx * a[i] + Sry * q[i]);
+#pragma unroll
+  for (int i = 0; i < 27; ++i) {
+    const double s = wave_sum_d(live ? (double)v27[i] : 0.0);
+    if (lane == 0) s_red[wv][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27)
+    p.partial[((size_t)b * p.nblk + blockIdx.x) * 27 + threadIdx.x] =
+        (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void epi_align_finish_kernel(EpiAlignParams p) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ double s_v[27];
+  if (tid < 27) {
+    double acc = 0.0;
+    for (int k = 0; k < p.nblk; ++k) acc += p.partial[((size_t)b * p.nblk + k) * 27 + tid];
+    s_v[tid] = acc;
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int i = tid / 6, j = tid % 6, lo = min(i, j), hi = max(i, j);
+    const int idx = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);  // position of (lo, hi) in the upper triangle, row-major
+    p.H[b * 36 + tid] = (float)s_v[idx];
+  }
+  if (tid < 6) p.bvec[b * 6 + tid] = (float)s_v[21 + tid];
+}
+
 }  // namespace mal
 
 using namespace mal;
+
+extern "C" int mal_epipolar_gradcoords(const float* depth, const float* poses, const float* K, int B, int h, int w, float* c_p,
+                                       float* P2, void* stream) {
+  if (B <= 0 || h < 1 || w < 1 || (double)B * 10 * h * w > 2.0e9 / 4) return MAL_ESHAPE;
+  if (!depth || !poses || !K || !c_p || !P2) return MAL_EINVAL;
+  EpiGradCoordParams p = {depth, poses, K, B, h, w, c_p, P2};
+  hipLaunchKernelGGL(epi_gradcoords_kernel, dim3((B * h * w + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+extern "C" size_t mal_direct_align_workspace_bytes(int B, int h, int w) {
+  if (B <= 0 || h <= 0 || w <= 0) return 0;
+  return (size_t)B * ((h * w + 255) / 256) * 27 * sizeof(double);
+}
+
+extern "C" int mal_direct_align_normal_eq(const float* src_feat, const float* tgt_feat, const float* src_w, const float* tgt_w,
+                                          const float* weight, const float* K, const float* p2, const float* P2, int B, int C,
+                                          int h, int w, float* H, float* b, void* ws, size_t ws_bytes, void* stream) {
+  if (B <= 0 || C < 1 || h < 1 || w < 1 || (double)B * C * h * w > 2.0e9 / 4) return MAL_ESHAPE;
+  if (!src_feat || !tgt_feat || !src_w || !tgt_w || !K || !p2 || !P2 || !H || !b || !ws) return MAL_EINVAL;
+  if (ws_bytes < mal_direct_align_workspace_bytes(B, h, w)) return MAL_EWORKSPACE;
+  EpiAlignParams p = {};
+  p.src = src_feat; p.tgt = tgt_feat; p.src_w = src_w; p.tgt_w = tgt_w; p.weight = weight; p.K = K; p.p2 = p2; p.P2 = P2;
+  p.B = B; p.C = C; p.h = h; p.w = w; p.nblk = (h * w + 255) / 256; p.partial = (double*)ws; p.H = H; p.bvec = b;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(epi_align_kernel, dim3(p.nblk, B), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(epi_align_finish_kernel, dim3(B), dim3(64), 0, st, p);
+  return launch_status();
+}
+
 
 extern "C" int mal_epipolar_coords(const float* depth, const float* poses, const float* K, int B, int h, int w, int r, int L,
                                    float softplus_delta, float ratio, float* coords, float* max_dx, float* depths,

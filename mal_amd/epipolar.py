@@ -68,6 +68,102 @@ class Reprojections(torch.nn.Module):
         return coords, max_dx, ds
 
 
+    def depth2gradcoords(self, poses, depths, intrinsics=None):
+        """-> (c1 (B,2,1,5,h,w), X1 (B,4,h*w)), utils.py:219-236 (``intrinsics`` is unused upstream too: the registered
+        ones are)"""
+        if self.K is None:
+            raise L.MalError("Reprojections: call _reg_intrinsics(K) first (depth_pose.py:471)")
+        _no_grad(poses, depths)
+        d = ops._req(depths.detach(), "depths")
+        B, _, h, w = d.shape
+        T = ops._req(poses.detach().float().reshape(B, 16).contiguous(), "poses")
+        K = ops._req(self.K.detach().float().reshape(B, 16).contiguous(), "K")
+        c_p = torch.empty(B, 2, 1, 5, h, w, dtype=torch.float32, device=d.device)
+        P2 = torch.empty(B, 4, h * w, dtype=torch.float32, device=d.device)
+        p = ops._p
+        L.check(L.load().mal_epipolar_gradcoords(p(d), p(T), p(K), B, h, w, p(c_p), p(P2), ops._stream()),
+                "mal_epipolar_gradcoords")
+        return c_p, P2
+
+
+def se3_exp(vec):
+    """dualrefine/layers.py:29-55 (a handful of 3x3 tensor ops on (B,6,1): plain torch on the device)"""
+    rho, phi = vec[:, :3], vec[:, 3:]
+    theta = torch.norm(phi, 2, 1, keepdim=True)
+    a = phi / theta
+    a_skew = torch.zeros((vec.shape[0], 3, 3), device=vec.device)
+    a_skew[:, 0, 1] = -a[:, 2, 0]
+    a_skew[:, 0, 2] = a[:, 1, 0]
+    a_skew[:, 1, 0] = a[:, 2, 0]
+    a_skew[:, 1, 2] = -a[:, 0, 0]
+    a_skew[:, 2, 0] = -a[:, 1, 0]
+    a_skew[:, 2, 1] = a[:, 0, 0]
+    eye = torch.eye(3, device=vec.device).unsqueeze(0)
+    aat = torch.bmm(a, a.permute(0, 2, 1))
+    R = torch.cos(theta) * eye + (1 - torch.cos(theta)) * aat + torch.sin(theta) * a_skew
+    J = (torch.sin(theta) / theta) * eye + (1 - (torch.sin(theta) / theta)) * aat + (1 - torch.cos(theta)) / theta * a_skew
+    T = torch.eye(4, device=vec.device).unsqueeze(0).repeat(vec.shape[0], 1, 1)
+    T[:, :3, :3] = R
+    T[:, :3, -1:] = torch.bmm(J, rho.type(J.dtype))
+    return T
+
+
+class PoseUpdate(torch.nn.Module):
+    """The geometric half of utils.py:258-407: ``compute_feat``, the pixel weights and ``direct_align`` (one
+    feature-metric Gauss-Newton step).  The learned weight / feature heads of upstream's module (its ``weights`` and
+    ``feats`` convolution stacks) are networks and stay with the caller: assign ``src_w`` / ``tgt_w`` (B,1,h,w), or call
+    ``compute_uncertainty`` with ``--disable_fixed_pose_weight`` for ones, as upstream."""
+
+    def __init__(self, args, inp_dim=None, norm_fn="batch"):
+        super().__init__()
+        self.args = args
+        if getattr(args, "robust_pose_loss", False):
+            raise NotImplementedError("--robust_pose_loss (utils.py:334-338) is not built")
+
+    def compute_uncertainty(self, feats):
+        if not getattr(self.args, "disable_fixed_pose_weight", False):
+            raise NotImplementedError("the learned pose-weight head (utils.py:289-292) is a network: compute it with the "
+                                      "caller's module and assign src_w / tgt_w")
+        bsz, _, ht, wd = feats.shape
+        self.src_w, self.tgt_w = feats.new_ones((bsz // 2, 1, ht, wd)), feats.new_ones((bsz // 2, 1, ht, wd))
+
+    def compute_feat(self, fmap1, fmap2):
+        _no_grad(fmap1, fmap2)
+        self.src_feat, self.tgt_feat = fmap1.detach().float(), fmap2.detach().float()
+
+    def normal_equations(self, calib_K, p2, P2, weight):
+        """utils.py:303-355 -> H (B,6,6), b (B,6) in two launches"""
+        _no_grad(p2, P2, weight, self.src_w, self.tgt_w)
+        src, tgt = ops._req(self.src_feat, "src_feat"), ops._req(self.tgt_feat, "tgt_feat")
+        B, C, h, w = src.shape
+        dev = src.device
+        sw, tw = ops._req(self.src_w.detach().float(), "src_w"), ops._req(self.tgt_w.detach().float(), "tgt_w")
+        wt = ops._req(weight.detach().float(), "weight") if weight is not None else None
+        K = ops._req(calib_K.detach().float().reshape(B, 16).contiguous(), "K")
+        c, X1 = ops._req(p2.detach(), "p2"), ops._req(P2.detach(), "P2")
+        if tuple(c.shape) != (B, 2, 1, 5, h, w) or tuple(X1.shape) != (B, 4, h * w):
+            raise L.MalError("direct_align: p2 must be (B,2,1,5,h,w) and P2 (B,4,h*w) as depth2gradcoords returns them")
+        H, b = torch.empty(B, 6, 6, dtype=torch.float32, device=dev), torch.empty(B, 6, dtype=torch.float32, device=dev)
+        lib, p = L.load(), ops._p
+        ws = torch.empty(lib.mal_direct_align_workspace_bytes(B, h, w), dtype=torch.uint8, device=dev)
+        L.check(lib.mal_direct_align_normal_eq(p(src), p(tgt), p(sw), p(tw), p(wt), p(K), p(c), p(X1), B, C, h, w, p(H), p(b),
+                                               p(ws), ws.numel(), ops._stream()), "mal_direct_align_normal_eq")
+        return H, b
+
+    def direct_align(self, poses, calib_K, p2, P2, weight):
+        """utils.py:303-368 -> (new poses (B,4,4), update (B,6,1)); the fall-backs of :357-365 kept"""
+        H, b = self.normal_equations(calib_K, p2, P2, weight)
+        Lc, info = torch.linalg.cholesky_ex(H)
+        if bool((info != 0).any()) or bool(torch.isnan(Lc).any()):
+            try:
+                update = torch.linalg.solve(H, b[..., None])
+            except Exception:
+                return poses, poses
+        else:
+            update = torch.cholesky_solve(b[..., None], Lc)
+        return torch.bmm(se3_exp(update).type(poses.dtype), poses), update
+
+
 class CoordSampler(torch.nn.Module):
     """corr.py:6-50"""
 

@@ -33,3 +33,26 @@ D = L * (2 * r + 1)
 alg = B * h * w * (2 * C * 4 + D * 4 + 2 * D * 4 + 4)  # both feature maps once, the correlation, the coordinates
 print("HIP %.0f us (%.1f GB/s algorithmic; %d (pixel,hypothesis) pairs -> %.1f G pair-channels/s)   CPU checker %.2f s (%d threads)" %
       (th * 1e6, alg / th / 1e9, B * h * w * D, B * h * w * D * C / th / 1e9, tc, torch.get_num_threads()))
+
+# ---- the pose refinement step of the same loop: depth2gradcoords + direct_align
+g5 = torch.Generator().manual_seed(7)
+f2s = (0.8 * f1 + 0.2 * f2).half().float()
+src_w, tgt_w, weight = (0.5 + torch.rand(B, 1, h, w, generator=g5) for _ in range(3))
+args.disable_fixed_pose_weight, args.robust_pose_loss = True, False
+P = epipolar.PoseUpdate(args)
+with torch.no_grad():
+    P.compute_feat(g[3], f2s.to(dev))
+    P.src_w, P.tgt_w = src_w.to(dev), tgt_w.to(dev)
+    wd = weight.to(dev)
+    def align():
+        c_p, P2 = R.depth2gradcoords(g[2], g[1], g[0])
+        return P.direct_align(g[2], g[0], c_p, P2, wd)
+    for _ in range(3): align()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20): align()
+    torch.cuda.synchronize(); ta = (time.perf_counter() - t) / 20
+    t = time.perf_counter()
+    c_p, P2 = E.depth2gradcoords(poses, depth, K)
+    E.direct_align(poses, f1, f2s, src_w, tgt_w, K, c_p, P2, weight)
+    tca = time.perf_counter() - t
+print("direct_align: HIP %.0f us (incl. the 6x6 solve and se3 update in torch)   CPU checker %.2f s" % (ta * 1e6, tca))

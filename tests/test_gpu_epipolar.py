@@ -74,3 +74,55 @@ def test_forward_only_is_enforced():
     S = epipolar.CoordSampler(_args(2, 1))
     with pytest.raises(_lib.MalError):
         S.register(torch.randn(1, 4, 8, 8, device=DEV, requires_grad=True), torch.randn(1, 4, 8, 8, device=DEV))
+
+
+def _align_case(i):
+    from mal_amd import epipolar
+    d = lambda t: t.to(DEV)
+    a = SimpleNamespace(corr_radius=2, disable_pose_updates=False, gap_factor="depth", gap_factor_depth_ratio=8, num_levels=1,
+                        disable_fixed_pose_weight=True, robust_pose_loss=False)
+    R = epipolar.Reprojections(a).to(DEV)
+    P = epipolar.PoseUpdate(a)
+    with torch.no_grad():
+        R._reg_intrinsics(d(i["K"]))
+        c_p, P2 = R.depth2gradcoords(d(i["poses"]), d(i["depth"]), d(i["K"]))
+        P.compute_feat(d(i["f1"]), d(i["f2"]))
+        P.src_w, P.tgt_w = d(i["src_w"]), d(i["tgt_w"])
+        H, b = P.normal_equations(d(i["K"]), c_p, P2, d(i["weight"]))
+        new_poses, update = P.direct_align(d(i["poses"]), d(i["K"]), c_p, P2, d(i["weight"]))
+    return c_p.cpu(), P2.cpu(), H.cpu(), b.cpu(), new_poses.cpu(), update.cpu()
+
+
+def _check_align(i, got, ref_cp, ref_P2, ref_new, ref_update):
+    from oracle import epi_oracle as E
+    c_p, P2, H, b, new_poses, update = got
+    assert (c_p - ref_cp).abs().max() <= 1e-4 * max(1.0, float(ref_cp.abs().max()))
+    assert torch.allclose(P2, ref_P2, rtol=1e-5, atol=1e-5)
+    rH, rb = E.normal_equations(i["f1"], i["f2"], i["src_w"], i["tgt_w"], i["K"], ref_cp, ref_P2, i["weight"])
+    assert (H - rH).abs().max() <= 1e-4 * float(rH.abs().max()) and (b - rb).abs().max() <= 1e-4 * float(rb.abs().max())
+    # the update solves a 6x6 system: its error is the normal equations' times the conditioning
+    assert (update - ref_update).abs().max() <= 2e-3 * max(1e-3, float(ref_update.abs().max()))
+    assert (new_poses - ref_new).abs().max() <= 2e-3
+
+
+@pytest.mark.parametrize("tag", ["epi_align_b2_c16_12x20_r4_l3", "epi_align_b1_c8_9x13_r2_l2_h2"])
+def test_direct_align_golden(tag):
+    from tests.test_epi_oracle import load_align
+    z, i = load_align(tag)
+    t = lambda k: torch.from_numpy(z[k])
+    _check_align(i, _align_case(i), t("out/c_p"), t("out/P2"), t("out/new_poses"), t("out/update"))
+
+
+def test_direct_align_dualrefine_size():
+    from oracle import epi_oracle as E
+    from oracle.gen_golden_epi import make_case
+    B, C, h, w = 8, 128, 48, 160
+    K, depth, poses, f1, f2 = make_case(B, C, h, w, seed=4, trans=0.05)
+    g = torch.Generator().manual_seed(7)
+    i = dict(K=K, depth=depth, poses=poses, f1=f1, f2=(0.8 * f1 + 0.2 * f2).half().float(),
+             src_w=0.5 + torch.rand(B, 1, h, w, generator=g), tgt_w=0.5 + torch.rand(B, 1, h, w, generator=g),
+             weight=0.5 + torch.rand(B, 1, h, w, generator=g))
+    with torch.no_grad():
+        c_p, P2 = E.depth2gradcoords(poses, depth, K)
+        new_poses, update = E.direct_align(poses, i["f1"], i["f2"], i["src_w"], i["tgt_w"], K, c_p, P2, i["weight"])
+    _check_align(i, _align_case(i), c_p, P2, new_poses, update)
