@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box (gpurun): measurements of the rows beyond the headline step -- operator route, temporal route, the
-# training harness (N1), the temporal-hint producer (N2) and the cost volume (N3) -- with rocprofv3 kernel stats for
+# training harness (N1), the temporal-hint producer (N2), the cost volume (N3) and the epipolar lookup / direct alignment (N4) -- with rocprofv3 kernel stats for
 # the two kernels-only benches.  Outputs land in gpurun_out/next/; copy what should be judged into profiles/.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -13,7 +13,9 @@ python bench.py --mode multiscale --no-cpu-baseline > $O/multiscale_bench.json 2
 python bench.py --mode train --steps 20 --warmup 5 > $O/train_bench.json 2> $O/train.err || exit 1
 python scripts/bench_costvol.py > $O/costvol.txt 2>&1 || exit 1
 python scripts/bench_dyn.py > $O/dyn.txt 2>&1 || exit 1
+python scripts/bench_epipolar.py > $O/epipolar.txt 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/costvol_stats -o s -- python3 $R/scripts/bench_costvol.py > $O/costvol_stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dyn_stats -o s -- python3 $R/scripts/bench_dyn.py > $O/dyn_stats.log 2>&1 || exit 1
-tail -1 $O/costvol.txt; tail -2 $O/dyn.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/epipolar_stats -o s -- python3 $R/scripts/bench_epipolar.py > $O/epipolar_stats.log 2>&1 || exit 1
+tail -1 $O/costvol.txt; tail -2 $O/dyn.txt; tail -2 $O/epipolar.txt
