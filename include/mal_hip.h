@@ -330,6 +330,10 @@ int mal_coord_sample_l1(const float* fmap1, const float* const* f2_pyramid, cons
 int mal_epipolar_gradcoords(const float* depth, const float* poses, const float* K, int B, int h, int w, float* c_p, float* P2,
                             void* stream);
 size_t mal_direct_align_workspace_bytes(int B, int h, int w);
+/* The rest of direct_align (utils.py:357-368): 6x6 Cholesky solve with upstream's fall-backs (general solve, then the
+ * unchanged pose), se3_exp (dualrefine/layers.py:29-55), new_poses (B,16) = exp(update) @ poses; update (B,6). */
+int mal_direct_align_update(const float* H, const float* b, const float* poses, int B, float* new_poses, float* update,
+                            void* stream);
 int mal_direct_align_normal_eq(const float* src_feat, const float* tgt_feat, const float* src_w, const float* tgt_w,
                                const float* weight, const float* K, const float* p2, const float* P2, int B, int C, int h, int w,
                                float* H, float* b, void* ws, size_t ws_bytes, void* stream);

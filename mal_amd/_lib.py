@@ -69,6 +69,7 @@ SIGNATURES = {
     "mal_coord_sample_l1": (i32, [c_fp, vp, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, vp]),
     "mal_epipolar_gradcoords": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, vp]),
     "mal_direct_align_workspace_bytes": (sz, [i32, i32, i32]),
+    "mal_direct_align_update": (i32, [c_fp, c_fp, c_fp, i32, c_fp, c_fp, vp]),
     "mal_direct_align_normal_eq": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, vp, sz, vp]),
     "mal_step_workspace_bytes": (sz, [i32, i32, i32]),
     "mal_loss_step_fwd": (i32, [vp]),

@@ -288,9 +288,156 @@ __global__ __launch_bounds__(64) void epi_align_finish_kernel(EpiAlignParams p) 
   if (tid < 6) p.bvec[b * 6 + tid] = (float)s_v[21 + tid];
 }
 
+// The rest of PoseUpdate.direct_align (utils.py:357-368) for one sample per thread: Cholesky solve of the 6x6 normal
+// equations (fall-backs as upstream: a general solve when the factorisation fails, the unchanged pose when that fails
+// too), se3_exp of the update (dualrefine/layers.py:29-55) and new_pose = exp(update) @ pose.  fp32 like torch.
+__global__ void epi_align_update_kernel(const float* H, const float* bvec, const float* poses, int B, float* new_poses,
+                                        float* update) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float A[6][6], rhs[6], x[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    rhs[i] = bvec[b * 6 + i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) A[i][j] = H[b * 36 + i * 6 + j];
+  }
+  // Cholesky A = L L^T (lower); every loop has constant bounds and is unrolled so the 6x6 arrays stay in registers
+  float Lm[6][6];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= Lm[j][k] * Lm[j][k];
+    ok = ok && (d > 0.f);
+    const float ljj = sqrtf(d);
+    Lm[j][j] = ljj;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float v = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= Lm[i][k] * Lm[j][k];
+      Lm[i][j] = v / ljj;
+    }
+  }
+  {
+    float y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float v = rhs[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) v -= Lm[i][k] * y[k];
+      y[i] = v / Lm[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      float v = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) v -= Lm[k][i] * x[k];
+      x[i] = v / Lm[i][i];
+    }
+  }
+  bool solved = ok;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) solved = solved && (x[i] == x[i]);  // NaN in the factor: fall through (utils.py:358-360)
+  if (!solved) {  // torch.linalg.solve: LU with partial pivoting (row swaps as selects, so the indices stay static)
+    float M[6][7];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) M[i][j] = A[i][j];
+      M[i][6] = rhs[i];
+    }
+    solved = true;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      int piv = c;
+      float best = fabsf(M[c][c]);
+#pragma unroll
+      for (int r_ = c + 1; r_ < 6; ++r_) {
+        const float v = fabsf(M[r_][c]);
+        if (v > best) { best = v; piv = r_; }
+      }
+      solved = solved && (best > 0.f);
+#pragma unroll
+      for (int r_ = c + 1; r_ < 6; ++r_)
+        if (piv == r_) {
+#pragma unroll
+          for (int j = 0; j < 7; ++j) { const float tmp = M[c][j]; M[c][j] = M[r_][j]; M[r_][j] = tmp; }
+        }
+#pragma unroll
+      for (int r_ = c + 1; r_ < 6; ++r_) {
+        const float f = M[r_][c] / M[c][c];
+#pragma unroll
+        for (int j = c; j < 7; ++j) M[r_][j] -= f * M[c][j];
+      }
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      float v = M[i][6];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) v -= M[i][k] * x[k];
+      x[i] = v / M[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) solved = solved && (x[i] == x[i]);
+  }
+  const float* P = poses + b * 16;
+  if (!solved) {  // utils.py:364-365: return poses, poses
+    for (int i = 0; i < 16; ++i) new_poses[b * 16 + i] = P[i];
+    for (int i = 0; i < 6; ++i) update[b * 6 + i] = 0.f;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) update[b * 6 + i] = x[i];
+  // se3_exp
+  const float rho[3] = {x[0], x[1], x[2]}, phi[3] = {x[3], x[4], x[5]};
+  const float theta = sqrtf(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]);
+  const float a[3] = {phi[0] / theta, phi[1] / theta, phi[2] / theta};
+  const float sk[3][3] = {{0.f, -a[2], a[1]}, {a[2], 0.f, -a[0]}, {-a[1], a[0], 0.f}};
+  const float ct = cosf(theta), st = sinf(theta), sot = st / theta, omc = (1.0f - ct), omcot = omc / theta;
+  float R[3][3], J[3][3], T[4][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float eye = i == j ? 1.0f : 0.0f, aat = a[i] * a[j];
+      R[i][j] = ct * eye + omc * aat + st * sk[i][j];
+      J[i][j] = sot * eye + (1.0f - sot) * aat + omcot * sk[i][j];
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T[i][j] = R[i][j];
+    T[i][3] = J[i][0] * rho[0] + J[i][1] * rho[1] + J[i][2] * rho[2];
+    T[3][i] = 0.f;
+  }
+  T[3][3] = 1.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc += T[i][k] * P[k * 4 + j];
+      new_poses[b * 16 + i * 4 + j] = acc;
+    }
+}
+
 }  // namespace mal
 
 using namespace mal;
+
+extern "C" int mal_direct_align_update(const float* H, const float* b, const float* poses, int B, float* new_poses,
+                                       float* update, void* stream) {
+  if (B <= 0) return MAL_ESHAPE;
+  if (!H || !b || !poses || !new_poses || !update) return MAL_EINVAL;
+  hipLaunchKernelGGL(epi_align_update_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, H, b, poses, B, new_poses,
+                     update);
+  return launch_status();
+}
+
 
 extern "C" int mal_epipolar_gradcoords(const float* depth, const float* poses, const float* K, int B, int h, int w, float* c_p,
                                        float* P2, void* stream) {

@@ -151,17 +151,17 @@ class PoseUpdate(torch.nn.Module):
         return H, b
 
     def direct_align(self, poses, calib_K, p2, P2, weight):
-        """utils.py:303-368 -> (new poses (B,4,4), update (B,6,1)); the fall-backs of :357-365 kept"""
+        """utils.py:303-368 -> (new poses (B,4,4), update (B,6,1)): normal equations (two launches), then the 6x6 solve
+        with upstream's fall-backs, se3_exp and the pose product in one more"""
         H, b = self.normal_equations(calib_K, p2, P2, weight)
-        Lc, info = torch.linalg.cholesky_ex(H)
-        if bool((info != 0).any()) or bool(torch.isnan(Lc).any()):
-            try:
-                update = torch.linalg.solve(H, b[..., None])
-            except Exception:
-                return poses, poses
-        else:
-            update = torch.cholesky_solve(b[..., None], Lc)
-        return torch.bmm(se3_exp(update).type(poses.dtype), poses), update
+        B = H.shape[0]
+        T = ops._req(poses.detach().float().reshape(B, 16).contiguous(), "poses")
+        new_poses = torch.empty(B, 4, 4, dtype=torch.float32, device=H.device)
+        update = torch.empty(B, 6, 1, dtype=torch.float32, device=H.device)
+        p = ops._p
+        L.check(L.load().mal_direct_align_update(p(H), p(b), p(T), B, p(new_poses), p(update), ops._stream()),
+                "mal_direct_align_update")
+        return new_poses.type(poses.dtype), update
 
 
 class CoordSampler(torch.nn.Module):

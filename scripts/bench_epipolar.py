@@ -55,4 +55,4 @@ with torch.no_grad():
     c_p, P2 = E.depth2gradcoords(poses, depth, K)
     E.direct_align(poses, f1, f2s, src_w, tgt_w, K, c_p, P2, weight)
     tca = time.perf_counter() - t
-print("direct_align: HIP %.0f us (incl. the 6x6 solve and se3 update in torch)   CPU checker %.2f s" % (ta * 1e6, tca))
+print("direct_align: HIP %.0f us (gradcoords + normal equations + solve/se3 update kernel)   CPU checker %.2f s" % (ta * 1e6, tca))
