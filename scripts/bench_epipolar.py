@@ -25,14 +25,8 @@ with torch.no_grad():
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(20): hip()
     torch.cuda.synchronize(); th = (time.perf_counter() - t) / 20
-    t = time.perf_counter()
-    rc, _, _ = E.depth2epipolarcoords(poses, depth, K, torch.tensor([1.0]), r=r, num_levels=L)
-    E.coord_sample(f1, E.pyramid(f2, L), rc, L, 1)
-    tc = time.perf_counter() - t
 D = L * (2 * r + 1)
 alg = B * h * w * (2 * C * 4 + D * 4 + 2 * D * 4 + 4)  # both feature maps once, the correlation, the coordinates
-print("HIP %.0f us (%.1f GB/s algorithmic; %d (pixel,hypothesis) pairs -> %.1f G pair-channels/s)   CPU checker %.2f s (%d threads)" %
-      (th * 1e6, alg / th / 1e9, B * h * w * D, B * h * w * D * C / th / 1e9, tc, torch.get_num_threads()))
 
 # ---- the pose refinement step of the same loop: depth2gradcoords + direct_align
 g5 = torch.Generator().manual_seed(7)
@@ -51,8 +45,15 @@ with torch.no_grad():
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(20): align()
     torch.cuda.synchronize(); ta = (time.perf_counter() - t) / 20
+    # the CPU checkers last: their OpenMP workers keep spinning for a while and would starve the launching thread
+    t = time.perf_counter()
+    rc, _, _ = E.depth2epipolarcoords(poses, depth, K, torch.tensor([1.0]), r=r, num_levels=L)
+    E.coord_sample(f1, E.pyramid(f2, L), rc, L, 1)
+    tc = time.perf_counter() - t
     t = time.perf_counter()
     c_p, P2 = E.depth2gradcoords(poses, depth, K)
     E.direct_align(poses, f1, f2s, src_w, tgt_w, K, c_p, P2, weight)
     tca = time.perf_counter() - t
+print("HIP %.0f us (%.1f GB/s algorithmic; %d (pixel,hypothesis) pairs -> %.1f G pair-channels/s)   CPU checker %.2f s (%d threads)" %
+      (th * 1e6, alg / th / 1e9, B * h * w * D, B * h * w * D * C / th / 1e9, tc, torch.get_num_threads()))
 print("direct_align: HIP %.0f us (gradcoords + normal equations + solve/se3 update kernel)   CPU checker %.2f s" % (ta * 1e6, tca))
