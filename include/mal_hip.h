@@ -317,6 +317,10 @@ int mal_cost_volume(const float* current_feats, const float* lookup_feats, const
  * out (B, L*heads*d1, h, w): per level and channel group (heads) the mean of |fmap1 - bilinear zero-padded sample|. */
 int mal_epipolar_coords(const float* depth, const float* poses, const float* K, int B, int h, int w, int r, int L,
                         float softplus_delta, float ratio, float* coords, float* max_dx, float* depths, void* stream);
+/* _iproj / pose / _proj for given depth hypotheses (Reprojections.depthbins2coords, utils.py:251-253): depths (B,1,D,h,w)
+ * -> coords (B,2,1,D,h,w). */
+int mal_epipolar_coords_of_depths(const float* depths, const float* poses, const float* K, int B, int D, int h, int w,
+                                 float* coords, void* stream);
 int mal_coord_sample_l1(const float* fmap1, const float* const* f2_pyramid, const float* coords, int B, int C, int h, int w,
                         int L, int d1, int heads, float* out, void* stream);
 /* The pose refinement step of the same loop (depth_pose.py:450-455), forward:

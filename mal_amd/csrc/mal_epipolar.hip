@@ -66,6 +66,36 @@ __global__ __launch_bounds__(256) void epi_coords_kernel(EpiCoordParams p) {
   p.max_dx[i] = mx;
 }
 
+// _iproj / pose / _proj for GIVEN depth hypotheses (Reprojections.depthbins2coords, utils.py:251-253): one thread per
+// (sample, hypothesis, pixel)
+__global__ __launch_bounds__(256) void epi_coords_of_depths_kernel(const float* depths, const float* poses, const float* K,
+                                                                   int B, int D, int h, int w, float* coords) {
+  const int hw = h * w;
+  const size_t n = (size_t)B * D * hw;
+  const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (i >= n) return;
+  const int pix = (int)(i % hw), s = (int)((i / hw) % D), b = (int)(i / ((size_t)hw * D));
+  const int y = pix / w, x = pix - y * w;
+  const float* Kb = K + b * 16;
+  const float* T = poses + b * 16;
+  const float fx = Kb[0], fy = Kb[5], cx = Kb[2], cy = Kb[6];
+  const float Z = depths[i];
+  const float X = div_((float)x - cx, fx), Y = div_((float)y - cy, fy);
+  const float X0[4] = {Z * X, Z * Y, Z, 1.0f};
+  float X1[3];
+  for (int r_ = 0; r_ < 3; ++r_) {
+    float acc = T[r_ * 4] * X0[0];
+    acc = fma_(T[r_ * 4 + 1], X0[1], acc);
+    acc = fma_(T[r_ * 4 + 2], X0[2], acc);
+    X1[r_] = fma_(T[r_ * 4 + 3], X0[3], acc);
+  }
+  const float inv = div_(1.0f, X1[2]);
+  const float d = inv > 100.0f ? 100.0f : inv;
+  const size_t o = ((size_t)b * 2 * D + s) * hw + pix;
+  coords[o] = fx * (X1[0] * d) + cx;
+  coords[o + (size_t)D * hw] = fy * (X1[1] * d) + cy;
+}
+
 struct EpiSampleParams {
   const float* fmap1; const float* f2[kEpiMaxLevels];
   const float* coords;
@@ -480,6 +510,16 @@ extern "C" int mal_epipolar_coords(const float* depth, const float* poses, const
   if (!depth || !poses || !K || !coords || !max_dx || !depths) return MAL_EINVAL;
   EpiCoordParams p = {depth, poses, K, B, h, w, r, L, softplus_delta, ratio, coords, max_dx, depths};
   hipLaunchKernelGGL(epi_coords_kernel, dim3((B * h * w + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+extern "C" int mal_epipolar_coords_of_depths(const float* depths, const float* poses, const float* K, int B, int D, int h,
+                                            int w, float* coords, void* stream) {
+  if (B <= 0 || D < 1 || h < 1 || w < 1 || (double)B * 2 * D * h * w > 2.0e9 / 4) return MAL_ESHAPE;
+  if (!depths || !poses || !K || !coords) return MAL_EINVAL;
+  const size_t n = (size_t)B * D * h * w;
+  hipLaunchKernelGGL(epi_coords_of_depths_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, depths,
+                     poses, K, B, D, h, w, coords);
   return launch_status();
 }
 

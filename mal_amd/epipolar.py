@@ -86,6 +86,36 @@ class Reprojections(torch.nn.Module):
         return c_p, P2
 
 
+    def depthbins2coords(self, poses, depths):
+        """-> (coords (B,2,1,num_depth_bins,h,w), depth hypotheses (B,1,num_depth_bins,h,w)), utils.py:231-255.  The
+        hypotheses are a few elementwise tensor ops (as upstream); their projection is the kernel."""
+        if self.K is None:
+            raise L.MalError("Reprojections: call _reg_intrinsics(K) first (depth_pose.py:471)")
+        _no_grad(poses, depths)
+        dep = ops._req(depths.detach(), "depths")
+        B, _, h, w = dep.shape
+        dev, n = dep.device, self.num_depth_bins
+        a = self.args
+        if getattr(a, "use_depth_bins_for_masking", False):
+            d = torch.linspace(float(self.min_depth_bin), float(self.max_depth_bin), n, device=dev)
+            d = d[None, None, :, None, None].repeat(B, 1, 1, h, w)
+        else:
+            lin = torch.linspace(0, 1, n, device=dev)
+            depths_ = 8 * (dep - a.min_depth) + a.min_depth
+            depths_ = torch.clamp(depths_, max=a.max_depth)
+            lin_ = (depths_ - a.min_depth) / (dep - a.min_depth)
+            lin = lin[None, None, :, None, None] * lin_[:, None]
+            d = lin * (dep[:, None] - a.min_depth) + a.min_depth
+        d = d.contiguous()
+        T = ops._req(poses.detach().float().reshape(B, 16).contiguous(), "poses")
+        K = ops._req(self.K.detach().float().reshape(B, 16).contiguous(), "K")
+        coords = torch.empty(B, 2, 1, n, h, w, dtype=torch.float32, device=dev)
+        p = ops._p
+        L.check(L.load().mal_epipolar_coords_of_depths(p(d), p(T), p(K), B, n, h, w, p(coords), ops._stream()),
+                "mal_epipolar_coords_of_depths")
+        return coords, d
+
+
 def se3_exp(vec):
     """dualrefine/layers.py:29-55 (a handful of 3x3 tensor ops on (B,6,1): plain torch on the device)"""
     rho, phi = vec[:, :3], vec[:, 3:]
@@ -183,6 +213,10 @@ class CoordSampler(torch.nn.Module):
 
     def _update_fmap1(self, fmap1):
         self.fmap1 = ops._req(fmap1.detach().float(), "fmap1").clone()
+
+    def __corr__(self, coords, num_levels=1, num_head=1):
+        """corr.py:52-75: the mean over all channels = the lookup with one head"""
+        return self(coords, num_levels, 1)
 
     def __call__(self, coords, num_levels=1, num_head=1):
         _no_grad(coords)

@@ -88,6 +88,31 @@ def coord_sample(fmap1, f2_pyramid, coords, num_levels=1, num_head=1):
     return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().float()
 
 
+def depthbins2coords(poses, depths, K, min_depth, max_depth, num_depth_bins=96, bins_range=None):
+    """utils.py:231-255 -> (coords (B,2,1,num_depth_bins,h,w), depth hypotheses (B,1,num_depth_bins,h,w)).
+    ``bins_range`` = (min_depth_bin, max_depth_bin) selects the ``--use_depth_bins_for_masking`` branch; otherwise the
+    hypotheses run from min_depth to 8x the pixel's depth (clamped to max_depth), linearly."""
+    bsz, _, ht, wd = depths.shape
+    if bins_range is not None:
+        d = torch.linspace(bins_range[0], bins_range[1], num_depth_bins)
+        d = d[None, None, :, None, None].repeat(bsz, 1, 1, ht, wd)
+    else:
+        lin = torch.linspace(0, 1, num_depth_bins)
+        depths_ = 8 * (depths - min_depth) + min_depth
+        depths_ = torch.clamp(depths_, max=max_depth)
+        lin_ = (depths_ - min_depth) / (depths - min_depth)
+        lin = lin[None, None, :, None, None] * lin_[:, None]
+        d = lin * (depths[:, None] - min_depth) + min_depth
+    X0 = iproj(d, K)
+    X1 = poses.type(X0.dtype) @ X0.reshape(bsz, 4, -1)
+    return proj(X1, K).reshape(bsz, 2, 1, num_depth_bins, ht, wd), d
+
+
+def corr_all_channels(fmap1, f2_pyramid, coords, num_levels=1):
+    """CoordSampler.__corr__ (corr.py:52-75): the mean over ALL channels, i.e. ``coord_sample`` with one head"""
+    return coord_sample(fmap1, f2_pyramid, coords, num_levels, 1)
+
+
 # ---------------------------------------------------------------- pose refinement step (forward)
 def depth2gradcoords(poses, depths, K):
     """utils.py:219-236 -> (c1 (B,2,1,5,h,w): the projection and its +-1 px neighbours in x and y, X1 (B,4,h*w))"""

@@ -93,6 +93,20 @@ def main():
             "in/f2": f2s.half().numpy(), "in/src_w": src_w.numpy(), "in/tgt_w": tgt_w.numpy(), "in/weight": weight.numpy(),
             "out/c_p": c_p.numpy(), "out/P2": P2.numpy(), "out/new_poses": new_poses.numpy(), "out/update": update.numpy()})
         print("  align", tuple(c_p.shape), update.flatten()[:3].tolist())
+        # the masking lookup (depth_pose.py:561-580): depthbins2coords (both branches) + CoordSampler.__corr__
+        if B * h * w > 200:  # 96 hypotheses per pixel: keep only the small case as a fixture
+            continue
+        outs = {}
+        with torch.no_grad():
+            for name, flag in (("lin", False), ("bins", True)):
+                args.use_depth_bins_for_masking = flag
+                c0, ds0 = R.depthbins2coords(poses, depth)
+                outs["out/c0_" + name], outs["out/ds0_" + name] = c0.numpy(), ds0.numpy()
+                outs["out/corr0_" + name] = S.__corr__(c0).numpy()
+        np.savez_compressed(os.path.join(OUT, tag.replace("epi_", "epi_bins_") + ".npz"), **{
+            "in/K": K.numpy(), "in/depth": depth.numpy(), "in/poses": poses.numpy(), "in/f1": f1.half().numpy(),
+            "in/f2": f2.half().numpy(), "in/range": np.array([0.1, 100.0, 1.0, 9.0], dtype=np.float32), **outs})
+        print("  bins", tuple(outs["out/c0_lin"].shape), float(outs["out/corr0_bins"].mean()))
 
 
 if __name__ == "__main__":

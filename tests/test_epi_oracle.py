@@ -45,3 +45,23 @@ def test_direct_align_oracle_reproduces_reference(tag):
     new_poses, update = E.direct_align(i["poses"], i["f1"], i["f2"], i["src_w"], i["tgt_w"], i["K"], c_p, P2, i["weight"])
     for got, key in ((c_p, "out/c_p"), (P2, "out/P2"), (update, "out/update"), (new_poses, "out/new_poses")):
         assert np.array_equal(got.numpy(), z[key]), key
+
+
+BINS_CASES = ["epi_bins_b1_c8_9x13_r2_l2_h2"]
+
+
+def load_bins(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    t = lambda k: torch.from_numpy(z[k].astype(np.float32))
+    return z, t("in/K"), t("in/depth"), t("in/poses"), t("in/f1"), t("in/f2"), [float(v) for v in z["in/range"]]
+
+
+@pytest.mark.parametrize("tag", BINS_CASES)
+def test_depthbins_lookup_oracle_reproduces_reference(tag):
+    """depthbins2coords (utils.py:231-255, both branches) + CoordSampler.__corr__ (corr.py:52-75): bit for bit"""
+    z, K, depth, poses, f1, f2, (dmin, dmax, bmin, bmax) = load_bins(tag)
+    for name, rng in (("lin", None), ("bins", (bmin, bmax))):
+        c0, ds0 = E.depthbins2coords(poses, depth, K, dmin, dmax, 96, rng)
+        corr0 = E.corr_all_channels(f1, E.pyramid(f2, 2), c0, 1)
+        for got, key in ((c0, "out/c0_"), (ds0, "out/ds0_"), (corr0, "out/corr0_")):
+            assert np.array_equal(got.numpy(), z[key + name]), key + name

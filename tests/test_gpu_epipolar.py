@@ -126,3 +126,29 @@ def test_direct_align_dualrefine_size():
         c_p, P2 = E.depth2gradcoords(poses, depth, K)
         new_poses, update = E.direct_align(poses, i["f1"], i["f2"], i["src_w"], i["tgt_w"], K, c_p, P2, i["weight"])
     _check_align(i, _align_case(i), c_p, P2, new_poses, update)
+
+
+def test_depthbins_lookup_golden():
+    """the masking lookup of depth_pose.py:561-580: depthbins2coords (both branches) + CoordSampler.__corr__"""
+    from tests.test_epi_oracle import BINS_CASES, load_bins
+    from mal_amd import epipolar
+    for tag in BINS_CASES:
+        z, K, depth, poses, f1, f2, (dmin, dmax, bmin, bmax) = load_bins(tag)
+        d = lambda t: t.to(DEV)
+        for name, flag in (("lin", False), ("bins", True)):
+            a = SimpleNamespace(corr_radius=2, disable_pose_updates=True, gap_factor="depth", gap_factor_depth_ratio=8,
+                                num_levels=2, min_depth=dmin, max_depth=dmax, use_depth_bins_for_masking=flag)
+            R = epipolar.Reprojections(a).to(DEV)
+            S = epipolar.CoordSampler(a)
+            with torch.no_grad():
+                R._reg_intrinsics(d(K))
+                R.update_depth_bins(bmax, bmin, 4.0, 4.0)
+                S.register(d(f1), d(f2), num_levels=2)
+                c0, ds0 = R.depthbins2coords(d(poses), d(depth))
+                corr0 = S.__corr__(c0)
+            rc, rd, rcorr = (torch.from_numpy(z[k + name]) for k in ("out/c0_", "out/ds0_", "out/corr0_"))
+            assert torch.allclose(ds0.cpu(), rd, rtol=1e-6, atol=1e-6)
+            # far hypotheses project far outside the image: compare where the reference coordinate is near the image
+            near = (rc.abs() < 1e4)
+            assert ((c0.cpu() - rc).abs()[near] <= 1e-4 * rc.abs()[near].clamp(min=1.0)).all()
+            assert (corr0.cpu() - rcorr).abs().max() <= 1e-4 * max(1.0, float(rcorr.abs().max()))
