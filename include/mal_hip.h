@@ -257,7 +257,24 @@ typedef struct mal_step_args {
   float *g_disp_teacher, *g_disp_student;         /* backward outputs, nullable */
   float *g_axisangle_m1, *g_translation_m1, *g_axisangle_p1, *g_translation_p1;
   void *ws; size_t ws_bytes; void *stream;
+  /* Parity instrumentation (tests; NULL in production): the per-pixel DECISIONS the teacher / student pass took,
+   * MAL_DEC_PLANES uint32 planes of B*H*W each -- what a CPU checker has to be told to reproduce the discontinuous
+   * choices of loss_utils.py:103-113,178-199,237-254 instead of re-deciding near-ties.  Requesting them selects
+   * instrumented instantiations of the same kernels (identical arithmetic); H, W < 4096.                       */
+  uint32_t *dec_teacher, *dec_student;
 } mal_step_args;
+enum {
+  MAL_DEC_WIN = 0,     /* bits 0-1: winning candidate of the per-pixel min (0/1 = warped frame -1/+1, 2/3 = syn -1/+1);
+                          bit 2: automask bit `min_c r_c <= identity + 1e-5*noise` (1 when the pass has no automask) */
+  MAL_DEC_DISTIL = 1,  /* student: index of the distillation argmin (0 teacher, 1 ensemble, 2 student) */
+  MAL_DEC_SMOOTH_X = 2,/* 1 + sign(d[y,x] - d[y,x+1]) of the smoothness term (layers.py:210-223), x < W-1 */
+  MAL_DEC_SMOOTH_Y = 3,/* 1 + sign(d[y,x] - d[y+1,x]), y < H-1 */
+  MAL_DEC_TAP0 = 4,    /* frame -1: x0 | y0 << 12 (floor of the clipped sampling position) | bit 24: x on/over the
+                          border (grid gradient cut), bit 25: same for y */
+  MAL_DEC_TAP1 = 5,    /* frame +1 */
+  MAL_DEC_L1 = 6,      /* 1 + sign(pred - target) of the winning candidate's L1 term, channels r | g << 2 | b << 4 */
+  MAL_DEC_PLANES = 7
+};
 size_t mal_step_workspace_bytes(int B, int H, int W);
 int mal_loss_step_fwd(const mal_step_args* args);
 int mal_loss_step_bwd(const mal_step_args* args);

@@ -99,10 +99,12 @@ class StepArgs(C.Structure):
                                    "mono_reproj", "ens_reproj", "multi_reproj", "consistency_mask_out", "g_total",
                                    "g_disp_teacher", "g_disp_student", "g_axisangle_m1", "g_translation_m1",
                                    "g_axisangle_p1", "g_translation_p1", "ws")] +
-                [("ws_bytes", sz), ("stream", vp)])
+                [("ws_bytes", sz), ("stream", vp), ("dec_teacher", vp), ("dec_student", vp)])
 
 
 STEP_NO_ENS, STEP_AUG_MASK = 1, 2
+# decision planes of mal_step_args.dec_teacher / dec_student (MAL_DEC_*)
+DEC_WIN, DEC_DISTIL, DEC_SMOOTH_X, DEC_SMOOTH_Y, DEC_TAP0, DEC_TAP1, DEC_L1, DEC_PLANES = 0, 1, 2, 3, 4, 5, 6, 7
 
 # flags (include/mal_hip.h)
 F_AUTOMASK, F_GRAD, F_POSE_GRAD, F_NO_SSIM, F_AVG, F_EPILOGUE, F_DUAL_DISTIL, F_SRC_PACKED, F_TGT_PACKED = 1, 2, 4, 8, 16, 32, 64, 128, 256

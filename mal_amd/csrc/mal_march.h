@@ -33,7 +33,11 @@ struct MarchParams {
   int packed;
   int flip_odd;  // odd row segments walk bottom-up: both tasks that share a segment boundary reach it together (L2 serves the halo)
   int debug;  // experiments only (mal_set_option("debug")): bit 0 = taps read the pixel's own address
+  // Parity instrumentation (tests only; DBG instantiations of the gradient passes): the per-pixel DECISIONS the pass
+  // took, as kDecPlanes uint32 planes of B*H*W each (include/mal_hip.h, MAL_DEC_*).  nullptr = the production kernels.
+  unsigned* dbg;
 };
+constexpr int kDecPlanes = MAL_DEC_PLANES;
 
 constexpr int kCamFloats = 40;  // P interleaved over the two frames [12][2], inv_K 3x3, 7 pad
 

@@ -129,10 +129,17 @@ struct PendingWarp {
 };
 
 // the parameter-block fields the warp needs, read together at the top of an iteration (one scalar-load wait)
-struct WarpConsts { const float* src[2]; int packed, debug, W, H, convention; float min_disp, range, eps, rw, rh; };
+struct WarpConsts {
+  const float* src[2]; int packed, debug, W, H, convention; float min_disp, range, eps, rw, rh;
+  unsigned* dbg; unsigned dbg_n, dbg_off; bool dbg_on;  // DBG: decision planes, plane stride, this pixel's byte offset, lane writes
+};
+// decision plane `plane` (mal_hip.h MAL_DEC_*), byte offset `boff` of the pixel inside a (B,1,H,W) map
+MAL_DEV void dec_store(unsigned* dbg, unsigned n, int plane, unsigned boff, unsigned v) {
+  *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dbg + (size_t)plane * n) + boff) = v;
+}
 
 // projection, tap weights and the eight gathers
-template <bool DERIV, bool POSE, class BeforeGathers>
+template <bool DERIV, bool POSE, bool DBG, class BeforeGathers>
 MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik)[9], int b, int gyr, int gxr,
                         float dispv, PendingWarp& w, BeforeGathers before_gathers) {
   const int W = p.W, H = p.H, HW = H * W, pix = gyr * W + gxr;
@@ -150,6 +157,9 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
     const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);  // x0+1 == W only with weight 0
     oo[f][0] = y0 * W + x0; oo[f][1] = y0 * W + x1; oo[f][2] = y1 * W + x0; oo[f][3] = y1 * W + x1;
     if (p.debug & 1) { oo[f][0] = oo[f][1] = oo[f][2] = oo[f][3] = pix; }
+    if (DBG && p.dbg_on)
+      dec_store(p.dbg, p.dbg_n, MAL_DEC_TAP0 + f, p.dbg_off,
+                (unsigned)x0 | ((unsigned)y0 << 12) | (s.mx[f] == 0.f ? 1u << 24 : 0u) | (s.my[f] == 0.f ? 1u << 25 : 0u));
   }
   before_gathers();
 #pragma unroll
@@ -221,7 +231,7 @@ MAL_DEV void warp_finish(PendingWarp& pw, f2 (&x)[3], DerivRow& d) {
   }
 }
 
-template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI>
+template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG = false>
 __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   constexpr int HALO = GRAD ? 2 : 1;
   constexpr int CW = 64 - 2 * HALO;
@@ -275,7 +285,11 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   const float sscale = p.sample_scale ? (p.sample_scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
 
   // ---- running state (pairs as in WarpRow: index k*3 + {x, x^2, xy} for the colour pairs k)
-  f2 hsA[9], hsB[9];             // partial vertical sums of the horizontal sums: centre r-1 (top+mid), centre r (top)
+  // The horizontal sums of the two previous rows: A = row r-2, B = row r-1.  The window sum of centre row r-1 is
+  // formed as (A + h(r)) + B -- outer rows first -- so that it is the SAME fp32 number whether the task walks down or
+  // up: a task recomputes its neighbour's boundary rows as halo, and a near-tie decision (argmin, automask) must not
+  // come out differently in the two tasks.
+  f2 hsA[9], hsB[9];
   f2 hyA[2], hyB[2];             // same for the target's (r,g): sum y, sum y^2
   float hzA[2], hzB[2];          // and its b channel
   f2 hcA[GRAD ? 9 : 1], hcB[GRAD ? 9 : 1];  // same for the 18 partial planes: output row c-1, c
@@ -397,6 +411,9 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = mp.packed; wc.debug = p.debug; wc.W = W; wc.H = H;
     wc.convention = p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
     wc.rw = norm_rw; wc.rh = norm_rh;
+    wc.dbg = DBG ? p.dbg : nullptr; wc.dbg_n = (unsigned)(p.B * HW);
+    wc.dbg_off = 0; wc.dbg_on = false;
+    if (DBG) { wc.dbg_on = r >= y_lo && r < y_hi && out_x; wc.dbg_off = moff(row_of(r)); }
 #ifdef MAL_STAGE_TIMERS
     auto tick = [&](int i) {
       if (wc.debug & 64) { const unsigned long long t = clock64(); tacc[i] += (unsigned)(t - tprev); tprev = t; }
@@ -427,7 +444,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       load_cam(cam_b, P, ik);
       // the next iteration's operands go out between the projection and the gathers (measured: behind the
       // gathers is 5 % slower even when the blend then waits for the gathers only)
-      warp_issue<GRAD, POSE>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
+      warp_issue<GRAD, POSE, DBG>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
     }
     __builtin_amdgcn_s_setprio(0);
     tick(1);  // small loads, prefetch, projection, gathers issued
@@ -480,6 +497,14 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       // every vertical edge is summed once: by the task that owns its physically upper row
       if ((flip ? r : qs) >= y_lo && (flip ? r : qs) < y_hi && out_x) acc_sy += fabsf(dfy) * wyu_;
       if (r >= y_lo && r < y_hi && out_x) { acc_sx += fabsf(dfx) * wxr; acc_d += dv_; }
+      if (DBG) {
+        // sign of d[y,x] - d[y,x+1] at (row r, x); sign of d[y] - d[y+1] at the edge's physically upper row, written
+        // by the task that owns it (the one that sums the edge)
+        if (wc.dbg_on) dec_store(wc.dbg, wc.dbg_n, MAL_DEC_SMOOTH_X, wc.dbg_off, (unsigned)(int)(sgnf(dfx) + 1.0f));
+        if ((flip ? r : qs) >= y_lo && (flip ? r : qs) < y_hi && out_x && vy)
+          dec_store(wc.dbg, wc.dbg_n, MAL_DEC_SMOOTH_Y, flip ? wc.dbg_off : so_c,
+                    (unsigned)(int)((flip ? -sgnf(dfy) : sgnf(dfy)) + 1.0f));
+      }
       sm_g1 = (sx - dpp_shr1(sx)) - sy;
       sm_n1 = n0;
       sm_d1 = dv_;
@@ -508,6 +533,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
         const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
         const float dd = target - dm;
         acc_dist += fabsf(dd) * mm;
+        if (DBG) dec_store(wc.dbg, wc.dbg_n, MAL_DEC_DISTIL, go, (unsigned)idx);
         if (p.cons_target) stf(p.cons_target, go, div_(1.0f, dmono * cm + dm * (1.0f - cm)));
         if (GRAD) {
           const float gc = sgnf(dc) * cm * ddepth;
@@ -549,14 +575,15 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       for (int i = 0; i < 9; ++i) coef[i] = bc(0.f);
     if (c_valid && !(wc.debug & 8)) {  // wave-uniform
       // the target's side of the statistics, shared by the two candidates
-      const f2 syq = hyA[0] + hy[0], syyq = hyA[1] + hy[1];
-      const float syz = hzA[0] + hz[0], syyz = hzA[1] + hz[1];
+      const f2 syq = (hyA[0] + hy[0]) + hyB[0], syyq = (hyA[1] + hy[1]) + hyB[1];
+      const float syz = (hzA[0] + hz[0]) + hzB[0], syyz = (hzA[1] + hz[1]) + hzB[1];
       const f2 vyq = fma2(-syq, syq, bc(9.0f) * syyq), d1yq = fma2(syq, syq, bc(kC1s));
       const float vyz = fma_(-syz, syz, 9.0f * syyz), d1yz = fma_(syz, syz, kC1s);
       f2 v[3], vc[3], pa[GRAD ? 3 : 1], pb[GRAD ? 3 : 1], pcq[GRAD ? 3 : 1];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const f2 sx = hsA[k * 3] + h[k * 3], sxx = hsA[k * 3 + 1] + h[k * 3 + 1], sxy = hsA[k * 3 + 2] + h[k * 3 + 2];
+        const f2 sx = (hsA[k * 3] + h[k * 3]) + hsB[k * 3], sxx = (hsA[k * 3 + 1] + h[k * 3 + 1]) + hsB[k * 3 + 1],
+                 sxy = (hsA[k * 3 + 2] + h[k * 3 + 2]) + hsB[k * 3 + 2];
         v[k] = ssim_sums2<GRAD>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
                                 &pa[GRAD ? k : 0], &pb[GRAD ? k : 0], &pcq[GRAD ? k : 0]);
         vc[k] = (f2){clamp01(v[k].x), clamp01(v[k].y)};
@@ -574,6 +601,8 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
         if (has_noise) idn += ld_noise * 0.00001f;
         w = (pi0.rp <= idn) ? 1.0f : 0.0f;
       }
+      if (DBG && out_x && c >= y_lo && c < y_hi)
+        dec_store(wc.dbg, wc.dbg_n, MAL_DEC_WIN, go, (unsigned)pi0.win | (w != 0.f ? 4u : 0u));
       if (has_ext) {
         float em = ld_ext;
         if (has_cost) {  // consistency_mask *= compute_matching_mask (trainer.py:592-593,1066-1076)
@@ -657,6 +686,9 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
         const float dwb = (w1_ ? wq.x[2].y : wq.x[2].x) - wq.yb;
         const f2 sgrg = (f2){sgnf(dwin.x), sgnf(dwin.y)};
         const float sgb = sgnf(dwb);
+        if (DBG && out_x)
+          dec_store(wc.dbg, wc.dbg_n, MAL_DEC_L1, so_q,
+                    (unsigned)(int)(sgrg.x + 1.0f) | ((unsigned)(int)(sgrg.y + 1.0f) << 2) | ((unsigned)(int)(sgb + 1.0f) << 4));
         const f2 sgk[3] = {sgrg, sgrg, bc(sgb)};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -727,13 +759,13 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     // ================= roll the row state =====================================================
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      hsA[i] = hsB[i] + h[i];
+      hsA[i] = hsB[i];
       hsB[i] = h[i];
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      hyA[i] = hyB[i] + hy[i]; hyB[i] = hy[i];
-      hzA[i] = hzB[i] + hz[i]; hzB[i] = hz[i];
+      hyA[i] = hyB[i]; hyB[i] = hy[i];
+      hzA[i] = hzB[i]; hzB[i] = hz[i];
     }
     if (GRAD) { y2rg = w1.yrg; y2b = w1.yb; }
     w1 = w0;
@@ -851,14 +883,15 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
     }
     const int c = r - 1;
     if (c >= y_lo && c < y_hi) {
-      const f2 syq = hyA[0] + hy[0], syyq = hyA[1] + hy[1];
-      const float syz = hzA[0] + hz[0], syyz = hzA[1] + hz[1];
+      const f2 syq = (hyA[0] + hy[0]) + hyB[0], syyq = (hyA[1] + hy[1]) + hyB[1];  // outer rows first, as in march_kernel
+      const float syz = (hzA[0] + hz[0]) + hzB[0], syyz = (hzA[1] + hz[1]) + hzB[1];
       const f2 vyq = fma2(-syq, syq, bc(9.0f) * syyq), d1yq = fma2(syq, syq, bc(kC1s));
       const float vyz = fma_(-syz, syz, 9.0f * syyz), d1yz = fma_(syz, syz, kC1s);
       f2 vc[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const f2 sx = hsA[k * 3] + h[k * 3], sxx = hsA[k * 3 + 1] + h[k * 3 + 1], sxy = hsA[k * 3 + 2] + h[k * 3 + 2];
+        const f2 sx = (hsA[k * 3] + h[k * 3]) + hsB[k * 3], sxx = (hsA[k * 3 + 1] + h[k * 3 + 1]) + hsB[k * 3 + 1],
+                 sxy = (hsA[k * 3 + 2] + h[k * 3 + 2]) + hsB[k * 3 + 2];
         const f2 v = ssim_sums2<false>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
                                        nullptr, nullptr, nullptr);
         vc[k] = (f2){clamp01(v.x), clamp01(v.y)};
@@ -870,9 +903,9 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
       if (out_x) stf(p.ident + (size_t)b * HW, (unsigned)(c * W + gxr) * 4u, fminf(rr.x, rr.y));
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i] + h[i]; hsB[i] = h[i]; }
+    for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i]; hsB[i] = h[i]; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { hyA[i] = hyB[i] + hy[i]; hyB[i] = hy[i]; hzA[i] = hzB[i] + hz[i]; hzB[i] = hz[i]; }
+    for (int i = 0; i < 2; ++i) { hyA[i] = hyB[i]; hyB[i] = hy[i]; hzA[i] = hzB[i]; hzB[i] = hz[i]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) x1[k] = x0[k];
     y1rg = y0rg; y1b = y0b;
@@ -933,7 +966,12 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   g_prof_start = g_prof_stop = nullptr;
   if (ev0) (void)hipEventRecord(ev0, st);
 #define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((march_kernel<G, A, P, E>), grid, block, 0, st, p)
-  if (!grad) {
+  if (p.dbg) {  // instrumented instantiations exist for the two gradient passes of the whole-step list
+    if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
+    if (grad && pose && automask && !epi) hipLaunchKernelGGL((march_kernel<true, true, true, false, true>), grid, block, 0, st, p);
+    else if (grad && !pose && !automask && epi) hipLaunchKernelGGL((march_kernel<true, false, false, true, true>), grid, block, 0, st, p);
+    else return MAL_EINVAL;
+  } else if (!grad) {
     if (automask) { if (epi) MAL_LAUNCH(false, true, false, true); else MAL_LAUNCH(false, true, false, false); }
     else          { if (epi) MAL_LAUNCH(false, false, false, true); else MAL_LAUNCH(false, false, false, false); }
   } else if (pose) {

@@ -107,14 +107,15 @@ __global__ __launch_bounds__(64, 4) void photo_march_fwd_kernel(PhotoMarchParams
       h[k * 3 + 2] = hsum3(x * y);
     }
     if (c_own) {  // wave-uniform
-      const f2 syq = hyA[0] + hy[0], syyq = hyA[1] + hy[1];
-      const float syz = hzA[0] + hz[0], syyz = hzA[1] + hz[1];
+      const f2 syq = (hyA[0] + hy[0]) + hyB[0], syyq = (hyA[1] + hy[1]) + hyB[1];  // outer rows first (mal_march.hip)
+      const float syz = (hzA[0] + hz[0]) + hzB[0], syyz = (hzA[1] + hz[1]) + hzB[1];
       const f2 vyq = fma2(-syq, syq, bc(9.0f) * syyq), d1yq = fma2(syq, syq, bc(kC1s));
       const float vyz = fma_(-syz, syz, 9.0f * syyz), d1yz = fma_(syz, syz, kC1s);
       f2 vc[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const f2 sx = hsA[k * 3] + h[k * 3], sxx = hsA[k * 3 + 1] + h[k * 3 + 1], sxy = hsA[k * 3 + 2] + h[k * 3 + 2];
+        const f2 sx = (hsA[k * 3] + h[k * 3]) + hsB[k * 3], sxx = (hsA[k * 3 + 1] + h[k * 3 + 1]) + hsB[k * 3 + 1],
+                 sxy = (hsA[k * 3 + 2] + h[k * 3 + 2]) + hsB[k * 3 + 2];
         const f2 v = ssim_sums2<false>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
                                        nullptr, nullptr, nullptr);
         vc[k] = (f2){clamp01(v.x), clamp01(v.y)};
@@ -142,9 +143,9 @@ __global__ __launch_bounds__(64, 4) void photo_march_fwd_kernel(PhotoMarchParams
       }
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i] + h[i]; hsB[i] = h[i]; }
+    for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i]; hsB[i] = h[i]; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { hyA[i] = hyB[i] + hy[i]; hyB[i] = hy[i]; hzA[i] = hzB[i] + hz[i]; hzB[i] = hz[i]; }
+    for (int i = 0; i < 2; ++i) { hyA[i] = hyB[i]; hyB[i] = hy[i]; hzA[i] = hzB[i]; hzB[i] = hz[i]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) x1[k] = x0[k];
     y1rg = y0rg; y1b = y0b;
@@ -224,15 +225,16 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
 #pragma unroll
     for (int i = 0; i < 9; ++i) coef[i] = bc(0.f);
     if (c_valid) {  // wave-uniform
-      const f2 syq = hyA[0] + hy[0], syyq = hyA[1] + hy[1];
-      const float syz = hzA[0] + hz[0], syyz = hzA[1] + hz[1];
+      const f2 syq = (hyA[0] + hy[0]) + hyB[0], syyq = (hyA[1] + hy[1]) + hyB[1];  // outer rows first (mal_march.hip)
+      const float syz = (hzA[0] + hz[0]) + hzB[0], syyz = (hzA[1] + hz[1]) + hzB[1];
       const f2 vyq = fma2(-syq, syq, bc(9.0f) * syyq), d1yq = fma2(syq, syq, bc(kC1s));
       const float vyz = fma_(-syz, syz, 9.0f * syyz), d1yz = fma_(syz, syz, kC1s);
       const float kk = -w0 * (0.85f / 3.0f) * 0.5f;
       const float kk0 = win0 == p.idx[0] ? kk : 0.f, kk1 = win0 == p.idx[1] ? kk : 0.f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const f2 sx = hsA[k * 3] + h[k * 3], sxx = hsA[k * 3 + 1] + h[k * 3 + 1], sxy = hsA[k * 3 + 2] + h[k * 3 + 2];
+        const f2 sx = (hsA[k * 3] + h[k * 3]) + hsB[k * 3], sxx = (hsA[k * 3 + 1] + h[k * 3 + 1]) + hsB[k * 3 + 1],
+                 sxy = (hsA[k * 3 + 2] + h[k * 3 + 2]) + hsB[k * 3 + 2];
         f2 pa, pb, pc;
         const f2 v = ssim_sums2<true>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
                                       &pa, &pb, &pc);
@@ -280,9 +282,9 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
       for (int i = 0; i < 9; ++i) { hcA[i] = hcB[i] + hc[i]; hcB[i] = bc(wyu) * hc[i]; }
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i] + h[i]; hsB[i] = h[i]; }
+    for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i]; hsB[i] = h[i]; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { hyA[i] = hyB[i] + hy[i]; hyB[i] = hy[i]; hzA[i] = hzB[i] + hz[i]; hzB[i] = hz[i]; }
+    for (int i = 0; i < 2; ++i) { hyA[i] = hyB[i]; hyB[i] = hy[i]; hzA[i] = hzB[i]; hzB[i] = hz[i]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { x2[k] = x1[k]; x1[k] = x0[k]; }
     y2rg = y1rg; y2b = y1b; y1rg = y0rg; y1b = y0b;

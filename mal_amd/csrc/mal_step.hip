@@ -272,6 +272,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.block_sums = w.bs_t; p.block_gP = w.bgP;
     p.smooth_gn = w.gn_t;
     p.cam = w.cam; p.cam_ready = cam_ready;
+    p.dbg = a->dec_teacher;
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
     if (rc) return rc;
     per_sample = p.strips * p.segs;
@@ -302,6 +303,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.block_sums = w.bs_s; p.block_gP = w.bgP;
     p.smooth_gn = w.gn_s;
     p.cam = w.cam; p.cam_ready = cam_ready;
+    p.dbg = a->dec_student;
     rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
     if (rc) return rc;
   }

@@ -19,6 +19,7 @@ from . import _lib as L
 from . import ops
 
 _WS = {}
+MAP_NAMES = ("mono_reproj", "multi_reproj", "consistency_mask", "ens_reproj", "dec_teacher", "dec_student")
 
 
 def _workspace(dev, B, H, W):
@@ -37,7 +38,7 @@ class LossStepFn(Function):
     @staticmethod
     def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg):
         color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise = consts
-        min_depth, max_depth, no_ens, w_main, w_distil, want_maps, aug_is_mask = cfg
+        min_depth, max_depth, no_ens, w_main, w_distil, want_maps, aug_is_mask, want_dec = cfg
         req = ops._req
         tens = [req(t, n) for t, n in ((disp_t, "disp_teacher"), (disp_s, "disp_student"), (aa_m1, "axisangle"),
                                        (tr_m1, "translation"), (aa_p1, "axisangle"), (tr_p1, "translation"))]
@@ -67,14 +68,17 @@ class LossStepFn(Function):
             a.mono_reproj, a.multi_reproj = p(maps["mono_reproj"]), p(maps["multi_reproj"])
             a.consistency_mask_out = p(maps["consistency_mask"])
             a.ens_reproj = p(maps.get("ens_reproj"))
+        if want_dec:  # parity instrumentation (tests): the kernels' per-pixel decisions, MAL_DEC_* planes
+            for k in ("dec_teacher", "dec_student"):
+                maps[k] = torch.zeros((L.DEC_PLANES, B, H, W), dtype=torch.int32, device=dev)
+            a.dec_teacher, a.dec_student = p(maps["dec_teacher"]), p(maps["dec_student"])
         ws = _workspace(dev, B, H, W)
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
         L.check(L.load().mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
         ctx.args = a
         ctx.keep = (tens, cons, ws, losses, total)  # the C struct holds raw pointers: keep the tensors alive
         ctx.set_materialize_grads(False)
-        outs = [total, losses] + [maps[k] for k in ("mono_reproj", "multi_reproj", "consistency_mask", "ens_reproj")
-                                  if k in maps]
+        outs = [total, losses] + [maps[k] for k in MAP_NAMES if k in maps]
         ctx.mark_non_differentiable(*outs[1:])
         return tuple(outs)
 
@@ -95,12 +99,15 @@ class LossStepFn(Function):
         return (*grads, None, None)
 
 
-def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=None, noise=None, want_maps=True):
+def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=None, noise=None, want_maps=True,
+              want_decisions=False):
     """process_batch's loss half in one call.  Reads the same dict entries as the reference:
     ``inputs[("color", f, 0)]``, ``("K", 0)``, ``("inv_K", 0)``; ``mono_outputs[("disp", 0)]``,
     ``("axisangle", 0, f)`` / ``("translation", 0, f)`` (networks/repdepth.py:155-156);
     ``outputs[("disp", 0)]``, ``"consistency_mask"``, ``"augmentation_mask"``, ``"lowest_cost"``.
     Writes ``outputs["consistency_mask"]`` (x matching mask, trainer.py:592-593) when ``want_maps``.
+    ``want_decisions`` (tests) adds ``maps["dec_teacher"]`` / ``["dec_student"]``: the per-pixel decisions of the two
+    gradient passes (int32 (MAL_DEC_PLANES,B,H,W), include/mal_hip.h).
     Returns (losses dict, loss_list or None, maps dict)."""
     from . import config, loss_utils
     if getattr(opt, "temporal", False) or getattr(opt, "main_temporal", False) or getattr(opt, "dual_distil", False) \
@@ -129,14 +136,15 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
     consts = (color0, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)],
               outputs["consistency_mask"].to(torch.float32), keep, outputs["lowest_cost"], noise)
     cfg = (opt.min_depth, opt.max_depth, bool(getattr(opt, "no_ens", False)), w_main, w_distil, bool(want_maps),
-           aug_is_mask)
+           aug_is_mask, bool(want_decisions))
     res = LossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
                            fix(tr[1]), consts, cfg)
     total, v = res[0].reshape(()), res[1]
     maps = {}
+    names = (["mono_reproj", "multi_reproj", "consistency_mask"] + ([] if cfg[2] else ["ens_reproj"])) if want_maps else []
+    names += ["dec_teacher", "dec_student"] if want_decisions else []
+    maps = dict(zip(names, res[2:]))
     if want_maps:
-        names = ["mono_reproj", "multi_reproj", "consistency_mask"] + ([] if cfg[2] else ["ens_reproj"])
-        maps = dict(zip(names, res[2:]))
         outputs["consistency_mask"] = maps["consistency_mask"]
     losses = {"reproj_loss/0": v[9], "consistency_loss/0": v[4], "distil_loss": v[6], "loss/0": v[11] if blc else v[10],
               "loss": total, "mono/reproj_loss/0": v[0], "mono/loss": v[2], "smooth_loss/mono": v[1],

@@ -60,6 +60,44 @@ def grid_sample_bilinear_border(src, grid, align_corners=True):
     return tap(y0, x0) * w_nw + tap(y0, x1) * w_ne + tap(y1, x0) * w_sw + tap(y1, x1) * w_se
 
 
+def grid_sample_forced_taps(src, grid, x0, y0, clipx, clipy, align_corners=True):
+    """The same bilinear border sampling with its two discontinuous choices TAKEN from the caller instead of
+    re-decided: ``x0``/``y0`` (B,Ho,Wo) long = floor of the clipped position, ``clipx``/``clipy`` bool = the clip is
+    active (no gradient to the grid).  Used by the decision-forced parity tests: a position within rounding distance
+    of an integer or of the border may fall on either side in two correct fp32 evaluations; the value is continuous
+    there, only d/d(grid) differs.  With the decisions this function itself would take it equals
+    ``grid_sample_bilinear_border`` exactly."""
+    B, C, H, W = src.shape
+    ix = unnormalize(grid[..., 0], W, align_corners)
+    iy = unnormalize(grid[..., 1], H, align_corners)
+    ix = torch.where(clipx, ix.detach().clamp(0.0, float(W - 1)), ix)
+    iy = torch.where(clipy, iy.detach().clamp(0.0, float(H - 1)), iy)
+    tx, ty = ix - x0.to(ix.dtype), iy - y0.to(iy.dtype)
+    x1, y1 = x0 + 1, y0 + 1
+    flat = src.reshape(B, C, H * W)
+
+    def tap(yy, xx):
+        ok = ((xx >= 0) & (xx < W) & (yy >= 0) & (yy < H))
+        idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).reshape(B, 1, -1).expand(B, C, -1)
+        v = torch.gather(flat, 2, idx).reshape(B, C, *xx.shape[1:])
+        return v * ok.unsqueeze(1).to(src.dtype)
+
+    w_nw = ((1 - tx) * (1 - ty)).unsqueeze(1)
+    w_ne = (tx * (1 - ty)).unsqueeze(1)
+    w_sw = ((1 - tx) * ty).unsqueeze(1)
+    w_se = (tx * ty).unsqueeze(1)
+    return tap(y0, x0) * w_nw + tap(y0, x1) * w_ne + tap(y1, x0) * w_sw + tap(y1, x1) * w_se
+
+
+def taps_of(grid, H, W, align_corners=True):
+    """The decisions ``grid_sample_bilinear_border`` takes for ``grid``: (x0, y0, clipx, clipy)."""
+    ix = unnormalize(grid[..., 0].detach(), W, align_corners)
+    iy = unnormalize(grid[..., 1].detach(), H, align_corners)
+    clipx, clipy = ~((ix > 0) & (ix < W - 1)), ~((iy > 0) & (iy < H - 1))
+    ix, iy = ix.clamp(0.0, float(W - 1)), iy.clamp(0.0, float(H - 1))
+    return torch.floor(ix).long(), torch.floor(iy).long(), clipx, clipy
+
+
 def reflection_pad1(x):
     """(B,C,H,W) -> (B,C,H+2,W+2), pad 1 with reflection (edge not repeated)."""
     x = torch.cat([x[:, :, 1:2, :], x, x[:, :, -2:-1, :]], 2)

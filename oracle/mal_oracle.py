@@ -181,10 +181,11 @@ def ssim(x, y, aten=True):
     return torch.clamp((1 - n / d) / 2, 0, 1)
 
 
-def compute_reprojection_loss(pred, target, no_ssim=False, aten=True):
+def compute_reprojection_loss(pred, target, no_ssim=False, aten=True, l1_sign=None):
     """manydepth/loss_utils.py:46-55 (== manydepth/trainer.py:1211-1223 with
-    ``no_ssim``, dualrefine/trainer.py:487-499).  0.85*mean_c SSIM + 0.15*mean_c |t-p|."""
-    l1 = torch.abs(target - pred).mean(1, True)
+    ``no_ssim``, dualrefine/trainer.py:487-499).  0.85*mean_c SSIM + 0.15*mean_c |t-p|.
+    ``l1_sign`` (decision-forced parity tests): |t-p| is taken as s*(p-t) with the given sign(p-t)."""
+    l1 = (torch.abs(target - pred) if l1_sign is None else l1_sign * (pred - target)).mean(1, True)
     if no_ssim:
         return l1
     return 0.85 * ssim(pred, target, aten=aten).mean(1, True) + 0.15 * l1
@@ -198,19 +199,21 @@ def compute_loss_masks(reprojection_loss, identity_reprojection_loss):
     return (torch.argmin(both, 1, keepdim=True) == 0).float()
 
 
-def get_smooth_loss(disp, img):
-    """manydepth/layers.py:210-223: edge-aware first-difference smoothness."""
-    dx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
-    dy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
+def get_smooth_loss(disp, img, signs=None):
+    """manydepth/layers.py:210-223: edge-aware first-difference smoothness.  ``signs`` = (sx, sy) (decision-forced
+    parity tests): |a-b| is taken as s*(a-b) with the given sign instead of re-deciding it where a ~ b."""
+    dx = disp[:, :, :, :-1] - disp[:, :, :, 1:]
+    dy = disp[:, :, :-1, :] - disp[:, :, 1:, :]
+    dx, dy = (torch.abs(dx), torch.abs(dy)) if signs is None else (dx * signs[0], dy * signs[1])
     ix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
     iy = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
     return (dx * torch.exp(-ix)).mean() + (dy * torch.exp(-iy)).mean()
 
 
-def normalized_smooth_loss(disp, color):
+def normalized_smooth_loss(disp, color, signs=None):
     """manydepth/loss_utils.py:119-121: disp / (mean_HW disp + 1e-7), then a12."""
     mean_disp = disp.mean(2, True).mean(3, True)
-    return get_smooth_loss(disp / (mean_disp + 1e-7), color)
+    return get_smooth_loss(disp / (mean_disp + 1e-7), color, signs)
 
 
 def _draw_noise(shape, noise):
@@ -237,13 +240,15 @@ def default_opt(**kw):
     return SimpleNamespace(**o)
 
 
-def generate_images_pred(opt, inputs, outputs, is_multi=False, synth=None, aten=True):
+def generate_images_pred(opt, inputs, outputs, is_multi=False, synth=None, aten=True, forced=None):
     """manydepth/trainer.py:1078-1170.
 
     Per scale: upsample disp to full res (bilinear, align_corners=False) unless
     v1_multiscale, a1, then for f in frame_ids[1:]: a2 -> a3 -> a4.  T is detached for
     the multi-frame (student) pass (:1107-1109).  ``synth(inputs, outputs, scale) ->
     bool`` stands in for dyn_utils.image_synthesis (:1161-1165); returns has_ins.
+    ``forced`` (decision-forced parity tests, scale 0 only): {"taps": {f: (x0, y0, clipx, clipy)}} -- the bilinear
+    taps and border clips are taken as given (aten_restated.grid_sample_forced_taps).
     """
     has_ins = False
     for scale in range(opt.sclm + 1):
@@ -263,7 +268,11 @@ def generate_images_pred(opt, inputs, outputs, is_multi=False, synth=None, aten=
             pts = backproject_depth(depth, inputs[("inv_K", src_scale)])
             grid = project_3d(pts, inputs[("K", src_scale)], T, H, W)
             outputs[("sample", f, scale)] = grid
-            outputs[("color", f, scale)] = grid_sample_border(inputs[("color", f, src_scale)], grid, aten=aten)
+            if forced is not None:
+                outputs[("color", f, scale)] = AR.grid_sample_forced_taps(inputs[("color", f, src_scale)], grid,
+                                                                          *forced["taps"][f])
+            else:
+                outputs[("color", f, scale)] = grid_sample_border(inputs[("color", f, src_scale)], grid, aten=aten)
             if not opt.disable_automasking:
                 outputs[("color_identity", f, scale)] = inputs[("color", f, src_scale)]
         if synth is not None and ((not is_multi and opt.temporal) or (is_multi and opt.main_temporal)):
@@ -302,41 +311,48 @@ def compute_matching_mask(outputs):
 # ----------------------------------------------------------------------------------
 
 
-def _candidate_losses(inputs, outputs, with_syn, no_ssim=False, aten=True):
+def _candidate_losses(inputs, outputs, with_syn, no_ssim=False, aten=True, l1_sign=None):
+    """``l1_sign`` holds the signs of the WINNING candidate's L1 term; it is applied to every candidate, which is
+    harmless because the forced argmin then selects the winner's value only."""
     target = inputs[("color", 0, 0)]
-    cand = [compute_reprojection_loss(outputs[("color", f, 0)], target, no_ssim, aten) for f in (-1, 1)]
+    cand = [compute_reprojection_loss(outputs[("color", f, 0)], target, no_ssim, aten, l1_sign) for f in (-1, 1)]
     if with_syn:
-        cand += [compute_reprojection_loss(outputs[("syn", f, 0)], target, no_ssim, aten) for f in (-1, 1)]
+        cand += [compute_reprojection_loss(outputs[("syn", f, 0)], target, no_ssim, aten, l1_sign) for f in (-1, 1)]
     ident = [compute_reprojection_loss(inputs[("color", f, 0)], target, no_ssim, aten) for f in (-1, 1)]
     return torch.cat(cand, 1), torch.cat(ident, 1)
 
 
-def compute_mono_losses(inputs, outputs, temporal, has_ins, noise=None, aten=True):
-    """manydepth/loss_utils.py:57-129 (teacher).  Returns (losses, min_c R (B,1,H,W))."""
-    R, I = _candidate_losses(inputs, outputs, bool(temporal and has_ins), aten=aten)
+def compute_mono_losses(inputs, outputs, temporal, has_ins, noise=None, aten=True, forced=None):
+    """manydepth/loss_utils.py:57-129 (teacher).  Returns (losses, min_c R (B,1,H,W)).
+    ``forced`` (decision-forced parity tests): {"win": long (B,1,H,W), "automask": (B,1,H,W), "smooth": (sx, sy)} --
+    the argmin over candidates, the automask comparison and the signs inside the smoothness term are taken as given."""
+    R, I = _candidate_losses(inputs, outputs, bool(temporal and has_ins), aten=aten,
+                             l1_sign=None if forced is None else forced.get("l1"))
     ident = torch.min(I, dim=1, keepdim=True)[0]
-    rp = torch.min(R, dim=1, keepdim=True)[0]
+    rp = torch.min(R, dim=1, keepdim=True)[0] if forced is None else torch.gather(R, 1, forced["win"])
     ident = ident + _draw_noise(ident.shape, noise) * 0.00001
-    mask = compute_loss_masks(rp, ident)
+    mask = compute_loss_masks(rp, ident) if forced is None else forced["automask"].to(rp.dtype)
     reproj = (rp * mask).sum() / (mask.sum() + 1e-7)
-    smooth = normalized_smooth_loss(outputs[("disp", 0)], inputs[("color", 0, 0)])
+    smooth = normalized_smooth_loss(outputs[("disp", 0)], inputs[("color", 0, 0)], None if forced is None else forced["smooth"])
     loss = reproj + 1e-3 * smooth / (2 ** 0)
     losses = {"reproj_loss/0": reproj, "loss/0": loss, "loss": loss}
-    return losses, torch.min(R, dim=1, keepdim=True)[0]
+    return losses, (torch.min(R, dim=1, keepdim=True)[0] if forced is None else rp)
 
 
 def compute_main_losses(inputs, outputs, mono_reproj, ensemble_reproj, opt, w_list, multi_has_ins,
-                        noise=None, aten=True):
+                        noise=None, aten=True, forced=None):
     """manydepth/loss_utils.py:131-281 (student).  Returns (losses, new_w_list, loss_list).
 
     The automask is computed and then replaced by ones (:181-192): the identity terms
     and the noise do not reach any value, but the CPU generator still advances (:178).
     The pareto branch (:256-265) needs manydepth/pareto.py, which upstream never
     committed: not restated.
+    ``forced`` (decision-forced parity tests): {"win", "distil": long (B,1,H,W), "smooth": (sx, sy)}.
     """
-    R, I = _candidate_losses(inputs, outputs, bool(multi_has_ins), aten=aten)
+    R, I = _candidate_losses(inputs, outputs, bool(multi_has_ins), aten=aten,
+                             l1_sign=None if forced is None else forced.get("l1"))
     ident = torch.min(I, dim=1, keepdim=True)[0]
-    rp = torch.min(R, dim=1, keepdim=True)[0]
+    rp = torch.min(R, dim=1, keepdim=True)[0] if forced is None else torch.gather(R, 1, forced["win"])
     multi_reproj = rp.clone()
     ident = ident + _draw_noise(ident.shape, noise) * 0.00001
     m = torch.ones_like(compute_loss_masks(rp, ident))
@@ -353,14 +369,19 @@ def compute_main_losses(inputs, outputs, mono_reproj, ensemble_reproj, opt, w_li
 
     losses = {"consistency_loss/0": consistency, "reproj_loss/0": reproj}
     loss = reproj + consistency
-    loss = loss + 1e-3 * normalized_smooth_loss(outputs[("disp", 0)], inputs[("color", 0, 0)]) / (2 ** 0)
+    loss = loss + 1e-3 * normalized_smooth_loss(outputs[("disp", 0)], inputs[("color", 0, 0)],
+                                                None if forced is None else forced["smooth"]) / (2 ** 0)
 
     if ensemble_reproj is None:
         idx = torch.min(torch.cat([mono_reproj, multi_reproj], 1), dim=1, keepdim=True)[1]
+        if forced is not None:
+            idx = (forced["distil"] != 0).long()  # the kernels number the 2-way argmin 0 (teacher) / 2 (student)
         teacher = outputs[("mono_depth", 0, 0)] if opt.dual_distil else mono_depth
         distil_depth = torch.where(idx == 0, teacher, multi_depth)
     else:
         idx = torch.min(torch.cat([mono_reproj, ensemble_reproj, multi_reproj], 1), dim=1, keepdim=True)[1]
+        if forced is not None:
+            idx = forced["distil"]
         if opt.learn_ens:
             _, ens_depth = disp_to_depth(outputs["ens_disp"], opt.min_depth, opt.max_depth)
         else:
@@ -498,32 +519,37 @@ class LossBalancing:
 
 
 def mal_loss_step(opt, inputs, mono_outputs, outputs, noise_mono=None, noise_main=None, w_list=None,
-                  synth=None, aten=True, freeze_tp=False):
+                  synth=None, aten=True, freeze_tp=False, forced=None):
     """manydepth/trainer.py:573-629, the loss part of process_batch with --distil.
 
     ``mono_outputs`` / ``outputs`` hold what the networks would have produced
     (("disp",0), ("cam_T_cam",0,f), and for the student "consistency_mask",
     "augmentation_mask", "lowest_cost").  Returns (losses, loss_list, mono_losses,
     mono_reproj, ensemble_reproj).
+    ``forced`` (decision-forced parity tests): {"teacher": {...}, "student": {...}, "cmask": (B,H,W)} -- every
+    discontinuous per-pixel choice of the two gradient passes is taken from the caller (the HIP kernels' own
+    decisions) instead of being re-decided; everything else is the same arithmetic.
     """
-    has_ins = generate_images_pred(opt, inputs, mono_outputs, synth=synth, aten=aten)
+    ft, fs = (None, None) if forced is None else (forced["teacher"], forced["student"])
+    has_ins = generate_images_pred(opt, inputs, mono_outputs, synth=synth, aten=aten, forced=ft)
     if not opt.temporal:
         has_ins = False
-    mono_losses, mono_reproj = compute_mono_losses(inputs, mono_outputs, opt.temporal, has_ins, noise_mono, aten)
+    mono_losses, mono_reproj = compute_mono_losses(inputs, mono_outputs, opt.temporal, has_ins, noise_mono, aten, ft)
     for key in list(mono_outputs.keys()):
         if isinstance(key, tuple) and key[0] in ("depth", "disp"):
             outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
-    outputs["consistency_mask"] = outputs["consistency_mask"] * compute_matching_mask(outputs)
+    outputs["consistency_mask"] = (outputs["consistency_mask"] * compute_matching_mask(outputs) if forced is None
+                                   else forced["cmask"].to(outputs["consistency_mask"].dtype))
     ensemble_reproj = None
     if not opt.no_ens:
         disp_ens = (mono_outputs[("disp", 0)].detach() + outputs[("disp", 0)].detach()) / 2.0
         ensemble_reproj = generate_images_pred_ensemble(
             opt, inputs, outputs[("cam_T_cam", 0, -1)].detach(), outputs[("cam_T_cam", 0, 1)].detach(), disp_ens, aten)
-    multi_has_ins = generate_images_pred(opt, inputs, outputs, is_multi=True, synth=synth, aten=aten)
+    multi_has_ins = generate_images_pred(opt, inputs, outputs, is_multi=True, synth=synth, aten=aten, forced=fs)
     if not opt.main_temporal:
         multi_has_ins = False
     losses, w_list, loss_list = compute_main_losses(inputs, outputs, mono_reproj, ensemble_reproj, opt, w_list,
-                                                    multi_has_ins, noise_main, aten)
+                                                    multi_has_ins, noise_main, aten, fs)
     if not freeze_tp:
         for k, v in mono_losses.items():
             losses[k] = losses[k] + v

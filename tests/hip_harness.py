@@ -9,13 +9,14 @@ from oracle import mal_oracle as O
 LEAVES = ("disp_teacher", "disp_student", "axisangle_m1", "translation_m1", "axisangle_p1", "translation_p1")
 
 
-def run_oracle(batch, opt_kw, n0, n1, w_list=(0.7, 0.3)):
+def run_oracle(batch, opt_kw, n0, n1, w_list=(0.7, 0.3), forced=None):
+    """``forced``: the per-pixel decisions to take instead of re-deciding them (oracle.mal_oracle.mal_loss_step)."""
     B, _, H, W = batch["color0"].shape
     opt = O.default_opt(height=H, width=W, batch_size=B, **opt_kw)
     inputs, mono_outputs, outputs, leaves = to_dicts(batch, O.transformation_from_parameters)
     synth = fake_image_synthesis(batch["syn_rects"]) if "syn_rects" in batch else None
     losses, loss_list, mono_losses, mono_reproj, ens = O.mal_loss_step(
-        opt, inputs, mono_outputs, outputs, n0.clone(), n1.clone(), list(w_list), synth=synth)
+        opt, inputs, mono_outputs, outputs, n0.clone(), n1.clone(), list(w_list), synth=synth, forced=forced)
     final = B * (w_list[0] * loss_list[0] + w_list[1] * loss_list[1]) if opt.loss_blc else losses["loss"]
     final.backward()
     # maps the tests need for tie analysis
@@ -34,6 +35,7 @@ def run_oracle(batch, opt_kw, n0, n1, w_list=(0.7, 0.3)):
                 consistency_mask=outputs["consistency_mask"].numpy(),
                 cons_target=outputs["consistency_target/0"].numpy(),
                 mono_color={f: mono_outputs[("color", f, 0)].detach().numpy() for f in (-1, 1)},
+                multi_color={f: outputs[("color", f, 0)].detach().numpy() for f in (-1, 1)},
                 mono_sample={f: mono_outputs[("sample", f, 0)].detach().numpy() for f in (-1, 1)},
                 multi_sample={f: outputs[("sample", f, 0)].detach().numpy() for f in (-1, 1)},
                 grads={k: (t.grad if t.grad is not None else torch.zeros_like(t)).numpy() for k, t in leaves.items()})
@@ -92,6 +94,88 @@ def run_hip(batch, opt_kw, n0, n1, fuse=True, w_list=(0.7, 0.3), device="cuda:0"
     if "consistency_target/0" in outputs:
         res["cons_target"] = outputs["consistency_target/0"].cpu().numpy()
     return res
+
+
+# ------------------------------------------------------------------ decision-exact parity (tests/test_gpu_decisions.py)
+DEC_KINDS = ("win_t", "automask", "win_s", "distil", "cmask", "tap_t", "tap_s", "smooth_t", "smooth_s", "l1_t", "l1_s")
+
+
+def _smooth_signs(disp):
+    """signs of the first differences of the mean-normalised disparity (layers.py:210-223, loss_utils.py:119-121)"""
+    n = disp / (disp.mean(2, True).mean(3, True) + 1e-7)
+    return torch.sign(n[:, :, :, :-1] - n[:, :, :, 1:]), torch.sign(n[:, :, :-1, :] - n[:, :, 1:, :])
+
+
+def oracle_decisions(o, batch, n0, no_ens=False):
+    """The decisions the free-running oracle took in ``o = run_oracle(...)``, in the layout ``forced=`` expects."""
+    from oracle import aten_restated as AR
+    B, _, H, W = batch["color0"].shape
+    t = torch.from_numpy
+    idn = t(o["ident"]) + n0 * 0.00001
+    rp_t = t(o["mono_cands"]).min(1, keepdim=True)[0]
+
+    def l1_signs(colors, win):  # sign(pred - target) of the winning candidate, per channel
+        pred = torch.where(win == 0, t(colors[-1]), t(colors[1]))
+        return torch.sign(pred - batch["color0"])
+
+    win_t, win_s = t(o["mono_cands"]).argmin(1, keepdim=True), t(o["multi_cands"]).argmin(1, keepdim=True)
+    teacher = dict(win=win_t, automask=(rp_t <= idn).float(), l1=l1_signs(o["mono_color"], win_t),
+                   smooth=_smooth_signs(batch["disp_teacher"]),
+                   taps={f: AR.taps_of(t(o["mono_sample"][f]), H, W) for f in (-1, 1)})
+    rp_s = t(o["multi_cands"]).min(1, keepdim=True)[0]
+    trio = [t(o["mono_reproj"])] + ([] if no_ens or o["ens"] is None else [t(o["ens"])]) + [rp_s]
+    idx = torch.cat(trio, 1).argmin(1, keepdim=True)
+    if len(trio) == 2:
+        idx = idx * 2  # numbered as the kernels do: 0 teacher, 2 student
+    student = dict(win=win_s, distil=idx, l1=l1_signs(o["multi_color"], win_s),
+                   smooth=_smooth_signs(batch["disp_student"]),
+                   taps={f: AR.taps_of(t(o["multi_sample"][f]), H, W) for f in (-1, 1)})
+    return dict(teacher=teacher, student=student, cmask=t(o["consistency_mask"]))
+
+
+def kernel_decisions(maps):
+    """``maps`` of mal_amd.step.loss_step(want_decisions=True) -> the same layout (include/mal_hip.h MAL_DEC_*)."""
+    def taps(pl):
+        pl = pl.long()
+        return pl & 0xfff, (pl >> 12) & 0xfff, ((pl >> 24) & 1).bool(), ((pl >> 25) & 1).bool()
+
+    def one(d, student):
+        d = torch.as_tensor(d).cpu()
+        r = dict(win=(d[0].long() & 3)[:, None], smooth=((d[2][:, None, :, :-1] - 1).float(), (d[3][:, None, :-1, :] - 1).float()),
+                 taps={-1: taps(d[4]), 1: taps(d[5])},
+                 l1=torch.stack([((d[6].long() >> s) & 3) - 1 for s in (0, 2, 4)], 1).float())
+        if student:
+            r["distil"] = d[1].long()[:, None]
+        else:
+            r["automask"] = ((d[0].long() >> 2) & 1).float()[:, None]
+        return r
+    return dict(teacher=one(maps["dec_teacher"], False), student=one(maps["dec_student"], True),
+                cmask=torch.as_tensor(maps["consistency_mask"]).cpu().float())
+
+
+def decision_differences(a, b):
+    """per kind: bool (B,1,H,W)-broadcastable map of pixels where two decision sets differ"""
+    d = {}
+    d["win_t"] = a["teacher"]["win"] != b["teacher"]["win"]
+    d["automask"] = a["teacher"]["automask"] != b["teacher"]["automask"]
+    d["win_s"] = a["student"]["win"] != b["student"]["win"]
+    d["distil"] = a["student"]["distil"] != b["student"]["distil"]
+    d["cmask"] = (a["cmask"] != b["cmask"])[:, None]
+    for who, k in (("teacher", "tap_t"), ("student", "tap_s")):
+        m = None
+        for f in (-1, 1):
+            for u, v in zip(a[who]["taps"][f], b[who]["taps"][f]):
+                m = (u != v) if m is None else (m | (u != v))
+        d[k] = m[:, None]
+    for who, k in (("teacher", "l1_t"), ("student", "l1_s")):
+        d[k] = (a[who]["l1"] != b[who]["l1"]).any(1, keepdim=True)
+    for who, k in (("teacher", "smooth_t"), ("student", "smooth_s")):
+        (ax, ay), (bx, by) = a[who]["smooth"], b[who]["smooth"]
+        m = torch.zeros(ax.shape[0], 1, ax.shape[2], ax.shape[3] + 1, dtype=torch.bool)
+        m[..., :, :-1] |= ax != bx
+        m[..., :-1, :] |= ay != by
+        d[k] = m
+    return {k: v.numpy() for k, v in d.items()}
 
 
 def dilate3(mask):

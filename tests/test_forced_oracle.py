@@ -1,0 +1,48 @@
+"""Decision-forced mode of the CPU oracle (``forced=`` of oracle.mal_oracle.mal_loss_step): told the decisions it
+would take by itself, it must reproduce the free-running oracle -- so that, told the HIP kernels' decisions, any
+remaining difference to the kernels is arithmetic, not a re-decided near-tie (tests/test_gpu_decisions.py)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_io as G
+from tests import hip_harness as HH
+
+
+@pytest.mark.parametrize("tag", ["step_b2_32x64_distil", "step_b2_32x64_noens", "step_b3_37x50_distil"])
+def test_forced_with_own_decisions_reproduces_free_run(tag):
+    z = G.load(tag)
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    n0, n1 = G.noises(z, (B, 1, H, W))
+    kw = G.opt_kwargs(z)
+    o = HH.run_oracle(b, kw, n0, n1)
+    dec = HH.oracle_decisions(o, b, n0, no_ens=bool(kw.get("no_ens")))
+    f = HH.run_oracle(b, kw, n0, n1, forced=dec)
+    for k, v in o["losses"].items():
+        assert abs(f["losses"][k] - v) <= 2e-6 * abs(v), k
+    for k in HH.LEAVES:
+        a, r = f["grads"][k], o["grads"][k]
+        # the restated sampler (explicit taps) and ATen's differ by fp32 association only
+        assert np.abs(a - r).max() <= 1e-4 * np.abs(r).max(), (k, np.abs(a - r).max() / np.abs(r).max())
+    d = HH.decision_differences(dec, dec)
+    assert not any(v.any() for v in d.values())
+
+
+def test_forcing_changes_only_the_forced_choice():
+    """flip one teacher winner: the value moves by the candidates' gap at that pixel, nothing else changes"""
+    z = G.load("step_b2_32x64_distil")
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    n0, n1 = G.noises(z, (B, 1, H, W))
+    o = HH.run_oracle(b, {}, n0, n1)
+    dec = HH.oracle_decisions(o, b, n0)
+    m = dec["teacher"]["automask"][0, 0]
+    y, x = [int(v[0]) for v in torch.nonzero(m)[:1].T]
+    dec["teacher"]["win"][0, 0, y, x] ^= 1
+    del dec["teacher"]["l1"]  # the signs belong to the old winner; without them |t-p| is re-decided
+    f = HH.run_oracle(b, {}, n0, n1, forced=dec)
+    gap = abs(float(o["mono_cands"][0, 0, y, x] - o["mono_cands"][0, 1, y, x]))
+    expect = gap / float(dec["teacher"]["automask"].sum())
+    got = f["mono_losses"]["reproj_loss/0"] - o["mono_losses"]["reproj_loss/0"]
+    assert abs(got - expect) <= 1e-2 * expect + 1e-7, (got, expect)  # the loss itself is an fp32 number near 0.1
