@@ -13,9 +13,16 @@ terms, pose composition and the full backward to the four leaves
 The path shards by batch with no data-path collective (each DDP rank
 normalises over its own batch); ranks are replicas over disjoint batches -> weak scaling.
 
+At N>1 (one process per GPU over RCCL; `--gpus N` without WORLD_SIZE spawns the N ranks itself through
+torch.distributed.run BEFORE anything touches the GPU) every step ends with the data-parallel exchange of the
+trainer -- ONE all-reduce of the flat 165 MB fp32 gradient bucket of RepDepth (mal_amd/dp.py; manydepth/trainer.py:
+309-311,469) -- timed inside the step and reported as its own `breakdown_ms` entry.
+
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline:     the teacher-pass fused kernel, timed live with HIP events on its stream
-  cpu_baseline: the CPU oracle (PyTorch-CPU restatement == the reference's path) on the host.
+  roofline:     the teacher-pass fused kernel, timed live with HIP events on its stream (--mode step only)
+  cpu_baseline: the CPU oracle (PyTorch-CPU restatement == the reference's path) on the host
+  train_step:   the WHOLE training step of the harness (networks through MIOpen + this loss path + all-reduce + Adam):
+                images/s and per-stage breakdown, so that the loss-path rate in `value` is never read as training throughput.
 """
 from __future__ import annotations
 
@@ -52,8 +59,32 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mal_set_option before the run (kernel experiments, e.g. march_rows=16)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU-oracle steps (median), after 3 warm-ups")
+    ap.add_argument("--train-steps", type=int, default=5,
+                    help="steps of the whole training step timed for the `train_step` block (0 = leave it out)")
     return ap.parse_args()
+
+
+N_GRAD_PARAMS = 41_247_150  # trainable fp32 parameters of RepDepth (tests/test_networks.py): 165 MB
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` on its own: start the N ranks (one process per GPU) as children through
+    torch.distributed.run and relay rank 0's JSON line.  Runs before this process has made any HIP call (a process
+    that has initialised the GPU must not exec or be re-used as a launcher on this pool); a failing rank makes the
+    whole launch exit non-zero."""
+    import socket
+    import subprocess
+    if os.environ.get("MAL_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 class TrainStep:
@@ -92,8 +123,12 @@ class Step:
         from mal_amd import config, layers, trainer, step as step_mod
         self.mode, self.step_mod = mode, step_mod
         from mal_amd.synthetic import make_batch
-        config.noise_source = "cuda"       # device RNG: no host randn / H2D on the step
+        # no host randn / H2D on the step: the whole-step API draws the tie-break noise inside its first
+        # kernel (Philox, keyed per rank); the operator-level modes use the device generator
+        config.noise_source = "philox" if mode == "step" else "cuda"
+        config.noise_seed = 0x4d414c5eed + seed
         config.consistency_target = False  # logging-only map (loss_utils.py:212-215)
+        self.one = torch.ones((), dtype=torch.float32, device=dev)  # d(loss)/d(loss): handed to backward, no fill launch
         self.layers = layers
         from mal_amd import ops
         self.ops = ops
@@ -139,7 +174,7 @@ class Step:
             outputs = {("disp", 0): lv["disp_student"], "consistency_mask": self.cmask,
                        "augmentation_mask": self.aug, "lowest_cost": self.lowest}
             losses, _, _ = self.step_mod.loss_step(self.lp.opt, self.inputs, mono_outputs, outputs, want_maps=False)
-            losses["loss"].backward()
+            losses["loss"].backward(gradient=self.one)
             return losses["loss"]
         self.ops.clear_packed_sources()  # a real step sees new images: repack them every step
         T_m1 = L.transformation_from_parameters(lv["axisangle_m1"], lv["translation_m1"], True)
@@ -184,7 +219,9 @@ def measured_copy_ceiling(dev, mib=1024, reps=5):
 
 def cpu_baseline(batch, steps):
     """The CPU oracle (oracle/mal_oracle.py, PyTorch-CPU ATen ops in the reference's order)
-    on the same workload: B=12 192x640, passes A+B+C forward+backward."""
+    on the same workload: B=12 192x640, passes A+B+C forward+backward.  SURVEY.md 8d: median of `steps` (10) runs after
+    3 warm-ups on the box's core share; one thread (the reference's OMP_NUM_THREADS=1, manydepth/trainer.py:8-10):
+    median of 3 after 1 warm-up, to keep the whole bench within minutes."""
     from mal_amd.synthetic import to_dicts
     from oracle import mal_oracle as O
     opt = O.default_opt(height=H, width=W, batch_size=B)
@@ -199,29 +236,37 @@ def cpu_baseline(batch, steps):
         losses, *_ = O.mal_loss_step(opt, inputs, mono_outputs, outputs)
         losses["loss"].backward()
 
-    one()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    dt = time.perf_counter() - t0
-    out = {"value": B * steps / dt, "unit": "images/s", "cores": threads, "kind": "port",
-           "sample": "%d steps of the same B=12 192x640 loss step (passes A+B+C fwd+bwd) after 1 warm-up, "
-                     "torch CPU threads=%d" % (steps, threads), "ms_per_step": 1e3 * dt / steps}
-    # what the reference's OMP_NUM_THREADS=1 (manydepth/trainer.py:8-10) would give: one thread, one step
+    def median_of(n_warm, n):
+        for _ in range(n_warm):
+            one()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            one()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    dt = median_of(3, steps)
+    out = {"value": B / dt, "unit": "images/s", "cores": threads, "kind": "port",
+           "sample": "median of %d steps of the same B=12 192x640 loss step (passes A+B+C fwd+bwd) after 3 warm-ups, "
+                     "torch CPU threads=%d" % (steps, threads), "ms_per_step": 1e3 * dt}
     torch.set_num_threads(1)
-    t0 = time.perf_counter()
-    one()
-    dt1 = time.perf_counter() - t0
+    dt1 = median_of(1, 3)
     torch.set_num_threads(all_threads)
-    out["single_thread"] = {"value": B / dt1, "unit": "images/s", "cores": 1, "sample": "1 step, no warm-up", "ms_per_step": 1e3 * dt1}
+    out["single_thread"] = {"value": B / dt1, "unit": "images/s", "cores": 1, "sample": "median of 3 steps after 1 warm-up",
+                            "ms_per_step": 1e3 * dt1}
     return out
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the MAL loss path has no CPU fallback")
     # MAL_BENCH_BACKEND=gloo rehearses the N>1 launch on a box with fewer GPUs than ranks (ranks share devices)
@@ -251,6 +296,7 @@ def main():
         args.no_cpu_baseline = True
     else:
         step = Step(dev, 1234 + rank, args.mode)
+    batch_cpu = step.batch_cpu
 
     def sync():
         # poll an event first: a blocking synchronize wakes the host up to ~0.1 ms late, which a short timed region
@@ -263,7 +309,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run = step
+    one_pass = step
     graph = None
     graph_note = None
     if args.graph:
@@ -278,100 +324,172 @@ def main():
             # thread_local: other threads of the process (the RCCL watchdog at N>1) may touch the runtime during capture
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 step()
-            run = graph.replay
+            one_pass = graph.replay
         except Exception as e:  # keep the measurement alive: eager launches (host-bound, slower), and say so
-            graph, run = None, step
+            graph, one_pass = None, step
             graph_note = "graph capture failed (%s: %s); eager launches" % (type(e).__name__, str(e).splitlines()[0][:120])
             torch.cuda.synchronize()
+
+    # N>1: the data-parallel exchange of the training step -- one all-reduce (mean) of the flat fp32 gradient bucket of
+    # RepDepth (165 MB; mal_amd/dp.py, manydepth/trainer.py:309-311,469).  The loss path has no parameters of its own,
+    # so outside --mode train (where the harness owns the real bucket) a buffer of the same size stands in for it.
+    bucket = None
+    if dist is not None and args.mode != "train":
+        from mal_amd.dp import FlatGradBucket
+        holder = torch.nn.Parameter(torch.zeros(N_GRAD_PARAMS, dtype=torch.float32,
+                                                device=dev if backend == "nccl" else "cpu"))
+        bucket = FlatGradBucket([holder])
+        bucket.flat.normal_()
+
+    def run():
+        one_pass()
+        if bucket is not None:
+            bucket.all_reduce_mean()
 
     # bring the GPU to its sustained clocks first (a few warm-up steps of 0.2 ms do not): ~0.1 s of the same step,
     # untimed and independent of --warmup, so that a short --steps run measures the steady state too
     t_ramp = time.perf_counter()
     while args.mode != "train" and time.perf_counter() - t_ramp < 0.1:
         for _ in range(20):
-            run()
+            one_pass()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         run()
-    # HIP events around the teacher-pass kernel (the first mal_pass_fused of a step), eager only
+    # HIP events around the teacher-pass kernel (the first marching launch of a step), eager only
     ev = []
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if graph is None:
+        if graph is None and args.mode == "step":
             a, b_ = lib.mal_event_create(), lib.mal_event_create()
             lib.mal_profile_next_pass(a, b_)
             ev.append((a, b_))
         run()
     sync()
     dt = time.perf_counter() - t0
+    n_ranks = world
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        n_ranks = dist.get_world_size()  # the ranks the collective actually saw
 
-    if graph is not None:  # kernel timing needs eager launches: a few extra steps outside the timed region
-        for i in range(20):
-            a, b_ = lib.mal_event_create(), lib.mal_event_create()
-            lib.mal_profile_next_pass(a, b_)
-            ev.append((a, b_))
-            step()
-        torch.cuda.synchronize()
+    # stages of the step, device time (HIP events on the current stream), outside the timed region
+    breakdown = None
+    if args.mode != "train":
+        n_bd = 20
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        acc = [0.0, 0.0]
+        for _ in range(n_bd):
+            e[0].record()
+            one_pass()
+            e[1].record()
+            if bucket is not None:
+                bucket.all_reduce_mean()
+            e[2].record()
+            torch.cuda.synchronize()
+            acc[0] += e[0].elapsed_time(e[1]) / n_bd
+            acc[1] += e[1].elapsed_time(e[2]) / n_bd
+        breakdown = {"loss_path_fwd_bwd": acc[0], "grad_all_reduce": acc[1] if bucket is not None else 0.0}
+
     durs = []
-    for a, b_ in ev:
-        ms = ctypes.c_float(0)
-        if lib.mal_event_elapsed_ms(a, b_, ctypes.byref(ms)) == 0:
-            durs.append(ms.value)
-        lib.mal_event_destroy(a), lib.mal_event_destroy(b_)
+    if args.mode == "step":
+        if graph is not None:  # kernel timing needs eager launches: a few extra steps outside the timed region
+            for i in range(20):
+                a, b_ = lib.mal_event_create(), lib.mal_event_create()
+                lib.mal_profile_next_pass(a, b_)
+                ev.append((a, b_))
+                step()
+            torch.cuda.synchronize()
+        for a, b_ in ev:
+            ms = ctypes.c_float(0)
+            if lib.mal_event_elapsed_ms(a, b_, ctypes.byref(ms)) == 0:
+                durs.append(ms.value)
+            lib.mal_event_destroy(a), lib.mal_event_destroy(b_)
     kern_ms = sum(durs) / max(len(durs), 1)
+
+    # the whole training step (all ranks take part: its all-reduce is a collective)
+    train_block = None
+    if args.mode != "train" and args.train_steps > 0:
+        try:
+            del step, graph
+            torch.cuda.empty_cache()
+            ts = TrainStep(dev, 1234 + rank)
+            for _ in range(2):
+                ts()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.train_steps):
+                ts()
+            sync()
+            dtt = time.perf_counter() - t1
+            if dist is not None:
+                t = torch.tensor([dtt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtt = float(t.item())
+            train_block = {"value": n_ranks * B * args.train_steps / dtt, "unit": "images/s", "ms_per_step": 1e3 * dtt / args.train_steps,
+                           "steps": args.train_steps, "breakdown_ms": ts.breakdown_ms(3),
+                           "what": "RepDepth (ResNet-18 x3 + decoders + pose + cost volume; fp32 torch.nn/MIOpen, random init) forward+backward, "
+                                   "this loss path, one flat-bucket gradient all-reduce, Adam; B=12 per GPU"}
+        except Exception as ex:  # the headline line must survive a failure of the side block
+            train_block = {"error": "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:200])}
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
     n_px = B * H * W
-    achieved = ALG_BYTES_PER_PX * n_px / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    copy_gbs = measured_copy_ceiling(dev)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("pass_kernel_teacher_bytes_per_launch")
-        except Exception:
-            traffic = None
     out = {
         "metric": "train images/sec at B=12 192x640 KITTI-shaped (MAL loss path: passes A+B+C fwd+bwd)",
-        "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "value": n_ranks * B * args.steps / dt, "unit": "images/s", "n_gpus": n_ranks, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "ManyDepth+MAL loss step, B=12 per GPU, 192x640, --distil (teacher+ensemble+student "
                                "passes, consistency+distillation+smoothness), fwd+bwd to disp/pose leaves; "
-                               "networks not included", "global_batch": B * world, "height": H, "width": W,
-                   "parallelism": "dp%d (replicas over disjoint batches, no data-path collective)" % world,
-                   "launch": "hip-graph" if graph is not None else (graph_note or "eager"),
+                               "networks not included (see train_step)", "global_batch": B * n_ranks, "height": H, "width": W,
+                   "parallelism": ("dp%d: replicas over disjoint batches, no data-path collective; every step ends with ONE RCCL "
+                                   "all-reduce (mean) of the 165 MB flat fp32 gradient bucket" % n_ranks) if n_ranks > 1
+                                  else "dp1 (single GPU: no collective)",
+                   "launch": "hip-graph" if args.graph and graph_note is None else (graph_note or "eager"),
                    "clock_ramp": "0.1 s of untimed steps before the --warmup steps (sustained clocks)",
                    "api": "mal_loss_step_fwd/_bwd (one host call per direction)" if args.mode == "step"
                           else "operator-level (mal_amd.loss_utils / MALLossPath)"},
-        "roofline": {"bound": "hbm", "kernel": "mal::march_kernel<true,true,true,false> (teacher pass: warp+SSIM+L1+"
-                                               "min+automask+smoothness fwd+bwd, one launch)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "alg_bytes_per_px": ALG_BYTES_PER_PX, "pixels_per_launch": n_px,
-                     "kernel_ms": kern_ms, "launches_timed": len(durs),
-                     "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None},
     }
+    if breakdown is not None:
+        out["breakdown_ms"] = breakdown
+    if args.mode == "step":
+        achieved = ALG_BYTES_PER_PX * n_px / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        copy_gbs = measured_copy_ceiling(dev)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("pass_kernel_teacher_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "mal::march_kernel<true,true,true,false> (teacher pass: warp+SSIM+L1+"
+                                                     "min+automask+smoothness fwd+bwd, one launch)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": traffic,
+                           "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel "
+                                             "(2*FETCH+WRITE, gfx950 correction), committed with the round; not re-measured in this run",
+                           "alg_bytes_per_px": ALG_BYTES_PER_PX, "pixels_per_launch": n_px,
+                           "kernel_ms": kern_ms, "launches_timed": len(durs),
+                           "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None}
     if args.mode == "train":
         out["metric"] = "train images/sec at B=12 192x640 KITTI-shaped (whole training step of the harness)"
         out["config"]["workload"] = ("RepDepth (ResNet-18 x3 + decoders + pose, cost volume) forward+backward through torch.nn/MIOpen, "
                                      "MAL loss step (6 HIP kernels), one flat-bucket gradient all-reduce (165 MB fp32), Adam; "
                                      "B=12 per GPU, 192x640, --distil, synthetic batch, random-init weights")
-        out["config"]["parallelism"] = "dp%d (one RCCL all-reduce of the flat gradient bucket per step)" % world
+        out["config"]["parallelism"] = "dp%d (one RCCL all-reduce of the flat gradient bucket per step)" % n_ranks
         out["config"]["api"] = "mal_amd.harness.TrainHarness.train_step"
         out["breakdown_ms"] = step.breakdown_ms()
-        out.pop("roofline")  # the kernel line belongs to the default mode
     elif args.mode != "step":
         out["config"]["workload"] += " [mode %s]" % args.mode
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(step.batch_cpu, args.cpu_steps)
+    if train_block is not None:
+        out["train_step"] = train_block
+    if n_ranks == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(batch_cpu, args.cpu_steps)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

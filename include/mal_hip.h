@@ -234,7 +234,10 @@ int mal_pose_bwd(const float* const* axisangle, const float* const* translation,
  * (mal_step_workspace_bytes); the same ws must be handed to _bwd. */
 enum {
   MAL_STEP_NO_ENS = 1,   /* --no_ens: 2-way distillation argmin, no ensemble pass */
-  MAL_STEP_AUG_MASK = 2  /* `augmentation_keep` holds augmentation_mask itself; 1 - mask is formed on the device */
+  MAL_STEP_AUG_MASK = 2, /* `augmentation_keep` holds augmentation_mask itself; 1 - mask is formed on the device */
+  MAL_STEP_NOISE_PHILOX = 4 /* the automask tie-break noise (loss_utils.py:105-106: + 1e-5 * randn) is drawn inside the
+                               step's first kernel: N(0,1) by Box-Muller from Philox4x32-10 keyed by noise_seed, counter =
+                               (pixel, step); `noise` must be NULL.  No host RNG, no device RNG launch on the step. */
 };
 typedef struct mal_step_args {
   int B, H, W;
@@ -262,7 +265,13 @@ typedef struct mal_step_args {
    * choices of loss_utils.py:103-113,178-199,237-254 instead of re-deciding near-ties.  Requesting them selects
    * instrumented instantiations of the same kernels (identical arithmetic); H, W < 4096.                       */
   uint32_t *dec_teacher, *dec_student;
+  /* MAL_STEP_NOISE_PHILOX: key; step number = *noise_counter when noise_counter != NULL (a device word the step's
+   * last kernel advances by one, so a replayed HIP graph draws fresh noise every replay), else noise_step;
+   * noise_out: (B,1,H,W) nullable, receives the N(0,1) values that were used (tests). */
+  uint64_t noise_seed, noise_step; uint64_t* noise_counter; float* noise_out;
 } mal_step_args;
+/* the same noise map on its own (tests; bit-identical to what the step draws for that seed / step) */
+int mal_tiebreak_noise(uint64_t seed, uint64_t step, int B, int H, int W, float* out, void* stream);
 enum {
   MAL_DEC_WIN = 0,     /* bits 0-1: winning candidate of the per-pixel min (0/1 = warped frame -1/+1, 2/3 = syn -1/+1);
                           bit 2: automask bit `min_c r_c <= identity + 1e-5*noise` (1 when the pass has no automask) */

@@ -70,8 +70,39 @@ int march_launch(MarchParams& p, int flags, hipStream_t st);
 // workgroups of the same launch compose the poses of both frames (layers.py:26-100), fill the camera block of
 // the marching passes and reset the completion counter of the step's last kernel.
 struct StepPoses { PoseParams pose; const float* K; const float* invK; float* cam; unsigned* ticket; };
+// Tie-break noise of the automask (loss_utils.py:105-106: identity + 1e-5 * randn) generated in the sweep and ADDED to
+// the identity map it writes: N(0,1) from Philox4x32-10 keyed by `seed`, counter = (pixel group, step) with
+// step = *counter (device, advanced by the step's last kernel so graph replays draw fresh noise) or `step`.
+struct TieNoise { int on; unsigned long long seed, step; const unsigned long long* counter; float* noise_out /*nullable*/; };
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
-                         const StepPoses* poses = nullptr);
+                         const StepPoses* poses = nullptr, const TieNoise* noise = nullptr);
+
+// Philox4x32-10 (Salmon et al., SC'11; the generator behind torch's device randn), one block of four 32-bit words
+MAL_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// the four N(0,1) values of pixel group `group` (= index of the pixel in row (y & ~3) of its column): Box-Muller on
+// the two word pairs; value j belongs to row (y & ~3) + j
+MAL_DEV void tie_noise4(unsigned long long seed, unsigned long long step, unsigned group, float (&n)[4]) {
+  unsigned o[4];
+  philox4x32_10(group, (unsigned)step, (unsigned)(step >> 32), 0x4d414cu, (unsigned)seed, (unsigned)(seed >> 32), o);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)o[2 * h] + 1.0f) * 2.3283064365386963e-10f;   // (0, 1]
+    const float u2 = (float)o[2 * h + 1] * 2.3283064365386963e-10f;       // [0, 1]
+    const float r = __builtin_sqrtf(-2.0f * __logf(u1));
+    n[2 * h] = r * __cosf(6.283185307179586f * u2);
+    n[2 * h + 1] = r * __sinf(6.283185307179586f * u2);
+  }
+}
 
 }  // namespace mal

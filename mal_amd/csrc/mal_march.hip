@@ -809,6 +809,7 @@ struct IdentParams {
   float* ident;                               // (B,1,H,W) out
   int B, H, W, strips, segs, rows, ntasks, per_xcd;
   int pose_blocks; StepPoses sp;              // the last pose_blocks workgroups: poses + camera block of sample b
+  TieNoise tn;                                // ident += 1e-5 * N(0,1) (Philox), see mal_march.h
 };
 
 __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
@@ -844,6 +845,8 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
   for (int i = 0; i < 2; ++i) { hyA[i] = bc(0.f); hyB[i] = bc(0.f); hzA[i] = 0.f; hzB[i] = 0.f; }
   f2 x1[3] = {bc(0.f), bc(0.f), bc(0.f)}, y1rg = bc(0.f);
   float y1b = 0.f;
+  float tn4[4] = {0.f, 0.f, 0.f, 0.f};  // tie-break noise of the current group of four rows of this column
+  const unsigned long long tn_step = p.tn.on ? (p.tn.counter ? *p.tn.counter : p.tn.step) : 0ull;
   auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
   // the nine planes of a pixel, requested one iteration ahead (see march_kernel)
   struct Px { float t[3], a[3], c[3]; };
@@ -900,7 +903,15 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
       const f2 l0 = y1rg - x1[0], l1 = y1rg - x1[1], l2 = bc(y1b) - x1[2];
       const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
       const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
-      if (out_x) stf(p.ident + (size_t)b * HW, (unsigned)(c * W + gxr) * 4u, fminf(rr.x, rr.y));
+      float idn = fminf(rr.x, rr.y);
+      if (p.tn.on) {  // wave-uniform
+        if ((c & 3) == 0 || c == y_lo) tie_noise4(p.tn.seed, tn_step, (unsigned)(b * HW + (c & ~3) * W + gxr), tn4);
+        const int j = c & 3;
+        const float nz = j == 0 ? tn4[0] : (j == 1 ? tn4[1] : (j == 2 ? tn4[2] : tn4[3]));
+        idn += nz * 0.00001f;
+        if (p.tn.noise_out && out_x) stf(p.tn.noise_out + (size_t)b * HW, (unsigned)(c * W + gxr) * 4u, nz);
+      }
+      if (out_x) stf(p.ident + (size_t)b * HW, (unsigned)(c * W + gxr) * 4u, idn);
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i]; hsB[i] = h[i]; }
@@ -988,8 +999,9 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
 
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
-                         const StepPoses* poses) {
+                         const StepPoses* poses, const TieNoise* noise) {
   IdentParams p = {};
+  if (noise) p.tn = *noise;
   p.pose_blocks = poses ? B : 0;
   if (poses) p.sp = *poses;
   p.target = target; p.src[0] = src0; p.src[1] = src1; p.packed[0] = packed0; p.packed[1] = packed1; p.packed_target = packed_target; p.ident = ident;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
                                                          const float* K, int per_sample, int B, int H, int W,
                                                          float w_main, float w_distil, double* ps, float* gT0, float* gT1,
                                                          double* stats, float* losses, float* coefs, float* loss_total,
-                                                         unsigned* ticket) {
+                                                         unsigned* ticket, unsigned long long* noise_counter) {
   __shared__ double s_part[256];
   __shared__ double s_gP[24];
   __shared__ double sh_tot[2][8];
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
   }
   __syncthreads();
   if (tid != 0) return;
+  if (noise_counter) *noise_counter += 1ull;  // every kernel of this step that reads it has finished (stream order)
   const double* st = sh_tot[0];
   const double* ss = sh_tot[1];
   const double N = (double)B * HW, Nx = (double)B * H * (W - 1), Ny = (double)B * (H - 1) * W;
@@ -218,6 +219,28 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
 
 using namespace mal;
 
+namespace mal {
+__global__ void tiebreak_noise_kernel(unsigned long long seed, unsigned long long step, int B, int H, int W, float* out) {
+  const int HW = H * W;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * HW) return;
+  const int b = (int)(i / HW), pix = (int)(i - (size_t)b * HW), y = pix / W, x = pix - y * W;
+  float n[4];
+  tie_noise4(seed, step, (unsigned)(b * HW + (y & ~3) * W + x), n);
+  out[i] = n[y & 3];
+}
+}  // namespace mal
+
+extern "C" int mal_tiebreak_noise(uint64_t seed, uint64_t step, int B, int H, int W, float* out, void* stream) {
+  int rc = check_shape(B, H, W);
+  if (rc) return rc;
+  if (!out) return MAL_EINVAL;
+  const size_t n = (size_t)B * H * W;
+  hipLaunchKernelGGL(tiebreak_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                     step, B, H, W, out);
+  return launch_status();
+}
+
 extern "C" size_t mal_step_workspace_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   return carve_step(nullptr, B, H, W).bytes;
@@ -256,8 +279,14 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     sp.pose.invert[0] = 1; sp.pose.invert[1] = 0;
     sp.pose.T[0] = w.T[0]; sp.pose.T[1] = w.T[1];
     sp.K = a->K; sp.invK = a->inv_K; sp.cam = w.cam; sp.ticket = w.ticket;
+    TieNoise tn = {};
+    if (a->flags & MAL_STEP_NOISE_PHILOX) {
+      if (a->noise) return MAL_EINVAL;
+      tn.on = 1; tn.seed = a->noise_seed; tn.step = a->noise_step; tn.counter = (const unsigned long long*)a->noise_counter;
+      tn.noise_out = a->noise_out;
+    }
     rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
-                              &sp);
+                              &sp, &tn);
     if (rc) return rc;
   }
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
@@ -310,7 +339,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   // 8. per-sample sums of both gradient passes, pose gradients, scalars
   hipLaunchKernelGGL(step_final_kernel, dim3(3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, w.bgP, a->K, per_sample, B, H, W,
                      a->w_main, a->w_distil, w.ps, w.gT[0], w.gT[1], w.sm_stats, a->losses, w.coefs, a->loss_total,
-                     w.ticket);
+                     w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr);
   return launch_status();
 }
 

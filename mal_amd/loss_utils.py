@@ -52,7 +52,8 @@ def draw_noise(shape, device):
     """The tie-break noise of loss_utils.py:105-106,178.  ``config.noise_source``:
     "cpu"  -- ``torch.randn(shape)`` from the global CPU generator then H2D, exactly the
               reference's stream (default);
-    "cuda" -- the device generator (no host work, no PCIe copy; same distribution)."""
+    "cuda" -- the device generator (no host work, no PCIe copy; same distribution);
+    "philox" -- only the whole-step API draws inside its kernels (mal_amd.step); here as "cuda"."""
     if config.noise_source == "cpu":
         return torch.randn(shape).to(device, non_blocking=True)
     return torch.randn(shape, device=device)

@@ -19,7 +19,16 @@ from . import _lib as L
 from . import ops
 
 _WS = {}
-MAP_NAMES = ("mono_reproj", "multi_reproj", "consistency_mask", "ens_reproj", "dec_teacher", "dec_student")
+_NOISE_COUNTER = {}  # per device: the step number of the "philox" noise stream, a device word the step itself advances
+MAP_NAMES = ("mono_reproj", "multi_reproj", "consistency_mask", "ens_reproj", "noise", "dec_teacher", "dec_student")
+
+
+def noise_counter(dev):
+    """(1,) int64 device tensor: how many steps of the in-kernel ("philox") tie-break noise stream have been drawn"""
+    t = _NOISE_COUNTER.get(dev.index)
+    if t is None:
+        t = _NOISE_COUNTER[dev.index] = torch.zeros(1, dtype=torch.int64, device=dev)
+    return t
 
 
 def _workspace(dev, B, H, W):
@@ -38,17 +47,23 @@ class LossStepFn(Function):
     @staticmethod
     def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg):
         color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise = consts
-        min_depth, max_depth, no_ens, w_main, w_distil, want_maps, aug_is_mask, want_dec = cfg
+        min_depth, max_depth, no_ens, w_main, w_distil, want_maps, aug_is_mask, want_dec, philox = cfg
         req = ops._req
         tens = [req(t, n) for t, n in ((disp_t, "disp_teacher"), (disp_s, "disp_student"), (aa_m1, "axisangle"),
                                        (tr_m1, "translation"), (aa_p1, "axisangle"), (tr_p1, "translation"))]
-        cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise)]
+        cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest)]
+        cons.append(None if noise is None else req(noise, "input"))
         B, _, H, W = tens[0].shape
         dev = tens[0].device
         a = L.StepArgs()
         a.B, a.H, a.W = B, H, W
         a.min_depth, a.max_depth = float(min_depth), float(max_depth)
         a.flags = (L.STEP_NO_ENS if no_ens else 0) | (L.STEP_AUG_MASK if aug_is_mask else 0)
+        if philox is not None:  # (seed, want the drawn values back)
+            a.flags |= L.STEP_NOISE_PHILOX
+            a.noise_seed = int(philox[0]) & 0xFFFFFFFFFFFFFFFF
+            ctr = noise_counter(tens[0].device)
+            a.noise_counter = ctr.data_ptr()
         a.w_main, a.w_distil = float(w_main), float(w_distil)
         p = ops._p
         a.disp_teacher, a.disp_student = p(tens[0]), p(tens[1])
@@ -68,6 +83,9 @@ class LossStepFn(Function):
             a.mono_reproj, a.multi_reproj = p(maps["mono_reproj"]), p(maps["multi_reproj"])
             a.consistency_mask_out = p(maps["consistency_mask"])
             a.ens_reproj = p(maps.get("ens_reproj"))
+        if philox is not None and philox[1]:
+            maps["noise"] = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+            a.noise_out = p(maps["noise"])
         if want_dec:  # parity instrumentation (tests): the kernels' per-pixel decisions, MAL_DEC_* planes
             for k in ("dec_teacher", "dec_student"):
                 maps[k] = torch.zeros((L.DEC_PLANES, B, H, W), dtype=torch.int32, device=dev)
@@ -100,7 +118,7 @@ class LossStepFn(Function):
 
 
 def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=None, noise=None, want_maps=True,
-              want_decisions=False):
+              want_decisions=False, want_noise=False):
     """process_batch's loss half in one call.  Reads the same dict entries as the reference:
     ``inputs[("color", f, 0)]``, ``("K", 0)``, ``("inv_K", 0)``; ``mono_outputs[("disp", 0)]``,
     ``("axisangle", 0, f)`` / ``("translation", 0, f)`` (networks/repdepth.py:155-156);
@@ -121,10 +139,14 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
     aa = {f: mono_outputs[("axisangle", 0, f)] for f in (-1, 1)}
     tr = {f: mono_outputs[("translation", 0, f)] for f in (-1, 1)}
     fix = lambda t: t[:, 0] if t.dim() == 4 else t  # the pose decoder emits (B,2,1,3); frame 0 of it is used
+    philox = None
     if noise is None and not getattr(opt, "disable_automasking", False):
-        noise = loss_utils.draw_noise((B, 1, H, W), dev)
-        if config.noise_source == "cpu":
-            torch.randn((B, 1, H, W))  # compute_main_losses' dead draw (loss_utils.py:178)
+        if config.noise_source == "philox":  # drawn inside the step's first kernel: no RNG launch, no host work
+            philox = (config.noise_seed, bool(want_noise))
+        else:
+            noise = loss_utils.draw_noise((B, 1, H, W), dev)
+            if config.noise_source == "cpu":
+                torch.randn((B, 1, H, W))  # compute_main_losses' dead draw (loss_utils.py:178)
     aug = outputs["augmentation_mask"][:opt.batch_size]
     aug_is_mask = aug.dtype == torch.float32 and aug.is_contiguous()  # then 1 - mask is formed on the device
     keep = aug.reshape(B) if aug_is_mask else (1 - aug).to(torch.float32).reshape(B)
@@ -136,12 +158,13 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
     consts = (color0, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)],
               outputs["consistency_mask"].to(torch.float32), keep, outputs["lowest_cost"], noise)
     cfg = (opt.min_depth, opt.max_depth, bool(getattr(opt, "no_ens", False)), w_main, w_distil, bool(want_maps),
-           aug_is_mask, bool(want_decisions))
+           aug_is_mask, bool(want_decisions), philox)
     res = LossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
                            fix(tr[1]), consts, cfg)
     total, v = res[0].reshape(()), res[1]
     maps = {}
     names = (["mono_reproj", "multi_reproj", "consistency_mask"] + ([] if cfg[2] else ["ens_reproj"])) if want_maps else []
+    names += ["noise"] if philox is not None and philox[1] else []
     names += ["dec_teacher", "dec_student"] if want_decisions else []
     maps = dict(zip(names, res[2:]))
     if want_maps:

@@ -94,9 +94,13 @@ def test_march_direction_option():
 
 
 def _check_step(b, kw, n0, n1):
+    """free-running oracle: scalars and maps (with the explicit allowance of the near-tie pixels, which move a MEAN by
+    at most their own terms); gradients: decision-exact (tests/test_gpu_decisions.py) -- the kernels' per-pixel
+    decisions are shown to differ from the oracle's only at near-ties, then every leaf is held at 1e-4 / the fp32
+    reference's own distance from exact arithmetic with the decisions forced.  No percent-level allowance anywhere."""
+    from tests.test_gpu_decisions import check_step_decision_exact
     B, _, H, W = b["color0"].shape
-    o = HH.run_oracle(b, kw, n0, n1)
-    h = run_step(b, kw, n0)
+    (h, o), _, _ = check_step_decision_exact(b, kw, n0, n1, return_runs=True)
     N = B * H * W
     amb_distil = HH.near_tie(np.concatenate([m for m in (o["mono_reproj"], o["ens"], o["multi_cands"].min(1, keepdims=True))
                                              if m is not None], 1), 2e-4)
@@ -112,31 +116,10 @@ def _check_step(b, kw, n0, n1):
     assert abs(h["losses"]["loss"] - o["final"]) <= 1e-4 * abs(o["final"]) + scale * (allow + allow_auto), (h["losses"]["loss"], o["final"])
     if kw.get("loss_blc"):
         assert abs(h["loss_list"][0] - o["loss_list"][0]) <= 1e-4 * abs(o["loss_list"][0]) + allow_auto
-    assert np.abs(h["maps"]["mono_reproj"] - o["mono_reproj"]).max() <= 1e-4
+    assert np.abs(h["maps"]["mono_reproj"].numpy() - o["mono_reproj"]).max() <= 1e-4
     if o["ens"] is not None:
-        assert np.abs(h["maps"]["ens_reproj"] - o["ens"]).max() <= 1e-4
-    assert (h["maps"]["consistency_mask"] != o["consistency_mask"]).mean() <= 1e-5
-    # gradients: per-pixel maps off the near-tie pixels, summed (pose) gradients against the fp64 floor
-    idn = o["ident"] + n0.numpy() * np.float32(1e-5)
-    amb_t = HH.dilate3(HH.near_tie(o["mono_cands"], 2e-4) | (np.abs(o["mono_reproj"] - idn) <= 1e-4))
-    amb_t |= HH.sample_ambiguous(o["mono_sample"], H, W)
-    amb_s = HH.dilate3(HH.near_tie(o["multi_cands"], 2e-4)) | HH.sample_ambiguous(o["multi_sample"], H, W) | amb_distil
-    amb_s |= np.abs(o["mono_depth"] - o["multi_depth"]) <= 1e-6 * np.abs(o["mono_depth"])
-    amb_t |= HH.smooth_sign_ambiguous(b["disp_teacher"].numpy())   # neighbours equal to a few ulp: sign of the
-    amb_s |= HH.smooth_sign_ambiguous(b["disp_student"].numpy())   # smoothness difference is a rounding matter
-    o64 = HH.oracle_fp64_grads(b, kw, n0, n1)
-    for key in HH.LEAVES:
-        g, r, r64 = h["grads"][key], o["grads"][key], o64[key]
-        extra = 0.0 if key == "disp_student" else renorm
-        if key.startswith("disp"):
-            keep = ~(amb_t if key == "disp_teacher" else amb_s)
-            err = np.abs(g - r)[keep]
-            assert (err > (2e-4 + extra) * np.abs(r).max()).mean() <= 2e-5, (key, err.max() / np.abs(r).max())
-            g, r, r64 = g[keep], r[keep], r64[keep]
-        elif any_auto:
-            extra += 2e-2  # the summed (pose) gradients gain or lose that pixel's whole contribution
-        floor = _l2rel(r, r64)
-        assert _l2rel(g, r) <= max(1e-4, 1.5 * floor) + extra, (key, _l2rel(g, r), floor)
+        assert np.abs(h["maps"]["ens_reproj"].numpy() - o["ens"]).max() <= 1e-4
+    assert (h["maps"]["consistency_mask"].numpy() != o["consistency_mask"]).mean() <= 1e-5
 
 
 def test_loss_step_equals_operator_route():
