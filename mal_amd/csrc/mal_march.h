@@ -15,11 +15,6 @@ struct MarchParams {
   // whole-step launch list (mal_step.hip): the teacher's depth is re-derived from its disparity and
   // the matching mask (trainer.py:1066-1076) is formed in place, so neither map touches HBM
   const float* mono_disp; const float* lowest_cost; float* cmask_out;
-  // smoothness of this pass's disparity folded into the sweep (GRAD passes of the whole-step list): d loss /
-  // d normalised-disp map out; per-task partials block_sums[task][4..7] = sum |dx d| w, sum |dy d| w, sum gn*disp,
-  // sum disp -- the 1/(mean+1e-7) of the mean normalisation is applied per sample afterwards
-  // (layers.py:210-223, loss_utils.py:119-121)
-  float* smooth_gn;
   // whole-step list: with g_distil == nullptr the two epilogue gradients leave as ONE map,
   // merge_cons * d cons + merge_distil * d distil (their loss weights do not depend on the data)
   float merge_cons, merge_distil;
@@ -74,9 +69,15 @@ struct StepPoses { PoseParams pose; const float* K; const float* invK; float* ca
 // the identity map it writes: N(0,1) from Philox4x32-10 keyed by `seed`, counter = (pixel group, step) with
 // step = *counter (device, advanced by the step's last kernel so graph replays draw fresh noise) or `step`.
 struct TieNoise { int on; unsigned long long seed, step; const unsigned long long* counter; float* noise_out /*nullable*/; };
+// Edge-aware smoothness (get_smooth_loss of the mean-normalised disparity, layers.py:210-223 + loss_utils.py:119-121)
+// of n <= 2 disparity maps in the identity/packing sweep: gn[m] = d loss / d normalised-disp map out (unnormalised by
+// the sample's 1/(mean+1e-7)), partials [task][m][4] = sum |dx d| w, sum |dy d| w, sum gn*disp, sum disp;
+// dec[m] (tests, nullable): decision planes receiving the signs taken (MAL_DEC_SMOOTH_X / _Y).
+struct SmoothParams { int n; const float* disp[2]; float* gn[2]; double* partials; unsigned* dec[2]; };
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
-                         const StepPoses* poses = nullptr, const TieNoise* noise = nullptr);
+                         const StepPoses* poses = nullptr, const TieNoise* noise = nullptr,
+                         const SmoothParams* smooth = nullptr, int* tasks_per_sample = nullptr);
 
 // Philox4x32-10 (Salmon et al., SC'11; the generator behind torch's device randn), one block of four 32-bit words
 MAL_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {

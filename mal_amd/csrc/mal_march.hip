@@ -155,7 +155,9 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
   for (int f = 0; f < 2; ++f) {
     const int x0 = (int)x0f[f], y0 = (int)y0f[f];
     const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);  // x0+1 == W only with weight 0
-    oo[f][0] = y0 * W + x0; oo[f][1] = y0 * W + x1; oo[f][2] = y1 * W + x0; oo[f][3] = y1 * W + x1;
+    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): rows and H*W are below 2^24 (march_launch checks)
+    const int r0 = (int)__umul24((unsigned)y0, (unsigned)W), r1 = (int)__umul24((unsigned)y1, (unsigned)W);
+    oo[f][0] = r0 + x0; oo[f][1] = r0 + x1; oo[f][2] = r1 + x0; oo[f][3] = r1 + x1;
     if (p.debug & 1) { oo[f][0] = oo[f][1] = oo[f][2] = oo[f][3] = pix; }
     if (DBG && p.dbg_on)
       dec_store(p.dbg, p.dbg_n, MAL_DEC_TAP0 + f, p.dbg_off,
@@ -168,7 +170,7 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
     if (p.packed & 1) {
       const float* sp = p.src[f] + (size_t)b * HW * kTexel;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) w.t[f][k] = ldt(sp, (unsigned)o[k] * (unsigned)(kTexel * 4));
+      for (int k = 0; k < 4; ++k) w.t[f][k] = ldt(sp, __umul24((unsigned)o[k], (unsigned)(kTexel * 4)));
     } else {
       const float* p0 = p.src[f] + (size_t)b * 3 * HW;
       const float* p1 = p0 + HW;
@@ -253,8 +255,8 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   const int lane = threadIdx.x;
   // Rows are LOGICAL rows of this task: odd segments see the sample upside down (physical row = H-1 - logical), so
   // they walk bottom-up and a segment boundary is reached by both of its tasks at the same time -- the halo rows one
-  // of them re-reads are then still in the XCD's L2.  Box filter, reflection padding and the smoothness stencil are
-  // symmetric under the flip; only addresses and the ray's row use the physical row (prow).
+  // of them re-reads are then still in the XCD's L2.  Box filter and reflection padding are symmetric under the flip;
+  // only addresses and the ray's row use the physical row (prow).
   const int ph_lo = seg * p.rows, ph_hi = min(ph_lo + p.rows, H);
   const bool flip = (seg & 1) != 0 && p.flip_odd != 0;
   const int y_lo = flip ? H - ph_hi : ph_lo, y_hi = flip ? H - ph_lo : ph_hi;
@@ -274,7 +276,11 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   const bool out_x = in_x && lane >= HALO && lane < 64 - HALO;
   // adjoint of the horizontal reflection: what this lane's partials count for when they are
   // shifted to the right neighbour (it is column 0 feeding column 1) / to the left neighbour
+#ifdef MAL_EXP_NOREFL  // experiment: what the adjoint's border multipliers cost
+  constexpr float sL = 1.0f, sR = 1.0f;
+#else
   const float sL = gx == 0 ? 2.0f : 1.0f, sR = gx == W - 1 ? 2.0f : 1.0f;
+#endif
 
   // (B,1,H,W) maps are addressed as (kernel-argument pointer) + (32-bit per-lane byte offset that already holds the
   // sample's base): no 64-bit pointer arithmetic per map and row (check_shape bounds a map below 2^31 bytes)
@@ -297,14 +303,6 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   PixInfo pi1;                   // row c-1 = r-2 (decided one iteration ago)
   f2 gP[POSE ? 12 : 1];          // d loss / d P of both frames
   float acc_rw = 0.f, acc_w = 0.f, acc_cons = 0.f, acc_dist = 0.f;  // per-lane partials (<= rows terms each)
-  // in-sweep smoothness state: normalised / raw disparity of the previous row, its pending gradient
-  // (the per-sample 1/(mean+1e-7) of the normalised disparity is a positive constant of the sample: it is
-  // factored out of |d n| and applied to the per-sample sums afterwards; the sample mean itself comes from
-  // the sum of the disparity over the task's pixels, partial slot 7)
-  const bool smooth = GRAD && p.smooth_gn != nullptr;
-  const float sm_nx = 1.0f / ((float)p.B * (float)H * (float)(W - 1)), sm_ny = 1.0f / ((float)p.B * (float)(H - 1) * (float)W);
-  float sm_n1 = 0.f, sm_d1 = 0.f, sm_g1 = 0.f;
-  float acc_sx = 0.f, acc_sy = 0.f, acc_sd = 0.f, acc_d = 0.f;  // per-lane partials over <= rows pixels: fp32, widened at the wave sum
 #pragma unroll
   for (int i = 0; i < 9; ++i) { hsA[i] = bc(0.f); hsB[i] = bc(0.f); }
 #pragma unroll
@@ -470,46 +468,6 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       }
     };
 
-    // ================= smoothness of row r (edges to the right and up), finishing row r-1 ======
-    if (smooth && !(wc.debug & 16)) {
-      const bool row_ok = r >= 0 && r < H;
-      const float n0 = dv_;
-      // right edge (r,x)-(r,x+1): exists for in-image x with x+1 < W
-      const float nR = dpp_shl1(n0);
-      const float eR = (fabsf(w0.yrg.x - dpp_shl1(w0.yrg.x)) + fabsf(w0.yrg.y - dpp_shl1(w0.yrg.y))) +
-                       fabsf(w0.yb - dpp_shl1(w0.yb));
-      const bool hx = row_ok && in_x && gx + 1 < W;
-      const float wxr = hx ? __expf(-(eR * (1.0f / 3.0f))) : 0.f;
-      const float dfx = n0 - nR;
-      const float sx = sgnf(dfx) * wxr * sm_nx;
-      // up edge (r-1,x)-(r,x): exists when both rows are image rows
-      const bool vy = row_ok && r >= 1 && in_x;
-      const float eU = (fabsf(w1.yrg.x - w0.yrg.x) + fabsf(w1.yrg.y - w0.yrg.y)) + fabsf(w1.yb - w0.yb);
-      const float wyu_ = vy ? __expf(-(eU * (1.0f / 3.0f))) : 0.f;
-      const float dfy = sm_n1 - n0;
-      const float sy = sgnf(dfy) * wyu_ * sm_ny;
-      const int qs = r - 1;  // row finished now: its down edge is this up edge
-      if (qs >= y_lo && qs < y_hi && out_x) {
-        const float g = sm_g1 + sy;
-        stf(p.smooth_gn, so_c, g);
-        acc_sd += g * sm_d1;
-      }
-      // every vertical edge is summed once: by the task that owns its physically upper row
-      if ((flip ? r : qs) >= y_lo && (flip ? r : qs) < y_hi && out_x) acc_sy += fabsf(dfy) * wyu_;
-      if (r >= y_lo && r < y_hi && out_x) { acc_sx += fabsf(dfx) * wxr; acc_d += dv_; }
-      if (DBG) {
-        // sign of d[y,x] - d[y,x+1] at (row r, x); sign of d[y] - d[y+1] at the edge's physically upper row, written
-        // by the task that owns it (the one that sums the edge)
-        if (wc.dbg_on) dec_store(wc.dbg, wc.dbg_n, MAL_DEC_SMOOTH_X, wc.dbg_off, (unsigned)(int)(sgnf(dfx) + 1.0f));
-        if ((flip ? r : qs) >= y_lo && (flip ? r : qs) < y_hi && out_x && vy)
-          dec_store(wc.dbg, wc.dbg_n, MAL_DEC_SMOOTH_Y, flip ? wc.dbg_off : so_c,
-                    (unsigned)(int)((flip ? -sgnf(dfy) : sgnf(dfy)) + 1.0f));
-      }
-      sm_g1 = (sx - dpp_shr1(sx)) - sy;
-      sm_n1 = n0;
-      sm_d1 = dv_;
-    }
-
     // ================= epilogue terms of output row (EPI): row q = r-2 with GRAD, c without ===
     auto epilogue = [&]() {
       const int q = GRAD ? r - 2 : r - 1;
@@ -548,7 +506,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       }
     };
     if (EPI && GRAD) epilogue();
-    tick(2);  // smoothness, epilogue terms
+    tick(2);  // epilogue terms
     finish_warp();
     tick(3);  // gather wait, blend, ring write
 
@@ -784,11 +742,6 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     double* o = p.block_sums + (size_t)task * 8;
     o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
   }
-  if (GRAD) {  // smoothness partials (zeros when the term is not folded in)
-    const double q0 = wave_sum_d((double)acc_sx), q1 = wave_sum_d((double)acc_sy), q2 = wave_sum_d((double)acc_sd);
-    const double q3 = wave_sum_d((double)acc_d);
-    if (lane == 0) { double* o = p.block_sums + (size_t)task * 8; o[4] = q0; o[5] = q1; o[6] = q2; o[7] = q3; }
-  }
   if (POSE) {  // block_gP[task][f][12]
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -810,9 +763,10 @@ struct IdentParams {
   int B, H, W, strips, segs, rows, ntasks, per_xcd;
   int pose_blocks; StepPoses sp;              // the last pose_blocks workgroups: poses + camera block of sample b
   TieNoise tn;                                // ident += 1e-5 * N(0,1) (Philox), see mal_march.h
+  SmoothParams sm;                            // edge-aware smoothness of up to two disparity maps in the same sweep
 };
 
-__global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
+__global__ __launch_bounds__(64, 3) void pack_identity_kernel(IdentParams p) {
   constexpr int HALO = 1, CW = 62;
   const int id = blockIdx.x;
   if (id >= p.per_xcd * 8) {  // whole-step list: poses of both frames and the camera block of sample b
@@ -845,9 +799,28 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
   for (int i = 0; i < 2; ++i) { hyA[i] = bc(0.f); hyB[i] = bc(0.f); hzA[i] = 0.f; hzB[i] = 0.f; }
   f2 x1[3] = {bc(0.f), bc(0.f), bc(0.f)}, y1rg = bc(0.f);
   float y1b = 0.f;
-  float tn4[4] = {0.f, 0.f, 0.f, 0.f};  // tie-break noise of the current group of four rows of this column
-  const unsigned long long tn_step = p.tn.on ? (p.tn.counter ? *p.tn.counter : p.tn.step) : 0ull;
   auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
+  float tn4[4] = {0.f, 0.f, 0.f, 0.f};  // tie-break noise of the current group of four rows of this column
+  // ---- edge-aware smoothness of the step's two disparity maps (layers.py:210-223 on disp / (mean + 1e-7),
+  // loss_utils.py:119-121), riding on the target rows this sweep holds anyway (this kernel is bandwidth-bound with
+  // arithmetic to spare; the marching passes are not).  The per-sample 1/(mean+1e-7) is a positive constant of the
+  // sample: it is factored out of |d n| and applied to the per-sample sums afterwards (step_final_kernel); per task:
+  // sum |dx d| w, sum |dy d| w, sum gn*d, sum d.  Every edge is summed once: by the task that owns its upper / left pixel.
+  const int nsm = p.sm.n;
+  const float sm_nx = 1.0f / ((float)p.B * (float)H * (float)(W - 1)), sm_ny = 1.0f / ((float)p.B * (float)(H - 1) * (float)W);
+  float sm_prev[2] = {0.f, 0.f}, sm_g1[2] = {0.f, 0.f};
+  float acc_sx[2] = {0.f, 0.f}, acc_sy[2] = {0.f, 0.f}, acc_sd[2] = {0.f, 0.f}, acc_d[2] = {0.f, 0.f};
+  const unsigned sm_lane = (unsigned)(b * HW + gxr) * 4u;
+  // no branches around loads (see march_kernel's request()): an absent map is read from the target image instead (a
+  // valid address) and the value dropped, so the number of loads per iteration is fixed and the waits can be counted
+  auto sm_request = [&](int rr, float (&dst)[2]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      // (the value of an absent map is never used: no select here, which would wait for the load at once)
+      dst[m] = ldf(m < nsm ? p.sm.disp[m] : p.target, (unsigned)(row_of(rr) * W) * 4u + sm_lane);
+    }
+  };
+  const unsigned long long tn_step = p.tn.on ? (p.tn.counter ? *p.tn.counter : p.tn.step) : 0ull;
   // the nine planes of a pixel, requested one iteration ahead (see march_kernel)
   struct Px { float t[3], a[3], c[3]; };
   auto request = [&](int rr, Px& q) {
@@ -857,12 +830,20 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
       q.t[ch] = ldf(tb + (size_t)ch * HW, bo); q.a[ch] = ldf(s0 + (size_t)ch * HW, bo); q.c[ch] = ldf(s1 + (size_t)ch * HW, bo);
     }
   };
+  // The operands of a row are requested TWO iterations ahead into two alternating buffers (the loop body is unrolled
+  // by two so that no register copy ties a row to the loads issued one iteration ago): with one row ahead every
+  // iteration waited for its predecessor's loads AND stores -- the stores sit in divergent blocks, so the compiler
+  // cannot count them and falls back to vmcnt(0) -- and the sweep ran latency-bound.
   const int r_first = max(y_lo - 1, -1);
-  Px nxt;
-  request(r_first, nxt);
-  for (int r = r_first; r <= y_hi; ++r) {
-    const Px cur = nxt;
-    request(r + 1, nxt);
+  Px bufA, bufB;
+  float smA[2], smB[2];
+  request(r_first, bufA);
+  sm_request(r_first, smA);
+  request(r_first + 1, bufB);
+  sm_request(r_first + 1, smB);
+  auto body = [&](const int r, Px& buf, float (&smb)[2]) {
+    const Px cur = buf;
+    const float sm_cur[2] = {smb[0], smb[1]};
     if (r >= y_lo && r < y_hi && out_x && p.packed[0]) {  // an image row owned by this task: emit its texels
       const size_t bo = (size_t)(r * W + gxr);
       st_texel(p.packed[0] + (size_t)b * HW * kTexel, bo, make_texel(cur.a[0], cur.a[1], cur.a[2]));
@@ -873,6 +854,39 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
     const f2 x0[3] = {(f2){cur.a[0], cur.a[1]}, (f2){cur.c[0], cur.c[1]}, (f2){cur.a[2], cur.c[2]}};
     const f2 y0rg = (f2){cur.t[0], cur.t[1]};
     const float y0b = cur.t[2];
+    if (nsm > 0) {  // wave-uniform
+      const bool row_ok = r >= 0 && r < H;
+      // edge weights from the target: right edge (r,x)-(r,x+1) and up edge (r-1,x)-(r,x)
+      const float eR = (fabsf(y0rg.x - dpp_shl1(y0rg.x)) + fabsf(y0rg.y - dpp_shl1(y0rg.y))) + fabsf(y0b - dpp_shl1(y0b));
+      const bool hx = row_ok && in_x && gx + 1 < W;
+      const float wxr = hx ? __expf(-(eR * (1.0f / 3.0f))) : 0.f;
+      const bool vy = row_ok && r >= 1 && in_x;
+      const float eU = (fabsf(y1rg.x - y0rg.x) + fabsf(y1rg.y - y0rg.y)) + fabsf(y1b - y0b);
+      const float wyu = vy ? __expf(-(eU * (1.0f / 3.0f))) : 0.f;
+      const int qs = r - 1;  // row finished now: its down edge is this up edge
+      const bool own_q = qs >= y_lo && qs < y_hi && out_x, own_r = r >= y_lo && r < y_hi && out_x;
+      const unsigned oq = (unsigned)(max(qs, 0) * W) * 4u + sm_lane, orow = (unsigned)(row_of(r) * W) * 4u + sm_lane;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (m >= nsm) break;
+        const float n0 = sm_cur[m];
+        const float dfx = n0 - dpp_shl1(n0), dfy = sm_prev[m] - n0;
+        const float sx = sgnf(dfx) * wxr * sm_nx, sy = sgnf(dfy) * wyu * sm_ny;
+        if (own_q) {
+          const float g = sm_g1[m] + sy;
+          stf(p.sm.gn[m], oq, g);
+          acc_sd[m] += g * sm_prev[m];
+          acc_sy[m] += fabsf(dfy) * wyu;
+        }
+        if (own_r) { acc_sx[m] += fabsf(dfx) * wxr; acc_d[m] += n0; }
+        if (p.sm.dec[m]) {  // parity instrumentation: the signs taken (MAL_DEC_SMOOTH_X / _Y planes)
+          if (own_r) dec_store(p.sm.dec[m], (unsigned)(p.B * HW), MAL_DEC_SMOOTH_X, orow, (unsigned)(int)(sgnf(dfx) + 1.0f));
+          if (own_q && vy) dec_store(p.sm.dec[m], (unsigned)(p.B * HW), MAL_DEC_SMOOTH_Y, oq, (unsigned)(int)(sgnf(dfy) + 1.0f));
+        }
+        sm_g1[m] = (sx - dpp_shr1(sx)) - sy;
+        sm_prev[m] = n0;
+      }
+    }
     f2 h[9], hy[2];
     float hz[2];
     hy[0] = hsum3(y0rg); hy[1] = hsum3(y0rg * y0rg);
@@ -920,6 +934,26 @@ __global__ __launch_bounds__(64, 4) void pack_identity_kernel(IdentParams p) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) x1[k] = x0[k];
     y1rg = y0rg; y1b = y0b;
+    // refill this buffer for row r+2 LAST, behind a scheduling barrier: its registers are free by now, so the loads
+    // land in the registers the loop carries (requested earlier, they would be copied at the back edge -- and a copy of a
+    // register that is being loaded waits for the load)
+    __builtin_amdgcn_sched_barrier(0);
+    request(r + 2, buf);
+    sm_request(r + 2, smb);
+  };
+  // rows r_first .. y_hi in pairs; an odd count runs one row past y_hi (every store is guarded by the row range, loads
+  // are clamped to the image)
+  for (int r = r_first; r <= y_hi; r += 2) {
+    body(r, bufA, smA);
+    body(r + 1, bufB, smB);
+  }
+  if (nsm > 0) {  // per-task partials [task][map][4], fixed-order second stage in step_final_kernel
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const double q0 = wave_sum_d((double)acc_sx[m]), q1 = wave_sum_d((double)acc_sy[m]);
+      const double q2 = wave_sum_d((double)acc_sd[m]), q3 = wave_sum_d((double)acc_d[m]);
+      if (lane == 0) { double* o = p.sm.partials + (size_t)task * 8 + m * 4; o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3; }
+    }
   }
 }
 
@@ -927,6 +961,8 @@ int g_pass_impl = 1;   // 1 = marching (this file, fastest); 0 = LDS-tiled v1 (m
 extern int g_costvol_impl;  // mal_costvol.hip
 int g_march_flip = 1;  // odd segments bottom-up (mal_set_option("march_flip", 0|1))
 int g_march_rows = 0;  // output rows per wave task; 0 = pick so that one round of tasks fills the chip
+int g_pack_rows = 9;   // rows per task of the identity / packing sweep: 22 segments x 11 strips x 12 samples = 2904 tasks <= 3072 (three waves per SIMD); measured 9: 31.8 us, 12: 33.8 us
+int g_march_rows_fwd = 0;  // the same for the forward-only passes (<= 168 VGPRs: three waves per SIMD); 0 = automatic
 int g_debug = 0;
 extern int g_photo_impl;  // mal_photo_march.hip
 
@@ -944,7 +980,7 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
              epi = flags & MAL_F_EPILOGUE;
   const int cw = grad ? 60 : 62;
   p.strips = (p.W + cw - 1) / cw;
-  int rows = g_march_rows;
+  int rows = grad ? g_march_rows : (g_march_rows_fwd > 0 ? g_march_rows_fwd : g_march_rows);
   if (rows <= 0) {
     // Every task is one wavefront that lives for (rows + 2*halo) iterations and the kernel runs at two
     // waves per SIMD (<= 256 VGPRs): the shortest makespan is the smallest `rows` whose task count still
@@ -969,6 +1005,7 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   p.per_xcd = (p.ntasks + 7) / 8;
   dim3 grid(p.per_xcd * 8), block(64);
   if (!p.cam) return MAL_EINVAL;
+  if ((long long)p.H * p.W >= (1ll << 24)) return MAL_ESHAPE;  // tap offsets use 24-bit multiplies
   if (!p.cam_ready) {
     hipLaunchKernelGGL(cam_setup_kernel, dim3(p.B), dim3(64), 0, st, p.K, p.T[0], p.T[1], p.invK, p.cam);
     p.cam_ready = 1;
@@ -999,18 +1036,20 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
 
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
-                         const StepPoses* poses, const TieNoise* noise) {
+                         const StepPoses* poses, const TieNoise* noise, const SmoothParams* smooth, int* tasks_per_sample) {
   IdentParams p = {};
   if (noise) p.tn = *noise;
+  if (smooth) p.sm = *smooth;
   p.pose_blocks = poses ? B : 0;
   if (poses) p.sp = *poses;
   p.target = target; p.src[0] = src0; p.src[1] = src1; p.packed[0] = packed0; p.packed[1] = packed1; p.packed_target = packed_target; p.ident = ident;
   p.B = B; p.H = H; p.W = W;
   p.strips = (W + 61) / 62;
-  p.rows = 12;  // 4 waves per SIMD fit (launch bounds): 16 segments x 11 strips x 12 samples = 2112 <= 4096
+  p.rows = g_pack_rows;  // three waves per SIMD fit (launch bounds, <= 168 VGPRs with the smoothness terms)
   p.segs = (H + p.rows - 1) / p.rows;
   p.ntasks = B * p.strips * p.segs;
   p.per_xcd = (p.ntasks + 7) / 8;
+  if (tasks_per_sample) *tasks_per_sample = p.strips * p.segs;
   hipLaunchKernelGGL(pack_identity_kernel, dim3(p.per_xcd * 8 + p.pose_blocks), dim3(64), 0, st, p);
   return launch_status();
 }
@@ -1027,6 +1066,8 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("photo_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_photo_impl = value; return MAL_OK; }
   if (eq("costvol_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_costvol_impl = value; return MAL_OK; }
   if (eq("march_flip")) { g_march_flip = value != 0; return MAL_OK; }
+  if (eq("pack_rows")) { if (value < 4 || value > 4096) return MAL_EINVAL; g_pack_rows = value; return MAL_OK; }
+  if (eq("march_rows_fwd")) { if (value < 0 || value > 4096) return MAL_EINVAL; g_march_rows_fwd = value; return MAL_OK; }
   if (eq("march_rows")) { if (value < 0 || value > 4096) return MAL_EINVAL; g_march_rows = value; return MAL_OK; }
   return MAL_EINVAL;
 }

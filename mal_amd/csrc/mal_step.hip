@@ -29,6 +29,7 @@ struct StepWs {
   float* ident; float* mono_reproj; float* ens_reproj;
   float* G_r_t; float* G_r_s; float* G_c; float* gn_t; float* gn_s;
   double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
+  double* bs_p;       // per-task smoothness partials of the first launch: [task][map][4]
   double* ps;         // per-sample sums of the teacher's, then the student's partials: [2][B][8]
   unsigned* ticket;   // completion counter of step_final_kernel
   double* sm_stats;   // [4B]: mean_t[b], mean_s[b], corr_t[b], corr_s[b] of the mean-normalised smoothness
@@ -50,6 +51,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   for (auto m : maps) *m = (float*)take(map);
   w.bs_t = (double*)take(nb * 8 * 8); w.bs_s = (double*)take(nb * 8 * 8); w.bs_e = (double*)take(nb * 8 * 8);
   w.bgP = (float*)take(nb * 24 * 4);
+  w.bs_p = (double*)take(nb * 8 * 8);
   w.ps = (double*)take((size_t)2 * B * 8 * 8);
   w.ticket = (unsigned*)take(4);
   w.sm_stats = (double*)take((size_t)4 * B * 8);
@@ -61,12 +63,14 @@ static StepWs carve_step(void* base, int B, int H, int W) {
 
 // ---------------------------------------------------------------- small kernels
 // Everything after the three passes, fixed summation order, no floating-point atomics.  3B blocks:
-//   blocks [0, 2B):  ps[pass][b][j] = sum over the sample's marching tasks (contiguous) of block_sums[task][j]
+//   blocks [0, 2B):  ps[pass][b][j] = sum over the sample's tasks (contiguous) of the per-task partials: j < 4 from the
+//                    marching pass (block_sums[task][j]), j >= 4 the smoothness partials of the first launch
 //   blocks [2B, 3B): g_T[f][b] = K_b^T [gP_fb ; 0]  from the teacher's per-task pose partials
 // and the block that finishes last (a ticket counter, reset by the step's first launch) turns the per-sample sums into the smoothness of the mean-normalised disparities (layers.py:210-223,
 // loss_utils.py:119-121), the loss scalars (loss_utils.py:112-127,198-279; trainer.py:625-629) and the
 // coefficients of the backward.
 __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, const double* bs_s, const float* bgP,
+                                                         const double* bs_p, int per_sample_p,
                                                          const float* K, int per_sample, int B, int H, int W,
                                                          float w_main, float w_distil, double* ps, float* gT0, float* gT1,
                                                          double* stats, float* losses, float* coefs, float* loss_total,
@@ -78,11 +82,13 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
   const int tid = threadIdx.x, HW = H * W;
   if ((int)blockIdx.x < 2 * B) {
     const int pass = blockIdx.x / B, b = blockIdx.x - pass * B;
-    const double* bs = (pass ? bs_s : bs_t) + (size_t)b * per_sample * 8;
     const int j = tid & 7, sub = tid >> 3;  // 32 strided partial sums per quantity
+    const double* bs = j < 4 ? (pass ? bs_s : bs_t) + (size_t)b * per_sample * 8 + j
+                             : bs_p + (size_t)b * per_sample_p * 8 + pass * 4 + (j - 4);
+    const int n_t = j < 4 ? per_sample : per_sample_p;
     double acc = 0.0;
 #pragma unroll 8
-    for (int t = sub; t < per_sample; t += 32) acc += bs[(size_t)t * 8 + j];  // independent loads: issue them together
+    for (int t = sub; t < n_t; t += 32) acc += bs[(size_t)t * 8];  // independent loads: issue them together
     s_part[tid] = acc;
     __syncthreads();
     if (tid < 8) {
@@ -269,6 +275,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   float* ens_reproj = no_ens ? nullptr : (a->ens_reproj ? a->ens_reproj : w.ens_reproj);
   float* multi_reproj = a->multi_reproj;  // only written when the caller wants the map
 
+  int per_sample_p = 1;
   // 1. identity term + texel packing of the three images (one texel load per pixel in the passes); B extra
   //    workgroups of the same launch: poses (frame -1 is inverted, networks/repdepth.py:159-160) + camera block
   {
@@ -285,8 +292,12 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
       tn.on = 1; tn.seed = a->noise_seed; tn.step = a->noise_step; tn.counter = (const unsigned long long*)a->noise_counter;
       tn.noise_out = a->noise_out;
     }
+    // both smoothness terms (teacher's and student's disparity) ride on this sweep: it holds the target rows anyway
+    SmoothParams sm = {};
+    sm.n = 2; sm.disp[0] = a->disp_teacher; sm.disp[1] = a->disp_student; sm.gn[0] = w.gn_t; sm.gn[1] = w.gn_s;
+    sm.partials = w.bs_p; sm.dec[0] = a->dec_teacher; sm.dec[1] = a->dec_student;
     rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
-                              &sp, &tn);
+                              &sp, &tn, &sm, &per_sample_p);
     if (rc) return rc;
   }
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
@@ -299,7 +310,6 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
     p.ident = w.ident; p.noise = a->noise; p.min_reproj = mono_reproj; p.g_reproj = w.G_r_t;
     p.block_sums = w.bs_t; p.block_gP = w.bgP;
-    p.smooth_gn = w.gn_t;
     p.cam = w.cam; p.cam_ready = cam_ready;
     p.dbg = a->dec_teacher;
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
@@ -330,14 +340,14 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.g_cons = w.G_c; p.g_distil = nullptr;  // one merged map: weights as coefs[2], coefs[3] of step_final_kernel
     p.merge_cons = (float)((double)a->w_main / ((double)B * H * W)); p.merge_distil = (float)((double)a->w_distil / ((double)B * H * W));
     p.block_sums = w.bs_s; p.block_gP = w.bgP;
-    p.smooth_gn = w.gn_s;
     p.cam = w.cam; p.cam_ready = cam_ready;
     p.dbg = a->dec_student;
     rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
     if (rc) return rc;
   }
   // 8. per-sample sums of both gradient passes, pose gradients, scalars
-  hipLaunchKernelGGL(step_final_kernel, dim3(3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, w.bgP, a->K, per_sample, B, H, W,
+  hipLaunchKernelGGL(step_final_kernel, dim3(3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, w.bgP, w.bs_p, per_sample_p, a->K,
+                     per_sample, B, H, W,
                      a->w_main, a->w_distil, w.ps, w.gT[0], w.gT[1], w.sm_stats, a->losses, w.coefs, a->loss_total,
                      w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr);
   return launch_status();
