@@ -235,6 +235,15 @@ int mal_pose_bwd(const float* const* axisangle, const float* const* translation,
 enum {
   MAL_STEP_NO_ENS = 1,   /* --no_ens: 2-way distillation argmin, no ensemble pass */
   MAL_STEP_AUG_MASK = 2, /* `augmentation_keep` holds augmentation_mask itself; 1 - mask is formed on the device */
+  MAL_STEP_TEMPORAL = 8, /* --temporal (loss_utils.py:84-88): r(syn_f, target) of the two synthesised images joins the
+                            teacher's per-pixel min.  Three calls around the producer (dyn_utils.image_synthesis):
+                              mal_loss_step_warp  first sweep + the teacher's warped images -> warp_m1 / warp_p1
+                              [syn_f = producer(warp_f)]
+                              mal_loss_step_fwd   syn_m1 / syn_p1 in; losses out; g_syn_* out = d sum(rp*w) / d syn_f
+                                                  (UNNORMALISED: the 1/(sum w + 1e-7) and loss weights are applied in _bwd)
+                              [g_warp_f = producer^T(g_syn_f), linear]
+                              mal_loss_step_bwd   g_warp_* in (same scale); runs the teacher's gradient sweep with the
+                                                  four-way decisions of _fwd and adds what arrives through syn */
   MAL_STEP_NOISE_PHILOX = 4 /* the automask tie-break noise (loss_utils.py:105-106: + 1e-5 * randn) is drawn inside the
                                step's first kernel: N(0,1) by Box-Muller from Philox4x32-10 keyed by noise_seed, counter =
                                (pixel, step); `noise` must be NULL.  No host RNG, no device RNG launch on the step. */
@@ -269,7 +278,13 @@ typedef struct mal_step_args {
    * last kernel advances by one, so a replayed HIP graph draws fresh noise every replay), else noise_step;
    * noise_out: (B,1,H,W) nullable, receives the N(0,1) values that were used (tests). */
   uint64_t noise_seed, noise_step; uint64_t* noise_counter; float* noise_out;
+  /* MAL_STEP_TEMPORAL, all (B,3,H,W) planar */
+  float *warp_m1, *warp_p1;               /* out of mal_loss_step_warp: outputs[("color", f, 0)] of the teacher */
+  const float *syn_m1, *syn_p1;           /* in of _fwd: outputs[("syn", f, 0)] */
+  float *g_syn_m1, *g_syn_p1;             /* out of _fwd */
+  const float *g_warp_m1, *g_warp_p1;     /* in of _bwd */
 } mal_step_args;
+int mal_loss_step_warp(const mal_step_args* args);
 /* the same noise map on its own (tests; bit-identical to what the step draws for that seed / step) */
 int mal_tiebreak_noise(uint64_t seed, uint64_t step, int B, int H, int W, float* out, void* stream);
 enum {

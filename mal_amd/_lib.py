@@ -75,6 +75,7 @@ SIGNATURES = {
     "mal_step_workspace_bytes": (sz, [i32, i32, i32]),
     "mal_loss_step_fwd": (i32, [vp]),
     "mal_loss_step_bwd": (i32, [vp]),
+    "mal_loss_step_warp": (i32, [vp]),
     "mal_tiebreak_noise": (i32, [C.c_uint64, C.c_uint64, i32, i32, i32, c_fp, vp]),
     "mal_set_option": (i32, [C.c_char_p, i32]),
     "mal_event_create": (vp, []),
@@ -101,10 +102,11 @@ class StepArgs(C.Structure):
                                    "g_disp_teacher", "g_disp_student", "g_axisangle_m1", "g_translation_m1",
                                    "g_axisangle_p1", "g_translation_p1", "ws")] +
                 [("ws_bytes", sz), ("stream", vp), ("dec_teacher", vp), ("dec_student", vp),
-                 ("noise_seed", C.c_uint64), ("noise_step", C.c_uint64), ("noise_counter", vp), ("noise_out", vp)])
+                 ("noise_seed", C.c_uint64), ("noise_step", C.c_uint64), ("noise_counter", vp), ("noise_out", vp)] +
+                [(n, vp) for n in ("warp_m1", "warp_p1", "syn_m1", "syn_p1", "g_syn_m1", "g_syn_p1", "g_warp_m1", "g_warp_p1")])
 
 
-STEP_NO_ENS, STEP_AUG_MASK, STEP_NOISE_PHILOX = 1, 2, 4
+STEP_NO_ENS, STEP_AUG_MASK, STEP_NOISE_PHILOX, STEP_TEMPORAL = 1, 2, 4, 8
 # decision planes of mal_step_args.dec_teacher / dec_student (MAL_DEC_*)
 DEC_WIN, DEC_DISTIL, DEC_SMOOTH_X, DEC_SMOOTH_Y, DEC_TAP0, DEC_TAP1, DEC_L1, DEC_PLANES = 0, 1, 2, 3, 4, 5, 6, 7
 

@@ -28,6 +28,15 @@ struct MarchParams {
   int packed;
   int flip_odd;  // odd row segments walk bottom-up: both tasks that share a segment boundary reach it together (L2 serves the halo)
   int debug;  // experiments only (mal_set_option("debug")): bit 0 = taps read the pixel's own address
+  // ---- temporal hint (loss_utils.py:84-88: r(syn_f, target) joins the per-pixel min), whole-step list
+  // forward-only pass that precedes the producer: the warped images as planar (B,3,H,W) (what image_synthesis reads,
+  // dyn_utils.py:127-128) and the winner among the two warped candidates
+  float* color_out[2]; unsigned char* argmin_out;
+  // TEMPORAL gradient pass (runs after the producer's backward): the decision of the four-way min and the automask are
+  // TAKEN from the materialised-candidate kernels (forced_arg: winner 0..3, forced_w: automask weight), and the
+  // gradient that reaches the warped images through syn (dyn_utils.py:145-146,163-164), g_color[f] planar (B,3,H,W),
+  // joins d loss / d warped colour before the chain rule through the warp
+  const float* forced_w; const unsigned char* forced_arg; const float* g_color[2];
   // Parity instrumentation (tests only; DBG instantiations of the gradient passes): the per-pixel DECISIONS the pass
   // took, as kDecPlanes uint32 planes of B*H*W each (include/mal_hip.h, MAL_DEC_*).  nullptr = the production kernels.
   unsigned* dbg;
@@ -59,6 +68,8 @@ MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, 
 // fills the task decomposition for `flags` (MAL_F_*), launches the matching instantiation on `st`
 // (bracketed by the one-shot profile events if armed).  Partials go to p.block_sums / p.block_gP.
 int march_launch(MarchParams& p, int flags, hipStream_t st);
+// tasks per sample of pack_identity_launch's decomposition (the per-task smoothness partials are laid out by it)
+int pack_identity_tasks_per_sample(int H, int W);
 // min_f r(src_f, target) of the RAW sources -> ident (B,1,H,W) (the identity term of
 // manydepth/loss_utils.py:92-101), and in the same sweep the two planar sources repacked as (B,H,W,kTexel) texels
 // (packed0/1 nullable together), optionally the target too.  With `poses` (the whole-step launch list) B extra

@@ -233,7 +233,7 @@ MAL_DEV void warp_finish(PendingWarp& pw, f2 (&x)[3], DerivRow& d) {
   }
 }
 
-template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG = false>
+template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG = false, bool TEMPORAL = false>
 __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   constexpr int HALO = GRAD ? 2 : 1;
   constexpr int CW = 64 - 2 * HALO;
@@ -335,17 +335,23 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   // projection allows; the work that does not need them sits between their issue and the blend.
   struct Ahead {
     float disp, disp2, y[3];                      // the row to warp
-    float ident, noise, ext, mono, cost;          // statistics row c
+    float ident, noise, ext, mono, cost;          // statistics row c (TEMPORAL: ident = forced weight, noise = forced winner)
     float e_mono, e_mr, e_er;                     // epilogue row
+    float gc[TEMPORAL ? 6 : 1];                   // TEMPORAL: d loss / d warped colour that arrives through syn, gradient row
   };
   // the map pointers of the parameter block, read together (one scalar-load wait per iteration)
-  struct Maps { const float *ident, *noise, *ext_mask, *lowest_cost, *mono_disp, *mono_depth, *mono_reproj, *ens_reproj, *target; int packed; };
+  struct Maps {
+    const float *ident, *noise, *ext_mask, *lowest_cost, *mono_disp, *mono_depth, *mono_reproj, *ens_reproj, *target; int packed;
+    const float* forced_w; const unsigned char* forced_arg; const float* gcol[2];  // TEMPORAL
+  };
   auto maps_of = [&](CParams& pp) {
     Maps m;
     m.ident = AUTOMASK ? pp.ident : nullptr; m.noise = AUTOMASK ? pp.noise : nullptr;
     m.ext_mask = pp.ext_mask; m.lowest_cost = pp.lowest_cost; m.mono_disp = pp.mono_disp;
     m.mono_depth = EPI ? pp.mono_depth : nullptr; m.mono_reproj = EPI ? pp.mono_reproj : nullptr;
     m.ens_reproj = EPI ? pp.ens_reproj : nullptr; m.target = pp.target; m.packed = pp.packed;
+    m.forced_w = TEMPORAL ? pp.forced_w : nullptr; m.forced_arg = TEMPORAL ? pp.forced_arg : nullptr;
+    m.gcol[0] = TEMPORAL ? pp.g_color[0] : nullptr; m.gcol[1] = TEMPORAL ? pp.g_color[1] : nullptr;
     return m;
   };
   auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
@@ -369,7 +375,16 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       return m ? v : absent;
     };
     a.ident = 0.f; a.noise = 0.f;
-    if (AUTOMASK) { a.ident = ldf(pp.ident, oc); a.noise = opt(pp.noise, oc, 0.f); }
+    if (AUTOMASK && !TEMPORAL) { a.ident = ldf(pp.ident, oc); a.noise = opt(pp.noise, oc, 0.f); }
+    if (TEMPORAL) {
+      a.ident = ldf(pp.forced_w, oc);
+      a.noise = (float)*(pp.forced_arg + (oc >> 2));
+      const unsigned og = moff(min(max(rr - 2, 0), H - 1)) - (unsigned)b * (unsigned)HW * 4u;  // pixel offset inside the sample
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) a.gc[f * 3 + ch] = ldf(pp.gcol[f] + ((size_t)b * 3 + ch) * HW, og);
+    }
     a.ext = opt(pp.ext_mask, oc, 1.f);
     a.mono = opt(pp.lowest_cost ? pp.mono_disp : nullptr, oc, 0.f);
     a.cost = opt(pp.lowest_cost, oc, 1.f);
@@ -509,6 +524,16 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     tick(2);  // epilogue terms
     finish_warp();
     tick(3);  // gather wait, blend, ring write
+    if (!GRAD && !AUTOMASK && !EPI) {  // the pass in front of the temporal-hint producer: the warped images, planar
+      float* const c0 = p.color_out[0];
+      float* const c1 = p.color_out[1];
+      if (c0 && r >= y_lo && r < y_hi && out_x) {
+        const unsigned og = moff(r) - (unsigned)b * (unsigned)HW * 4u;
+        const size_t pl = (size_t)b * 3 * HW;
+        stf(c0 + pl, og, w0.x[0].x); stf(c0 + pl + HW, og, w0.x[0].y); stf(c0 + pl + 2 * (size_t)HW, og, w0.x[2].x);
+        stf(c1 + pl, og, w0.x[1].x); stf(c1 + pl + HW, og, w0.x[1].y); stf(c1 + pl + 2 * (size_t)HW, og, w0.x[2].y);
+      }
+    }
 
     // ================= stage H: horizontal 3-sums of row r ====================================
     f2 h[9], hy[2];
@@ -552,14 +577,23 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
       pi0.win = (rr.y < rr.x) ? 1 : 0;
       pi0.rp = pi0.win ? rr.y : rr.x;
+      if (!GRAD && !AUTOMASK && !EPI) {
+        unsigned char* const am = p.argmin_out;
+        if (am && out_x && c >= y_lo && c < y_hi) am[so_c >> 2] = (unsigned char)pi0.win;
+      }
       float w = 1.0f;
       const unsigned go = so_c;
-      if (AUTOMASK) {
+      if (AUTOMASK && !TEMPORAL) {
         float idn = ld_ident;
         if (has_noise) idn += ld_noise * 0.00001f;
         w = (pi0.rp <= idn) ? 1.0f : 0.0f;
       }
-      if (DBG && out_x && c >= y_lo && c < y_hi)
+      if (TEMPORAL) {  // decided over all four candidates by the materialised-candidate kernels: a warped candidate
+        const int arg4 = (int)ld_noise;  // carries weight only where one of them won (then it is this pass's own winner)
+        if (DBG && out_x && c >= y_lo && c < y_hi)
+          dec_store(wc.dbg, wc.dbg_n, MAL_DEC_WIN, go, (unsigned)(arg4 < 2 ? pi0.win : arg4) | (ld_ident != 0.f ? 4u : 0u));
+        w = arg4 < 2 ? ld_ident : 0.0f;
+      } else if (DBG && out_x && c >= y_lo && c < y_hi)
         dec_store(wc.dbg, wc.dbg_n, MAL_DEC_WIN, go, (unsigned)pi0.win | (w != 0.f ? 4u : 0u));
       if (has_ext) {
         float em = ld_ext;
@@ -656,6 +690,11 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
           const f2 xq = wq.x[k], yq = k < 2 ? wq.yrg : bc(wq.yb);
           const f2 sg = sgk[k];
           g[k] = fma2(lwk[k], sg, fma2(SC, yq, fma2(SB, xq, SA)));
+        }
+        if (TEMPORAL) {  // what reaches the warped colours through the synthesised images
+          g[0] += (f2){cur.gc[0], cur.gc[1]};
+          g[1] += (f2){cur.gc[3], cur.gc[4]};
+          g[2] += (f2){cur.gc[2], cur.gc[5]};
         }
         float gdisp;
         if (POSE) {
@@ -1014,7 +1053,13 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   g_prof_start = g_prof_stop = nullptr;
   if (ev0) (void)hipEventRecord(ev0, st);
 #define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((march_kernel<G, A, P, E>), grid, block, 0, st, p)
-  if (p.dbg) {  // instrumented instantiations exist for the two gradient passes of the whole-step list
+  if (p.forced_w) {  // TEMPORAL teacher pass
+    if (!(grad && pose && automask && !epi) || !p.forced_arg || !p.g_color[0] || !p.g_color[1]) return MAL_EINVAL;
+    if (p.dbg) {
+      if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
+      hipLaunchKernelGGL((march_kernel<true, true, true, false, true, true>), grid, block, 0, st, p);
+    } else hipLaunchKernelGGL((march_kernel<true, true, true, false, false, true>), grid, block, 0, st, p);
+  } else if (p.dbg) {  // instrumented instantiations exist for the two gradient passes of the whole-step list
     if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
     if (grad && pose && automask && !epi) hipLaunchKernelGGL((march_kernel<true, true, true, false, true>), grid, block, 0, st, p);
     else if (grad && !pose && !automask && epi) hipLaunchKernelGGL((march_kernel<true, false, false, true, true>), grid, block, 0, st, p);
@@ -1033,6 +1078,8 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   if (ev1) (void)hipEventRecord(ev1, st);
   return launch_status();
 }
+
+int pack_identity_tasks_per_sample(int H, int W) { return ((W + 61) / 62) * ((H + g_pack_rows - 1) / g_pack_rows); }
 
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,

@@ -448,6 +448,24 @@ int photo_march_fwd(const float* target, const float* const* cand, int n_cand, c
   return launch_status();
 }
 
+// one more pair (indices idx0, idx0+1) on top of a running min / argmin that is already in min_reproj / argmin (the
+// temporal hint of the whole-step list: the warped candidates' min comes from the marching pass); this is the last
+// pair: weight (automask) and the per-task partials [task][2] are formed.  *per_sample_out = tasks per sample.
+int photo_march_fwd_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
+                         const float* noise, int B, int H, int W, float* min_reproj, uint8_t* argmin, float* weight_out,
+                         double* block_sums, int* per_sample_out, hipStream_t st) {
+  PhotoMarchParams p = {};
+  p.target = target; p.B = B; p.H = H; p.W = W;
+  p.cand[0] = cand0; p.cand[1] = cand1; p.idx[0] = idx0; p.idx[1] = idx0 + 1;
+  p.prev_min = min_reproj; p.prev_arg = argmin; p.last = 1; p.automask = 1;
+  p.ident = ident; p.noise = noise;
+  p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;
+  decompose(p, 62, 4);
+  *per_sample_out = p.strips * p.segs;
+  hipLaunchKernelGGL(photo_march_fwd_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
+  return launch_status();
+}
+
 int photo_march_bwd(const float* target, const float* const* cand, int n_cand, const uint8_t* argmin, const float* weight,
                     const float* scale, const double* sums, int B, int H, int W, float* const* g_cand, hipStream_t st) {
   for (int pr = 0; pr < (n_cand + 1) / 2; ++pr) {

@@ -21,6 +21,13 @@
 
 namespace mal {
 
+// mal_photo_march.hip: the materialised-candidate kernels (the two synthesised images of the temporal hint)
+int photo_march_fwd_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
+                         const float* noise, int B, int H, int W, float* min_reproj, uint8_t* argmin, float* weight_out,
+                         double* block_sums, int* per_sample_out, hipStream_t st);
+int photo_march_bwd(const float* target, const float* const* cand, int n_cand, const uint8_t* argmin, const float* weight,
+                    const float* scale, const double* sums, int B, int H, int W, float* const* g_cand, hipStream_t st);
+
 constexpr int kLossSlots = 16;
 
 struct StepWs {
@@ -30,6 +37,9 @@ struct StepWs {
   float* G_r_t; float* G_r_s; float* G_c; float* gn_t; float* gn_s;
   double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
   double* bs_p;       // per-task smoothness partials of the first launch: [task][map][4]
+  // temporal hint: winner of the four-way min (0/1 warped, 2/3 syn) and automask weight of the teacher, the
+  // materialised-candidate kernel's per-task partials [task][2], what the step remembers between its calls
+  unsigned char* arg_t; float* w_t; double* bs_ph;
   double* ps;         // per-sample sums of the teacher's, then the student's partials: [2][B][8]
   unsigned* ticket;   // completion counter of step_final_kernel
   double* sm_stats;   // [4B]: mean_t[b], mean_s[b], corr_t[b], corr_s[b] of the mean-normalised smoothness
@@ -52,6 +62,9 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   w.bs_t = (double*)take(nb * 8 * 8); w.bs_s = (double*)take(nb * 8 * 8); w.bs_e = (double*)take(nb * 8 * 8);
   w.bgP = (float*)take(nb * 24 * 4);
   w.bs_p = (double*)take(nb * 8 * 8);
+  w.arg_t = (unsigned char*)take((size_t)B * HW);
+  w.w_t = (float*)take(map);
+  w.bs_ph = (double*)take(nb * 2 * 8);
   w.ps = (double*)take((size_t)2 * B * 8 * 8);
   w.ticket = (unsigned*)take(4);
   w.sm_stats = (double*)take((size_t)4 * B * 8);
@@ -71,6 +84,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
 // coefficients of the backward.
 __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, const double* bs_s, const float* bgP,
                                                          const double* bs_p, int per_sample_p,
+                                                         const double* bs_ph, int per_sample_ph,
                                                          const float* K, int per_sample, int B, int H, int W,
                                                          float w_main, float w_distil, double* ps, float* gT0, float* gT1,
                                                          double* stats, float* losses, float* coefs, float* loss_total,
@@ -83,12 +97,15 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
   if ((int)blockIdx.x < 2 * B) {
     const int pass = blockIdx.x / B, b = blockIdx.x - pass * B;
     const int j = tid & 7, sub = tid >> 3;  // 32 strided partial sums per quantity
-    const double* bs = j < 4 ? (pass ? bs_s : bs_t) + (size_t)b * per_sample * 8 + j
+    // temporal hint: the teacher's sum(rp*w), sum(w) come from the materialised-candidate kernel ([task][2])
+    const bool ph = pass == 0 && bs_ph != nullptr;
+    const double* bs = j < 4 ? (ph ? bs_ph + (size_t)b * per_sample_ph * 2 + (j & 1) : (pass ? bs_s : bs_t) + (size_t)b * per_sample * 8 + j)
                              : bs_p + (size_t)b * per_sample_p * 8 + pass * 4 + (j - 4);
-    const int n_t = j < 4 ? per_sample : per_sample_p;
+    const int n_t = j < 4 ? (ph ? (j < 2 ? per_sample_ph : 0) : per_sample) : per_sample_p;
+    const size_t stride = (j < 4 && ph) ? 2 : 8;
     double acc = 0.0;
 #pragma unroll 8
-    for (int t = sub; t < n_t; t += 32) acc += bs[(size_t)t * 8];  // independent loads: issue them together
+    for (int t = sub; t < n_t; t += 32) acc += bs[(size_t)t * stride];  // independent loads: issue them together
     s_part[tid] = acc;
     __syncthreads();
     if (tid < 8) {
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
       for (int k = 0; k < 32; ++k) a += s_part[k * 8 + tid];
       ps[((size_t)pass * B + b) * 8 + tid] = a;
     }
-  } else {
+  } else if (bgP != nullptr) {
     const int b = blockIdx.x - 2 * B;
     // 24 sums of per_sample partials: 10 threads per value (240 of 256), then a 10-term sum (fixed order)
     const int v = tid % 24, sub = tid / 24;
@@ -195,6 +212,35 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
   coefs[4] = w_main * 1e-3f;                                // smoothness
 }
 
+// the pose branch of step_final_kernel on its own (temporal hint: the teacher's sweep runs in the backward call)
+__global__ __launch_bounds__(256) void step_pose_reduce_kernel(const float* bgP, const float* K, int per_sample, float* gT0,
+                                                               float* gT1) {
+  __shared__ double s_part[256];
+  __shared__ double s_gP[24];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int v = tid % 24, sub = tid / 24;
+  double acc = 0.0;
+  if (sub < 10) {
+#pragma unroll 8
+    for (int t = sub; t < per_sample; t += 10) acc += (double)bgP[((size_t)b * per_sample + t) * 24 + v];
+  }
+  s_part[tid] = acc;
+  __syncthreads();
+  if (tid < 24) {
+    double a = 0.0;
+    for (int k = 0; k < 10; ++k) a += s_part[k * 24 + tid];
+    s_gP[tid] = a;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int f = tid >> 4, e = tid & 15, k = e >> 2, j = e & 3;
+    const float* Kb = K + b * 16;
+    double a = 0.0;
+    for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
+    (f ? gT1 : gT0)[b * 16 + e] = (float)a;
+  }
+}
+
 // d total / d disp for both maps; block 0 also scales the pose gradients and runs the backward of
 // transformation_from_parameters (pp.gT = the scaled gradients, pp.g_axisangle / g_translation nullable)
 __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, const float* G_r_s, const float* G_cd,
@@ -264,70 +310,108 @@ static int step_check(const mal_step_args* a) {
   return MAL_OK;
 }
 
+// 1. identity term + texel packing of the three images (one texel load per pixel in the passes) + both smoothness
+//    terms + the tie-break noise; B extra workgroups of the same launch: poses (frame -1 is inverted,
+//    networks/repdepth.py:159-160) + camera block
+static int first_sweep(const mal_step_args* a, const StepWs& w, hipStream_t st, int* per_sample_p) {
+  const int B = a->B, H = a->H, W = a->W;
+  StepPoses sp = {};
+  sp.pose.B = B; sp.pose.F = 2;
+  sp.pose.axisangle[0] = a->axisangle_m1; sp.pose.axisangle[1] = a->axisangle_p1;
+  sp.pose.translation[0] = a->translation_m1; sp.pose.translation[1] = a->translation_p1;
+  sp.pose.invert[0] = 1; sp.pose.invert[1] = 0;
+  sp.pose.T[0] = w.T[0]; sp.pose.T[1] = w.T[1];
+  sp.K = a->K; sp.invK = a->inv_K; sp.cam = w.cam; sp.ticket = w.ticket;
+  TieNoise tn = {};
+  if (a->flags & MAL_STEP_NOISE_PHILOX) {
+    if (a->noise) return MAL_EINVAL;
+    tn.on = 1; tn.seed = a->noise_seed; tn.step = a->noise_step; tn.counter = (const unsigned long long*)a->noise_counter;
+    tn.noise_out = a->noise_out;
+  }
+  // both smoothness terms (teacher's and student's disparity) ride on this sweep: it holds the target rows anyway
+  SmoothParams sm = {};
+  sm.n = 2; sm.disp[0] = a->disp_teacher; sm.disp[1] = a->disp_student; sm.gn[0] = w.gn_t; sm.gn[1] = w.gn_s;
+  sm.partials = w.bs_p; sm.dec[0] = a->dec_teacher; sm.dec[1] = a->dec_student;
+  return pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
+                              &sp, &tn, &sm, per_sample_p);
+}
+
+static MarchParams teacher_params(const mal_step_args* a, const StepWs& w, float* mono_reproj) {
+  MarchParams p = march_params(a->B, a->H, a->W, a->min_depth, a->max_depth, 1e-7f, 0);
+  p.disp = a->disp_teacher; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+  p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+  p.min_reproj = mono_reproj; p.block_gP = w.bgP;
+  p.cam = w.cam; p.cam_ready = 1;  // the first launch filled the camera block
+  return p;
+}
+
+// MAL_STEP_TEMPORAL, first call: the first sweep and the teacher's warped images (forward only: the per-pixel min over
+// the two warped candidates and its winner stay in the workspace for mal_loss_step_fwd)
+extern "C" int mal_loss_step_warp(const mal_step_args* a) {
+  int rc = step_check(a);
+  if (rc) return rc;
+  if (!(a->flags & MAL_STEP_TEMPORAL) || !a->warp_m1 || !a->warp_p1) return MAL_EINVAL;
+  StepWs w = carve_step(a->ws, a->B, a->H, a->W);
+  hipStream_t st = (hipStream_t)a->stream;
+  int per_sample_p = 1;
+  rc = first_sweep(a, w, st, &per_sample_p);
+  if (rc) return rc;
+  MarchParams p = teacher_params(a, w, a->mono_reproj ? a->mono_reproj : w.mono_reproj);
+  p.block_sums = w.bs_t;
+  p.color_out[0] = a->warp_m1; p.color_out[1] = a->warp_p1; p.argmin_out = w.arg_t;
+  return march_launch(p, MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+}
+
 extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   int rc = step_check(a);
   if (rc) return rc;
   const int B = a->B, H = a->H, W = a->W;
   StepWs w = carve_step(a->ws, B, H, W);
   hipStream_t st = (hipStream_t)a->stream;
-  const bool no_ens = a->flags & MAL_STEP_NO_ENS;
+  const bool no_ens = a->flags & MAL_STEP_NO_ENS, temporal = a->flags & MAL_STEP_TEMPORAL;
   float* mono_reproj = a->mono_reproj ? a->mono_reproj : w.mono_reproj;
   float* ens_reproj = no_ens ? nullptr : (a->ens_reproj ? a->ens_reproj : w.ens_reproj);
   float* multi_reproj = a->multi_reproj;  // only written when the caller wants the map
 
-  int per_sample_p = 1;
-  // 1. identity term + texel packing of the three images (one texel load per pixel in the passes); B extra
-  //    workgroups of the same launch: poses (frame -1 is inverted, networks/repdepth.py:159-160) + camera block
-  {
-    StepPoses sp = {};
-    sp.pose.B = B; sp.pose.F = 2;
-    sp.pose.axisangle[0] = a->axisangle_m1; sp.pose.axisangle[1] = a->axisangle_p1;
-    sp.pose.translation[0] = a->translation_m1; sp.pose.translation[1] = a->translation_p1;
-    sp.pose.invert[0] = 1; sp.pose.invert[1] = 0;
-    sp.pose.T[0] = w.T[0]; sp.pose.T[1] = w.T[1];
-    sp.K = a->K; sp.invK = a->inv_K; sp.cam = w.cam; sp.ticket = w.ticket;
-    TieNoise tn = {};
-    if (a->flags & MAL_STEP_NOISE_PHILOX) {
-      if (a->noise) return MAL_EINVAL;
-      tn.on = 1; tn.seed = a->noise_seed; tn.step = a->noise_step; tn.counter = (const unsigned long long*)a->noise_counter;
-      tn.noise_out = a->noise_out;
-    }
-    // both smoothness terms (teacher's and student's disparity) ride on this sweep: it holds the target rows anyway
-    SmoothParams sm = {};
-    sm.n = 2; sm.disp[0] = a->disp_teacher; sm.disp[1] = a->disp_student; sm.gn[0] = w.gn_t; sm.gn[1] = w.gn_s;
-    sm.partials = w.bs_p; sm.dec[0] = a->dec_teacher; sm.dec[1] = a->dec_student;
-    rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
-                              &sp, &tn, &sm, &per_sample_p);
-    if (rc) return rc;
-  }
+  int per_sample_p = 1, per_sample_ph = 0;
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
   int per_sample = 1;
-  int cam_ready = 1;  // the first launch filled the camera block
-  // 5. teacher pass
-  {
-    MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
-    p.disp = a->disp_teacher; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
-    p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
-    p.ident = w.ident; p.noise = a->noise; p.min_reproj = mono_reproj; p.g_reproj = w.G_r_t;
-    p.block_sums = w.bs_t; p.block_gP = w.bgP;
-    p.cam = w.cam; p.cam_ready = cam_ready;
+  if (!temporal) {
+    rc = first_sweep(a, w, st, &per_sample_p);
+    if (rc) return rc;
+    // teacher pass: forward and gradient in one sweep
+    MarchParams p = teacher_params(a, w, mono_reproj);
+    p.ident = w.ident; p.noise = a->noise; p.g_reproj = w.G_r_t;
+    p.block_sums = w.bs_t;
     p.dbg = a->dec_teacher;
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
     if (rc) return rc;
-    per_sample = p.strips * p.segs;
-    cam_ready = p.cam_ready;
+  } else {
+    // mal_loss_step_warp ran the first sweep and left min_f r(warp_f) / its winner in mono_reproj / arg_t: the two
+    // synthesised images join the running min (first minimum wins, as torch.min over [warp-1, warp+1, syn-1, syn+1],
+    // loss_utils.py:79-90,103), the automask and the teacher's sums are formed over all four, and the gradient w.r.t.
+    // the synthesised images leaves unnormalised
+    if (!a->syn_m1 || !a->syn_p1 || !a->g_syn_m1 || !a->g_syn_p1) return MAL_EINVAL;
+    per_sample_p = pack_identity_tasks_per_sample(H, W);
+    rc = photo_march_fwd_more(a->color0, a->syn_m1, a->syn_p1, 2, w.ident, a->noise, B, H, W, mono_reproj, w.arg_t, w.w_t,
+                              w.bs_ph, &per_sample_ph, st);
+    if (rc) return rc;
+    const float* cand[4] = {a->syn_m1, a->syn_p1, a->syn_m1, a->syn_p1};
+    float* g_cand[4] = {nullptr, nullptr, a->g_syn_m1, a->g_syn_p1};
+    rc = photo_march_bwd(a->color0, cand, 4, w.arg_t, w.w_t, nullptr, nullptr, B, H, W, g_cand, st);
+    if (rc) return rc;
   }
-  // 6. ensemble pass (no gradient)
+  // ensemble pass (no gradient)
   if (!no_ens) {
     MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
     p.disp = a->disp_teacher; p.disp2 = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
     p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
     p.min_reproj = ens_reproj; p.block_sums = w.bs_e; p.block_gP = w.bgP;
-    p.cam = w.cam; p.cam_ready = cam_ready;
+    p.cam = w.cam; p.cam_ready = 1;
     rc = march_launch(p, packed, st);
     if (rc) return rc;
   }
-  // 7. student pass with the consistency / distillation epilogue
+  // student pass with the consistency / distillation epilogue
   {
     MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
     p.disp = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
@@ -340,13 +424,15 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.g_cons = w.G_c; p.g_distil = nullptr;  // one merged map: weights as coefs[2], coefs[3] of step_final_kernel
     p.merge_cons = (float)((double)a->w_main / ((double)B * H * W)); p.merge_distil = (float)((double)a->w_distil / ((double)B * H * W));
     p.block_sums = w.bs_s; p.block_gP = w.bgP;
-    p.cam = w.cam; p.cam_ready = cam_ready;
+    p.cam = w.cam; p.cam_ready = 1;
     p.dbg = a->dec_student;
     rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
     if (rc) return rc;
+    per_sample = p.strips * p.segs;
   }
-  // 8. per-sample sums of both gradient passes, pose gradients, scalars
-  hipLaunchKernelGGL(step_final_kernel, dim3(3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, w.bgP, w.bs_p, per_sample_p, a->K,
+  // per-sample sums of both gradient passes, pose gradients (temporal: in _bwd, after the teacher's sweep), scalars
+  hipLaunchKernelGGL(step_final_kernel, dim3(temporal ? 2 * B : 3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, temporal ? nullptr : w.bgP,
+                     w.bs_p, per_sample_p, temporal ? w.bs_ph : nullptr, per_sample_ph, a->K,
                      per_sample, B, H, W,
                      a->w_main, a->w_distil, w.ps, w.gT[0], w.gT[1], w.sm_stats, a->losses, w.coefs, a->loss_total,
                      w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr);
@@ -359,6 +445,19 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   const int B = a->B, H = a->H, W = a->W, HW = H * W;
   StepWs w = carve_step(a->ws, B, H, W);
   hipStream_t st = (hipStream_t)a->stream;
+  if (a->flags & MAL_STEP_TEMPORAL) {
+    // the teacher's gradient sweep, with the decisions of the four-way min taken from _fwd and the gradient that
+    // reaches the warped images through syn added before the chain rule through the warp
+    if (!a->g_warp_m1 || !a->g_warp_p1) return MAL_EINVAL;
+    MarchParams p = teacher_params(a, w, nullptr);
+    p.g_reproj = w.G_r_t; p.block_sums = w.bs_t;
+    p.ident = w.ident;  // unused by the TEMPORAL instantiation (the launch checks the flag combination only)
+    p.forced_w = w.w_t; p.forced_arg = w.arg_t; p.g_color[0] = a->g_warp_m1; p.g_color[1] = a->g_warp_p1;
+    p.dbg = a->dec_teacher;
+    rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(step_pose_reduce_kernel, dim3(B), dim3(256), 0, st, w.bgP, a->K, p.strips * p.segs, w.gT[0], w.gT[1]);
+  }
   size_t g = ((size_t)B * HW + 255) / 256;
   if (g > 2048) g = 2048;
   PoseParams pp = {};

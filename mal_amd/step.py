@@ -41,98 +41,174 @@ def _workspace(dev, B, H, W):
     return ws
 
 
+def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=False):
+    """the mal_step_args block of one step, the tensors it points to (kept alive by the caller) and the map dict"""
+    color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise = consts
+    min_depth, max_depth, no_ens, w_main, w_distil, want_maps, aug_is_mask, want_dec, philox = cfg
+    req = ops._req
+    tens = [req(t, n) for t, n in ((disp_t, "disp_teacher"), (disp_s, "disp_student"), (aa_m1, "axisangle"),
+                                   (tr_m1, "translation"), (aa_p1, "axisangle"), (tr_p1, "translation"))]
+    cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest)]
+    cons.append(None if noise is None else req(noise, "input"))
+    B, _, H, W = tens[0].shape
+    dev = tens[0].device
+    a = L.StepArgs()
+    a.B, a.H, a.W = B, H, W
+    a.min_depth, a.max_depth = float(min_depth), float(max_depth)
+    a.flags = (L.STEP_NO_ENS if no_ens else 0) | (L.STEP_AUG_MASK if aug_is_mask else 0) | (L.STEP_TEMPORAL if temporal else 0)
+    if philox is not None:  # (seed, want the drawn values back)
+        a.flags |= L.STEP_NOISE_PHILOX
+        a.noise_seed = int(philox[0]) & 0xFFFFFFFFFFFFFFFF
+        ctr = noise_counter(tens[0].device)
+        a.noise_counter = ctr.data_ptr()
+    a.w_main, a.w_distil = float(w_main), float(w_distil)
+    p = ops._p
+    a.disp_teacher, a.disp_student = p(tens[0]), p(tens[1])
+    a.axisangle_m1, a.translation_m1, a.axisangle_p1, a.translation_p1 = (p(t) for t in tens[2:])
+    (a.color0, a.color_m1, a.color_p1, a.K, a.inv_K, a.consistency_mask, a.augmentation_keep, a.lowest_cost,
+     a.noise) = (p(t) for t in cons)
+    losses = torch.empty(16, dtype=torch.float32, device=dev)
+    total = torch.empty(1, dtype=torch.float32, device=dev)  # its own tensor: no select/copy nodes in the backward
+    a.losses, a.loss_total = p(losses), p(total)
+    maps = {}
+    if want_maps:
+        new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        maps = dict(mono_reproj=new((B, 1, H, W)), multi_reproj=new((B, 1, H, W)),
+                    consistency_mask=new((B, H, W)))
+        if not no_ens:
+            maps["ens_reproj"] = new((B, 1, H, W))
+        a.mono_reproj, a.multi_reproj = p(maps["mono_reproj"]), p(maps["multi_reproj"])
+        a.consistency_mask_out = p(maps["consistency_mask"])
+        a.ens_reproj = p(maps.get("ens_reproj"))
+    if philox is not None and philox[1]:
+        maps["noise"] = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        a.noise_out = p(maps["noise"])
+    if want_dec:  # parity instrumentation (tests): the kernels' per-pixel decisions, MAL_DEC_* planes
+        for k in ("dec_teacher", "dec_student"):
+            maps[k] = torch.zeros((L.DEC_PLANES, B, H, W), dtype=torch.int32, device=dev)
+        a.dec_teacher, a.dec_student = p(maps["dec_teacher"]), p(maps["dec_student"])
+    ws = _workspace(dev, B, H, W)
+    a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
+    return a, (tens, cons, ws, losses, total), maps
+
+
+def _run_bwd(ctx, g_total):
+    tens = ctx.keep[0]
+    # only the total is differentiable through this node: the 16 slots are its terms, for logging
+    g_total = g_total.reshape(1).contiguous()
+    a = ctx.args
+    grads = [torch.empty_like(t) if ctx.needs_input_grad[i] else None for i, t in enumerate(tens)]
+    a.g_total = ops._p(g_total)
+    (a.g_disp_teacher, a.g_disp_student, a.g_axisangle_m1, a.g_translation_m1, a.g_axisangle_p1,
+     a.g_translation_p1) = (ops._p(g) for g in grads)
+    L.check(L.load().mal_loss_step_bwd(C.byref(a)), "mal_loss_step_bwd")
+    return grads
+
+
 class LossStepFn(Function):
     """leaves: disp_teacher, disp_student, axisangle_m1, translation_m1, axisangle_p1, translation_p1."""
 
     @staticmethod
     def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg):
-        color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise = consts
-        min_depth, max_depth, no_ens, w_main, w_distil, want_maps, aug_is_mask, want_dec, philox = cfg
-        req = ops._req
-        tens = [req(t, n) for t, n in ((disp_t, "disp_teacher"), (disp_s, "disp_student"), (aa_m1, "axisangle"),
-                                       (tr_m1, "translation"), (aa_p1, "axisangle"), (tr_p1, "translation"))]
-        cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest)]
-        cons.append(None if noise is None else req(noise, "input"))
-        B, _, H, W = tens[0].shape
-        dev = tens[0].device
-        a = L.StepArgs()
-        a.B, a.H, a.W = B, H, W
-        a.min_depth, a.max_depth = float(min_depth), float(max_depth)
-        a.flags = (L.STEP_NO_ENS if no_ens else 0) | (L.STEP_AUG_MASK if aug_is_mask else 0)
-        if philox is not None:  # (seed, want the drawn values back)
-            a.flags |= L.STEP_NOISE_PHILOX
-            a.noise_seed = int(philox[0]) & 0xFFFFFFFFFFFFFFFF
-            ctr = noise_counter(tens[0].device)
-            a.noise_counter = ctr.data_ptr()
-        a.w_main, a.w_distil = float(w_main), float(w_distil)
-        p = ops._p
-        a.disp_teacher, a.disp_student = p(tens[0]), p(tens[1])
-        a.axisangle_m1, a.translation_m1, a.axisangle_p1, a.translation_p1 = (p(t) for t in tens[2:])
-        (a.color0, a.color_m1, a.color_p1, a.K, a.inv_K, a.consistency_mask, a.augmentation_keep, a.lowest_cost,
-         a.noise) = (p(t) for t in cons)
-        losses = torch.empty(16, dtype=torch.float32, device=dev)
-        total = torch.empty(1, dtype=torch.float32, device=dev)  # its own tensor: no select/copy nodes in the backward
-        a.losses, a.loss_total = p(losses), p(total)
-        maps = {}
-        if want_maps:
-            new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)
-            maps = dict(mono_reproj=new((B, 1, H, W)), multi_reproj=new((B, 1, H, W)),
-                        consistency_mask=new((B, H, W)))
-            if not no_ens:
-                maps["ens_reproj"] = new((B, 1, H, W))
-            a.mono_reproj, a.multi_reproj = p(maps["mono_reproj"]), p(maps["multi_reproj"])
-            a.consistency_mask_out = p(maps["consistency_mask"])
-            a.ens_reproj = p(maps.get("ens_reproj"))
-        if philox is not None and philox[1]:
-            maps["noise"] = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-            a.noise_out = p(maps["noise"])
-        if want_dec:  # parity instrumentation (tests): the kernels' per-pixel decisions, MAL_DEC_* planes
-            for k in ("dec_teacher", "dec_student"):
-                maps[k] = torch.zeros((L.DEC_PLANES, B, H, W), dtype=torch.int32, device=dev)
-            a.dec_teacher, a.dec_student = p(maps["dec_teacher"]), p(maps["dec_student"])
-        ws = _workspace(dev, B, H, W)
-        a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
+        a, keep, maps = _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg)
         L.check(L.load().mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
         ctx.args = a
-        ctx.keep = (tens, cons, ws, losses, total)  # the C struct holds raw pointers: keep the tensors alive
+        ctx.keep = keep  # the C struct holds raw pointers: keep the tensors alive
         ctx.set_materialize_grads(False)
-        outs = [total, losses] + [maps[k] for k in MAP_NAMES if k in maps]
+        outs = [keep[4], keep[3]] + [maps[k] for k in MAP_NAMES if k in maps]
         ctx.mark_non_differentiable(*outs[1:])
         return tuple(outs)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_total, *_):
-        tens = ctx.keep[0]
         if g_total is None:
             return (None,) * 8
-        # only the total is differentiable through this node: the 16 slots are its terms, for logging
-        g_total = g_total.reshape(1).contiguous()
+        return (*_run_bwd(ctx, g_total), None, None)
+
+
+class TemporalLossStepFn(Function):
+    """The step with the temporal hint (``--temporal``, loss_utils.py:84-88): three library calls around the producer
+    ``synth(inputs, outputs, scale) -> has_ins`` (upstream: dyn_utils.image_synthesis), which reads the teacher's
+    warped images ``outputs[("color", f, 0)]`` and writes ``outputs[("syn", f, 0)]`` with ordinary autograd ops
+    (dyn_utils.py:127-128,145-146,163-168).  Forward: mal_loss_step_warp -> producer (recorded by autograd on a
+    private copy of the warped images) -> mal_loss_step_fwd (hands back d loss / d syn); backward: the producer's own
+    backward (torch.autograd.grad on that private graph), then mal_loss_step_bwd, whose teacher sweep adds what arrives
+    through syn to d loss / d warped colour before the chain rule through the warp."""
+
+    @staticmethod
+    def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, synth, inputs, expose):
+        a, keep, maps = _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=True)
+        B, _, H, W = keep[0][0].shape
+        dev = keep[0][0].device
+        warp = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+        a.warp_m1, a.warp_p1 = warp[0].data_ptr(), warp[1].data_ptr()
+        lib = L.load()
+        L.check(lib.mal_loss_step_warp(C.byref(a)), "mal_loss_step_warp")
+        with torch.enable_grad():
+            leaf = [w.detach().requires_grad_(True) for w in warp]
+            local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1]}
+            has_ins = bool(synth(inputs, local, 0))
+        if has_ins:
+            syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
+            syn_data = [ops._req(s.detach(), "syn") for s in syn]
+        else:  # no matched instance anywhere: syn == warp ties with it and never wins (first minimum), as if absent
+            syn, syn_data = None, warp
+        g_syn = [torch.empty_like(w) for w in warp]
+        a.syn_m1, a.syn_p1 = syn_data[0].data_ptr(), syn_data[1].data_ptr()
+        a.g_syn_m1, a.g_syn_p1 = g_syn[0].data_ptr(), g_syn[1].data_ptr()
+        L.check(lib.mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
+        ctx.args, ctx.keep = a, keep
+        ctx.graph = (leaf, syn, syn_data, g_syn, warp)
+        ctx.set_materialize_grads(False)
+        expose[("color", -1, 0)], expose[("color", 1, 0)] = warp
+        if has_ins:
+            expose[("syn", -1, 0)], expose[("syn", 1, 0)] = syn_data
+        expose["has_ins"] = has_ins
+        outs = [keep[4], keep[3]] + [maps[k] for k in MAP_NAMES if k in maps]
+        ctx.mark_non_differentiable(*outs[1:])
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_total, *_):
+        if g_total is None:
+            return (None,) * 11
+        leaf, syn, syn_data, g_syn, warp = ctx.graph
+        if syn is None:
+            g_warp = g_syn  # the identity producer
+        else:
+            g_warp = torch.autograd.grad(syn, leaf, g_syn, allow_unused=True)
+            g_warp = [torch.zeros_like(w) if g is None else g.contiguous() for g, w in zip(g_warp, warp)]
         a = ctx.args
-        grads = [torch.empty_like(t) if ctx.needs_input_grad[i] else None for i, t in enumerate(tens)]
-        a.g_total = ops._p(g_total)
-        (a.g_disp_teacher, a.g_disp_student, a.g_axisangle_m1, a.g_translation_m1, a.g_axisangle_p1,
-         a.g_translation_p1) = (ops._p(g) for g in grads)
-        L.check(L.load().mal_loss_step_bwd(C.byref(a)), "mal_loss_step_bwd")
-        return (*grads, None, None)
+        a.g_warp_m1, a.g_warp_p1 = g_warp[0].data_ptr(), g_warp[1].data_ptr()
+        ctx.g_warp = g_warp
+        return (*_run_bwd(ctx, g_total), None, None, None, None, None)
 
 
 def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=None, noise=None, want_maps=True,
-              want_decisions=False, want_noise=False):
+              want_decisions=False, want_noise=False, image_synthesis=None):
     """process_batch's loss half in one call.  Reads the same dict entries as the reference:
     ``inputs[("color", f, 0)]``, ``("K", 0)``, ``("inv_K", 0)``; ``mono_outputs[("disp", 0)]``,
     ``("axisangle", 0, f)`` / ``("translation", 0, f)`` (networks/repdepth.py:155-156);
     ``outputs[("disp", 0)]``, ``"consistency_mask"``, ``"augmentation_mask"``, ``"lowest_cost"``.
+    With ``opt.temporal`` the producer ``image_synthesis(inputs, outputs, scale) -> has_ins`` is called between the
+    library calls (``TemporalLossStepFn``); ``mono_outputs`` then receives ``("color", f, 0)``, ``("syn", f, 0)`` and
+    ``"has_ins"`` as the reference's generate_images_pred leaves them (trainer.py:1122-1125,1161-1165).
     Writes ``outputs["consistency_mask"]`` (x matching mask, trainer.py:592-593) when ``want_maps``.
     ``want_decisions`` (tests) adds ``maps["dec_teacher"]`` / ``["dec_student"]``: the per-pixel decisions of the two
     gradient passes (int32 (MAL_DEC_PLANES,B,H,W), include/mal_hip.h).
     Returns (losses dict, loss_list or None, maps dict)."""
     from . import config, loss_utils
-    if getattr(opt, "temporal", False) or getattr(opt, "main_temporal", False) or getattr(opt, "dual_distil", False) \
+    if getattr(opt, "main_temporal", False) or getattr(opt, "dual_distil", False) \
             or getattr(opt, "learn_ens", False) or getattr(opt, "no_ssim", False) or not getattr(opt, "distil", True) \
             or getattr(opt, "sclm", 0) != 0:
-        raise L.MalError("loss_step covers the --distil single-scale configuration; use MALLossPath."
-                         "compute_batch_losses for temporal / dual_distil / learn_ens / no_ssim / non-distil runs")
+        raise L.MalError("loss_step covers the --distil [--temporal] single-scale configuration; use MALLossPath."
+                         "compute_batch_losses for main_temporal / dual_distil / learn_ens / no_ssim / non-distil runs")
+    temporal = bool(getattr(opt, "temporal", False))
+    if temporal and image_synthesis is None:
+        raise L.MalError("loss_step with opt.temporal needs image_synthesis(inputs, outputs, scale) -> has_ins "
+                         "(upstream: dyn_utils.image_synthesis bound to the segmenter and the matcher, trainer.py:1161-1165)")
     color0 = inputs[("color", 0, 0)]
     B, _, H, W = color0.shape
     dev = color0.device
@@ -159,8 +235,12 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
               outputs["consistency_mask"].to(torch.float32), keep, outputs["lowest_cost"], noise)
     cfg = (opt.min_depth, opt.max_depth, bool(getattr(opt, "no_ens", False)), w_main, w_distil, bool(want_maps),
            aug_is_mask, bool(want_decisions), philox)
-    res = LossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
-                           fix(tr[1]), consts, cfg)
+    if temporal:
+        res = TemporalLossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
+                                       fix(tr[1]), consts, cfg, image_synthesis, inputs, mono_outputs)
+    else:
+        res = LossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
+                               fix(tr[1]), consts, cfg)
     total, v = res[0].reshape(()), res[1]
     maps = {}
     names = (["mono_reproj", "multi_reproj", "consistency_mask"] + ([] if cfg[2] else ["ens_reproj"])) if want_maps else []

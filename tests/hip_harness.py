@@ -23,7 +23,10 @@ def run_oracle(batch, opt_kw, n0, n1, w_list=(0.7, 0.3), forced=None):
     with torch.no_grad():
         target = inputs[("color", 0, 0)]
         R = torch.cat([O.compute_reprojection_loss(outputs[("color", f, 0)], target) for f in (-1, 1)], 1)
-        Rm = torch.cat([O.compute_reprojection_loss(mono_outputs[("color", f, 0)], target) for f in (-1, 1)], 1)
+        mono_pred = [mono_outputs[("color", f, 0)] for f in (-1, 1)]
+        if ("syn", -1, 0) in mono_outputs and opt.temporal:  # the teacher's four candidates (loss_utils.py:79-90)
+            mono_pred += [mono_outputs[("syn", f, 0)] for f in (-1, 1)]
+        Rm = torch.cat([O.compute_reprojection_loss(c, target) for c in mono_pred], 1)
         I = torch.cat([O.compute_reprojection_loss(inputs[("color", f, 0)], target) for f in (-1, 1)], 1)
     return dict(final=final.item(), losses={k: v.item() for k, v in losses.items()},
                 mono_losses={k: v.item() for k, v in mono_losses.items()},
@@ -35,6 +38,7 @@ def run_oracle(batch, opt_kw, n0, n1, w_list=(0.7, 0.3), forced=None):
                 consistency_mask=outputs["consistency_mask"].numpy(),
                 cons_target=outputs["consistency_target/0"].numpy(),
                 mono_color={f: mono_outputs[("color", f, 0)].detach().numpy() for f in (-1, 1)},
+                mono_preds=[c.detach().numpy() for c in mono_pred],
                 multi_color={f: outputs[("color", f, 0)].detach().numpy() for f in (-1, 1)},
                 mono_sample={f: mono_outputs[("sample", f, 0)].detach().numpy() for f in (-1, 1)},
                 multi_sample={f: outputs[("sample", f, 0)].detach().numpy() for f in (-1, 1)},
@@ -114,12 +118,14 @@ def oracle_decisions(o, batch, n0, no_ens=False):
     idn = t(o["ident"]) + n0 * 0.00001
     rp_t = t(o["mono_cands"]).min(1, keepdim=True)[0]
 
-    def l1_signs(colors, win):  # sign(pred - target) of the winning candidate, per channel
-        pred = torch.where(win == 0, t(colors[-1]), t(colors[1]))
+    def l1_signs(preds, win):  # sign(pred - target) of the winning candidate, per channel
+        pred = t(preds[0])
+        for i in range(1, len(preds)):
+            pred = torch.where(win == i, t(preds[i]), pred)
         return torch.sign(pred - batch["color0"])
 
     win_t, win_s = t(o["mono_cands"]).argmin(1, keepdim=True), t(o["multi_cands"]).argmin(1, keepdim=True)
-    teacher = dict(win=win_t, automask=(rp_t <= idn).float(), l1=l1_signs(o["mono_color"], win_t),
+    teacher = dict(win=win_t, automask=(rp_t <= idn).float(), l1=l1_signs(o["mono_preds"], win_t),
                    smooth=_smooth_signs(batch["disp_teacher"]),
                    taps={f: AR.taps_of(t(o["mono_sample"][f]), H, W) for f in (-1, 1)})
     rp_s = t(o["multi_cands"]).min(1, keepdim=True)[0]
@@ -127,7 +133,7 @@ def oracle_decisions(o, batch, n0, no_ens=False):
     idx = torch.cat(trio, 1).argmin(1, keepdim=True)
     if len(trio) == 2:
         idx = idx * 2  # numbered as the kernels do: 0 teacher, 2 student
-    student = dict(win=win_s, distil=idx, l1=l1_signs(o["multi_color"], win_s),
+    student = dict(win=win_s, distil=idx, l1=l1_signs([o["multi_color"][-1], o["multi_color"][1]], win_s),
                    smooth=_smooth_signs(batch["disp_student"]),
                    taps={f: AR.taps_of(t(o["multi_sample"][f]), H, W) for f in (-1, 1)})
     return dict(teacher=teacher, student=student, cmask=t(o["consistency_mask"]))
