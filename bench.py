@@ -50,8 +50,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a HIP graph (default); 0: eager launches")
-    ap.add_argument("--mode", choices=["step", "ops", "temporal", "train", "multiscale"], default="step",
-                    help="step: mal_loss_step (one C call per direction, the headline); ops: the operator-level API; "
+    ap.add_argument("--mode", choices=["step", "distil", "ops", "temporal", "train", "multiscale"], default="step",
+                    help="step: --temporal --distil through mal_loss_step (BASELINE configs[1], the headline: three library "
+                         "calls around the temporal-hint producer); distil: --distil only (one C call per direction); "
+                         "ops: the operator-level API; "
                          "temporal: --temporal --distil through the operator-level API; train: the whole training step "
                          "of the harness (RepDepth networks + loss step + flat-bucket all-reduce + Adam, eager); "
                          "multiscale: the non-distil compute_losses with sclm=3 (four disparity scales, "
@@ -125,7 +127,7 @@ class Step:
         from mal_amd.synthetic import make_batch
         # no host randn / H2D on the step: the whole-step API draws the tie-break noise inside its first
         # kernel (Philox, keyed per rank); the operator-level modes use the device generator
-        config.noise_source = "philox" if mode == "step" else "cuda"
+        config.noise_source = "philox" if mode in ("step", "distil") else "cuda"
         config.noise_seed = 0x4d414c5eed + seed
         config.consistency_target = False  # logging-only map (loss_utils.py:212-215)
         self.one = torch.ones((), dtype=torch.float32, device=dev)  # d(loss)/d(loss): handed to backward, no fill launch
@@ -140,13 +142,15 @@ class Step:
                        ("disp_teacher", "disp_student", "axisangle_m1", "translation_m1", "axisangle_p1",
                         "translation_p1")}
         self.cmask, self.aug, self.lowest = mv(b["consistency_mask"]), mv(b["augmentation_mask"]), mv(b["lowest_cost"])
-        if mode == "temporal":
+        self.synth = None
+        if mode in ("temporal", "step"):
             # --temporal --distil: dyn_utils.image_synthesis itself (N2: the patch shifts in HIP) with stand-ins for its
-            # two external models, three matched instances per sample
+            # two external models (Mask2Former, Hungarian matcher: out of scope), three matched instances per sample
             from mal_amd import dyn_utils
             from mal_amd.synthetic import instance_stub
             ins_model, matcher = instance_stub(B, H, W, n_inst=3, seed=seed, device=dev)
             synth = lambda inputs, outputs, scale: dyn_utils.image_synthesis(inputs, outputs, scale, 0.5, ins_model, matcher)
+            self.synth = synth
             self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, temporal=True), fuse=True,
                                        image_synthesis=synth)
         elif mode == "multiscale":
@@ -166,14 +170,15 @@ class Step:
         L, lv = self.layers, self.leaves
         for t in lv.values():
             t.grad = None
-        if self.mode == "step":  # one C call forward (incl. texel packing every step), one backward
+        if self.mode in ("step", "distil"):  # the whole-step API (texel packing redone every step: a real step sees new images)
             mono_outputs = {("disp", 0): lv["disp_teacher"]}
             for f, s in ((-1, "m1"), (1, "p1")):
                 mono_outputs[("axisangle", 0, f)] = lv["axisangle_" + s]
                 mono_outputs[("translation", 0, f)] = lv["translation_" + s]
             outputs = {("disp", 0): lv["disp_student"], "consistency_mask": self.cmask,
                        "augmentation_mask": self.aug, "lowest_cost": self.lowest}
-            losses, _, _ = self.step_mod.loss_step(self.lp.opt, self.inputs, mono_outputs, outputs, want_maps=False)
+            losses, _, _ = self.step_mod.loss_step(self.lp.opt, self.inputs, mono_outputs, outputs, want_maps=False,
+                                                   image_synthesis=self.synth)
             losses["loss"].backward(gradient=self.one)
             return losses["loss"]
         self.ops.clear_packed_sources()  # a real step sees new images: repack them every step
@@ -360,7 +365,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if graph is None and args.mode == "step":
+        if graph is None and args.mode in ("step", "distil"):
             a, b_ = lib.mal_event_create(), lib.mal_event_create()
             lib.mal_profile_next_pass(a, b_)
             ev.append((a, b_))
@@ -393,7 +398,7 @@ def main():
         breakdown = {"loss_path_fwd_bwd": acc[0], "grad_all_reduce": acc[1] if bucket is not None else 0.0}
 
     durs = []
-    if args.mode == "step":
+    if args.mode in ("step", "distil"):
         if graph is not None:  # kernel timing needs eager launches: a few extra steps outside the timed region
             for i in range(20):
                 a, b_ = lib.mal_event_create(), lib.mal_event_create()
@@ -444,20 +449,27 @@ def main():
         "value": n_ranks * B * args.steps / dt, "unit": "images/s", "n_gpus": n_ranks, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "ManyDepth+MAL loss step, B=12 per GPU, 192x640, --distil (teacher+ensemble+student "
-                               "passes, consistency+distillation+smoothness), fwd+bwd to disp/pose leaves; "
-                               "networks not included (see train_step)", "global_batch": B * n_ranks, "height": H, "width": W,
+        "config": {"workload": ("ManyDepth+MAL loss step, B=12 per GPU, 192x640, --temporal --distil (teacher pass with the two "
+                                "synthesised candidates of the temporal hint, ensemble + student passes, consistency + distillation "
+                                "+ smoothness), fwd+bwd to disp/pose leaves incl. the gradient through syn; the hint's producer "
+                                "(dyn_utils.image_synthesis, N2 kernels) runs inside the step with stand-ins for its two external "
+                                "models, 3 matched instances per sample; scale 0 as the shipped decoder emits (SURVEY 9.1); "
+                                "networks not included (see train_step)") if args.mode in ("step", "temporal") else
+                               ("ManyDepth+MAL loss step, B=12 per GPU, 192x640, --distil (teacher+ensemble+student "
+                                "passes, consistency+distillation+smoothness), fwd+bwd to disp/pose leaves; "
+                                "networks not included (see train_step)"), "global_batch": B * n_ranks, "height": H, "width": W,
                    "parallelism": ("dp%d: replicas over disjoint batches, no data-path collective; every step ends with ONE RCCL "
                                    "all-reduce (mean) of the 165 MB flat fp32 gradient bucket" % n_ranks) if n_ranks > 1
                                   else "dp1 (single GPU: no collective)",
                    "launch": "hip-graph" if args.graph and graph_note is None else (graph_note or "eager"),
                    "clock_ramp": "0.1 s of untimed steps before the --warmup steps (sustained clocks)",
-                   "api": "mal_loss_step_fwd/_bwd (one host call per direction)" if args.mode == "step"
-                          else "operator-level (mal_amd.loss_utils / MALLossPath)"},
+                   "api": {"step": "mal_loss_step_warp/_fwd/_bwd (three host calls around the producer)",
+                           "distil": "mal_loss_step_fwd/_bwd (one host call per direction)"}.get(
+                               args.mode, "operator-level (mal_amd.loss_utils / MALLossPath)")},
     }
     if breakdown is not None:
         out["breakdown_ms"] = breakdown
-    if args.mode == "step":
+    if args.mode in ("step", "distil"):
         achieved = ALG_BYTES_PER_PX * n_px / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         copy_gbs = measured_copy_ceiling(dev)
         traffic = None
@@ -467,8 +479,12 @@ def main():
                 traffic = json.load(open(tpath)).get("pass_kernel_teacher_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "mal::march_kernel<true,true,true,false> (teacher pass: warp+SSIM+L1+"
-                                                     "min+automask+smoothness fwd+bwd, one launch)",
+        out["roofline"] = {"bound": "hbm", "kernel": ("mal::march_kernel<true,true,true,false,false,true> (teacher gradient sweep with the "
+                                                      "temporal hint: warp+SSIM+L1+min+automask fwd+bwd of the two warped candidates "
+                                                      "under the four-way decisions, + the gradient arriving through syn; one launch)")
+                                                     if args.mode == "step" else
+                                                     ("mal::march_kernel<true,true,true,false> (teacher pass: warp+SSIM+L1+"
+                                                      "min+automask fwd+bwd, one launch)"),
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic,
                            "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel "
@@ -484,7 +500,7 @@ def main():
         out["config"]["parallelism"] = "dp%d (one RCCL all-reduce of the flat gradient bucket per step)" % n_ranks
         out["config"]["api"] = "mal_amd.harness.TrainHarness.train_step"
         out["breakdown_ms"] = step.breakdown_ms()
-    elif args.mode != "step":
+    elif args.mode not in ("step", "distil"):
         out["config"]["workload"] += " [mode %s]" % args.mode
     if train_block is not None:
         out["train_step"] = train_block

@@ -329,6 +329,9 @@ typedef struct mal_dyn_item {
   int32_t* delta; uint8_t* flags;                /* forward out, backward in */
   void* ws; size_t ws_bytes;                     /* forward scratch: mal_dyn_workspace_bytes(num) */
   const float* g_ori_last; const float* g_ori_next; float* g_img_last; float* g_img_next;  /* backward */
+  /* optional: instance i is row idx_last[i] / idx_next[i] (device int64) of mask_last / mask_next -- the matcher's
+   * selection (dyn_utils.py:147-150) applied inside the kernels instead of by a gather per sample and frame; NULL = row i */
+  const int64_t* idx_last; const int64_t* idx_next;
 } mal_dyn_item;
 int mal_dyn_batch_fwd(const mal_dyn_item* items, int n_items, int C, int H, int W, int replace, void* stream);
 int mal_dyn_batch_bwd(const mal_dyn_item* items, int n_items, int C, int H, int W, void* stream);

@@ -88,7 +88,7 @@ class DynItem(C.Structure):
     """mal_dyn_item (include/mal_hip.h)."""
     _fields_ = [("mask_last", vp), ("mask_next", vp), ("num", i32), ("img_last", vp), ("img_next", vp),
                 ("ori_last", vp), ("ori_next", vp), ("delta", vp), ("flags", vp), ("ws", vp), ("ws_bytes", sz),
-                ("g_ori_last", vp), ("g_ori_next", vp), ("g_img_last", vp), ("g_img_next", vp)]
+                ("g_ori_last", vp), ("g_ori_next", vp), ("g_img_last", vp), ("g_img_next", vp), ("idx_last", vp), ("idx_next", vp)]
 
 
 class StepArgs(C.Structure):

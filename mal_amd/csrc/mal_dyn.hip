@@ -23,6 +23,9 @@ namespace mal {
 
 struct DynParams {
   const uint8_t* mask_last; const uint8_t* mask_next;  // (num,H,W) bytes, non-zero = set
+  // instance i is row idx_*[i] of the mask tensor (the matcher's selection, dyn_utils.py:147-150, applied here instead of
+  // by one gather launch per sample and frame); nullptr = row i
+  const long long* idx_last; const long long* idx_next;
   int num, C, H, W, replace;
   const float* img_last; const float* img_next;         // (C,H,W)
   float* ori_last; float* ori_next;
@@ -48,7 +51,8 @@ __global__ __launch_bounds__(1024) void dyn_extents_kernel(DynBatch bt) {
   for (int k = tid; k < H + W; k += 1024) sh[k] = 0;
   if (tid < 4) res[tid] = (tid & 1) ? 0x7fffffff : 0;  // low, top, right, left: max / min
   __syncthreads();
-  const uint8_t* m = (which ? p.mask_next : p.mask_last) + (size_t)i * HW;
+  const long long* sel = which ? p.idx_next : p.idx_last;
+  const uint8_t* m = (which ? p.mask_next : p.mask_last) + (size_t)(sel ? sel[i] : i) * HW;
   auto mark = [&](int k) { rowf[k / W] = 1; colf[k % W] = 1; };  // same-value stores: benign races
   if ((HW & 15) == 0 && (reinterpret_cast<size_t>(m) & 15) == 0) {
     // masks are mostly empty: scan 16 bytes per load, look at the bytes only where a word is non-zero
@@ -95,11 +99,22 @@ __global__ void dyn_delta_kernel(DynBatch bt) {
   p.delta[i * 2] = dx; p.delta[i * 2 + 1] = dy;
 }
 
-__global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynBatch bt) {
-  extern __shared__ int s_delta[];  // [num][2]
-  const DynParams& p = bt.s[blockIdx.z];
-  for (int k = threadIdx.x; k < p.num * 2; k += 256) s_delta[k] = p.delta[k];
+// the per-instance small data of a sample in shared memory: displacement [num][2], then mask rows [num][2]
+MAL_DEV void stage_instances(const DynParams& p, int* s_delta) {
+  for (int k = threadIdx.x; k < p.num * 2; k += 256) {
+    s_delta[k] = p.delta[k];
+    const int i = k >> 1;
+    const long long* sel = (k & 1) ? p.idx_next : p.idx_last;
+    s_delta[2 * p.num + k] = sel ? (int)sel[i] : i;
+  }
   __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynBatch bt) {
+  extern __shared__ int s_delta[];  // [num][2] displacements, [num][2] mask rows
+  const DynParams& p = bt.s[blockIdx.z];
+  stage_instances(p, s_delta);
+  const int* s_row = s_delta + 2 * p.num;
   const int H = p.H, W = p.W, HW = H * W;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= HW) return;
@@ -107,8 +122,8 @@ __global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynBatch bt) {
   bool region = false, any_l = false, any_n = false, bg_l = false, bg_n = false;
   float accl[4] = {0.f, 0.f, 0.f, 0.f}, accn[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i = 0; i < p.num; ++i) {
-    const uint8_t* ml = p.mask_last + (size_t)i * HW;
-    const uint8_t* mn = p.mask_next + (size_t)i * HW;
+    const uint8_t* ml = p.mask_last + (size_t)s_row[2 * i] * HW;
+    const uint8_t* mn = p.mask_next + (size_t)s_row[2 * i + 1] * HW;
     const bool a = ml[pix] != 0, b = mn[pix] != 0;
     region |= a | b; bg_l |= a & !b; bg_n |= b & !a;
     const int dx = s_delta[2 * i], dy = s_delta[2 * i + 1];
@@ -138,8 +153,8 @@ __global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynBatch bt) {
 __global__ __launch_bounds__(256) void dyn_synth_bwd_kernel(DynBatch bt) {
   extern __shared__ int s_delta[];
   const DynParams& p = bt.s[blockIdx.z];
-  for (int k = threadIdx.x; k < p.num * 2; k += 256) s_delta[k] = p.delta[k];
-  __syncthreads();
+  stage_instances(p, s_delta);
+  const int* s_row = s_delta + 2 * p.num;
   const int H = p.H, W = p.W, HW = H * W;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= HW) return;
@@ -159,12 +174,12 @@ __global__ __launch_bounds__(256) void dyn_synth_bwd_kernel(DynBatch bt) {
   // where p was copied to: instance i took img_last(p) to p + d_i (if that lies in the replaced region)
   for (int i = 0; i < p.num; ++i) {
     const int dx = s_delta[2 * i], dy = s_delta[2 * i + 1];
-    if (p.mask_last[(size_t)i * HW + pix]) {
+    if (p.mask_last[(size_t)s_row[2 * i] * HW + pix]) {
       const int rd = r + dx, cd = c + dy;
       if (rd >= 0 && rd < H && cd >= 0 && cd < W && (p.flags[rd * W + cd] & 1))
         for (int ch = 0; ch < p.C; ++ch) gl[ch] += p.g_ori_last[(size_t)ch * HW + rd * W + cd];
     }
-    if (p.mask_next[(size_t)i * HW + pix]) {
+    if (p.mask_next[(size_t)s_row[2 * i + 1] * HW + pix]) {
       const int rd = r - dx, cd = c - dy;
       if (rd >= 0 && rd < H && cd >= 0 && cd < W && (p.flags[rd * W + cd] & 1))
         for (int ch = 0; ch < p.C; ++ch) gn[ch] += p.g_ori_next[(size_t)ch * HW + rd * W + cd];
@@ -203,13 +218,14 @@ static int dyn_fwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, int
     if (a.ws_bytes < mal_dyn_workspace_bytes(a.num)) return MAL_EWORKSPACE;
     DynParams& p = bt.s[k];
     p.mask_last = a.mask_last; p.mask_next = a.mask_next; p.num = a.num; p.C = C; p.H = H; p.W = W; p.replace = replace;
+    p.idx_last = (const long long*)a.idx_last; p.idx_next = (const long long*)a.idx_next;
     p.img_last = a.img_last; p.img_next = a.img_next; p.ori_last = a.ori_last; p.ori_next = a.ori_next;
     p.ext = (int*)a.ws; p.delta = a.delta; p.flags = a.flags;
     max_num = a.num > max_num ? a.num : max_num;
   }
   hipLaunchKernelGGL(dyn_extents_kernel, dim3(max_num, 2, n), dim3(1024), (size_t)(H + W + 4) * sizeof(int), st, bt);
   hipLaunchKernelGGL(dyn_delta_kernel, dim3(1, 1, n), dim3(64), 0, st, bt);
-  hipLaunchKernelGGL(dyn_synth_fwd_kernel, dim3((H * W + 255) / 256, 1, n), dim3(256), (size_t)max_num * 2 * sizeof(int), st, bt);
+  hipLaunchKernelGGL(dyn_synth_fwd_kernel, dim3((H * W + 255) / 256, 1, n), dim3(256), (size_t)max_num * 4 * sizeof(int), st, bt);
   return launch_status();
 }
 
@@ -225,11 +241,12 @@ static int dyn_bwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, hip
       return MAL_EINVAL;
     DynParams& p = bt.s[k];
     p.mask_last = a.mask_last; p.mask_next = a.mask_next; p.num = a.num; p.C = C; p.H = H; p.W = W;
+    p.idx_last = (const long long*)a.idx_last; p.idx_next = (const long long*)a.idx_next;
     p.delta = a.delta; p.flags = a.flags;
     p.g_ori_last = a.g_ori_last; p.g_ori_next = a.g_ori_next; p.g_img_last = a.g_img_last; p.g_img_next = a.g_img_next;
     max_num = a.num > max_num ? a.num : max_num;
   }
-  hipLaunchKernelGGL(dyn_synth_bwd_kernel, dim3((H * W + 255) / 256, 1, n), dim3(256), (size_t)max_num * 2 * sizeof(int), st, bt);
+  hipLaunchKernelGGL(dyn_synth_bwd_kernel, dim3((H * W + 255) / 256, 1, n), dim3(256), (size_t)max_num * 4 * sizeof(int), st, bt);
   return launch_status();
 }
 

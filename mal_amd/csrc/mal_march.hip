@@ -1049,8 +1049,11 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
     hipLaunchKernelGGL(cam_setup_kernel, dim3(p.B), dim3(64), 0, st, p.K, p.T[0], p.T[1], p.invK, p.cam);
     p.cam_ready = 1;
   }
-  hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
-  g_prof_start = g_prof_stop = nullptr;
+  // mal_profile_next_pass times the next TEACHER gradient sweep (GRAD + AUTOMASK + POSE, no epilogue: the north-star
+  // kernel, with or without the temporal hint), not whichever marching launch happens to come first
+  const bool named = grad && pose && automask && !epi;
+  hipEvent_t ev0 = named ? g_prof_start : nullptr, ev1 = named ? g_prof_stop : nullptr;
+  if (named) g_prof_start = g_prof_stop = nullptr;
   if (ev0) (void)hipEventRecord(ev0, st);
 #define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((march_kernel<G, A, P, E>), grid, block, 0, st, p)
   if (p.forced_w) {  // TEMPORAL teacher pass

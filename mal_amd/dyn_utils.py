@@ -92,17 +92,31 @@ class BatchSynthesisFn(Function):
         cl, cn = ops._req(color_last, "color_last"), ops._req(color_next, "color_next")
         B, C, H, W = cl.shape
         dev = cl.device
-        syn_last, syn_next = cl.clone(), cn.clone()
         lib, p = L.load(), ops._p
+        # the kernels write every pixel of a listed sample: only the others need the copy of the warped images
+        every = len({it[0] for it in items}) == B
+        syn_last, syn_next = (torch.empty_like(cl), torch.empty_like(cn)) if every else (cl.clone(), cn.clone())
         if not items:
-            ctx.saved, ctx.dims = [], (C, H, W)
+            ctx.saved, ctx.dims, ctx.every = [], (C, H, W), False
             return syn_last, syn_next
         arr = (L.DynItem * len(items))()
         saved = []
-        for k, (b, mask_last, mask_next) in enumerate(items):
-            if mask_last.shape != mask_next.shape or mask_last.dim() != 3 or tuple(mask_last.shape[1:]) != (H, W):
-                raise L.MalError("image_synthesis: masks must be two (num,H,W) tensors matching the images")
-            num = mask_last.shape[0]
+        for k, item in enumerate(items):
+            b, mask_last, mask_next = item[:3]
+            idx_last, idx_next = (item[3], item[4]) if len(item) == 5 else (None, None)
+            if mask_last.dim() != 3 or mask_next.dim() != 3 or tuple(mask_last.shape[1:]) != (H, W) or \
+                    tuple(mask_next.shape[1:]) != (H, W):
+                raise L.MalError("image_synthesis: masks must be two (n,H,W) tensors matching the images")
+            if idx_last is None:
+                if mask_last.shape != mask_next.shape:
+                    raise L.MalError("image_synthesis: the two frames must hold the same number of matched instances")
+                num = mask_last.shape[0]
+            else:  # the matcher's row selections travel to the kernels as they are (device int64)
+                idx_last = idx_last.to(device=dev, dtype=torch.int64).contiguous()
+                idx_next = idx_next.to(device=dev, dtype=torch.int64).contiguous()
+                num = idx_last.numel()
+                if idx_next.numel() != num:
+                    raise L.MalError("image_synthesis: the two frames must hold the same number of matched instances")
             ml, mn = _as_u8(mask_last, dev), _as_u8(mask_next, dev)
             delta = torch.empty(num, 2, dtype=torch.int32, device=dev)
             flags = torch.empty(H, W, dtype=torch.uint8, device=dev)
@@ -111,10 +125,11 @@ class BatchSynthesisFn(Function):
             a.mask_last, a.mask_next, a.num = p(ml), p(mn), num
             a.img_last, a.img_next, a.ori_last, a.ori_next = p(cl[b]), p(cn[b]), p(syn_last[b]), p(syn_next[b])
             a.delta, a.flags, a.ws, a.ws_bytes = p(delta), p(flags), p(ws), ws.numel()
-            saved.append((b, ml, mn, num, delta, flags, ws))
+            a.idx_last, a.idx_next = p(idx_last), p(idx_next)
+            saved.append((b, ml, mn, num, delta, flags, ws, idx_last, idx_next))
         # all samples in one call: three launches (extents, displacements, synthesis) for up to 16 samples
         L.check(lib.mal_dyn_batch_fwd(arr, len(items), C, H, W, 1 if replace else 0, ops._stream()), "mal_dyn_batch_fwd")
-        ctx.saved, ctx.dims = saved, (C, H, W)
+        ctx.saved, ctx.dims, ctx.every = saved, (C, H, W), every
         return syn_last, syn_next
 
     @staticmethod
@@ -122,14 +137,16 @@ class BatchSynthesisFn(Function):
     def backward(ctx, g_last, g_next):
         C, H, W = ctx.dims
         g_last, g_next = g_last.contiguous(), g_next.contiguous()
-        gl, gn = g_last.clone(), g_next.clone()  # samples without instances: the identity
         if not ctx.saved:
-            return gl, gn, None, None
+            return g_last.clone(), g_next.clone(), None, None
+        # samples without instances: the identity (a copy); the kernel writes every pixel of the listed ones
+        gl, gn = (torch.empty_like(g_last), torch.empty_like(g_next)) if ctx.every else (g_last.clone(), g_next.clone())
         lib, p = L.load(), ops._p
         arr = (L.DynItem * len(ctx.saved))()
-        for k, (b, ml, mn, num, delta, flags, ws) in enumerate(ctx.saved):
+        for k, (b, ml, mn, num, delta, flags, ws, idx_last, idx_next) in enumerate(ctx.saved):
             a = arr[k]
             a.mask_last, a.mask_next, a.num, a.delta, a.flags = p(ml), p(mn), num, p(delta), p(flags)
+            a.idx_last, a.idx_next = p(idx_last), p(idx_next)
             a.g_ori_last, a.g_ori_next, a.g_img_last, a.g_img_next = p(g_last[b]), p(g_next[b]), p(gl[b]), p(gn[b])
         L.check(lib.mal_dyn_batch_bwd(arr, len(ctx.saved), C, H, W, ops._stream()), "mal_dyn_batch_bwd")
         return gl, gn, None, None
@@ -143,17 +160,27 @@ def image_synthesis(inputs, outputs, scale, thres, ins_model, matcher):
     instances = generate_instances(inputs[("color", 0, 0)], ins_model)
     color_last, color_next = outputs[("color", -1, scale)], outputs[("color", 1, scale)]
     items = []
+    confident = []
     for b in range(bs):
         cur = instances[b]["instances"]
         instances_cur = cur[cur.scores > thres]
-        if len(instances_cur) == 0:
-            continue
-        both = generate_instances(torch.stack([color_last[b].detach(), color_next[b].detach()], dim=0), ins_model)
+        if len(instances_cur) > 0:
+            confident.append((b, instances_cur))
+    # upstream stacks (warped last, warped next) of a sample for the segmenter, one small copy per sample (:139-140);
+    # here the pairs of the whole batch are laid out by ONE copy and the segmenter sees sample b's pair as a view
+    pairs = torch.stack([color_last.detach(), color_next.detach()], dim=1) if confident else None
+    for b, instances_cur in confident:
+        both = generate_instances(pairs[b], ins_model)
         ins_last, ins_next = both[0]["instances"], both[1]["instances"]
         slice_last, slice_next = matcher(ins_last, ins_next, instances_cur)
         if len(slice_last) + len(slice_next) == 0:
             continue
-        items.append((b, ins_last.pred_masks[slice_last].bool(), ins_next.pred_masks[slice_next].bool()))
+        if torch.is_tensor(slice_last) and torch.is_tensor(slice_next) and slice_last.dtype == torch.int64 \
+                and slice_next.dtype == torch.int64 and ins_last.pred_masks.dtype in (torch.bool, torch.uint8):
+            # the matcher's selections (index tensors) are applied inside the kernels: no gather launch per sample/frame
+            items.append((b, ins_last.pred_masks, ins_next.pred_masks, slice_last, slice_next))
+        else:
+            items.append((b, ins_last.pred_masks[slice_last].bool(), ins_next.pred_masks[slice_next].bool()))
     if not items:
         return False
     outputs[("syn", -1, scale)], outputs[("syn", 1, scale)] = BatchSynthesisFn.apply(color_last, color_next, items, False)

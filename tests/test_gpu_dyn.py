@@ -67,8 +67,11 @@ class _Instances:
         return _Instances(self.scores[sel], self.pred_masks[sel])
 
 
-def test_image_synthesis_control_flow():
-    """dyn_utils.py:121-170: samples without confident or matched instances keep their warped images."""
+@pytest.mark.parametrize("as_tensor", [False, True], ids=["list_selection", "index_tensor_selection"])
+def test_image_synthesis_control_flow(as_tensor):
+    """dyn_utils.py:121-170: samples without confident or matched instances keep their warped images.  The matcher's
+    selection arrives as Python lists (applied by torch indexing, as upstream) or as int64 index tensors (applied inside
+    the kernels: no gather launch per sample and frame)."""
     from mal_amd import dyn_utils
     from oracle import dyn_oracle as D
     from oracle.gen_golden_dyn import make_masks
@@ -89,7 +92,9 @@ def test_image_synthesis_control_flow():
 
     def matcher(ins_last, ins_next, cur):
         b = calls["b"]
-        return ([0, 2], [0, 2]) if b == 0 else ([], [])  # sample 2 has confident instances but no match
+        if b != 0:
+            return [], []  # sample 2 has confident instances but no match
+        return (torch.tensor([2, 0], device=DEV), torch.tensor([2, 0], device=DEV)) if as_tensor else ([2, 0], [2, 0])
 
     # image_synthesis calls generate_instances per sample in order; track which sample is being processed
     order = iter([0, 2])
@@ -112,7 +117,7 @@ def test_image_synthesis_control_flow():
     sl, sn = outputs[("syn", -1, 0)].detach().cpu(), outputs[("syn", 1, 0)].detach().cpu()
     for b in (1, 2):
         assert torch.equal(sl[b], color[-1][b].cpu()) and torch.equal(sn[b], color[1][b].cpu())
-    ml, mn = masks[0][0][[0, 2]], masks[0][1][[0, 2]]
+    ml, mn = masks[0][0][[2, 0]], masks[0][1][[2, 0]]
     rl, rn = color[-1][0].cpu().clone().requires_grad_(True), color[1][0].cpu().clone().requires_grad_(True)
     ol, on = D.generate_dynamic_instance(ml, mn, rl, rn, False)
     assert torch.equal(sl[0], ol.detach()) and torch.equal(sn[0], on.detach())
