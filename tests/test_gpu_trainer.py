@@ -75,12 +75,19 @@ def test_non_distil_losses_two_scales(fuse, no_ssim):
     for ref, got in ((ref_t, got_t), (ref_s, got_s)):
         assert set(ref) == set(got), (sorted(ref), sorted(got))
         for k, v in ref.items():
-            assert abs(float(got[k].detach()) - float(v)) <= 2e-4 * abs(float(v)) + 1e-6, (k, float(got[k].detach()), float(v))
+            # the masked mean sum(rp*m)/sum(m) moves by at most (rp_i + mean)/sum(m) <~ 1/(B*H*W) per automask pixel that
+            # sits at rounding distance of its threshold and takes the other side: two such pixels allowed here (the
+            # whole-step route is checked decision-exactly instead, tests/test_gpu_decisions.py)
+            tie = 2.0 / (B * H * W) if ("reproj" in k or k.startswith("loss")) else 0.0
+            assert abs(float(got[k].detach()) - float(v)) <= 2e-4 * abs(float(v)) + 1e-6 + tie, (k, float(got[k].detach()), float(v))
     for k in ("disp_teacher", "disp_student", "disp_lo"):
         g, r = hl[k].grad.cpu().numpy(), leaves[k].grad.numpy()
         # one near-tie pixel taking the other branch moves its own gradient, and through the bilinear
         # upsampling's adjoint up to 9 pixels of the half-resolution map
-        assert (np.abs(g - r) > 2e-4 * np.abs(r).max()).mean() <= (2e-2 if k == "disp_lo" else 5e-3), k
+        # ... and an automask pixel that flips rescales EVERY teacher gradient by sum(m)/(sum(m) +- 1): two flips over a
+        # mask that covers at least half of the pixels (renorm; the whole-step route forces the decisions instead)
+        renorm = 4.0 / (B * H * W)
+        assert (np.abs(g - r) > (2e-4 + renorm) * np.abs(r).max()).mean() <= (2e-2 if k == "disp_lo" else 5e-3), k
     for k in ("axisangle_m1", "translation_m1", "axisangle_p1", "translation_p1"):
         assert _l2rel(hl[k].grad.cpu().numpy(), leaves[k].grad.numpy()) <= 2e-2, k
 
