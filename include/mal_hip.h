@@ -404,6 +404,10 @@ void* mal_event_create(void);
 int mal_event_destroy(void* ev);
 int mal_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int mal_profile_next_pass(void* start, void* stop);
+/* Parity instrumentation for the operator-level fused pass (tests): the next mal_pass_fused call whose flags are
+ * GRAD|AUTOMASK|POSE_GRAD (no epilogue) or GRAD|EPILOGUE (no automask, no pose gradient) writes its per-pixel decisions
+ * into `planes` (MAL_DEC_PLANES x B*H*W uint32, MAL_DEC_* above; the smoothness planes stay untouched) -- one shot. */
+int mal_decisions_next_pass(uint32_t* planes);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ SIGNATURES = {
     "mal_event_destroy": (i32, [vp]),
     "mal_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
     "mal_profile_next_pass": (i32, [vp, vp]),
+    "mal_decisions_next_pass": (i32, [vp]),
 }
 
 class DynItem(C.Structure):

@@ -1003,6 +1003,7 @@ int g_march_rows = 0;  // output rows per wave task; 0 = pick so that one round 
 int g_pack_rows = 9;   // rows per task of the identity / packing sweep: 22 segments x 11 strips x 12 samples = 2904 tasks <= 3072 (three waves per SIMD); measured 9: 31.8 us, 12: 33.8 us
 int g_march_rows_fwd = 0;  // the same for the forward-only passes (<= 168 VGPRs: three waves per SIMD); 0 = automatic
 int g_debug = 0;
+unsigned* g_dec_next = nullptr;  // mal_decisions_next_pass: decision planes for the next instrumentable gradient pass
 extern int g_photo_impl;  // mal_photo_march.hip
 
 MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, float eps, int convention) {
@@ -1108,6 +1109,11 @@ int pack_identity_launch(const float* target, const float* src0, const float* sr
 
 using namespace mal;
 
+extern "C" int mal_decisions_next_pass(uint32_t* planes) {
+  g_dec_next = planes;
+  return MAL_OK;
+}
+
 extern "C" int mal_set_option(const char* name, int value) {
   if (!name) return MAL_EINVAL;
   auto eq = [&](const char* s) { const char* a = name; while (*a && *a == *s) { ++a; ++s; } return *a == *s; };
@@ -1184,6 +1190,10 @@ extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float
   p.cons_target = consistency_target; p.depth_out = depth_out; p.block_sums = w.block_sums; p.block_gP = w.block_gP;
   p.cam = w.cam;
   hipStream_t st = (hipStream_t)stream;
+  if (g_dec_next && grad && ((pose && automask && !epi) || (!pose && !automask && epi))) {
+    p.dbg = g_dec_next;  // one-shot (tests): the instrumented instantiation of the same kernel
+    g_dec_next = nullptr;
+  }
   rc = march_launch(p, flags, st);
   if (rc) return rc;
   return launch_pass_finalize(w.block_sums, w.block_gP, K, p.ntasks, p.strips * p.segs, B, sums,

@@ -313,6 +313,10 @@ def clear_packed_sources():
 
 
 # ------------------------------------------------------------------ the fused pass
+# tests set this to a list: every instrumentable fused gradient pass then appends its decision planes (MAL_DEC_*)
+DECISION_SINK = None
+
+
 def pass_fused(disp, K, inv_K, Ts, srcs, target, ident=None, noise=None, ext_mask=None, mono_depth=None,
                mono_reproj=None, ens_reproj=None, min_depth=0.1, max_depth=100.0, eps=1e-7, convention=0, flags=0,
                want_min=True, want_cons_target=False, want_depth=False, disp2=None, sample_scale=None):
@@ -338,6 +342,11 @@ def pass_fused(disp, K, inv_K, Ts, srcs, target, ident=None, noise=None, ext_mas
         srcs = [packed_source(s) for s in srcs]
         target = packed_source(target)
         flags |= L.F_SRC_PACKED | L.F_TGT_PACKED
+    if DECISION_SINK is not None and grad and ((pose and (flags & L.F_AUTOMASK) and not epi) or
+                                               (epi and not pose and not (flags & L.F_AUTOMASK))):
+        dec = torch.zeros((L.DEC_PLANES, B, H, W), dtype=torch.int32, device=dev)  # parity instrumentation (tests)
+        L.check(L.load().mal_decisions_next_pass(_p(dec)), "mal_decisions_next_pass")
+        DECISION_SINK.append(dec)
     L.check(L.load().mal_pass_fused(
         _p(disp), _p(disp2), _p(K), _p(inv_K), L.ptr_array([_p(t) for t in Ts]), L.ptr_array([_p(s) for s in srcs]),
         _p(target), _p(ident), _p(noise), _p(ext_mask), _p(sample_scale), _p(mono_depth), _p(mono_reproj), _p(ens_reproj), B, H, W, 2, min_depth,

@@ -567,13 +567,14 @@ def dr_default_opt(**kw):
     o = dict(height=192, width=640, batch_size=8, min_depth=0.1, max_depth=100.0, frame_ids=[0, -1, 1],
              scales=[0], n_losses=1, v1_multiscale=False, disable_automasking=False, no_ssim=False,
              disparity_smoothness=1e-3, avg_reprojection=False, disable_motion_masking=False,
-             Dstar_T0_pair=False)
+             Dstar_T0_pair=False, Tstar_D0_pair=False)
     o.update(kw)
     return SimpleNamespace(**o)
 
 
-def dr_generate_images_pred(opt, inputs, outputs, aten=True):
-    """dualrefine/trainer.py:395-451 (the debug prints at :452-455 are not behaviour)."""
+def dr_generate_images_pred(opt, inputs, outputs, aten=True, forced=None):
+    """dualrefine/trainer.py:395-451 (the debug prints at :452-455 are not behaviour).
+    ``forced`` (decision-forced parity tests): {(scale, it): {"taps": {f: (x0, y0, clipx, clipy)}, ...}}."""
     for scale in opt.scales:
         n = opt.n_losses + 1 if scale in (0, 1, 2) else 1
         for it in range(n):
@@ -597,14 +598,20 @@ def dr_generate_images_pred(opt, inputs, outputs, aten=True):
                 pts = backproject_depth(depth, inputs[("inv_K", 0)])
                 grid = project_3d(pts, inputs[("K", 0)], T, H, W, convention="dualrefine")
                 outputs[("sample", f, scale, it)] = grid
-                outputs[("color", f, scale, it)] = grid_sample_border(
-                    inputs[("color", f, 0)], grid, convention="dualrefine", aten=aten)
+                if forced is not None and (scale, it) in forced:
+                    outputs[("color", f, scale, it)] = AR.grid_sample_forced_taps(
+                        inputs[("color", f, 0)], grid, *forced[(scale, it)]["taps"][f], align_corners=False)
+                else:
+                    outputs[("color", f, scale, it)] = grid_sample_border(
+                        inputs[("color", f, 0)], grid, convention="dualrefine", aten=aten)
                 if not opt.disable_automasking:
                     outputs[("color_identity", f, scale, it)] = inputs[("color", f, 0)]
 
 
-def dr_compute_losses(opt, inputs, outputs, noises=None, aten=True):
-    """dualrefine/trainer.py:530-633 (the f_thres > 0 branch: per (scale, deq_iter))."""
+def dr_compute_losses(opt, inputs, outputs, noises=None, aten=True, forced=None):
+    """dualrefine/trainer.py:530-633 (the f_thres > 0 branch: per (scale, deq_iter)).
+    ``forced`` (decision-forced parity tests): {(scale, it): {"win", "automask", "l1"}} -- min over the two warped
+    candidates, automask comparison and L1 signs taken as given (avg_reprojection has no argmin to force)."""
     losses = {}
     total = 0
     k = 0
@@ -618,19 +625,22 @@ def dr_compute_losses(opt, inputs, outputs, noises=None, aten=True):
             color = inputs[("color", 0, scale)]
             target = inputs[("color", 0, 0)]
             fids = opt.frame_ids[1:]
-            R = torch.cat([compute_reprojection_loss(outputs[("color", f, scale, it)], target, opt.no_ssim, aten)
-                           for f in fids], 1)
+            fd = None if forced is None else forced.get((scale, it))
+            R = torch.cat([compute_reprojection_loss(outputs[("color", f, scale, it)], target, opt.no_ssim, aten,
+                                                     None if fd is None else fd.get("l1")) for f in fids], 1)
             ident = None
             if not opt.disable_automasking:
                 I = torch.cat([compute_reprojection_loss(inputs[("color", f, 0)], target, opt.no_ssim, aten)
                                for f in fids], 1)
                 ident = I.mean(1, keepdim=True) if opt.avg_reprojection else torch.min(I, dim=1, keepdim=True)[0]
             rp = R.mean(1, keepdim=True) if opt.avg_reprojection else torch.min(R, dim=1, keepdim=True)[0]
+            if fd is not None and not opt.avg_reprojection:
+                rp = torch.gather(R, 1, fd["win"])
             if not opt.disable_automasking:
                 nz = None if noises is None else noises[k]
                 ident = ident + _draw_noise(ident.shape, nz) * 0.00001
             k += 1
-            mask = compute_loss_masks(rp, ident)
+            mask = compute_loss_masks(rp, ident) if fd is None else fd["automask"].to(rp.dtype)
             if it > 0:
                 if not opt.disable_motion_masking:
                     mask = mask * outputs["consistency_mask"]
@@ -651,3 +661,39 @@ def dr_compute_losses(opt, inputs, outputs, noises=None, aten=True):
             losses["loss/{}_{}".format(scale, it)] = loss
     losses["loss"] = total / len(opt.scales)
     return losses
+
+
+def dr_pose_update_generate_images_pred(opt, inputs, outputs, aten=True):
+    """dualrefine/trainer.py:457-480: frame -1 warped once more with the refined pose ``("cam_T_cam", 0, -1, 1)`` and the
+    last iteration's depth (the iteration-0 depth, detached, with --Tstar_D0_pair).  The debug prints and ``exit(0)`` of
+    :481-484 are not behaviour."""
+    if getattr(opt, "Tstar_D0_pair", False):
+        depth = outputs[("depth", 0, 0, 0)].clone().detach()
+    else:
+        depth = outputs[("depth", 0, 0, opt.n_losses)]
+    H, W = depth.shape[-2:]
+    pts = backproject_depth(depth, inputs[("inv_K", 0)])
+    grid = project_3d(pts, inputs[("K", 0)], outputs[("cam_T_cam", 0, -1, 1)], H, W, convention="dualrefine")
+    outputs[("color", -1, 0, 0, 1)] = grid_sample_border(inputs[("color", -1, 0)], grid, convention="dualrefine", aten=aten)
+
+
+def dr_compute_pose_update_losses(opt, inputs, outputs, noise=None, aten=True):
+    """dualrefine/trainer.py:699-767: min (or mean, --avg_reprojection) over {frame -1 under the refined pose,
+    frame +1 of iteration 0}, automask against the raw sources, masked mean; no smoothness / consistency term."""
+    target = inputs[("color", 0, 0)]
+    R = []
+    for f in opt.frame_ids[1:]:
+        pred = outputs[("color", -1, 0, 0, 1)] if f == -1 else outputs[("color", f, 0, 0)]
+        R.append(compute_reprojection_loss(pred, target, opt.no_ssim, aten))
+    R = torch.cat(R, 1)
+    ident = None
+    if not opt.disable_automasking:
+        I = torch.cat([compute_reprojection_loss(inputs[("color", f, 0)], target, opt.no_ssim, aten)
+                       for f in opt.frame_ids[1:]], 1)
+        ident = I.mean(1, keepdim=True) if opt.avg_reprojection else torch.min(I, dim=1, keepdim=True)[0]
+    rp = R.mean(1, keepdim=True) if opt.avg_reprojection else torch.min(R, dim=1, keepdim=True)[0]
+    if not opt.disable_automasking:
+        ident = ident + _draw_noise(ident.shape, noise) * 0.00001
+    mask = compute_loss_masks(rp, ident)
+    reproj = (rp * mask).sum() / (mask.sum() + 1e-7)
+    return {"reproj_loss/pose_0": reproj, "loss/pose_0_0": reproj, "loss": reproj}

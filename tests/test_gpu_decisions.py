@@ -228,3 +228,107 @@ def test_decisions_do_not_change_results():
         assert c["losses"][k] == v, k
     for k, v in a["grads"].items():
         assert np.array_equal(c["grads"][k], v), k
+
+
+# ------------------------------------------------------------------ a17: DualRefine's loss loops (operator-level route)
+def _dr_build(batch, dev, pose_fn, dtype=torch.float32):
+    mv = lambda t: (t.to(dtype) if t.is_floating_point() else t).to(dev).contiguous()
+    inputs = {("color", f, 0): mv(batch[k]) for f, k in ((0, "color0"), (-1, "color_m1"), (1, "color_p1"))}
+    inputs[("K", 0)], inputs[("inv_K", 0)] = mv(batch["K"]), mv(batch["inv_K"])
+    leaves = {k: mv(batch[k]).clone().requires_grad_(True) for k in HH.LEAVES}
+    T_m1 = pose_fn(leaves["axisangle_m1"], leaves["translation_m1"], True)
+    T_p1 = pose_fn(leaves["axisangle_p1"], leaves["translation_p1"], False)
+    outputs = {("disp", 0, 0): leaves["disp_teacher"], ("disp", 0, 1): leaves["disp_student"],
+               ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1, ("cam_T_cam", 0, -1, 1): T_m1 * 1.0,
+               "consistency_mask": mv(batch["consistency_mask"]).unsqueeze(1)}
+    return inputs, outputs, leaves
+
+
+def _dr_oracle(batch, kw, noises, forced=None, dtype=torch.float32):
+    from oracle import mal_oracle as O
+    inputs, outputs, leaves = _dr_build(batch, "cpu", O.transformation_from_parameters, dtype)
+    opt = O.dr_default_opt(**kw)
+    O.dr_generate_images_pred(opt, inputs, outputs, forced=forced)
+    ref = O.dr_compute_losses(opt, inputs, outputs, noises=[n.clone().to(dtype) for n in noises], forced=forced)
+    ref["loss"].backward()
+    return ref, {k: t.grad.numpy() for k, t in leaves.items()}, inputs, outputs
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 72), (8, 192, 640)], ids=["b2_40x72", "b8_192x640"])
+def test_dualrefine_decision_exact(shape):
+    """a17 (dualrefine/trainer.py:395-451,530-633; BASELINE.json configs[4] = B=8 192x640): the two (scale 0, deq_iter)
+    passes run through mal_pass_fused; their decisions are exported (mal_decisions_next_pass) and forced on the oracle's
+    restatement of the same lines -- every leaf then agrees at 1e-4 / the fp32 oracle's own distance from exact."""
+    from mal_amd import dualrefine, layers, ops
+    from mal_amd.synthetic import make_batch
+    from oracle import aten_restated as AR
+    B, H, W = shape
+    N = B * H * W
+    batch = make_batch(B, H, W, seed=321)
+    torch.manual_seed(5)
+    noises = [torch.randn(B, 1, H, W) for _ in range(2)]
+    kw = dict(height=H, width=W, batch_size=B, n_losses=1)
+    inputs, outputs, gl = _dr_build(batch, "cuda:0", layers.transformation_from_parameters)
+    lp = dualrefine.DualRefineLossPath(dualrefine.default_options(**kw), fuse=True)
+    ops.DECISION_SINK = []
+    try:
+        lp.generate_images_pred(inputs, outputs)
+        got = lp.compute_losses(inputs, outputs, noises=[n.to("cuda:0") for n in noises])
+        got["loss"].backward()
+        torch.cuda.synchronize()
+        sink = [d.cpu() for d in ops.DECISION_SINK]
+    finally:
+        ops.DECISION_SINK = None
+    assert len(sink) == 2, len(sink)  # (scale 0, iteration 0) and (scale 0, iteration 1)
+
+    def decode(d):
+        def taps(pl):
+            pl = pl.long()
+            return pl & 0xfff, (pl >> 12) & 0xfff, ((pl >> 24) & 1).bool(), ((pl >> 25) & 1).bool()
+        return dict(win=(d[0].long() & 3)[:, None], automask=((d[0].long() >> 2) & 1).float()[:, None],
+                    taps={-1: taps(d[4]), 1: taps(d[5])},
+                    l1=torch.stack([((d[6].long() >> s) & 3) - 1 for s in (0, 2, 4)], 1).float())
+    forced = {(0, it): decode(sink[it]) for it in (0, 1)}
+    # ---- the kernels' decisions against the free-running oracle's: a handful of pixels
+    ref, gref, oin, oout = _dr_oracle(batch, kw, noises)
+    counts = {}
+    for it in (0, 1):
+        for f in (-1, 1):
+            mine = AR.taps_of(oout[("sample", f, 0, it)], H, W, align_corners=False)
+            diff = None
+            for u, v in zip(forced[(0, it)]["taps"][f], mine):
+                diff = (u != v) if diff is None else (diff | (u != v))
+            counts[("tap", it, f)] = int(diff.sum())
+        from oracle import mal_oracle as O
+        R = torch.cat([O.compute_reprojection_loss(oout[("color", f, 0, it)], oin[("color", 0, 0)]) for f in (-1, 1)], 1)
+        counts[("win", it)] = int((R.argmin(1, keepdim=True) != forced[(0, it)]["win"]).sum())
+    assert all(v <= 3e-4 * N + 8 for v in counts.values()), counts
+    # ---- same decisions on both sides
+    f32, g32, _, _ = _dr_oracle(batch, kw, noises, forced=forced)
+    f64, g64, _, _ = _dr_oracle(batch, kw, noises, forced=_to64(forced), dtype=torch.float64)
+    for k, v in f32.items():
+        assert abs(float(got[k].detach()) - float(v)) <= 2e-5 * abs(float(v)), (k, float(got[k].detach()), float(v))
+    for key in HH.LEAVES:
+        g, r32, r64 = gl[key].grad.cpu().numpy(), g32[key], g64[key]
+        tol = max(1e-4, 1.25 * _l2rel(r32, r64))
+        assert _l2rel(g, r64) <= tol, (key, _l2rel(g, r64), _l2rel(r32, r64))
+        if key.startswith("disp"):
+            sc = np.abs(r64).max()
+            tol_px = max(1e-4, 1.25 * np.abs(r32 - r64).max() / sc)
+            amb = HH.smooth_sign_ambiguous(batch[key].numpy())  # the operator route's smoothness kernel exports no signs
+            worst = (np.abs(g - r64) * ~amb).max() / sc
+            assert worst <= tol_px, (key, worst, tol_px)
+    # ---- the pose-update losses (dualrefine/trainer.py:457-480,699-767; materialised candidates, free-running)
+    torch.manual_seed(6)
+    nz = torch.randn(B, 1, H, W)
+    from oracle import mal_oracle as O
+    oopt = O.dr_default_opt(**kw)
+    O.dr_pose_update_generate_images_pred(oopt, oin, oout)
+    rp = O.dr_compute_pose_update_losses(oopt, oin, oout, noise=nz.clone())
+    lp.pose_update_generate_images_pred(inputs, outputs)
+    gp = lp.compute_pose_update_losses(inputs, outputs, noise=nz.to("cuda:0"))
+    assert set(gp) == set(rp)
+    # the warped image is continuous in the sampling position, which two fp32 evaluations place a few ulp of ~600 apart
+    assert np.abs(outputs[("color", -1, 0, 0, 1)].detach().cpu().numpy() - oout[("color", -1, 0, 0, 1)].detach().numpy()).max() <= 5e-5
+    for k, v in rp.items():  # two automask pixels at rounding distance of their threshold allowed (see test_gpu_trainer.py)
+        assert abs(float(gp[k].detach()) - float(v)) <= 1e-4 * abs(float(v)) + 2.0 / N, (k, float(gp[k].detach()), float(v))
