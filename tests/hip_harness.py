@@ -22,7 +22,10 @@ def run_oracle(batch, opt_kw, n0, n1, w_list=(0.7, 0.3), forced=None):
     # maps the tests need for tie analysis
     with torch.no_grad():
         target = inputs[("color", 0, 0)]
-        R = torch.cat([O.compute_reprojection_loss(outputs[("color", f, 0)], target) for f in (-1, 1)], 1)
+        multi_pred = [outputs[("color", f, 0)] for f in (-1, 1)]
+        if ("syn", -1, 0) in outputs and opt.main_temporal:
+            multi_pred += [outputs[("syn", f, 0)] for f in (-1, 1)]
+        R = torch.cat([O.compute_reprojection_loss(c, target) for c in multi_pred], 1)
         mono_pred = [mono_outputs[("color", f, 0)] for f in (-1, 1)]
         if ("syn", -1, 0) in mono_outputs and opt.temporal:  # the teacher's four candidates (loss_utils.py:79-90)
             mono_pred += [mono_outputs[("syn", f, 0)] for f in (-1, 1)]
@@ -227,10 +230,18 @@ def smooth_sign_ambiguous(disp, rel=4e-7):
     return amb
 
 
-def near_tie(maps, tol):
-    """pixels where the smallest two of the stacked (B,K,H,W) maps are within tol (relative)."""
+def near_tie(maps, tol, distinct=False):
+    """pixels where the smallest two of the stacked (B,K,H,W) maps are within tol (relative).  ``distinct``: candidates
+    that are EXACTLY equal count as one (the temporal hint's synthesised image equals the warped one wherever no
+    instance moved: whichever of the two is reported as the winner, the gradient reaches the same pixels)."""
     s = np.sort(maps, axis=1)
-    return (np.abs(s[:, 1:2] - s[:, 0:1]) <= tol * np.maximum(np.abs(s[:, 0:1]), 1e-3))
+    if not distinct:
+        return (np.abs(s[:, 1:2] - s[:, 0:1]) <= tol * np.maximum(np.abs(s[:, 0:1]), 1e-3))
+    gap = np.full(s[:, 0:1].shape, np.inf)
+    for k in range(s.shape[1] - 1, 0, -1):
+        g = s[:, k:k + 1] - s[:, 0:1]
+        gap = np.where(g > 0, g, gap)
+    return gap <= tol * np.maximum(np.abs(s[:, 0:1]), 1e-3)
 
 
 def sample_ambiguous(sample, H, W, tol=5e-4):

@@ -79,16 +79,14 @@ def _check_case(tag, fuse, full):
 
     # ---- per-pixel disparity gradients outside the near-tie pixels
     idn = o["ident"] + n0.numpy() * np.float32(1e-5)
-    amb_t = HH.dilate3(HH.near_tie(o["mono_cands"], 2e-4) | (np.abs(o["mono_reproj"] - idn) <= 1e-4))
+    amb_t = HH.dilate3(HH.near_tie(o["mono_cands"], 2e-4, distinct=temporal) | (np.abs(o["mono_reproj"] - idn) <= 1e-4))
     amb_t |= HH.sample_ambiguous(o["mono_sample"], H, W)
-    amb_s = HH.dilate3(HH.near_tie(o["multi_cands"], 2e-4)) | HH.sample_ambiguous(o["multi_sample"], H, W) | amb_distil
+    amb_s = HH.dilate3(HH.near_tie(o["multi_cands"], 2e-4, distinct=temporal)) | HH.sample_ambiguous(o["multi_sample"], H, W) | amb_distil
     amb_s |= np.abs(o["mono_depth"] - o["multi_depth"]) <= 1e-6 * np.abs(o["mono_depth"])
     if kw.get("dual_distil"):  # the teacher's depth then also receives the distillation gradient
         amb_t |= amb_distil
-    if temporal:  # the synthesised candidates add their own ties; only aggregate checks below
-        amb_t[:] = True
-        if kw.get("main_temporal"):
-            amb_s[:] = True
+    if temporal:  # the synthesised candidates add their own ties (exactly equal candidates count as one)
+        amb_t |= HH.dilate3(HH.near_tie(o["mono_cands"], 2e-4, distinct=True))
     for key, amb in (("disp_teacher", amb_t), ("disp_student", amb_s)):
         g, r = h["grads"][key], o["grads"][key]
         sc = np.abs(r).max()
@@ -97,7 +95,7 @@ def _check_case(tag, fuse, full):
             err = np.abs(g - r)[good]
             tol = 2e-4 + (renorm if key == "disp_teacher" else 0.0)
             assert (err > tol * sc).mean() <= 2e-5, (key, err.max() / sc, (err > tol * sc).mean())
-        assert amb.mean() <= 0.05 or temporal, (key, "near-tie fraction", amb.mean())
+        assert amb.mean() <= 0.05, (key, "near-tie fraction", amb.mean())
 
     # ---- summed gradients: never further from the fp32 reference than it is from fp64
     # (per-pixel leaves: over the pixels outside the near-tie set, where one flipped branch cannot
