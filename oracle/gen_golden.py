@@ -207,6 +207,110 @@ def run_reference_step(ML, MLU, q, opt_kw, noise_seed, full, tag):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", "final_loss", d["final_loss"])
 
 
+def multiscale_inputs(q, sclm):
+    """the per-scale inputs of the sclm>0 path derived from a quantised batch: ("color", 0, s) = the target pooled by
+    2**s (mono_dataset.py:150-166 resizes; pooling keeps the fixture self-contained) and per-scale disparities =
+    the full-resolution ones pooled and rounded to fp16 (exactly representable on disk)"""
+    color = {s: F.avg_pool2d(q["color0"], 2 ** s) for s in range(1, sclm + 1)}
+    disp = {name: {s: F.avg_pool2d(q[name], 2 ** s).half().float() for s in range(1, sclm + 1)}
+            for name in ("disp_teacher", "disp_student")}
+    return color, disp
+
+
+def run_reference_multiscale(ML, MLU, q, sclm, noise_seed, tag):
+    """The non-distillation ``Trainer.compute_losses`` over ``sclm+1`` disparity scales for both networks
+    (manydepth/trainer.py:1078-1170 per-scale upsample + warp, :1248-1475 per-scale loss / 2**scale, total / (sclm+1)):
+    the glue restated here, every arithmetic step through the reference's own objects (``SSIM``,
+    ``compute_reprojection_loss``, ``compute_loss_masks``, ``get_smooth_loss``, ``disp_to_depth``, ``BackprojectDepth``,
+    ``Project3D``) and ATen's ``interpolate`` / ``grid_sample``."""
+    from mal_amd.synthetic import to_dicts
+    from oracle.mal_oracle import default_opt
+    B, _, H, W = q["color0"].shape
+    opt = default_opt(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+    inputs, mono_outputs, outputs, leaves = to_dicts(q, ML.transformation_from_parameters)
+    color_s, disp_s = multiscale_inputs(q, sclm)
+    for s in range(1, sclm + 1):
+        inputs[("color", 0, s)] = color_s[s]
+        for name, outs in (("disp_teacher", mono_outputs), ("disp_student", outputs)):
+            leaf = disp_s[name][s].clone().requires_grad_(True)
+            leaves["%s_s%d" % (name, s)] = leaf
+            outs[("disp", s)] = leaf
+    ssim = ML.SSIM()
+    backproject, project = ML.BackprojectDepth(B, H, W), ML.Project3D(B, H, W)
+
+    def gen_pred(outs, is_multi):  # trainer.py:1088-1125, not v1_multiscale: every scale is warped at full resolution
+        for scale in range(sclm + 1):
+            disp = F.interpolate(outs[("disp", scale)], [H, W], mode="bilinear", align_corners=False)
+            _, depth = ML.disp_to_depth(disp, opt.min_depth, opt.max_depth)
+            outs[("depth", 0, scale)] = depth
+            for f in (-1, 1):
+                T = outs[("cam_T_cam", 0, f)]
+                if is_multi:
+                    T = T.detach()
+                pts = backproject(depth, inputs[("inv_K", 0)])
+                grid = project(pts, inputs[("K", 0)], T)
+                outs[("color", f, scale)] = F.grid_sample(inputs[("color", f, 0)], grid, padding_mode="border",
+                                                          align_corners=True)
+
+    def losses_of(outs, is_multi, noises):  # trainer.py:1248-1475
+        losses, total = {}, 0
+        target = inputs[("color", 0, 0)]
+        for scale in range(sclm + 1):
+            disp, color = outs[("disp", scale)], inputs[("color", 0, scale)]
+            R = torch.cat([MLU.compute_reprojection_loss(ssim, outs[("color", f, scale)], target) for f in (-1, 1)], 1)
+            I = torch.cat([MLU.compute_reprojection_loss(ssim, inputs[("color", f, 0)], target) for f in (-1, 1)], 1)
+            ident, _ = torch.min(I, dim=1, keepdim=True)
+            rp, _ = torch.min(R, dim=1, keepdim=True)
+            ident = ident + noises[scale] * 0.00001
+            mask = MLU.compute_loss_masks(rp, ident)
+            cons = 0
+            if is_multi:
+                mask = torch.ones_like(mask)
+                mask = mask * outs["consistency_mask"].unsqueeze(1)
+                mask = mask * (1 - outs["augmentation_mask"][:B])
+                cmask = (1 - mask).float()
+            reproj = (rp * mask).sum() / (mask.sum() + 1e-7)
+            if is_multi:
+                multi_depth, mono_depth = outs[("depth", 0, scale)], outs[("mono_depth", 0, scale)].detach()
+                cons = (torch.abs(multi_depth - mono_depth) * cmask).mean()
+                losses["consistency_loss/%d" % scale] = cons
+            losses["reproj_loss/%d" % scale] = reproj
+            loss = reproj + cons
+            mean_disp = disp.mean(2, True).mean(3, True)
+            loss = loss + opt.disparity_smoothness * ML.get_smooth_loss(disp / (mean_disp + 1e-7), color) / (2 ** scale)
+            total = total + loss
+            losses["loss/%d" % scale] = loss
+        losses["loss"] = total / (sclm + 1)
+        return losses
+
+    torch.manual_seed(noise_seed)
+    noises_t = [torch.randn(B, 1, H, W) for _ in range(sclm + 1)]
+    noises_s = [torch.randn(B, 1, H, W) for _ in range(sclm + 1)]  # drawn upstream too; dead for the student's value
+    gen_pred(mono_outputs, False)
+    lt = losses_of(mono_outputs, False, noises_t)
+    for key in list(mono_outputs.keys()):
+        if isinstance(key, tuple) and key[0] in ("depth", "disp"):
+            outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
+    gen_pred(outputs, True)
+    ls = losses_of(outputs, True, noises_s)
+    (lt["loss"] + ls["loss"]).backward()
+    d = {"in/noise_seed": np.int64(noise_seed), "sclm": np.int64(sclm)}
+    for k, v in lt.items():
+        d["teacher/" + k] = np.float64(v.item())
+    for k, v in ls.items():
+        d["student/" + k] = np.float64(v.item())
+    for k, t in leaves.items():
+        d["grad/" + k] = (t.grad if t.grad is not None else torch.zeros_like(t)).numpy()
+    for s in range(1, sclm + 1):
+        for name in ("disp_teacher", "disp_student"):
+            d["in/%s_s%d" % (name, s)] = disp_s[name][s].half().numpy()
+    d.update(pack_inputs(q))
+    d["opt"] = np.array(repr(sorted({"sclm": sclm, "distil": False}.items())))
+    path = os.path.join(OUT, tag + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", "teacher", d["teacher/loss"], "student", d["student/loss"])
+
+
 def run_reference_layers(ML, MLU, DL, tag, B=2, H=24, W=40, seed=77):
     from mal_amd.synthetic import make_batch
     q = quantize_batch(make_batch(B, H, W, seed))
@@ -292,6 +396,7 @@ def main():
     run_reference_step(ML, MLU, ragged, {}, 1006, True, "step_b3_37x50_distil")
     big = quantize_batch(make_batch(2, 192, 640, seed=1234))
     run_reference_step(ML, MLU, big, {}, 2000, False, "step_b2_192x640_distil")
+    run_reference_multiscale(ML, MLU, quantize_batch(make_batch(2, 48, 96, seed=1237)), 3, 1007, "multiscale_b2_48x96_sclm3")
 
 
 if __name__ == "__main__":

@@ -36,6 +36,30 @@ def batch_from_golden(z):
     return b
 
 
+MULTISCALE_CASE = "multiscale_b2_48x96_sclm3"
+
+
+def multiscale_dicts(z, pose_fn, device="cpu"):
+    """the sclm>0 fixture (oracle/gen_golden.py run_reference_multiscale) as the reference's dicts: per-scale disparities
+    for both networks (leaves), ("color", 0, s) = the target pooled by 2**s"""
+    from mal_amd.synthetic import to_dicts
+    b = batch_from_golden(z)
+    sclm = int(z["sclm"])
+    inputs, mono_outputs, outputs, leaves = to_dicts(b, pose_fn, device=device)
+    for s in range(1, sclm + 1):
+        inputs[("color", 0, s)] = torch.nn.functional.avg_pool2d(b["color0"], 2 ** s).to(device)
+        for name, outs in (("disp_teacher", mono_outputs), ("disp_student", outputs)):
+            leaf = torch.from_numpy(z["in/%s_s%d" % (name, s)].astype(np.float32)).to(device).requires_grad_(True)
+            leaves["%s_s%d" % (name, s)] = leaf
+            outs[("disp", s)] = leaf
+    return b, sclm, inputs, mono_outputs, outputs, leaves
+
+
+def multiscale_noises(z, shape, sclm):
+    torch.manual_seed(int(z["in/noise_seed"]))
+    return [torch.randn(shape) for _ in range(sclm + 1)], [torch.randn(shape) for _ in range(sclm + 1)]
+
+
 def opt_kwargs(z):
     return dict(ast.literal_eval(str(z["opt"])))
 

@@ -117,3 +117,102 @@ def test_generate_images_pred_dictionary_contract():
     O.generate_images_pred(O.default_opt(height=H, width=W, batch_size=B), oin, oout)
     assert np.abs(mono_outputs[("color", 1, 0)].detach().cpu().numpy() - oout[("color", 1, 0)].detach().numpy()).max() <= 1e-5
     assert np.abs(mono_outputs[("depth", 0, 0)].detach().cpu().numpy() / oout[("depth", 0, 0)].detach().numpy() - 1).max() <= 1e-6
+
+
+def _run_multiscale(inputs, mono_outputs, outputs, leaves, opt_kw, nt, ns, hip, fuse=True):
+    """both networks' compute_losses over sclm+1 scales (trainer.py:573-612 with not opt.distil), backward of the sum"""
+    if hip:
+        from mal_amd import trainer, config
+        lp = trainer.LossPath(trainer.default_options(**opt_kw), fuse=fuse)
+        old = config.noise_source
+        config.noise_source = "given"
+        try:
+            lp.generate_images_pred(inputs, mono_outputs)
+            lt, _ = lp.compute_losses(inputs, mono_outputs, is_multi=False, noises=[n.to(DEV) for n in nt])
+            for key in list(mono_outputs.keys()):
+                if isinstance(key, tuple) and key[0] in ("depth", "disp"):
+                    outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
+            lp.generate_images_pred(inputs, outputs, is_multi=True)
+            ls, _ = lp.compute_losses(inputs, outputs, is_multi=True)
+        finally:
+            config.noise_source = old
+    else:
+        opt = O.default_opt(**opt_kw)
+        O.generate_images_pred(opt, inputs, mono_outputs)
+        lt = O.compute_losses(opt, inputs, mono_outputs, is_multi=False, noises=[n.clone() for n in nt])
+        for key in list(mono_outputs.keys()):
+            if isinstance(key, tuple) and key[0] in ("depth", "disp"):
+                outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
+        O.generate_images_pred(opt, inputs, outputs, is_multi=True)
+        ls = O.compute_losses(opt, inputs, outputs, is_multi=True, noises=[n.clone() for n in ns])
+    (lt["loss"] + ls["loss"]).backward()
+    return lt, ls
+
+
+@pytest.mark.parametrize("fuse", [True, False], ids=["fused", "explicit"])
+def test_four_scales_against_the_reference_fixture(fuse):
+    """sclm=3 (BASELINE configs[1]'s "4 scales"): the fixture holds the reference's own numbers for both networks'
+    compute_losses over four disparity scales (oracle/gen_golden.py run_reference_multiscale)"""
+    from mal_amd import layers
+    from tests import golden_io as G
+    z = G.load(G.MULTISCALE_CASE)
+    b, sclm, inputs, mono_outputs, outputs, leaves = G.multiscale_dicts(z, layers.transformation_from_parameters, DEV)
+    B, _, H, W = b["color0"].shape
+    nt, ns = G.multiscale_noises(z, (B, 1, H, W), sclm)
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+    lt, ls = _run_multiscale(inputs, mono_outputs, outputs, leaves, kw, nt, ns, hip=True, fuse=fuse)
+    N = B * H * W
+    for who, d in (("teacher", lt), ("student", ls)):
+        for k, v in d.items():
+            ref = float(z["%s/%s" % (who, k)])
+            # an automask pixel at rounding distance of its threshold moves a masked mean by <~ 1/N: two allowed per scale
+            tie = 2.0 * (sclm + 1) / N if (who == "teacher" and ("reproj" in k or k.startswith("loss"))) else 0.0
+            assert abs(float(v.detach()) - ref) <= 2e-4 * abs(ref) + 1e-6 + tie, (who, k, float(v.detach()), ref)
+    renorm = 4.0 / N
+    for k, t in leaves.items():
+        g, r = t.grad.cpu().numpy(), z["grad/" + k].reshape(t.shape)
+        if g.ndim == 4:
+            bad = (np.abs(g - r) > (2e-4 + renorm) * np.abs(r).max()).mean()
+            assert bad <= (2e-2 if k[-1].isdigit() else 5e-3), (k, bad)
+        else:
+            assert _l2rel(g, r) <= 2e-2, k
+
+
+def test_four_scales_at_baseline_size():
+    """B=12 192x640, sclm=3 against the oracle (whose glue the fixture above pins)"""
+    from mal_amd import layers
+    B, H, W, sclm = 12, 192, 640, 3
+    batch = make_batch(B, H, W, seed=79)
+    g = torch.Generator().manual_seed(12)
+    nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
+    ns = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+
+    def build(dev, pose_fn):
+        inputs, mono_outputs, outputs, leaves = to_dicts(batch, pose_fn, device=dev)
+        for s in range(1, sclm + 1):
+            inputs[("color", 0, s)] = torch.nn.functional.avg_pool2d(batch["color0"], 2 ** s).to(dev)
+            for name, outs in (("disp_teacher", mono_outputs), ("disp_student", outputs)):
+                leaf = torch.nn.functional.avg_pool2d(batch[name], 2 ** s).to(dev).clone().requires_grad_(True)
+                leaves["%s_s%d" % (name, s)] = leaf
+                outs[("disp", s)] = leaf
+        return inputs, mono_outputs, outputs, leaves
+
+    oi, om, oo, ol = build("cpu", O.transformation_from_parameters)
+    rt, rs = _run_multiscale(oi, om, oo, ol, kw, nt, ns, hip=False)
+    hi, hm, ho, hl = build(DEV, layers.transformation_from_parameters)
+    lt, ls = _run_multiscale(hi, hm, ho, hl, kw, nt, ns, hip=True)
+    N = B * H * W
+    for ref, got, who in ((rt, lt, "teacher"), (rs, ls, "student")):
+        assert set(ref) == set(got)
+        for k, v in ref.items():
+            tie = 40.0 * (sclm + 1) / N if (who == "teacher" and ("reproj" in k or k.startswith("loss"))) else 0.0
+            assert abs(float(got[k].detach()) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + tie, (who, k, float(got[k].detach()), float(v))
+    for k in hl:
+        gq, r = hl[k].grad.cpu().numpy(), ol[k].grad.numpy()
+        if gq.ndim == 4:  # near-tie pixels (a few tens per 1.5 M, tests/test_gpu_decisions.py) and their neighbourhoods
+            bad = (np.abs(gq - r) > 3e-4 * np.abs(r).max()).mean()
+            sc = int(k[-1]) if k[-1].isdigit() else 0  # a pixel of scale s collects the gradient of 4**s full-resolution pixels
+            assert bad <= 1e-3 * (1 + 4 ** sc / 8.0), (k, bad)
+        else:
+            assert _l2rel(gq, r) <= 2e-2, (k, _l2rel(gq, r))

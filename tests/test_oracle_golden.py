@@ -116,6 +116,32 @@ def test_step_against_reference(tag):
         G.assert_close(r["loss_list"][1].item(), z["loss_list1"], 0)
 
 
+def test_multiscale_compute_losses_against_reference():
+    """sclm=3 (BASELINE configs[1]'s "4 scales"): the non-distillation compute_losses of both networks over four disparity
+    scales (manydepth/trainer.py:1088-1125,1248-1475) -- per-scale upsample + warp, loss / 2**scale, total / (sclm+1) --
+    reproduces the fixture generated through the reference's own SSIM / compute_reprojection_loss / compute_loss_masks /
+    get_smooth_loss / geometry objects, bit for bit."""
+    z = G.load(G.MULTISCALE_CASE)
+    b, sclm, inputs, mono_outputs, outputs, leaves = G.multiscale_dicts(z, O.transformation_from_parameters)
+    B, _, H, W = b["color0"].shape
+    nt, ns = G.multiscale_noises(z, (B, 1, H, W), sclm)
+    opt = O.default_opt(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+    O.generate_images_pred(opt, inputs, mono_outputs)
+    lt = O.compute_losses(opt, inputs, mono_outputs, is_multi=False, noises=nt)
+    for key in list(mono_outputs.keys()):
+        if isinstance(key, tuple) and key[0] in ("depth", "disp"):
+            outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
+    O.generate_images_pred(opt, inputs, outputs, is_multi=True)
+    ls = O.compute_losses(opt, inputs, outputs, is_multi=True, noises=ns)
+    (lt["loss"] + ls["loss"]).backward()
+    for who, d in (("teacher", lt), ("student", ls)):
+        for k, v in d.items():
+            G.assert_close(v.item(), z["%s/%s" % (who, k)], 0, who + "/" + k)
+    for k, t in leaves.items():
+        g = t.grad if t.grad is not None else torch.zeros_like(t)
+        G.assert_close(g, z["grad/" + k], 0, "grad/" + k)
+
+
 def test_step_full_size_against_reference():
     z = G.load(G.BIG_CASE)
     B, _, H, W = z["in/color0"].shape
