@@ -1,0 +1,74 @@
+"""GPU, two ranks on ONE card over gloo: the data-parallel contract of SURVEY.md 8e driven through the real training
+step (mal_amd.harness.TrainHarness.train_step: RepDepth networks -> HIP loss step -> backward into the flat gradient
+bucket -> one all-reduce -> Adam).  Identical per-rank batches must leave every rank with the gradients a single process
+computes; distinct batches with the mean of the per-rank gradients (manydepth/trainer.py:309-311,469: DDP averages)."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, same_batch, out_dir):
+    import random
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mal_amd import harness
+        dev = torch.device("cuda:0")  # both ranks share the card (gloo moves the bucket through the host)
+        torch.manual_seed(0)
+        random.seed(0)
+        # no random matching augmentation / pose dropout: ranks must run the same computation on the same data
+        opt = harness.default_options(batch_size=2, height=64, width=128, no_matching_augmentation=True)
+        h = harness.TrainHarness(opt, dev)
+        inputs = harness.synthetic_inputs(opt, dev, seed=11 if same_batch else 11 + rank)
+        seen = {}
+        reduce_ = h.bucket.all_reduce_mean
+
+        def spy(*a, **k):  # what this rank computed locally, before the exchange
+            seen["local"] = h.bucket.flat.detach().clone()
+            return reduce_(*a, **k)
+
+        h.bucket.all_reduce_mean = spy
+        h.model.train()
+        random.seed(5)  # the model draws its augmentation decisions from `random`
+        torch.manual_seed(5)
+        h.train_step(inputs)
+        torch.cuda.synchronize()
+        torch.save({"local": seen["local"].cpu(), "reduced": h.bucket.flat.detach().cpu()},
+                   os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("same_batch", [True, False], ids=["identical_batches", "distinct_batches"])
+def test_train_step_data_parallel_semantics(tmp_path, same_batch):
+    import torch.multiprocessing as mp
+    from mal_amd import build
+    build.build(verbose=False)
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), same_batch, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % k)) for k in range(world)]
+    scale = float(r[0]["local"].abs().max())
+    assert scale > 0
+    # every rank ends with the same reduced bucket
+    assert torch.equal(r[0]["reduced"], r[1]["reduced"])
+    mean = (r[0]["local"].double() + r[1]["local"].double()) / 2
+    assert float((r[0]["reduced"].double() - mean).abs().max()) <= 1e-6 * scale
+    if same_batch:  # ... which is what one process computes on that batch (MIOpen's reductions are not bit-reproducible
+        # between processes: 1e-4 of the largest gradient)
+        assert float((r[0]["local"] - r[1]["local"]).abs().max()) <= 1e-4 * scale
+        assert float((r[0]["reduced"] - r[0]["local"]).abs().max()) <= 1e-4 * scale
+    else:
+        assert float((r[0]["local"] - r[1]["local"]).abs().max()) > 1e-3 * scale
