@@ -418,14 +418,17 @@ def main():
     kern_ms_plain = kern_ms
     if args.mode == "step":
         plain = Step(dev, 1234 + rank, "distil")
-        pd = []
-        for i in range(23):
+        pev = []
+        for i in range(60):  # back to back (no host sync in between: the clocks stay where the timed region had them)
             a, b_ = lib.mal_event_create(), lib.mal_event_create()
             lib.mal_profile_next_pass(a, b_)
             plain()
-            torch.cuda.synchronize()
+            pev.append((a, b_))
+        torch.cuda.synchronize()
+        pd = []
+        for i, (a, b_) in enumerate(pev):
             ms = ctypes.c_float(0)
-            if i >= 3 and lib.mal_event_elapsed_ms(a, b_, ctypes.byref(ms)) == 0:
+            if i >= 40 and lib.mal_event_elapsed_ms(a, b_, ctypes.byref(ms)) == 0:
                 pd.append(ms.value)
             lib.mal_event_destroy(a), lib.mal_event_destroy(b_)
         kern_ms_plain = sum(pd) / max(len(pd), 1)

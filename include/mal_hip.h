@@ -283,6 +283,9 @@ typedef struct mal_step_args {
   const float *syn_m1, *syn_p1;           /* in of _fwd: outputs[("syn", f, 0)] */
   float *g_syn_m1, *g_syn_p1;             /* out of _fwd */
   const float *g_warp_m1, *g_warp_p1;     /* in of _bwd */
+  int warp_sample_stride;                 /* floats between two samples of warp_m1 / warp_p1; 0 = 3*H*W.  6*H*W with
+                                             warp_p1 = warp_m1 + 3*H*W lays the two images of a sample side by side --
+                                             the (2,3,H,W) pair the instance segmenter is fed (dyn_utils.py:139-140) */
 } mal_step_args;
 int mal_loss_step_warp(const mal_step_args* args);
 /* the same noise map on its own (tests; bit-identical to what the step draws for that seed / step) */

@@ -104,7 +104,8 @@ class StepArgs(C.Structure):
                                    "g_axisangle_p1", "g_translation_p1", "ws")] +
                 [("ws_bytes", sz), ("stream", vp), ("dec_teacher", vp), ("dec_student", vp),
                  ("noise_seed", C.c_uint64), ("noise_step", C.c_uint64), ("noise_counter", vp), ("noise_out", vp)] +
-                [(n, vp) for n in ("warp_m1", "warp_p1", "syn_m1", "syn_p1", "g_syn_m1", "g_syn_p1", "g_warp_m1", "g_warp_p1")])
+                [(n, vp) for n in ("warp_m1", "warp_p1", "syn_m1", "syn_p1", "g_syn_m1", "g_syn_p1", "g_warp_m1", "g_warp_p1")] +
+                [("warp_sample_stride", i32)])
 
 
 STEP_NO_ENS, STEP_AUG_MASK, STEP_NOISE_PHILOX, STEP_TEMPORAL = 1, 2, 4, 8

@@ -29,7 +29,7 @@ struct DynParams {
   int num, C, H, W, replace;
   const float* img_last; const float* img_next;         // (C,H,W)
   float* ori_last; float* ori_next;
-  int* ext;       // [num][2][4]: low, top, right, left of (last, next)
+  int* ext;       // [num][2][kExtChunks][4]: low, top, right, left of (last, next), per band of rows
   int* delta;     // [num][2]: row, column displacement of the "last" copy
   uint8_t* flags; // [H*W]: bit0 region, bit1 any_last, bit2 any_next, bit3 last's background is img_next, bit4 next's is img_last
   const float* g_ori_last; const float* g_ori_next; float* g_img_last; float* g_img_next;
@@ -39,12 +39,18 @@ struct DynParams {
 // microseconds each when launched one by one
 constexpr int kDynBatch = 16;
 struct DynBatch { DynParams s[kDynBatch]; };
+// the extents of one (instance, frame) mask are found by kExtChunks workgroups, one band of rows each (72 workgroups
+// for 12 samples x 3 instances x 2 frames left most of the chip idle); the displacement kernel merges the bands
+constexpr int kExtChunks = 8;
 
 __global__ __launch_bounds__(1024) void dyn_extents_kernel(DynBatch bt) {
   extern __shared__ int sh[];  // row flags [H], column flags [W], then 4 results
   const DynParams& p = bt.s[blockIdx.z];
   if ((int)blockIdx.x >= p.num) return;  // the grid is as wide as the sample with the most instances
-  const int i = blockIdx.x, which = blockIdx.y, tid = threadIdx.x, H = p.H, W = p.W, HW = H * W;
+  const int i = blockIdx.x, which = blockIdx.y / kExtChunks, chunk = blockIdx.y % kExtChunks, tid = threadIdx.x;
+  const int H = p.H, W = p.W;
+  const int band = (H + kExtChunks - 1) / kExtChunks, r_lo = chunk * band, r_hi = min(r_lo + band, H);
+  const int k_lo = r_lo * W, HW = max(r_hi, r_lo) * W;  // this workgroup scans pixels [k_lo, HW)
   int* rowf = sh;
   int* colf = sh + H;
   int* res = sh + H + W;
@@ -52,12 +58,12 @@ __global__ __launch_bounds__(1024) void dyn_extents_kernel(DynBatch bt) {
   if (tid < 4) res[tid] = (tid & 1) ? 0x7fffffff : 0;  // low, top, right, left: max / min
   __syncthreads();
   const long long* sel = which ? p.idx_next : p.idx_last;
-  const uint8_t* m = (which ? p.mask_next : p.mask_last) + (size_t)(sel ? sel[i] : i) * HW;
+  const uint8_t* m = (which ? p.mask_next : p.mask_last) + (size_t)(sel ? sel[i] : i) * ((size_t)H * W);
   auto mark = [&](int k) { rowf[k / W] = 1; colf[k % W] = 1; };  // same-value stores: benign races
-  if ((HW & 15) == 0 && (reinterpret_cast<size_t>(m) & 15) == 0) {
+  if ((HW & 15) == 0 && (k_lo & 15) == 0 && (reinterpret_cast<size_t>(m) & 15) == 0) {
     // masks are mostly empty: scan 16 bytes per load, look at the bytes only where a word is non-zero
     const uint4* m16 = reinterpret_cast<const uint4*>(m);
-    for (int k = tid; k < HW / 16; k += 1024) {
+    for (int k = k_lo / 16 + tid; k < HW / 16; k += 1024) {
       const uint4 v = m16[k];
       const unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(1024) void dyn_extents_kernel(DynBatch bt) {
             if ((w4[j] >> (8 * t)) & 0xffu) mark(k * 16 + j * 4 + t);
     }
   } else {
-    for (int k = tid; k < HW; k += 1024)
+    for (int k = k_lo + tid; k < HW; k += 1024)
       if (m[k]) mark(k);
   }
   __syncthreads();
@@ -76,19 +82,25 @@ __global__ __launch_bounds__(1024) void dyn_extents_kernel(DynBatch bt) {
   for (int c = 1 + tid; c < W; c += 1024)
     if (colf[c]) { atomicMax(&res[2], c); atomicMin(&res[3], c); }
   __syncthreads();
-  if (tid < 4) {
-    int v = res[tid];
-    if (v == 0x7fffffff) v = 0;  // nothing present: argmin over an all-"inf" row returns index 0
-    p.ext[(i * 2 + which) * 4 + tid] = v;
-  }
+  if (tid < 4) p.ext[((i * 2 + which) * kExtChunks + chunk) * 4 + tid] = res[tid];  // merged by dyn_delta_kernel
 }
 
 __global__ void dyn_delta_kernel(DynBatch bt) {
   const DynParams& p = bt.s[blockIdx.z];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.num) return;
-  const int* el = p.ext + (i * 2 + 0) * 4;
-  const int* en = p.ext + (i * 2 + 1) * 4;
+  int el[4], en[4];  // low, top, right, left of (last, next): max / min over the row bands
+  for (int which = 0; which < 2; ++which) {
+    int* e = which ? en : el;
+    for (int t = 0; t < 4; ++t) e[t] = (t & 1) ? 0x7fffffff : 0;
+    for (int c = 0; c < kExtChunks; ++c)
+      for (int t = 0; t < 4; ++t) {
+        const int v = p.ext[((i * 2 + which) * kExtChunks + c) * 4 + t];
+        e[t] = (t & 1) ? min(e[t], v) : max(e[t], v);
+      }
+    for (int t = 0; t < 4; ++t)
+      if (e[t] == 0x7fffffff) e[t] = 0;  // nothing present: argmin over an all-"inf" row returns index 0
+  }
   auto pick = [](int a, int b) {  // larger magnitude, the first on a tie; half, rounded half-to-even
     const int s = abs(b) > abs(a) ? b : a;
     return (int)rintf((float)s * 0.5f);
@@ -202,7 +214,7 @@ static int dyn_check(int num, int C, int H, int W) {
 }
 
 extern "C" size_t mal_dyn_workspace_bytes(int num) {
-  return num > 0 ? align256((size_t)num * 8 * sizeof(int)) : 0;
+  return num > 0 ? align256((size_t)num * 8 * kExtChunks * sizeof(int)) : 0;
 }
 
 static int dyn_fwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, int replace, hipStream_t st) {
@@ -223,7 +235,7 @@ static int dyn_fwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, int
     p.ext = (int*)a.ws; p.delta = a.delta; p.flags = a.flags;
     max_num = a.num > max_num ? a.num : max_num;
   }
-  hipLaunchKernelGGL(dyn_extents_kernel, dim3(max_num, 2, n), dim3(1024), (size_t)(H + W + 4) * sizeof(int), st, bt);
+  hipLaunchKernelGGL(dyn_extents_kernel, dim3(max_num, 2 * kExtChunks, n), dim3(1024), (size_t)(H + W + 4) * sizeof(int), st, bt);
   hipLaunchKernelGGL(dyn_delta_kernel, dim3(1, 1, n), dim3(64), 0, st, bt);
   hipLaunchKernelGGL(dyn_synth_fwd_kernel, dim3((H * W + 255) / 256, 1, n), dim3(256), (size_t)max_num * 4 * sizeof(int), st, bt);
   return launch_status();

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       float* const c1 = p.color_out[1];
       if (c0 && r >= y_lo && r < y_hi && out_x) {
         const unsigned og = moff(r) - (unsigned)b * (unsigned)HW * 4u;
-        const size_t pl = (size_t)b * 3 * HW;
+        const size_t pl = (size_t)b * (p.color_out_stride ? (size_t)p.color_out_stride : 3 * (size_t)HW);
         stf(c0 + pl, og, w0.x[0].x); stf(c0 + pl + HW, og, w0.x[0].y); stf(c0 + pl + 2 * (size_t)HW, og, w0.x[2].x);
         stf(c1 + pl, og, w0.x[1].x); stf(c1 + pl + HW, og, w0.x[1].y); stf(c1 + pl + 2 * (size_t)HW, og, w0.x[2].y);
       }

@@ -359,6 +359,7 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   MarchParams p = teacher_params(a, w, a->mono_reproj ? a->mono_reproj : w.mono_reproj);
   p.block_sums = w.bs_t;
   p.color_out[0] = a->warp_m1; p.color_out[1] = a->warp_p1; p.argmin_out = w.arg_t;
+  p.color_out_stride = a->warp_sample_stride;
   return march_launch(p, MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
 }
 

@@ -89,13 +89,18 @@ class BatchSynthesisFn(Function):
 
     @staticmethod
     def forward(ctx, color_last, color_next, items, replace):
-        cl, cn = ops._req(color_last, "color_last"), ops._req(color_next, "color_next")
+        # per-sample pointers are handed to the kernels: a batch-strided tensor (samples contiguous) needs no copy
+        ok = lambda t: t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t[0].is_contiguous()
+        cl = color_last if ok(color_last) else ops._req(color_last, "color_last")
+        cn = color_next if ok(color_next) else ops._req(color_next, "color_next")
         B, C, H, W = cl.shape
         dev = cl.device
         lib, p = L.load(), ops._p
         # the kernels write every pixel of a listed sample: only the others need the copy of the warped images
         every = len({it[0] for it in items}) == B
-        syn_last, syn_next = (torch.empty_like(cl), torch.empty_like(cn)) if every else (cl.clone(), cn.clone())
+        new = lambda: torch.empty(cl.shape, dtype=torch.float32, device=dev)
+        syn_last, syn_next = (new(), new()) if every else (cl.clone(memory_format=torch.contiguous_format),
+                                                           cn.clone(memory_format=torch.contiguous_format))
         if not items:
             ctx.saved, ctx.dims, ctx.every = [], (C, H, W), False
             return syn_last, syn_next
@@ -168,7 +173,10 @@ def image_synthesis(inputs, outputs, scale, thres, ins_model, matcher):
             confident.append((b, instances_cur))
     # upstream stacks (warped last, warped next) of a sample for the segmenter, one small copy per sample (:139-140);
     # here the pairs of the whole batch are laid out by ONE copy and the segmenter sees sample b's pair as a view
-    pairs = torch.stack([color_last.detach(), color_next.detach()], dim=1) if confident else None
+    # ... or by none: the whole-step API lays the two warped images of a sample side by side and says so
+    pairs = outputs.get(("color_pair", scale))
+    if pairs is None and confident:
+        pairs = torch.stack([color_last.detach(), color_next.detach()], dim=1)
     for b, instances_cur in confident:
         both = generate_instances(pairs[b], ins_model)
         ins_last, ins_next = both[0]["instances"], both[1]["instances"]

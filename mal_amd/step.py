@@ -141,13 +141,17 @@ class TemporalLossStepFn(Function):
         a, keep, maps = _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=True)
         B, _, H, W = keep[0][0].shape
         dev = keep[0][0].device
-        warp = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+        # the two warped images of a sample side by side: the (2,3,H,W) pair the instance segmenter is fed is then a VIEW
+        # (upstream stacks it per sample, dyn_utils.py:139-140); ("color", f, 0) are the two batch-strided halves
+        pair = torch.empty((B, 2, 3, H, W), dtype=torch.float32, device=dev)
+        warp = [pair[:, 0], pair[:, 1]]
         a.warp_m1, a.warp_p1 = warp[0].data_ptr(), warp[1].data_ptr()
+        a.warp_sample_stride = 6 * H * W
         lib = L.load()
         L.check(lib.mal_loss_step_warp(C.byref(a)), "mal_loss_step_warp")
         with torch.enable_grad():
             leaf = [w.detach().requires_grad_(True) for w in warp]
-            local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1]}
+            local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1], ("color_pair", 0): pair}
             has_ins = bool(synth(inputs, local, 0))
         if has_ins:
             syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
