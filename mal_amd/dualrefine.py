@@ -181,6 +181,10 @@ class DualRefineLossPath:
                 loss = loss + opt.disparity_smoothness * loss_utils._smooth(disp, color) / (2 ** scale)
                 total = total + loss
                 losses["loss/{}_{}".format(scale, it)] = loss
+            # upstream updates its running `loss` in place (dualrefine/trainer.py:624,630): the per-iteration entries of a
+            # scale alias one tensor and all read as the sum over the scale's iterations
+            for key in [k for k in losses if k.startswith("loss/{}_".format(scale))]:
+                losses[key] = loss
         losses["loss"] = total / self.num_scales
         return losses
 

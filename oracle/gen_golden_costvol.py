@@ -2,10 +2,13 @@
 
     python -m oracle.gen_golden_costvol
 
-``manydepth.networks.resnet_encoder`` is not importable (torchvision); its ``match_features`` glue is restated
-in oracle/costvol_oracle.py and run HERE with the reference's own ``BackprojectDepth`` / ``Project3D`` objects
+``manydepth.networks.resnet_encoder`` is not importable as shipped (torchvision); its ``match_features`` glue is
+restated in oracle/costvol_oracle.py and run HERE with the reference's own ``BackprojectDepth`` / ``Project3D`` objects
 (``manydepth.layers``) doing the geometry and ATen doing the sampling, exactly as upstream wires them
-(resnet_encoder.py:271-276).
+(resnet_encoder.py:271-276).  Since round 2 the module IS imported as well -- with an inert stand-in for torchvision,
+whose classes only its constructors touch -- and the reference's own ``ResnetEncoderMatching.compute_depth_bins`` /
+``match_features`` / ``compute_confidence_mask`` / ``indices_to_disparity`` are called unbound on the same cases
+(``costvol_ref_*.npz``): they equal the restated glue exactly, so the glue is pinned too.
 """
 from __future__ import annotations
 
@@ -38,6 +41,53 @@ def make_case(B, F_, C, h, w, D, seed):
     return cur, look, poses, K, invK
 
 
+def import_encoder():
+    """``manydepth/networks/resnet_encoder.py`` with an inert stand-in for torchvision (its ResNet classes are only
+    subclassed / instantiated by constructors that are not called here) and ``manydepth.networks`` as a bare namespace
+    (its __init__ pulls every network module)."""
+    import types
+    sys.path.insert(0, REF)
+    if "torchvision" not in sys.modules:
+        tv, models, resnet = types.ModuleType("torchvision"), types.ModuleType("torchvision.models"), types.ModuleType("torchvision.models.resnet")
+        models.ResNet = type("ResNet", (torch.nn.Module,), {})
+        resnet.BasicBlock = resnet.Bottleneck = type("Block", (torch.nn.Module,), {})
+        models.resnet, tv.models = resnet, models
+        sys.modules.update({"torchvision": tv, "torchvision.models": models, "torchvision.models.resnet": resnet})
+    import manydepth  # noqa: F401
+    if "manydepth.networks" not in sys.modules:
+        ns = types.ModuleType("manydepth.networks")
+        ns.__path__ = [os.path.join(REF, "manydepth", "networks")]
+        sys.modules["manydepth.networks"] = ns
+    import manydepth.networks.resnet_encoder as RE
+    return RE.ResnetEncoderMatching
+
+
+def reference_encoder_outputs(Enc, ML, cur, look, poses, K, invK, min_bin, max_bin, D, binning):
+    """the reference's OWN ``ResnetEncoderMatching.compute_depth_bins`` / ``match_features`` /
+    ``compute_confidence_mask`` / ``indices_to_disparity`` (resnet_encoder.py:121-233,247-263) called unbound, and the
+    lines of ``forward`` between them (:296-316), on a namespace object carrying what they read from ``self``"""
+    import types
+    B, F_, C, h, w = look.shape
+    me = types.SimpleNamespace(depth_binning=binning, num_depth_bins=D, matching_height=h, matching_width=w, device="cpu",
+                               set_missing_to_max=True, is_cuda=False,
+                               backprojector=ML.BackprojectDepth(batch_size=D, height=h, width=w),
+                               projector=ML.Project3D(batch_size=D, height=h, width=w))
+    if binning == "linear":  # upstream passes the tracker's tensors (.item() at :131); the inverse branch feeds them to
+        Enc.compute_depth_bins(me, torch.tensor(min_bin), torch.tensor(max_bin))  # np.linspace, which only takes numbers
+    else:
+        Enc.compute_depth_bins(me, min_bin, max_bin)
+    me.compute_confidence_mask = types.MethodType(Enc.compute_confidence_mask, me)
+    with torch.no_grad():
+        cv, miss = Enc.match_features(me, cur, look, poses, K, invK)
+        conf = Enc.compute_confidence_mask(me, cv.detach() * (1 - miss.detach()))
+        viz = cv.clone().detach()
+        viz[viz == 0] = 100
+        _, argmin = torch.min(viz, 1)
+        low = torch.as_tensor(np.asarray(Enc.indices_to_disparity(me, argmin)))  # a numpy array with inverse bins
+        cvm = cv * conf.unsqueeze(1)
+    return cv, miss, cvm, low, conf, torch.as_tensor(np.asarray(me.depth_bins), dtype=torch.float32)
+
+
 def main():
     sys.path.insert(0, REF)
     import manydepth.layers as ML
@@ -57,6 +107,16 @@ def main():
              "out/masked_cost_volume": cvm.numpy(), "out/lowest_cost": low.numpy(), "out/confidence": conf.numpy()}
         np.savez_compressed(os.path.join(OUT, tag + ".npz"), **d)
         print(tag, cv.shape, float(miss.mean()), float(conf.mean()))
+        # the same case through the reference's own encoder methods: the restated glue above must equal it exactly
+        Enc = import_encoder()
+        rcv, rmiss, rcvm, rlow, rconf, rbins = reference_encoder_outputs(Enc, ML, cur, look, poses, K, invK, 0.4, 9.0, D, binning)
+        same = (torch.equal(rbins, bins.float()), torch.equal(rcv, cv), torch.equal(rmiss, miss), torch.equal(rcvm, cvm),
+                torch.equal(rlow.float(), low.float()), torch.equal(rconf, conf))
+        print("   reference ResnetEncoderMatching methods == restated glue:", same)
+        d2 = dict(d)
+        d2.update({"out/cost_volume": rcv.numpy(), "out/missing": rmiss.numpy(), "out/masked_cost_volume": rcvm.numpy(),
+                   "out/lowest_cost": rlow.float().numpy(), "out/confidence": rconf.numpy(), "in/bins": rbins.numpy()})
+        np.savez_compressed(os.path.join(OUT, tag.replace("costvol_", "costvol_ref_") + ".npz"), **d2)
 
 
 if __name__ == "__main__":

@@ -659,6 +659,11 @@ def dr_compute_losses(opt, inputs, outputs, noises=None, aten=True, forced=None)
             loss = loss + opt.disparity_smoothness * normalized_smooth_loss(disp, color) / (2 ** scale)
             total = total + loss
             losses["loss/{}_{}".format(scale, it)] = loss
+        # upstream's running `loss` is updated IN PLACE (`loss += ...`, :624,630), so every "loss/{scale}_{it}" entry of a
+        # scale aliases one tensor and reads as the sum over the scale's iterations; `total_loss` took the value each
+        # iteration had at the time (:631)
+        for key in [k for k in losses if k.startswith("loss/{}_".format(scale))]:
+            losses[key] = loss
     losses["loss"] = total / len(opt.scales)
     return losses
 

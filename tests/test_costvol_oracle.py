@@ -7,7 +7,9 @@ import torch
 from oracle import costvol_oracle as CO
 from tests import golden_io as G
 
-CASES = ["costvol_b2_f2_16x28", "costvol_b1_f1_11x17"]
+# costvol_ref_*: the same cases produced by the reference's OWN ResnetEncoderMatching.compute_depth_bins /
+# match_features / compute_confidence_mask / indices_to_disparity, called unbound (oracle/gen_golden_costvol.py)
+CASES = ["costvol_b2_f2_16x28", "costvol_b1_f1_11x17", "costvol_ref_b2_f2_16x28", "costvol_ref_b1_f1_11x17"]
 
 
 def load(tag):

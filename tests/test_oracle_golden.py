@@ -142,6 +142,42 @@ def test_multiscale_compute_losses_against_reference():
         G.assert_close(g, z["grad/" + k], 0, "grad/" + k)
 
 
+def test_dualrefine_loops_against_reference_trainer_methods():
+    """a17: the fixture was produced by the reference's OWN ``Trainer.generate_images_pred`` / ``compute_losses`` /
+    ``pose_update_generate_images_pred`` / ``compute_pose_update_losses`` (dualrefine/trainer.py:395-767) called unbound
+    (oracle/gen_golden_dr.py); the oracle's restatement of those loops reproduces losses and gradients bit for bit."""
+    z = G.load("dualrefine_b2_40x72")
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    torch.manual_seed(int(z["in/noise_seed"]))
+    noises = [torch.randn(B, 1, H, W) for _ in range(2)]
+    torch.manual_seed(int(z["in/noise_seed"]) + 1)
+    nz_pose = torch.randn(B, 1, H, W)
+    inputs = {("color", f, 0): b[k] for f, k in ((0, "color0"), (-1, "color_m1"), (1, "color_p1"))}
+    inputs[("K", 0)], inputs[("inv_K", 0)] = b["K"], b["inv_K"]
+    leaves = {k: b[k].clone().requires_grad_(True) for k in ("disp_teacher", "disp_student", "axisangle_m1", "translation_m1",
+                                                            "axisangle_p1", "translation_p1")}
+    T_m1 = O.transformation_from_parameters(leaves["axisangle_m1"], leaves["translation_m1"], True)
+    T_p1 = O.transformation_from_parameters(leaves["axisangle_p1"], leaves["translation_p1"], False)
+    outputs = {("disp", 0, 0): leaves["disp_teacher"], ("disp", 0, 1): leaves["disp_student"],
+               ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1, ("cam_T_cam", 0, -1, 1): T_m1 * 1.0,
+               "consistency_mask": b["consistency_mask"].unsqueeze(1)}
+    opt = O.dr_default_opt(height=H, width=W, batch_size=B, n_losses=1)
+    O.dr_generate_images_pred(opt, inputs, outputs)
+    losses = O.dr_compute_losses(opt, inputs, outputs, noises=noises)
+    losses["loss"].backward()
+    for k, v in losses.items():
+        G.assert_close(v.item(), z["losses/" + k], 0, k)
+    for k, t in leaves.items():
+        G.assert_close(t.grad, z["grad/" + k], 0, "grad/" + k)
+    G.assert_close(outputs[("depth", 0, 0, 1)].detach(), z["depth_0_1"], 0)
+    O.dr_pose_update_generate_images_pred(opt, inputs, outputs)
+    G.assert_close(outputs[("color", -1, 0, 0, 1)].detach(), z["color_m1_pose"], 0)
+    pl = O.dr_compute_pose_update_losses(opt, inputs, outputs, noise=nz_pose)
+    for k, v in pl.items():
+        G.assert_close(v.item(), z["pose_losses/" + k], 0, k)
+
+
 def test_step_full_size_against_reference():
     z = G.load(G.BIG_CASE)
     B, _, H, W = z["in/color0"].shape
