@@ -370,6 +370,20 @@ int mal_epipolar_coords_of_depths(const float* depths, const float* poses, const
                                  float* coords, void* stream);
 int mal_coord_sample_l1(const float* fmap1, const float* const* f2_pyramid, const float* coords, int B, int C, int h, int w,
                         int L, int d1, int heads, float* out, void* stream);
+/* VJPs of the two lookup functions (the DEQ solver differentiates through them in training,
+ * dualrefine/networks/depth_pose.py:426-455).  mal_epipolar_coords_bwd: cotangents of (coords, max_dx, depths) --
+ * the last two nullable -- -> g_depth (B,1,h,w), g_poses (B,16; row 3 zero), g_dd (1) = d / d softplus(delta); fixed
+ * summation order.  mal_coord_sample_l1_bwd: cotangent of the lookup's output -> g_fmap1 (B,C,h,w), g_f2_pyramid[l]
+ * (level shapes), g_coords; g_fmap1 / g_f2_pyramid[l] must be ZERO on entry (accumulated with float atomics, as
+ * ATen's grid_sampler backward does); any of the three may be NULL. */
+size_t mal_epipolar_coords_bwd_workspace_bytes(int B, int h, int w);
+int mal_epipolar_coords_bwd(const float* depth, const float* poses, const float* K, const float* g_coords,
+                            const float* g_max_dx, const float* g_depths, int B, int h, int w, int r, int L,
+                            float softplus_delta, float ratio, float* g_depth, float* g_poses, float* g_dd,
+                            void* ws, size_t ws_bytes, void* stream);
+int mal_coord_sample_l1_bwd(const float* fmap1, const float* const* f2_pyramid, const float* coords, const float* g_out,
+                            int B, int C, int h, int w, int L, int d1, int heads, float* g_fmap1,
+                            float* const* g_f2_pyramid, float* g_coords, void* stream);
 /* The pose refinement step of the same loop (depth_pose.py:450-455), forward:
  * mal_epipolar_gradcoords = Reprojections.depth2gradcoords (utils.py:219-236): c_p (B,2,1,5,h,w) = the projection and its
  * +-1 px neighbours in x and y, P2 (B,4,h*w) = the transformed points.

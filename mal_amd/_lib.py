@@ -67,6 +67,10 @@ SIGNATURES = {
     "mal_dyn_batch_bwd": (i32, [vp, i32, i32, i32, i32, vp]),
     "mal_epipolar_coords": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, f32, f32, c_fp, c_fp, c_fp, vp]),
     "mal_coord_sample_l1": (i32, [c_fp, vp, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, vp]),
+    "mal_epipolar_coords_bwd_workspace_bytes": (sz, [i32, i32, i32]),
+    "mal_epipolar_coords_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, f32, f32, c_fp, c_fp, c_fp,
+                                      vp, sz, vp]),
+    "mal_coord_sample_l1_bwd": (i32, [c_fp, vp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, vp, c_fp, vp]),
     "mal_epipolar_coords_of_depths": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, vp]),
     "mal_epipolar_gradcoords": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, vp]),
     "mal_direct_align_workspace_bytes": (sz, [i32, i32, i32]),

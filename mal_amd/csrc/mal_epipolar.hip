@@ -170,6 +170,211 @@ __global__ __launch_bounds__(256) void epi_sample_kernel(EpiSampleParams p) {
   }
 }
 
+// ---------------------------------------------------------------- VJPs of the lookup
+// depth2epipolarcoords backward: cotangents of (coords, max_dx, depths) -> d/d depth (per pixel), d/d poses[:3] and
+// d/d softplus(delta) (per-workgroup partials, fixed-order second stage; no atomics).  One thread per pixel re-derives
+// the forward chain of each hypothesis:  Z = z0 + dx_j 2^l gap,  gap = dd z0 / ratio / r;  X1 = T[:3] (ZX, ZY, Z, 1);
+// d = min(1/X1z, 100);  u = fx X1x d + cx,  v = fy X1y d + cy.
+struct EpiCoordBwdParams {
+  const float* depth; const float* poses; const float* K;
+  const float* g_coords; const float* g_max_dx; const float* g_depths;  // the last two nullable
+  int B, h, w, r, L, nblk; float dd, ratio;
+  float* g_depth; double* partial;  // [B][nblk][13]: d/dT rows 0..2 (12), d/d dd
+};
+
+__global__ __launch_bounds__(256) void epi_coords_bwd_kernel(EpiCoordBwdParams p) {
+  __shared__ double s_red[13][4];
+  const int hw = p.h * p.w, d1 = 2 * p.r + 1, D = p.L * d1;
+  const int b = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x;
+  const bool live = pix < hw;
+  float acc[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) acc[k] = 0.f;
+  if (live) {
+    const int y = pix / p.w, x = pix - y * p.w, i = b * hw + pix;
+    const float* Kb = p.K + b * 16;
+    const float* T = p.poses + b * 16;
+    const float fx = Kb[0], fy = Kb[5], cx = Kb[2], cy = Kb[6];
+    const float z0 = p.depth[i];
+    const float X = div_((float)x - cx, fx), Y = div_((float)y - cy, fy);
+    const float gap = div_(div_(p.dd * z0, p.ratio), (float)p.r);
+    const float dgap_dz0 = div_(div_(p.dd, p.ratio), (float)p.r), dgap_ddd = div_(div_(z0, p.ratio), (float)p.r);
+    float g_z0 = 0.f;
+    for (int s = 0; s < D; ++s) {
+      const int level = s / d1, j = s - level * d1;
+      const float cj = (float)(j - p.r) * (float)(1 << level);  // d Z / d gap
+      const float Z = z0 + cj * gap;
+      const float X0[4] = {Z * X, Z * Y, Z, 1.0f};
+      float X1[3];
+      for (int r_ = 0; r_ < 3; ++r_) {
+        float a = T[r_ * 4] * X0[0];
+        a = fma_(T[r_ * 4 + 1], X0[1], a);
+        a = fma_(T[r_ * 4 + 2], X0[2], a);
+        X1[r_] = fma_(T[r_ * 4 + 3], X0[3], a);
+      }
+      const float inv = div_(1.0f, X1[2]);
+      const bool clamped = inv > 100.0f;
+      const float d = clamped ? 100.0f : inv;
+      const size_t o = ((size_t)b * 2 * D + s) * hw + pix;
+      const float gu = p.g_coords[o], gv = p.g_coords[o + (size_t)D * hw];
+      float gX1[3];
+      gX1[0] = gu * fx * d;
+      gX1[1] = gv * fy * d;
+      const float g_d = gu * fx * X1[0] + gv * fy * X1[1];
+      gX1[2] = clamped ? 0.f : -g_d * inv * inv;  // torch.clamp(max=100) passes the gradient where 1/Z <= 100
+      float gZ = p.g_depths ? p.g_depths[((size_t)b * D + s) * hw + pix] : 0.f;
+#pragma unroll
+      for (int r_ = 0; r_ < 3; ++r_) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r_ * 4 + c] += gX1[r_] * X0[c];
+        gZ += gX1[r_] * (T[r_ * 4] * X + T[r_ * 4 + 1] * Y + T[r_ * 4 + 2]);
+      }
+      g_z0 += gZ * (1.0f + cj * dgap_dz0);
+      acc[12] += gZ * cj * dgap_ddd;
+    }
+    if (p.g_max_dx) {  // max over the level-0 offsets dx_j * gap: at j = 2r for gap >= 0, at j = 0 otherwise
+      const float gm = p.g_max_dx[i], cm = gap >= 0.f ? (float)p.r : -(float)p.r;
+      g_z0 += gm * cm * dgap_dz0;
+      acc[12] += gm * cm * dgap_ddd;
+    }
+    p.g_depth[i] = g_z0;
+  }
+  // 13 sums over the workgroup: wave shuffle, then the four waves in order
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const double v = wave_sum_d((double)acc[k]);
+    if (lane == 0) s_red[k][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 13)
+    p.partial[((size_t)b * p.nblk + blockIdx.x) * 13 + threadIdx.x] =
+        ((s_red[threadIdx.x][0] + s_red[threadIdx.x][1]) + s_red[threadIdx.x][2]) + s_red[threadIdx.x][3];
+}
+
+// second stage: g_poses (B,16) rows 0..2 (row 3 receives nothing), g_dd (1) -- sums over workgroups / samples in order
+__global__ __launch_bounds__(64) void epi_coords_bwd_finish_kernel(const double* partial, int B, int nblk, float* g_poses,
+                                                                   float* g_dd) {
+  const int t = threadIdx.x;
+  if (t < 12)
+    for (int b = 0; b < B; ++b) {
+      double a = 0.0;
+      for (int k = 0; k < nblk; ++k) a += partial[((size_t)b * nblk + k) * 13 + t];
+      g_poses[b * 16 + t] = (float)a;
+    }
+  if (t >= 12 && t < 16)
+    for (int b = 0; b < B; ++b) g_poses[b * 16 + t] = 0.f;
+  if (t == 16) {
+    double a = 0.0;
+    for (int b = 0; b < B; ++b)
+      for (int k = 0; k < nblk; ++k) a += partial[((size_t)b * nblk + k) * 13 + 12];
+    *g_dd = (float)a;
+  }
+}
+
+// CoordSampler.__call__ backward: cotangent of out (B, L*heads*d1, h, w) -> d/d fmap1, d/d each pyramid level of
+// fmap2 (scatter: float atomics, as ATen's grid_sampler backward does -- the one place of this library whose summation
+// order is not fixed), d/d coords.  Same decomposition as the forward: lane = pixel, a wavefront owns kEpiG hypotheses of
+// one level and walks the channel planes re-deriving the samples.
+struct EpiSampleBwdParams {
+  const float* fmap1; const float* f2[kEpiMaxLevels];
+  const float* coords; const float* g_out;
+  int B, C, h, w, L, d1, heads;
+  float* g_fmap1; float* g_f2[kEpiMaxLevels]; float* g_coords;  // g_fmap1 / g_f2 zero-initialised by the caller; each nullable
+};
+
+__global__ __launch_bounds__(256) void epi_sample_bwd_kernel(EpiSampleBwdParams p) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hw = p.h * p.w, D = p.L * p.d1;
+  const int gpl = (p.d1 + kEpiG - 1) / kEpiG;
+  const int level = blockIdx.y / gpl, j0 = (blockIdx.y - level * gpl) * kEpiG, b = blockIdx.z;
+  const int pix0 = (blockIdx.x * 4 + wv) * 64;
+  if (pix0 >= hw) return;
+  const bool live = pix0 + lane < hw;
+  const int pix = min(pix0 + lane, hw - 1);
+  const int hl = p.h >> level, wl = p.w >> level, hwl = hl * wl;
+  const float* f2l = p.f2[level];
+  float* g_f2l = p.g_f2[level];
+  unsigned off[kEpiG][4];
+  float wt[kEpiG][4], dwx[kEpiG][4], dwy[kEpiG][4];  // tap weights and their derivatives w.r.t. (ix, iy), zero where padding
+  bool act[kEpiG];
+#pragma unroll
+  for (int g = 0; g < kEpiG; ++g) {
+    act[g] = live && j0 + g < p.d1;
+    const int s = level * p.d1 + min(j0 + g, p.d1 - 1);
+    const size_t o = ((size_t)b * 2 * D + s) * hw + pix;
+    const float u = p.coords[o], v = p.coords[o + (size_t)D * hw];
+    const float gx = div_(2.0f * (u + 0.5f), (float)p.w) - 1.0f, gy = div_(2.0f * (v + 0.5f), (float)p.h) - 1.0f;
+    const float ix = ((gx + 1.0f) * (float)wl - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)hl - 1.0f) / 2.0f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float xc = fminf(fmaxf(x0f, -2.0f), (float)wl + 1.0f), yc = fminf(fmaxf(y0f, -2.0f), (float)hl + 1.0f);
+    const bool wild = !(x0f == xc && y0f == yc);
+    const int x0 = (int)xc, y0 = (int)yc, x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = ix - x0f, ty = iy - y0f, ex = (x0f + 1.0f) - ix, ey = (y0f + 1.0f) - iy;
+    const bool vx0 = x0 >= 0 && x0 < wl, vx1 = x1 >= 0 && x1 < wl, vy0 = y0 >= 0 && y0 < hl, vy1 = y1 >= 0 && y1 < hl;
+    const int cx0 = min(max(x0, 0), wl - 1), cx1 = min(max(x1, 0), wl - 1), cy0 = min(max(y0, 0), hl - 1), cy1 = min(max(y1, 0), hl - 1);
+    off[g][0] = (unsigned)(cy0 * wl + cx0) * 4u; off[g][1] = (unsigned)(cy0 * wl + cx1) * 4u;
+    off[g][2] = (unsigned)(cy1 * wl + cx0) * 4u; off[g][3] = (unsigned)(cy1 * wl + cx1) * 4u;
+    const bool v00 = !wild && vx0 && vy0, v10 = !wild && vx1 && vy0, v01 = !wild && vx0 && vy1, v11 = !wild && vx1 && vy1;
+    wt[g][0] = v00 ? ex * ey : 0.f; wt[g][1] = v10 ? tx * ey : 0.f; wt[g][2] = v01 ? ex * ty : 0.f; wt[g][3] = v11 ? tx * ty : 0.f;
+    dwx[g][0] = v00 ? -ey : 0.f; dwx[g][1] = v10 ? ey : 0.f; dwx[g][2] = v01 ? -ty : 0.f; dwx[g][3] = v11 ? ty : 0.f;
+    dwy[g][0] = v00 ? -ex : 0.f; dwy[g][1] = v10 ? -tx : 0.f; dwy[g][2] = v01 ? ex : 0.f; dwy[g][3] = v11 ? tx : 0.f;
+  }
+  const int cg = p.C / p.heads;
+  const float inv_cg = 1.0f / (float)cg;
+  float g_ix[kEpiG], g_iy[kEpiG];
+#pragma unroll
+  for (int g = 0; g < kEpiG; ++g) { g_ix[g] = 0.f; g_iy[g] = 0.f; }
+  for (int head = 0; head < p.heads; ++head) {
+    float go[kEpiG];  // cotangent of this head's output for each hypothesis, / channels per head
+#pragma unroll
+    for (int g = 0; g < kEpiG; ++g) {
+      const int j = min(j0 + g, p.d1 - 1);
+      go[g] = act[g] ? p.g_out[((size_t)b * D * p.heads + (size_t)level * p.heads * p.d1 + (size_t)head * p.d1 + j) * hw + pix] * inv_cg
+                     : 0.f;
+    }
+    for (int c = head * cg; c < (head + 1) * cg; ++c) {
+      const size_t plane1 = ((size_t)b * p.C + c) * hw;
+      const float f1 = p.fmap1[plane1 + pix];
+      const char* pl = reinterpret_cast<const char*>(f2l + ((size_t)b * p.C + c) * hwl);
+      char* gpl2 = g_f2l ? reinterpret_cast<char*>(g_f2l + ((size_t)b * p.C + c) * hwl) : nullptr;
+      float g_f1 = 0.f;
+#pragma unroll
+      for (int g = 0; g < kEpiG; ++g) {
+        const float a = *reinterpret_cast<const float*>(pl + off[g][0]), bb = *reinterpret_cast<const float*>(pl + off[g][1]);
+        const float cc = *reinterpret_cast<const float*>(pl + off[g][2]), d = *reinterpret_cast<const float*>(pl + off[g][3]);
+        float o = a * wt[g][0];
+        o = fma_(bb, wt[g][1], o);
+        o = fma_(cc, wt[g][2], o);
+        o = fma_(d, wt[g][3], o);
+        const float df = f1 - o;
+        const float k = go[g] * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));  // d |f1 - o| / d f1, times the cotangent
+        g_f1 += k;
+        g_ix[g] -= k * (((a * dwx[g][0] + bb * dwx[g][1]) + cc * dwx[g][2]) + d * dwx[g][3]);
+        g_iy[g] -= k * (((a * dwy[g][0] + bb * dwy[g][1]) + cc * dwy[g][2]) + d * dwy[g][3]);
+        if (gpl2 && act[g] && k != 0.f) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (wt[g][t] != 0.f) atomicAdd(reinterpret_cast<float*>(gpl2 + off[g][t]), -k * wt[g][t]);
+        }
+      }
+      if (p.g_fmap1 && live && g_f1 != 0.f) atomicAdd(p.g_fmap1 + plane1 + pix, g_f1);
+    }
+  }
+  if (p.g_coords) {
+    // ix = ((gx+1) wl - 1)/2 with gx = 2 (u + 0.5)/w - 1  =>  d ix / d u = wl / w
+    const float sx = (float)wl / (float)p.w, sy = (float)hl / (float)p.h;
+#pragma unroll
+    for (int g = 0; g < kEpiG; ++g) {
+      if (!act[g]) continue;
+      const int s = level * p.d1 + j0 + g;
+      const size_t o = ((size_t)b * 2 * D + s) * hw + pix;
+      p.g_coords[o] = g_ix[g] * sx;
+      p.g_coords[o + (size_t)D * hw] = g_iy[g] * sy;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- pose refinement step (forward)
 struct EpiGradCoordParams {
   const float* depth; const float* poses; const float* K;
@@ -536,6 +741,48 @@ extern "C" int mal_coord_sample_l1(const float* fmap1, const float* const* f2_py
     p.f2[l] = f2_pyramid[l];
   }
   hipLaunchKernelGGL(epi_sample_kernel, dim3((h * w + 255) / 256, L * ((d1 + kEpiG - 1) / kEpiG), B), dim3(256), 0,
+                     (hipStream_t)stream, p);
+  return launch_status();
+}
+
+extern "C" size_t mal_epipolar_coords_bwd_workspace_bytes(int B, int h, int w) {
+  if (B <= 0 || h < 1 || w < 1) return 0;
+  return align256((size_t)B * ((h * w + 255) / 256) * 13 * sizeof(double));
+}
+
+extern "C" int mal_epipolar_coords_bwd(const float* depth, const float* poses, const float* K, const float* g_coords,
+                                       const float* g_max_dx, const float* g_depths, int B, int h, int w, int r, int L,
+                                       float softplus_delta, float ratio, float* g_depth, float* g_poses, float* g_dd,
+                                       void* ws, size_t ws_bytes, void* stream) {
+  if (B <= 0 || h < 1 || w < 1 || r < 1 || L < 1 || L > kEpiMaxLevels) return MAL_ESHAPE;
+  if ((double)B * 2 * L * (2 * r + 1) * h * w > 2.0e9 / 4) return MAL_ESHAPE;
+  if (!depth || !poses || !K || !g_coords || !g_depth || !g_poses || !g_dd || !ws) return MAL_EINVAL;
+  if (ws_bytes < mal_epipolar_coords_bwd_workspace_bytes(B, h, w)) return MAL_EWORKSPACE;
+  EpiCoordBwdParams p = {};
+  p.depth = depth; p.poses = poses; p.K = K; p.g_coords = g_coords; p.g_max_dx = g_max_dx; p.g_depths = g_depths;
+  p.B = B; p.h = h; p.w = w; p.r = r; p.L = L; p.nblk = (h * w + 255) / 256; p.dd = softplus_delta; p.ratio = ratio;
+  p.g_depth = g_depth; p.partial = (double*)ws;
+  hipLaunchKernelGGL(epi_coords_bwd_kernel, dim3(p.nblk, B), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(epi_coords_bwd_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p.partial, B, p.nblk, g_poses, g_dd);
+  return launch_status();
+}
+
+extern "C" int mal_coord_sample_l1_bwd(const float* fmap1, const float* const* f2_pyramid, const float* coords,
+                                       const float* g_out, int B, int C, int h, int w, int L, int d1, int heads,
+                                       float* g_fmap1, float* const* g_f2_pyramid, float* g_coords, void* stream) {
+  if (B <= 0 || C < 1 || h < 1 || w < 1 || L < 1 || L > kEpiMaxLevels || d1 < 1 || heads < 1 || C % heads) return MAL_ESHAPE;
+  if ((h >> (L - 1)) < 1 || (w >> (L - 1)) < 1) return MAL_ESHAPE;
+  if ((double)B * C * h * w > 2.0e9 / 4 || (double)B * 2 * L * d1 * h * w > 2.0e9 / 4) return MAL_ESHAPE;
+  if (!fmap1 || !f2_pyramid || !coords || !g_out) return MAL_EINVAL;
+  EpiSampleBwdParams p = {};
+  p.fmap1 = fmap1; p.coords = coords; p.g_out = g_out; p.B = B; p.C = C; p.h = h; p.w = w; p.L = L; p.d1 = d1; p.heads = heads;
+  p.g_fmap1 = g_fmap1; p.g_coords = g_coords;
+  for (int l = 0; l < L; ++l) {
+    if (!f2_pyramid[l]) return MAL_EINVAL;
+    p.f2[l] = f2_pyramid[l];
+    p.g_f2[l] = g_f2_pyramid ? g_f2_pyramid[l] : nullptr;
+  }
+  hipLaunchKernelGGL(epi_sample_bwd_kernel, dim3((h * w + 255) / 256, L * ((d1 + kEpiG - 1) / kEpiG), B), dim3(256), 0,
                      (hipStream_t)stream, p);
   return launch_status();
 }

@@ -5,8 +5,10 @@
     Reprojections.depth2epipolarcoords(poses, depths)      dualrefine/networks/utils/utils.py:112-217
     CoordSampler.register / __call__(coords, levels, heads) dualrefine/networks/corr.py:6-50
 
-Forward only (inference; training differentiates through both inside the DEQ solver -- their VJPs are not built yet,
-so tensors that require grad are refused rather than silently detached).  No CPU fallback.
+The correlation lookup (``depth2epipolarcoords`` + ``CoordSampler.__call__``) is differentiable (round 2: the DEQ solver
+differentiates through both in training, depth_pose.py:426-455): autograd Functions over ``mal_epipolar_coords_bwd`` /
+``mal_coord_sample_l1_bwd``.  The pose-refinement step (``depth2gradcoords``, ``direct_align``) and the masking lookup
+are forward-only: tensors that require grad are refused there rather than silently detached.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -15,6 +17,88 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from . import ops
+
+
+class EpipolarCoordsFn(torch.autograd.Function):
+    """(depths (B,1,h,w), poses (B,4,4), K, softplus(delta) (1,)) -> (coords, max_dx, depth hypotheses);
+    utils.py:180-217 and its VJP (d/d depths, d/d poses, d/d softplus(delta))."""
+
+    @staticmethod
+    def forward(ctx, depths, poses, K, dd_t, r, Lv, ratio):
+        d = ops._req(depths.float(), "depths")
+        B, _, h, w = d.shape
+        dev = d.device
+        T = ops._req(poses.float().reshape(B, 16).contiguous(), "poses")
+        Kc = ops._req(K.float().reshape(B, 16).contiguous(), "K")
+        dd = float(dd_t.detach().float().cpu())
+        d1 = 2 * r + 1
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        coords, max_dx, ds = new(B, 2, Lv, d1, h, w), new(B, 1, h, w), new(B, 1, Lv * d1, h, w)
+        p = ops._p
+        L.check(L.load().mal_epipolar_coords(p(d), p(T), p(Kc), B, h, w, r, Lv, dd, float(ratio), p(coords), p(max_dx), p(ds),
+                                             ops._stream()), "mal_epipolar_coords")
+        ctx.save_for_backward(d, T, Kc)
+        ctx.cfg = (r, Lv, dd, float(ratio), tuple(poses.shape), tuple(dd_t.shape), dd_t.device)
+        ctx.set_materialize_grads(False)
+        return coords, max_dx, ds
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_coords, g_max_dx, g_ds):
+        d, T, Kc = ctx.saved_tensors
+        r, Lv, dd, ratio, pshape, dshape, ddev = ctx.cfg
+        B, _, h, w = d.shape
+        dev = d.device
+        if g_coords is None:
+            g_coords = torch.zeros(B, 2, Lv, 2 * r + 1, h, w, dtype=torch.float32, device=dev)
+        gc = ops._req(g_coords.float(), "g_coords")
+        gm = None if g_max_dx is None else ops._req(g_max_dx.float(), "g_max_dx")
+        gs = None if g_ds is None else ops._req(g_ds.float(), "g_depths")
+        g_depth = torch.empty_like(d)
+        g_poses = torch.empty(B, 16, dtype=torch.float32, device=dev)
+        g_dd = torch.empty(1, dtype=torch.float32, device=dev)
+        lib, p = L.load(), ops._p
+        ws = torch.empty(lib.mal_epipolar_coords_bwd_workspace_bytes(B, h, w), dtype=torch.uint8, device=dev)
+        L.check(lib.mal_epipolar_coords_bwd(p(d), p(T), p(Kc), p(gc), p(gm), p(gs), B, h, w, r, Lv, dd, ratio, p(g_depth),
+                                            p(g_poses), p(g_dd), p(ws), ws.numel(), ops._stream()), "mal_epipolar_coords_bwd")
+        return g_depth, g_poses.reshape(pshape), None, g_dd.reshape(dshape).to(ddev), None, None, None
+
+
+class CoordSampleFn(torch.autograd.Function):
+    """(fmap1, coords, pyramid levels of fmap2...) -> the L1 correlation lookup (corr.py:25-50) and its VJP"""
+
+    @staticmethod
+    def forward(ctx, fmap1, coords, num_levels, num_head, *pyramid):
+        f1 = ops._req(fmap1.float(), "fmap1")
+        c = ops._req(coords.float(), "coords")
+        pyr = [ops._req(f.float(), "fmap2 level") for f in pyramid]
+        B, two, n1, d1, h, w = c.shape
+        C = f1.shape[1]
+        out = torch.empty(B, num_levels * num_head * d1, h, w, dtype=torch.float32, device=c.device)
+        p = ops._p
+        L.check(L.load().mal_coord_sample_l1(p(f1), L.ptr_array([p(f) for f in pyr]), p(c), B, C, h, w, num_levels, d1,
+                                             num_head, p(out), ops._stream()), "mal_coord_sample_l1")
+        ctx.save_for_backward(f1, c, *pyr)
+        ctx.cfg = (num_levels, num_head)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out):
+        f1, c, *pyr = ctx.saved_tensors
+        num_levels, num_head = ctx.cfg
+        B, two, n1, d1, h, w = c.shape
+        C = f1.shape[1]
+        need = ctx.needs_input_grad
+        g_f1 = torch.zeros_like(f1) if need[0] else None
+        g_c = torch.zeros_like(c) if need[1] else None
+        g_pyr = [torch.zeros_like(f) if need[4 + i] else None for i, f in enumerate(pyr)]
+        p = ops._p
+        L.check(L.load().mal_coord_sample_l1_bwd(p(f1), L.ptr_array([p(f) for f in pyr]), p(c), p(ops._req(g_out.float(), "g_out")),
+                                                 B, C, h, w, num_levels, d1, num_head, p(g_f1),
+                                                 L.ptr_array([p(g) for g in g_pyr]), p(g_c), ops._stream()),
+                "mal_coord_sample_l1_bwd")
+        return (g_f1, g_c, None, None, *g_pyr)
 
 
 def _no_grad(*ts):
@@ -51,21 +135,8 @@ class Reprojections(torch.nn.Module):
                                       "(dualrefine/networks/utils/utils.py:177,193)")
         if self.K is None:
             raise L.MalError("Reprojections: call _reg_intrinsics(K) first (depth_pose.py:471)")
-        _no_grad(poses, depths, self.delta)
-        d = ops._req(depths.detach(), "depths")
-        B, _, h, w = d.shape
-        dev = d.device
-        T = ops._req(poses.detach().float().reshape(B, 16).contiguous(), "poses")
-        K = ops._req(self.K.detach().float().reshape(B, 16).contiguous(), "K")
-        Lv, d1 = self.args.num_levels, 2 * self.r + 1
-        dd = float(F.softplus(self.delta.detach().float().cpu()))
-        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        coords, max_dx, ds = new(B, 2, Lv, d1, h, w), new(B, 1, h, w), new(B, 1, Lv * d1, h, w)
-        p = ops._p
-        L.check(L.load().mal_epipolar_coords(p(d), p(T), p(K), B, h, w, self.r, Lv, dd,
-                                             float(self.args.gap_factor_depth_ratio), p(coords), p(max_dx), p(ds),
-                                             ops._stream()), "mal_epipolar_coords")
-        return coords, max_dx, ds
+        return EpipolarCoordsFn.apply(depths, poses, self.K.detach(), F.softplus(self.delta.float()), self.r,
+                                      self.args.num_levels, float(self.args.gap_factor_depth_ratio))
 
 
     def depth2gradcoords(self, poses, depths, intrinsics=None):
@@ -202,32 +273,24 @@ class CoordSampler(torch.nn.Module):
         self.args = args
 
     def register(self, fmap1, fmap2, num_levels=4):
-        _no_grad(fmap1, fmap2)
         self.num_levels = num_levels
-        self.fmap1 = ops._req(fmap1.detach().float(), "fmap1").clone()
-        f2 = ops._req(fmap2.detach().float(), "fmap2").clone()
+        self.fmap1 = ops._req(fmap1.float(), "fmap1")
+        f2 = ops._req(fmap2.float(), "fmap2")
         self.f2_pyramid = [f2]
-        for _ in range(num_levels - 1):  # corr.py:19-23 (a dense pooling: torch)
+        for _ in range(num_levels - 1):  # corr.py:19-23 (a dense pooling: torch, differentiable)
             f2 = F.avg_pool2d(f2, 2, stride=2)
             self.f2_pyramid.append(f2.contiguous())
 
     def _update_fmap1(self, fmap1):
-        self.fmap1 = ops._req(fmap1.detach().float(), "fmap1").clone()
+        self.fmap1 = ops._req(fmap1.float(), "fmap1")
 
     def __corr__(self, coords, num_levels=1, num_head=1):
         """corr.py:52-75: the mean over all channels = the lookup with one head"""
         return self(coords, num_levels, 1)
 
     def __call__(self, coords, num_levels=1, num_head=1):
-        _no_grad(coords)
-        c = ops._req(coords.detach(), "coords")
-        B, two, n1, d1, h, w = c.shape
+        B, two, n1, d1, h, w = coords.shape
         C = self.fmap1.shape[1]
         if two != 2 or n1 != num_levels or tuple(self.fmap1.shape) != (B, C, h, w) or num_levels > len(self.f2_pyramid):
             raise L.MalError("CoordSampler: coords must be (B,2,num_levels,d,h,w) matching the registered feature maps")
-        out = torch.empty(B, num_levels * num_head * d1, h, w, dtype=torch.float32, device=c.device)
-        p = ops._p
-        L.check(L.load().mal_coord_sample_l1(p(self.fmap1), L.ptr_array([p(f) for f in self.f2_pyramid[:num_levels]]), p(c),
-                                             B, C, h, w, num_levels, d1, num_head, p(out), ops._stream()),
-                "mal_coord_sample_l1")
-        return out
+        return CoordSampleFn.apply(self.fmap1, coords, num_levels, num_head, *self.f2_pyramid[:num_levels])

@@ -76,6 +76,21 @@ def main():
             "in/delta": np.float32(0.7), "in/minmax": np.array([9.0, 1.0], dtype=np.float32),
             "out/coords": c.numpy(), "out/max_dx": max_dx.numpy(), "out/depths": ds.numpy(), "out/corr": corr.numpy()})
         print(tag, tuple(c.shape), tuple(corr.shape), float(corr.mean()))
+        # ---- VJPs: autograd through the reference's own Reprojections / CoordSampler
+        gg = torch.Generator().manual_seed(seed + 500)
+        w_corr, w_ds, w_mx = torch.randn(corr.shape, generator=gg), 0.1 * torch.randn(ds.shape, generator=gg), torch.randn(max_dx.shape, generator=gg)
+        dg, pg = depth.clone().requires_grad_(True), poses.clone().requires_grad_(True)
+        f1g, f2g = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+        R.delta.grad = None
+        cg, mg, sg = R.depth2epipolarcoords(pg, dg)
+        S2 = Cn.CoordSampler(args)
+        S2.register(f1g, f2g, num_levels=L)
+        ((S2(cg, L, heads) * w_corr).sum() + (sg * w_ds).sum() + (mg * w_mx).sum()).backward()
+        np.savez_compressed(os.path.join(OUT, tag.replace("epi_", "epi_grad_") + ".npz"), **{
+            "in/w_corr": w_corr.numpy(), "in/w_ds": w_ds.numpy(), "in/w_mx": w_mx.numpy(),
+            "grad/depth": dg.grad.numpy(), "grad/poses": pg.grad.numpy(), "grad/delta": R.delta.grad.numpy().copy(),
+            "grad/f1": f1g.grad.numpy(), "grad/f2": f2g.grad.numpy()})
+        print("  grads", float(dg.grad.abs().sum()), float(pg.grad.abs().sum()), float(R.delta.grad))
         # pose refinement step (utils.py:219-236, 303-368): PoseUpdate.direct_align without --robust_pose_loss
         g2 = torch.Generator().manual_seed(seed + 100)
         f2s = (0.8 * f1 + 0.2 * f2).half().float()  # a target that resembles the source, so the step is well conditioned

@@ -65,3 +65,29 @@ def test_depthbins_lookup_oracle_reproduces_reference(tag):
         corr0 = E.corr_all_channels(f1, E.pyramid(f2, 2), c0, 1)
         for got, key in ((c0, "out/c0_"), (ds0, "out/ds0_"), (corr0, "out/corr0_")):
             assert np.array_equal(got.numpy(), z[key + name]), key + name
+
+
+GRAD_CASES = ["epi_grad_b2_c16_12x20_r4_l3", "epi_grad_b1_c8_9x13_r2_l2_h2"]
+
+
+def oracle_lookup_grads(K, depth, poses, f1, f2, r, L, heads, delta, w_corr, w_ds, w_mx):
+    """autograd through the restated lookup with the fixture's cotangents -> grads w.r.t. depth, poses, delta, f1, f2"""
+    dg, pg = depth.clone().requires_grad_(True), poses.clone().requires_grad_(True)
+    f1g, f2g = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    dl = delta.clone().requires_grad_(True)
+    c, max_dx, ds = E.depth2epipolarcoords(pg, dg, K, dl, r=r, num_levels=L)
+    corr = E.coord_sample(f1g, E.pyramid(f2g, L), c, L, heads)
+    ((corr * w_corr).sum() + (ds * w_ds).sum() + (max_dx * w_mx).sum()).backward()
+    return {"depth": dg.grad, "poses": pg.grad, "delta": dl.grad, "f1": f1g.grad, "f2": f2g.grad}
+
+
+@pytest.mark.parametrize("tag", GRAD_CASES)
+def test_lookup_vjp_oracle_reproduces_reference(tag):
+    """gradients of the lookup taken by autograd through the reference's own Reprojections / CoordSampler
+    (oracle/gen_golden_epi.py) = autograd through the restatement, bit for bit"""
+    z, K, depth, poses, f1, f2, r, L, heads, delta = load(tag.replace("epi_grad_", "epi_"))
+    zg = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    t = lambda k: torch.from_numpy(zg[k])
+    g = oracle_lookup_grads(K, depth, poses, f1, f2, r, L, heads, delta, t("in/w_corr"), t("in/w_ds"), t("in/w_mx"))
+    for k, v in g.items():
+        assert np.array_equal(v.numpy().reshape(zg["grad/" + k].shape), zg["grad/" + k]), k

@@ -69,11 +69,14 @@ def test_dualrefine_size_against_the_cpu_checker():
     check(run(K, depth, poses, f1, f2, r, L, 1, 0.7), (rc, rmax, rds, rcorr))
 
 
-def test_forward_only_is_enforced():
+def test_forward_only_is_enforced_where_no_vjp_exists():
+    """the lookup is differentiable; the pose-refinement step is not yet and refuses tensors that require grad"""
     from mal_amd import epipolar, _lib
-    S = epipolar.CoordSampler(_args(2, 1))
+    R = epipolar.Reprojections(_args(2, 1)).to(DEV)
+    K = torch.eye(4, device=DEV).repeat(1, 1, 1)
+    R._reg_intrinsics(K)
     with pytest.raises(_lib.MalError):
-        S.register(torch.randn(1, 4, 8, 8, device=DEV, requires_grad=True), torch.randn(1, 4, 8, 8, device=DEV))
+        R.depth2gradcoords(torch.eye(4, device=DEV)[None], torch.ones(1, 1, 8, 8, device=DEV, requires_grad=True))
 
 
 def _align_case(i):
@@ -152,3 +155,63 @@ def test_depthbins_lookup_golden():
             near = (rc.abs() < 1e4)
             assert ((c0.cpu() - rc).abs()[near] <= 1e-4 * rc.abs()[near].clamp(min=1.0)).all()
             assert (corr0.cpu() - rcorr).abs().max() <= 1e-4 * max(1.0, float(rcorr.abs().max()))
+
+
+# ------------------------------------------------------------------ VJPs of the lookup (round 2)
+def run_grads(K, depth, poses, f1, f2, r, L, heads, delta, w_corr, w_ds, w_mx):
+    from mal_amd import epipolar
+    d = lambda t: t.to(DEV)
+    R = epipolar.Reprojections(_args(r, L)).to(DEV)
+    with torch.no_grad():
+        R.delta.fill_(float(delta))
+    R._reg_intrinsics(d(K))
+    dg, pg = d(depth).clone().requires_grad_(True), d(poses).clone().requires_grad_(True)
+    f1g, f2g = d(f1).clone().requires_grad_(True), d(f2).clone().requires_grad_(True)
+    c, max_dx, ds = R.depth2epipolarcoords(pg, dg)
+    S = epipolar.CoordSampler(_args(r, L))
+    S.register(f1g, f2g, num_levels=L)
+    corr = S(c, L, heads)
+    ((corr * d(w_corr)).sum() + (ds * d(w_ds)).sum() + (max_dx * d(w_mx)).sum()).backward()
+    torch.cuda.synchronize()
+    return {"depth": dg.grad.cpu(), "poses": pg.grad.cpu(), "delta": R.delta.grad.cpu(), "f1": f1g.grad.cpu(), "f2": f2g.grad.cpu()}
+
+
+def check_grads(got, ref, n_pix):
+    for k, r in ref.items():
+        g = got[k].reshape(r.shape)
+        sc = float(r.abs().max())
+        if k in ("poses", "delta"):  # sums over all pixels and hypotheses
+            assert float((g - r).abs().max()) <= 1e-4 * sc + 1e-6, (k, float((g - r).abs().max()), sc)
+        else:
+            # a sample within rounding distance of a tap boundary takes the neighbouring taps (value continuous, slope
+            # not): a handful of elements, the rest at 1e-4 of the map's scale
+            bad = ((g - r).abs() > 1e-4 * sc).float().mean().item()
+            assert bad <= 2e-4 + 4.0 / g.numel(), (k, bad)
+            assert float(np.linalg.norm((g - r).numpy().ravel()) / np.linalg.norm(r.numpy().ravel())) <= 2e-3, k
+
+
+@pytest.mark.parametrize("tag", ["epi_grad_b2_c16_12x20_r4_l3", "epi_grad_b1_c8_9x13_r2_l2_h2"])
+def test_lookup_vjp_golden(tag):
+    """gradients of the lookup against those autograd takes through the reference's own classes (the fixture)"""
+    import os
+    from tests.test_epi_oracle import GOLDEN
+    z, K, depth, poses, f1, f2, r, L, heads, delta = load(tag.replace("epi_grad_", "epi_"))
+    zg = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    t = lambda k: torch.from_numpy(zg[k])
+    got = run_grads(K, depth, poses, f1, f2, r, L, heads, float(delta), t("in/w_corr"), t("in/w_ds"), t("in/w_mx"))
+    check_grads(got, {k: t("grad/" + k) for k in ("depth", "poses", "delta", "f1", "f2")}, depth.numel())
+
+
+def test_lookup_vjp_dualrefine_size():
+    """B=8, 128 channels, 48x160, radius 8, 3 levels: against autograd through the CPU checker"""
+    from oracle.gen_golden_epi import make_case
+    from tests.test_epi_oracle import oracle_lookup_grads
+    B, C, h, w, r, L, heads = 8, 128, 48, 160, 8, 3, 1
+    K, depth, poses, f1, f2 = make_case(B, C, h, w, seed=31)
+    g = torch.Generator().manual_seed(32)
+    D = L * (2 * r + 1)
+    w_corr, w_ds, w_mx = torch.randn(B, D * heads, h, w, generator=g), 0.1 * torch.randn(B, 1, D, h, w, generator=g), torch.randn(B, 1, h, w, generator=g)
+    delta = torch.tensor([0.7])
+    ref = oracle_lookup_grads(K, depth, poses, f1, f2, r, L, heads, delta, w_corr, w_ds, w_mx)
+    got = run_grads(K, depth, poses, f1, f2, r, L, heads, 0.7, w_corr, w_ds, w_mx)
+    check_grads(got, ref, depth.numel())
