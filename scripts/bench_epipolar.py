@@ -25,6 +25,20 @@ with torch.no_grad():
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(20): hip()
     torch.cuda.synchronize(); th = (time.perf_counter() - t) / 20
+# ---- the same lookup forward + backward (the DEQ solver differentiates through it in training)
+dg, pg = g[1].clone().requires_grad_(True), g[2].clone().requires_grad_(True)
+f1g, f2g = g[3].clone().requires_grad_(True), g[4].clone().requires_grad_(True)
+def hip_fb():
+    for t_ in (dg, pg, f1g, f2g):
+        t_.grad = None
+    c, max_dx, ds = R.depth2epipolarcoords(pg, dg)
+    S2 = epipolar.CoordSampler(args)
+    S2.register(f1g, f2g, num_levels=L)
+    S2(c, L, 1).sum().backward()
+for _ in range(3): hip_fb()
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(10): hip_fb()
+torch.cuda.synchronize(); tfb = (time.perf_counter() - t) / 10
 D = L * (2 * r + 1)
 alg = B * h * w * (2 * C * 4 + D * 4 + 2 * D * 4 + 4)  # both feature maps once, the correlation, the coordinates
 
@@ -67,4 +81,6 @@ print("bound: vector-memory address path: %.1f M dword wave-loads -> %.1f G wave
       "lie several rows apart under these synthetic poses" %
       (wave_loads / 1e6, wave_loads / th / 1e9, wave_loads / th / WAVE_LOAD_CEILING[1], WAVE_LOAD_CEILING[1] / 1e9,
        wave_loads / th / WAVE_LOAD_CEILING[4], WAVE_LOAD_CEILING[4] / 1e9))
+print("lookup forward + backward (VJPs w.r.t. depth, pose, delta, both feature maps; the scatter into the feature pyramid uses "
+      "float atomics, %.2f G lane-adds): HIP %.0f us" % (B * h * w * D * C * 4 / 1e9, tfb * 1e6))
 print("direct_align: HIP %.0f us (gradcoords + normal equations + solve/se3 update kernel)   CPU checker %.2f s" % (ta * 1e6, tca))
