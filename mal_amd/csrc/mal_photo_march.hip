@@ -156,6 +156,12 @@ __global__ __launch_bounds__(64, 4) void photo_march_fwd_kernel(PhotoMarchParams
   }
 }
 
+// FUSED (the temporal hint inside the whole-step list): the forward of the pair -- r of both candidates, the running min
+// continued from prev_min / prev_arg, the automask, the outputs and the per-task sums of photo_march_fwd_kernel -- is
+// formed in the same sweep instead of being read back from the argmin / weight maps of an earlier launch.  Halo rows
+// and lanes re-decide their pixels (same arithmetic as the owner: the window sums are direction-symmetric and these
+// kernels do not flip), so the outputs must not alias prev_min / prev_arg.
+template <bool FUSED>
 __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams p) {
   constexpr int HALO = 2, CW = 60;
   const int id = blockIdx.x;
@@ -190,6 +196,7 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
   float y1b = 0.f, y2b = 0.f;
   float w1 = 0.f;  // weight and winner of row c-1 = r-2
   int win1 = 255;
+  float acc_rw = 0.f, acc_w = 0.f;  // FUSED: sum rp*w, sum w over the pixels this task owns
   auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
   const int r_first = max(y_lo - HALO, -1), r_last = y_hi - 1 + HALO;
   Px9 nxt;
@@ -201,10 +208,18 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
     const bool c_valid = c >= 0 && c < H && c >= y_lo - 1 && c <= y_hi;
     float w0 = 0.f;
     int win0 = 255;
+    float pm = 0.f, idn = 0.f;  // FUSED: running min of the earlier candidates, identity term (+ noise) of the centre row
     if (c_valid) {
       const unsigned go = (unsigned)(c * W + gxr);
-      w0 = in_x ? ldf(p.weight_in + map_b, go * 4u) : 0.f;  // not a pixel: contributes nothing
-      win0 = p.argmin_in[map_b + go];
+      if (!FUSED) {
+        w0 = in_x ? ldf(p.weight_in + map_b, go * 4u) : 0.f;  // not a pixel: contributes nothing
+        win0 = p.argmin_in[map_b + go];
+      } else {
+        pm = ldf(p.prev_min + map_b, go * 4u);
+        win0 = p.prev_arg[map_b + go];
+        idn = ldf(p.ident + map_b, go * 4u);
+        if (p.noise) idn += ldf(p.noise + map_b, go * 4u) * 0.00001f;
+      }
     }
     const f2 x0[3] = {(f2){cur.a[0], cur.a[1]}, (f2){cur.c[0], cur.c[1]}, (f2){cur.a[2], cur.c[2]}};
     const f2 y0rg = (f2){cur.t[0], cur.t[1]};
@@ -229,19 +244,44 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
       const float syz = (hzA[0] + hz[0]) + hzB[0], syyz = (hzA[1] + hz[1]) + hzB[1];
       const f2 vyq = fma2(-syq, syq, bc(9.0f) * syyq), d1yq = fma2(syq, syq, bc(kC1s));
       const float vyz = fma_(-syz, syz, 9.0f * syyz), d1yz = fma_(syz, syz, kC1s);
-      const float kk = -w0 * (0.85f / 3.0f) * 0.5f;
-      const float kk0 = win0 == p.idx[0] ? kk : 0.f, kk1 = win0 == p.idx[1] ? kk : 0.f;
+      f2 vraw[3], pa[3], pb[3], pc[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const f2 sx = (hsA[k * 3] + h[k * 3]) + hsB[k * 3], sxx = (hsA[k * 3 + 1] + h[k * 3 + 1]) + hsB[k * 3 + 1],
                  sxy = (hsA[k * 3 + 2] + h[k * 3 + 2]) + hsB[k * 3 + 2];
-        f2 pa, pb, pc;
-        const f2 v = ssim_sums2<true>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
-                                      &pa, &pb, &pc);
+        vraw[k] = ssim_sums2<true>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
+                                   &pa[k], &pb[k], &pc[k]);
+      }
+      if (FUSED) {  // the forward of this pair at the centre row, exactly as photo_march_fwd_kernel forms it
+        const f2 vc0 = (f2){clamp01(vraw[0].x), clamp01(vraw[0].y)}, vc1 = (f2){clamp01(vraw[1].x), clamp01(vraw[1].y)},
+                 vc2 = (f2){clamp01(vraw[2].x), clamp01(vraw[2].y)};
+        const f2 ssum = (f2){(vc0.x + vc0.y) + vc2.x, (vc1.x + vc1.y) + vc2.y};
+        const f2 l0 = y1rg - x1[0], l1 = y1rg - x1[1], l2 = bc(y1b) - x1[2];
+        const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
+        const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
+        float rp = pm;  // running min, first minimum wins (torch.min)
+        if (rr.x < rp) { rp = rr.x; win0 = p.idx[0]; }
+        if (rr.y < rp) { rp = rr.y; win0 = p.idx[1]; }
+        const float w = (rp <= idn) ? 1.0f : 0.0f;
+        w0 = in_x ? w : 0.f;
+        if (out_x && c >= y_lo && c < y_hi) {
+          const unsigned go = (unsigned)(c * W + gxr);
+          stf(p.min_reproj + map_b, go * 4u, rp);
+          p.argmin[map_b + go] = (uint8_t)win0;
+          stf(p.weight_out + map_b, go * 4u, w);
+          acc_rw += rp * w;
+          acc_w += w;
+        }
+      }
+      const float kk = -w0 * (0.85f / 3.0f) * 0.5f;
+      const float kk0 = win0 == p.idx[0] ? kk : 0.f, kk1 = win0 == p.idx[1] ? kk : 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
         // torch.clamp passes gradient on [0,1] inclusive (clamped == raw)
+        const f2 v = vraw[k];
         const float ka = k == 1 ? kk1 : kk0, kb = k == 0 ? kk0 : kk1;
         const f2 g = (f2){clamp01(v.x) == v.x ? ka : 0.f, clamp01(v.y) == v.y ? kb : 0.f};
-        coef[k * 3 + 0] = g * pa; coef[k * 3 + 1] = g * pb; coef[k * 3 + 2] = g * pc;
+        coef[k * 3 + 0] = g * pa[k]; coef[k * 3 + 1] = g * pb[k]; coef[k * 3 + 2] = g * pc[k];
       }
     }
     // ---- horizontal sums of the partial planes of row c
@@ -289,6 +329,10 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
     for (int k = 0; k < 3; ++k) { x2[k] = x1[k]; x1[k] = x0[k]; }
     y2rg = y1rg; y2b = y1b; y1rg = y0rg; y1b = y0b;
     w1 = w0; win1 = win0;
+  }
+  if (FUSED) {
+    const double r0 = wave_sum_d((double)acc_rw), r1 = wave_sum_d((double)acc_w);
+    if (lane == 0) { p.block_sums[(size_t)task * 2] = r0; p.block_sums[(size_t)task * 2 + 1] = r1; }
   }
 }
 
@@ -448,24 +492,6 @@ int photo_march_fwd(const float* target, const float* const* cand, int n_cand, c
   return launch_status();
 }
 
-// one more pair (indices idx0, idx0+1) on top of a running min / argmin that is already in min_reproj / argmin (the
-// temporal hint of the whole-step list: the warped candidates' min comes from the marching pass); this is the last
-// pair: weight (automask) and the per-task partials [task][2] are formed.  *per_sample_out = tasks per sample.
-int photo_march_fwd_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
-                         const float* noise, int B, int H, int W, float* min_reproj, uint8_t* argmin, float* weight_out,
-                         double* block_sums, int* per_sample_out, hipStream_t st) {
-  PhotoMarchParams p = {};
-  p.target = target; p.B = B; p.H = H; p.W = W;
-  p.cand[0] = cand0; p.cand[1] = cand1; p.idx[0] = idx0; p.idx[1] = idx0 + 1;
-  p.prev_min = min_reproj; p.prev_arg = argmin; p.last = 1; p.automask = 1;
-  p.ident = ident; p.noise = noise;
-  p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;
-  decompose(p, 62, 4);
-  *per_sample_out = p.strips * p.segs;
-  hipLaunchKernelGGL(photo_march_fwd_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
-  return launch_status();
-}
-
 int photo_march_bwd(const float* target, const float* const* cand, int n_cand, const uint8_t* argmin, const float* weight,
                     const float* scale, const double* sums, int B, int H, int W, float* const* g_cand, hipStream_t st) {
   for (int pr = 0; pr < (n_cand + 1) / 2; ++pr) {
@@ -479,8 +505,28 @@ int photo_march_bwd(const float* target, const float* const* cand, int n_cand, c
     p.cand[1] = i1 >= 0 ? cand[i1] : cand[i0]; p.idx[1] = i1; p.g_cand[1] = i1 >= 0 ? g_cand[i1] : nullptr;
     p.argmin_in = argmin; p.weight_in = weight; p.scale = scale; p.sums = sums;
     decompose(p, 60, 2);
-    hipLaunchKernelGGL(photo_march_bwd_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(photo_march_bwd_kernel<false>, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
   }
+  return launch_status();
+}
+
+// The temporal hint of the whole-step list in ONE sweep: candidates (cand0, cand1) = indices (idx0, idx0+1) join the
+// running min prev_min / prev_arg (which must not alias the outputs), automask against ident (+ noise), outputs
+// min_reproj / argmin / weight_out, per-task partials [task][2], and d sum(rp*w) / d candidate, unnormalised.
+int photo_march_fused_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
+                           const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
+                           float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
+                           float* g_cand1, int* per_sample_out, hipStream_t st) {
+  if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
+  PhotoMarchParams p = {};
+  p.target = target; p.B = B; p.H = H; p.W = W;
+  p.cand[0] = cand0; p.cand[1] = cand1; p.idx[0] = idx0; p.idx[1] = idx0 + 1;
+  p.prev_min = prev_min; p.prev_arg = prev_arg; p.ident = ident; p.noise = noise;
+  p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;
+  p.g_cand[0] = g_cand0; p.g_cand[1] = g_cand1;
+  decompose(p, 60, 2);
+  *per_sample_out = p.strips * p.segs;
+  hipLaunchKernelGGL(photo_march_bwd_kernel<true>, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
   return launch_status();
 }
 

@@ -22,11 +22,10 @@
 namespace mal {
 
 // mal_photo_march.hip: the materialised-candidate kernels (the two synthesised images of the temporal hint)
-int photo_march_fwd_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
-                         const float* noise, int B, int H, int W, float* min_reproj, uint8_t* argmin, float* weight_out,
-                         double* block_sums, int* per_sample_out, hipStream_t st);
-int photo_march_bwd(const float* target, const float* const* cand, int n_cand, const uint8_t* argmin, const float* weight,
-                    const float* scale, const double* sums, int B, int H, int W, float* const* g_cand, hipStream_t st);
+int photo_march_fused_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
+                           const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
+                           float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
+                           float* g_cand1, int* per_sample_out, hipStream_t st);
 
 constexpr int kLossSlots = 16;
 
@@ -40,6 +39,7 @@ struct StepWs {
   // temporal hint: winner of the four-way min (0/1 warped, 2/3 syn) and automask weight of the teacher, the
   // materialised-candidate kernel's per-task partials [task][2], what the step remembers between its calls
   unsigned char* arg_t; float* w_t; double* bs_ph;
+  float* rp_warp; unsigned char* arg_warp;  // ... and min_f r(warp_f) / its winner as the pass in front of the producer leaves them
   double* ps;         // per-sample sums of the teacher's, then the student's partials: [2][B][8]
   unsigned* ticket;   // completion counter of step_final_kernel
   double* sm_stats;   // [4B]: mean_t[b], mean_s[b], corr_t[b], corr_s[b] of the mean-normalised smoothness
@@ -65,6 +65,8 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   w.arg_t = (unsigned char*)take((size_t)B * HW);
   w.w_t = (float*)take(map);
   w.bs_ph = (double*)take(nb * 2 * 8);
+  w.rp_warp = (float*)take(map);
+  w.arg_warp = (unsigned char*)take((size_t)B * HW);
   w.ps = (double*)take((size_t)2 * B * 8 * 8);
   w.ticket = (unsigned*)take(4);
   w.sm_stats = (double*)take((size_t)4 * B * 8);
@@ -356,9 +358,9 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   int per_sample_p = 1;
   rc = first_sweep(a, w, st, &per_sample_p);
   if (rc) return rc;
-  MarchParams p = teacher_params(a, w, a->mono_reproj ? a->mono_reproj : w.mono_reproj);
+  MarchParams p = teacher_params(a, w, w.rp_warp);
   p.block_sums = w.bs_t;
-  p.color_out[0] = a->warp_m1; p.color_out[1] = a->warp_p1; p.argmin_out = w.arg_t;
+  p.color_out[0] = a->warp_m1; p.color_out[1] = a->warp_p1; p.argmin_out = w.arg_warp;
   p.color_out_stride = a->warp_sample_stride;
   return march_launch(p, MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
 }
@@ -388,18 +390,14 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
     if (rc) return rc;
   } else {
-    // mal_loss_step_warp ran the first sweep and left min_f r(warp_f) / its winner in mono_reproj / arg_t: the two
+    // mal_loss_step_warp ran the first sweep and left min_f r(warp_f) / its winner in rp_warp / arg_warp: the two
     // synthesised images join the running min (first minimum wins, as torch.min over [warp-1, warp+1, syn-1, syn+1],
     // loss_utils.py:79-90,103), the automask and the teacher's sums are formed over all four, and the gradient w.r.t.
     // the synthesised images leaves unnormalised
     if (!a->syn_m1 || !a->syn_p1 || !a->g_syn_m1 || !a->g_syn_p1) return MAL_EINVAL;
     per_sample_p = pack_identity_tasks_per_sample(H, W);
-    rc = photo_march_fwd_more(a->color0, a->syn_m1, a->syn_p1, 2, w.ident, a->noise, B, H, W, mono_reproj, w.arg_t, w.w_t,
-                              w.bs_ph, &per_sample_ph, st);
-    if (rc) return rc;
-    const float* cand[4] = {a->syn_m1, a->syn_p1, a->syn_m1, a->syn_p1};
-    float* g_cand[4] = {nullptr, nullptr, a->g_syn_m1, a->g_syn_p1};
-    rc = photo_march_bwd(a->color0, cand, 4, w.arg_t, w.w_t, nullptr, nullptr, B, H, W, g_cand, st);
+    rc = photo_march_fused_more(a->color0, a->syn_m1, a->syn_p1, 2, w.ident, a->noise, w.rp_warp, w.arg_warp, B, H, W,
+                                mono_reproj, w.arg_t, w.w_t, w.bs_ph, a->g_syn_m1, a->g_syn_p1, &per_sample_ph, st);
     if (rc) return rc;
   }
   // ensemble pass (no gradient)
