@@ -50,14 +50,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a HIP graph (default); 0: eager launches")
-    ap.add_argument("--mode", choices=["step", "distil", "ops", "temporal", "train", "multiscale"], default="step",
+    ap.add_argument("--mode", choices=["step", "distil", "ops", "temporal", "train", "multiscale", "multiscale_ops"], default="step",
                     help="step: --temporal --distil through mal_loss_step (BASELINE configs[1], the headline: three library "
                          "calls around the temporal-hint producer); distil: --distil only (one C call per direction); "
                          "ops: the operator-level API; "
                          "temporal: --temporal --distil through the operator-level API; train: the whole training step "
                          "of the harness (RepDepth networks + loss step + flat-bucket all-reduce + Adam, eager); "
                          "multiscale: the non-distil compute_losses with sclm=3 (four disparity scales, "
-                         "manydepth/trainer.py:1248-1475) through the operator-level API")
+                         "manydepth/trainer.py:1248-1475) for both networks through mal_loss_multiscale (one C call per "
+                         "direction); multiscale_ops: the same through the operator-level API")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mal_set_option before the run (kernel experiments, e.g. march_rows=16)")
@@ -127,7 +128,7 @@ class Step:
         from mal_amd.synthetic import make_batch
         # no host randn / H2D on the step: the whole-step API draws the tie-break noise inside its first
         # kernel (Philox, keyed per rank); the operator-level modes use the device generator
-        config.noise_source = "philox" if mode in ("step", "distil") else "cuda"
+        config.noise_source = "philox" if mode in ("step", "distil", "multiscale") else "cuda"
         config.noise_seed = 0x4d414c5eed + seed
         config.consistency_target = False  # logging-only map (loss_utils.py:212-215)
         self.one = torch.ones((), dtype=torch.float32, device=dev)  # d(loss)/d(loss): handed to backward, no fill launch
@@ -153,7 +154,7 @@ class Step:
             self.synth = synth
             self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, temporal=True), fuse=True,
                                        image_synthesis=synth)
-        elif mode == "multiscale":
+        elif mode in ("multiscale", "multiscale_ops"):
             # --scales 0..3 semantics (sclm=3): per-scale disparities upsampled to full resolution, loss
             # / 2**scale, total / (sclm+1); the shipped decoder only feeds scale 0, so the lower scales are pooled copies
             self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, sclm=3, distil=False), fuse=True)
@@ -181,13 +182,26 @@ class Step:
                                                    image_synthesis=self.synth)
             losses["loss"].backward(gradient=self.one)
             return losses["loss"]
+        if self.mode == "multiscale":  # trainer.py:573-612 with not opt.distil, both networks, four scales: one call
+            mono_outputs = {("disp", 0): lv["disp_teacher"]}
+            for f, s in ((-1, "m1"), (1, "p1")):
+                mono_outputs[("axisangle", 0, f)] = lv["axisangle_" + s]
+                mono_outputs[("translation", 0, f)] = lv["translation_" + s]
+            outputs = {("disp", 0): lv["disp_student"], "consistency_mask": self.cmask, "augmentation_mask": self.aug,
+                       "lowest_cost": self.lowest}
+            for sc in (1, 2, 3):
+                mono_outputs[("disp", sc)] = lv["disp_teacher_s%d" % sc]
+                outputs[("disp", sc)] = lv["disp_student_s%d" % sc]
+            losses, _ = self.step_mod.loss_step_multiscale(self.lp.opt, self.inputs, mono_outputs, outputs, want_maps=False)
+            losses["loss"].backward(gradient=self.one)
+            return losses["loss"]
         self.ops.clear_packed_sources()  # a real step sees new images: repack them every step
         T_m1 = L.transformation_from_parameters(lv["axisangle_m1"], lv["translation_m1"], True)
         T_p1 = L.transformation_from_parameters(lv["axisangle_p1"], lv["translation_p1"], False)
         mono_outputs = {("disp", 0): lv["disp_teacher"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1}
         outputs = {("disp", 0): lv["disp_student"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1,
                    "consistency_mask": self.cmask, "augmentation_mask": self.aug, "lowest_cost": self.lowest}
-        if self.mode == "multiscale":  # trainer.py:573-612 with not opt.distil: compute_losses for both nets
+        if self.mode == "multiscale_ops":  # trainer.py:573-612 with not opt.distil: compute_losses for both nets, op by op
             for sc in (1, 2, 3):
                 mono_outputs[("disp", sc)] = lv["disp_teacher_s%d" % sc]
                 outputs[("disp", sc)] = lv["disp_student_s%d" % sc]
@@ -485,7 +499,8 @@ def main():
                    "launch": "hip-graph" if args.graph and graph_note is None else (graph_note or "eager"),
                    "clock_ramp": "0.1 s of untimed steps before the --warmup steps (sustained clocks)",
                    "api": {"step": "mal_loss_step_warp/_fwd/_bwd (three host calls around the producer)",
-                           "distil": "mal_loss_step_fwd/_bwd (one host call per direction)"}.get(
+                           "distil": "mal_loss_step_fwd/_bwd (one host call per direction)",
+                           "multiscale": "mal_loss_multiscale_fwd/_bwd (one host call per direction)"}.get(
                                args.mode, "operator-level (mal_amd.loss_utils / MALLossPath)")},
     }
     if breakdown is not None:

@@ -306,6 +306,51 @@ size_t mal_step_workspace_bytes(int B, int H, int W);
 int mal_loss_step_fwd(const mal_step_args* args);
 int mal_loss_step_bwd(const mal_step_args* args);
 
+/* ---- the loss half of process_batch WITHOUT --distil and with sclm > 0 (BASELINE.json configs[1] runs the four-scale
+ * decoder): manydepth/trainer.py:573-612 calling compute_losses (:1248-1475) for the teacher and for the student over
+ * scales 0..sclm, after generate_images_pred (:1078-1170) upsampled each scale's disparity to full resolution
+ * (bilinear, align_corners=False) and warped the full-resolution sources with it.  Per scale s:
+ *   teacher  reproj_s = sum(min_f r * automask) / (sum automask + 1e-7), identity term from the raw sources + 1e-5 noise_s
+ *   student  mask m = consistency_mask (x matching mask, :592-593, when lowest_cost is given) x (1 - augmentation_mask);
+ *            reproj_s over m;  consistency_s = mean |depth_student_s - depth_teacher_s| (1 - m)
+ *   both     + 1e-3 * smooth(disp_s / mean disp_s, color_s) / 2**s        (disp_s, color_s at the scale's own size)
+ * total = (sum_s loss_teacher_s + sum_s loss_student_s) / (sclm + 1).  One host call forward (first sweep, upsampling,
+ * 2 marching launches + 2 smoothness sweeps per scale, one reduction), one backward (adjoint upsampling, gathered in a
+ * fixed order: no atomics).  --v1_multiscale, --ensemble, --no_ssim and the temporal hint are not covered (MAL_EINVAL
+ * is not how they fail: the Python mirror routes them through the operator-level API).                              */
+enum { MAL_MS_MAX_SCALES = 4 };
+typedef struct mal_ms_args {
+  int B, H, W, sclm;                              /* scale s is (H >> s, W >> s); H, W divisible by 2**sclm */
+  float min_depth, max_depth;
+  int flags;                                      /* MAL_STEP_AUG_MASK, MAL_STEP_NOISE_PHILOX */
+  const float *color0, *color_m1, *color_p1;      /* (B,3,H,W) */
+  const float *color0_s[MAL_MS_MAX_SCALES];       /* inputs[("color",0,s)]: (B,3,H>>s,W>>s); [0] NULL = color0 */
+  const float *K, *inv_K;                         /* (B,16) */
+  const float *disp_teacher[MAL_MS_MAX_SCALES], *disp_student[MAL_MS_MAX_SCALES]; /* (B,1,H>>s,W>>s) */
+  const float *axisangle_m1, *translation_m1, *axisangle_p1, *translation_p1;     /* (B,3) */
+  const float *consistency_mask;                  /* (B,H,W) */
+  const float *augmentation_keep;                 /* (B) */
+  const float *lowest_cost;                       /* (B,H,W) nullable: no matching mask */
+  const float *noise[MAL_MS_MAX_SCALES];          /* (B,1,H,W) each, all NULL with MAL_STEP_NOISE_PHILOX */
+  uint64_t noise_seed, noise_step; uint64_t* noise_counter;
+  float *losses;                                  /* 48: [net][scale][reproj, consistency, smooth, loss] (net 0 teacher),
+                                                     [32] teacher total, [33] student total, [34] their sum,
+                                                     [36+s] reproj student+teacher, [40+s] loss student+teacher */
+  float *loss_total;                              /* nullable: receives losses[34] */
+  float *consistency_mask_out;                    /* (B,H,W) nullable */
+  const float *g_total;                           /* backward: device scalar, nullable = 1 */
+  float *g_disp_teacher[MAL_MS_MAX_SCALES], *g_disp_student[MAL_MS_MAX_SCALES];   /* backward outputs, nullable */
+  float *g_axisangle_m1, *g_translation_m1, *g_axisangle_p1, *g_translation_p1;
+  void *ws; size_t ws_bytes; void *stream;
+} mal_ms_args;
+size_t mal_ms_workspace_bytes(int B, int H, int W, int sclm);
+int mal_loss_multiscale_fwd(const mal_ms_args* args);
+int mal_loss_multiscale_bwd(const mal_ms_args* args);
+/* F.interpolate(x, [H, W], mode="bilinear", align_corners=False) of a (B,1,h,w) map and its adjoint (a gather in a
+ * fixed order), as the step uses them (tests) */
+int mal_upsample_bilinear(const float* x, int B, int h, int w, int H, int W, float* out, void* stream);
+int mal_upsample_bilinear_adjoint(const float* g_out, int B, int h, int w, int H, int W, float* g_x, void* stream);
+
 /* ---- N2: the temporal-hint producer's per-sample arithmetic, manydepth/dyn_utils.py:6-119 --------
  * (fill_dynamic_obj + generate_dynamic_instance), given the matched instance masks of the two warped frames
  * (num,H,W as bytes, non-zero = set; Mask2Former and the matcher stay outside).  Per instance the displacement

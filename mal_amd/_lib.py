@@ -81,6 +81,11 @@ SIGNATURES = {
     "mal_loss_step_bwd": (i32, [vp]),
     "mal_loss_step_warp": (i32, [vp]),
     "mal_tiebreak_noise": (i32, [C.c_uint64, C.c_uint64, i32, i32, i32, c_fp, vp]),
+    "mal_ms_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "mal_loss_multiscale_fwd": (i32, [vp]),
+    "mal_loss_multiscale_bwd": (i32, [vp]),
+    "mal_upsample_bilinear": (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, vp]),
+    "mal_upsample_bilinear_adjoint": (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, vp]),
     "mal_set_option": (i32, [C.c_char_p, i32]),
     "mal_event_create": (vp, []),
     "mal_event_destroy": (i32, [vp]),
@@ -112,6 +117,21 @@ class StepArgs(C.Structure):
                 [("warp_sample_stride", i32)])
 
 
+class MsArgs(C.Structure):
+    """mal_ms_args (include/mal_hip.h)."""
+    _fields_ = ([("B", i32), ("H", i32), ("W", i32), ("sclm", i32), ("min_depth", f32), ("max_depth", f32), ("flags", i32)] +
+                [(n, vp) for n in ("color0", "color_m1", "color_p1")] + [("color0_s", vp * 4), ("K", vp), ("inv_K", vp),
+                 ("disp_teacher", vp * 4), ("disp_student", vp * 4)] +
+                [(n, vp) for n in ("axisangle_m1", "translation_m1", "axisangle_p1", "translation_p1", "consistency_mask",
+                                   "augmentation_keep", "lowest_cost")] +
+                [("noise", vp * 4), ("noise_seed", C.c_uint64), ("noise_step", C.c_uint64), ("noise_counter", vp),
+                 ("losses", vp), ("loss_total", vp), ("consistency_mask_out", vp), ("g_total", vp),
+                 ("g_disp_teacher", vp * 4), ("g_disp_student", vp * 4)] +
+                [(n, vp) for n in ("g_axisangle_m1", "g_translation_m1", "g_axisangle_p1", "g_translation_p1", "ws")] +
+                [("ws_bytes", sz), ("stream", vp)])
+
+
+MS_MAX_SCALES = 4
 STEP_NO_ENS, STEP_AUG_MASK, STEP_NOISE_PHILOX, STEP_TEMPORAL = 1, 2, 4, 8
 # decision planes of mal_step_args.dec_teacher / dec_student (MAL_DEC_*)
 DEC_WIN, DEC_DISTIL, DEC_SMOOTH_X, DEC_SMOOTH_Y, DEC_TAP0, DEC_TAP1, DEC_L1, DEC_PLANES = 0, 1, 2, 3, 4, 5, 6, 7

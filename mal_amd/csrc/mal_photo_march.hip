@@ -430,8 +430,9 @@ __global__ __launch_bounds__(1024) void smooth_march_finish_kernel(const double*
 }
 
 // partial: [>= B*tasks][4]; stats [2B]; sums [2B]
-int smooth_march(const float* disp, const float* img, int B, int H, int W, int normalise, float* gn, double* partial,
-                 double* stats, double* sums, double* loss_out, hipStream_t st) {
+// the sweep alone: gn (unnormalised gradient map) and the per-task partials [task][4]; tasks of a sample are contiguous
+int smooth_march_sweep(const float* disp, const float* img, int B, int H, int W, float* gn, double* partial,
+                       hipStream_t st, int* per_sample) {
   SmoothMarchParams p = {};
   p.disp = disp; p.img = img; p.gn = gn; p.partial = partial; p.B = B; p.H = H; p.W = W;
   p.strips = (W + 61) / 62;
@@ -439,8 +440,16 @@ int smooth_march(const float* disp, const float* img, int B, int H, int W, int n
   p.segs = (H + p.rows - 1) / p.rows;
   p.ntasks = B * p.strips * p.segs;
   p.per_xcd = (p.ntasks + 7) / 8;
+  if (per_sample) *per_sample = p.strips * p.segs;
   hipLaunchKernelGGL(smooth_march_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
-  hipLaunchKernelGGL(smooth_march_finish_kernel, dim3(1), dim3(1024), 0, st, partial, p.strips * p.segs, B, H, W, normalise,
+  return launch_status();
+}
+int smooth_march(const float* disp, const float* img, int B, int H, int W, int normalise, float* gn, double* partial,
+                 double* stats, double* sums, double* loss_out, hipStream_t st) {
+  int per_sample = 1;
+  int rc = smooth_march_sweep(disp, img, B, H, W, gn, partial, st, &per_sample);
+  if (rc) return rc;
+  hipLaunchKernelGGL(smooth_march_finish_kernel, dim3(1), dim3(1024), 0, st, partial, per_sample, B, H, W, normalise,
                      stats, sums, loss_out);
   return launch_status();
 }

@@ -274,14 +274,28 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
 using namespace mal;
 
 namespace mal {
-__global__ void tiebreak_noise_kernel(unsigned long long seed, unsigned long long step, int B, int H, int W, float* out) {
+// blockIdx.y = map k of `maps`: step number (counter ? *counter : step) * mult + k
+struct NoiseMaps { float* out[4]; };
+__global__ void tiebreak_noise_kernel(unsigned long long seed, unsigned long long step, const unsigned long long* counter,
+                                      unsigned mult, int B, int H, int W, NoiseMaps maps) {
   const int HW = H * W;
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= (size_t)B * HW) return;
   const int b = (int)(i / HW), pix = (int)(i - (size_t)b * HW), y = pix / W, x = pix - y * W;
+  const unsigned long long st = (counter ? *counter : step) * mult + blockIdx.y;
   float n[4];
-  tie_noise4(seed, step, (unsigned)(b * HW + (y & ~3) * W + x), n);
-  out[i] = n[y & 3];
+  tie_noise4(seed, st, (unsigned)(b * HW + (y & ~3) * W + x), n);
+  maps.out[blockIdx.y][i] = n[y & 3];
+}
+// n <= 4 noise maps in one launch (the multi-scale step draws one per scale: step number = step * mult + k)
+int tiebreak_noise_launch(unsigned long long seed, unsigned long long step, const unsigned long long* counter, unsigned mult,
+                          int n, int B, int H, int W, float* const* out, hipStream_t st) {
+  NoiseMaps maps = {};
+  for (int k = 0; k < n; ++k) maps.out[k] = out[k];
+  const size_t px = (size_t)B * H * W;
+  hipLaunchKernelGGL(tiebreak_noise_kernel, dim3((unsigned)((px + 255) / 256), n), dim3(256), 0, st, seed, step, counter, mult,
+                     B, H, W, maps);
+  return launch_status();
 }
 }  // namespace mal
 
@@ -289,10 +303,7 @@ extern "C" int mal_tiebreak_noise(uint64_t seed, uint64_t step, int B, int H, in
   int rc = check_shape(B, H, W);
   if (rc) return rc;
   if (!out) return MAL_EINVAL;
-  const size_t n = (size_t)B * H * W;
-  hipLaunchKernelGGL(tiebreak_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
-                     step, B, H, W, out);
-  return launch_status();
+  return tiebreak_noise_launch(seed, step, nullptr, 1u, 1, B, H, W, &out, (hipStream_t)stream);
 }
 
 extern "C" size_t mal_step_workspace_bytes(int B, int H, int W) {

@@ -1,0 +1,506 @@
+// mal_loss_multiscale_fwd / _bwd: the loss half of process_batch without --distil and with sclm > 0
+// (manydepth/trainer.py:573-612 -> compute_losses, :1248-1475, for the teacher and for the student; generate_images_pred,
+// :1078-1170, upsamples every scale's disparity to full resolution and warps the full-resolution sources with it) as one
+// host call per direction.
+//
+// The operator-level route issues, per step at sclm = 3, 16 fused passes + 8 identity terms + 8 smoothness operators and
+// ~250 ATen launches of glue between them (F.interpolate and its atomics-scattered backward, the per-scale scalar
+// arithmetic, autograd's accumulation): 1.8 ms at B=12 192x640.  Here:
+//
+//   forward  1 first sweep (identity term, texel packing, poses, camera block)           shared by all scales
+//            1 noise launch (Philox, one map per scale)   1 upsampling launch (all scales, both networks)
+//            per scale: teacher pass (fwd + gradient), student pass (fwd + gradient + consistency), 2 smoothness sweeps
+//            1 reduction: per-sample sums, pose gradients per scale, loss scalars, coefficients of the backward
+//   backward 1 launch: per (network, scale) the adjoint of the upsampling as a GATHER in a fixed order (ATen scatters
+//            with atomics) of the weighted gradient maps + the smoothness gradient; pose backward in its first block
+#include "mal_march.h"
+#include "mal_device.h"
+#include "mal_pose.h"
+
+namespace mal {
+
+// mal_photo_march.hip / mal_step.hip
+int smooth_march_sweep(const float* disp, const float* img, int B, int H, int W, float* gn, double* partial,
+                       hipStream_t st, int* per_sample);
+int tiebreak_noise_launch(unsigned long long seed, unsigned long long step, const unsigned long long* counter, unsigned mult,
+                          int n, int B, int H, int W, float* const* out, hipStream_t st);
+
+constexpr int kMsS = MAL_MS_MAX_SCALES;
+constexpr int kMsLossSlots = 48;
+
+struct MsWs {
+  float* packed[3]; float* T[2]; float* gTs[2]; float* cam; unsigned* ticket;
+  float* ident; float* cmask;
+  float* noise[kMsS];
+  float* up[2][kMsS];    // disparities of scale s >= 1 at full resolution (net 0 teacher, 1 student)
+  float* G_r[2][kMsS];   // d (sum rp*w) / d upsampled disparity, unnormalised
+  float* G_c[kMsS];      // d consistency_s / d upsampled student disparity, already weighted by 1/((sclm+1) N)
+  float* gn[2][kMsS];    // smoothness: d / d normalised disparity at the scale's own size
+  double* bs[2][kMsS]; float* bgP[kMsS]; double* sm[2][kMsS];
+  double* ps;            // [2S][B][8]
+  double* stats;         // [2][2S][B]: mean, mean-coupling term
+  float* gT;             // [S][2][B*16]
+  float* coefs;          // [3S]: cR[net*S + s], cS[s]
+  size_t bytes;
+};
+
+static MsWs carve_ms(void* base, int B, int H, int W, int sclm) {
+  MsWs w = {};
+  char* p = (char*)base;
+  size_t o = 0;
+  const int S = sclm + 1;
+  const size_t HW = (size_t)H * W, map = B * HW * sizeof(float), nb = ws_blocks(B, H, W);
+  auto take = [&](size_t bytes) { char* r = p + o; o += align256(bytes); return r; };
+  for (int i = 0; i < 3; ++i) w.packed[i] = (float*)take(B * HW * kTexel * sizeof(float));
+  for (int f = 0; f < 2; ++f) { w.T[f] = (float*)take(B * 16 * 4); w.gTs[f] = (float*)take(B * 16 * 4); }
+  w.cam = (float*)take((size_t)B * kCamFloats * 4);
+  w.ticket = (unsigned*)take(4);
+  w.ident = (float*)take(map); w.cmask = (float*)take(map);
+  for (int s = 0; s < S; ++s) {
+    w.noise[s] = (float*)take(map);
+    for (int n = 0; n < 2; ++n) {
+      w.up[n][s] = s ? (float*)take(map) : nullptr;
+      w.G_r[n][s] = (float*)take(map);
+      w.gn[n][s] = (float*)take(map >> (2 * s));
+      w.bs[n][s] = (double*)take(nb * 8 * 8);
+      w.sm[n][s] = (double*)take(nb * 4 * 8);
+    }
+    w.G_c[s] = (float*)take(map);
+    w.bgP[s] = (float*)take(nb * 24 * 4);
+  }
+  w.ps = (double*)take((size_t)2 * S * B * 8 * 8);
+  w.stats = (double*)take((size_t)2 * 2 * S * B * 8);
+  w.gT = (float*)take((size_t)S * 2 * B * 16 * 4);
+  w.coefs = (float*)take(3 * kMsS * 4);
+  w.bytes = o;
+  return w;
+}
+
+// ---------------------------------------------------------------- bilinear upsampling (align_corners=False) + adjoint
+// ATen's area_pixel_compute_source_index: src = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out (float);
+// i0 = (int)src, i1 = i0 + (i0 < in - 1), lambda1 = src - i0, lambda0 = 1 - lambda1.
+struct Tap { int i0, i1; float l0, l1; };
+MAL_DEV Tap tap_of(int dst, float scale, int n_in) {
+  float src = fma_(scale, (float)dst + 0.5f, -0.5f);  // contracted in ATen's builds (exact either way for power-of-two factors)
+  src = src < 0.f ? 0.f : src;
+  Tap t;
+  t.i0 = (int)src;
+  t.i1 = t.i0 + (t.i0 < n_in - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.0f - t.l1;
+  return t;
+}
+// weight with which output index `dst` reads input index `i`
+MAL_DEV float tap_weight(int dst, float scale, int n_in, int i) {
+  const Tap t = tap_of(dst, scale, n_in);
+  return (t.i0 == i ? t.l0 : 0.f) + (t.i1 == i ? t.l1 : 0.f);
+}
+
+// h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d) as ATen's builds contract it (device and host kernels alike, measured
+// bit for bit by scripts/upsample_probe.py): the first product of each sum becomes the fused multiply-add
+MAL_DEV float bilinear_value(float h0, float h1, float w0, float w1, float a, float b, float c, float d) {
+  const float top = fma_(w0, a, w1 * b), bot = fma_(w0, c, w1 * d);
+  return fma_(h0, top, h1 * bot);
+}
+
+struct UpMaps { const float* src[2 * kMsS]; float* dst[2 * kMsS]; int h[2 * kMsS], w[2 * kMsS]; };
+// blockIdx.y = map; one thread per output pixel; the value as ATen's CUDA kernel associates it:
+// h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d)
+__global__ __launch_bounds__(256) void upsample_kernel(UpMaps m, int B, int H, int W) {
+  const int k = blockIdx.y, h = m.h[k], w = m.w[k], HW = H * W;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * HW) return;
+  const int b = (int)(i / HW), pix = (int)(i - (size_t)b * HW), y = pix / W, x = pix - y * W;
+  const Tap ty = tap_of(y, (float)h / (float)H, h), tx = tap_of(x, (float)w / (float)W, w);
+  const float* s = m.src[k] + (size_t)b * h * w;
+  const float a = s[ty.i0 * w + tx.i0], bb = s[ty.i0 * w + tx.i1], c = s[ty.i1 * w + tx.i0], d = s[ty.i1 * w + tx.i1];
+  m.dst[k][i] = bilinear_value(ty.l0, ty.l1, tx.l0, tx.l1, a, bb, c, d);
+}
+
+// Adjoint as a gather: input pixel (i, j) of a map upsampled by f = H / h (a power of two <= 8) is read by the output
+// rows [f i - f/2, f i + 3f/2) and the same span of columns.  `f` adjacent lanes share one input pixel: lane k takes the
+// columns f j - f/2 + k and + f of every row of the span, the f partial sums are added by xor-shuffles (fixed order).
+// value gathered: ca * A + cb * Bm (Bm nullable).
+MAL_DEV float adjoint_gather(const float* __restrict__ A, float ca, const float* __restrict__ Bm, float cb, int i, int j,
+                             int k, int f, int h, int w, int H, int W) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const int X0 = f * j - (f >> 1) + k, X1 = X0 + f;
+  const bool in0 = X0 >= 0 && X0 < W, in1 = X1 >= 0 && X1 < W;
+  const float wx0 = in0 ? tap_weight(X0, sx, w, j) : 0.f, wx1 = in1 ? tap_weight(X1, sx, w, j) : 0.f;
+  const int c0 = in0 ? X0 : 0, c1 = in1 ? X1 : 0;
+  float acc = 0.f;
+  const int Y0 = f * i - (f >> 1);
+  for (int dy = 0; dy < 2 * f; ++dy) {
+    const int Y = Y0 + dy;
+    if (Y < 0 || Y >= H) continue;
+    const float wy = tap_weight(Y, sy, h, i);
+    float v0 = ca * A[Y * W + c0], v1 = ca * A[Y * W + c1];
+    if (Bm) { v0 = fma_(cb, Bm[Y * W + c0], v0); v1 = fma_(cb, Bm[Y * W + c1], v1); }
+    acc += wy * (wx0 * v0 + wx1 * v1);
+  }
+  for (int d = 1; d < f; d <<= 1) acc += __shfl_xor(acc, d);
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* g_out, int B, int h, int w, int H, int W, float* g_x) {
+  const int f = H / h;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t q = t / f;
+  const int k = (int)(t - q * f);
+  const bool live = q < (size_t)B * h * w;
+  const size_t qq = live ? q : 0;
+  const int b = (int)(qq / ((size_t)h * w)), pix = (int)(qq - (size_t)b * h * w), i = pix / w, j = pix - i * w;
+  const float v = adjoint_gather(g_out + (size_t)b * H * W, 1.0f, nullptr, 0.f, i, j, k, f, h, w, H, W);
+  if (live && k == 0) g_x[q] = v;
+}
+
+// ---------------------------------------------------------------- reduction + scalars
+struct MsFinal {
+  const double* bs[2][kMsS]; const double* sm[2][kMsS]; const float* bgP[kMsS]; int per_sample_sm[kMsS];
+  const float* K; int per_sample, B, H, W, S;
+  double* ps; double* stats; float* gT; float* losses; float* coefs; float* loss_total; unsigned* ticket;
+  unsigned long long* noise_counter;
+};
+
+// 2S*B blocks: ps[pass][b][j], pass = net*S + s: j < 4 from the marching pass's partials, j >= 4 the smoothness sweep's;
+// S*B blocks: g_T[s][f][b] = K_b^T [gP ; 0] from the teacher's per-task pose partials of scale s;
+// the block that finishes last: loss scalars (trainer.py:1447-1475) and the coefficients of the backward.
+__global__ __launch_bounds__(256) void ms_final_kernel(MsFinal p) {
+  __shared__ double s_part[256];
+  __shared__ double s_gP[24];
+  __shared__ double sh_tot[2 * kMsS][8];
+  __shared__ unsigned s_last;
+  const int tid = threadIdx.x, B = p.B, S = p.S;
+  if ((int)blockIdx.x < 2 * S * B) {
+    const int pass = blockIdx.x / B, b = blockIdx.x - pass * B, net = pass / S, s = pass - net * S;
+    const int j = tid & 7, sub = tid >> 3;
+    const int n_t = j < 4 ? p.per_sample : p.per_sample_sm[s];
+    const size_t stride = j < 4 ? 8 : 4;
+    const double* q = j < 4 ? p.bs[net][s] + (size_t)b * p.per_sample * 8 + j
+                            : p.sm[net][s] + (size_t)b * p.per_sample_sm[s] * 4 + (j - 4);
+    double acc = 0.0;
+#pragma unroll 8
+    for (int t = sub; t < n_t; t += 32) acc += q[(size_t)t * stride];
+    s_part[tid] = acc;
+    __syncthreads();
+    if (tid < 8) {
+      double a = 0.0;
+      for (int k = 0; k < 32; ++k) a += s_part[k * 8 + tid];
+      p.ps[((size_t)pass * B + b) * 8 + tid] = a;
+    }
+  } else {
+    const int r = blockIdx.x - 2 * S * B, s = r / B, b = r - s * B;
+    const int v = tid % 24, sub = tid / 24;
+    double acc = 0.0;
+    if (sub < 10) {
+#pragma unroll 8
+      for (int t = sub; t < p.per_sample; t += 10) acc += (double)p.bgP[s][((size_t)b * p.per_sample + t) * 24 + v];
+    }
+    s_part[tid] = acc;
+    __syncthreads();
+    if (tid < 24) {
+      double a = 0.0;
+      for (int k = 0; k < 10; ++k) a += s_part[k * 24 + tid];
+      s_gP[tid] = a;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int f = tid >> 4, e = tid & 15, k = e >> 2, j = e & 3;
+      const float* Kb = p.K + b * 16;
+      double a = 0.0;
+      for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
+      p.gT[((size_t)(s * 2 + f) * B + b) * 16 + e] = (float)a;
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(p.ticket, 1u);
+  __syncthreads();
+  if (s_last != gridDim.x - 1) return;
+  __threadfence();
+  // per-sample statistics of the smoothness gradient (mean of the scale's own disparity map)
+  for (int i = tid; i < 2 * S * B; i += 256) {
+    const int s = (i / B) % S;
+    const double hw = (double)((p.H >> s) * (p.W >> s));
+    const double* q = p.ps + (size_t)i * 8;
+    const double mean = q[7] / hw;
+    const double m = (double)((float)mean + 1e-7f);
+    p.stats[i] = mean;
+    p.stats[2 * S * B + i] = q[6] / (hw * m * m);
+  }
+  // sums over samples in sample order; the smoothness slots weighted by the sample's 1/(mean + 1e-7)
+  if (tid < 2 * S * 8) {
+    const int pass = tid >> 3, j = tid & 7, s = pass % S;
+    const double hw = (double)((p.H >> s) * (p.W >> s));
+    double a = 0.0;
+    for (int b = 0; b < B; ++b) {
+      const double* q = p.ps + ((size_t)pass * B + b) * 8;
+      double v = q[j];
+      if (j == 4 || j == 5) v = v * (double)div_(1.0f, (float)(q[7] / hw) + 1e-7f);
+      a += v;
+    }
+    sh_tot[pass][j] = a;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  if (p.noise_counter) *p.noise_counter += 1ull;
+  const double N = (double)B * p.H * p.W;
+  float total[2] = {0.f, 0.f};
+  for (int net = 0; net < 2; ++net)
+    for (int s = 0; s < S; ++s) {
+      const double* t = sh_tot[net * S + s];
+      const int h = p.H >> s, w = p.W >> s;
+      const double Nx = (double)B * h * (w - 1), Ny = (double)B * (h - 1) * w;
+      const float reproj = (float)(t[0] / (t[1] + 1e-7));
+      const float cons = net ? (float)(t[2] / N) : 0.f;
+      const float smooth = (float)(t[4] / Nx + t[5] / Ny);
+      const float loss = (net ? reproj + cons : reproj) + (1e-3f * smooth) / (float)(1 << s);
+      float* o = p.losses + (net * kMsS + s) * 4;
+      o[0] = reproj; o[1] = cons; o[2] = smooth; o[3] = loss;
+      total[net] += loss;
+      p.coefs[net * S + s] = (float)(1.0 / ((double)S * (t[1] + 1e-7)));
+    }
+  for (int net = 0; net < 2; ++net)
+    for (int s = S; s < kMsS; ++s)
+      for (int k = 0; k < 4; ++k) p.losses[(net * kMsS + s) * 4 + k] = 0.f;
+  for (int s = 0; s < S; ++s) p.coefs[2 * S + s] = (float)(1e-3 / ((double)(1 << s) * (double)S));
+  p.losses[32] = div_(total[0], (float)S);
+  p.losses[33] = div_(total[1], (float)S);
+  p.losses[34] = p.losses[33] + p.losses[32];
+  p.losses[35] = 0.f;
+  for (int s = 0; s < kMsS; ++s) {  // process_batch adds the teacher's entries to the student's (trainer.py:614-616)
+    p.losses[36 + s] = p.losses[(kMsS + s) * 4 + 0] + p.losses[s * 4 + 0];
+    p.losses[40 + s] = p.losses[(kMsS + s) * 4 + 3] + p.losses[s * 4 + 3];
+  }
+  for (int i = 44; i < kMsLossSlots; ++i) p.losses[i] = 0.f;
+  if (p.loss_total) *p.loss_total = p.losses[34];
+}
+
+// ---------------------------------------------------------------- backward
+struct MsAssemble {
+  const float* G_r[2][kMsS]; const float* G_c[kMsS]; const float* gn[2][kMsS]; float* g_disp[2][kMsS];
+  const float* coefs; const double* stats; const float* g_total; const float* gT;
+  float* gTs0; float* gTs1;
+  int B, H, W, S;
+};
+
+// blockIdx.y = net*S + s.  g_disp[net][s] = adjoint-upsample(cR * G_r + g * G_c) + cS * (gn / (mean+eps) - corr);
+// block (0,0) also sums the pose gradients over the scales and runs the backward of transformation_from_parameters
+__global__ __launch_bounds__(256) void ms_assemble_kernel(MsAssemble p, PoseParams pp, int pose_bwd) {
+  const int pass = blockIdx.y, S = p.S, net = pass / S, s = pass - net * S, B = p.B;
+  const float g = p.g_total ? *p.g_total : 1.0f;
+  if (blockIdx.x == 0 && pass == 0) {
+    for (int i = threadIdx.x; i < B * 16; i += 256) {
+      float a0 = 0.f, a1 = 0.f;
+      for (int k = 0; k < S; ++k) {
+        const float c = p.coefs[k] * g;
+        a0 = fma_(c, p.gT[(size_t)(k * 2 + 0) * B * 16 + i], a0);
+        a1 = fma_(c, p.gT[(size_t)(k * 2 + 1) * B * 16 + i], a1);
+      }
+      p.gTs0[i] = a0; p.gTs1[i] = a1;
+    }
+    __syncthreads();
+    if (pose_bwd)
+      for (int i = threadIdx.x; i < B * 2; i += 256) pose_bwd_one(pp, i / B, i % B);
+  }
+  float* out = p.g_disp[net][s];
+  if (!out) return;
+  const int f = 1 << s, h = p.H >> s, w = p.W >> s, hw = h * w;
+  const float cR = p.coefs[pass] * g, cS = p.coefs[2 * S + s] * g;
+  const float* G_c = net ? p.G_c[s] : nullptr;
+  const size_t nthreads = (size_t)B * hw * f;
+  for (size_t t0 = blockIdx.x * (size_t)blockDim.x; t0 < nthreads; t0 += (size_t)gridDim.x * blockDim.x) {
+    const size_t t = t0 + threadIdx.x;
+    const size_t q = t / f;
+    const int k = (int)(t - q * f);
+    const bool live = q < (size_t)B * hw;
+    const size_t qq = live ? q : 0;
+    const int b = (int)(qq / hw), pix = (int)(qq - (size_t)b * hw);
+    float v;
+    if (s == 0) {
+      v = cR * p.G_r[net][0][qq];
+      if (G_c) v = fma_(g, G_c[qq], v);
+    } else {
+      const int i = pix / w, j = pix - i * w;
+      const size_t ob = (size_t)b * p.H * p.W;
+      v = adjoint_gather(p.G_r[net][s] + ob, cR, G_c ? G_c + ob : nullptr, g, i, j, k, f, h, w, p.H, p.W);
+    }
+    if (live && k == 0) {
+      const float inv = div_(1.0f, (float)p.stats[pass * B + b] + 1e-7f);
+      const float corr = (float)p.stats[2 * S * B + pass * B + b];
+      out[q] = v + cS * (p.gn[net][s][q] * inv - corr);
+    }
+  }
+}
+
+}  // namespace mal
+
+using namespace mal;
+
+static int ms_check(const mal_ms_args* a) {
+  if (!a) return MAL_EINVAL;
+  int rc = check_shape(a->B, a->H, a->W);
+  if (rc) return rc;
+  if (a->sclm < 0 || a->sclm >= kMsS) return MAL_EINVAL;
+  const int f = 1 << a->sclm;
+  if (a->H % f || a->W % f || (a->H >> a->sclm) < 2 || (a->W >> a->sclm) < 2) return MAL_ESHAPE;
+  if (!a->color0 || !a->color_m1 || !a->color_p1 || !a->K || !a->inv_K || !a->axisangle_m1 || !a->translation_m1 ||
+      !a->axisangle_p1 || !a->translation_p1 || !a->consistency_mask || !a->augmentation_keep || !a->losses || !a->ws)
+    return MAL_EINVAL;
+  for (int s = 0; s <= a->sclm; ++s) {
+    if (!a->disp_teacher[s] || !a->disp_student[s] || (s && !a->color0_s[s])) return MAL_EINVAL;
+    if ((a->flags & MAL_STEP_NOISE_PHILOX) && a->noise[s]) return MAL_EINVAL;
+  }
+  if (a->ws_bytes < carve_ms(nullptr, a->B, a->H, a->W, a->sclm).bytes) return MAL_EWORKSPACE;
+  return MAL_OK;
+}
+
+extern "C" size_t mal_ms_workspace_bytes(int B, int H, int W, int sclm) {
+  if (B <= 0 || H <= 0 || W <= 0 || sclm < 0 || sclm >= kMsS) return 0;
+  return carve_ms(nullptr, B, H, W, sclm).bytes;
+}
+
+extern "C" int mal_upsample_bilinear(const float* x, int B, int h, int w, int H, int W, float* out, void* stream) {
+  if (!x || !out || B <= 0 || h <= 0 || w <= 0 || H < h || W < w) return MAL_EINVAL;
+  UpMaps m = {};
+  m.src[0] = x; m.dst[0] = out; m.h[0] = h; m.w[0] = w;
+  const size_t n = (size_t)B * H * W;
+  hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream, m, B, H, W);
+  return launch_status();
+}
+
+extern "C" int mal_upsample_bilinear_adjoint(const float* g_out, int B, int h, int w, int H, int W, float* g_x, void* stream) {
+  if (!g_out || !g_x || B <= 0 || h <= 0 || w <= 0) return MAL_EINVAL;
+  const int f = h ? H / h : 0;
+  if ((f != 1 && f != 2 && f != 4 && f != 8) || H != h * f || W != w * f) return MAL_ESHAPE;
+  const size_t n = (size_t)B * h * w * f;
+  hipLaunchKernelGGL(upsample_adjoint_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_out, B, h,
+                     w, H, W, g_x);
+  return launch_status();
+}
+
+extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
+  int rc = ms_check(a);
+  if (rc) return rc;
+  const int B = a->B, H = a->H, W = a->W, S = a->sclm + 1;
+  MsWs w = carve_ms(a->ws, B, H, W, a->sclm);
+  hipStream_t st = (hipStream_t)a->stream;
+  // 1. first sweep: identity term (no noise: every scale adds its own), texel packing, poses, camera block
+  {
+    StepPoses sp = {};
+    sp.pose.B = B; sp.pose.F = 2;
+    sp.pose.axisangle[0] = a->axisangle_m1; sp.pose.axisangle[1] = a->axisangle_p1;
+    sp.pose.translation[0] = a->translation_m1; sp.pose.translation[1] = a->translation_p1;
+    sp.pose.invert[0] = 1; sp.pose.invert[1] = 0;
+    sp.pose.T[0] = w.T[0]; sp.pose.T[1] = w.T[1];
+    sp.K = a->K; sp.invK = a->inv_K; sp.cam = w.cam; sp.ticket = w.ticket;
+    rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
+                              &sp, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  const float* noise[kMsS];
+  for (int s = 0; s < S; ++s) noise[s] = a->noise[s];
+  if (a->flags & MAL_STEP_NOISE_PHILOX) {
+    rc = tiebreak_noise_launch(a->noise_seed, a->noise_step, (const unsigned long long*)a->noise_counter, (unsigned)S, S, B, H, W,
+                               w.noise, st);
+    if (rc) return rc;
+    for (int s = 0; s < S; ++s) noise[s] = w.noise[s];
+  }
+  // 2. every scale's disparity at full resolution (trainer.py:1094-1096)
+  if (S > 1) {
+    UpMaps m = {};
+    int k = 0;
+    for (int s = 1; s < S; ++s)
+      for (int n = 0; n < 2; ++n, ++k) {
+        m.src[k] = n ? a->disp_student[s] : a->disp_teacher[s];
+        m.dst[k] = w.up[n][s]; m.h[k] = H >> s; m.w[k] = W >> s;
+      }
+    const size_t px = (size_t)B * H * W;
+    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((px + 255) / 256), k), dim3(256), 0, st, m, B, H, W);
+    rc = launch_status();
+    if (rc) return rc;
+  }
+  const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
+  const float merge_cons = (float)(1.0 / ((double)S * (double)B * H * W));
+  int per_sample = 1;
+  MsFinal fin = {};
+  for (int s = 0; s < S; ++s) {
+    const float* disp_t = s ? w.up[0][s] : a->disp_teacher[0];
+    const float* disp_s = s ? w.up[1][s] : a->disp_student[0];
+    {  // teacher: automask against the identity term + this scale's noise (trainer.py:1296-1311)
+      MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
+      p.disp = disp_t; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+      p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+      p.ident = w.ident; p.noise = noise[s]; p.g_reproj = w.G_r[0][s];
+      p.block_sums = w.bs[0][s]; p.block_gP = w.bgP[s];
+      p.cam = w.cam; p.cam_ready = 1;
+      rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
+      if (rc) return rc;
+    }
+    {  // student: mask = consistency (x matching, formed at scale 0 from the teacher's scale-0 depth, trainer.py:592-593)
+       // x (1 - augmentation); consistency term against the teacher's depth of the same scale (:1330-1336)
+      MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
+      p.disp = disp_s; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+      p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+      p.sample_scale = a->augmentation_keep; p.sample_scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0;
+      p.mono_disp = disp_t;
+      if (s == 0) {
+        p.ext_mask = a->consistency_mask; p.lowest_cost = a->lowest_cost;
+        if (a->lowest_cost) p.cmask_out = a->consistency_mask_out ? a->consistency_mask_out : w.cmask;
+      } else {
+        p.ext_mask = a->lowest_cost ? (a->consistency_mask_out ? a->consistency_mask_out : w.cmask) : a->consistency_mask;
+      }
+      p.mono_reproj = w.ident;  // the distillation selection is not part of this loss: any map serves, its term has weight 0
+      p.g_reproj = w.G_r[1][s]; p.g_cons = w.G_c[s]; p.g_distil = nullptr;
+      p.merge_cons = merge_cons; p.merge_distil = 0.f;
+      p.block_sums = w.bs[1][s]; p.block_gP = w.bgP[s];
+      p.cam = w.cam; p.cam_ready = 1;
+      rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
+      if (rc) return rc;
+      per_sample = p.strips * p.segs;
+    }
+    // smoothness of both disparity maps at the scale's own size against the target at that size (:1469-1471)
+    const float* img = (s == 0 && !a->color0_s[0]) ? a->color0 : a->color0_s[s];
+    for (int n = 0; n < 2; ++n) {
+      rc = smooth_march_sweep(n ? a->disp_student[s] : a->disp_teacher[s], img, B, H >> s, W >> s, w.gn[n][s], w.sm[n][s], st,
+                              &fin.per_sample_sm[s]);
+      if (rc) return rc;
+      fin.bs[n][s] = w.bs[n][s]; fin.sm[n][s] = w.sm[n][s];
+    }
+    fin.bgP[s] = w.bgP[s];
+  }
+  fin.K = a->K; fin.per_sample = per_sample; fin.B = B; fin.H = H; fin.W = W; fin.S = S;
+  fin.ps = w.ps; fin.stats = w.stats; fin.gT = w.gT; fin.losses = a->losses; fin.coefs = w.coefs;
+  fin.loss_total = a->loss_total; fin.ticket = w.ticket;
+  fin.noise_counter = (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr;
+  hipLaunchKernelGGL(ms_final_kernel, dim3(3 * S * B), dim3(256), 0, st, fin);
+  return launch_status();
+}
+
+extern "C" int mal_loss_multiscale_bwd(const mal_ms_args* a) {
+  int rc = ms_check(a);
+  if (rc) return rc;
+  const int B = a->B, H = a->H, W = a->W, S = a->sclm + 1;
+  MsWs w = carve_ms(a->ws, B, H, W, a->sclm);
+  MsAssemble p = {};
+  for (int s = 0; s < S; ++s) {
+    for (int n = 0; n < 2; ++n) { p.G_r[n][s] = w.G_r[n][s]; p.gn[n][s] = w.gn[n][s]; }
+    p.G_c[s] = w.G_c[s];
+    p.g_disp[0][s] = a->g_disp_teacher[s]; p.g_disp[1][s] = a->g_disp_student[s];
+  }
+  p.coefs = w.coefs; p.stats = w.stats; p.g_total = a->g_total; p.gT = w.gT; p.gTs0 = w.gTs[0]; p.gTs1 = w.gTs[1];
+  p.B = B; p.H = H; p.W = W; p.S = S;
+  PoseParams pp = {};
+  pp.B = B; pp.F = 2;
+  pp.axisangle[0] = a->axisangle_m1; pp.axisangle[1] = a->axisangle_p1;
+  pp.translation[0] = a->translation_m1; pp.translation[1] = a->translation_p1;
+  pp.invert[0] = 1; pp.invert[1] = 0;
+  pp.gT[0] = w.gTs[0]; pp.gT[1] = w.gTs[1];
+  pp.g_axisangle[0] = a->g_axisangle_m1; pp.g_axisangle[1] = a->g_axisangle_p1;
+  pp.g_translation[0] = a->g_translation_m1; pp.g_translation[1] = a->g_translation_p1;
+  const int pose_bwd = (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) ? 1 : 0;
+  size_t g = ((size_t)B * H * W + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(ms_assemble_kernel, dim3((unsigned)g, 2 * S), dim3(256), 0, (hipStream_t)a->stream, p, pp, pose_bwd);
+  return launch_status();
+}

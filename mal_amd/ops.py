@@ -416,3 +416,23 @@ def sum_f64(x):
     ws = workspace(x.device, 1, 2, 2)
     L.check(L.load().mal_sum_f64(_p(x), x.numel(), _p(out), _p(ws), ws.numel(), _stream()), "mal_sum_f64")
     return out
+
+
+# ------------------------------------------------------------------ per-scale disparity -> full resolution
+def upsample_bilinear(x, H, W):
+    """F.interpolate(x, [H, W], mode="bilinear", align_corners=False) of a (B,1,h,w) map (trainer.py:1094-1096), with
+    ATen's association of the four products"""
+    x = _req(x, "x")
+    B, _, h, w = x.shape
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    L.check(L.load().mal_upsample_bilinear(_p(x), B, h, w, H, W, _p(out), _stream()), "mal_upsample_bilinear")
+    return out
+
+
+def upsample_bilinear_adjoint(g_out, h, w):
+    """its adjoint for power-of-two factors <= 8, gathered in a fixed order (ATen scatters with atomics)"""
+    g_out = _req(g_out, "g_out")
+    B, _, H, W = g_out.shape
+    g = torch.empty((B, 1, h, w), dtype=torch.float32, device=g_out.device)
+    L.check(L.load().mal_upsample_bilinear_adjoint(_p(g_out), B, h, w, H, W, _p(g), _stream()), "mal_upsample_bilinear_adjoint")
+    return g

@@ -258,3 +258,141 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
               "smooth_loss/multi": v[5], "main/reproj_loss/0": v[3]}
     loss_list = [v[11], v[6]] if blc else None
     return losses, loss_list, maps
+
+
+# ---------------------------------------------------------------------------------- sclm > 0, no --distil
+_WS_MS = {}
+
+
+def _workspace_ms(dev, B, H, W, sclm):
+    need = L.load().mal_ms_workspace_bytes(B, H, W, sclm)
+    key = (dev.index, ops._stream(), B, H, W, sclm)
+    ws = _WS_MS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WS_MS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    return ws
+
+
+class MultiScaleLossFn(Function):
+    """leaves: disp_teacher[0..sclm], disp_student[0..sclm], axisangle_m1, translation_m1, axisangle_p1, translation_p1"""
+
+    @staticmethod
+    def forward(ctx, consts, cfg, *leaves):
+        colors, colors_s, K, inv_K, cmask, keep, lowest, noises = consts
+        min_depth, max_depth, sclm, aug_is_mask, philox, want_maps = cfg
+        S = sclm + 1
+        req, p = ops._req, ops._p
+        tens = [req(t, "leaf") for t in leaves]
+        cons = [req(t, "input") for t in (*colors, *colors_s, K, inv_K, cmask, keep)]
+        cons += [None if t is None else req(t, "input") for t in (lowest, *(noises or ()))]
+        B, _, H, W = tens[0].shape
+        dev = tens[0].device
+        for s in range(S):
+            for t in (tens[s], tens[S + s]):
+                if tuple(t.shape) != (B, 1, H >> s, W >> s):
+                    raise L.MalError("loss_step_multiscale: the disparity of scale %d must be (B,1,%d,%d)" % (s, H >> s, W >> s))
+        a = L.MsArgs()
+        a.B, a.H, a.W, a.sclm = B, H, W, sclm
+        a.min_depth, a.max_depth = float(min_depth), float(max_depth)
+        a.flags = L.STEP_AUG_MASK if aug_is_mask else 0
+        a.color0, a.color_m1, a.color_p1 = (p(t) for t in cons[:3])
+        for s in range(1, S):
+            a.color0_s[s] = p(cons[3 + s - 1])
+        o = 3 + sclm
+        a.K, a.inv_K, a.consistency_mask, a.augmentation_keep = (p(t) for t in cons[o:o + 4])
+        a.lowest_cost = p(cons[o + 4])
+        for s in range(S):
+            a.disp_teacher[s], a.disp_student[s] = p(tens[s]), p(tens[S + s])
+            if noises is not None:
+                a.noise[s] = p(cons[o + 5 + s])
+        a.axisangle_m1, a.translation_m1, a.axisangle_p1, a.translation_p1 = (p(t) for t in tens[2 * S:])
+        if philox is not None:
+            a.flags |= L.STEP_NOISE_PHILOX
+            a.noise_seed = int(philox) & 0xFFFFFFFFFFFFFFFF
+            a.noise_counter = noise_counter(dev).data_ptr()
+        losses = torch.empty(48, dtype=torch.float32, device=dev)
+        total = torch.empty(1, dtype=torch.float32, device=dev)
+        a.losses, a.loss_total = p(losses), p(total)
+        outs = [total, losses]
+        if want_maps and lowest is not None:
+            cm = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+            a.consistency_mask_out = p(cm)
+            outs.append(cm)
+        ws = _workspace_ms(dev, B, H, W, sclm)
+        a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
+        L.check(L.load().mal_loss_multiscale_fwd(C.byref(a)), "mal_loss_multiscale_fwd")
+        ctx.args, ctx.keep, ctx.S = a, (tens, cons, ws, losses, total), S
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*outs[1:])
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_total, *_):
+        tens, S = ctx.keep[0], ctx.S
+        if g_total is None:
+            return (None,) * (2 + len(tens))
+        g_total = g_total.reshape(1).contiguous()
+        a = ctx.args
+        grads = [torch.empty_like(t) if ctx.needs_input_grad[2 + i] else None for i, t in enumerate(tens)]
+        a.g_total = ops._p(g_total)
+        for s in range(S):
+            a.g_disp_teacher[s], a.g_disp_student[s] = ops._p(grads[s]), ops._p(grads[S + s])
+        a.g_axisangle_m1, a.g_translation_m1, a.g_axisangle_p1, a.g_translation_p1 = (ops._p(g) for g in grads[2 * S:])
+        L.check(L.load().mal_loss_multiscale_bwd(C.byref(a)), "mal_loss_multiscale_bwd")
+        return (None, None, *grads)
+
+
+def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_maps=True):
+    """process_batch's loss half WITHOUT ``--distil`` (manydepth/trainer.py:573-612 with ``compute_losses``, :1248-1475,
+    for both networks) over scales 0..``opt.sclm`` in one call per direction.  Reads ``inputs[("color", f, 0)]``,
+    ``("color", 0, s)``, ``("K", 0)``, ``("inv_K", 0)``; ``mono_outputs[("disp", s)]``, ``("axisangle", 0, f)``,
+    ``("translation", 0, f)``; ``outputs[("disp", s)]``, ``"consistency_mask"``, ``"augmentation_mask"`` and, when present,
+    ``"lowest_cost"`` (then the matching mask of trainer.py:592-593 is applied and ``outputs["consistency_mask"]``
+    rewritten).  ``noises``: one (B,1,H,W) N(0,1) map per scale (default: drawn as ``config.noise_source`` says).
+    Returns (losses, mono_losses): ``losses`` as process_batch leaves it (the teacher's entries added to the
+    student's, :614-616; ``losses["loss"]`` carries the gradient), ``mono_losses`` the teacher's own."""
+    from . import config, loss_utils
+    sclm = int(getattr(opt, "sclm", 0))
+    unsupported = [k for k in ("distil", "temporal", "v1_multiscale", "ensemble", "no_ssim", "disable_automasking",
+                               "disable_motion_masking", "no_matching_augmentation") if getattr(opt, k, False)]
+    if unsupported or sclm >= L.MS_MAX_SCALES or list(opt.frame_ids) != [0, -1, 1]:
+        raise L.MalError("loss_step_multiscale covers the non-distil sclm <= 3 configuration with frames [0,-1,1]; %s: use "
+                         "MALLossPath.compute_batch_losses" % (", ".join(unsupported) or "this configuration"))
+    color0 = inputs[("color", 0, 0)]
+    B, _, H, W = color0.shape
+    dev = color0.device
+    fix = lambda t: t[:, 0] if t.dim() == 4 else t
+    aa = {f: fix(mono_outputs[("axisangle", 0, f)]) for f in (-1, 1)}
+    tr = {f: fix(mono_outputs[("translation", 0, f)]) for f in (-1, 1)}
+    philox = None
+    if noises is None:
+        if config.noise_source == "philox":
+            philox = config.noise_seed
+        else:
+            noises = [loss_utils.draw_noise((B, 1, H, W), dev) for _ in range(sclm + 1)]
+            if config.noise_source == "cpu":
+                for _ in range(sclm + 1):
+                    torch.randn((B, 1, H, W))  # the student's dead draws (trainer.py:1305-1308,1325)
+    aug = outputs["augmentation_mask"][:opt.batch_size]
+    aug_is_mask = aug.dtype == torch.float32 and aug.is_contiguous()
+    keep = aug.reshape(B) if aug_is_mask else (1 - aug).to(torch.float32).reshape(B)
+    consts = ((color0, inputs[("color", -1, 0)], inputs[("color", 1, 0)]), [inputs[("color", 0, s)] for s in range(1, sclm + 1)],
+              inputs[("K", 0)], inputs[("inv_K", 0)], outputs["consistency_mask"].to(torch.float32), keep,
+              outputs.get("lowest_cost"), noises)
+    cfg = (opt.min_depth, opt.max_depth, sclm, aug_is_mask, philox, bool(want_maps))
+    leaves = [mono_outputs[("disp", s)] for s in range(sclm + 1)] + [outputs[("disp", s)] for s in range(sclm + 1)] + \
+             [aa[-1], tr[-1], aa[1], tr[1]]
+    res = MultiScaleLossFn.apply(consts, cfg, *leaves)
+    total, v = res[0].reshape(()), res[1]
+    if len(res) > 2:
+        outputs["consistency_mask"] = res[2]
+    losses, mono_losses = {"loss": total}, {"loss": v[32]}
+    for s in range(sclm + 1):
+        losses["reproj_loss/%d" % s], losses["loss/%d" % s] = v[36 + s], v[40 + s]
+        losses["consistency_loss/%d" % s] = v[(4 + s) * 4 + 1]
+        losses["main/reproj_loss/%d" % s], losses["main/loss/%d" % s] = v[(4 + s) * 4], v[(4 + s) * 4 + 3]
+        losses["smooth_loss/multi/%d" % s], mono_losses["smooth_loss/%d" % s] = v[(4 + s) * 4 + 2], v[s * 4 + 2]
+        mono_losses["reproj_loss/%d" % s], mono_losses["loss/%d" % s] = v[s * 4], v[s * 4 + 3]
+    losses["main/loss"] = v[33]
+    return losses, mono_losses

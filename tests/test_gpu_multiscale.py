@@ -1,0 +1,205 @@
+"""The non-distil, sclm > 0 loss half of process_batch as one library call per direction (mal_loss_multiscale_fwd/_bwd,
+manydepth/trainer.py:573-612 + :1078-1170 + :1248-1475): against the reference's own numbers (the four-scale fixture),
+against the CPU oracle at BASELINE.json's size, and against itself (in-kernel noise == the same noise handed in)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from mal_amd.synthetic import make_batch, to_dicts
+from oracle import mal_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    from mal_amd import build
+    build.build(verbose=False)
+
+
+def _l2rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 12, 48, 96), (1, 24, 80, 192, 640), (3, 10, 14, 20, 28), (2, 5, 7, 20, 28)])
+def test_upsampling_is_atens(shape):
+    from mal_amd import ops
+    B, h, w, H, W = shape
+    x = torch.rand(B, 1, h, w, generator=torch.Generator().manual_seed(5)).to(DEV)
+    up = ops.upsample_bilinear(x, H, W)
+    ref = torch.nn.functional.interpolate(x, [H, W], mode="bilinear", align_corners=False)
+    assert torch.equal(up, ref), float((up - ref).abs().max())  # ATen's device kernel: bit for bit
+    cpu = torch.nn.functional.interpolate(x.cpu(), [H, W], mode="bilinear", align_corners=False)
+    # the host kernel the oracle runs: the same bits on its vectorised path (wide rows), an ulp away on its scalar one
+    assert (up.cpu() - cpu).abs().max() <= 1.2e-7
+    # the adjoint (a gather in a fixed order) against autograd through ATen in float64
+    g = torch.randn(B, 1, H, W, generator=torch.Generator().manual_seed(6))
+    xd = x.cpu().double().requires_grad_(True)
+    (torch.nn.functional.interpolate(xd, [H, W], mode="bilinear", align_corners=False) * g.double()).sum().backward()
+    got = ops.upsample_bilinear_adjoint(g.to(DEV), h, w).cpu().double()
+    assert (got - xd.grad).abs().max() <= 2e-6 * xd.grad.abs().max()
+    again = ops.upsample_bilinear_adjoint(g.to(DEV), h, w).cpu().double()
+    assert torch.equal(got, again)  # deterministic
+
+
+def _hip_step(inputs, mono_outputs, outputs, leaves, kw, noises):
+    from mal_amd import step, trainer
+    for f, s in ((-1, "m1"), (1, "p1")):
+        mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + s]
+        mono_outputs[("translation", 0, f)] = leaves["translation_" + s]
+    losses, mono_losses = step.loss_step_multiscale(trainer.default_options(**kw), inputs, mono_outputs, outputs,
+                                                    noises=None if noises is None else [n.to(DEV) for n in noises])
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    return losses, mono_losses
+
+
+def _oracle_step(inputs, mono_outputs, outputs, kw, nt, ns, matching=False):
+    opt = O.default_opt(**kw)
+    O.generate_images_pred(opt, inputs, mono_outputs)
+    lt = O.compute_losses(opt, inputs, mono_outputs, is_multi=False, noises=[n.clone() for n in nt])
+    for key in list(mono_outputs.keys()):
+        if isinstance(key, tuple) and key[0] in ("depth", "disp"):
+            outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
+    if matching:  # trainer.py:592-593
+        outputs["consistency_mask"] = outputs["consistency_mask"] * O.compute_matching_mask(outputs)
+    O.generate_images_pred(opt, inputs, outputs, is_multi=True)
+    ls = O.compute_losses(opt, inputs, outputs, is_multi=True, noises=[n.clone() for n in ns])
+    (lt["loss"] + ls["loss"]).backward()
+    return lt, ls
+
+
+def test_four_scales_against_the_reference_fixture():
+    """sclm=3 (BASELINE configs[1]'s "4 scales"): the reference's own numbers for both networks' compute_losses over four
+    disparity scales (oracle/gen_golden.py run_reference_multiscale)"""
+    from tests import golden_io as G
+    z = G.load(G.MULTISCALE_CASE)
+    b, sclm, inputs, mono_outputs, outputs, leaves = G.multiscale_dicts(z, lambda a, t, inv: None, DEV)
+    outputs.pop("lowest_cost", None)  # the fixture calls compute_losses directly: no matching mask
+    B, _, H, W = b["color0"].shape
+    nt, _ = G.multiscale_noises(z, (B, 1, H, W), sclm)
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+    losses, mono_losses = _hip_step(inputs, mono_outputs, outputs, leaves, kw, nt)
+    N = B * H * W
+    got = {"teacher": mono_losses, "student": {k.replace("main/", ""): v for k, v in losses.items() if k.startswith("main/")}}
+    for s in range(sclm + 1):
+        got["student"]["consistency_loss/%d" % s] = losses["consistency_loss/%d" % s]
+    checked = 0
+    for who in ("teacher", "student"):
+        for k, v in got[who].items():
+            key = "%s/%s" % (who, k)
+            if key not in z:
+                continue
+            ref = float(z[key])
+            tie = 2.0 * (sclm + 1) / N if (who == "teacher" and ("reproj" in k or k.startswith("loss"))) else 0.0
+            assert abs(float(v) - ref) <= 2e-4 * abs(ref) + 1e-6 + tie, (who, k, float(v), ref)
+            checked += 1
+    assert checked >= 4 * (sclm + 1) + 2
+    total = float(z["teacher/loss"]) + float(z["student/loss"])
+    assert abs(float(losses["loss"].detach()) - total) <= 2e-4 * abs(total) + 2.0 * (sclm + 1) / N
+    renorm = 4.0 / N
+    for k, t in leaves.items():
+        g, r = t.grad.cpu().numpy(), z["grad/" + k].reshape(t.shape)
+        if g.ndim == 4:
+            bad = (np.abs(g - r) > (2e-4 + renorm) * np.abs(r).max()).mean()
+            assert bad <= (2e-2 if k[-1].isdigit() else 5e-3), (k, bad)
+        else:
+            assert _l2rel(g, r) <= 2e-2, k
+
+
+def _build(batch, dev, sclm):
+    inputs, mono_outputs, outputs, leaves = to_dicts(batch, O.transformation_from_parameters if dev == "cpu" else
+                                                      (lambda a, t, inv: None), device=dev)
+    for s in range(1, sclm + 1):
+        inputs[("color", 0, s)] = torch.nn.functional.avg_pool2d(batch["color0"], 2 ** s).to(dev)
+        for name, outs in (("disp_teacher", mono_outputs), ("disp_student", outputs)):
+            leaf = torch.nn.functional.avg_pool2d(batch[name], 2 ** s).to(dev).clone().requires_grad_(True)
+            leaves["%s_s%d" % (name, s)] = leaf
+            outs[("disp", s)] = leaf
+    return inputs, mono_outputs, outputs, leaves
+
+
+@pytest.mark.parametrize("case", [(12, 192, 640, 3, True), (3, 40, 72, 2, False), (2, 32, 64, 0, True)],
+                         ids=["baseline-b12-192x640-sclm3", "b3-40x72-sclm2", "b2-32x64-sclm0"])
+def test_against_the_oracle(case):
+    B, H, W, sclm, matching = case
+    batch = make_batch(B, H, W, seed=79)
+    g = torch.Generator().manual_seed(12)
+    nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+    oi, om, oo, ol = _build(batch, "cpu", sclm)
+    rt, rs = _oracle_step(oi, om, oo, kw, nt, nt, matching=matching)
+    hi, hm, ho, hl = _build(batch, DEV, sclm)
+    if not matching:
+        ho.pop("lowest_cost")
+    losses, mono_losses = _hip_step(hi, hm, ho, hl, kw, nt)
+    N = B * H * W
+    tie_t = 40.0 * (sclm + 1) / N
+    for k, v in rt.items():
+        assert abs(float(mono_losses[k]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + tie_t, ("teacher", k, float(mono_losses[k]), float(v))
+    for k, v in rs.items():
+        name = k if k.startswith("consistency") else "main/" + k
+        # a pixel whose matching-mask test sits at rounding distance moves the masked mean by <~ 1/N
+        assert abs(float(losses[name]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + (4.0 / N if matching else 0.0), (
+            "student", k, float(losses[name]), float(v))
+    for s in range(sclm + 1):  # process_batch's sums (trainer.py:614-616)
+        for k in ("reproj_loss/%d" % s, "loss/%d" % s):
+            assert abs(float(losses[k]) - (float(losses["main/" + k]) + float(mono_losses[k]))) <= 1e-6
+    if matching:
+        ref_mask = oo["consistency_mask"].numpy()
+        assert (ho["consistency_mask"].cpu().numpy() != ref_mask).mean() <= 1e-4
+    for k in hl:
+        gq, r = hl[k].grad.cpu().numpy(), ol[k].grad.numpy()
+        if gq.ndim == 4:
+            bad = (np.abs(gq - r) > 3e-4 * np.abs(r).max()).mean()
+            sc = int(k[-1]) if k[-1].isdigit() else 0
+            # near-tie pixels and their neighbourhoods: a few tens per map whatever its size
+            assert bad <= max(1e-3 * (1 + 4 ** sc / 8.0), 40.0 / gq.size), (k, bad)
+        else:
+            assert _l2rel(gq, r) <= 2e-2, (k, _l2rel(gq, r))
+
+
+def test_in_kernel_noise_equals_the_same_noise_handed_in():
+    from mal_amd import _lib, config, ops, step
+    B, H, W, sclm = 2, 48, 96, 3
+    S = sclm + 1
+    batch = make_batch(B, H, W, seed=5)
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+    old = config.noise_source, config.noise_seed
+    config.noise_source, config.noise_seed = "philox", 4242
+    try:
+        ctr = step.noise_counter(torch.device(DEV))
+        c0 = int(ctr.item())
+        hi, hm, ho, hl = _build(batch, DEV, sclm)
+        l1, m1 = _hip_step(hi, hm, ho, hl, kw, None)
+        assert int(ctr.item()) == c0 + 1
+        noises = []
+        for s in range(S):
+            out = torch.empty(B, 1, H, W, device=DEV)
+            _lib.check(_lib.load().mal_tiebreak_noise(C.c_uint64(4242), C.c_uint64(c0 * S + s), B, H, W, out.data_ptr(),
+                                                      ops._stream()), "mal_tiebreak_noise")
+            noises.append(out)
+        assert not torch.equal(noises[0], noises[1])
+        hi2, hm2, ho2, hl2 = _build(batch, DEV, sclm)
+        l2, m2 = _hip_step(hi2, hm2, ho2, hl2, kw, noises)
+        assert int(ctr.item()) == c0 + 1
+        assert float(l1["loss"]) == float(l2["loss"])
+        for k in hl:
+            assert torch.equal(hl[k].grad, hl2[k].grad), k
+    finally:
+        config.noise_source, config.noise_seed = old
+
+
+def test_unsupported_configurations_are_refused():
+    from mal_amd import _lib, step, trainer
+    batch = make_batch(2, 32, 64, seed=1)
+    hi, hm, ho, hl = _build(batch, DEV, 1)
+    with pytest.raises(_lib.MalError):
+        step.loss_step_multiscale(trainer.default_options(height=32, width=64, batch_size=2, sclm=1, distil=True), hi, hm, ho)
+    with pytest.raises(_lib.MalError):
+        step.loss_step_multiscale(trainer.default_options(height=32, width=64, batch_size=2, sclm=1, distil=False, ensemble=True),
+                                  hi, hm, ho)
