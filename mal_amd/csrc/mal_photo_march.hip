@@ -348,11 +348,8 @@ struct SmoothMarchParams {
   int B, H, W, strips, segs, rows, ntasks, per_xcd;
 };
 
-__global__ __launch_bounds__(64, 4) void smooth_march_kernel(SmoothMarchParams p) {
+MAL_DEV void smooth_march_task(const SmoothMarchParams& p, int task) {
   constexpr int HALO = 1, CW = 62;
-  const int id = blockIdx.x;
-  const int task = (id & 7) * p.per_xcd + (id >> 3);
-  if (task >= p.ntasks) return;
   const int per_b = p.strips * p.segs;
   const int b = task / per_b, tt = task - b * per_b;
   const int seg = tt / p.strips, strip = tt - seg * p.strips;
@@ -402,6 +399,26 @@ __global__ __launch_bounds__(64, 4) void smooth_march_kernel(SmoothMarchParams p
   if (lane == 0) { double* o = p.partial + (size_t)task * 4; o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; }
 }
 
+__global__ __launch_bounds__(64, 4) void smooth_march_kernel(SmoothMarchParams p) {
+  const int id = blockIdx.x;
+  const int task = (id & 7) * p.per_xcd + (id >> 3);
+  if (task >= p.ntasks) return;
+  smooth_march_task(p, task);
+}
+
+// several maps (of different sizes) in one launch: the multi-scale step sweeps 2 maps per scale, and the small ones are
+// all launch latency on their own.  first[k] = first task of map k, first[n] = total.
+constexpr int kSmoothBatch = 8;
+struct SmoothMarchBatch { SmoothMarchParams m[kSmoothBatch]; int first[kSmoothBatch + 1]; int n, per_xcd; };
+__global__ __launch_bounds__(64, 4) void smooth_march_batch_kernel(SmoothMarchBatch q) {
+  const int id = blockIdx.x;
+  const int task = (id & 7) * q.per_xcd + (id >> 3);
+  if (task >= q.first[q.n]) return;
+  int k = 0;
+  while (k + 1 < q.n && task >= q.first[k + 1]) ++k;
+  smooth_march_task(q.m[k], task - q.first[k]);
+}
+
 // per-sample sums over the tasks (contiguous), then loss, means, coupling terms: one workgroup, one wave per sample
 // (16 at a time), the loss summed over the samples in sample order
 __global__ __launch_bounds__(1024) void smooth_march_finish_kernel(const double* partial, int per_sample, int B, int H, int W,
@@ -442,6 +459,26 @@ int smooth_march_sweep(const float* disp, const float* img, int B, int H, int W,
   p.per_xcd = (p.ntasks + 7) / 8;
   if (per_sample) *per_sample = p.strips * p.segs;
   hipLaunchKernelGGL(smooth_march_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
+  return launch_status();
+}
+// n <= 8 maps in one launch; per_sample[k] receives the tasks per sample of map k
+int smooth_march_sweep_batch(int n, const float* const* disp, const float* const* img, int B, const int* H, const int* W,
+                             float* const* gn, double* const* partial, hipStream_t st, int* per_sample) {
+  if (n <= 0 || n > kSmoothBatch) return MAL_EINVAL;
+  SmoothMarchBatch q = {};
+  q.n = n;
+  for (int k = 0; k < n; ++k) {
+    SmoothMarchParams& p = q.m[k];
+    p.disp = disp[k]; p.img = img[k]; p.gn = gn[k]; p.partial = partial[k]; p.B = B; p.H = H[k]; p.W = W[k];
+    p.strips = (W[k] + 61) / 62;
+    p.rows = 12;
+    p.segs = (H[k] + p.rows - 1) / p.rows;
+    p.ntasks = B * p.strips * p.segs;
+    q.first[k + 1] = q.first[k] + p.ntasks;
+    if (per_sample) per_sample[k] = p.strips * p.segs;
+  }
+  q.per_xcd = (q.first[n] + 7) / 8;
+  hipLaunchKernelGGL(smooth_march_batch_kernel, dim3(q.per_xcd * 8), dim3(64), 0, st, q);
   return launch_status();
 }
 int smooth_march(const float* disp, const float* img, int B, int H, int W, int normalise, float* gn, double* partial,

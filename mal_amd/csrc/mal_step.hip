@@ -274,25 +274,29 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
 using namespace mal;
 
 namespace mal {
-// blockIdx.y = map k of `maps`: step number (counter ? *counter : step) * mult + k
+// blockIdx.y = map k of `maps`: step number (counter ? *counter : step) * mult + k.  One thread per pixel GROUP (the four
+// rows (y & ~3) .. + 3 of a column share one Philox block): consecutive threads = consecutive columns
 struct NoiseMaps { float* out[4]; };
 __global__ void tiebreak_noise_kernel(unsigned long long seed, unsigned long long step, const unsigned long long* counter,
                                       unsigned mult, int B, int H, int W, NoiseMaps maps) {
-  const int HW = H * W;
+  const int H4 = (H + 3) >> 2;
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= (size_t)B * HW) return;
-  const int b = (int)(i / HW), pix = (int)(i - (size_t)b * HW), y = pix / W, x = pix - y * W;
+  if (i >= (size_t)B * H4 * W) return;
+  const int x = (int)(i % W), row = (int)(i / W), y4 = row % H4, b = row / H4, y0 = y4 * 4;
   const unsigned long long st = (counter ? *counter : step) * mult + blockIdx.y;
   float n[4];
-  tie_noise4(seed, st, (unsigned)(b * HW + (y & ~3) * W + x), n);
-  maps.out[blockIdx.y][i] = n[y & 3];
+  tie_noise4(seed, st, (unsigned)(b * H * W + y0 * W + x), n);
+  float* o = maps.out[blockIdx.y] + (size_t)b * H * W + (size_t)y0 * W + x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (y0 + j < H) o[(size_t)j * W] = n[j];
 }
 // n <= 4 noise maps in one launch (the multi-scale step draws one per scale: step number = step * mult + k)
 int tiebreak_noise_launch(unsigned long long seed, unsigned long long step, const unsigned long long* counter, unsigned mult,
                           int n, int B, int H, int W, float* const* out, hipStream_t st) {
   NoiseMaps maps = {};
   for (int k = 0; k < n; ++k) maps.out[k] = out[k];
-  const size_t px = (size_t)B * H * W;
+  const size_t px = (size_t)B * ((H + 3) / 4) * W;
   hipLaunchKernelGGL(tiebreak_noise_kernel, dim3((unsigned)((px + 255) / 256), n), dim3(256), 0, st, seed, step, counter, mult,
                      B, H, W, maps);
   return launch_status();

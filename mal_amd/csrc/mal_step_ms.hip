@@ -20,8 +20,8 @@
 namespace mal {
 
 // mal_photo_march.hip / mal_step.hip
-int smooth_march_sweep(const float* disp, const float* img, int B, int H, int W, float* gn, double* partial,
-                       hipStream_t st, int* per_sample);
+int smooth_march_sweep_batch(int n, const float* const* disp, const float* const* img, int B, const int* H, const int* W,
+                             float* const* gn, double* const* partial, hipStream_t st, int* per_sample);
 int tiebreak_noise_launch(unsigned long long seed, unsigned long long step, const unsigned long long* counter, unsigned mult,
                           int n, int B, int H, int W, float* const* out, hipStream_t st);
 
@@ -104,42 +104,76 @@ MAL_DEV float bilinear_value(float h0, float h1, float w0, float w1, float a, fl
 }
 
 struct UpMaps { const float* src[2 * kMsS]; float* dst[2 * kMsS]; int h[2 * kMsS], w[2 * kMsS]; };
-// blockIdx.y = map; one thread per output pixel; the value as ATen's CUDA kernel associates it:
-// h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d)
+// grid (x chunks, B*H rows, maps); one thread per V consecutive output pixels of a row (V = 4 when W % 4 == 0: one 16-byte
+// store)
+template <int V>
 __global__ __launch_bounds__(256) void upsample_kernel(UpMaps m, int B, int H, int W) {
-  const int k = blockIdx.y, h = m.h[k], w = m.w[k], HW = H * W;
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= (size_t)B * HW) return;
-  const int b = (int)(i / HW), pix = (int)(i - (size_t)b * HW), y = pix / W, x = pix - y * W;
-  const Tap ty = tap_of(y, (float)h / (float)H, h), tx = tap_of(x, (float)w / (float)W, w);
-  const float* s = m.src[k] + (size_t)b * h * w;
-  const float a = s[ty.i0 * w + tx.i0], bb = s[ty.i0 * w + tx.i1], c = s[ty.i1 * w + tx.i0], d = s[ty.i1 * w + tx.i1];
-  m.dst[k][i] = bilinear_value(ty.l0, ty.l1, tx.l0, tx.l1, a, bb, c, d);
+  const int k = blockIdx.z, h = m.h[k], w = m.w[k];
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * V, row = blockIdx.y;
+  if (x0 >= W) return;
+  const int b = row / H, y = row - b * H;  // uniform: scalar unit
+  const Tap ty = tap_of(y, (float)h / (float)H, h);
+  const float* s0 = m.src[k] + (size_t)b * h * w + ty.i0 * w;
+  const float* s1 = m.src[k] + (size_t)b * h * w + ty.i1 * w;
+  float o[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const Tap tx = tap_of(x0 + v, (float)w / (float)W, w);
+    o[v] = bilinear_value(ty.l0, ty.l1, tx.l0, tx.l1, s0[tx.i0], s0[tx.i1], s1[tx.i0], s1[tx.i1]);
+  }
+  float* d = m.dst[k] + (size_t)row * W + x0;
+  if (V == 4) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+  else d[0] = o[0];
+}
+static void upsample_launch(const UpMaps& m, int n, int B, int H, int W, hipStream_t st) {
+  bool vec = W % 4 == 0;
+  for (int k = 0; k < n; ++k) vec = vec && ((uintptr_t)m.dst[k] % 16 == 0);
+  if (vec) hipLaunchKernelGGL(upsample_kernel<4>, dim3((W / 4 + 255) / 256, B * H, n), dim3(256), 0, st, m, B, H, W);
+  else hipLaunchKernelGGL(upsample_kernel<1>, dim3((W + 255) / 256, B * H, n), dim3(256), 0, st, m, B, H, W);
 }
 
 // Adjoint as a gather: input pixel (i, j) of a map upsampled by f = H / h (a power of two <= 8) is read by the output
 // rows [f i - f/2, f i + 3f/2) and the same span of columns.  `f` adjacent lanes share one input pixel: lane k takes the
 // columns f j - f/2 + k and + f of every row of the span, the f partial sums are added by xor-shuffles (fixed order).
 // value gathered: ca * A + cb * Bm (Bm nullable).
-MAL_DEV float adjoint_gather(const float* __restrict__ A, float ca, const float* __restrict__ Bm, float cb, int i, int j,
-                             int k, int f, int h, int w, int H, int W) {
+template <int F>
+MAL_DEV float adjoint_gather_f(const float* __restrict__ A, float ca, const float* __restrict__ Bm, float cb, int i, int j,
+                               int k, int h, int w, int H, int W) {
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-  const int X0 = f * j - (f >> 1) + k, X1 = X0 + f;
+  const int X0 = F * j - (F >> 1) + k, X1 = X0 + F;
   const bool in0 = X0 >= 0 && X0 < W, in1 = X1 >= 0 && X1 < W;
   const float wx0 = in0 ? tap_weight(X0, sx, w, j) : 0.f, wx1 = in1 ? tap_weight(X1, sx, w, j) : 0.f;
   const int c0 = in0 ? X0 : 0, c1 = in1 ? X1 : 0;
+  const int Y0 = F * i - (F >> 1);
+  // every load of the span issued before the first use: rows outside the map are clamped and carry weight 0
+  float va[2 * F][2], vb[2 * F][2];
+#pragma unroll
+  for (int dy = 0; dy < 2 * F; ++dy) {
+    const int Yc = min(max(Y0 + dy, 0), H - 1);
+    va[dy][0] = A[Yc * W + c0]; va[dy][1] = A[Yc * W + c1];
+    if (Bm) { vb[dy][0] = Bm[Yc * W + c0]; vb[dy][1] = Bm[Yc * W + c1]; }
+  }
   float acc = 0.f;
-  const int Y0 = f * i - (f >> 1);
-  for (int dy = 0; dy < 2 * f; ++dy) {
+#pragma unroll
+  for (int dy = 0; dy < 2 * F; ++dy) {
     const int Y = Y0 + dy;
-    if (Y < 0 || Y >= H) continue;
-    const float wy = tap_weight(Y, sy, h, i);
-    float v0 = ca * A[Y * W + c0], v1 = ca * A[Y * W + c1];
-    if (Bm) { v0 = fma_(cb, Bm[Y * W + c0], v0); v1 = fma_(cb, Bm[Y * W + c1], v1); }
+    const float wy = (Y >= 0 && Y < H) ? tap_weight(Y, sy, h, i) : 0.f;
+    float v0 = ca * va[dy][0], v1 = ca * va[dy][1];
+    if (Bm) { v0 = fma_(cb, vb[dy][0], v0); v1 = fma_(cb, vb[dy][1], v1); }
     acc += wy * (wx0 * v0 + wx1 * v1);
   }
-  for (int d = 1; d < f; d <<= 1) acc += __shfl_xor(acc, d);
+#pragma unroll
+  for (int d = 1; d < F; d <<= 1) acc += __shfl_xor(acc, d);
   return acc;
+}
+MAL_DEV float adjoint_gather(const float* __restrict__ A, float ca, const float* __restrict__ Bm, float cb, int i, int j,
+                             int k, int f, int h, int w, int H, int W) {
+  switch (f) {  // uniform per launch / per blockIdx.y
+    case 1: return adjoint_gather_f<1>(A, ca, Bm, cb, i, j, k, h, w, H, W);
+    case 2: return adjoint_gather_f<2>(A, ca, Bm, cb, i, j, k, h, w, H, W);
+    case 4: return adjoint_gather_f<4>(A, ca, Bm, cb, i, j, k, h, w, H, W);
+    default: return adjoint_gather_f<8>(A, ca, Bm, cb, i, j, k, h, w, H, W);
+  }
 }
 
 __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* g_out, int B, int h, int w, int H, int W, float* g_x) {
@@ -228,49 +262,70 @@ __global__ __launch_bounds__(256) void ms_final_kernel(MsFinal p) {
     p.stats[i] = mean;
     p.stats[2 * S * B + i] = q[6] / (hw * m * m);
   }
-  // sums over samples in sample order; the smoothness slots weighted by the sample's 1/(mean + 1e-7)
+  // sums over samples in sample order; the smoothness slots weighted by the sample's 1/(mean + 1e-7).  One thread per
+  // (pass, sample, slot) fetches and weighs its term (one round trip for all), 8 threads per pass then add B terms.
+  constexpr int kStage = 2 * kMsS * 16 * 8;  // staged in LDS up to B = 16; beyond, the summing threads re-fetch
+  __shared__ double s_term[kStage];
+  const bool staged = 2 * S * B * 8 <= kStage;
+  for (int i = tid; staged && i < 2 * S * B * 8; i += 256) {
+    const int j = i & 7, s = ((i >> 3) / B) % S;
+    const double* q = p.ps + (size_t)(i >> 3) * 8;
+    double v = q[j];
+    if (j == 4 || j == 5) v = v * (double)div_(1.0f, (float)(q[7] / (double)((p.H >> s) * (p.W >> s))) + 1e-7f);
+    s_term[i] = v;
+  }
+  __syncthreads();
   if (tid < 2 * S * 8) {
     const int pass = tid >> 3, j = tid & 7, s = pass % S;
     const double hw = (double)((p.H >> s) * (p.W >> s));
     double a = 0.0;
     for (int b = 0; b < B; ++b) {
-      const double* q = p.ps + ((size_t)pass * B + b) * 8;
-      double v = q[j];
-      if (j == 4 || j == 5) v = v * (double)div_(1.0f, (float)(q[7] / hw) + 1e-7f);
+      double v;
+      if (staged) v = s_term[((size_t)pass * B + b) * 8 + j];
+      else {
+        const double* q = p.ps + ((size_t)pass * B + b) * 8;
+        v = q[j];
+        if (j == 4 || j == 5) v = v * (double)div_(1.0f, (float)(q[7] / hw) + 1e-7f);
+      }
       a += v;
     }
     sh_tot[pass][j] = a;
   }
   __syncthreads();
+  // one thread per (network, scale): its four scalars and its coefficient (double divisions: not on one thread in a row)
+  __shared__ float s_loss[2 * kMsS], s_rep[2 * kMsS];
+  if (tid < 2 * S) {
+    const int net = tid / S, s = tid - net * S;
+    const double N = (double)B * p.H * p.W;
+    const double* t = sh_tot[tid];
+    const int h = p.H >> s, w = p.W >> s;
+    const double Nx = (double)B * h * (w - 1), Ny = (double)B * (h - 1) * w;
+    const float reproj = (float)(t[0] / (t[1] + 1e-7));
+    const float cons = net ? (float)(t[2] / N) : 0.f;
+    const float smooth = (float)(t[4] / Nx + t[5] / Ny);
+    const float loss = (net ? reproj + cons : reproj) + (1e-3f * smooth) / (float)(1 << s);
+    float* o = p.losses + (net * kMsS + s) * 4;
+    o[0] = reproj; o[1] = cons; o[2] = smooth; o[3] = loss;
+    s_loss[tid] = loss; s_rep[tid] = reproj;
+    p.coefs[tid] = (float)(1.0 / ((double)S * (t[1] + 1e-7)));
+    if (net == 0) p.coefs[2 * S + s] = (float)(1e-3 / ((double)(1 << s) * (double)S));
+  }
+  __syncthreads();
   if (tid != 0) return;
   if (p.noise_counter) *p.noise_counter += 1ull;
-  const double N = (double)B * p.H * p.W;
   float total[2] = {0.f, 0.f};
   for (int net = 0; net < 2; ++net)
-    for (int s = 0; s < S; ++s) {
-      const double* t = sh_tot[net * S + s];
-      const int h = p.H >> s, w = p.W >> s;
-      const double Nx = (double)B * h * (w - 1), Ny = (double)B * (h - 1) * w;
-      const float reproj = (float)(t[0] / (t[1] + 1e-7));
-      const float cons = net ? (float)(t[2] / N) : 0.f;
-      const float smooth = (float)(t[4] / Nx + t[5] / Ny);
-      const float loss = (net ? reproj + cons : reproj) + (1e-3f * smooth) / (float)(1 << s);
-      float* o = p.losses + (net * kMsS + s) * 4;
-      o[0] = reproj; o[1] = cons; o[2] = smooth; o[3] = loss;
-      total[net] += loss;
-      p.coefs[net * S + s] = (float)(1.0 / ((double)S * (t[1] + 1e-7)));
-    }
+    for (int s = 0; s < S; ++s) total[net] += s_loss[net * S + s];
   for (int net = 0; net < 2; ++net)
     for (int s = S; s < kMsS; ++s)
       for (int k = 0; k < 4; ++k) p.losses[(net * kMsS + s) * 4 + k] = 0.f;
-  for (int s = 0; s < S; ++s) p.coefs[2 * S + s] = (float)(1e-3 / ((double)(1 << s) * (double)S));
   p.losses[32] = div_(total[0], (float)S);
   p.losses[33] = div_(total[1], (float)S);
   p.losses[34] = p.losses[33] + p.losses[32];
   p.losses[35] = 0.f;
   for (int s = 0; s < kMsS; ++s) {  // process_batch adds the teacher's entries to the student's (trainer.py:614-616)
-    p.losses[36 + s] = p.losses[(kMsS + s) * 4 + 0] + p.losses[s * 4 + 0];
-    p.losses[40 + s] = p.losses[(kMsS + s) * 4 + 3] + p.losses[s * 4 + 3];
+    p.losses[36 + s] = s < S ? s_rep[S + s] + s_rep[s] : 0.f;
+    p.losses[40 + s] = s < S ? s_loss[S + s] + s_loss[s] : 0.f;
   }
   for (int i = 44; i < kMsLossSlots; ++i) p.losses[i] = 0.f;
   if (p.loss_total) *p.loss_total = p.losses[34];
@@ -282,14 +337,21 @@ struct MsAssemble {
   const float* coefs; const double* stats; const float* g_total; const float* gT;
   float* gTs0; float* gTs1;
   int B, H, W, S;
+  unsigned first[2 * kMsS + 1];
 };
 
 // blockIdx.y = net*S + s.  g_disp[net][s] = adjoint-upsample(cR * G_r + g * G_c) + cS * (gn / (mean+eps) - corr);
 // block (0,0) also sums the pose gradients over the scales and runs the backward of transformation_from_parameters
-__global__ __launch_bounds__(256) void ms_assemble_kernel(MsAssemble p, PoseParams pp, int pose_bwd) {
-  const int pass = blockIdx.y, S = p.S, net = pass / S, s = pass - net * S, B = p.B;
+__global__ __launch_bounds__(256) void ms_assemble_kernel(MsAssemble p, PoseParams pp, int pose_bwd, int vec0) {
+  // workgroups of pass k: [first[k], first[k+1]) -- exactly as many as the pass has work for (an idle workgroup costs
+  // ~0.4 ns of dispatch, and a y-dimension sized for the largest pass launched as many idle as busy ones)
+  const int S = p.S, B = p.B;
+  int pass = 0;
+  while (pass + 1 < 2 * S && blockIdx.x >= p.first[pass + 1]) ++pass;
+  const unsigned blk = blockIdx.x - p.first[pass];
+  const int net = pass / S, s = pass - net * S;
   const float g = p.g_total ? *p.g_total : 1.0f;
-  if (blockIdx.x == 0 && pass == 0) {
+  if (blockIdx.x == 0) {
     for (int i = threadIdx.x; i < B * 16; i += 256) {
       float a0 = 0.f, a1 = 0.f;
       for (int k = 0; k < S; ++k) {
@@ -305,32 +367,55 @@ __global__ __launch_bounds__(256) void ms_assemble_kernel(MsAssemble p, PosePara
   }
   float* out = p.g_disp[net][s];
   if (!out) return;
-  const int f = 1 << s, h = p.H >> s, w = p.W >> s, hw = h * w;
+  const int f = 1 << s, h = p.H >> s, w = p.W >> s, W = p.W, H = p.H;
+  const unsigned hw = (unsigned)(h * w), npix = (unsigned)B * hw;
   const float cR = p.coefs[pass] * g, cS = p.coefs[2 * S + s] * g;
   const float* G_c = net ? p.G_c[s] : nullptr;
-  const size_t nthreads = (size_t)B * hw * f;
-  for (size_t t0 = blockIdx.x * (size_t)blockDim.x; t0 < nthreads; t0 += (size_t)gridDim.x * blockDim.x) {
-    const size_t t = t0 + threadIdx.x;
-    const size_t q = t / f;
-    const int k = (int)(t - q * f);
-    const bool live = q < (size_t)B * hw;
-    const size_t qq = live ? q : 0;
-    const int b = (int)(qq / hw), pix = (int)(qq - (size_t)b * hw);
-    float v;
-    if (s == 0) {
-      v = cR * p.G_r[net][0][qq];
-      if (G_c) v = fma_(g, G_c[qq], v);
+  const float* gn = p.gn[net][s];
+  // ONE element of work per thread and every load of it issued up front (the maps were written a step ago: this kernel
+  // is HBM latency x bytes in flight): scale 0 four consecutive pixels (vec0: W % 4 == 0), the others member k of the f
+  // lanes that share output pixel q
+  const unsigned t = blk * 256u + threadIdx.x;
+  if (s == 0) {
+    const float* G_r = p.G_r[net][0];
+    if (vec0) {
+      const unsigned q = t * 4u;
+      if (q >= npix) return;
+      const unsigned b = q / hw;
+      const float inv = div_(1.0f, (float)p.stats[pass * B + b] + 1e-7f), corr = (float)p.stats[2 * S * B + pass * B + b];
+      const float4 r = *reinterpret_cast<const float4*>(G_r + q), n4 = *reinterpret_cast<const float4*>(gn + q);
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (G_c) c = *reinterpret_cast<const float4*>(G_c + q);
+      const float rr[4] = {r.x, r.y, r.z, r.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w}, cc[4] = {c.x, c.y, c.z, c.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = cR * rr[e];
+        if (G_c) v = fma_(g, cc[e], v);
+        o[e] = v + cS * (nn[e] * inv - corr);
+      }
+      *reinterpret_cast<float4*>(out + q) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
-      const int i = pix / w, j = pix - i * w;
-      const size_t ob = (size_t)b * p.H * p.W;
-      v = adjoint_gather(p.G_r[net][s] + ob, cR, G_c ? G_c + ob : nullptr, g, i, j, k, f, h, w, p.H, p.W);
+      if (t >= npix) return;
+      const unsigned b = t / hw;
+      const float inv = div_(1.0f, (float)p.stats[pass * B + b] + 1e-7f), corr = (float)p.stats[2 * S * B + pass * B + b];
+      float v = cR * G_r[t];
+      if (G_c) v = fma_(g, G_c[t], v);
+      out[t] = v + cS * (gn[t] * inv - corr);
     }
-    if (live && k == 0) {
-      const float inv = div_(1.0f, (float)p.stats[pass * B + b] + 1e-7f);
-      const float corr = (float)p.stats[2 * S * B + pass * B + b];
-      out[q] = v + cS * (p.gn[net][s][q] * inv - corr);
-    }
+    return;
   }
+  const unsigned q = t >> s;
+  const int k = (int)(t & (unsigned)(f - 1));
+  const bool live = q < npix;
+  const unsigned qq = live ? q : 0u;
+  const unsigned b = qq / hw, pix = qq - b * hw;
+  const int i = (int)(pix / (unsigned)w), j = (int)(pix - (unsigned)i * (unsigned)w);
+  const size_t ob = (size_t)b * H * W;
+  const float gnv = gn[qq];
+  const float inv = div_(1.0f, (float)p.stats[pass * B + b] + 1e-7f), corr = (float)p.stats[2 * S * B + pass * B + b];
+  const float v = adjoint_gather(p.G_r[net][s] + ob, cR, G_c ? G_c + ob : nullptr, g, i, j, k, f, h, w, H, W);
+  if (live && k == 0) out[q] = v + cS * (gnv * inv - corr);
 }
 
 }  // namespace mal
@@ -364,8 +449,7 @@ extern "C" int mal_upsample_bilinear(const float* x, int B, int h, int w, int H,
   if (!x || !out || B <= 0 || h <= 0 || w <= 0 || H < h || W < w) return MAL_EINVAL;
   UpMaps m = {};
   m.src[0] = x; m.dst[0] = out; m.h[0] = h; m.w[0] = w;
-  const size_t n = (size_t)B * H * W;
-  hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream, m, B, H, W);
+  upsample_launch(m, 1, B, H, W, (hipStream_t)stream);
   return launch_status();
 }
 
@@ -415,8 +499,7 @@ extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
         m.src[k] = n ? a->disp_student[s] : a->disp_teacher[s];
         m.dst[k] = w.up[n][s]; m.h[k] = H >> s; m.w[k] = W >> s;
       }
-    const size_t px = (size_t)B * H * W;
-    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((px + 255) / 256), k), dim3(256), 0, st, m, B, H, W);
+    upsample_launch(m, k, B, H, W, st);
     rc = launch_status();
     if (rc) return rc;
   }
@@ -459,15 +542,24 @@ extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
       if (rc) return rc;
       per_sample = p.strips * p.segs;
     }
-    // smoothness of both disparity maps at the scale's own size against the target at that size (:1469-1471)
-    const float* img = (s == 0 && !a->color0_s[0]) ? a->color0 : a->color0_s[s];
-    for (int n = 0; n < 2; ++n) {
-      rc = smooth_march_sweep(n ? a->disp_student[s] : a->disp_teacher[s], img, B, H >> s, W >> s, w.gn[n][s], w.sm[n][s], st,
-                              &fin.per_sample_sm[s]);
-      if (rc) return rc;
-      fin.bs[n][s] = w.bs[n][s]; fin.sm[n][s] = w.sm[n][s];
-    }
+    for (int n = 0; n < 2; ++n) { fin.bs[n][s] = w.bs[n][s]; fin.sm[n][s] = w.sm[n][s]; }
     fin.bgP[s] = w.bgP[s];
+  }
+  {  // smoothness of both disparity maps at every scale's own size against the target at that size (:1469-1471): ONE launch
+    const float *sd[2 * kMsS], *si[2 * kMsS];
+    float* sg[2 * kMsS];
+    double* sp[2 * kMsS];
+    int sh[2 * kMsS], sw[2 * kMsS], per[2 * kMsS];
+    for (int s = 0; s < S; ++s)
+      for (int n = 0; n < 2; ++n) {
+        const int k = 2 * s + n;
+        sd[k] = n ? a->disp_student[s] : a->disp_teacher[s];
+        si[k] = (s == 0 && !a->color0_s[0]) ? a->color0 : a->color0_s[s];
+        sg[k] = w.gn[n][s]; sp[k] = w.sm[n][s]; sh[k] = H >> s; sw[k] = W >> s;
+      }
+    rc = smooth_march_sweep_batch(2 * S, sd, si, B, sh, sw, sg, sp, st, per);
+    if (rc) return rc;
+    for (int s = 0; s < S; ++s) fin.per_sample_sm[s] = per[2 * s];
   }
   fin.K = a->K; fin.per_sample = per_sample; fin.B = B; fin.H = H; fin.W = W; fin.S = S;
   fin.ps = w.ps; fin.stats = w.stats; fin.gT = w.gT; fin.losses = a->losses; fin.coefs = w.coefs;
@@ -499,8 +591,19 @@ extern "C" int mal_loss_multiscale_bwd(const mal_ms_args* a) {
   pp.g_axisangle[0] = a->g_axisangle_m1; pp.g_axisangle[1] = a->g_axisangle_p1;
   pp.g_translation[0] = a->g_translation_m1; pp.g_translation[1] = a->g_translation_p1;
   const int pose_bwd = (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) ? 1 : 0;
-  size_t g = ((size_t)B * H * W + 255) / 256;
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(ms_assemble_kernel, dim3((unsigned)g, 2 * S), dim3(256), 0, (hipStream_t)a->stream, p, pp, pose_bwd);
+  // one unit of work per thread: B*H*W / 4 quads at scale 0 (B*H*W when W % 4 != 0), B*H*W / 2**s group members above;
+  // a pass whose output is not wanted gets no workgroups (pass 0 keeps one: it carries the pose backward)
+  bool vec0 = W % 4 == 0;
+  for (int n = 0; n < 2; ++n) vec0 = vec0 && ((uintptr_t)p.g_disp[n][0] % 16 == 0);
+  const size_t px = (size_t)B * H * W;
+  for (int k = 0; k < 2 * S; ++k) {
+    const int s = k % S;
+    const size_t units = s ? px >> s : (vec0 ? px / 4 : px);
+    unsigned blocks = p.g_disp[k / S][s] ? (unsigned)((units + 255) / 256) : 0u;
+    if (k == 0 && blocks == 0) blocks = 1;
+    p.first[k + 1] = p.first[k] + blocks;
+  }
+  hipLaunchKernelGGL(ms_assemble_kernel, dim3(p.first[2 * S]), dim3(256), 0, (hipStream_t)a->stream, p, pp, pose_bwd,
+                     vec0 ? 1 : 0);
   return launch_status();
 }
