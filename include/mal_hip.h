@@ -432,11 +432,11 @@ int mal_coord_sample_l1_bwd(const float* fmap1, const float* const* f2_pyramid, 
 /* The pose refinement step of the same loop (depth_pose.py:450-455), forward:
  * mal_epipolar_gradcoords = Reprojections.depth2gradcoords (utils.py:219-236): c_p (B,2,1,5,h,w) = the projection and its
  * +-1 px neighbours in x and y, P2 (B,4,h*w) = the transformed points.
- * mal_direct_align_normal_eq = PoseUpdate.direct_align up to the solve (utils.py:303-355, without --robust_pose_loss):
+ * mal_direct_align_normal_eq = PoseUpdate.direct_align up to the solve (utils.py:303-355; robust != 0: with the
+ * --robust_pose_loss weights of :344-355, scaled_barron(0, 0.1) of the squared residual x the in-image test):
  * src_feat / tgt_feat (B,C,h,w), src_w / tgt_w (B,1,h,w) (tgt_w is sampled at the projection as :388-390), weight (B,1,h,w)
  * nullable, K (B,16), p2 = c_p, P2 as above -> H (B,6,6) = sum_px w J^T J and b (B,6) = sum_px -res w J of the
- * feature-metric Gauss-Newton step; ws: mal_direct_align_workspace_bytes(B,h,w).  The 6x6 solve and the se3 update are
- * the caller's (torch.linalg on the device in mal_amd/epipolar.py). */
+ * feature-metric Gauss-Newton step; ws: mal_direct_align_workspace_bytes(B,h,w). */
 int mal_epipolar_gradcoords(const float* depth, const float* poses, const float* K, int B, int h, int w, float* c_p, float* P2,
                             void* stream);
 size_t mal_direct_align_workspace_bytes(int B, int h, int w);
@@ -446,7 +446,24 @@ int mal_direct_align_update(const float* H, const float* b, const float* poses, 
                             void* stream);
 int mal_direct_align_normal_eq(const float* src_feat, const float* tgt_feat, const float* src_w, const float* tgt_w,
                                const float* weight, const float* K, const float* p2, const float* P2, int B, int C, int h, int w,
-                               float* H, float* b, void* ws, size_t ws_bytes, void* stream);
+                               int robust, float* H, float* b, void* ws, size_t ws_bytes, void* stream);
+/* VJPs of the three (the last unrolled solver step differentiates through the pose update, depth_pose.py:450-455).
+ * mal_epipolar_gradcoords_bwd: cotangents of c_p and P2 (nullable) -> g_depth (B,1,h,w), g_poses (B,16); fixed order.
+ * mal_direct_align_normal_eq_bwd: cotangents of H (B,36) and b (B,6) -> every output nullable: g_src_feat (B,C,h,w),
+ * g_tgt_feat (B,C,h,w) and g_tgt_w (B,1,h,w) (ZERO on entry: accumulated with float atomics, as ATen's grid_sampler
+ * backward), g_src_w, g_weight (B,1,h,w), g_p2 (B,2,1,5,h,w), g_P2 (B,4,h*w; row 3 zero).  K receives no gradient.
+ * mal_direct_align_update_bwd: cotangents of new_poses (B,16) and update (B,6; nullable) -> g_H (B,36; symmetrised on the
+ * Cholesky path as torch.linalg.cholesky's backward), g_b (B,6), g_poses (B,16). */
+size_t mal_epipolar_gradcoords_bwd_workspace_bytes(int B, int h, int w);
+int mal_epipolar_gradcoords_bwd(const float* depth, const float* poses, const float* K, const float* g_c_p, const float* g_P2,
+                                int B, int h, int w, float* g_depth, float* g_poses, void* ws, size_t ws_bytes, void* stream);
+int mal_direct_align_normal_eq_bwd(const float* src_feat, const float* tgt_feat, const float* src_w, const float* tgt_w,
+                                   const float* weight, const float* K, const float* p2, const float* P2, const float* g_H,
+                                   const float* g_b, int B, int C, int h, int w, int robust, float* g_src_feat,
+                                   float* g_tgt_feat, float* g_src_w, float* g_tgt_w, float* g_weight, float* g_p2, float* g_P2,
+                                   void* stream);
+int mal_direct_align_update_bwd(const float* H, const float* b, const float* poses, const float* g_new_poses,
+                                const float* g_update, int B, float* g_H, float* g_b, float* g_poses, void* stream);
 
 /* ---- library options:
  * "pass_impl"   formulation of the fused pass: 1 = register-marching (default); 0 / 2 = the LDS-tiled first

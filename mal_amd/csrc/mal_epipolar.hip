@@ -421,9 +421,25 @@ struct EpiAlignParams {
   int B, C, h, w, nblk;                    // nblk = workgroups per sample
   double* partial;                         // [B][nblk][27]
   float* H; float* bvec;                   // (B,36), (B,6)
+  int robust;                              // --robust_pose_loss (utils.py:344-355)
+  // backward
+  const float* g_H; const float* g_b;      // (B,36), (B,6)
+  float* g_src; float* g_tgt; float* g_src_w; float* g_tgt_w; float* g_weight; float* g_p2; float* g_P2;
 };
 
-struct Tap4 { unsigned o[4]; float w[4]; };
+// --robust_pose_loss: scaled_barron(0, 0.1) of the squared residual (losses.py:8-19,41-90: alpha = 0 -> 2 log1p(x/2), first
+// derivative 2 / (x + 2) at x = cost / 0.1**2), times the in-image test of the projected centre with a 2 px margin
+// (utils.py:409-412).  -> weight, d weight / d cost
+constexpr float kBarronA2 = 0.010000000000000002f;
+MAL_DEV float robust_weight(float cost, float u, float v, int h, int w, float* d_cost) {
+  const float y = div_(cost, kBarronA2);
+  const float wl = div_(2.0f, y + 2.0f);
+  const bool valid = u >= 2.0f && u <= (float)(w - 3) && v >= 2.0f && v <= (float)(h - 3);
+  *d_cost = valid ? -div_(div_(2.0f, (y + 2.0f) * (y + 2.0f)), kBarronA2) : 0.f;
+  return valid ? wl : 0.f;
+}
+
+struct Tap4 { unsigned o[4]; float w[4]; float tx, ty, ex, ey; bool v[4]; };  // v: tap inside the map (and the position sane)
 
 // bilinear, zero-padded, align_corners=False sample position (u, v) in pixels of an (h,w) map (corr.py:38-39 /
 // utils.py:374-379 + grid_sample's unnormalise)
@@ -440,10 +456,12 @@ MAL_DEV Tap4 taps_at(float u, float v, int h, int w) {
   const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1), cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
   t.o[0] = (unsigned)(cy0 * w + cx0) * 4u; t.o[1] = (unsigned)(cy0 * w + cx1) * 4u;
   t.o[2] = (unsigned)(cy1 * w + cx0) * 4u; t.o[3] = (unsigned)(cy1 * w + cx1) * 4u;
-  t.w[0] = (!wild && vx0 && vy0) ? ex * ey : 0.f;
-  t.w[1] = (!wild && vx1 && vy0) ? tx * ey : 0.f;
-  t.w[2] = (!wild && vx0 && vy1) ? ex * ty : 0.f;
-  t.w[3] = (!wild && vx1 && vy1) ? tx * ty : 0.f;
+  t.v[0] = !wild && vx0 && vy0; t.v[1] = !wild && vx1 && vy0; t.v[2] = !wild && vx0 && vy1; t.v[3] = !wild && vx1 && vy1;
+  t.w[0] = t.v[0] ? ex * ey : 0.f;
+  t.w[1] = t.v[1] ? tx * ey : 0.f;
+  t.w[2] = t.v[2] ? ex * ty : 0.f;
+  t.w[3] = t.v[3] ? tx * ty : 0.f;
+  t.tx = tx; t.ty = ty; t.ex = ex; t.ey = ey;
   return t;
 }
 MAL_DEV float sample4(const char* plane, const Tap4& t) {
@@ -470,7 +488,7 @@ __global__ __launch_bounds__(256) void epi_align_kernel(EpiAlignParams p) {
 #pragma unroll
   for (int k = 0; k < 5; ++k)
     t[k] = taps_at(p.p2[(((size_t)b * 2 + 0) * 5 + k) * hw + pix], p.p2[(((size_t)b * 2 + 1) * 5 + k) * hw + pix], p.h, p.w);
-  float Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Srx = 0.f, Sry = 0.f;
+  float Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Srx = 0.f, Sry = 0.f, cost = 0.f;
 #pragma unroll 2
   for (int c = 0; c < p.C; ++c) {
     const char* pl = reinterpret_cast<const char*>(p.tgt + ((size_t)b * p.C + c) * hw);
@@ -479,9 +497,15 @@ __global__ __launch_bounds__(256) void epi_align_kernel(EpiAlignParams p) {
     const float r = p.src[((size_t)b * p.C + c) * hw + pix] - f0;
     Sxx = fma_(gx, gx, Sxx); Sxy = fma_(gx, gy, Sxy); Syy = fma_(gy, gy, Syy);
     Srx = fma_(r, gx, Srx); Sry = fma_(r, gy, Sry);
+    cost = fma_(r, r, cost);
   }
   float wgt = p.src_w[(size_t)b * hw + pix] * sample4(reinterpret_cast<const char*>(p.tgt_w + (size_t)b * hw), t[0]);
   if (p.weight) wgt *= p.weight[(size_t)b * hw + pix];
+  if (p.robust) {
+    float unused;
+    wgt *= robust_weight(cost, p.p2[(((size_t)b * 2 + 0) * 5) * hw + pix], p.p2[(((size_t)b * 2 + 1) * 5) * hw + pix], p.h, p.w,
+                         &unused);
+  }
   if (!live) wgt = 0.f;
   const float X = p.P2[((size_t)b * 4 + 0) * hw + pix], Y = p.P2[((size_t)b * 4 + 1) * hw + pix], Z = p.P2[((size_t)b * 4 + 2) * hw + pix];
   const float fx = p.K[b * 16], fy = p.K[b * 16 + 5];
@@ -526,21 +550,224 @@ __global__ __launch_bounds__(64) void epi_align_finish_kernel(EpiAlignParams p) 
   if (tid < 6) p.bvec[b * 6 + tid] = (float)s_v[21 + tid];
 }
 
-// The rest of PoseUpdate.direct_align (utils.py:357-368) for one sample per thread: Cholesky solve of the 6x6 normal
-// equations (fall-backs as upstream: a general solve when the factorisation fails, the unchanged pose when that fails
-// too), se3_exp of the update (dualrefine/layers.py:29-55) and new_pose = exp(update) @ pose.  fp32 like torch.
-__global__ void epi_align_update_kernel(const float* H, const float* bvec, const float* poses, int B, float* new_poses,
-                                        float* update) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  float A[6][6], rhs[6], x[6];
+// ---------------------------------------------------------------- pose refinement step (backward)
+// Reprojections.depth2gradcoords backward: cotangents of c_p (B,2,1,5,h,w) and P2 (B,4,hw; nullable) -> d/d depth, and per
+// workgroup the 16 partial sums of d/d pose (fixed order; epi_rows_finish_kernel adds them)
+struct EpiGradCoordBwdParams {
+  const float* depth; const float* poses; const float* K; const float* g_cp; const float* g_P2;
+  int B, h, w, nblk;
+  float* g_depth; double* partial;  // [B][nblk][16]
+};
+
+__global__ __launch_bounds__(256) void epi_gradcoords_bwd_kernel(EpiGradCoordBwdParams p) {
+  __shared__ double s_red[16][4];
+  const int hw = p.h * p.w, b = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x;
+  const bool live = pix < hw;
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  if (live) {
+    const int y = pix / p.w, x = pix - y * p.w, i = b * hw + pix;
+    const float* Kb = p.K + b * 16;
+    const float* T = p.poses + b * 16;
+    const float fx = Kb[0], fy = Kb[5], cx = Kb[2], cy = Kb[6];
+    const float Z = p.depth[i];
+    const float X = div_((float)x - cx, fx), Y = div_((float)y - cy, fy);
+    const float X0[4] = {Z * X, Z * Y, Z, 1.0f};
+    float X1[3];
+#pragma unroll
+    for (int r_ = 0; r_ < 3; ++r_) {
+      float a = T[r_ * 4] * X0[0];
+      a = fma_(T[r_ * 4 + 1], X0[1], a);
+      a = fma_(T[r_ * 4 + 2], X0[2], a);
+      X1[r_] = fma_(T[r_ * 4 + 3], X0[3], a);
+    }
+    const float inv = div_(1.0f, X1[2]);
+    const bool clamped = inv > 100.0f;
+    const float d = clamped ? 100.0f : inv;
+    float gu = 0.f, gv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      gu += p.g_cp[(((size_t)b * 2 + 0) * 5 + k) * hw + pix];
+      gv += p.g_cp[(((size_t)b * 2 + 1) * 5 + k) * hw + pix];
+    }
+    float gX1[4];
+    gX1[0] = gu * fx * d;
+    gX1[1] = gv * fy * d;
+    const float g_d = gu * fx * X1[0] + gv * fy * X1[1];
+    gX1[2] = clamped ? 0.f : -g_d * inv * inv;
+    gX1[3] = 0.f;
+    if (p.g_P2)
+#pragma unroll
+      for (int r_ = 0; r_ < 4; ++r_) gX1[r_] += p.g_P2[((size_t)b * 4 + r_) * hw + pix];
+    float gZ = 0.f;
+#pragma unroll
+    for (int r_ = 0; r_ < 4; ++r_) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[r_ * 4 + c] = gX1[r_] * X0[c];
+      gZ += gX1[r_] * (T[r_ * 4] * X + T[r_ * 4 + 1] * Y + T[r_ * 4 + 2]);
+    }
+    p.g_depth[i] = gZ;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double v = wave_sum_d((double)acc[k]);
+    if (lane == 0) s_red[k][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16)
+    p.partial[((size_t)b * p.nblk + blockIdx.x) * 16 + threadIdx.x] =
+        ((s_red[threadIdx.x][0] + s_red[threadIdx.x][1]) + s_red[threadIdx.x][2]) + s_red[threadIdx.x][3];
+}
+
+// out[b][t] = sum over the workgroups (in order) of partial[b][k][t], t < n
+__global__ __launch_bounds__(64) void epi_rows_finish_kernel(const double* partial, int nblk, int n, float* out) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= n) return;
+  double a = 0.0;
+  for (int k = 0; k < nblk; ++k) a += partial[((size_t)b * nblk + k) * n + t];
+  out[b * n + t] = (float)a;
+}
+
+// PoseUpdate.direct_align backward up to the solve: cotangents of H (B,36) and b (B,6) -> every input of the normal
+// equations.  Same decomposition as the forward (lane = pixel, two walks over the channel planes): the first re-derives
+// the five channel sums, from which d/d(weight factors), d/d(the sums) and d/d(the two Jacobian rows) follow in registers;
+// the second re-derives each channel's samples and sends d/d(sample k) to the four taps of position k (float atomics, as
+// ATen's grid_sampler backward: the one unordered sum) and to the position itself through the bilinear slopes.
+//   H = sum_pix w (Sxx a a^T + Sxy (a q^T + q a^T) + Syy q q^T),   b = sum_pix w (Srx a + Sry q)
+__global__ __launch_bounds__(256) void epi_align_bwd_kernel(EpiAlignParams p) {
+  __shared__ float s_G[36], s_gb[6];
+  const int hw = p.h * p.w, b = blockIdx.y;
+  if (threadIdx.x < 36) {  // Gs = G + G^T: H is built symmetric, both triangles carry the same sum
+    const int i = threadIdx.x / 6, j = threadIdx.x % 6;
+    s_G[threadIdx.x] = p.g_H[b * 36 + i * 6 + j] + p.g_H[b * 36 + j * 6 + i];
+  }
+  if (threadIdx.x < 6) s_gb[threadIdx.x] = p.g_b[b * 6 + threadIdx.x];
+  __syncthreads();
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= hw) return;
+  Tap4 t[5];
+  float uu[5], vv[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    uu[k] = p.p2[(((size_t)b * 2 + 0) * 5 + k) * hw + pix];
+    vv[k] = p.p2[(((size_t)b * 2 + 1) * 5 + k) * hw + pix];
+    t[k] = taps_at(uu[k], vv[k], p.h, p.w);
+  }
+  float Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Srx = 0.f, Sry = 0.f, cost = 0.f;
+#pragma unroll 2
+  for (int c = 0; c < p.C; ++c) {
+    const char* pl = reinterpret_cast<const char*>(p.tgt + ((size_t)b * p.C + c) * hw);
+    const float f0 = sample4(pl, t[0]);
+    const float gx = (sample4(pl, t[1]) - sample4(pl, t[2])) / 2.0f, gy = (sample4(pl, t[3]) - sample4(pl, t[4])) / 2.0f;
+    const float r = p.src[((size_t)b * p.C + c) * hw + pix] - f0;
+    Sxx = fma_(gx, gx, Sxx); Sxy = fma_(gx, gy, Sxy); Syy = fma_(gy, gy, Syy);
+    Srx = fma_(r, gx, Srx); Sry = fma_(r, gy, Sry);
+    cost = fma_(r, r, cost);
+  }
+  const char* twp = reinterpret_cast<const char*>(p.tgt_w + (size_t)b * hw);
+  const float sw = p.src_w[(size_t)b * hw + pix], tw = sample4(twp, t[0]);
+  const float wt = p.weight ? p.weight[(size_t)b * hw + pix] : 1.0f;
+  float rw = 1.0f, drw_dcost = 0.f;
+  if (p.robust) rw = robust_weight(cost, uu[0], vv[0], p.h, p.w, &drw_dcost);
+  const float wgt = ((sw * tw) * wt) * rw;
+  const float X = p.P2[((size_t)b * 4 + 0) * hw + pix], Y = p.P2[((size_t)b * 4 + 1) * hw + pix], Z = p.P2[((size_t)b * 4 + 2) * hw + pix];
+  const float fx = p.K[b * 16], fy = p.K[b * 16 + 5];
+  const float fxz = div_(fx, Z), fyz = div_(fy, Z);
+  const float fxxz2 = div_(fxz * X, Z), fyyz2 = div_(fyz * Y, Z);
+  const float a[6] = {fxz, 0.f, -fxxz2, -fxxz2 * Y, fx + fxxz2 * X, -fxz * Y};
+  const float q[6] = {0.f, fyz, -fyyz2, -fy - fyyz2 * Y, fyyz2 * X, fyz * X};
+  float ua[6], uq[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    rhs[i] = bvec[b * 6 + i];
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) A[i][j] = H[b * 36 + i * 6 + j];
+    for (int j = 0; j < 6; ++j) { s0 = fma_(s_G[i * 6 + j], a[j], s0); s1 = fma_(s_G[i * 6 + j], q[j], s1); }
+    ua[i] = s0; uq[i] = s1;
   }
-  // Cholesky A = L L^T (lower); every loop has constant bounds and is unrolled so the 6x6 arrays stay in registers
+  float a_ua = 0.f, a_uq = 0.f, q_uq = 0.f, gb_a = 0.f, gb_q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    a_ua = fma_(a[i], ua[i], a_ua); a_uq = fma_(a[i], uq[i], a_uq); q_uq = fma_(q[i], uq[i], q_uq);
+    gb_a = fma_(s_gb[i], a[i], gb_a); gb_q = fma_(s_gb[i], q[i], gb_q);
+  }
+  // d / d (the pixel's weight), d / d (the five channel sums)
+  const float dw = (Sxx * (0.5f * a_ua) + Sxy * a_uq + Syy * (0.5f * q_uq)) + (Srx * gb_a + Sry * gb_q);
+  const float dSxx = wgt * 0.5f * a_ua, dSxy = wgt * a_uq, dSyy = wgt * 0.5f * q_uq, dSrx = wgt * gb_a, dSry = wgt * gb_q;
+  // d / d (the Jacobian rows) -> d / d (X, Y, Z)
+  float da[6], dq[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    da[i] = wgt * ((Sxx * ua[i] + Sxy * uq[i]) + Srx * s_gb[i]);
+    dq[i] = wgt * ((Sxy * ua[i] + Syy * uq[i]) + Sry * s_gb[i]);
+  }
+  float d_fxz = da[0] - Y * da[5], d_fxxz2 = (-da[2] - Y * da[3]) + X * da[4];
+  float d_fyz = dq[1] + X * dq[5], d_fyyz2 = (-dq[2] - Y * dq[3]) + X * dq[4];
+  float dX = fxxz2 * da[4] + (fyyz2 * dq[4] + fyz * dq[5]);
+  float dY = (-fxxz2 * da[3] - fxz * da[5]) - fyyz2 * dq[3];
+  const float iz = div_(1.0f, Z);
+  d_fxz += d_fxxz2 * X * iz; dX += d_fxxz2 * fxz * iz;
+  d_fyz += d_fyyz2 * Y * iz; dY += d_fyyz2 * fyz * iz;
+  const float dZ = -(d_fxxz2 * fxxz2 + d_fyyz2 * fyyz2 + d_fxz * fxz + d_fyz * fyz) * iz;
+  if (p.g_P2) {
+    p.g_P2[((size_t)b * 4 + 0) * hw + pix] = dX; p.g_P2[((size_t)b * 4 + 1) * hw + pix] = dY;
+    p.g_P2[((size_t)b * 4 + 2) * hw + pix] = dZ; p.g_P2[((size_t)b * 4 + 3) * hw + pix] = 0.f;
+  }
+  // the factors of the weight
+  if (p.g_src_w) p.g_src_w[(size_t)b * hw + pix] = dw * ((tw * wt) * rw);
+  if (p.g_weight) p.g_weight[(size_t)b * hw + pix] = dw * ((sw * tw) * rw);
+  const float dtw = dw * ((sw * wt) * rw);
+  const float dcost = dw * ((sw * tw) * wt) * drw_dcost;
+  float gu[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, gv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  auto slopes = [&](const char* plane, const Tap4& tp, float* dix, float* diy) {  // of the zero-padded bilinear sample
+    const float v00 = tp.v[0] ? *reinterpret_cast<const float*>(plane + tp.o[0]) : 0.f;
+    const float v01 = tp.v[1] ? *reinterpret_cast<const float*>(plane + tp.o[1]) : 0.f;
+    const float v10 = tp.v[2] ? *reinterpret_cast<const float*>(plane + tp.o[2]) : 0.f;
+    const float v11 = tp.v[3] ? *reinterpret_cast<const float*>(plane + tp.o[3]) : 0.f;
+    *dix = (v01 - v00) * tp.ey + (v11 - v10) * tp.ty;
+    *diy = (v10 - v00) * tp.ex + (v11 - v01) * tp.tx;
+  };
+  auto scatter = [&](float* plane, const Tap4& tp, float g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (tp.v[j] && g != 0.f) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + tp.o[j]), g * tp.w[j]);
+  };
+  {
+    float dix, diy;
+    slopes(twp, t[0], &dix, &diy);
+    gu[0] = dtw * dix; gv[0] = dtw * diy;
+    if (p.g_tgt_w) scatter(p.g_tgt_w + (size_t)b * hw, t[0], dtw);
+  }
+  for (int c = 0; c < p.C; ++c) {
+    const size_t po = ((size_t)b * p.C + c) * hw;
+    const char* pl = reinterpret_cast<const char*>(p.tgt + po);
+    const float f0 = sample4(pl, t[0]);
+    const float gx = (sample4(pl, t[1]) - sample4(pl, t[2])) / 2.0f, gy = (sample4(pl, t[3]) - sample4(pl, t[4])) / 2.0f;
+    const float r = p.src[po + pix] - f0;
+    const float dgx = (2.0f * gx * dSxx + gy * dSxy) + r * dSrx, dgy = (2.0f * gy * dSyy + gx * dSxy) + r * dSry;
+    const float dr = (gx * dSrx + gy * dSry) + 2.0f * r * dcost;
+    if (p.g_src) p.g_src[po + pix] = dr;
+    const float df[5] = {-dr, 0.5f * dgx, -0.5f * dgx, 0.5f * dgy, -0.5f * dgy};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      float dix, diy;
+      slopes(pl, t[k], &dix, &diy);
+      gu[k] = fma_(df[k], dix, gu[k]); gv[k] = fma_(df[k], diy, gv[k]);
+      if (p.g_tgt) scatter(p.g_tgt + po, t[k], df[k]);
+    }
+  }
+  if (p.g_p2)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      p.g_p2[(((size_t)b * 2 + 0) * 5 + k) * hw + pix] = gu[k];
+      p.g_p2[(((size_t)b * 2 + 1) * 5 + k) * hw + pix] = gv[k];
+    }
+}
+
+// x = A^-1 rhs as PoseUpdate.direct_align does it (utils.py:357-368): Cholesky, else LU with partial pivoting, else failure.
+// `chol` says which succeeded.  Constant loop bounds, fully unrolled: the 6x6 arrays stay in registers.
+MAL_DEV bool solve6(const float (&A)[6][6], const float (&rhs)[6], float (&x)[6], bool* chol) {
   float Lm[6][6];
   bool ok = true;
 #pragma unroll
@@ -579,6 +806,7 @@ __global__ void epi_align_update_kernel(const float* H, const float* bvec, const
   bool solved = ok;
 #pragma unroll
   for (int i = 0; i < 6; ++i) solved = solved && (x[i] == x[i]);  // NaN in the factor: fall through (utils.py:358-360)
+  *chol = solved;
   if (!solved) {  // torch.linalg.solve: LU with partial pivoting (row swaps as selects, so the indices stay static)
     float M[6][7];
 #pragma unroll
@@ -621,6 +849,70 @@ __global__ void epi_align_update_kernel(const float* H, const float* bvec, const
 #pragma unroll
     for (int i = 0; i < 6; ++i) solved = solved && (x[i] == x[i]);
   }
+  return solved;
+}
+
+// se3_exp (dualrefine/layers.py:29-55) on any scalar type: float for the forward, Dual6 (value + six partials, forward-mode)
+// for the Jacobian the backward needs -- the same code, so the two cannot drift apart
+struct Dual6 {
+  float v; float d[6];
+};
+MAL_DEV Dual6 dual_const(float v) { Dual6 r; r.v = v; for (int k = 0; k < 6; ++k) r.d[k] = 0.f; return r; }
+MAL_DEV Dual6 dual_var(float v, int i) { Dual6 r = dual_const(v); r.d[i] = 1.0f; return r; }
+MAL_DEV Dual6 operator+(const Dual6& a, const Dual6& b) { Dual6 r; r.v = a.v + b.v; for (int k = 0; k < 6; ++k) r.d[k] = a.d[k] + b.d[k]; return r; }
+MAL_DEV Dual6 operator-(const Dual6& a, const Dual6& b) { Dual6 r; r.v = a.v - b.v; for (int k = 0; k < 6; ++k) r.d[k] = a.d[k] - b.d[k]; return r; }
+MAL_DEV Dual6 operator-(const Dual6& a) { Dual6 r; r.v = -a.v; for (int k = 0; k < 6; ++k) r.d[k] = -a.d[k]; return r; }
+MAL_DEV Dual6 operator*(const Dual6& a, const Dual6& b) { Dual6 r; r.v = a.v * b.v; for (int k = 0; k < 6; ++k) r.d[k] = a.d[k] * b.v + a.v * b.d[k]; return r; }
+MAL_DEV Dual6 operator/(const Dual6& a, const Dual6& b) {
+  Dual6 r; r.v = a.v / b.v;
+  for (int k = 0; k < 6; ++k) r.d[k] = (a.d[k] - r.v * b.d[k]) / b.v;
+  return r;
+}
+MAL_DEV Dual6 sqrt_(const Dual6& a) { Dual6 r; r.v = sqrtf(a.v); for (int k = 0; k < 6; ++k) r.d[k] = a.d[k] / (2.0f * r.v); return r; }
+MAL_DEV Dual6 sin_(const Dual6& a) { Dual6 r; r.v = sinf(a.v); const float c = cosf(a.v); for (int k = 0; k < 6; ++k) r.d[k] = c * a.d[k]; return r; }
+MAL_DEV Dual6 cos_(const Dual6& a) { Dual6 r; r.v = cosf(a.v); const float s = -sinf(a.v); for (int k = 0; k < 6; ++k) r.d[k] = s * a.d[k]; return r; }
+MAL_DEV float sqrt_(float a) { return sqrtf(a); }
+MAL_DEV float sin_(float a) { return sinf(a); }
+MAL_DEV float cos_(float a) { return cosf(a); }
+MAL_DEV float lit(float, float v) { return v; }
+MAL_DEV Dual6 lit(const Dual6&, float v) { return dual_const(v); }
+
+// T[:3,:4] of exp(x): rotation R (Rodrigues), translation J rho
+template <class S>
+MAL_DEV void se3_exp_rows(const S (&x)[6], S (&T)[3][4]) {
+  const S zero = lit(x[0], 0.f), one = lit(x[0], 1.f);
+  const S theta = sqrt_(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+  const S a[3] = {x[3] / theta, x[4] / theta, x[5] / theta};
+  const S sk[3][3] = {{zero, -a[2], a[1]}, {a[2], zero, -a[0]}, {-a[1], a[0], zero}};
+  const S ct = cos_(theta), st = sin_(theta), sot = st / theta, omc = one - ct, omcot = omc / theta;
+  S J[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const S aat = a[i] * a[j];
+      if (i == j) { T[i][j] = ct + omc * aat + st * sk[i][j]; J[i][j] = sot + (one - sot) * aat + omcot * sk[i][j]; }
+      else        { T[i][j] = omc * aat + st * sk[i][j];      J[i][j] = (one - sot) * aat + omcot * sk[i][j]; }
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) T[i][3] = J[i][0] * x[0] + J[i][1] * x[1] + J[i][2] * x[2];
+}
+
+// The rest of PoseUpdate.direct_align (utils.py:357-368) for one sample per thread: the 6x6 solve with upstream's
+// fall-backs, se3_exp of the update and new_pose = exp(update) @ pose.  fp32 like torch.
+__global__ void epi_align_update_kernel(const float* H, const float* bvec, const float* poses, int B, float* new_poses,
+                                        float* update) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float A[6][6], rhs[6], x[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    rhs[i] = bvec[b * 6 + i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) A[i][j] = H[b * 36 + i * 6 + j];
+  }
+  bool chol;
+  const bool solved = solve6(A, rhs, x, &chol);
   const float* P = poses + b * 16;
   if (!solved) {  // utils.py:364-365: return poses, poses
     for (int i = 0; i < 16; ++i) new_poses[b * 16 + i] = P[i];
@@ -629,38 +921,83 @@ __global__ void epi_align_update_kernel(const float* H, const float* bvec, const
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) update[b * 6 + i] = x[i];
-  // se3_exp
-  const float rho[3] = {x[0], x[1], x[2]}, phi[3] = {x[3], x[4], x[5]};
-  const float theta = sqrtf(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]);
-  const float a[3] = {phi[0] / theta, phi[1] / theta, phi[2] / theta};
-  const float sk[3][3] = {{0.f, -a[2], a[1]}, {a[2], 0.f, -a[0]}, {-a[1], a[0], 0.f}};
-  const float ct = cosf(theta), st = sinf(theta), sot = st / theta, omc = (1.0f - ct), omcot = omc / theta;
-  float R[3][3], J[3][3], T[4][4];
+  float T[3][4];
+  se3_exp_rows<float>(x, T);
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float eye = i == j ? 1.0f : 0.0f, aat = a[i] * a[j];
-      R[i][j] = ct * eye + omc * aat + st * sk[i][j];
-      J[i][j] = sot * eye + (1.0f - sot) * aat + omcot * sk[i][j];
-    }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) T[i][j] = R[i][j];
-    T[i][3] = J[i][0] * rho[0] + J[i][1] * rho[1] + J[i][2] * rho[2];
-    T[3][i] = 0.f;
-  }
-  T[3][3] = 1.0f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int i = 0; i < 3; ++i) {
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc += T[i][k] * P[k * 4 + j];
       new_poses[b * 16 + i * 4 + j] = acc;
     }
+    new_poses[b * 16 + 12 + j] = P[12 + j];  // row 3 of exp(update) is (0,0,0,1)
+  }
+}
+
+// Its VJP, one sample per thread: cotangents of (new_poses, update) -> d/dH (B,36), d/db (B,6), d/dposes (B,16).
+//   new = E P:  g_E = g_new P^T (rows 0..2; row 3 of E is constant), g_P = E^T g_new
+//   E = se3_exp(x): g_x[k] = sum_ij g_E[i][j] dE[i][j]/dx[k] (forward-mode through the same code) + g_update[k]
+//   x = H^-1 b:  g_b = H^-T g_x;  g_H = -(g_b x^T), symmetrised on the Cholesky path as torch.linalg.cholesky's backward does
+// The failure path of the forward (poses returned unchanged) passes g_new through.
+__global__ void epi_align_update_bwd_kernel(const float* H, const float* bvec, const float* poses, const float* g_new,
+                                            const float* g_update, int B, float* g_H, float* g_b, float* g_poses) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float A[6][6], rhs[6], x[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    rhs[i] = bvec[b * 6 + i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) A[i][j] = H[b * 36 + i * 6 + j];
+  }
+  bool chol;
+  const bool solved = solve6(A, rhs, x, &chol);
+  const float* P = poses + b * 16;
+  const float* gn = g_new + b * 16;
+  if (!solved) {
+    for (int i = 0; i < 16; ++i) g_poses[b * 16 + i] = gn[i];
+    for (int i = 0; i < 36; ++i) g_H[b * 36 + i] = 0.f;
+    for (int i = 0; i < 6; ++i) g_b[b * 6 + i] = 0.f;
+    return;
+  }
+  Dual6 xd[6], Td[3][4];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xd[k] = dual_var(x[k], k);
+  se3_exp_rows<Dual6>(xd, Td);
+  float gx[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gx[k] = g_update ? g_update[b * 6 + k] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gE = 0.f;  // (g_new P^T)[i][j]
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gE += gn[i * 4 + k] * P[j * 4 + k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gx[k] += gE * Td[i][j].d[k];
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = k == 3 ? gn[12 + j] : 0.f;  // row 3 of E is (0,0,0,1)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) acc += Td[i][k].v * gn[i * 4 + j];
+      g_poses[b * 16 + k * 4 + j] = acc;
+    }
+  float y[6];
+  bool chol2;
+  solve6(A, gx, y, &chol2);  // H is symmetric: H^-T = H^-1
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    g_b[b * 6 + i] = y[i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      g_H[b * 36 + i * 6 + j] = chol ? -0.5f * (y[i] * x[j] + x[i] * y[j]) : -(y[i] * x[j]);
+  }
 }
 
 }  // namespace mal
@@ -677,6 +1014,33 @@ extern "C" int mal_direct_align_update(const float* H, const float* b, const flo
 }
 
 
+extern "C" int mal_direct_align_update_bwd(const float* H, const float* b, const float* poses, const float* g_new_poses,
+                                           const float* g_update, int B, float* g_H, float* g_b, float* g_poses, void* stream) {
+  if (B <= 0) return MAL_ESHAPE;
+  if (!H || !b || !poses || !g_new_poses || !g_H || !g_b || !g_poses) return MAL_EINVAL;
+  hipLaunchKernelGGL(epi_align_update_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, H, b, poses, g_new_poses,
+                     g_update, B, g_H, g_b, g_poses);
+  return launch_status();
+}
+
+extern "C" size_t mal_epipolar_gradcoords_bwd_workspace_bytes(int B, int h, int w) {
+  if (B <= 0 || h <= 0 || w <= 0) return 0;
+  return (size_t)B * ((h * w + 255) / 256) * 16 * sizeof(double);
+}
+
+extern "C" int mal_epipolar_gradcoords_bwd(const float* depth, const float* poses, const float* K, const float* g_c_p,
+                                           const float* g_P2, int B, int h, int w, float* g_depth, float* g_poses, void* ws,
+                                           size_t ws_bytes, void* stream) {
+  if (B <= 0 || h < 1 || w < 1 || (double)B * 10 * h * w > 2.0e9 / 4) return MAL_ESHAPE;
+  if (!depth || !poses || !K || !g_c_p || !g_depth || !g_poses || !ws) return MAL_EINVAL;
+  if (ws_bytes < mal_epipolar_gradcoords_bwd_workspace_bytes(B, h, w)) return MAL_EWORKSPACE;
+  EpiGradCoordBwdParams p = {depth, poses, K, g_c_p, g_P2, B, h, w, (h * w + 255) / 256, g_depth, (double*)ws};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(epi_gradcoords_bwd_kernel, dim3(p.nblk, B), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(epi_rows_finish_kernel, dim3(B), dim3(64), 0, st, p.partial, p.nblk, 16, g_poses);
+  return launch_status();
+}
+
 extern "C" int mal_epipolar_gradcoords(const float* depth, const float* poses, const float* K, int B, int h, int w, float* c_p,
                                        float* P2, void* stream) {
   if (B <= 0 || h < 1 || w < 1 || (double)B * 10 * h * w > 2.0e9 / 4) return MAL_ESHAPE;
@@ -691,14 +1055,32 @@ extern "C" size_t mal_direct_align_workspace_bytes(int B, int h, int w) {
   return (size_t)B * ((h * w + 255) / 256) * 27 * sizeof(double);
 }
 
+extern "C" int mal_direct_align_normal_eq_bwd(const float* src_feat, const float* tgt_feat, const float* src_w,
+                                              const float* tgt_w, const float* weight, const float* K, const float* p2,
+                                              const float* P2, const float* g_H, const float* g_b, int B, int C, int h, int w,
+                                              int robust, float* g_src_feat, float* g_tgt_feat, float* g_src_w, float* g_tgt_w,
+                                              float* g_weight, float* g_p2, float* g_P2, void* stream) {
+  if (B <= 0 || C < 1 || h < 1 || w < 1 || (double)B * C * h * w > 2.0e9 / 4) return MAL_ESHAPE;
+  if (!src_feat || !tgt_feat || !src_w || !tgt_w || !K || !p2 || !P2 || !g_H || !g_b) return MAL_EINVAL;
+  if (g_weight && !weight) return MAL_EINVAL;
+  EpiAlignParams p = {};
+  p.src = src_feat; p.tgt = tgt_feat; p.src_w = src_w; p.tgt_w = tgt_w; p.weight = weight; p.K = K; p.p2 = p2; p.P2 = P2;
+  p.B = B; p.C = C; p.h = h; p.w = w; p.nblk = (h * w + 255) / 256; p.robust = robust ? 1 : 0;
+  p.g_H = g_H; p.g_b = g_b; p.g_src = g_src_feat; p.g_tgt = g_tgt_feat; p.g_src_w = g_src_w; p.g_tgt_w = g_tgt_w;
+  p.g_weight = g_weight; p.g_p2 = g_p2; p.g_P2 = g_P2;
+  hipLaunchKernelGGL(epi_align_bwd_kernel, dim3(p.nblk, B), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
 extern "C" int mal_direct_align_normal_eq(const float* src_feat, const float* tgt_feat, const float* src_w, const float* tgt_w,
                                           const float* weight, const float* K, const float* p2, const float* P2, int B, int C,
-                                          int h, int w, float* H, float* b, void* ws, size_t ws_bytes, void* stream) {
+                                          int h, int w, int robust, float* H, float* b, void* ws, size_t ws_bytes, void* stream) {
   if (B <= 0 || C < 1 || h < 1 || w < 1 || (double)B * C * h * w > 2.0e9 / 4) return MAL_ESHAPE;
   if (!src_feat || !tgt_feat || !src_w || !tgt_w || !K || !p2 || !P2 || !H || !b || !ws) return MAL_EINVAL;
   if (ws_bytes < mal_direct_align_workspace_bytes(B, h, w)) return MAL_EWORKSPACE;
   EpiAlignParams p = {};
   p.src = src_feat; p.tgt = tgt_feat; p.src_w = src_w; p.tgt_w = tgt_w; p.weight = weight; p.K = K; p.p2 = p2; p.P2 = P2;
+  p.robust = robust ? 1 : 0;
   p.B = B; p.C = C; p.h = h; p.w = w; p.nblk = (h * w + 255) / 256; p.partial = (double*)ws; p.H = H; p.bvec = b;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(epi_align_kernel, dim3(p.nblk, B), dim3(256), 0, st, p);

@@ -5,10 +5,13 @@
     Reprojections.depth2epipolarcoords(poses, depths)      dualrefine/networks/utils/utils.py:112-217
     CoordSampler.register / __call__(coords, levels, heads) dualrefine/networks/corr.py:6-50
 
-The correlation lookup (``depth2epipolarcoords`` + ``CoordSampler.__call__``) is differentiable (round 2: the DEQ solver
-differentiates through both in training, depth_pose.py:426-455): autograd Functions over ``mal_epipolar_coords_bwd`` /
-``mal_coord_sample_l1_bwd``.  The pose-refinement step (``depth2gradcoords``, ``direct_align``) and the masking lookup
-are forward-only: tensors that require grad are refused there rather than silently detached.  No CPU fallback.
+The correlation lookup (``depth2epipolarcoords`` + ``CoordSampler.__call__``) and the pose-refinement step
+(``depth2gradcoords`` + ``PoseUpdate.direct_align``, with or without ``--robust_pose_loss``) are differentiable (the last
+unrolled solver step differentiates through all of them in training, depth_pose.py:426-455): autograd Functions over
+``mal_epipolar_coords_bwd`` / ``mal_coord_sample_l1_bwd`` / ``mal_epipolar_gradcoords_bwd`` /
+``mal_direct_align_normal_eq_bwd`` / ``mal_direct_align_update_bwd``.  The masking lookup (``depthbins2coords``, run
+under no_grad upstream) is forward-only: tensors that require grad are refused there rather than silently detached.
+No CPU fallback.
 """
 from __future__ import annotations
 
@@ -101,10 +104,131 @@ class CoordSampleFn(torch.autograd.Function):
         return (g_f1, g_c, None, None, *g_pyr)
 
 
+class GradCoordsFn(torch.autograd.Function):
+    """(depths (B,1,h,w), poses (B,4,4), K) -> (c_p (B,2,1,5,h,w), P2 (B,4,h*w)); utils.py:219-236 and its VJP"""
+
+    @staticmethod
+    def forward(ctx, depths, poses, K):
+        d = ops._req(depths.float(), "depths")
+        B, _, h, w = d.shape
+        T = ops._req(poses.float().reshape(B, 16).contiguous(), "poses")
+        Kc = ops._req(K.float().reshape(B, 16).contiguous(), "K")
+        c_p = torch.empty(B, 2, 1, 5, h, w, dtype=torch.float32, device=d.device)
+        P2 = torch.empty(B, 4, h * w, dtype=torch.float32, device=d.device)
+        p = ops._p
+        L.check(L.load().mal_epipolar_gradcoords(p(d), p(T), p(Kc), B, h, w, p(c_p), p(P2), ops._stream()),
+                "mal_epipolar_gradcoords")
+        ctx.save_for_backward(d, T, Kc)
+        ctx.pshape = tuple(poses.shape)
+        ctx.set_materialize_grads(False)
+        return c_p, P2
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_cp, g_P2):
+        d, T, Kc = ctx.saved_tensors
+        B, _, h, w = d.shape
+        dev = d.device
+        if g_cp is None and g_P2 is None:
+            return None, None, None
+        gc = torch.zeros(B, 2, 1, 5, h, w, dtype=torch.float32, device=dev) if g_cp is None else ops._req(g_cp.float(), "g_c_p")
+        gP = None if g_P2 is None else ops._req(g_P2.float(), "g_P2")
+        g_depth = torch.empty_like(d)
+        g_poses = torch.empty(B, 16, dtype=torch.float32, device=dev)
+        lib, p = L.load(), ops._p
+        ws = torch.empty(lib.mal_epipolar_gradcoords_bwd_workspace_bytes(B, h, w), dtype=torch.uint8, device=dev)
+        L.check(lib.mal_epipolar_gradcoords_bwd(p(d), p(T), p(Kc), p(gc), p(gP), B, h, w, p(g_depth), p(g_poses), p(ws),
+                                                ws.numel(), ops._stream()), "mal_epipolar_gradcoords_bwd")
+        return g_depth, g_poses.reshape(ctx.pshape), None
+
+
+class NormalEquationsFn(torch.autograd.Function):
+    """(src_feat, tgt_feat, src_w, tgt_w, weight or None, p2, P2, K, robust) -> (H (B,6,6), b (B,6)); utils.py:303-355"""
+
+    @staticmethod
+    def forward(ctx, src_feat, tgt_feat, src_w, tgt_w, weight, p2, P2, K, robust):
+        src, tgt = ops._req(src_feat.float(), "src_feat"), ops._req(tgt_feat.float(), "tgt_feat")
+        B, C, h, w = src.shape
+        dev = src.device
+        sw, tw = ops._req(src_w.float(), "src_w"), ops._req(tgt_w.float(), "tgt_w")
+        wt = ops._req(weight.float(), "weight") if weight is not None else None
+        Kc = ops._req(K.float().reshape(B, 16).contiguous(), "K")
+        c, X1 = ops._req(p2.float(), "p2"), ops._req(P2.float(), "P2")
+        if tuple(c.shape) != (B, 2, 1, 5, h, w) or tuple(X1.shape) != (B, 4, h * w):
+            raise L.MalError("direct_align: p2 must be (B,2,1,5,h,w) and P2 (B,4,h*w) as depth2gradcoords returns them")
+        H, b = torch.empty(B, 6, 6, dtype=torch.float32, device=dev), torch.empty(B, 6, dtype=torch.float32, device=dev)
+        lib, p = L.load(), ops._p
+        ws = torch.empty(lib.mal_direct_align_workspace_bytes(B, h, w), dtype=torch.uint8, device=dev)
+        L.check(lib.mal_direct_align_normal_eq(p(src), p(tgt), p(sw), p(tw), p(wt), p(Kc), p(c), p(X1), B, C, h, w,
+                                               1 if robust else 0, p(H), p(b), p(ws), ws.numel(), ops._stream()),
+                "mal_direct_align_normal_eq")
+        ctx.save_for_backward(src, tgt, sw, tw, wt, Kc, c, X1)
+        ctx.robust = bool(robust)
+        return H, b
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_H, g_b):
+        src, tgt, sw, tw, wt, Kc, c, X1 = ctx.saved_tensors
+        B, C, h, w = src.shape
+        need = ctx.needs_input_grad
+        gH, gb = ops._req(g_H.float().reshape(B, 36).contiguous(), "g_H"), ops._req(g_b.float().contiguous(), "g_b")
+        new = lambda t, zero=False: (torch.zeros_like(t) if zero else torch.empty_like(t))
+        g_src = new(src) if need[0] else None
+        g_tgt = new(tgt, True) if need[1] else None        # scattered into with atomics
+        g_sw = new(sw) if need[2] else None
+        g_tw = new(tw, True) if need[3] else None
+        g_wt = new(wt) if (need[4] and wt is not None) else None
+        g_c = new(c) if need[5] else None
+        g_X1 = new(X1) if need[6] else None
+        p = ops._p
+        L.check(L.load().mal_direct_align_normal_eq_bwd(p(src), p(tgt), p(sw), p(tw), p(wt), p(Kc), p(c), p(X1), p(gH), p(gb), B,
+                                                        C, h, w, 1 if ctx.robust else 0, p(g_src), p(g_tgt), p(g_sw), p(g_tw),
+                                                        p(g_wt), p(g_c), p(g_X1), ops._stream()),
+                "mal_direct_align_normal_eq_bwd")
+        return g_src, g_tgt, g_sw, g_tw, g_wt, g_c, g_X1, None, None
+
+
+class AlignUpdateFn(torch.autograd.Function):
+    """(H (B,6,6), b (B,6), poses (B,4,4)) -> (new_poses (B,4,4), update (B,6,1)); utils.py:357-368"""
+
+    @staticmethod
+    def forward(ctx, H, b, poses):
+        B = H.shape[0]
+        Hc, bc = ops._req(H.float().reshape(B, 36).contiguous(), "H"), ops._req(b.float().contiguous(), "b")
+        T = ops._req(poses.float().reshape(B, 16).contiguous(), "poses")
+        new_poses = torch.empty(B, 4, 4, dtype=torch.float32, device=Hc.device)
+        update = torch.empty(B, 6, 1, dtype=torch.float32, device=Hc.device)
+        p = ops._p
+        L.check(L.load().mal_direct_align_update(p(Hc), p(bc), p(T), B, p(new_poses), p(update), ops._stream()),
+                "mal_direct_align_update")
+        ctx.save_for_backward(Hc, bc, T)
+        ctx.set_materialize_grads(False)
+        return new_poses, update
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_new, g_update):
+        Hc, bc, T = ctx.saved_tensors
+        B = Hc.shape[0]
+        dev = Hc.device
+        if g_new is None and g_update is None:
+            return None, None, None
+        gn = torch.zeros(B, 16, dtype=torch.float32, device=dev) if g_new is None else \
+            ops._req(g_new.float().reshape(B, 16).contiguous(), "g_new_poses")
+        gu = None if g_update is None else ops._req(g_update.float().reshape(B, 6).contiguous(), "g_update")
+        g_H, g_b = torch.empty(B, 36, dtype=torch.float32, device=dev), torch.empty(B, 6, dtype=torch.float32, device=dev)
+        g_T = torch.empty(B, 16, dtype=torch.float32, device=dev)
+        p = ops._p
+        L.check(L.load().mal_direct_align_update_bwd(p(Hc), p(bc), p(T), p(gn), p(gu), B, p(g_H), p(g_b), p(g_T), ops._stream()),
+                "mal_direct_align_update_bwd")
+        return g_H.reshape(B, 6, 6), g_b, g_T.reshape(B, 4, 4)
+
+
 def _no_grad(*ts):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
-        raise L.MalError("mal_amd.epipolar is forward-only: call it under torch.no_grad() (the VJPs of the epipolar lookup "
-                         "are not implemented)")
+        raise L.MalError("the masking lookup (depthbins2coords) is forward-only: call it under torch.no_grad() as upstream does "
+                         "(depth_pose.py:522); the correlation lookup and the pose-refinement step are differentiable")
 
 
 class Reprojections(torch.nn.Module):
@@ -144,18 +268,7 @@ class Reprojections(torch.nn.Module):
         ones are)"""
         if self.K is None:
             raise L.MalError("Reprojections: call _reg_intrinsics(K) first (depth_pose.py:471)")
-        _no_grad(poses, depths)
-        d = ops._req(depths.detach(), "depths")
-        B, _, h, w = d.shape
-        T = ops._req(poses.detach().float().reshape(B, 16).contiguous(), "poses")
-        K = ops._req(self.K.detach().float().reshape(B, 16).contiguous(), "K")
-        c_p = torch.empty(B, 2, 1, 5, h, w, dtype=torch.float32, device=d.device)
-        P2 = torch.empty(B, 4, h * w, dtype=torch.float32, device=d.device)
-        p = ops._p
-        L.check(L.load().mal_epipolar_gradcoords(p(d), p(T), p(K), B, h, w, p(c_p), p(P2), ops._stream()),
-                "mal_epipolar_gradcoords")
-        return c_p, P2
-
+        return GradCoordsFn.apply(depths, poses, self.K.detach())
 
     def depthbins2coords(self, poses, depths):
         """-> (coords (B,2,1,num_depth_bins,h,w), depth hypotheses (B,1,num_depth_bins,h,w)), utils.py:231-255.  The
@@ -218,8 +331,6 @@ class PoseUpdate(torch.nn.Module):
     def __init__(self, args, inp_dim=None, norm_fn="batch"):
         super().__init__()
         self.args = args
-        if getattr(args, "robust_pose_loss", False):
-            raise NotImplementedError("--robust_pose_loss (utils.py:334-338) is not built")
 
     def compute_uncertainty(self, feats):
         if not getattr(self.args, "disable_fixed_pose_weight", False):
@@ -229,39 +340,18 @@ class PoseUpdate(torch.nn.Module):
         self.src_w, self.tgt_w = feats.new_ones((bsz // 2, 1, ht, wd)), feats.new_ones((bsz // 2, 1, ht, wd))
 
     def compute_feat(self, fmap1, fmap2):
-        _no_grad(fmap1, fmap2)
-        self.src_feat, self.tgt_feat = fmap1.detach().float(), fmap2.detach().float()
+        self.src_feat, self.tgt_feat = fmap1.float(), fmap2.float()
 
     def normal_equations(self, calib_K, p2, P2, weight):
-        """utils.py:303-355 -> H (B,6,6), b (B,6) in two launches"""
-        _no_grad(p2, P2, weight, self.src_w, self.tgt_w)
-        src, tgt = ops._req(self.src_feat, "src_feat"), ops._req(self.tgt_feat, "tgt_feat")
-        B, C, h, w = src.shape
-        dev = src.device
-        sw, tw = ops._req(self.src_w.detach().float(), "src_w"), ops._req(self.tgt_w.detach().float(), "tgt_w")
-        wt = ops._req(weight.detach().float(), "weight") if weight is not None else None
-        K = ops._req(calib_K.detach().float().reshape(B, 16).contiguous(), "K")
-        c, X1 = ops._req(p2.detach(), "p2"), ops._req(P2.detach(), "P2")
-        if tuple(c.shape) != (B, 2, 1, 5, h, w) or tuple(X1.shape) != (B, 4, h * w):
-            raise L.MalError("direct_align: p2 must be (B,2,1,5,h,w) and P2 (B,4,h*w) as depth2gradcoords returns them")
-        H, b = torch.empty(B, 6, 6, dtype=torch.float32, device=dev), torch.empty(B, 6, dtype=torch.float32, device=dev)
-        lib, p = L.load(), ops._p
-        ws = torch.empty(lib.mal_direct_align_workspace_bytes(B, h, w), dtype=torch.uint8, device=dev)
-        L.check(lib.mal_direct_align_normal_eq(p(src), p(tgt), p(sw), p(tw), p(wt), p(K), p(c), p(X1), B, C, h, w, p(H), p(b),
-                                               p(ws), ws.numel(), ops._stream()), "mal_direct_align_normal_eq")
-        return H, b
+        """utils.py:303-355 -> H (B,6,6), b (B,6) in two launches (``--robust_pose_loss``: :344-355 inside the same)"""
+        return NormalEquationsFn.apply(self.src_feat, self.tgt_feat, self.src_w, self.tgt_w, weight, p2, P2, calib_K.detach(),
+                                       bool(getattr(self.args, "robust_pose_loss", False)))
 
     def direct_align(self, poses, calib_K, p2, P2, weight):
         """utils.py:303-368 -> (new poses (B,4,4), update (B,6,1)): normal equations (two launches), then the 6x6 solve
-        with upstream's fall-backs, se3_exp and the pose product in one more"""
+        with upstream's fall-backs, se3_exp and the pose product in one more; differentiable end to end"""
         H, b = self.normal_equations(calib_K, p2, P2, weight)
-        B = H.shape[0]
-        T = ops._req(poses.detach().float().reshape(B, 16).contiguous(), "poses")
-        new_poses = torch.empty(B, 4, 4, dtype=torch.float32, device=H.device)
-        update = torch.empty(B, 6, 1, dtype=torch.float32, device=H.device)
-        p = ops._p
-        L.check(L.load().mal_direct_align_update(p(H), p(b), p(T), B, p(new_poses), p(update), ops._stream()),
-                "mal_direct_align_update")
+        new_poses, update = AlignUpdateFn.apply(H, b, poses)
         return new_poses.type(poses.dtype), update
 
 

@@ -159,8 +159,21 @@ def sample_tgt(tgt_feat, tgt_w, p2):
     return f[..., 0], grads, w
 
 
-def normal_equations(src_feat, tgt_feat, src_w, tgt_w, K, p2, P2, weight=None):
-    """utils.py:303-355 up to the solve (without --robust_pose_loss, the default): H (B,6,6), b (B,6)"""
+def robust_weights(res, p2, height, width):
+    """--robust_pose_loss, utils.py:344-348: scaled_barron(0, 0.1) of the squared residual (losses.py:8-19,41-90 with
+    alpha = 0: first derivative 2 / (x + 2) at x = cost / 0.1**2) x the in-image test of the projected centre with a
+    2 px margin (utils.py:409-412)"""
+    batch_size = p2.shape[0]
+    cost = (res[..., 0] ** 2).sum(-1).reshape(batch_size, 1, height, width)
+    w_loss = 2 / (cost / (0.1 ** 2) + 2)
+    pts, pad = p2[:, :, 0, 0], 2
+    hi = torch.tensor([width - pad - 1, height - pad - 1]).to(pts).reshape(1, 2, 1, 1)
+    valid = torch.all((pts >= pad) & (pts <= hi), 1, keepdim=True)
+    return w_loss * valid.float()
+
+
+def normal_equations(src_feat, tgt_feat, src_w, tgt_w, K, p2, P2, weight=None, robust=False):
+    """utils.py:303-355 up to the solve: H (B,6,6), b (B,6)"""
     batch_size, channels, height, width = src_feat.shape
     warped, grads, warped_w = sample_tgt(tgt_feat, tgt_w, p2)
     X, Y, Z = P2[:, 0], P2[:, 1], P2[:, 2]
@@ -177,15 +190,17 @@ def normal_equations(src_feat, tgt_feat, src_w, tgt_w, K, p2, P2, weight=None):
     w = src_w * warped_w
     if weight is not None:
         w = w * weight
+    if robust:
+        w = w * robust_weights(res, p2, height, width)
     JW = J * w.reshape(batch_size, height * width, 1, 1)
     H = (JW.transpose(2, 3) @ J).sum(1)
     b = (-res * JW).sum(2).sum(1)
     return H, b
 
 
-def direct_align(poses, src_feat, tgt_feat, src_w, tgt_w, K, p2, P2, weight=None):
+def direct_align(poses, src_feat, tgt_feat, src_w, tgt_w, K, p2, P2, weight=None, robust=False):
     """utils.py:303-368: one Gauss-Newton step on the feature-metric error -> (new poses (B,4,4), update (B,6,1))"""
-    H, b = normal_equations(src_feat, tgt_feat, src_w, tgt_w, K, p2, P2, weight)
+    H, b = normal_equations(src_feat, tgt_feat, src_w, tgt_w, K, p2, P2, weight, robust)
     L = torch.linalg.cholesky(H)
     update = torch.cholesky_solve(b[..., None], L)
     return torch.bmm(se3_exp(update).type(poses.dtype), poses), update

@@ -108,6 +108,27 @@ def main():
             "in/f2": f2s.half().numpy(), "in/src_w": src_w.numpy(), "in/tgt_w": tgt_w.numpy(), "in/weight": weight.numpy(),
             "out/c_p": c_p.numpy(), "out/P2": P2.numpy(), "out/new_poses": new_poses.numpy(), "out/update": update.numpy()})
         print("  align", tuple(c_p.shape), update.flatten()[:3].tolist())
+        # ---- VJP of the refinement step, with and without --robust_pose_loss (utils.py:344-355): autograd through the
+        # reference's own depth2gradcoords + PoseUpdate.direct_align
+        g3 = torch.Generator().manual_seed(seed + 700)
+        Wn, Wu = torch.randn(B, 4, 4, generator=g3), torch.randn(B, 6, 1, generator=g3)
+        for robust in (False, True):
+            args.robust_pose_loss = robust
+            Pg = U.PoseUpdate(args, C, norm_fn="none")
+            leaves = {k: v.clone().requires_grad_(True) for k, v in dict(
+                poses=poses, depth=depth, f1=f1, f2=f2s, src_w=src_w, tgt_w=tgt_w, weight=weight).items()}
+            cg, Pg2 = R.depth2gradcoords(leaves["poses"], leaves["depth"], K)
+            Pg.compute_feat(leaves["f1"], leaves["f2"])
+            Pg.src_w, Pg.tgt_w = leaves["src_w"], leaves["tgt_w"]
+            npg, upg = Pg.direct_align(leaves["poses"], K, cg, Pg2, leaves["weight"])
+            ((npg * Wn).sum() + (upg * Wu).sum()).backward()
+            name = tag.replace("epi_", "epi_aligngrad_") + ("_robust" if robust else "")
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), **{
+                "in/Wn": Wn.numpy(), "in/Wu": Wu.numpy(), "out/new_poses": npg.detach().numpy(), "out/update": upg.detach().numpy(),
+                **{"grad/" + k: v.grad.numpy() for k, v in leaves.items()}})
+            print("  aligngrad robust=%d" % robust, upg.detach().flatten()[:3].tolist(),
+                  {k: float(v.grad.abs().sum()) for k, v in leaves.items()})
+        args.robust_pose_loss = False
         # the masking lookup (depth_pose.py:561-580): depthbins2coords (both branches) + CoordSampler.__corr__
         if B * h * w > 200:  # 96 hypotheses per pixel: keep only the small case as a fixture
             continue

@@ -91,3 +91,37 @@ def test_lookup_vjp_oracle_reproduces_reference(tag):
     g = oracle_lookup_grads(K, depth, poses, f1, f2, r, L, heads, delta, t("in/w_corr"), t("in/w_ds"), t("in/w_mx"))
     for k, v in g.items():
         assert np.array_equal(v.numpy().reshape(zg["grad/" + k].shape), zg["grad/" + k]), k
+
+
+ALIGNGRAD_CASES = [t + r for t in ("epi_aligngrad_b2_c16_12x20_r4_l3", "epi_aligngrad_b1_c8_9x13_r2_l2_h2") for r in ("", "_robust")]
+ALIGN_LEAVES = ("poses", "depth", "f1", "f2", "src_w", "tgt_w", "weight")
+
+
+def load_aligngrad(tag):
+    """inputs of the align fixture of the same case + the cotangents / outputs / gradients of the VJP fixture"""
+    robust = tag.endswith("_robust")
+    base = tag[:-len("_robust")] if robust else tag
+    z, i = load_align(base.replace("epi_aligngrad_", "epi_align_"))
+    g = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    return i, {k: torch.from_numpy(g[k]) for k in g.files}, robust
+
+
+def oracle_align_grads(i, Wn, Wu, robust):
+    lv = {k: i[k].clone().requires_grad_(True) for k in ALIGN_LEAVES}
+    c_p, P2 = E.depth2gradcoords(lv["poses"], lv["depth"], i["K"])
+    new_poses, update = E.direct_align(lv["poses"], lv["f1"], lv["f2"], lv["src_w"], lv["tgt_w"], i["K"], c_p, P2, lv["weight"],
+                                       robust=robust)
+    ((new_poses * Wn).sum() + (update * Wu).sum()).backward()
+    return new_poses.detach(), update.detach(), {k: v.grad for k, v in lv.items()}
+
+
+@pytest.mark.parametrize("tag", ALIGNGRAD_CASES)
+def test_direct_align_vjp_oracle_reproduces_reference(tag):
+    """the refinement step's outputs (incl. --robust_pose_loss, utils.py:344-355) and its gradients w.r.t. every input, as
+    autograd takes them through the reference's own depth2gradcoords + PoseUpdate.direct_align"""
+    i, g, robust = load_aligngrad(tag)
+    new_poses, update, grads = oracle_align_grads(i, g["in/Wn"], g["in/Wu"], robust)
+    assert np.array_equal(new_poses.numpy(), g["out/new_poses"].numpy()) and np.array_equal(update.numpy(), g["out/update"].numpy())
+    for k in ALIGN_LEAVES:
+        r = g["grad/" + k]
+        assert float((grads[k] - r).abs().max()) <= 1e-5 * float(r.abs().max()) + 1e-9, k

@@ -70,13 +70,17 @@ def test_dualrefine_size_against_the_cpu_checker():
 
 
 def test_forward_only_is_enforced_where_no_vjp_exists():
-    """the lookup is differentiable; the pose-refinement step is not yet and refuses tensors that require grad"""
+    """the lookup and the pose-refinement step are differentiable; the masking lookup (run under no_grad upstream,
+    depth_pose.py:522) refuses tensors that require grad instead of silently detaching them"""
     from mal_amd import epipolar, _lib
-    R = epipolar.Reprojections(_args(2, 1)).to(DEV)
-    K = torch.eye(4, device=DEV).repeat(1, 1, 1)
-    R._reg_intrinsics(K)
+    a = _args(2, 1)
+    a.use_depth_bins_for_masking, a.min_depth, a.max_depth = False, 0.1, 100.0
+    R = epipolar.Reprojections(a).to(DEV)
+    R._reg_intrinsics(torch.eye(4, device=DEV).repeat(1, 1, 1))
     with pytest.raises(_lib.MalError):
-        R.depth2gradcoords(torch.eye(4, device=DEV)[None], torch.ones(1, 1, 8, 8, device=DEV, requires_grad=True))
+        R.depthbins2coords(torch.eye(4, device=DEV)[None], torch.ones(1, 1, 8, 8, device=DEV, requires_grad=True))
+    c_p, P2 = R.depth2gradcoords(torch.eye(4, device=DEV)[None], torch.ones(1, 1, 8, 8, device=DEV, requires_grad=True))
+    assert c_p.requires_grad and P2.requires_grad
 
 
 def _align_case(i):
@@ -215,3 +219,114 @@ def test_lookup_vjp_dualrefine_size():
     ref = oracle_lookup_grads(K, depth, poses, f1, f2, r, L, heads, delta, w_corr, w_ds, w_mx)
     got = run_grads(K, depth, poses, f1, f2, r, L, heads, 0.7, w_corr, w_ds, w_mx)
     check_grads(got, ref, depth.numel())
+
+
+# ---------------------------------------------------------------- VJP of the pose-refinement step
+def _align_objects(robust):
+    from mal_amd import epipolar
+    a = SimpleNamespace(corr_radius=2, disable_pose_updates=False, gap_factor="depth", gap_factor_depth_ratio=8, num_levels=1,
+                        disable_fixed_pose_weight=True, robust_pose_loss=robust)
+    return epipolar.Reprojections(a).to(DEV), epipolar.PoseUpdate(a)
+
+
+def run_align_grads(i, Wn, Wu, robust):
+    """depth2gradcoords + direct_align on the device, backward of sum(new_poses Wn) + sum(update Wu)"""
+    from tests.test_epi_oracle import ALIGN_LEAVES
+    R, P = _align_objects(robust)
+    d = lambda t: t.to(DEV)
+    lv = {k: d(i[k]).clone().requires_grad_(True) for k in ALIGN_LEAVES}
+    R._reg_intrinsics(d(i["K"]))
+    c_p, P2 = R.depth2gradcoords(lv["poses"], lv["depth"], d(i["K"]))
+    P.compute_feat(lv["f1"], lv["f2"])
+    P.src_w, P.tgt_w = lv["src_w"], lv["tgt_w"]
+    new_poses, update = P.direct_align(lv["poses"], d(i["K"]), c_p, P2, lv["weight"])
+    ((new_poses * d(Wn)).sum() + (update * d(Wu)).sum()).backward()
+    torch.cuda.synchronize()
+    return new_poses.detach().cpu(), update.detach().cpu(), {k: v.grad.cpu() for k, v in lv.items()}
+
+
+def _check_maps(got, ref, tol, what):
+    for k, r in ref.items():
+        g = got[k].reshape(r.shape)
+        sc = float(r.abs().max())
+        if g.numel() <= 64:
+            assert float((g - r).abs().max()) <= tol * sc + 1e-7, (what, k, float((g - r).abs().max()), sc)
+        else:  # a sample within rounding distance of a tap boundary takes the neighbouring taps: a handful of elements
+            bad = ((g - r).abs() > tol * sc).float().mean().item()
+            assert bad <= 2e-4 + 4.0 / g.numel(), (what, k, bad)
+            assert float(np.linalg.norm((g - r).numpy().ravel()) / (np.linalg.norm(r.numpy().ravel()) + 1e-30)) <= 20 * tol, (what, k)
+
+
+@pytest.mark.parametrize("tag", [t + r for t in ("epi_aligngrad_b2_c16_12x20_r4_l3", "epi_aligngrad_b1_c8_9x13_r2_l2_h2")
+                                 for r in ("", "_robust")])
+def test_direct_align_vjp_golden(tag):
+    """end to end against the gradients autograd takes through the reference's own classes (the fixture).  The chain holds
+    a 6x6 solve: errors are the pieces' (1e-4, next test) times its conditioning"""
+    from tests.test_epi_oracle import load_aligngrad, ALIGN_LEAVES
+    i, g, robust = load_aligngrad(tag)
+    new_poses, update, grads = run_align_grads(i, g["in/Wn"], g["in/Wu"], robust)
+    assert (update - g["out/update"]).abs().max() <= 2e-3 * max(1e-3, float(g["out/update"].abs().max()))
+    assert (new_poses - g["out/new_poses"]).abs().max() <= 2e-3
+    _check_maps(grads, {k: g["grad/" + k] for k in ALIGN_LEAVES}, 5e-3, tag)
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["plain", "robust_pose_loss"])
+def test_direct_align_vjp_pieces_dualrefine_size(robust):
+    """B=8, 128 channels, 48x160: each of the three VJPs on its own against autograd through the CPU checker, 1e-4"""
+    from mal_amd import epipolar
+    from oracle import epi_oracle as E
+    from oracle.gen_golden_epi import make_case
+    B, C, h, w = 8, 128, 48, 160
+    K, depth, poses, f1, f2 = make_case(B, C, h, w, seed=4, trans=0.05)
+    g = torch.Generator().manual_seed(17)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    f2 = (0.8 * f1 + 0.2 * f2).half().float()
+    src_w, tgt_w, weight = (0.5 + torch.rand(B, 1, h, w, generator=g) for _ in range(3))
+    d = lambda t: t.to(DEV)
+    leaf = lambda t, dev="cpu": t.to(dev).clone().requires_grad_(True)
+    # ---- depth2gradcoords
+    w_cp, w_P2 = rnd(B, 2, 1, 5, h, w), rnd(B, 4, h * w)
+    ol = dict(depth=leaf(depth), poses=leaf(poses))
+    c_p, P2 = E.depth2gradcoords(ol["poses"], ol["depth"], K)
+    ((c_p * w_cp).sum() + (P2 * w_P2).sum()).backward()
+    R, P = _align_objects(robust)
+    R._reg_intrinsics(d(K))
+    hl = dict(depth=leaf(depth, DEV), poses=leaf(poses, DEV))
+    hc, hP = R.depth2gradcoords(hl["poses"], hl["depth"], d(K))
+    ((hc * d(w_cp)).sum() + (hP * d(w_P2)).sum()).backward()
+    _check_maps({k: v.grad.cpu() for k, v in hl.items()}, {k: v.grad for k, v in ol.items()}, 1e-4, "gradcoords")
+    # ---- normal equations (same p2 / P2 on both sides)
+    c_p, P2 = c_p.detach(), P2.detach()
+    g_H, g_b = rnd(B, 6, 6), rnd(B, 6)
+    names = ("f1", "f2", "src_w", "tgt_w", "weight", "p2", "P2")
+    vals = (f1, f2, src_w, tgt_w, weight, c_p, P2)
+    ol = {k: leaf(v) for k, v in zip(names, vals)}
+    H, b = E.normal_equations(ol["f1"], ol["f2"], ol["src_w"], ol["tgt_w"], K, ol["p2"], ol["P2"], ol["weight"], robust=robust)
+    ((H * g_H).sum() + (b * g_b).sum()).backward()
+    hl = {k: leaf(v, DEV) for k, v in zip(names, vals)}
+    P.compute_feat(hl["f1"], hl["f2"])
+    P.src_w, P.tgt_w = hl["src_w"], hl["tgt_w"]
+    hH, hb = P.normal_equations(d(K), hl["p2"], hl["P2"], hl["weight"])
+    assert (hH.detach().cpu() - H.detach()).abs().max() <= 1e-4 * float(H.detach().abs().max())
+    assert (hb.detach().cpu() - b.detach()).abs().max() <= 1e-4 * float(b.detach().abs().max())
+    ((hH * d(g_H)).sum() + (hb * d(g_b)).sum()).backward()
+    _check_maps({k: v.grad.cpu() for k, v in hl.items()}, {k: v.grad for k, v in ol.items()}, 1e-4, "normal_equations")
+    # ---- solve + se3_exp + pose product (H, b from the checker; torch.linalg.cholesky's backward symmetrises d/dH)
+    H0, b0 = H.detach(), b.detach()
+    g_new, g_up = rnd(B, 4, 4), rnd(B, 6, 1)
+    ol = dict(H=leaf(H0), b=leaf(b0), poses=leaf(poses))
+    Lc = torch.linalg.cholesky(ol["H"])
+    up = torch.cholesky_solve(ol["b"][..., None], Lc)
+    new = torch.bmm(E.se3_exp(up), ol["poses"])
+    ((new * g_new).sum() + (up * g_up).sum()).backward()
+    hl = dict(H=leaf(H0, DEV), b=leaf(b0, DEV), poses=leaf(poses, DEV))
+    hn, hu = epipolar.AlignUpdateFn.apply(hl["H"], hl["b"], hl["poses"])
+    ((hn * d(g_new)).sum() + (hu * d(g_up)).sum()).backward()
+    assert (hu.detach().cpu() - up.detach()).abs().max() <= 2e-3 * max(1e-3, float(up.abs().max()))
+    ref = {k: v.grad for k, v in ol.items()}
+    ref["H"] = 0.5 * (ref["H"] + ref["H"].transpose(1, 2))
+    got = {k: v.grad.cpu() for k, v in hl.items()}
+    for k in ref:  # per sample: the conditioning of the 6x6 systems differs
+        for s in range(B):
+            sc = float(ref[k][s].abs().max())
+            assert float((got[k][s] - ref[k][s]).abs().max()) <= 2e-3 * sc + 1e-7, (k, s)
