@@ -59,6 +59,27 @@ with torch.no_grad():
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(20): align()
     torch.cuda.synchronize(); ta = (time.perf_counter() - t) / 20
+# ---- the same step forward + backward (the last unrolled solver step differentiates through it), plain and robust
+def align_fb(robust):
+    args.robust_pose_loss = robust
+    Pg = epipolar.PoseUpdate(args)
+    lv = [t_.to(dev).clone().requires_grad_(True) for t_ in (poses, depth, f1, f2s, src_w, tgt_w, weight)]
+    def run():
+        for t_ in lv:
+            t_.grad = None
+        c_p, P2 = R.depth2gradcoords(lv[0], lv[1], g[0])
+        Pg.compute_feat(lv[2], lv[3])
+        Pg.src_w, Pg.tgt_w = lv[4], lv[5]
+        new_poses, update = Pg.direct_align(lv[0], g[0], c_p, P2, lv[6])
+        (new_poses.sum() + update.sum()).backward()
+    for _ in range(3): run()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / 10
+tafb, tafb_r = align_fb(False), align_fb(True)
+args.robust_pose_loss = False
+with torch.no_grad():
     # the CPU checkers last: their OpenMP workers keep spinning for a while and would starve the launching thread
     t = time.perf_counter()
     rc, _, _ = E.depth2epipolarcoords(poses, depth, K, torch.tensor([1.0]), r=r, num_levels=L)
@@ -84,3 +105,5 @@ print("bound: vector-memory address path: %.1f M dword wave-loads -> %.1f G wave
 print("lookup forward + backward (VJPs w.r.t. depth, pose, delta, both feature maps; the scatter into the feature pyramid uses "
       "float atomics, %.2f G lane-adds): HIP %.0f us" % (B * h * w * D * C * 4 / 1e9, tfb * 1e6))
 print("direct_align: HIP %.0f us (gradcoords + normal equations + solve/se3 update kernel)   CPU checker %.2f s" % (ta * 1e6, tca))
+print("direct_align forward + backward (VJPs w.r.t. poses, depth, both feature maps, the three weight maps; %.2f G lane-adds "
+      "into the target features): HIP %.0f us, with --robust_pose_loss %.0f us" % (B * h * w * C * 20 / 1e9, tafb * 1e6, tafb_r * 1e6))
