@@ -419,8 +419,9 @@ int mal_coord_sample_l1(const float* fmap1, const float* const* f2_pyramid, cons
  * dualrefine/networks/depth_pose.py:426-455).  mal_epipolar_coords_bwd: cotangents of (coords, max_dx, depths) --
  * the last two nullable -- -> g_depth (B,1,h,w), g_poses (B,16; row 3 zero), g_dd (1) = d / d softplus(delta); fixed
  * summation order.  mal_coord_sample_l1_bwd: cotangent of the lookup's output -> g_fmap1 (B,C,h,w), g_f2_pyramid[l]
- * (level shapes), g_coords; g_fmap1 / g_f2_pyramid[l] must be ZERO on entry (accumulated with float atomics, as
- * ATen's grid_sampler backward does); any of the three may be NULL. */
+ * (level shapes), g_coords; g_fmap1 / g_f2_pyramid[l] are ACCUMULATED into (zero them first); any of the three may be
+ * NULL.  With ws and planes that fit the LDS the sums are exact integer (fixed-point) accumulations per (sample, channel)
+ * plane -- order-independent --; otherwise float atomics, as ATen's grid_sampler backward. */
 size_t mal_epipolar_coords_bwd_workspace_bytes(int B, int h, int w);
 int mal_epipolar_coords_bwd(const float* depth, const float* poses, const float* K, const float* g_coords,
                             const float* g_max_dx, const float* g_depths, int B, int h, int w, int r, int L,
@@ -428,7 +429,8 @@ int mal_epipolar_coords_bwd(const float* depth, const float* poses, const float*
                             void* ws, size_t ws_bytes, void* stream);
 int mal_coord_sample_l1_bwd(const float* fmap1, const float* const* f2_pyramid, const float* coords, const float* g_out,
                             int B, int C, int h, int w, int L, int d1, int heads, float* g_fmap1,
-                            float* const* g_f2_pyramid, float* g_coords, void* stream);
+                            float* const* g_f2_pyramid, float* g_coords, void* ws, size_t ws_bytes, void* stream);
+size_t mal_coord_sample_l1_bwd_workspace_bytes(int B); /* ws nullable: without it the feature cotangents use global atomics */
 /* The pose refinement step of the same loop (depth_pose.py:450-455), forward:
  * mal_epipolar_gradcoords = Reprojections.depth2gradcoords (utils.py:219-236): c_p (B,2,1,5,h,w) = the projection and its
  * +-1 px neighbours in x and y, P2 (B,4,h*w) = the transformed points.
@@ -461,7 +463,8 @@ int mal_direct_align_normal_eq_bwd(const float* src_feat, const float* tgt_feat,
                                    const float* weight, const float* K, const float* p2, const float* P2, const float* g_H,
                                    const float* g_b, int B, int C, int h, int w, int robust, float* g_src_feat,
                                    float* g_tgt_feat, float* g_src_w, float* g_tgt_w, float* g_weight, float* g_p2, float* g_P2,
-                                   void* stream);
+                                   void* ws, size_t ws_bytes, void* stream);
+size_t mal_direct_align_bwd_workspace_bytes(int B, int h, int w); /* ws nullable: without it g_tgt_feat is scattered with global atomics */
 int mal_direct_align_update_bwd(const float* H, const float* b, const float* poses, const float* g_new_poses,
                                 const float* g_update, int B, float* g_H, float* g_b, float* g_poses, void* stream);
 
@@ -474,6 +477,8 @@ int mal_direct_align_update_bwd(const float* H, const float* b, const float* pos
  * "costvol_impl" 1 (default): cost volume with planar features, lane = pixel; 0: channel-last, lane = channel;
  * "photo_impl"  mal_photo_fwd/bwd: 1 = marching kernels, two candidates per launch (default for SSIM + min);
  *               0 = one pixel per thread (ATen's summation order; always used for MAL_F_NO_SSIM / MAL_F_AVG);
+ * "epi_bwd_planes" 1 (default): the feature-map cotangents of the N4 VJPs are accumulated per (sample, channel) plane in
+ *               LDS when the planes fit; 0: global float atomics everywhere (the first formulation, kept for A/B);
  * "fwd_waves", "debug": kernel experiments. */
 int mal_set_option(const char* name, int value);
 

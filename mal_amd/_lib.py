@@ -70,7 +70,8 @@ SIGNATURES = {
     "mal_epipolar_coords_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "mal_epipolar_coords_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, f32, f32, c_fp, c_fp, c_fp,
                                       vp, sz, vp]),
-    "mal_coord_sample_l1_bwd": (i32, [c_fp, vp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, vp, c_fp, vp]),
+    "mal_coord_sample_l1_bwd": (i32, [c_fp, vp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, vp, c_fp, vp, sz, vp]),
+    "mal_coord_sample_l1_bwd_workspace_bytes": (sz, [i32]),
     "mal_epipolar_coords_of_depths": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, vp]),
     "mal_epipolar_gradcoords": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, vp]),
     "mal_direct_align_workspace_bytes": (sz, [i32, i32, i32]),
@@ -78,7 +79,8 @@ SIGNATURES = {
     "mal_direct_align_normal_eq": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp, vp, sz, vp]),
     "mal_epipolar_gradcoords_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "mal_epipolar_gradcoords_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, vp, sz, vp]),
-    "mal_direct_align_normal_eq_bwd": (i32, [c_fp] * 10 + [i32] * 5 + [c_fp] * 7 + [vp]),
+    "mal_direct_align_normal_eq_bwd": (i32, [c_fp] * 10 + [i32] * 5 + [c_fp] * 7 + [vp, sz, vp]),
+    "mal_direct_align_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "mal_direct_align_update_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp, vp]),
     "mal_step_workspace_bytes": (sz, [i32, i32, i32]),
     "mal_loss_step_fwd": (i32, [vp]),

@@ -21,6 +21,7 @@ constexpr int kEpiMaxLevels = 4;
 #define MAL_EPI_G 3  // 2-3: 0.70 ms, 4: 0.77, 6: 0.73 at B=8, 128 channels, 48x160, 51 hypotheses
 #endif
 constexpr int kEpiG = MAL_EPI_G;  // hypotheses per wavefront
+int g_epi_bwd_planes = 1;         // option "epi_bwd_planes": 0 = the global-atomic scatter everywhere (A/B)
 
 struct EpiCoordParams {
   const float* depth; const float* poses; const float* K;
@@ -375,6 +376,112 @@ __global__ __launch_bounds__(256) void epi_sample_bwd_kernel(EpiSampleBwdParams 
   }
 }
 
+// The same cotangents w.r.t. the two feature maps with NO global atomics: a workgroup owns ONE channel plane of a sample
+// -- fmap1's plane and every pyramid level's plane of fmap2 --, walks all pixels and all hypotheses of that sample
+// (lane = pixel: coordinates and cotangent are coalesced reads, re-read per channel from the L2), adds what each sample
+// sends to its four taps into the level planes held in LDS and writes every plane out once.  d/d fmap1 is a per-thread
+// register sum.  The LDS planes are 64-bit FIXED-POINT accumulators (ds_add_u64; least significant bit = max|cotangent|
+// / channels x 2^-30, so 2^33 full-magnitude hits fit): scripts/lds_atomic_probe.hip measures ds_add_f32 at 0.33
+// lane-adds per cycle per CU whatever the addresses -- one lane at a time --, ds_add_u32 at 13 and ds_add_u64 at 7.5-9;
+// and integer addition is associative, so this sum does not depend on the order either.  The global-atomic scatter
+// above ran at 36 G lane-adds/s (1.6 G of them at DualRefine's size: 44 ms) and float LDS adds at 216 G/s (7.4 ms); it
+// remains the path for planes that do not fit the LDS (48x160 + 24x80 + 12x40 accumulators = 79 KB of the 160).
+struct LevelTaps { unsigned o[4]; float w[4]; };
+MAL_DEV LevelTaps level_taps(float u, float v, int w, int h, int wl, int hl) {
+  LevelTaps t;
+  const float gx = div_(2.0f * (u + 0.5f), (float)w) - 1.0f, gy = div_(2.0f * (v + 0.5f), (float)h) - 1.0f;
+  const float ix = ((gx + 1.0f) * (float)wl - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)hl - 1.0f) / 2.0f;
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float xc = fminf(fmaxf(x0f, -2.0f), (float)wl + 1.0f), yc = fminf(fmaxf(y0f, -2.0f), (float)hl + 1.0f);
+  const bool wild = !(x0f == xc && y0f == yc);
+  const int x0 = (int)xc, y0 = (int)yc, x1 = x0 + 1, y1 = y0 + 1;
+  const float tx = ix - x0f, ty = iy - y0f, ex = (x0f + 1.0f) - ix, ey = (y0f + 1.0f) - iy;
+  const bool vx0 = x0 >= 0 && x0 < wl, vx1 = x1 >= 0 && x1 < wl, vy0 = y0 >= 0 && y0 < hl, vy1 = y1 >= 0 && y1 < hl;
+  const int cx0 = min(max(x0, 0), wl - 1), cx1 = min(max(x1, 0), wl - 1), cy0 = min(max(y0, 0), hl - 1), cy1 = min(max(y1, 0), hl - 1);
+  t.o[0] = (unsigned)(cy0 * wl + cx0); t.o[1] = (unsigned)(cy0 * wl + cx1);
+  t.o[2] = (unsigned)(cy1 * wl + cx0); t.o[3] = (unsigned)(cy1 * wl + cx1);
+  t.w[0] = (!wild && vx0 && vy0) ? ex * ey : 0.f;
+  t.w[1] = (!wild && vx1 && vy0) ? tx * ey : 0.f;
+  t.w[2] = (!wild && vx0 && vy1) ? ex * ty : 0.f;
+  t.w[3] = (!wild && vx1 && vy1) ? tx * ty : 0.f;
+  return t;
+}
+
+constexpr int kPlaneThreads = 512;
+constexpr float kFixOne = 1073741824.0f;  // 2^30
+MAL_DEV void fix_add(unsigned long long* cell, float v, float to_fix) {
+  const long long q = (long long)__float2int_rn(v * to_fix);  // |v * to_fix| <= 2^30
+  atomicAdd(cell, (unsigned long long)q);
+}
+MAL_DEV float fix_value(unsigned long long cell, float lsb) { return (float)((double)(long long)cell * (double)lsb); }
+
+// gmax[b] = max |x| over sample b's n values (bits of a non-negative float order like unsigned integers)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t n, unsigned* gmax) {
+  __shared__ unsigned s_m[4];
+  const float* xb = x + (size_t)blockIdx.y * n;
+  unsigned m = 0u;
+  for (size_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) m = max(m, __float_as_uint(fabsf(xb[i])));
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_down((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(gmax + blockIdx.y, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));
+}
+
+__global__ __launch_bounds__(kPlaneThreads) void epi_sample_bwd_planes_kernel(EpiSampleBwdParams p, const unsigned* gmax) {
+  extern __shared__ unsigned long long s_q[];  // the level planes of d/d fmap2[b, c], back to back, fixed point
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int hw = p.h * p.w, D = p.L * p.d1;
+  int lo[kEpiMaxLevels + 1];
+  lo[0] = 0;
+  for (int l = 0; l < p.L; ++l) lo[l + 1] = lo[l] + (p.h >> l) * (p.w >> l);
+  for (int i = tid; i < lo[p.L]; i += kPlaneThreads) s_q[i] = 0ull;
+  __syncthreads();
+  const int cg = p.C / p.heads, head = c / cg;
+  const float inv_cg = 1.0f / (float)cg;
+  const float G = __uint_as_float(gmax[b]) * inv_cg;            // no contribution exceeds it (tap weights <= 1)
+  const float to_fix = G > 0.f ? div_(kFixOne, G) : 0.f, lsb = G > 0.f ? div_(G, kFixOne) : 0.f;
+  const size_t plane1 = ((size_t)b * p.C + c) * hw;
+  for (int pix = tid; pix < hw; pix += kPlaneThreads) {
+    const float f1 = p.fmap1[plane1 + pix];
+    float g_f1 = 0.f;
+    for (int level = 0; level < p.L; ++level) {
+      const int hl = p.h >> level, wl = p.w >> level;
+      const float* pl = p.f2[level] + ((size_t)b * p.C + c) * (size_t)(hl * wl);
+      unsigned long long* sq = s_q + lo[level];
+      const bool want = p.g_f2[level] != nullptr;
+#pragma unroll 3
+      for (int j = 0; j < p.d1; ++j) {
+        const int s_ = level * p.d1 + j;
+        const size_t o = ((size_t)b * 2 * D + s_) * hw + pix;
+        const float u = p.coords[o], v = p.coords[o + (size_t)D * hw];
+        const float go = p.g_out[((size_t)b * D * p.heads + (size_t)level * p.heads * p.d1 + (size_t)head * p.d1 + j) * hw + pix] * inv_cg;
+        const LevelTaps t = level_taps(u, v, p.w, p.h, wl, hl);
+        float smp = pl[t.o[0]] * t.w[0];
+        smp = fma_(pl[t.o[1]], t.w[1], smp);
+        smp = fma_(pl[t.o[2]], t.w[2], smp);
+        smp = fma_(pl[t.o[3]], t.w[3], smp);
+        const float df = f1 - smp;
+        const float k = go * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+        g_f1 += k;
+        if (want && k != 0.f) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (t.w[q] != 0.f) fix_add(sq + t.o[q], -k * t.w[q], to_fix);
+        }
+      }
+    }
+    if (p.g_fmap1) p.g_fmap1[plane1 + pix] += g_f1;
+  }
+  __syncthreads();
+  for (int level = 0; level < p.L; ++level) {
+    float* out = p.g_f2[level];
+    if (!out) continue;
+    const int hwl = (p.h >> level) * (p.w >> level);
+    out += ((size_t)b * p.C + c) * hwl;
+    for (int i = tid; i < hwl; i += kPlaneThreads) out[i] += fix_value(s_q[lo[level] + i], lsb);
+  }
+}
+
 // ---------------------------------------------------------------- pose refinement step (forward)
 struct EpiGradCoordParams {
   const float* depth; const float* poses; const float* K;
@@ -425,6 +532,7 @@ struct EpiAlignParams {
   // backward
   const float* g_H; const float* g_b;      // (B,36), (B,6)
   float* g_src; float* g_tgt; float* g_src_w; float* g_tgt_w; float* g_weight; float* g_p2; float* g_P2;
+  float* coef;  // (B,6,hw) nullable: d/d(Sxx, Sxy, Syy, Srx, Sry, cost) per pixel, for epi_align_bwd_planes_kernel
 };
 
 // --robust_pose_loss: scaled_barron(0, 0.1) of the squared residual (losses.py:8-19,41-90: alpha = 0 -> 2 log1p(x/2), first
@@ -719,6 +827,11 @@ __global__ __launch_bounds__(256) void epi_align_bwd_kernel(EpiAlignParams p) {
   if (p.g_weight) p.g_weight[(size_t)b * hw + pix] = dw * ((sw * tw) * rw);
   const float dtw = dw * ((sw * wt) * rw);
   const float dcost = dw * ((sw * tw) * wt) * drw_dcost;
+  if (p.coef) {
+    const float cf[6] = {dSxx, dSxy, dSyy, dSrx, dSry, dcost};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p.coef[((size_t)b * 6 + k) * hw + pix] = cf[k];
+  }
   float gu[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, gv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   auto slopes = [&](const char* plane, const Tap4& tp, float* dix, float* diy) {  // of the zero-padded bilinear sample
     const float v00 = tp.v[0] ? *reinterpret_cast<const float*>(plane + tp.o[0]) : 0.f;
@@ -763,6 +876,59 @@ __global__ __launch_bounds__(256) void epi_align_bwd_kernel(EpiAlignParams p) {
       p.g_p2[(((size_t)b * 2 + 0) * 5 + k) * hw + pix] = gu[k];
       p.g_p2[(((size_t)b * 2 + 1) * 5 + k) * hw + pix] = gv[k];
     }
+}
+
+// d/d tgt_feat without global atomics (see epi_sample_bwd_planes_kernel): a workgroup owns one channel plane of a
+// sample, re-derives for every pixel the five samples of that channel and -- with the per-pixel coefficients the kernel
+// above left in `coef` -- what each sends to its four taps, accumulated in LDS (48x160 floats = 30 KB), written once.
+__global__ __launch_bounds__(kPlaneThreads) void epi_align_bwd_planes_kernel(EpiAlignParams p) {
+  extern __shared__ unsigned long long s_q[];  // fixed point, see epi_sample_bwd_planes_kernel
+  __shared__ unsigned s_m[kPlaneThreads / 64];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, hw = p.h * p.w;
+  for (int i = tid; i < hw; i += kPlaneThreads) s_q[i] = 0ull;
+  const size_t po = ((size_t)b * p.C + c) * hw;
+  const char* pl = reinterpret_cast<const char*>(p.tgt + po);
+  // two walks over the plane's pixels: the largest |d/d sample| first (the fixed-point scale), then the accumulation
+  float to_fix = 0.f, lsb = 0.f;
+  unsigned m = 0u;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int pix = tid; pix < hw; pix += kPlaneThreads) {
+      Tap4 t[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        t[k] = taps_at(p.p2[(((size_t)b * 2 + 0) * 5 + k) * hw + pix], p.p2[(((size_t)b * 2 + 1) * 5 + k) * hw + pix], p.h, p.w);
+      float cf[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cf[k] = p.coef[((size_t)b * 6 + k) * hw + pix];
+      const float f0 = sample4(pl, t[0]);
+      const float gx = (sample4(pl, t[1]) - sample4(pl, t[2])) / 2.0f, gy = (sample4(pl, t[3]) - sample4(pl, t[4])) / 2.0f;
+      const float r = p.src[po + pix] - f0;
+      const float dgx = (2.0f * gx * cf[0] + gy * cf[1]) + r * cf[3], dgy = (2.0f * gy * cf[2] + gx * cf[1]) + r * cf[4];
+      const float dr = (gx * cf[3] + gy * cf[4]) + 2.0f * r * cf[5];
+      if (pass == 0) {
+        m = max(m, __float_as_uint(fmaxf(fabsf(dr), 0.5f * fmaxf(fabsf(dgx), fabsf(dgy)))));
+      } else {
+        const float df[5] = {-dr, 0.5f * dgx, -0.5f * dgx, 0.5f * dgy, -0.5f * dgy};
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (t[k].v[j] && df[k] != 0.f) fix_add(s_q + (t[k].o[j] >> 2), df[k] * t[k].w[j], to_fix);
+      }
+    }
+    if (pass == 0) {
+      for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_down((int)m, o, 64));
+      if ((tid & 63) == 0) s_m[tid >> 6] = m;
+      __syncthreads();
+      unsigned mm = 0u;
+      for (int k = 0; k < kPlaneThreads / 64; ++k) mm = max(mm, s_m[k]);
+      const float G = __uint_as_float(mm);
+      to_fix = G > 0.f ? div_(kFixOne, G) : 0.f;
+      lsb = G > 0.f ? div_(G, kFixOne) : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < hw; i += kPlaneThreads) p.g_tgt[po + i] += fix_value(s_q[i], lsb);
 }
 
 // x = A^-1 rhs as PoseUpdate.direct_align does it (utils.py:357-368): Cholesky, else LU with partial pivoting, else failure.
@@ -1004,6 +1170,22 @@ __global__ void epi_align_update_bwd_kernel(const float* H, const float* bvec, c
 
 using namespace mal;
 
+// LDS a workgroup of `kernel` may ask for: the device's per-block limit (160 KB on gfx950), raised from the default 64 KB
+static size_t plane_lds_limit(const void* kernel) {
+  static size_t limit = 0;
+  if (limit == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+      limit = (size_t)v;
+    else
+      limit = 64 * 1024;
+  }
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit);
+  (void)hipGetLastError();
+  return limit;
+}
+
+
 extern "C" int mal_direct_align_update(const float* H, const float* b, const float* poses, int B, float* new_poses,
                                        float* update, void* stream) {
   if (B <= 0) return MAL_ESHAPE;
@@ -1055,20 +1237,35 @@ extern "C" size_t mal_direct_align_workspace_bytes(int B, int h, int w) {
   return (size_t)B * ((h * w + 255) / 256) * 27 * sizeof(double);
 }
 
+extern "C" size_t mal_direct_align_bwd_workspace_bytes(int B, int h, int w) {
+  if (B <= 0 || h <= 0 || w <= 0) return 0;
+  return (size_t)B * 6 * h * w * sizeof(float);
+}
+
 extern "C" int mal_direct_align_normal_eq_bwd(const float* src_feat, const float* tgt_feat, const float* src_w,
                                               const float* tgt_w, const float* weight, const float* K, const float* p2,
                                               const float* P2, const float* g_H, const float* g_b, int B, int C, int h, int w,
                                               int robust, float* g_src_feat, float* g_tgt_feat, float* g_src_w, float* g_tgt_w,
-                                              float* g_weight, float* g_p2, float* g_P2, void* stream) {
+                                              float* g_weight, float* g_p2, float* g_P2, void* ws, size_t ws_bytes,
+                                              void* stream) {
   if (B <= 0 || C < 1 || h < 1 || w < 1 || (double)B * C * h * w > 2.0e9 / 4) return MAL_ESHAPE;
   if (!src_feat || !tgt_feat || !src_w || !tgt_w || !K || !p2 || !P2 || !g_H || !g_b) return MAL_EINVAL;
   if (g_weight && !weight) return MAL_EINVAL;
+  // d/d tgt_feat through LDS planes when a plane fits and the caller handed the per-pixel coefficient scratch
+  const bool planes = g_epi_bwd_planes && g_tgt_feat && ws && ws_bytes >= mal_direct_align_bwd_workspace_bytes(B, h, w) &&
+                      (size_t)h * w * sizeof(unsigned long long) <= plane_lds_limit((const void*)epi_align_bwd_planes_kernel);
   EpiAlignParams p = {};
   p.src = src_feat; p.tgt = tgt_feat; p.src_w = src_w; p.tgt_w = tgt_w; p.weight = weight; p.K = K; p.p2 = p2; p.P2 = P2;
   p.B = B; p.C = C; p.h = h; p.w = w; p.nblk = (h * w + 255) / 256; p.robust = robust ? 1 : 0;
   p.g_H = g_H; p.g_b = g_b; p.g_src = g_src_feat; p.g_tgt = g_tgt_feat; p.g_src_w = g_src_w; p.g_tgt_w = g_tgt_w;
   p.g_weight = g_weight; p.g_p2 = g_p2; p.g_P2 = g_P2;
-  hipLaunchKernelGGL(epi_align_bwd_kernel, dim3(p.nblk, B), dim3(256), 0, (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  if (planes) { p.coef = (float*)ws; p.g_tgt = nullptr; }
+  hipLaunchKernelGGL(epi_align_bwd_kernel, dim3(p.nblk, B), dim3(256), 0, st, p);
+  if (planes) {
+    p.g_tgt = g_tgt_feat;
+    hipLaunchKernelGGL(epi_align_bwd_planes_kernel, dim3(C, B), dim3(kPlaneThreads), (size_t)h * w * sizeof(unsigned long long), st, p);
+  }
   return launch_status();
 }
 
@@ -1149,9 +1346,12 @@ extern "C" int mal_epipolar_coords_bwd(const float* depth, const float* poses, c
   return launch_status();
 }
 
+extern "C" size_t mal_coord_sample_l1_bwd_workspace_bytes(int B) { return B > 0 ? align256((size_t)B * sizeof(unsigned)) : 0; }
+
 extern "C" int mal_coord_sample_l1_bwd(const float* fmap1, const float* const* f2_pyramid, const float* coords,
                                        const float* g_out, int B, int C, int h, int w, int L, int d1, int heads,
-                                       float* g_fmap1, float* const* g_f2_pyramid, float* g_coords, void* stream) {
+                                       float* g_fmap1, float* const* g_f2_pyramid, float* g_coords, void* ws, size_t ws_bytes,
+                                       void* stream) {
   if (B <= 0 || C < 1 || h < 1 || w < 1 || L < 1 || L > kEpiMaxLevels || d1 < 1 || heads < 1 || C % heads) return MAL_ESHAPE;
   if ((h >> (L - 1)) < 1 || (w >> (L - 1)) < 1) return MAL_ESHAPE;
   if ((double)B * C * h * w > 2.0e9 / 4 || (double)B * 2 * L * d1 * h * w > 2.0e9 / 4) return MAL_ESHAPE;
@@ -1164,7 +1364,24 @@ extern "C" int mal_coord_sample_l1_bwd(const float* fmap1, const float* const* f
     p.f2[l] = f2_pyramid[l];
     p.g_f2[l] = g_f2_pyramid ? g_f2_pyramid[l] : nullptr;
   }
-  hipLaunchKernelGGL(epi_sample_bwd_kernel, dim3((h * w + 255) / 256, L * ((d1 + kEpiG - 1) / kEpiG), B), dim3(256), 0,
-                     (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  size_t plane_floats = 0;
+  bool any_f2 = false;
+  for (int l = 0; l < L; ++l) { plane_floats += (size_t)(h >> l) * (w >> l); any_f2 = any_f2 || p.g_f2[l]; }
+  const size_t lds = plane_floats * sizeof(unsigned long long);
+  const bool planes = g_epi_bwd_planes && (g_fmap1 || any_f2) && ws && ws_bytes >= (size_t)B * sizeof(unsigned) &&
+                      lds <= plane_lds_limit((const void*)epi_sample_bwd_planes_kernel);
+  if (planes) {
+    // d/d fmap1, d/d fmap2 levels: one workgroup per (sample, channel), LDS accumulation; d/d coords: the sweep below
+    unsigned* gmax = (unsigned*)ws;
+    (void)hipMemsetAsync(gmax, 0, (size_t)B * sizeof(unsigned), st);
+    const size_t n = (size_t)L * heads * d1 * h * w;
+    hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, g_out, n, gmax);
+    hipLaunchKernelGGL(epi_sample_bwd_planes_kernel, dim3(C, B), dim3(kPlaneThreads), lds, st, p, gmax);
+    if (!g_coords) return launch_status();
+    p.g_fmap1 = nullptr;
+    for (int l = 0; l < L; ++l) p.g_f2[l] = nullptr;
+  }
+  hipLaunchKernelGGL(epi_sample_bwd_kernel, dim3((h * w + 255) / 256, L * ((d1 + kEpiG - 1) / kEpiG), B), dim3(256), 0, st, p);
   return launch_status();
 }

@@ -96,11 +96,12 @@ class CoordSampleFn(torch.autograd.Function):
         g_f1 = torch.zeros_like(f1) if need[0] else None
         g_c = torch.zeros_like(c) if need[1] else None
         g_pyr = [torch.zeros_like(f) if need[4 + i] else None for i, f in enumerate(pyr)]
-        p = ops._p
-        L.check(L.load().mal_coord_sample_l1_bwd(p(f1), L.ptr_array([p(f) for f in pyr]), p(c), p(ops._req(g_out.float(), "g_out")),
-                                                 B, C, h, w, num_levels, d1, num_head, p(g_f1),
-                                                 L.ptr_array([p(g) for g in g_pyr]), p(g_c), ops._stream()),
-                "mal_coord_sample_l1_bwd")
+        lib, p = L.load(), ops._p
+        go = ops._req(g_out.float(), "g_out")
+        ws = torch.empty(lib.mal_coord_sample_l1_bwd_workspace_bytes(B), dtype=torch.uint8, device=c.device)
+        L.check(lib.mal_coord_sample_l1_bwd(p(f1), L.ptr_array([p(f) for f in pyr]), p(c), p(go), B, C, h, w, num_levels, d1,
+                                            num_head, p(g_f1), L.ptr_array([p(g) for g in g_pyr]), p(g_c), p(ws), ws.numel(),
+                                            ops._stream()), "mal_coord_sample_l1_bwd")
         return (g_f1, g_c, None, None, *g_pyr)
 
 
@@ -181,10 +182,12 @@ class NormalEquationsFn(torch.autograd.Function):
         g_wt = new(wt) if (need[4] and wt is not None) else None
         g_c = new(c) if need[5] else None
         g_X1 = new(X1) if need[6] else None
-        p = ops._p
-        L.check(L.load().mal_direct_align_normal_eq_bwd(p(src), p(tgt), p(sw), p(tw), p(wt), p(Kc), p(c), p(X1), p(gH), p(gb), B,
-                                                        C, h, w, 1 if ctx.robust else 0, p(g_src), p(g_tgt), p(g_sw), p(g_tw),
-                                                        p(g_wt), p(g_c), p(g_X1), ops._stream()),
+        lib, p = L.load(), ops._p
+        ws = torch.empty(lib.mal_direct_align_bwd_workspace_bytes(B, h, w), dtype=torch.uint8, device=src.device) if need[1] else None
+        L.check(lib.mal_direct_align_normal_eq_bwd(p(src), p(tgt), p(sw), p(tw), p(wt), p(Kc), p(c), p(X1), p(gH), p(gb), B,
+                                                   C, h, w, 1 if ctx.robust else 0, p(g_src), p(g_tgt), p(g_sw), p(g_tw),
+                                                   p(g_wt), p(g_c), p(g_X1), p(ws), ws.numel() if ws is not None else 0,
+                                                   ops._stream()),
                 "mal_direct_align_normal_eq_bwd")
         return g_src, g_tgt, g_sw, g_tw, g_wt, g_c, g_X1, None, None
 

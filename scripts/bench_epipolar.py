@@ -102,8 +102,9 @@ print("bound: vector-memory address path: %.1f M dword wave-loads -> %.1f G wave
       "lie several rows apart under these synthetic poses" %
       (wave_loads / 1e6, wave_loads / th / 1e9, wave_loads / th / WAVE_LOAD_CEILING[1], WAVE_LOAD_CEILING[1] / 1e9,
        wave_loads / th / WAVE_LOAD_CEILING[4], WAVE_LOAD_CEILING[4] / 1e9))
-print("lookup forward + backward (VJPs w.r.t. depth, pose, delta, both feature maps; the scatter into the feature pyramid uses "
-      "float atomics, %.2f G lane-adds): HIP %.0f us" % (B * h * w * D * C * 4 / 1e9, tfb * 1e6))
+print("lookup forward + backward (VJPs w.r.t. depth, pose, delta, both feature maps; the %.2f G lane-adds of the scatter into the "
+      "feature pyramid go to 64-bit fixed-point planes in LDS, one workgroup per (sample, channel)): HIP %.0f us" %
+      (B * h * w * D * C * 4 / 1e9, tfb * 1e6))
 print("direct_align: HIP %.0f us (gradcoords + normal equations + solve/se3 update kernel)   CPU checker %.2f s" % (ta * 1e6, tca))
 print("direct_align forward + backward (VJPs w.r.t. poses, depth, both feature maps, the three weight maps; %.2f G lane-adds "
-      "into the target features): HIP %.0f us, with --robust_pose_loss %.0f us" % (B * h * w * C * 20 / 1e9, tafb * 1e6, tafb_r * 1e6))
+      "into the target features, LDS planes as above): HIP %.0f us, with --robust_pose_loss %.0f us" % (B * h * w * C * 20 / 1e9, tafb * 1e6, tafb_r * 1e6))
