@@ -286,6 +286,9 @@ typedef struct mal_step_args {
   int warp_sample_stride;                 /* floats between two samples of warp_m1 / warp_p1; 0 = 3*H*W.  6*H*W with
                                              warp_p1 = warp_m1 + 3*H*W lays the two images of a sample side by side --
                                              the (2,3,H,W) pair the instance segmenter is fed (dyn_utils.py:139-140) */
+  float *warp2_m1, *warp2_p1;             /* nullable, contiguous (B,3,H,W): a second copy of the warped images, written by
+                                             mal_loss_step_warp -- the buffers the producer makes syn_f in (it then only
+                                             overwrites the pixels its instances touch, mal_dyn_item.prefilled)           */
 } mal_step_args;
 int mal_loss_step_warp(const mal_step_args* args);
 /* the same noise map on its own (tests; bit-identical to what the step draws for that seed / step) */
@@ -380,6 +383,12 @@ typedef struct mal_dyn_item {
   /* optional: instance i is row idx_last[i] / idx_next[i] (device int64) of mask_last / mask_next -- the matcher's
    * selection (dyn_utils.py:147-150) applied inside the kernels instead of by a gather per sample and frame; NULL = row i */
   const int64_t* idx_last; const int64_t* idx_next;
+  /* forward: ori_last / ori_next already hold img_last / img_next (the step's warp pass wrote both copies): only the pixels
+   * of the instances' region are written */
+  int prefilled;
+  /* backward IN PLACE (g_img_* == g_ori_*: the cotangent buffers become the gradients): only region pixels change; they
+   * are formed in g_tmp_* (C,H,W scratch, contents irrelevant) by one launch and moved by a second */
+  float* g_tmp_last; float* g_tmp_next;
 } mal_dyn_item;
 int mal_dyn_batch_fwd(const mal_dyn_item* items, int n_items, int C, int H, int W, int replace, void* stream);
 int mal_dyn_batch_bwd(const mal_dyn_item* items, int n_items, int C, int H, int W, void* stream);

@@ -33,6 +33,8 @@ struct DynParams {
   int* delta;     // [num][2]: row, column displacement of the "last" copy
   uint8_t* flags; // [H*W]: bit0 region, bit1 any_last, bit2 any_next, bit3 last's background is img_next, bit4 next's is img_last
   const float* g_ori_last; const float* g_ori_next; float* g_img_last; float* g_img_next;
+  int prefilled;                       // forward: ori_* already hold img_*: only region pixels are written
+  float* g_tmp_last; float* g_tmp_next;  // backward in place (g_img_* == g_ori_*): scratch for the region pixels
 };
 
 // Up to kDynBatch samples per launch (blockIdx.z = sample): a step's temporal hint is 12 samples x 3 kernels of a few
@@ -85,10 +87,9 @@ __global__ __launch_bounds__(1024) void dyn_extents_kernel(DynBatch bt) {
   if (tid < 4) p.ext[((i * 2 + which) * kExtChunks + chunk) * 4 + tid] = res[tid];  // merged by dyn_delta_kernel
 }
 
-__global__ void dyn_delta_kernel(DynBatch bt) {
-  const DynParams& p = bt.s[blockIdx.z];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.num) return;
+// displacement of instance i from the band extents (dyn_utils.py:53-103): of (low_next-low_last, top_next-top_last) the one
+// of larger magnitude (the first on a tie), halved and rounded half-to-even; columns alike; replace=1 zeroes |d| < 3
+MAL_DEV void instance_delta(const DynParams& p, int i, int* dx_out, int* dy_out) {
   int el[4], en[4];  // low, top, right, left of (last, next): max / min over the row bands
   for (int which = 0; which < 2; ++which) {
     int* e = which ? en : el;
@@ -108,13 +109,23 @@ __global__ void dyn_delta_kernel(DynBatch bt) {
   int dx = pick(en[0] - el[0], en[1] - el[1]);
   int dy = pick(en[2] - el[2], en[3] - el[3]);
   if (p.replace) { if (abs(dx) < 3) dx = 0; if (abs(dy) < 3) dy = 0; }
-  p.delta[i * 2] = dx; p.delta[i * 2 + 1] = dy;
+  *dx_out = dx; *dy_out = dy;
 }
 
-// the per-instance small data of a sample in shared memory: displacement [num][2], then mask rows [num][2]
-MAL_DEV void stage_instances(const DynParams& p, int* s_delta) {
+// the per-instance small data of a sample in shared memory: displacement [num][2], then mask rows [num][2].  Forward
+// (from_ext): every workgroup derives the displacements from the band extents itself (a few hundred integers from the L2:
+// no launch of its own for it) and the sample's first workgroup records them for the backward.
+MAL_DEV void stage_instances(const DynParams& p, int* s_delta, bool from_ext) {
+  if (from_ext) {
+    for (int i = threadIdx.x; i < p.num; i += 256) {
+      int dx, dy;
+      instance_delta(p, i, &dx, &dy);
+      s_delta[2 * i] = dx; s_delta[2 * i + 1] = dy;
+      if (blockIdx.x == 0) { p.delta[2 * i] = dx; p.delta[2 * i + 1] = dy; }
+    }
+  }
   for (int k = threadIdx.x; k < p.num * 2; k += 256) {
-    s_delta[k] = p.delta[k];
+    if (!from_ext) s_delta[k] = p.delta[k];
     const int i = k >> 1;
     const long long* sel = (k & 1) ? p.idx_next : p.idx_last;
     s_delta[2 * p.num + k] = sel ? (int)sel[i] : i;
@@ -125,7 +136,7 @@ MAL_DEV void stage_instances(const DynParams& p, int* s_delta) {
 __global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynBatch bt) {
   extern __shared__ int s_delta[];  // [num][2] displacements, [num][2] mask rows
   const DynParams& p = bt.s[blockIdx.z];
-  stage_instances(p, s_delta);
+  stage_instances(p, s_delta, true);
   const int* s_row = s_delta + 2 * p.num;
   const int H = p.H, W = p.W, HW = H * W;
   const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -155,6 +166,7 @@ __global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynBatch bt) {
     }
   }
   p.flags[pix] = (uint8_t)((region ? 1 : 0) | (any_l ? 2 : 0) | (any_n ? 4 : 0) | (bg_l ? 8 : 0) | (bg_n ? 16 : 0));
+  if (p.prefilled && !region) return;  // ori_* hold the images already
   for (int ch = 0; ch < p.C; ++ch) {
     const float il = p.img_last[(size_t)ch * HW + pix], in = p.img_next[(size_t)ch * HW + pix];
     p.ori_last[(size_t)ch * HW + pix] = region ? (any_l ? accl[ch] : (bg_l ? in : il)) : il;
@@ -162,16 +174,20 @@ __global__ __launch_bounds__(256) void dyn_synth_fwd_kernel(DynBatch bt) {
   }
 }
 
+// REGION: the in-place form, first launch -- only pixels of the instances' region change (everywhere else the gradient
+// IS the cotangent): their new values go to g_tmp_*, dyn_apply_region_kernel moves them once every gather has been served
+template <bool REGION>
 __global__ __launch_bounds__(256) void dyn_synth_bwd_kernel(DynBatch bt) {
   extern __shared__ int s_delta[];
   const DynParams& p = bt.s[blockIdx.z];
-  stage_instances(p, s_delta);
+  stage_instances(p, s_delta, false);
   const int* s_row = s_delta + 2 * p.num;
   const int H = p.H, W = p.W, HW = H * W;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= HW) return;
   const int r = pix / W, c = pix - r * W;
   const int f = p.flags[pix];
+  if (REGION && !(f & 1)) return;
   // where the two outputs at p read the two images AT p
   const bool ol_from_l = !(f & 1) || (!(f & 2) && !(f & 8)), ol_from_n = (f & 1) && !(f & 2) && (f & 8);
   const bool on_from_n = !(f & 1) || (!(f & 4) && !(f & 16)), on_from_l = (f & 1) && !(f & 4) && (f & 16);
@@ -197,15 +213,246 @@ __global__ __launch_bounds__(256) void dyn_synth_bwd_kernel(DynBatch bt) {
         for (int ch = 0; ch < p.C; ++ch) gn[ch] += p.g_ori_next[(size_t)ch * HW + rd * W + cd];
     }
   }
+  float* const out_l = REGION ? p.g_tmp_last : p.g_img_last;
+  float* const out_n = REGION ? p.g_tmp_next : p.g_img_next;
   for (int ch = 0; ch < p.C; ++ch) {
-    if (p.g_img_last) p.g_img_last[(size_t)ch * HW + pix] = gl[ch];
-    if (p.g_img_next) p.g_img_next[(size_t)ch * HW + pix] = gn[ch];
+    if (out_l) out_l[(size_t)ch * HW + pix] = gl[ch];
+    if (out_n) out_n[(size_t)ch * HW + pix] = gn[ch];
+  }
+}
+
+__global__ __launch_bounds__(256) void dyn_apply_region_kernel(DynBatch bt) {
+  const DynParams& p = bt.s[blockIdx.z];
+  const int HW = p.H * p.W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= HW || !(p.flags[pix] & 1)) return;
+  for (int ch = 0; ch < p.C; ++ch) {
+    p.g_img_last[(size_t)ch * HW + pix] = p.g_tmp_last[(size_t)ch * HW + pix];
+    p.g_img_next[(size_t)ch * HW + pix] = p.g_tmp_next[(size_t)ch * HW + pix];
+  }
+}
+
+// ---------------------------------------------------------------- four pixels per thread
+// The kernels above are one memory round trip after another per wave (a byte per lane, the shifted byte behind a test):
+// 25 us for work whose bytes need 5.  For W % 4 == 0 a thread owns four consecutive pixels of a row: mask bytes arrive
+// as 32-bit words (the shifted ones as the two words that straddle them, funnel-shifted), every load of an instance is
+// unconditional, the images move as float4 -- and only where no pixel of the quad lies in the instances' region.
+MAL_DEV unsigned nz4(unsigned w) {  // bit k = byte k of w is non-zero
+  return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
+}
+// bytes row[cs .. cs+3] for any integer cs, bytes outside [0, W) read as zero; row 4-byte aligned, W % 4 == 0
+MAL_DEV unsigned bytes4_at(const uint8_t* row, int cs, int W) {
+  const unsigned* rw = reinterpret_cast<const unsigned*>(row);
+  const int a0 = cs >> 2, sh = (cs & 3) * 8, wmax = (W >> 2) - 1;
+  const unsigned l0 = rw[min(max(a0, 0), wmax)], l1 = rw[min(max(a0 + 1, 0), wmax)];
+  const unsigned w0 = (a0 >= 0 && a0 <= wmax) ? l0 : 0u, w1 = (a0 + 1 >= 0 && a0 + 1 <= wmax) ? l1 : 0u;
+  return sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
+}
+
+// Branches around LOADS serialise a wave (one wait per basic block): the quad kernels load unconditionally from
+// predicated addresses (a miss reads element 0 and contributes +0.0f, which changes no sum), behind WAVE-uniform guards
+// (`__any`) so that the ~90 % of wavefronts without a pixel in any instance's region skip the work altogether.
+MAL_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+MAL_DEV void st4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+
+template <int C>
+__global__ __launch_bounds__(256) void dyn_synth_fwd4_kernel(DynBatch bt) {
+  extern __shared__ int s_delta[];
+  const DynParams& p = bt.s[blockIdx.z];
+  stage_instances(p, s_delta, true);
+  const int* s_row = s_delta + 2 * p.num;
+  const int H = p.H, W = p.W, HW = H * W, W4 = W >> 2;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= (HW >> 2)) return;
+  const int r = q / W4, c = (q - r * W4) * 4, pix = r * W + c;
+  const float* __restrict__ il = p.img_last;
+  const float* __restrict__ in = p.img_next;
+  unsigned region = 0u, any_l = 0u, any_n = 0u, bg_l = 0u, bg_n = 0u;  // bit k = pixel pix + k
+  float accl[4][C], accn[4][C];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) { accl[k][ch] = 0.f; accn[k][ch] = 0.f; }
+  for (int i = 0; i < p.num; ++i) {
+    const uint8_t* ml = p.mask_last + (size_t)s_row[2 * i] * HW;
+    const uint8_t* mn = p.mask_next + (size_t)s_row[2 * i + 1] * HW;
+    const int dx = s_delta[2 * i], dy = s_delta[2 * i + 1];
+    const int rl = r - dx, rn = r + dx;  // source rows of the "last" copy (moves by +d) and of the "next" copy (-d)
+    const unsigned wa = *reinterpret_cast<const unsigned*>(ml + pix), wb = *reinterpret_cast<const unsigned*>(mn + pix);
+    const unsigned sl_raw = bytes4_at(ml + (size_t)min(max(rl, 0), H - 1) * W, c - dy, W);
+    const unsigned sn_raw = bytes4_at(mn + (size_t)min(max(rn, 0), H - 1) * W, c + dy, W);
+    const unsigned a4 = nz4(wa), b4 = nz4(wb);
+    const unsigned sl = (rl >= 0 && rl < H) ? nz4(sl_raw) : 0u, sn = (rn >= 0 && rn < H) ? nz4(sn_raw) : 0u;
+    region |= a4 | b4; bg_l |= a4 & ~b4; bg_n |= b4 & ~a4;
+    any_l |= sl; any_n |= sn;
+    if (__any((sl | sn) != 0u)) {
+      const int bl = rl * W + (c - dy), bn = rn * W + (c + dy);
+      float vl[4][C], vn[4][C];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+          vl[k][ch] = il[(size_t)ch * HW + (((sl >> k) & 1u) ? bl + k : 0)];
+          vn[k][ch] = in[(size_t)ch * HW + (((sn >> k) & 1u) ? bn + k : 0)];
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+          accl[k][ch] += ((sl >> k) & 1u) ? vl[k][ch] : 0.f;
+          accn[k][ch] += ((sn >> k) & 1u) ? vn[k][ch] : 0.f;
+        }
+    }
+  }
+  unsigned fw = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    fw |= ((((region >> k) & 1u)) | (((any_l >> k) & 1u) << 1) | (((any_n >> k) & 1u) << 2) | (((bg_l >> k) & 1u) << 3) |
+           (((bg_n >> k) & 1u) << 4)) << (8 * k);
+  *reinterpret_cast<unsigned*>(p.flags + pix) = fw;
+  if (p.prefilled && !__any(region != 0u)) return;  // ori_* hold the images already
+  float ol[C][4], on[C][4];
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) {
+    const float4 a = ld4(il + (size_t)ch * HW + pix), b = ld4(in + (size_t)ch * HW + pix);
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool rg = (region >> k) & 1u;
+      ol[ch][k] = rg ? (((any_l >> k) & 1u) ? accl[k][ch] : (((bg_l >> k) & 1u) ? bv[k] : av[k])) : av[k];
+      on[ch][k] = rg ? (((any_n >> k) & 1u) ? accn[k][ch] : (((bg_n >> k) & 1u) ? av[k] : bv[k])) : bv[k];
+    }
+  }
+  if (!p.prefilled) {
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) { st4(p.ori_last + (size_t)ch * HW + pix, ol[ch]); st4(p.ori_next + (size_t)ch * HW + pix, on[ch]); }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if ((region >> k) & 1u) {
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) { p.ori_last[(size_t)ch * HW + pix + k] = ol[ch][k]; p.ori_next[(size_t)ch * HW + pix + k] = on[ch][k]; }
+    }
+}
+
+// the adjoint, same order of additions per pixel as dyn_synth_bwd_kernel
+template <int C, bool REGION>
+__global__ __launch_bounds__(256) void dyn_synth_bwd4_kernel(DynBatch bt) {
+  extern __shared__ int s_delta[];
+  const DynParams& p = bt.s[blockIdx.z];
+  stage_instances(p, s_delta, false);
+  const int* s_row = s_delta + 2 * p.num;
+  const int H = p.H, W = p.W, HW = H * W, W4 = W >> 2;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= (HW >> 2)) return;
+  const int r = q / W4, c = (q - r * W4) * 4, pix = r * W + c;
+  const float* __restrict__ go_l = p.g_ori_last;
+  const float* __restrict__ go_n = p.g_ori_next;
+  const unsigned fw = *reinterpret_cast<const unsigned*>(p.flags + pix);
+  float* const out_l = REGION ? p.g_tmp_last : p.g_img_last;
+  float* const out_n = REGION ? p.g_tmp_next : p.g_img_next;
+  const bool wave_region = __any((fw & 0x01010101u) != 0u);
+  if (REGION && !wave_region) return;
+  float gl[C][4], gn[C][4];
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) {
+    const float4 a4 = ld4(go_l + (size_t)ch * HW + pix), b4 = ld4(go_n + (size_t)ch * HW + pix);
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = (int)((fw >> (8 * k)) & 0xffu);
+      const bool ol_from_l = !(f & 1) || (!(f & 2) && !(f & 8)), ol_from_n = (f & 1) && !(f & 2) && (f & 8);
+      const bool on_from_n = !(f & 1) || (!(f & 4) && !(f & 16)), on_from_l = (f & 1) && !(f & 4) && (f & 16);
+      float l = 0.f, n = 0.f;
+      l += ol_from_l ? a[k] : 0.f;
+      l += on_from_l ? b[k] : 0.f;
+      n += on_from_n ? b[k] : 0.f;
+      n += ol_from_n ? a[k] : 0.f;
+      gl[ch][k] = l; gn[ch][k] = n;
+    }
+  }
+  if (wave_region) {
+    for (int i = 0; i < p.num; ++i) {
+      const int dx = s_delta[2 * i], dy = s_delta[2 * i + 1];
+      const unsigned ma = nz4(*reinterpret_cast<const unsigned*>(p.mask_last + (size_t)s_row[2 * i] * HW + pix));
+      const unsigned mb = nz4(*reinterpret_cast<const unsigned*>(p.mask_next + (size_t)s_row[2 * i + 1] * HW + pix));
+      // where pixel p was copied to: "last" to p + d, "next" to p - d, if that pixel lies in the replaced region
+      const int rdl = r + dx, rdn = r - dx;
+      const unsigned fl = bytes4_at(p.flags + (size_t)min(max(rdl, 0), H - 1) * W, c + dy, W);
+      const unsigned fn = bytes4_at(p.flags + (size_t)min(max(rdn, 0), H - 1) * W, c - dy, W);
+      unsigned hl = 0u, hn = 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hl |= (((fl >> (8 * k)) & 1u) & ((ma >> k) & 1u)) << k;
+        hn |= (((fn >> (8 * k)) & 1u) & ((mb >> k) & 1u)) << k;
+      }
+      if (rdl < 0 || rdl >= H) hl = 0u;
+      if (rdn < 0 || rdn >= H) hn = 0u;
+      if (__any((hl | hn) != 0u)) {
+        const int bl = rdl * W + (c + dy), bn = rdn * W + (c - dy);
+        float vl[C][4], vn[C][4];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            vl[ch][k] = go_l[(size_t)ch * HW + (((hl >> k) & 1u) ? bl + k : 0)];
+            vn[ch][k] = go_n[(size_t)ch * HW + (((hn >> k) & 1u) ? bn + k : 0)];
+          }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            gl[ch][k] += ((hl >> k) & 1u) ? vl[ch][k] : 0.f;
+            gn[ch][k] += ((hn >> k) & 1u) ? vn[ch][k] : 0.f;
+          }
+      }
+    }
+  }
+  if (!REGION) {
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      if (out_l) st4(out_l + (size_t)ch * HW + pix, gl[ch]);
+      if (out_n) st4(out_n + (size_t)ch * HW + pix, gn[ch]);
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if ((fw >> (8 * k)) & 1u) {
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) { out_l[(size_t)ch * HW + pix + k] = gl[ch][k]; out_n[(size_t)ch * HW + pix + k] = gn[ch][k]; }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void dyn_apply_region4_kernel(DynBatch bt) {
+  const DynParams& p = bt.s[blockIdx.z];
+  const int HW = p.H * p.W;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= (HW >> 2)) return;
+  const int pix = q * 4;
+  const unsigned fw = *reinterpret_cast<const unsigned*>(p.flags + pix);
+  if (!__any((fw & 0x01010101u) != 0u)) return;
+  const float* __restrict__ tl = p.g_tmp_last;
+  const float* __restrict__ tn = p.g_tmp_next;
+  float4 vl[C], vn[C];
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) { vl[ch] = ld4(tl + (size_t)ch * HW + pix); vn[ch] = ld4(tn + (size_t)ch * HW + pix); }
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) {
+    const float a[4] = {vl[ch].x, vl[ch].y, vl[ch].z, vl[ch].w}, b[4] = {vn[ch].x, vn[ch].y, vn[ch].z, vn[ch].w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((fw >> (8 * k)) & 1u) { p.g_img_last[(size_t)ch * HW + pix + k] = a[k]; p.g_img_next[(size_t)ch * HW + pix + k] = b[k]; }
   }
 }
 
 }  // namespace mal
 
 using namespace mal;
+
+static bool aligned_to(const void* ptr, size_t a) { return ptr == nullptr || (reinterpret_cast<uintptr_t>(ptr) & (a - 1)) == 0; }
 
 static int dyn_check(int num, int C, int H, int W) {
   if (num < 1 || num > MAL_MAX_INSTANCES || C < 1 || C > 4) return MAL_EINVAL;
@@ -232,18 +479,27 @@ static int dyn_fwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, int
     p.mask_last = a.mask_last; p.mask_next = a.mask_next; p.num = a.num; p.C = C; p.H = H; p.W = W; p.replace = replace;
     p.idx_last = (const long long*)a.idx_last; p.idx_next = (const long long*)a.idx_next;
     p.img_last = a.img_last; p.img_next = a.img_next; p.ori_last = a.ori_last; p.ori_next = a.ori_next;
-    p.ext = (int*)a.ws; p.delta = a.delta; p.flags = a.flags;
+    p.ext = (int*)a.ws; p.delta = a.delta; p.flags = a.flags; p.prefilled = a.prefilled;
     max_num = a.num > max_num ? a.num : max_num;
   }
   hipLaunchKernelGGL(dyn_extents_kernel, dim3(max_num, 2 * kExtChunks, n), dim3(1024), (size_t)(H + W + 4) * sizeof(int), st, bt);
-  hipLaunchKernelGGL(dyn_delta_kernel, dim3(1, 1, n), dim3(64), 0, st, bt);
-  hipLaunchKernelGGL(dyn_synth_fwd_kernel, dim3((H * W + 255) / 256, 1, n), dim3(256), (size_t)max_num * 4 * sizeof(int), st, bt);
+  bool quad = (W & 3) == 0 && C == 3;
+  for (int k = 0; k < n && quad; ++k) {
+    const DynParams& q = bt.s[k];
+    quad = aligned_to(q.mask_last, 4) && aligned_to(q.mask_next, 4) && aligned_to(q.flags, 4) && aligned_to(q.img_last, 16) &&
+           aligned_to(q.img_next, 16) && aligned_to(q.ori_last, 16) && aligned_to(q.ori_next, 16);
+  }
+  if (quad)
+    hipLaunchKernelGGL(dyn_synth_fwd4_kernel<3>, dim3((H * W / 4 + 255) / 256, 1, n), dim3(256), (size_t)max_num * 4 * sizeof(int), st, bt);
+  else
+    hipLaunchKernelGGL(dyn_synth_fwd_kernel, dim3((H * W + 255) / 256, 1, n), dim3(256), (size_t)max_num * 4 * sizeof(int), st, bt);
   return launch_status();
 }
 
 static int dyn_bwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, hipStream_t st) {
   DynBatch bt = {};
   int max_num = 0;
+  bool region = false;
   for (int k = 0; k < n; ++k) {
     const mal_dyn_item& a = it[k];
     int rc = dyn_check(a.num, C, H, W);
@@ -256,9 +512,32 @@ static int dyn_bwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, hip
     p.idx_last = (const long long*)a.idx_last; p.idx_next = (const long long*)a.idx_next;
     p.delta = a.delta; p.flags = a.flags;
     p.g_ori_last = a.g_ori_last; p.g_ori_next = a.g_ori_next; p.g_img_last = a.g_img_last; p.g_img_next = a.g_img_next;
+    p.g_tmp_last = a.g_tmp_last; p.g_tmp_next = a.g_tmp_next;
+    const bool inplace = a.g_img_last == a.g_ori_last || a.g_img_next == a.g_ori_next;
+    if (inplace && (a.g_img_last != a.g_ori_last || a.g_img_next != a.g_ori_next || !a.g_tmp_last || !a.g_tmp_next)) return MAL_EINVAL;
+    if (k == 0) region = inplace;
+    else if (region != inplace) return MAL_EINVAL;
     max_num = a.num > max_num ? a.num : max_num;
   }
-  hipLaunchKernelGGL(dyn_synth_bwd_kernel, dim3((H * W + 255) / 256, 1, n), dim3(256), (size_t)max_num * 4 * sizeof(int), st, bt);
+  bool quad = (W & 3) == 0 && C == 3;
+  for (int k = 0; k < n && quad; ++k) {
+    const DynParams& q = bt.s[k];
+    quad = aligned_to(q.mask_last, 4) && aligned_to(q.mask_next, 4) && aligned_to(q.flags, 4) && aligned_to(q.g_ori_last, 16) && aligned_to(q.g_ori_next, 16) && aligned_to(q.g_img_last, 16) &&
+           aligned_to(q.g_img_next, 16) && aligned_to(q.g_tmp_last, 16) && aligned_to(q.g_tmp_next, 16);
+  }
+  const size_t lds = (size_t)max_num * 4 * sizeof(int);
+  const dim3 grid((H * W + 255) / 256, 1, n), grid4((H * W / 4 + 255) / 256, 1, n);
+  if (region && quad) {
+    hipLaunchKernelGGL((dyn_synth_bwd4_kernel<3, true>), grid4, dim3(256), lds, st, bt);
+    hipLaunchKernelGGL(dyn_apply_region4_kernel<3>, grid4, dim3(256), 0, st, bt);
+  } else if (region) {
+    hipLaunchKernelGGL(dyn_synth_bwd_kernel<true>, grid, dim3(256), lds, st, bt);
+    hipLaunchKernelGGL(dyn_apply_region_kernel, grid, dim3(256), 0, st, bt);
+  } else if (quad) {
+    hipLaunchKernelGGL((dyn_synth_bwd4_kernel<3, false>), grid4, dim3(256), lds, st, bt);
+  } else {
+    hipLaunchKernelGGL(dyn_synth_bwd_kernel<false>, grid, dim3(256), lds, st, bt);
+  }
   return launch_status();
 }
 

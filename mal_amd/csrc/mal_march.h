@@ -33,6 +33,9 @@ struct MarchParams {
   // dyn_utils.py:127-128) and the winner among the two warped candidates
   float* color_out[2]; unsigned char* argmin_out;
   int color_out_stride;  // floats between two samples of color_out (0 = 3*H*W: contiguous (B,3,H,W))
+  // a second copy, contiguous (B,3,H,W) each, nullable: the buffers the synthesised images are made in -- the producer
+  // then overwrites only the pixels its instances touch instead of copying every sample (dyn_utils.py:127-128)
+  float* color_out2[2];
   // TEMPORAL gradient pass (runs after the producer's backward): the decision of the four-way min and the automask are
   // TAKEN from the materialised-candidate kernels (forced_arg: winner 0..3, forced_w: automask weight), and the
   // gradient that reaches the warped images through syn (dyn_utils.py:145-146,163-164), g_color[f] planar (B,3,H,W),

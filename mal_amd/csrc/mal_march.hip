@@ -532,6 +532,12 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
         const size_t pl = (size_t)b * (p.color_out_stride ? (size_t)p.color_out_stride : 3 * (size_t)HW);
         stf(c0 + pl, og, w0.x[0].x); stf(c0 + pl + HW, og, w0.x[0].y); stf(c0 + pl + 2 * (size_t)HW, og, w0.x[2].x);
         stf(c1 + pl, og, w0.x[1].x); stf(c1 + pl + HW, og, w0.x[1].y); stf(c1 + pl + 2 * (size_t)HW, og, w0.x[2].y);
+        if (p.color_out2[0]) {
+          float* const d0 = p.color_out2[0] + (size_t)b * 3 * (size_t)HW;
+          float* const d1 = p.color_out2[1] + (size_t)b * 3 * (size_t)HW;
+          stf(d0, og, w0.x[0].x); stf(d0 + HW, og, w0.x[0].y); stf(d0 + 2 * (size_t)HW, og, w0.x[2].x);
+          stf(d1, og, w0.x[1].x); stf(d1 + HW, og, w0.x[1].y); stf(d1 + 2 * (size_t)HW, og, w0.x[2].y);
+        }
       }
     }
 

@@ -250,11 +250,43 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
                                                             const float* coefs, const double* stats, const float* g_total,
                                                             int B, int HW, const float* gT0, const float* gT1,
                                                             float* gTs0, float* gTs1, float* g_disp_t, float* g_disp_s,
-                                                            PoseParams pp, int pose_bwd) {
+                                                            PoseParams pp, int pose_bwd, const float* bgP, const float* K,
+                                                            int per_sample) {
   const float g = g_total ? *g_total : 1.0f;
   const float cRt = coefs[0] * g, cRs = coefs[1] * g, cS = coefs[4] * g;  // coefs[2], [3] are already inside G_cd
   const size_t n = (size_t)B * HW;
-  if (blockIdx.x == 0) {
+  if (bgP) {
+    // temporal hint: the teacher's sweep ran in this backward call, its pose partials are still per task: workgroup b
+    // reduces sample b's (step_final_kernel's pose branch), scales and runs that sample's pose backward
+    if ((int)blockIdx.x < B) {
+      __shared__ double s_part[256];
+      __shared__ double s_gP[24];
+      const int tid = threadIdx.x, b = blockIdx.x;
+      const int v = tid % 24, sub = tid / 24;
+      double acc = 0.0;
+      if (sub < 10) {
+#pragma unroll 8
+        for (int t = sub; t < per_sample; t += 10) acc += (double)bgP[((size_t)b * per_sample + t) * 24 + v];
+      }
+      s_part[tid] = acc;
+      __syncthreads();
+      if (tid < 24) {
+        double a = 0.0;
+        for (int k = 0; k < 10; ++k) a += s_part[k * 24 + tid];
+        s_gP[tid] = a;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        const int f = tid >> 4, e = tid & 15, k = e >> 2, j = e & 3;
+        const float* Kb = K + b * 16;
+        double a = 0.0;
+        for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
+        (f ? gTs1 : gTs0)[b * 16 + e] = (float)a * cRt;
+      }
+      __syncthreads();
+      if (pose_bwd && tid < 2) pose_bwd_one(pp, tid, b);
+    }
+  } else if (blockIdx.x == 0) {
     for (int i = threadIdx.x; i < B * 16; i += 256) { gTs0[i] = gT0[i] * cRt; gTs1[i] = gT1[i] * cRt; }
     __syncthreads();
     if (pose_bwd)
@@ -377,6 +409,8 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   p.block_sums = w.bs_t;
   p.color_out[0] = a->warp_m1; p.color_out[1] = a->warp_p1; p.argmin_out = w.arg_warp;
   p.color_out_stride = a->warp_sample_stride;
+  p.color_out2[0] = a->warp2_m1; p.color_out2[1] = a->warp2_p1;
+  if ((a->warp2_m1 == nullptr) != (a->warp2_p1 == nullptr)) return MAL_EINVAL;
   return march_launch(p, MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
 }
 
@@ -459,6 +493,7 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   const int B = a->B, H = a->H, W = a->W, HW = H * W;
   StepWs w = carve_step(a->ws, B, H, W);
   hipStream_t st = (hipStream_t)a->stream;
+  int per_sample_t = 0;
   if (a->flags & MAL_STEP_TEMPORAL) {
     // the teacher's gradient sweep, with the decisions of the four-way min taken from _fwd and the gradient that
     // reaches the warped images through syn added before the chain rule through the warp
@@ -470,10 +505,11 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
     p.dbg = a->dec_teacher;
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(step_pose_reduce_kernel, dim3(B), dim3(256), 0, st, w.bgP, a->K, p.strips * p.segs, w.gT[0], w.gT[1]);
+    per_sample_t = p.strips * p.segs;
   }
   size_t g = ((size_t)B * HW + 255) / 256;
   if (g > 2048) g = 2048;
+  if (g < (size_t)B) g = (size_t)B;
   PoseParams pp = {};
   pp.B = B; pp.F = 2;
   pp.axisangle[0] = a->axisangle_m1; pp.axisangle[1] = a->axisangle_p1;
@@ -485,7 +521,7 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   const int pose_bwd = (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) ? 1 : 0;
   hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.gn_t,
                      w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
-                     a->g_disp_teacher, a->g_disp_student, pp, pose_bwd);
+                     a->g_disp_teacher, a->g_disp_student, pp, pose_bwd, per_sample_t ? w.bgP : nullptr, a->K, per_sample_t);
   rc = launch_status();
   return rc;
 }

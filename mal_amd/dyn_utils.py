@@ -80,6 +80,11 @@ def _as_u8(mask, dev):
     return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
 
 
+# data pointers of cotangent buffers their owner allows ``BatchSynthesisFn.backward`` to overwrite with its result
+# (mal_amd.step registers the buffers it allocates for d loss / d syn around its call of the producer's backward)
+INPLACE_COTANGENTS = set()
+
+
 class BatchSynthesisFn(Function):
     """``image_synthesis``'s tensor work for the whole batch as ONE autograd node: (color_last, color_next) (B,C,H,W) and
     ``items`` = [(b, mask_last, mask_next)] for the samples with matched instances -> (syn_last, syn_next).  Samples
@@ -88,7 +93,7 @@ class BatchSynthesisFn(Function):
     node per sample in the autograd graph."""
 
     @staticmethod
-    def forward(ctx, color_last, color_next, items, replace):
+    def forward(ctx, color_last, color_next, items, replace, prefilled=None):
         # per-sample pointers are handed to the kernels: a batch-strided tensor (samples contiguous) needs no copy
         ok = lambda t: t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t[0].is_contiguous()
         cl = color_last if ok(color_last) else ops._req(color_last, "color_last")
@@ -96,11 +101,19 @@ class BatchSynthesisFn(Function):
         B, C, H, W = cl.shape
         dev = cl.device
         lib, p = L.load(), ops._p
-        # the kernels write every pixel of a listed sample: only the others need the copy of the warped images
+        # the kernels write every pixel of a listed sample: only the others need the copy of the warped images ... unless
+        # the caller hands buffers that hold the warped images already (the whole-step API's warp pass writes them twice):
+        # then only the pixels of the instances' regions are written
         every = len({it[0] for it in items}) == B
         new = lambda: torch.empty(cl.shape, dtype=torch.float32, device=dev)
-        syn_last, syn_next = (new(), new()) if every else (cl.clone(memory_format=torch.contiguous_format),
-                                                           cn.clone(memory_format=torch.contiguous_format))
+        if prefilled is not None:
+            syn_last, syn_next = prefilled
+            if not (ok(syn_last) and ok(syn_next) and syn_last.is_contiguous() and syn_next.is_contiguous()
+                    and syn_last.shape == cl.shape and syn_next.shape == cl.shape):
+                raise L.MalError("image_synthesis: the prefilled buffers must be two contiguous (B,C,H,W) float32 device tensors")
+        else:
+            syn_last, syn_next = (new(), new()) if every else (cl.clone(memory_format=torch.contiguous_format),
+                                                               cn.clone(memory_format=torch.contiguous_format))
         if not items:
             ctx.saved, ctx.dims, ctx.every = [], (C, H, W), False
             return syn_last, syn_next
@@ -131,6 +144,7 @@ class BatchSynthesisFn(Function):
             a.img_last, a.img_next, a.ori_last, a.ori_next = p(cl[b]), p(cn[b]), p(syn_last[b]), p(syn_next[b])
             a.delta, a.flags, a.ws, a.ws_bytes = p(delta), p(flags), p(ws), ws.numel()
             a.idx_last, a.idx_next = p(idx_last), p(idx_next)
+            a.prefilled = 1 if prefilled is not None else 0
             saved.append((b, ml, mn, num, delta, flags, ws, idx_last, idx_next))
         # all samples in one call: three launches (extents, displacements, synthesis) for up to 16 samples
         L.check(lib.mal_dyn_batch_fwd(arr, len(items), C, H, W, 1 if replace else 0, ops._stream()), "mal_dyn_batch_fwd")
@@ -141,20 +155,30 @@ class BatchSynthesisFn(Function):
     @once_differentiable
     def backward(ctx, g_last, g_next):
         C, H, W = ctx.dims
+        # cotangent buffers whose owner says they may be overwritten (the whole-step API allocates them for exactly this):
+        # outside the instances' regions the gradient IS the cotangent, so only the region pixels are touched, in place
+        inplace = g_last.data_ptr() in INPLACE_COTANGENTS and g_next.data_ptr() in INPLACE_COTANGENTS \
+            and g_last.is_contiguous() and g_next.is_contiguous()
         g_last, g_next = g_last.contiguous(), g_next.contiguous()
         if not ctx.saved:
-            return g_last.clone(), g_next.clone(), None, None
-        # samples without instances: the identity (a copy); the kernel writes every pixel of the listed ones
-        gl, gn = (torch.empty_like(g_last), torch.empty_like(g_next)) if ctx.every else (g_last.clone(), g_next.clone())
+            return (g_last, g_next, None, None, None) if inplace else (g_last.clone(), g_next.clone(), None, None, None)
         lib, p = L.load(), ops._p
+        if inplace:
+            gl, gn = g_last, g_next
+            tmp_l, tmp_n = torch.empty_like(g_last), torch.empty_like(g_next)
+        else:
+            # samples without instances: the identity (a copy); the kernel writes every pixel of the listed ones
+            gl, gn = (torch.empty_like(g_last), torch.empty_like(g_next)) if ctx.every else (g_last.clone(), g_next.clone())
         arr = (L.DynItem * len(ctx.saved))()
         for k, (b, ml, mn, num, delta, flags, ws, idx_last, idx_next) in enumerate(ctx.saved):
             a = arr[k]
             a.mask_last, a.mask_next, a.num, a.delta, a.flags = p(ml), p(mn), num, p(delta), p(flags)
             a.idx_last, a.idx_next = p(idx_last), p(idx_next)
             a.g_ori_last, a.g_ori_next, a.g_img_last, a.g_img_next = p(g_last[b]), p(g_next[b]), p(gl[b]), p(gn[b])
+            if inplace:
+                a.g_tmp_last, a.g_tmp_next = p(tmp_l[b]), p(tmp_n[b])
         L.check(lib.mal_dyn_batch_bwd(arr, len(ctx.saved), C, H, W, ops._stream()), "mal_dyn_batch_bwd")
-        return gl, gn, None, None
+        return gl, gn, None, None, None
 
 
 def image_synthesis(inputs, outputs, scale, thres, ins_model, matcher):
@@ -191,5 +215,8 @@ def image_synthesis(inputs, outputs, scale, thres, ins_model, matcher):
             items.append((b, ins_last.pred_masks[slice_last].bool(), ins_next.pred_masks[slice_next].bool()))
     if not items:
         return False
-    outputs[("syn", -1, scale)], outputs[("syn", 1, scale)] = BatchSynthesisFn.apply(color_last, color_next, items, False)
+    # ("syn_prefilled", scale): two (B,3,H,W) buffers that hold the warped images already (the whole-step API's warp pass
+    # writes them twice): the synthesised images are made in them, touching only the instances' regions
+    outputs[("syn", -1, scale)], outputs[("syn", 1, scale)] = BatchSynthesisFn.apply(
+        color_last, color_next, items, False, outputs.get(("syn_prefilled", scale)))
     return True

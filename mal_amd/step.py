@@ -147,18 +147,25 @@ class TemporalLossStepFn(Function):
         warp = [pair[:, 0], pair[:, 1]]
         a.warp_m1, a.warp_p1 = warp[0].data_ptr(), warp[1].data_ptr()
         a.warp_sample_stride = 6 * H * W
+        # ... and a second time into the buffers the synthesised images are made in: a producer that knows the key
+        # ("syn_prefilled", scale) -- mal_amd.dyn_utils.image_synthesis -- then overwrites only the pixels of its instances'
+        # regions instead of copying every sample first (dyn_utils.py:127-128)
+        pre = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+        a.warp2_m1, a.warp2_p1 = pre[0].data_ptr(), pre[1].data_ptr()
         lib = L.load()
         L.check(lib.mal_loss_step_warp(C.byref(a)), "mal_loss_step_warp")
         with torch.enable_grad():
             leaf = [w.detach().requires_grad_(True) for w in warp]
-            local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1], ("color_pair", 0): pair}
+            local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1], ("color_pair", 0): pair,
+                     ("syn_prefilled", 0): (pre[0], pre[1])}
             has_ins = bool(synth(inputs, local, 0))
         if has_ins:
             syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
             syn_data = [ops._req(s.detach(), "syn") for s in syn]
         else:  # no matched instance anywhere: syn == warp ties with it and never wins (first minimum), as if absent
             syn, syn_data = None, warp
-        g_syn = [torch.empty_like(w) for w in warp]
+        # the cotangents of syn: this node's own buffers, which the producer's backward may turn into its result in place
+        g_syn = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
         a.syn_m1, a.syn_p1 = syn_data[0].data_ptr(), syn_data[1].data_ptr()
         a.g_syn_m1, a.g_syn_p1 = g_syn[0].data_ptr(), g_syn[1].data_ptr()
         L.check(lib.mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
@@ -182,7 +189,13 @@ class TemporalLossStepFn(Function):
         if syn is None:
             g_warp = g_syn  # the identity producer
         else:
-            g_warp = torch.autograd.grad(syn, leaf, g_syn, allow_unused=True)
+            from . import dyn_utils
+            ptrs = {g.data_ptr() for g in g_syn}
+            dyn_utils.INPLACE_COTANGENTS |= ptrs  # mal_amd.dyn_utils.image_synthesis turns them into its result in place
+            try:
+                g_warp = torch.autograd.grad(syn, leaf, g_syn, allow_unused=True)
+            finally:
+                dyn_utils.INPLACE_COTANGENTS -= ptrs
             g_warp = [torch.zeros_like(w) if g is None else g.contiguous() for g, w in zip(g_warp, warp)]
         a = ctx.args
         a.g_warp_m1, a.g_warp_p1 = g_warp[0].data_ptr(), g_warp[1].data_ptr()
