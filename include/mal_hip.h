@@ -289,6 +289,10 @@ typedef struct mal_step_args {
   float *warp2_m1, *warp2_p1;             /* nullable, contiguous (B,3,H,W): a second copy of the warped images, written by
                                              mal_loss_step_warp -- the buffers the producer makes syn_f in (it then only
                                              overwrites the pixels its instances touch, mal_dyn_item.prefilled)           */
+  const uint8_t *syn_region;              /* nullable, (B,H,W) bytes, bit 0 = the producer touched this pixel (elsewhere
+                                             syn_f == warp_f): mal_loss_step_fwd then evaluates the synthesised candidates
+                                             only where their 3x3 window can differ -- an exact tie goes to the warped
+                                             candidate anyway, torch.min takes the first minimum                          */
 } mal_step_args;
 int mal_loss_step_warp(const mal_step_args* args);
 /* the same noise map on its own (tests; bit-identical to what the step draws for that seed / step) */

@@ -87,6 +87,50 @@ __global__ __launch_bounds__(1024) void dyn_extents_kernel(DynBatch bt) {
   if (tid < 4) p.ext[((i * 2 + which) * kExtChunks + chunk) * 4 + tid] = res[tid];  // merged by dyn_delta_kernel
 }
 
+MAL_DEV unsigned nz4(unsigned w) {  // bit k = byte k of w is non-zero
+  return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
+}
+
+// The same extents for W % 16 == 0 without the row / column flag arrays: a thread's 16 bytes lie in one row, so it knows
+// its row and, from the non-zero bytes' bit mask, its first and last marked column; four wave-level min / max
+// reductions, one LDS atomic per wave and quantity, one barrier.
+__global__ __launch_bounds__(1024) void dyn_extents16_kernel(DynBatch bt) {
+  __shared__ int res[4];
+  const DynParams& p = bt.s[blockIdx.z];
+  if ((int)blockIdx.x >= p.num) return;
+  const int i = blockIdx.x, which = blockIdx.y / kExtChunks, chunk = blockIdx.y % kExtChunks, tid = threadIdx.x;
+  const int H = p.H, W = p.W, W16 = W >> 4;
+  const int band = (H + kExtChunks - 1) / kExtChunks, r_lo = chunk * band, r_hi = min(r_lo + band, H);
+  if (tid < 4) res[tid] = (tid & 1) ? 0x7fffffff : 0;  // low, top, right, left: max / min
+  __syncthreads();
+  const long long* sel = which ? p.idx_next : p.idx_last;
+  const uint4* m16 = reinterpret_cast<const uint4*>((which ? p.mask_next : p.mask_last) + (size_t)(sel ? sel[i] : i) * ((size_t)H * W));
+  int rmax = 0, rmin = 0x7fffffff, cmax = 0, cmin = 0x7fffffff;
+  for (int k = r_lo * W16 + tid; k < max(r_hi, r_lo) * W16; k += 1024) {
+    const uint4 v = m16[k];
+    const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+    unsigned m = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m |= nz4(w4[j]) << (4 * j);
+    if (m) {
+      const int row = k / W16, col0 = (k - row * W16) * 16;
+      if (row >= 1) { rmax = max(rmax, row); rmin = min(rmin, row); }
+      const unsigned m1 = col0 == 0 ? (m & ~1u) : m;  // column 0 is invisible, as row 0
+      if (m1) { cmax = max(cmax, col0 + 31 - __clz((int)m1)); cmin = min(cmin, col0 + __ffs((int)m1) - 1); }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    rmax = max(rmax, __shfl_down(rmax, o, 64)); rmin = min(rmin, __shfl_down(rmin, o, 64));
+    cmax = max(cmax, __shfl_down(cmax, o, 64)); cmin = min(cmin, __shfl_down(cmin, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    if (rmax > 0) { atomicMax(&res[0], rmax); atomicMin(&res[1], rmin); }
+    if (cmax > 0) { atomicMax(&res[2], cmax); atomicMin(&res[3], cmin); }
+  }
+  __syncthreads();
+  if (tid < 4) p.ext[((i * 2 + which) * kExtChunks + chunk) * 4 + tid] = res[tid];
+}
+
 // displacement of instance i from the band extents (dyn_utils.py:53-103): of (low_next-low_last, top_next-top_last) the one
 // of larger magnitude (the first on a tie), halved and rounded half-to-even; columns alike; replace=1 zeroes |d| < 3
 MAL_DEV void instance_delta(const DynParams& p, int i, int* dx_out, int* dy_out) {
@@ -237,9 +281,6 @@ __global__ __launch_bounds__(256) void dyn_apply_region_kernel(DynBatch bt) {
 // 25 us for work whose bytes need 5.  For W % 4 == 0 a thread owns four consecutive pixels of a row: mask bytes arrive
 // as 32-bit words (the shifted ones as the two words that straddle them, funnel-shifted), every load of an instance is
 // unconditional, the images move as float4 -- and only where no pixel of the quad lies in the instances' region.
-MAL_DEV unsigned nz4(unsigned w) {  // bit k = byte k of w is non-zero
-  return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
-}
 // bytes row[cs .. cs+3] for any integer cs, bytes outside [0, W) read as zero; row 4-byte aligned, W % 4 == 0
 MAL_DEV unsigned bytes4_at(const uint8_t* row, int cs, int W) {
   const unsigned* rw = reinterpret_cast<const unsigned*>(row);
@@ -482,7 +523,12 @@ static int dyn_fwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, int
     p.ext = (int*)a.ws; p.delta = a.delta; p.flags = a.flags; p.prefilled = a.prefilled;
     max_num = a.num > max_num ? a.num : max_num;
   }
-  hipLaunchKernelGGL(dyn_extents_kernel, dim3(max_num, 2 * kExtChunks, n), dim3(1024), (size_t)(H + W + 4) * sizeof(int), st, bt);
+  bool wide = (W & 15) == 0;
+  for (int k = 0; k < n && wide; ++k) wide = aligned_to(bt.s[k].mask_last, 16) && aligned_to(bt.s[k].mask_next, 16);
+  if (wide)
+    hipLaunchKernelGGL(dyn_extents16_kernel, dim3(max_num, 2 * kExtChunks, n), dim3(1024), 0, st, bt);
+  else
+    hipLaunchKernelGGL(dyn_extents_kernel, dim3(max_num, 2 * kExtChunks, n), dim3(1024), (size_t)(H + W + 4) * sizeof(int), st, bt);
   bool quad = (W & 3) == 0 && C == 3;
   for (int k = 0; k < n && quad; ++k) {
     const DynParams& q = bt.s[k];

@@ -31,6 +31,11 @@ struct PhotoMarchParams {
   const uint8_t* argmin_in; const float* weight_in; const float* scale; const double* sums;
   float* g_cand[2];                              // (B,3,H,W) each, [1] nullable
   int B, H, W, strips, segs, rows, ntasks, per_xcd;
+  // FUSED, nullable: (B,H,W) bytes, bit 0 = the pixel lies in the region the producer of this pair touched (elsewhere the
+  // pair EQUALS the candidates behind prev_min / prev_arg).  A candidate whose 3x3 window holds no such pixel ties with
+  // its original and the first minimum wins (torch.min): it is not evaluated there; a task without such a pixel within
+  // two pixels of its tile copies the running min through and writes zero gradients.
+  const uint8_t* region;
 };
 
 struct Px9 { float t[3], a[3], c[3]; };
@@ -198,28 +203,73 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
   int win1 = 255;
   float acc_rw = 0.f, acc_w = 0.f;  // FUSED: sum rp*w, sum w over the pixels this task owns
   auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
+  const uint8_t* rgn = (FUSED && p.region) ? p.region + map_b : nullptr;
+  if (FUSED && rgn) {
+    // does the producer's region come within two pixels of this tile?  (owned pixel <- decisions of its 3x3 neighbours <-
+    // their 3x3 windows)
+    unsigned any = 0u;  // every load issued before the first use: no short-circuit
+#pragma unroll 8
+    for (int rr = max(y_lo - 2, 0); rr <= min(y_hi + 1, H - 1); ++rr) any |= rgn[rr * W + gxr];
+    if (!__any((any & 1u) && in_x)) {
+      for (int c = y_lo; c < y_hi; ++c) {
+        if (!out_x) continue;
+        const unsigned go = (unsigned)(c * W + gxr);
+        const float pm = ldf(p.prev_min + map_b, go * 4u);
+        float idn = ldf(p.ident + map_b, go * 4u);
+        if (p.noise) idn += ldf(p.noise + map_b, go * 4u) * 0.00001f;
+        const float w = (pm <= idn) ? 1.0f : 0.0f;
+        stf(p.min_reproj + map_b, go * 4u, pm);
+        p.argmin[map_b + go] = p.prev_arg[map_b + go];
+        stf(p.weight_out + map_b, go * 4u, w);
+        acc_rw += pm * w;
+        acc_w += w;
+        stf(ga, go * 4u, 0.f); stf(ga + HW, go * 4u, 0.f); stf(ga + 2 * (size_t)HW, go * 4u, 0.f);
+        if (gb) { stf(gb, go * 4u, 0.f); stf(gb + HW, go * 4u, 0.f); stf(gb + 2 * (size_t)HW, go * 4u, 0.f); }
+      }
+      const double r0 = wave_sum_d((double)acc_rw), r1 = wave_sum_d((double)acc_w);
+      if (lane == 0) { p.block_sums[(size_t)task * 2] = r0; p.block_sums[(size_t)task * 2 + 1] = r1; }
+      return;
+    }
+  }
+  float nfA = 0.f, nfB = 0.f;  // region within one column, of rows r-2 and r-1
   const int r_first = max(y_lo - HALO, -1), r_last = y_hi - 1 + HALO;
   Px9 nxt;
   request9(p, tb, ab, cb, HW, row_of(r_first), gxr, nxt);
+  unsigned fr_nxt = (FUSED && rgn) ? rgn[row_of(r_first) * W + gxr] : 1u;  // the region byte travels one row ahead, like the planes
+  float pm_nxt = 0.f, idn_nxt = 0.f;
+  int win_nxt = 255;
+  if (FUSED) {  // centre row of the first iteration: r_first - 1
+    const unsigned g0 = (unsigned)(min(max(r_first - 1, 0), H - 1) * W + gxr);
+    pm_nxt = ldf(p.prev_min + map_b, g0 * 4u);
+    win_nxt = p.prev_arg[map_b + g0];
+    idn_nxt = ldf(p.ident + map_b, g0 * 4u);
+    if (p.noise) idn_nxt += ldf(p.noise + map_b, g0 * 4u) * 0.00001f;
+  }
   for (int r = r_first; r <= r_last; ++r) {
     const Px9 cur = nxt;
+    const unsigned fr_cur = fr_nxt;
     request9(p, tb, ab, cb, HW, row_of(r + 1), gxr, nxt);
+    if (FUSED && rgn) fr_nxt = rgn[row_of(r + 1) * W + gxr];
     const int c = r - 1;
     const bool c_valid = c >= 0 && c < H && c >= y_lo - 1 && c <= y_hi;
     float w0 = 0.f;
     int win0 = 255;
     float pm = 0.f, idn = 0.f;  // FUSED: running min of the earlier candidates, identity term (+ noise) of the centre row
-    if (c_valid) {
+    if (FUSED) {
+      // the centre row's maps were requested an iteration ago (a lone wave on a SIMD -- most tasks leave early when a
+      // region map is given -- would otherwise stall a full memory round trip per row here)
+      pm = pm_nxt; win0 = win_nxt; idn = idn_nxt;
+      const int cn = min(max(r, 0), H - 1);  // next iteration's centre row (clamped: unused when not valid)
+      const unsigned gn = (unsigned)(cn * W + gxr);
+      pm_nxt = ldf(p.prev_min + map_b, gn * 4u);
+      win_nxt = p.prev_arg[map_b + gn];
+      idn_nxt = ldf(p.ident + map_b, gn * 4u);
+      if (p.noise) idn_nxt += ldf(p.noise + map_b, gn * 4u) * 0.00001f;
+      if (!c_valid) { pm = 0.f; win0 = 255; idn = 0.f; }
+    } else if (c_valid) {
       const unsigned go = (unsigned)(c * W + gxr);
-      if (!FUSED) {
-        w0 = in_x ? ldf(p.weight_in + map_b, go * 4u) : 0.f;  // not a pixel: contributes nothing
-        win0 = p.argmin_in[map_b + go];
-      } else {
-        pm = ldf(p.prev_min + map_b, go * 4u);
-        win0 = p.prev_arg[map_b + go];
-        idn = ldf(p.ident + map_b, go * 4u);
-        if (p.noise) idn += ldf(p.noise + map_b, go * 4u) * 0.00001f;
-      }
+      w0 = in_x ? ldf(p.weight_in + map_b, go * 4u) : 0.f;  // not a pixel: contributes nothing
+      win0 = p.argmin_in[map_b + go];
     }
     const f2 x0[3] = {(f2){cur.a[0], cur.a[1]}, (f2){cur.c[0], cur.c[1]}, (f2){cur.a[2], cur.c[2]}};
     const f2 y0rg = (f2){cur.t[0], cur.t[1]};
@@ -234,6 +284,14 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
       h[k * 3 + 0] = hsum3(x);
       h[k * 3 + 1] = hsum3(x * x);
       h[k * 3 + 2] = hsum3(x * y);
+    }
+    // does the producer's region reach the 3x3 window of the centre row's pixel?  (rows r-2, r-1, r; without a region map: yes)
+    bool near_c = true;
+    if (FUSED && rgn) {
+      const float fr = (fr_cur & 1u) ? 1.0f : 0.0f;
+      const float nf = (dpp_shr1(fr) + fr) + dpp_shl1(fr);
+      near_c = (nfA + nfB) + nf > 0.f;
+      nfA = nfB; nfB = nf;
     }
     // ---- SSIM partials of the centre row c for the candidate that won there (if it is one of this pair)
     f2 coef[9];
@@ -260,8 +318,10 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
         const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
         const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
         float rp = pm;  // running min, first minimum wins (torch.min)
-        if (rr.x < rp) { rp = rr.x; win0 = p.idx[0]; }
-        if (rr.y < rp) { rp = rr.y; win0 = p.idx[1]; }
+        if (near_c) {
+          if (rr.x < rp) { rp = rr.x; win0 = p.idx[0]; }
+          if (rr.y < rp) { rp = rr.y; win0 = p.idx[1]; }
+        }
         const float w = (rp <= idn) ? 1.0f : 0.0f;
         w0 = in_x ? w : 0.f;
         if (out_x && c >= y_lo && c < y_hi) {
@@ -503,9 +563,10 @@ static int device_slots() {
   return slots;
 }
 
-static void decompose(PhotoMarchParams& p, int cw, int waves_per_simd) {
+int g_syn_rows = 4;  // option "syn_rows": rows per task of the fused sweep when a region map makes most tasks leave early
+static void decompose(PhotoMarchParams& p, int cw, int waves_per_simd, int rows_min = 8) {
   p.strips = (p.W + cw - 1) / cw;
-  int rows = 8;
+  int rows = rows_min;
   const long long cap = (long long)device_slots() * waves_per_simd;
   while (rows < p.H && (long long)p.B * p.strips * ((p.H + rows - 1) / rows) > cap) ++rows;
   p.rows = rows;
@@ -562,14 +623,17 @@ int photo_march_bwd(const float* target, const float* const* cand, int n_cand, c
 int photo_march_fused_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
                            const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
-                           float* g_cand1, int* per_sample_out, hipStream_t st) {
+                           float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region) {
   if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
   PhotoMarchParams p = {};
   p.target = target; p.B = B; p.H = H; p.W = W;
   p.cand[0] = cand0; p.cand[1] = cand1; p.idx[0] = idx0; p.idx[1] = idx0 + 1;
   p.prev_min = prev_min; p.prev_arg = prev_arg; p.ident = ident; p.noise = noise;
   p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;
-  p.g_cand[0] = g_cand0; p.g_cand[1] = g_cand1;
+  p.g_cand[0] = g_cand0; p.g_cand[1] = g_cand1; p.region = region;
+  // with a region map the few tasks that do the full work set the kernel's duration (every task is resident at once, and
+  // a wavefront alone on its SIMD marches no faster): shorter tasks, four times as many (the workspace holds 2-row tasks)
+  if (region && g_syn_rows >= 2 && g_syn_rows < 8) decompose(p, 60, 8, g_syn_rows); else
   decompose(p, 60, 2);
   *per_sample_out = p.strips * p.segs;
   hipLaunchKernelGGL(photo_march_bwd_kernel<true>, dim3(p.per_xcd * 8), dim3(64), 0, st, p);

@@ -116,7 +116,10 @@ class BatchSynthesisFn(Function):
                                                                cn.clone(memory_format=torch.contiguous_format))
         if not items:
             ctx.saved, ctx.dims, ctx.every = [], (C, H, W), False
-            return syn_last, syn_next
+            return syn_last, syn_next, None
+        # the per-pixel predicates of all samples in ONE (B,H,W) byte map (bit 0: the pixel lies in the instances' region):
+        # what the backward needs, and what tells a consumer where syn can differ from the warped images at all
+        flags_all = (torch.empty if every else torch.zeros)((B, H, W), dtype=torch.uint8, device=dev)
         arr = (L.DynItem * len(items))()
         saved = []
         for k, item in enumerate(items):
@@ -137,7 +140,7 @@ class BatchSynthesisFn(Function):
                     raise L.MalError("image_synthesis: the two frames must hold the same number of matched instances")
             ml, mn = _as_u8(mask_last, dev), _as_u8(mask_next, dev)
             delta = torch.empty(num, 2, dtype=torch.int32, device=dev)
-            flags = torch.empty(H, W, dtype=torch.uint8, device=dev)
+            flags = flags_all[b]
             ws = torch.empty(lib.mal_dyn_workspace_bytes(num), dtype=torch.uint8, device=dev)
             a = arr[k]
             a.mask_last, a.mask_next, a.num = p(ml), p(mn), num
@@ -149,11 +152,12 @@ class BatchSynthesisFn(Function):
         # all samples in one call: three launches (extents, displacements, synthesis) for up to 16 samples
         L.check(lib.mal_dyn_batch_fwd(arr, len(items), C, H, W, 1 if replace else 0, ops._stream()), "mal_dyn_batch_fwd")
         ctx.saved, ctx.dims, ctx.every = saved, (C, H, W), every
-        return syn_last, syn_next
+        ctx.mark_non_differentiable(flags_all)
+        return syn_last, syn_next, flags_all
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_last, g_next):
+    def backward(ctx, g_last, g_next, _g_flags=None):
         C, H, W = ctx.dims
         # cotangent buffers whose owner says they may be overwritten (the whole-step API allocates them for exactly this):
         # outside the instances' regions the gradient IS the cotangent, so only the region pixels are touched, in place
@@ -217,6 +221,10 @@ def image_synthesis(inputs, outputs, scale, thres, ins_model, matcher):
         return False
     # ("syn_prefilled", scale): two (B,3,H,W) buffers that hold the warped images already (the whole-step API's warp pass
     # writes them twice): the synthesised images are made in them, touching only the instances' regions
-    outputs[("syn", -1, scale)], outputs[("syn", 1, scale)] = BatchSynthesisFn.apply(
-        color_last, color_next, items, False, outputs.get(("syn_prefilled", scale)))
+    syn_last, syn_next, region = BatchSynthesisFn.apply(color_last, color_next, items, False,
+                                                        outputs.get(("syn_prefilled", scale)))
+    outputs[("syn", -1, scale)], outputs[("syn", 1, scale)] = syn_last, syn_next
+    # (B,H,W) bytes, bit 0: where syn can differ from the warped images (a consumer may skip the synthesised candidates
+    # elsewhere: an exact tie goes to the warped one anyway, loss_utils.py:103)
+    outputs[("syn_region", scale)] = region
     return True

@@ -159,9 +159,15 @@ class TemporalLossStepFn(Function):
             local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1], ("color_pair", 0): pair,
                      ("syn_prefilled", 0): (pre[0], pre[1])}
             has_ins = bool(synth(inputs, local, 0))
+        region = None
         if has_ins:
             syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
             syn_data = [ops._req(s.detach(), "syn") for s in syn]
+            region = local.get(("syn_region", 0))
+            if region is not None:
+                if not (region.is_cuda and region.dtype == torch.uint8 and tuple(region.shape) == (B, H, W) and region.is_contiguous()):
+                    raise L.MalError("loss_step: ('syn_region', 0) must be a contiguous (B,H,W) uint8 device tensor")
+                a.syn_region = region.data_ptr()
         else:  # no matched instance anywhere: syn == warp ties with it and never wins (first minimum), as if absent
             syn, syn_data = None, warp
         # the cotangents of syn: this node's own buffers, which the producer's backward may turn into its result in place
@@ -171,6 +177,7 @@ class TemporalLossStepFn(Function):
         L.check(lib.mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
         ctx.args, ctx.keep = a, keep
         ctx.graph = (leaf, syn, syn_data, g_syn, warp)
+        ctx.region = region  # the C struct holds its pointer
         ctx.set_materialize_grads(False)
         expose[("color", -1, 0)], expose[("color", 1, 0)] = warp
         if has_ins:
