@@ -130,3 +130,105 @@ def test_image_synthesis_control_flow(as_tensor):
     assert torch.equal(gl[0], rl.grad) and torch.equal(gn[0], rn.grad)
     for b in (1, 2):
         assert torch.equal(gl[b], wl[b]) and torch.equal(gn[b], wn[b])
+
+
+def _stub_items(B, H, W, listed, seed):
+    from oracle.gen_golden_dyn import make_masks
+    items = []
+    for b in listed:
+        ml, mn = make_masks(3, H, W, seed=seed + b, edge_cases=False)
+        items.append((b, ml.to(DEV), mn.to(DEV)))
+    return items
+
+
+@pytest.mark.parametrize("shape,listed", [((3, 24, 40), (0, 2)), ((2, 32, 64), (0, 1)), ((2, 21, 37), (1,))],
+                         ids=["w40-one-sample-skipped", "w64-every-sample", "w37-scalar-kernels"])
+def test_prefilled_and_in_place_equal_the_plain_node(shape, listed):
+    """the whole-step API's protocol -- syn made in buffers that hold the warped images already, the cotangent buffers
+    turned into the gradients in place, the region map handed out -- against the plain autograd node: bit for bit"""
+    from mal_amd import dyn_utils
+    B, H, W = shape
+    g = torch.Generator().manual_seed(31)
+    cl, cn = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    wl, wn = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    items = _stub_items(B, H, W, listed, 40)
+    a_l, a_n = cl.clone().requires_grad_(True), cn.clone().requires_grad_(True)
+    sl, sn, region = dyn_utils.BatchSynthesisFn.apply(a_l, a_n, items, False, None)
+    gl, gn = torch.autograd.grad([sl, sn], [a_l, a_n], [wl.clone(), wn.clone()])
+    # prefilled + in place
+    b_l, b_n = cl.clone().requires_grad_(True), cn.clone().requires_grad_(True)
+    pre = (cl.clone(), cn.clone())
+    pl, pn, region2 = dyn_utils.BatchSynthesisFn.apply(b_l, b_n, items, False, pre)
+    assert pl.data_ptr() == pre[0].data_ptr() and pn.data_ptr() == pre[1].data_ptr()
+    assert torch.equal(pl, sl) and torch.equal(pn, sn) and torch.equal(region2, region)
+    ct = [wl.clone(), wn.clone()]
+    ptrs = {t.data_ptr() for t in ct}
+    dyn_utils.INPLACE_COTANGENTS |= ptrs
+    try:
+        hl, hn = torch.autograd.grad([pl, pn], [b_l, b_n], ct)
+    finally:
+        dyn_utils.INPLACE_COTANGENTS -= ptrs
+    assert hl.data_ptr() == ct[0].data_ptr() and hn.data_ptr() == ct[1].data_ptr()  # really in place
+    assert torch.equal(hl, gl) and torch.equal(hn, gn)
+    # the region map: bit 0 = some instance's mask (either frame) holds the pixel; zero for samples not listed
+    for b in range(B):
+        want = torch.zeros(H, W, dtype=torch.bool, device=DEV)
+        for (bb, ml, mn) in items:
+            if bb == b:
+                want = (ml.bool() | mn.bool()).any(0)
+        assert torch.equal((region[b] & 1).bool(), want), b
+        assert torch.equal(sl[b][:, ~want], cl[b][:, ~want])  # syn differs from the warped image only there
+
+
+def test_step_with_the_region_map_equals_the_dense_path():
+    """loss_step with mal_amd.dyn_utils.image_synthesis (pre-filled syn buffers, in-place producer backward, region map:
+    synthesised candidates skipped where their window cannot differ) against the same step driven by a producer that
+    offers none of that (every candidate evaluated everywhere): same losses, same gradients; and with the map no
+    synthesised candidate ever wins outside the dilated region (an exact tie goes to the warped one, loss_utils.py:103)"""
+    from mal_amd import _lib, dyn_utils, step, trainer
+    from mal_amd.synthetic import instance_stub, make_batch, to_dicts
+    B, H, W = 3, 64, 128
+    batch = make_batch(B, H, W, seed=11)
+    opt = trainer.default_options(height=H, width=W, batch_size=B, temporal=True)
+    g = torch.Generator().manual_seed(2)
+    noise = torch.randn(B, 1, H, W, generator=g).to(DEV)
+
+    def run(dense):
+        ins_model, matcher = instance_stub(B, H, W, n_inst=2, seed=5, device=DEV)
+
+        def synth(inputs, outputs, scale):
+            if not dense:
+                return dyn_utils.image_synthesis(inputs, outputs, scale, 0.5, ins_model, matcher)
+            plain = {k: v for k, v in outputs.items() if k[0] != "syn_prefilled"}
+            has = dyn_utils.image_synthesis(inputs, plain, scale, 0.5, ins_model, matcher)
+            for k in (("syn", -1, scale), ("syn", 1, scale)):
+                if k in plain:
+                    outputs[k] = plain[k]
+            seen["region"] = plain.get(("syn_region", scale))
+            return has
+
+        inputs, mono_outputs, outputs, leaves = to_dicts(batch, lambda a, t, inv: None, device=DEV)
+        for f, s in ((-1, "m1"), (1, "p1")):
+            mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + s]
+            mono_outputs[("translation", 0, f)] = leaves["translation_" + s]
+        losses, _, maps = step.loss_step(opt, inputs, mono_outputs, outputs, noise=noise.clone(), want_decisions=True,
+                                         image_synthesis=synth)
+        losses["loss"].backward()
+        torch.cuda.synchronize()
+        return ({k: float(v.detach()) for k, v in losses.items()}, {k: t.grad.cpu() for k, t in leaves.items()},
+                maps["dec_teacher"][_lib.DEC_WIN].cpu())
+
+    seen = {}
+    l_dense, g_dense, win_dense = run(True)
+    l_sparse, g_sparse, win_sparse = run(False)
+    for k, v in l_dense.items():
+        assert abs(l_sparse[k] - v) <= 2e-6 * abs(v) + 1e-9, (k, l_sparse[k], v)
+    for k, r in g_dense.items():
+        sc = float(r.abs().max())
+        bad = ((g_sparse[k] - r).abs() > 1e-4 * sc).float().mean().item()
+        assert bad <= 1e-3, (k, bad)
+    region = (seen["region"] & 1).bool().cpu()
+    near = torch.nn.functional.max_pool2d(region[:, None].float(), 3, 1, 1)[:, 0] > 0
+    syn_won = (win_sparse & 3) >= 2
+    assert not bool((syn_won & ~near).any())          # with the map: never outside the dilated region
+    assert bool((syn_won & near).any())               # ... and the synthesised candidates do win somewhere inside
