@@ -3,10 +3,12 @@
 // frames.  (Mask2Former and the Hungarian matcher that produce the masks stay outside this library.)
 //
 // Upstream this is a TorchScript loop over instances with (num, 3, H, W) temporaries per call and per
-// sample; here it is three launches per sample and no temporaries:
+// sample; here it is two launches for up to 16 samples and no temporaries (the scalar kernels first; the 16-byte /
+// four-pixel forms further down are what runs for W % 16 == 0 / W % 4 == 0):
 //   dyn_extents_kernel   per (instance, frame): which rows / columns >= 1 hold mask pixels (the reference
 //                        weighs the mask by the row / column index, so index 0 is invisible) -> low, top,
-//                        right, left; then, per instance, the displacement: of (low_next-low_last,
+//                        right, left per band of rows; the synthesis kernel's workgroups merge the bands and derive,
+//                        per instance, the displacement: of (low_next-low_last,
 //                        top_next-top_last) the one of larger magnitude (the first on a tie), halved and rounded
 //                        half-to-even; columns alike; replace=1 zeroes magnitudes < 3   (dyn_utils.py:53-103)
 //   dyn_synth_fwd_kernel per pixel p:
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(1024) void dyn_extents_kernel(DynBatch bt) {
   for (int c = 1 + tid; c < W; c += 1024)
     if (colf[c]) { atomicMax(&res[2], c); atomicMin(&res[3], c); }
   __syncthreads();
-  if (tid < 4) p.ext[((i * 2 + which) * kExtChunks + chunk) * 4 + tid] = res[tid];  // merged by dyn_delta_kernel
+  if (tid < 4) p.ext[((i * 2 + which) * kExtChunks + chunk) * 4 + tid] = res[tid];  // merged by instance_delta
 }
 
 MAL_DEV unsigned nz4(unsigned w) {  // bit k = byte k of w is non-zero

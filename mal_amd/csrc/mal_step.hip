@@ -214,37 +214,9 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
   coefs[4] = w_main * 1e-3f;                                // smoothness
 }
 
-// the pose branch of step_final_kernel on its own (temporal hint: the teacher's sweep runs in the backward call)
-__global__ __launch_bounds__(256) void step_pose_reduce_kernel(const float* bgP, const float* K, int per_sample, float* gT0,
-                                                               float* gT1) {
-  __shared__ double s_part[256];
-  __shared__ double s_gP[24];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int v = tid % 24, sub = tid / 24;
-  double acc = 0.0;
-  if (sub < 10) {
-#pragma unroll 8
-    for (int t = sub; t < per_sample; t += 10) acc += (double)bgP[((size_t)b * per_sample + t) * 24 + v];
-  }
-  s_part[tid] = acc;
-  __syncthreads();
-  if (tid < 24) {
-    double a = 0.0;
-    for (int k = 0; k < 10; ++k) a += s_part[k * 24 + tid];
-    s_gP[tid] = a;
-  }
-  __syncthreads();
-  if (tid < 32) {
-    const int f = tid >> 4, e = tid & 15, k = e >> 2, j = e & 3;
-    const float* Kb = K + b * 16;
-    double a = 0.0;
-    for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
-    (f ? gT1 : gT0)[b * 16 + e] = (float)a;
-  }
-}
-
 // d total / d disp for both maps; block 0 also scales the pose gradients and runs the backward of
-// transformation_from_parameters (pp.gT = the scaled gradients, pp.g_axisangle / g_translation nullable)
+// transformation_from_parameters (pp.gT = the scaled gradients, pp.g_axisangle / g_translation nullable).  With the
+// temporal hint (bgP != nullptr) the first B workgroups reduce their sample's pose partials first.
 __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, const float* G_r_s, const float* G_cd,
                                                             const float* gn_t, const float* gn_s,
                                                             const float* coefs, const double* stats, const float* g_total,
