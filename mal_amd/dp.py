@@ -30,6 +30,7 @@ class FlatGradBucket:
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=dt, device=dev)
         self.group = process_group
+        self._avg = None
         off = 0
         for p in self.params:
             if p.device != dev or p.dtype != dt:
@@ -55,10 +56,23 @@ class FlatGradBucket:
         return True
 
     def all_reduce_mean(self, async_op=False):
-        """sum over ranks, then / world_size (DDP's gradient averaging)."""
+        """mean over ranks (DDP's gradient averaging): ONE collective.  RCCL/NCCL average inside the collective
+        (``ReduceOp.AVG``: no second pass over the 165 MB bucket); backends without it (gloo) sum, then scale."""
         ws = self.world_size
         if ws == 1:
             return None
+        if self._avg is None:  # decided once: does this backend take ReduceOp.AVG?
+            self._avg = False
+            if self.flat.is_cuda and dist.get_backend(self.group) == "nccl":
+                try:
+                    probe = torch.zeros(1, dtype=self.flat.dtype, device=self.flat.device)
+                    dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.group)
+                    self._avg = True
+                except Exception:
+                    self._avg = False
+        if self._avg:
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            return work if async_op else None
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
             return _Scaled(work, self.flat, 1.0 / ws)
