@@ -293,6 +293,9 @@ typedef struct mal_step_args {
                                              syn_f == warp_f): mal_loss_step_fwd then evaluates the synthesised candidates
                                              only where their 3x3 window can differ -- an exact tie goes to the warped
                                              candidate anyway, torch.min takes the first minimum                          */
+  float *g_syn_region_m1, *g_syn_region_p1; /* nullable (with syn_region), (B,3,H,W): g_syn_* once more, written only at
+                                             touched pixels -- what a producer's in-place backward gathers from
+                                             (mal_dyn_item.region_only) */
 } mal_step_args;
 int mal_loss_step_warp(const mal_step_args* args);
 /* the same noise map on its own (tests; bit-identical to what the step draws for that seed / step) */
@@ -393,6 +396,9 @@ typedef struct mal_dyn_item {
   /* backward IN PLACE (g_img_* == g_ori_*: the cotangent buffers become the gradients): only region pixels change; they
    * are formed in g_tmp_* (C,H,W scratch, contents irrelevant) by one launch and moved by a second */
   float* g_tmp_last; float* g_tmp_next;
+  /* backward, third form: g_ori_* are SNAPSHOTS valid at region pixels only (mal_step_args.g_syn_region_*), g_img_* the
+   * buffers that hold the cotangent everywhere: one launch writes the region pixels of g_img_* (no scratch, no move) */
+  int region_only;
 } mal_dyn_item;
 int mal_dyn_batch_fwd(const mal_dyn_item* items, int n_items, int C, int H, int W, int replace, void* stream);
 int mal_dyn_batch_bwd(const mal_dyn_item* items, int n_items, int C, int H, int W, void* stream);

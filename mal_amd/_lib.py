@@ -105,7 +105,7 @@ class DynItem(C.Structure):
     _fields_ = [("mask_last", vp), ("mask_next", vp), ("num", i32), ("img_last", vp), ("img_next", vp),
                 ("ori_last", vp), ("ori_next", vp), ("delta", vp), ("flags", vp), ("ws", vp), ("ws_bytes", sz),
                 ("g_ori_last", vp), ("g_ori_next", vp), ("g_img_last", vp), ("g_img_next", vp), ("idx_last", vp), ("idx_next", vp),
-                ("prefilled", i32), ("g_tmp_last", vp), ("g_tmp_next", vp)]
+                ("prefilled", i32), ("g_tmp_last", vp), ("g_tmp_next", vp), ("region_only", i32)]
 
 
 class StepArgs(C.Structure):
@@ -121,7 +121,8 @@ class StepArgs(C.Structure):
                 [("ws_bytes", sz), ("stream", vp), ("dec_teacher", vp), ("dec_student", vp),
                  ("noise_seed", C.c_uint64), ("noise_step", C.c_uint64), ("noise_counter", vp), ("noise_out", vp)] +
                 [(n, vp) for n in ("warp_m1", "warp_p1", "syn_m1", "syn_p1", "g_syn_m1", "g_syn_p1", "g_warp_m1", "g_warp_p1")] +
-                [("warp_sample_stride", i32), ("warp2_m1", vp), ("warp2_p1", vp), ("syn_region", vp)])
+                [("warp_sample_stride", i32), ("warp2_m1", vp), ("warp2_p1", vp), ("syn_region", vp), ("g_syn_region_m1", vp),
+                 ("g_syn_region_p1", vp)])
 
 
 class MsArgs(C.Structure):

@@ -547,7 +547,7 @@ static int dyn_fwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, int
 static int dyn_bwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, hipStream_t st) {
   DynBatch bt = {};
   int max_num = 0;
-  bool region = false;
+  int region = 0;  // 0: out of place; 1: in place through scratch + move; 2: region snapshots, straight into g_img_*
   for (int k = 0; k < n; ++k) {
     const mal_dyn_item& a = it[k];
     int rc = dyn_check(a.num, C, H, W);
@@ -563,8 +563,13 @@ static int dyn_bwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, hip
     p.g_tmp_last = a.g_tmp_last; p.g_tmp_next = a.g_tmp_next;
     const bool inplace = a.g_img_last == a.g_ori_last || a.g_img_next == a.g_ori_next;
     if (inplace && (a.g_img_last != a.g_ori_last || a.g_img_next != a.g_ori_next || !a.g_tmp_last || !a.g_tmp_next)) return MAL_EINVAL;
-    if (k == 0) region = inplace;
-    else if (region != inplace) return MAL_EINVAL;
+    if (a.region_only) {  // the cotangents are region snapshots: the region kernels write straight into g_img_*
+      if (inplace || !a.g_img_last || !a.g_img_next) return MAL_EINVAL;
+      p.g_tmp_last = a.g_img_last; p.g_tmp_next = a.g_img_next;
+    }
+    const int form = a.region_only ? 2 : (inplace ? 1 : 0);
+    if (k == 0) region = form;
+    else if (region != form) return MAL_EINVAL;
     max_num = a.num > max_num ? a.num : max_num;
   }
   bool quad = (W & 3) == 0 && C == 3;
@@ -577,10 +582,10 @@ static int dyn_bwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, hip
   const dim3 grid((H * W + 255) / 256, 1, n), grid4((H * W / 4 + 255) / 256, 1, n);
   if (region && quad) {
     hipLaunchKernelGGL((dyn_synth_bwd4_kernel<3, true>), grid4, dim3(256), lds, st, bt);
-    hipLaunchKernelGGL(dyn_apply_region4_kernel<3>, grid4, dim3(256), 0, st, bt);
+    if (region == 1) hipLaunchKernelGGL(dyn_apply_region4_kernel<3>, grid4, dim3(256), 0, st, bt);
   } else if (region) {
     hipLaunchKernelGGL(dyn_synth_bwd_kernel<true>, grid, dim3(256), lds, st, bt);
-    hipLaunchKernelGGL(dyn_apply_region_kernel, grid, dim3(256), 0, st, bt);
+    if (region == 1) hipLaunchKernelGGL(dyn_apply_region_kernel, grid, dim3(256), 0, st, bt);
   } else if (quad) {
     hipLaunchKernelGGL((dyn_synth_bwd4_kernel<3, false>), grid4, dim3(256), lds, st, bt);
   } else {

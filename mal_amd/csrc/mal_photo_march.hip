@@ -36,6 +36,9 @@ struct PhotoMarchParams {
   // its original and the first minimum wins (torch.min): it is not evaluated there; a task without such a pixel within
   // two pixels of its tile copies the running min through and writes zero gradients.
   const uint8_t* region;
+  // FUSED with a region map, nullable: a second copy of the gradient, written ONLY at region pixels -- the snapshot the
+  // producer's in-place backward gathers from while it overwrites g_cand at those very pixels
+  float* g_region[2];
 };
 
 struct Px9 { float t[3], a[3], c[3]; };
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
   Px9 nxt;
   request9(p, tb, ab, cb, HW, row_of(r_first), gxr, nxt);
   unsigned fr_nxt = (FUSED && rgn) ? rgn[row_of(r_first) * W + gxr] : 1u;  // the region byte travels one row ahead, like the planes
+  unsigned fr_m0 = 0u, fr_m1 = 0u;  // region bytes of rows r-1 and r-2
   float pm_nxt = 0.f, idn_nxt = 0.f;
   int win_nxt = 255;
   if (FUSED) {  // centre row of the first iteration: r_first - 1
@@ -247,6 +251,8 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
   }
   for (int r = r_first; r <= r_last; ++r) {
     const Px9 cur = nxt;
+    const unsigned fr_q = fr_m1;  // region byte of the gradient row q = r-2
+    fr_m1 = fr_m0; fr_m0 = fr_nxt;
     const unsigned fr_cur = fr_nxt;
     request9(p, tb, ab, cb, HW, row_of(r + 1), gxr, nxt);
     if (FUSED && rgn) fr_nxt = rgn[row_of(r + 1) * W + gxr];
@@ -373,6 +379,12 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
         const unsigned bo = (unsigned)(q * W + gxr) * 4u;
         stf(ga, bo, g[0].x); stf(ga + HW, bo, g[0].y); stf(ga + 2 * (size_t)HW, bo, g[2].x);
         if (gb) { stf(gb, bo, g[1].x); stf(gb + HW, bo, g[1].y); stf(gb + 2 * (size_t)HW, bo, g[2].y); }
+        if (FUSED && p.g_region[0] && (fr_q & 1u)) {
+          float* ra = p.g_region[0] + (size_t)b * 3 * HW;
+          float* rb = p.g_region[1] + (size_t)b * 3 * HW;
+          stf(ra, bo, g[0].x); stf(ra + HW, bo, g[0].y); stf(ra + 2 * (size_t)HW, bo, g[2].x);
+          stf(rb, bo, g[1].x); stf(rb + HW, bo, g[1].y); stf(rb + 2 * (size_t)HW, bo, g[2].y);
+        }
       }
     }
     // ---- rolls
@@ -623,7 +635,8 @@ int photo_march_bwd(const float* target, const float* const* cand, int n_cand, c
 int photo_march_fused_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
                            const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
-                           float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region) {
+                           float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
+                           float* g_region1) {
   if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
   PhotoMarchParams p = {};
   p.target = target; p.B = B; p.H = H; p.W = W;
@@ -631,6 +644,7 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
   p.prev_min = prev_min; p.prev_arg = prev_arg; p.ident = ident; p.noise = noise;
   p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;
   p.g_cand[0] = g_cand0; p.g_cand[1] = g_cand1; p.region = region;
+  if (region && g_region0 && g_region1) { p.g_region[0] = g_region0; p.g_region[1] = g_region1; }
   // with a region map the few tasks that do the full work set the kernel's duration (every task is resident at once, and
   // a wavefront alone on its SIMD marches no faster): shorter tasks, four times as many (the workspace holds 2-row tasks)
   if (region && g_syn_rows >= 2 && g_syn_rows < 8) decompose(p, 60, 8, g_syn_rows); else

@@ -25,7 +25,8 @@ namespace mal {
 int photo_march_fused_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
                            const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
-                           float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region);
+                           float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
+                           float* g_region1);
 
 constexpr int kLossSlots = 16;
 
@@ -418,7 +419,8 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     if (!a->syn_m1 || !a->syn_p1 || !a->g_syn_m1 || !a->g_syn_p1) return MAL_EINVAL;
     per_sample_p = pack_identity_tasks_per_sample(H, W);
     rc = photo_march_fused_more(a->color0, a->syn_m1, a->syn_p1, 2, w.ident, a->noise, w.rp_warp, w.arg_warp, B, H, W,
-                                mono_reproj, w.arg_t, w.w_t, w.bs_ph, a->g_syn_m1, a->g_syn_p1, &per_sample_ph, st, a->syn_region);
+                                mono_reproj, w.arg_t, w.w_t, w.bs_ph, a->g_syn_m1, a->g_syn_p1, &per_sample_ph, st, a->syn_region,
+                                a->g_syn_region_m1, a->g_syn_region_p1);
     if (rc) return rc;
   }
   // ensemble pass (no gradient)

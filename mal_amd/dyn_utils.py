@@ -80,9 +80,12 @@ def _as_u8(mask, dev):
     return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
 
 
-# data pointers of cotangent buffers their owner allows ``BatchSynthesisFn.backward`` to overwrite with its result
-# (mal_amd.step registers the buffers it allocates for d loss / d syn around its call of the producer's backward)
-INPLACE_COTANGENTS = set()
+# cotangent buffers their owner allows ``BatchSynthesisFn.backward`` to overwrite with its result, by data pointer
+# (mal_amd.step registers the buffers it allocates for d loss / d syn around its call of the producer's backward).
+# Value: None, or a SNAPSHOT of the same cotangent that is valid at the instances' region pixels (the step's fused sweep
+# writes one when it has the region map): the backward then gathers from the snapshot and writes the region pixels of the
+# registered buffer in one launch, without scratch.
+INPLACE_COTANGENTS = {}
 
 
 class BatchSynthesisFn(Function):
@@ -167,9 +170,13 @@ class BatchSynthesisFn(Function):
         if not ctx.saved:
             return (g_last, g_next, None, None, None) if inplace else (g_last.clone(), g_next.clone(), None, None, None)
         lib, p = L.load(), ops._p
+        snap_l = snap_n = None
         if inplace:
             gl, gn = g_last, g_next
-            tmp_l, tmp_n = torch.empty_like(g_last), torch.empty_like(g_next)
+            snap_l, snap_n = INPLACE_COTANGENTS[g_last.data_ptr()], INPLACE_COTANGENTS[g_next.data_ptr()]
+            if snap_l is None or snap_n is None:
+                snap_l = snap_n = None
+                tmp_l, tmp_n = torch.empty_like(g_last), torch.empty_like(g_next)
         else:
             # samples without instances: the identity (a copy); the kernel writes every pixel of the listed ones
             gl, gn = (torch.empty_like(g_last), torch.empty_like(g_next)) if ctx.every else (g_last.clone(), g_next.clone())
@@ -179,7 +186,9 @@ class BatchSynthesisFn(Function):
             a.mask_last, a.mask_next, a.num, a.delta, a.flags = p(ml), p(mn), num, p(delta), p(flags)
             a.idx_last, a.idx_next = p(idx_last), p(idx_next)
             a.g_ori_last, a.g_ori_next, a.g_img_last, a.g_img_next = p(g_last[b]), p(g_next[b]), p(gl[b]), p(gn[b])
-            if inplace:
+            if snap_l is not None:
+                a.g_ori_last, a.g_ori_next, a.region_only = p(snap_l[b]), p(snap_n[b]), 1
+            elif inplace:
                 a.g_tmp_last, a.g_tmp_next = p(tmp_l[b]), p(tmp_n[b])
         L.check(lib.mal_dyn_batch_bwd(arr, len(ctx.saved), C, H, W, ops._stream()), "mal_dyn_batch_bwd")
         return gl, gn, None, None, None

@@ -159,7 +159,7 @@ class TemporalLossStepFn(Function):
             local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1], ("color_pair", 0): pair,
                      ("syn_prefilled", 0): (pre[0], pre[1])}
             has_ins = bool(synth(inputs, local, 0))
-        region = None
+        region = snap = None
         if has_ins:
             syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
             syn_data = [ops._req(s.detach(), "syn") for s in syn]
@@ -168,6 +168,10 @@ class TemporalLossStepFn(Function):
                 if not (region.is_cuda and region.dtype == torch.uint8 and tuple(region.shape) == (B, H, W) and region.is_contiguous()):
                     raise L.MalError("loss_step: ('syn_region', 0) must be a contiguous (B,H,W) uint8 device tensor")
                 a.syn_region = region.data_ptr()
+                # ... and with the map the sweep leaves a second copy of d/d syn at the touched pixels: what the
+                # producer's in-place backward gathers from
+                snap = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+                a.g_syn_region_m1, a.g_syn_region_p1 = snap[0].data_ptr(), snap[1].data_ptr()
         else:  # no matched instance anywhere: syn == warp ties with it and never wins (first minimum), as if absent
             syn, syn_data = None, warp
         # the cotangents of syn: this node's own buffers, which the producer's backward may turn into its result in place
@@ -177,7 +181,7 @@ class TemporalLossStepFn(Function):
         L.check(lib.mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
         ctx.args, ctx.keep = a, keep
         ctx.graph = (leaf, syn, syn_data, g_syn, warp)
-        ctx.region = region  # the C struct holds its pointer
+        ctx.region, ctx.snap = region, snap  # the C struct holds their pointers
         ctx.set_materialize_grads(False)
         expose[("color", -1, 0)], expose[("color", 1, 0)] = warp
         if has_ins:
@@ -197,12 +201,14 @@ class TemporalLossStepFn(Function):
             g_warp = g_syn  # the identity producer
         else:
             from . import dyn_utils
-            ptrs = {g.data_ptr() for g in g_syn}
-            dyn_utils.INPLACE_COTANGENTS |= ptrs  # mal_amd.dyn_utils.image_synthesis turns them into its result in place
+            # mal_amd.dyn_utils.image_synthesis turns the cotangent buffers into its result in place
+            reg = {g.data_ptr(): (ctx.snap[i] if ctx.snap is not None else None) for i, g in enumerate(g_syn)}
+            dyn_utils.INPLACE_COTANGENTS.update(reg)
             try:
                 g_warp = torch.autograd.grad(syn, leaf, g_syn, allow_unused=True)
             finally:
-                dyn_utils.INPLACE_COTANGENTS -= ptrs
+                for k in reg:
+                    dyn_utils.INPLACE_COTANGENTS.pop(k, None)
             g_warp = [torch.zeros_like(w) if g is None else g.contiguous() for g, w in zip(g_warp, warp)]
         a = ctx.args
         a.g_warp_m1, a.g_warp_p1 = g_warp[0].data_ptr(), g_warp[1].data_ptr()

@@ -161,15 +161,21 @@ def test_prefilled_and_in_place_equal_the_plain_node(shape, listed):
     pl, pn, region2 = dyn_utils.BatchSynthesisFn.apply(b_l, b_n, items, False, pre)
     assert pl.data_ptr() == pre[0].data_ptr() and pn.data_ptr() == pre[1].data_ptr()
     assert torch.equal(pl, sl) and torch.equal(pn, sn) and torch.equal(region2, region)
-    ct = [wl.clone(), wn.clone()]
-    ptrs = {t.data_ptr() for t in ct}
-    dyn_utils.INPLACE_COTANGENTS |= ptrs
-    try:
-        hl, hn = torch.autograd.grad([pl, pn], [b_l, b_n], ct)
-    finally:
-        dyn_utils.INPLACE_COTANGENTS -= ptrs
-    assert hl.data_ptr() == ct[0].data_ptr() and hn.data_ptr() == ct[1].data_ptr()  # really in place
-    assert torch.equal(hl, gl) and torch.equal(hn, gn)
+    for snapshots in (False, True):
+        ct = [wl.clone(), wn.clone()]
+        reg = {t.data_ptr(): None for t in ct}
+        if snapshots:  # a second copy of the cotangent that is valid at region pixels only (NaN elsewhere: never read)
+            rg = (region & 1).bool()[:, None].expand(B, 3, H, W)
+            snap = [torch.where(rg, t, torch.full_like(t, float("nan"))) for t in ct]
+            reg = {t.data_ptr(): s_ for t, s_ in zip(ct, snap)}
+        dyn_utils.INPLACE_COTANGENTS.update(reg)
+        try:
+            hl, hn = torch.autograd.grad([pl, pn], [b_l, b_n], ct, retain_graph=True)
+        finally:
+            for k in reg:
+                dyn_utils.INPLACE_COTANGENTS.pop(k, None)
+        assert hl.data_ptr() == ct[0].data_ptr() and hn.data_ptr() == ct[1].data_ptr()  # really in place
+        assert torch.equal(hl, gl) and torch.equal(hn, gn), snapshots
     # the region map: bit 0 = some instance's mask (either frame) holds the pixel; zero for samples not listed
     for b in range(B):
         want = torch.zeros(H, W, dtype=torch.bool, device=DEV)
