@@ -41,6 +41,10 @@ struct MarchParams {
   // gradient that reaches the warped images through syn (dyn_utils.py:145-146,163-164), g_color[f] planar (B,3,H,W),
   // joins d loss / d warped colour before the chain rule through the warp
   const float* forced_w; const unsigned char* forced_arg; const float* g_color[2];
+  // ... and, running in the backward call where the loss scalars exist already, it finishes the teacher's disparity
+  // gradient itself instead of leaving the unnormalised map to the assembly kernel (fin_out nullable):
+  //   fin_out = coefs[0] g_total * G + coefs[4] g_total * (fin_gn / (mean_b + 1e-7) - corr_b),  mean / corr in fin_stats
+  const float* fin_gn; const float* fin_coefs; const double* fin_stats; const float* fin_g_total; float* fin_out;
   // Parity instrumentation (tests only; DBG instantiations of the gradient passes): the per-pixel DECISIONS the pass
   // took, as kDecPlanes uint32 planes of B*H*W each (include/mal_hip.h, MAL_DEC_*).  nullptr = the production kernels.
   unsigned* dbg;

@@ -343,6 +343,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   struct Maps {
     const float *ident, *noise, *ext_mask, *lowest_cost, *mono_disp, *mono_depth, *mono_reproj, *ens_reproj, *target; int packed;
     const float* forced_w; const unsigned char* forced_arg; const float* gcol[2];  // TEMPORAL
+    const float* fin_gn;                                                             // TEMPORAL
   };
   auto maps_of = [&](CParams& pp) {
     Maps m;
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     m.ens_reproj = EPI ? pp.ens_reproj : nullptr; m.target = pp.target; m.packed = pp.packed;
     m.forced_w = TEMPORAL ? pp.forced_w : nullptr; m.forced_arg = TEMPORAL ? pp.forced_arg : nullptr;
     m.gcol[0] = TEMPORAL ? pp.g_color[0] : nullptr; m.gcol[1] = TEMPORAL ? pp.g_color[1] : nullptr;
+    m.fin_gn = TEMPORAL ? pp.fin_gn : nullptr;
     return m;
   };
   auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
@@ -395,9 +397,17 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       a.e_mr = ldf(pp.mono_reproj, oq);
       a.e_er = opt(pp.ens_reproj, oq, 0.f);
     }
+    if (TEMPORAL) a.e_mono = opt(pp.fin_gn, oq, 0.f);  // the smoothness gradient of the gradient row (fin_out)
   };
   Ahead nxt;
   request(maps_of(p), r_first, nxt);
+  float fin_cR = 0.f, fin_cS = 0.f, fin_inv = 0.f, fin_corr = 0.f;
+  if (TEMPORAL && p.fin_out) {
+    const float gg = p.fin_g_total ? *p.fin_g_total : 1.0f;
+    fin_cR = p.fin_coefs[0] * gg; fin_cS = p.fin_coefs[4] * gg;
+    fin_inv = div_(1.0f, (float)p.fin_stats[b] + 1e-7f);
+    fin_corr = (float)p.fin_stats[2 * p.B + b];
+  }
   // reciprocals of the grid normalisation's divisors, once per wave (scalar registers)
   const float norm_rw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
       int, refined_rcp(p.convention == 0 ? (float)(W - 1) : (float)W))));
@@ -738,7 +748,10 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
           const f2 ts = (t0 + t1) + t2;
           gdisp = ts.x + ts.y;
         }
-        if (out_x) stf(p.g_reproj, so_q, gdisp);
+        if (out_x) {
+          if (TEMPORAL && p.fin_out) stf(p.fin_out, so_q, fma_(fin_cR, gdisp, fin_cS * (le_mono * fin_inv - fin_corr)));
+          else stf(p.g_reproj, so_q, gdisp);
+        }
       }
       // roll the partial-plane sums: (row c: top+mid) <- (row c: top) + hc(c) ; (row c+1: top) <- hc(c)
       {

@@ -468,6 +468,7 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   StepWs w = carve_step(a->ws, B, H, W);
   hipStream_t st = (hipStream_t)a->stream;
   int per_sample_t = 0;
+  bool teacher_done = false;
   if (a->flags & MAL_STEP_TEMPORAL) {
     // the teacher's gradient sweep, with the decisions of the four-way min taken from _fwd and the gradient that
     // reaches the warped images through syn added before the chain rule through the warp
@@ -476,6 +477,9 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
     p.g_reproj = w.G_r_t; p.block_sums = w.bs_t;
     p.ident = w.ident;  // unused by the TEMPORAL instantiation (the launch checks the flag combination only)
     p.forced_w = w.w_t; p.forced_arg = w.arg_t; p.g_color[0] = a->g_warp_m1; p.g_color[1] = a->g_warp_p1;
+    // the loss scalars exist already: the sweep writes d total / d disp_teacher itself (the assembly does the student's)
+    p.fin_gn = w.gn_t; p.fin_coefs = w.coefs; p.fin_stats = w.sm_stats; p.fin_g_total = a->g_total; p.fin_out = a->g_disp_teacher;
+    teacher_done = a->g_disp_teacher != nullptr;
     p.dbg = a->dec_teacher;
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
     if (rc) return rc;
@@ -495,7 +499,8 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   const int pose_bwd = (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) ? 1 : 0;
   hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.gn_t,
                      w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
-                     a->g_disp_teacher, a->g_disp_student, pp, pose_bwd, per_sample_t ? w.bgP : nullptr, a->K, per_sample_t);
+                     teacher_done ? nullptr : a->g_disp_teacher, a->g_disp_student, pp, pose_bwd, per_sample_t ? w.bgP : nullptr,
+                     a->K, per_sample_t);
   rc = launch_status();
   return rc;
 }
