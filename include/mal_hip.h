@@ -498,6 +498,9 @@ int mal_direct_align_update_bwd(const float* H, const float* b, const float* pos
  *               0 = one pixel per thread (ATen's summation order; always used for MAL_F_NO_SSIM / MAL_F_AVG);
  * "epi_bwd_planes" 1 (default): the feature-map cotangents of the N4 VJPs are accumulated per (sample, channel) plane in
  *               LDS when the planes fit; 0: global float atomics everywhere (the first formulation, kept for A/B);
+ * "step_overlap" 1 (default): with MAL_STEP_TEMPORAL the ensemble pass runs on a side stream beside the producer (forked
+ *               after the warp pass, joined before the student pass; events, capturable); 0: in line; 2: beside the
+ *               fused sweep (slower: kept for A/B);  "syn_rows": rows per task of the fused sweep given a region map;
  * "fwd_waves", "debug": kernel experiments. */
 int mal_set_option(const char* name, int value);
 

@@ -1026,6 +1026,7 @@ unsigned* g_dec_next = nullptr;  // mal_decisions_next_pass: decision planes for
 extern int g_photo_impl;  // mal_photo_march.hip
 extern int g_epi_bwd_planes;  // mal_epipolar.hip
 extern int g_syn_rows;        // mal_photo_march.hip
+extern int g_step_overlap;    // mal_step.hip
 
 MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, float eps, int convention) {
   MarchParams p = {};
@@ -1142,6 +1143,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("debug")) { g_debug = value; return MAL_OK; }
   if (eq("photo_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_photo_impl = value; return MAL_OK; }
   if (eq("costvol_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_costvol_impl = value; return MAL_OK; }
+  if (eq("step_overlap")) { if (value < 0 || value > 2) return MAL_EINVAL; g_step_overlap = value; return MAL_OK; }
   if (eq("syn_rows")) { if (value < 2 || value > 64) return MAL_EINVAL; g_syn_rows = value; return MAL_OK; }
   if (eq("epi_bwd_planes")) { g_epi_bwd_planes = value != 0; return MAL_OK; }
   if (eq("march_flip")) { g_march_flip = value != 0; return MAL_OK; }

@@ -36,6 +36,7 @@ struct StepWs {
   float* ident; float* mono_reproj; float* ens_reproj;
   float* G_r_t; float* G_r_s; float* G_c; float* gn_t; float* gn_s;
   double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
+  float* bgP_e;       // the ensemble pass's own (unused) pose-partial sink: it may run beside other launches
   double* bs_p;       // per-task smoothness partials of the first launch: [task][map][4]
   // temporal hint: winner of the four-way min (0/1 warped, 2/3 syn) and automask weight of the teacher, the
   // materialised-candidate kernel's per-task partials [task][2], what the step remembers between its calls
@@ -62,6 +63,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   for (auto m : maps) *m = (float*)take(map);
   w.bs_t = (double*)take(nb * 8 * 8); w.bs_s = (double*)take(nb * 8 * 8); w.bs_e = (double*)take(nb * 8 * 8);
   w.bgP = (float*)take(nb * 24 * 4);
+  w.bgP_e = (float*)take(nb * 24 * 4);
   w.bs_p = (double*)take(nb * 8 * 8);
   w.arg_t = (unsigned char*)take((size_t)B * HW);
   w.w_t = (float*)take(map);
@@ -367,6 +369,46 @@ static MarchParams teacher_params(const mal_step_args* a, const StepWs& w, float
   return p;
 }
 
+// the ensemble pass (no gradient): the averaged disparity is formed inside the kernel (trainer.py:594-600)
+static int launch_ensemble(const mal_step_args* a, const StepWs& w, float* ens_reproj, hipStream_t st) {
+  MarchParams p = march_params(a->B, a->H, a->W, a->min_depth, a->max_depth, 1e-7f, 0);
+  p.disp = a->disp_teacher; p.disp2 = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+  p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+  p.min_reproj = ens_reproj; p.block_sums = w.bs_e; p.block_gP = w.bgP_e;
+  p.cam = w.cam; p.cam_ready = 1;
+  return march_launch(p, MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+}
+
+// Temporal hint: between the warp pass and the fused sweep the device runs the producer's small, latency-bound kernels
+// (and whatever the segmenter does) -- the ensemble pass depends on none of it.  It is forked onto a side stream AFTER the
+// warp pass (beside it, two ALU-bound passes only slow each other down: measured) and joined before the student pass,
+// which reads its map.  Fork / join through events: capturable into the caller's HIP graph.
+namespace mal { int g_step_overlap = 1; }  // option "step_overlap"
+struct SideStream { hipStream_t s; hipEvent_t fork, join; bool ok; };
+static SideStream* side_stream() {
+  static SideStream ss = {};
+  static bool init = false;
+  if (!init) {
+    init = true;
+    ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+    (void)hipGetLastError();
+  }
+  return ss.ok ? &ss : nullptr;
+}
+static bool ensemble_forked(const mal_step_args* a) {
+  return g_step_overlap && (a->flags & MAL_STEP_TEMPORAL) && !(a->flags & MAL_STEP_NO_ENS) && side_stream() != nullptr;
+}
+
+static int fork_ensemble(const mal_step_args* a, const StepWs& w, hipStream_t st) {
+  SideStream* ss = side_stream();
+  if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return MAL_ELAUNCH;
+  int rc = launch_ensemble(a, w, a->ens_reproj ? a->ens_reproj : w.ens_reproj, ss->s);
+  if (rc) return rc;
+  return hipEventRecord(ss->join, ss->s) == hipSuccess ? MAL_OK : MAL_ELAUNCH;
+}
+
 // MAL_STEP_TEMPORAL, first call: the first sweep and the teacher's warped images (forward only: the per-pixel min over
 // the two warped candidates and its winner stay in the workspace for mal_loss_step_fwd)
 extern "C" int mal_loss_step_warp(const mal_step_args* a) {
@@ -384,7 +426,13 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   p.color_out_stride = a->warp_sample_stride;
   p.color_out2[0] = a->warp2_m1; p.color_out2[1] = a->warp2_p1;
   if ((a->warp2_m1 == nullptr) != (a->warp2_p1 == nullptr)) return MAL_EINVAL;
-  return march_launch(p, MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+  rc = march_launch(p, MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+  if (rc) return rc;
+  if (ensemble_forked(a) && g_step_overlap == 1) {
+    rc = fork_ensemble(a, w, st);
+    if (rc) return rc;
+  }
+  return MAL_OK;
 }
 
 extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
@@ -417,21 +465,24 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     // loss_utils.py:79-90,103), the automask and the teacher's sums are formed over all four, and the gradient w.r.t.
     // the synthesised images leaves unnormalised
     if (!a->syn_m1 || !a->syn_p1 || !a->g_syn_m1 || !a->g_syn_p1) return MAL_EINVAL;
+    if (ensemble_forked(a) && g_step_overlap == 2) {
+      rc = fork_ensemble(a, w, st);
+      if (rc) return rc;
+    }
     per_sample_p = pack_identity_tasks_per_sample(H, W);
     rc = photo_march_fused_more(a->color0, a->syn_m1, a->syn_p1, 2, w.ident, a->noise, w.rp_warp, w.arg_warp, B, H, W,
                                 mono_reproj, w.arg_t, w.w_t, w.bs_ph, a->g_syn_m1, a->g_syn_p1, &per_sample_ph, st, a->syn_region,
                                 a->g_syn_region_m1, a->g_syn_region_p1);
     if (rc) return rc;
   }
-  // ensemble pass (no gradient)
+  // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp
   if (!no_ens) {
-    MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
-    p.disp = a->disp_teacher; p.disp2 = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
-    p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
-    p.min_reproj = ens_reproj; p.block_sums = w.bs_e; p.block_gP = w.bgP;
-    p.cam = w.cam; p.cam_ready = 1;
-    rc = march_launch(p, packed, st);
-    if (rc) return rc;
+    if (ensemble_forked(a)) {
+      if (hipStreamWaitEvent(st, side_stream()->join, 0) != hipSuccess) return MAL_ELAUNCH;
+    } else {
+      rc = launch_ensemble(a, w, ens_reproj, st);
+      if (rc) return rc;
+    }
   }
   // student pass with the consistency / distillation epilogue
   {
