@@ -191,11 +191,11 @@ def test_temporal_hint_decision_exact(tag):
             assert _l2rel(g, r.reshape(g.shape)) <= 1e-4, (key, _l2rel(g, r.reshape(g.shape)))
 
 
-def test_temporal_at_baseline_size():
-    """--temporal --distil at B=12 192x640 (BASELINE.json configs[1] as written), rectangles standing in for the
-    instance patches as in the golden vectors"""
+@pytest.mark.parametrize("B,H,W", [(12, 192, 640), (12, 192, 512)], ids=["kitti_b12_192x640", "cityscapes_b12_192x512"])
+def test_temporal_at_baseline_size(B, H, W):
+    """--temporal --distil at B=12 192x640 (BASELINE.json configs[1] as written) and at CityScapes' 192x512 (configs[3]),
+    rectangles standing in for the instance patches as in the golden vectors"""
     from mal_amd.synthetic import make_batch
-    B, H, W = 12, 192, 640
     b = make_batch(B, H, W, seed=78, with_syn=True)
     g = torch.Generator().manual_seed(6)
     n0, n1 = torch.randn(B, 1, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
