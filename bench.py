@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a HIP graph (default); 0: eager launches")
-    ap.add_argument("--mode", choices=["step", "distil", "ops", "temporal", "train", "multiscale", "multiscale_ops"], default="step",
+    ap.add_argument("--mode", choices=["step", "distil", "ops", "temporal", "train", "multiscale", "multiscale_ops", "dualrefine"], default="step",
                     help="step: --temporal --distil through mal_loss_step (BASELINE configs[1], the headline: three library "
                          "calls around the temporal-hint producer); distil: --distil only (one C call per direction); "
                          "ops: the operator-level API; "
@@ -58,7 +58,9 @@ def parse():
                          "of the harness (RepDepth networks + loss step + flat-bucket all-reduce + Adam, eager); "
                          "multiscale: the non-distil compute_losses with sclm=3 (four disparity scales, "
                          "manydepth/trainer.py:1248-1475) for both networks through mal_loss_multiscale (one C call per "
-                         "direction); multiscale_ops: the same through the operator-level API")
+                         "direction); multiscale_ops: the same through the operator-level API; dualrefine: BASELINE configs[4], "
+                         "DualRefine's loss loops over (scale 0, deq_iter 0..1) at B=8 (dualrefine/trainer.py:395-451,530-633) "
+                         "through DualRefineLossPath")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mal_set_option before the run (kernel experiments, e.g. march_rows=16)")
@@ -135,7 +137,8 @@ class Step:
         self.layers = layers
         from mal_amd import ops
         self.ops = ops
-        b = make_batch(B, H, W, seed=seed)
+        self.B = 8 if mode == "dualrefine" else B  # BASELINE configs[4] is quoted at B=8
+        b = make_batch(self.B, H, W, seed=seed)
         mv = lambda t: t.to(dev).contiguous()
         self.inputs = {("color", 0, 0): mv(b["color0"]), ("color", -1, 0): mv(b["color_m1"]),
                        ("color", 1, 0): mv(b["color_p1"]), ("K", 0): mv(b["K"]), ("inv_K", 0): mv(b["inv_K"])}
@@ -154,6 +157,11 @@ class Step:
             self.synth = synth
             self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, temporal=True), fuse=True,
                                        image_synthesis=synth)
+        elif mode == "dualrefine":
+            from mal_amd import dualrefine
+            self.lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=self.B, n_losses=1),
+                                                    fuse=True)
+            self.cmask4 = self.cmask.unsqueeze(1)
         elif mode in ("multiscale", "multiscale_ops"):
             # --scales 0..3 semantics (sclm=3): per-scale disparities upsampled to full resolution, loss
             # / 2**scale, total / (sclm+1); the shipped decoder only feeds scale 0, so the lower scales are pooled copies
@@ -198,6 +206,13 @@ class Step:
         self.ops.clear_packed_sources()  # a real step sees new images: repack them every step
         T_m1 = L.transformation_from_parameters(lv["axisangle_m1"], lv["translation_m1"], True)
         T_p1 = L.transformation_from_parameters(lv["axisangle_p1"], lv["translation_p1"], False)
+        if self.mode == "dualrefine":  # 4-tuple keys: ("disp", 0, deq_iter); iteration 1 refines pose -1
+            outputs = {("disp", 0, 0): lv["disp_teacher"], ("disp", 0, 1): lv["disp_student"], ("cam_T_cam", 0, -1): T_m1,
+                       ("cam_T_cam", 0, 1): T_p1, ("cam_T_cam", 0, -1, 1): T_m1 * 1.0, "consistency_mask": self.cmask4}
+            self.lp.generate_images_pred(self.inputs, outputs)
+            losses = self.lp.compute_losses(self.inputs, outputs)
+            losses["loss"].backward()
+            return losses["loss"]
         mono_outputs = {("disp", 0): lv["disp_teacher"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1}
         outputs = {("disp", 0): lv["disp_student"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1,
                    "consistency_mask": self.cmask, "augmentation_mask": self.aug, "lowest_cost": self.lowest}
@@ -508,7 +523,7 @@ def main():
     n_px = B * H * W
     out = {
         "metric": "train images/sec at B=12 192x640 KITTI-shaped (MAL loss path: passes A+B+C fwd+bwd)",
-        "value": n_ranks * B * args.steps / dt, "unit": "images/s", "n_gpus": n_ranks, "steps": args.steps,
+        "value": n_ranks * getattr(step, "B", B) * args.steps / dt, "unit": "images/s", "n_gpus": n_ranks, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("ManyDepth+MAL loss step, B=12 per GPU, 192x640, --temporal --distil (teacher pass with the two "
@@ -571,6 +586,12 @@ def main():
         out["config"]["parallelism"] = "dp%d (one RCCL all-reduce of the flat gradient bucket per step)" % n_ranks
         out["config"]["api"] = "mal_amd.harness.TrainHarness.train_step"
         out["breakdown_ms"] = step.breakdown_ms()
+    elif args.mode == "dualrefine":
+        out["config"]["workload"] = ("DualRefine+MAL loss loops, B=8 per GPU, 192x640 (BASELINE configs[4]): generate_images_pred + "
+                                     "compute_losses over (scale 0, deq_iter 0..1), convention B warps (align_corners=False), fwd+bwd "
+                                     "to disp/pose leaves; networks not included")
+        out["config"]["global_batch"] = getattr(step, "B", B) * n_ranks
+        out["metric"] = "train images/sec at B=8 192x640 KITTI-shaped (DualRefine+MAL loss loops, fwd+bwd)"
     elif args.mode not in ("step", "distil"):
         out["config"]["workload"] += " [mode %s]" % args.mode
     if train_block is not None:

@@ -10,6 +10,7 @@ cd $R
 python bench.py --mode ops --no-cpu-baseline > $O/ops_bench.json 2> $O/ops.err || exit 1
 python bench.py --mode temporal --no-cpu-baseline > $O/temporal_bench.json 2> $O/temporal.err || exit 1
 python bench.py --mode multiscale_ops --no-cpu-baseline --train-steps 0 > $O/multiscale_ops_bench.json 2> $O/multiscale_ops.err || exit 1
+python bench.py --mode dualrefine --no-cpu-baseline --train-steps 0 > $O/dualrefine_bench.json 2> $O/dualrefine.err || exit 1
 python bench.py --mode train --steps 20 --warmup 5 > $O/train_bench.json 2> $O/train.err || exit 1
 python scripts/bench_costvol.py > $O/costvol.txt 2>&1 || exit 1
 python scripts/bench_dyn.py > $O/dyn.txt 2>&1 || exit 1
