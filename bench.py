@@ -61,6 +61,8 @@ def parse():
                          "direction); multiscale_ops: the same through the operator-level API; dualrefine: BASELINE configs[4], "
                          "DualRefine's loss loops over (scale 0, deq_iter 0..1) at B=8 (dualrefine/trainer.py:395-451,530-633) "
                          "through DualRefineLossPath")
+    ap.add_argument("--width", type=int, default=640, help="image width: 640 (KITTI, the headline) or 512 (CityScapes, "
+                                                            "BASELINE configs[3]); the metric string follows it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mal_set_option before the run (kernel experiments, e.g. march_rows=16)")
@@ -296,6 +298,8 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args)  # does not return
+    global W
+    W = args.width
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -598,6 +602,15 @@ def main():
         out["train_step"] = train_block
     if n_ranks == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(batch_cpu, args.cpu_steps)
+    if W != 640:  # --width: the strings above are written for the headline size
+        def resize(o):
+            if isinstance(o, str):
+                return o.replace("192x640", "192x%d" % W).replace("KITTI-shaped", "CityScapes-shaped" if W == 512 else "KITTI-shaped")
+            if isinstance(o, dict):
+                return {k: resize(v) for k, v in o.items()}
+            return o
+        out = resize(out)
+        out["config"]["width"] = W
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
