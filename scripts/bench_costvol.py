@@ -30,7 +30,7 @@ tc = time.perf_counter() - t
 
 # What bounds these gather kernels is the vector-memory address path, not HBM: scripts/vmem_probe.hip measures, per CU,
 # 5.4 cycles per dword wave-load whose 64 lanes fall in one 128-byte line (chip: 102 G wave-loads/s), 16 cycles over 2-4
-# lines (37.5 G/s), 32 over 8 (18.8 G/s), 64 over 16 or more (9.5 G/s) -- all L1 hits (gpurun_out/vmem_probe.txt).
+# lines (37.5 G/s), 32 over 8 (18.8 G/s), 64 over 16 or more (9.5 G/s) -- all L1 hits (profiles/r02_vmem_probe.txt).
 WAVE_LOAD_CEILING = {1: 102.0e9, 4: 37.5e9, 8: 18.8e9, 16: 9.5e9}
 wave_loads = B * h * w * D * C * 4 / 64.0  # four taps per (pixel, bin, channel), 64 pixels per wave
 # algorithmic traffic: read both feature maps once, write the volume + masks
