@@ -67,8 +67,8 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mal_set_option before the run (kernel experiments, e.g. march_rows=16)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU-oracle steps (median), after 3 warm-ups")
-    ap.add_argument("--train-steps", type=int, default=5,
-                    help="steps of the whole training step timed for the `train_step` block (0 = leave it out)")
+    ap.add_argument("--train-steps", type=int, default=20,
+                    help="steps of the whole training step timed for the `train_step` block after 3 warm-ups (0 = leave it out)")
     return ap.parse_args()
 
 
@@ -103,8 +103,14 @@ class TrainStep:
         config.noise_source = "cuda"
         random.seed(seed)
         torch.manual_seed(seed)
-        self.opt = harness.default_options(batch_size=B, height=H, width=W)
-        self.h = harness.TrainHarness(self.opt, dev)
+        # BASELINE configs[1] as written: --temporal --distil; the temporal hint's two external models (Mask2Former, the
+        # Hungarian matcher: out of scope) are the same stand-ins the headline step uses, three instances per sample
+        from mal_amd import dyn_utils
+        from mal_amd.synthetic import instance_stub
+        self.opt = harness.default_options(batch_size=B, height=H, width=W, temporal=True)
+        ins_model, matcher = instance_stub(B, H, W, n_inst=3, seed=seed, device=dev)
+        synth = lambda inputs, outputs, scale: dyn_utils.image_synthesis(inputs, outputs, scale, 0.5, ins_model, matcher)
+        self.h = harness.TrainHarness(self.opt, dev, image_synthesis=synth)
         self.inputs = harness.synthetic_inputs(self.opt, dev, seed=seed)
         self.batch_cpu = None
 
@@ -253,6 +259,53 @@ def measured_copy_ceiling(dev, mib=1024, reps=5):
     return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def shader_clock_mhz(lib, dev):
+    """sustained shader clock with two packed-FMA wavefronts on every SIMD (mal_clock_probe: s_memtime ticks over the
+    constant 100 MHz counter), after ~1 ms of the same load"""
+    out = torch.zeros(3, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(10):
+        if lib.mal_clock_probe(out.data_ptr(), 400, st) != 0:
+            return None
+    torch.cuda.synchronize()
+    t, r = int(out[0].item()), int(out[1].item())
+    return 100.0 * t / r if r > 0 else None
+
+
+def valu_bound(lib, dev, kernel_ms, hbm_frac):
+    """What actually bounds the north-star kernel: its row loop priced by instruction class from the
+    compiler's listing of the shipped sources (mal_amd.build.valu_report -> mal_amd/lib/valu_cost.json; per-class
+    cycles measured by scripts/valu_probe.hip), times the row-loop iterations of all tasks, over the chip's SIMDs at the
+    clock measured in this run = the time the vector ALUs alone need; `valu_frac` = that / the measured kernel time."""
+    try:
+        from mal_amd import build, _lib
+        rep = build.valu_report()
+        k = rep["kernels"]["teacher"]
+        g = [ctypes.c_int(0) for _ in range(4)]
+        flags = _lib.F_GRAD | _lib.F_AUTOMASK | _lib.F_POSE_GRAD
+        _lib.check(lib.mal_march_geometry(B, H, W, flags, *[ctypes.byref(x) for x in g]), "mal_march_geometry")
+        strips, segs, rows, iters = (x.value for x in g)
+        tasks = B * strips * segs
+        simds = torch.cuda.get_device_properties(dev).multi_processor_count * 4
+        mhz = shader_clock_mhz(lib, dev)
+        if not mhz or kernel_ms <= 0:
+            return {"valu": {"error": "no clock / kernel time"}}
+        cycles = k["pipe_cycles"] * iters * tasks / simds
+        valu_us = cycles / mhz
+        frac = valu_us / (kernel_ms * 1e3)
+        return {"bound": "valu" if frac > hbm_frac else "hbm",
+                "valu": {"valu_frac": frac, "valu_us": valu_us, "pipe_cycles_per_row": k["pipe_cycles"],
+                         "valu_instructions_per_row": k["valu_instructions"], "classes": k["classes"],
+                         "row_iterations_per_task": iters, "rows_per_task": rows, "tasks": tasks, "simds": simds,
+                         "shader_clock_mhz": mhz,
+                         "how": "pipe_cycles_per_row x row_iterations_per_task x tasks / simds / clock; classes from the "
+                                "compiler's listing of the shipped kernel (mal_amd/lib/valu_cost.json, digest %s), cycle "
+                                "prices from scripts/valu_probe.hip (profiles/r02_valu_probe.txt); an upper estimate: the "
+                                "first and last iterations of a task skip the gradient / statistics stages" % rep["digest"][:12]}}
+    except Exception as ex:  # the line survives; the block says why it is missing
+        return {"valu": {"error": "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:200])}}
+
+
 def cpu_baseline(batch, steps):
     """The CPU oracle (oracle/mal_oracle.py, PyTorch-CPU ATen ops in the reference's order)
     on the same workload: B=12 192x640, passes A+B+C forward+backward.  SURVEY.md 8d: median of `steps` (10) runs after
@@ -335,6 +388,7 @@ def main():
     else:
         step = Step(dev, 1234 + rank, args.mode)
     batch_cpu = step.batch_cpu
+    step_B = getattr(step, "B", B)  # images per rank and step (read here: the train_step block below frees `step`)
 
     def sync():
         # poll an event first: a blocking synchronize wakes the host up to ~0.1 ms late, which a short timed region
@@ -411,6 +465,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         n_ranks = dist.get_world_size()  # the ranks the collective actually saw
+
+    # the same step as eager launches (what a trainer whose producer cannot be captured into a graph would see: the
+    # real producer calls two external models with a data-dependent number of instances between the library calls)
+    eager_ms = None
+    if graph is not None:
+        n_e = max(args.steps, 50)
+        for _ in range(5):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(n_e):
+            step()
+            if bucket is not None:
+                bucket.all_reduce_mean()
+        sync()
+        eager_ms = 1e3 * (time.perf_counter() - t1) / n_e
 
     # stages of the step, device time (HIP events on the current stream), outside the timed region
     breakdown = None
@@ -497,11 +567,9 @@ def main():
     # the whole training step (all ranks take part: its all-reduce is a collective)
     train_block = None
     if args.mode != "train" and args.train_steps > 0:
-        try:
-            del step, graph
-            torch.cuda.empty_cache()
+        def train_side_block():
             ts = TrainStep(dev, 1234 + rank)
-            for _ in range(2):
+            for _ in range(3):
                 ts()
             sync()
             t1 = time.perf_counter()
@@ -513,12 +581,22 @@ def main():
                 t = torch.tensor([dtt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dtt = float(t.item())
-            train_block = {"value": n_ranks * B * args.train_steps / dtt, "unit": "images/s", "ms_per_step": 1e3 * dtt / args.train_steps,
-                           "steps": args.train_steps, "breakdown_ms": ts.breakdown_ms(3),
-                           "what": "RepDepth (ResNet-18 x3 + decoders + pose + cost volume; fp32 torch.nn/MIOpen, random init) forward+backward, "
-                                   "this loss path, one flat-bucket gradient all-reduce, Adam; B=12 per GPU"}
-        except Exception as ex:  # the headline line must survive a failure of the side block
-            train_block = {"error": "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:200])}
+            return {"value": n_ranks * B * args.train_steps / dtt, "unit": "images/s", "ms_per_step": 1e3 * dtt / args.train_steps,
+                    "steps": args.train_steps, "warmup": 3, "n_gpus": n_ranks, "breakdown_ms": ts.breakdown_ms(3),
+                    "exchange": ts.h.exchange_note(),
+                    "what": "RepDepth (ResNet-18 x3 + decoders + pose + cost volume; fp32 torch.nn/MIOpen, random init) forward+backward, "
+                            "this loss path (--temporal --distil, the producer's external models stubbed), the flat-bucket gradient "
+                            "all-reduce launched from inside the backward, Adam; B=12 per GPU"}
+
+        del step, graph, one_pass
+        torch.cuda.empty_cache()
+        if dist is not None:
+            train_block = train_side_block()  # N>1: a failing collective must fail the run
+        else:
+            try:
+                train_block = train_side_block()
+            except Exception as ex:  # N=1: the headline line survives a failure of the side block, and says so
+                train_block = {"error": "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:200])}
 
     if rank != 0:
         if dist is not None:
@@ -527,7 +605,7 @@ def main():
     n_px = B * H * W
     out = {
         "metric": "train images/sec at B=12 192x640 KITTI-shaped (MAL loss path: passes A+B+C fwd+bwd)",
-        "value": n_ranks * getattr(step, "B", B) * args.steps / dt, "unit": "images/s", "n_gpus": n_ranks, "steps": args.steps,
+        "value": n_ranks * step_B * args.steps / dt, "unit": "images/s", "n_gpus": n_ranks, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("ManyDepth+MAL loss step, B=12 per GPU, 192x640, --temporal --distil (teacher pass with the two "
@@ -549,6 +627,13 @@ def main():
                            "multiscale": "mal_loss_multiscale_fwd/_bwd (one host call per direction)"}.get(
                                args.mode, "operator-level (mal_amd.loss_utils / MALLossPath)")},
     }
+    if eager_ms is not None:
+        out["eager_ms_per_step"] = eager_ms
+        out["eager_value"] = n_ranks * step_B / (eager_ms * 1e-3)
+    if n_ranks > 1:
+        # the loss path alone cannot amortise the trainer's 165 MB exchange: the curve over N that the
+        # >= 6x target is about is the whole training step's
+        out["scaling_metric"] = "train_step"
     if breakdown is not None:
         out["breakdown_ms"] = breakdown
     if overlapped is not None:
@@ -573,6 +658,7 @@ def main():
                            "alg_bytes_per_px": ALG_BYTES_PER_PX, "pixels_per_launch": n_px,
                            "kernel_ms": kern_ms_plain, "launches_timed": 20 if args.mode == "step" else len(durs),
                            "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None}
+        out["roofline"].update(valu_bound(lib, dev, kern_ms_plain, achieved / HBM_PEAK_GBS))
     if args.mode == "step" and kern_ms > 0:
         # the same sweep as the headline step runs it: decisions of the four-way min taken from the materialised-candidate
         # kernels, + 24 B/px of d loss / d warped colour arriving through syn (SURVEY.md 8d counts +24 B/px backward)
@@ -590,11 +676,12 @@ def main():
         out["config"]["parallelism"] = "dp%d (one RCCL all-reduce of the flat gradient bucket per step)" % n_ranks
         out["config"]["api"] = "mal_amd.harness.TrainHarness.train_step"
         out["breakdown_ms"] = step.breakdown_ms()
+        out["exchange"] = step.h.exchange_note()
     elif args.mode == "dualrefine":
         out["config"]["workload"] = ("DualRefine+MAL loss loops, B=8 per GPU, 192x640 (BASELINE configs[4]): generate_images_pred + "
                                      "compute_losses over (scale 0, deq_iter 0..1), convention B warps (align_corners=False), fwd+bwd "
                                      "to disp/pose leaves; networks not included")
-        out["config"]["global_batch"] = getattr(step, "B", B) * n_ranks
+        out["config"]["global_batch"] = step_B * n_ranks
         out["metric"] = "train images/sec at B=8 192x640 KITTI-shaped (DualRefine+MAL loss loops, fwd+bwd)"
     elif args.mode not in ("step", "distil"):
         out["config"]["workload"] += " [mode %s]" % args.mode

@@ -510,6 +510,14 @@ void* mal_event_create(void);
 int mal_event_destroy(void* ev);
 int mal_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int mal_profile_next_pass(void* start, void* stop);
+/* The task decomposition march_launch picks for a fused pass over (B,H,W) with `flags` (MAL_F_GRAD decides the halo) on
+ * the current device: strips x segs wavefront tasks per sample, `rows` output rows per task, `iterations` of the row
+ * loop a full task runs (rows + its halo rows).  bench.py prices the kernel's vector-ALU time with it. */
+int mal_march_geometry(int B, int H, int W, int flags, int* strips, int* segs, int* rows, int* iterations);
+/* Shader clock under load: two wavefronts of packed FMAs on every SIMD for `iters` rounds of 64 instructions; wave 0
+ * leaves out3[0] = shader-clock ticks (s_memtime) and out3[1] = ticks of the constant 100 MHz counter (s_memrealtime)
+ * around its loop (out3: 3 device words, the third is scratch).  clock_MHz = 100 * out3[0] / out3[1]. */
+int mal_clock_probe(unsigned long long* out3, int iters, void* stream);
 /* Parity instrumentation for the operator-level fused pass (tests): the next mal_pass_fused call whose flags are
  * GRAD|AUTOMASK|POSE_GRAD (no epilogue) or GRAD|EPILOGUE (no automask, no pose gradient) writes its per-pixel decisions
  * into `planes` (MAL_DEC_PLANES x B*H*W uint32, MAL_DEC_* above; the smoothness planes stay untouched) -- one shot. */

@@ -97,6 +97,8 @@ SIGNATURES = {
     "mal_event_destroy": (i32, [vp]),
     "mal_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
     "mal_profile_next_pass": (i32, [vp, vp]),
+    "mal_march_geometry": (i32, [i32, i32, i32, i32] + [C.POINTER(i32)] * 4),
+    "mal_clock_probe": (i32, [vp, i32, vp]),
     "mal_decisions_next_pass": (i32, [vp]),
 }
 

@@ -73,5 +73,109 @@ def build(force=False, verbose=True):
     return LIB
 
 
+# ---- vector-ALU price of the marching kernels' row loop, from the compiler's own output -------------------------
+# cycles per wave64 instruction on MI355X at >= 2 waves per SIMD, measured by scripts/valu_probe.hip
+# (profiles/r02_valu_probe.txt): plain fp32 2.7, packed fp32 4.2, DPP 4.3, transcendental 8, 32-bit integer multiply 8
+VALU_COSTS = {"plain": 2.7, "packed": 4.2, "dpp": 4.3, "transcendental": 8.0, "mul32": 8.0, "mov": 2.7, "cmp/select": 2.7,
+              "lane": 2.7}
+VALU_JSON = os.path.join(LIBDIR, "valu_cost.json")
+# the instantiations bench.py prices: name -> substring of the mangled symbol
+VALU_KERNELS = {"teacher": "march_kernelILb1ELb1ELb1ELb0ELb0ELb0EE", "teacher_temporal": "march_kernelILb1ELb1ELb1ELb0ELb0ELb1EE",
+                "student": "march_kernelILb1ELb0ELb0ELb1ELb0ELb0EE", "ensemble": "march_kernelILb0ELb0ELb0ELb0ELb0ELb0EE"}
+
+
+def _valu_class(op):
+    if op.startswith("v_pk_"):
+        return "packed"
+    if "dpp" in op:
+        return "dpp"
+    if op.startswith(("v_rcp", "v_exp", "v_log", "v_sqrt", "v_rsq", "v_sin", "v_cos")):
+        return "transcendental"
+    if op.startswith(("v_mul_lo", "v_mul_hi")):
+        return "mul32"
+    if op.startswith("v_mov") or op.startswith("v_accvgpr"):
+        return "mov"
+    if op.startswith(("v_cndmask", "v_cmp")):
+        return "cmp/select"
+    if op.startswith(("v_readlane", "v_writelane", "v_readfirstlane")):
+        return "lane"
+    return "plain"
+
+
+def valu_cost_of(asm_text, key):
+    """Instruction classes of the longest backward-branch loop (the row loop) of the kernel whose mangled name contains
+    ``key`` in a ``hipcc -S`` listing: {"loop_instructions", "valu_instructions", "pipe_cycles", "classes": {class:
+    {"instr", "cycles"}}} with VALU_COSTS as prices."""
+    import collections
+    import re
+    lines = asm_text.split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and l.rstrip().split(":")[0].endswith("E"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    labels, ins = {}, []
+    for l in lines[start + 1:end]:
+        t = l.strip()
+        m = re.match(r"^(\.LBB\w+):", t)
+        if m:
+            labels[m.group(1)] = len(ins)
+            continue
+        if not t or t.startswith((";", ".")):
+            continue
+        ins.append(t)
+    best = (0, 0, 0)
+    for i, t in enumerate(ins):
+        m = re.match(r"s_cbranch\w*\s+(\.LBB\w+)|s_branch\s+(\.LBB\w+)", t)
+        if m:
+            tgt = labels.get(m.group(1) or m.group(2))
+            if tgt is not None and tgt < i and i - tgt > best[0]:
+                best = (i - tgt, tgt, i)
+    loop = ins[best[1]:best[2] + 1]
+    cnt = collections.Counter()
+    for t in loop:
+        op = re.split(r"\s+", t)[0]
+        if op.startswith("v_"):
+            cnt[_valu_class(op)] += 1
+    classes = {k: {"instr": n, "cycles": round(n * VALU_COSTS[k], 1)} for k, n in cnt.most_common()}
+    return {"loop_instructions": len(loop), "valu_instructions": sum(cnt.values()),
+            "pipe_cycles": round(sum(c["cycles"] for c in classes.values()), 1), "classes": classes}
+
+
+def valu_report(force=False, verbose=False):
+    """mal_amd/lib/valu_cost.json: the row loop of the marching kernels priced from the listing of the SAME sources and flags
+    the shipped library was built from (stamped with the same digest).  bench.py puts it into its `roofline.valu` block."""
+    import json
+    dig = _digest()
+    if not force and os.path.exists(VALU_JSON):
+        try:
+            old = json.load(open(VALU_JSON))
+            if old.get("digest") == dig:
+                return old
+        except Exception:
+            pass
+    os.makedirs(LIBDIR, exist_ok=True)
+    asm = os.path.join(LIBDIR, "mal_march.s")
+    cmd = [_hipcc()] + FLAGS + ["--cuda-device-only", "-S", os.path.join(CSRC, "mal_march.hip"), "-o", asm]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    text = open(asm).read()
+    out = {"digest": dig, "source": "hipcc -S --cuda-device-only mal_amd/csrc/mal_march.hip with mal_amd.build.FLAGS; longest "
+                                    "backward-branch loop of each kernel = its row loop",
+           "costs_cycles_per_wave64_instruction": VALU_COSTS,
+           "costs_source": "scripts/valu_probe.hip on MI355X, >= 2 waves per SIMD (profiles/r02_valu_probe.txt)",
+           "kernels": {}}
+    for name, key in VALU_KERNELS.items():
+        try:
+            out["kernels"][name] = valu_cost_of(text, key)
+        except StopIteration:
+            pass
+    with open(VALU_JSON, "w") as fh:
+        json.dump(out, fh, indent=1)
+    os.remove(asm)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--valu" in sys.argv:
+        import json
+        print(json.dumps(valu_report(force=True, verbose=True)["kernels"], indent=1))

@@ -1037,9 +1037,9 @@ MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, 
   return p;
 }
 
-int march_launch(MarchParams& p, int flags, hipStream_t st) {
-  const bool grad = flags & MAL_F_GRAD, automask = flags & MAL_F_AUTOMASK, pose = flags & MAL_F_POSE_GRAD,
-             epi = flags & MAL_F_EPILOGUE;
+// the task decomposition of a pass over (B,H,W) with `flags`: strips x segs tasks per sample, `rows` output rows each
+static void march_decompose(MarchParams& p, int flags) {
+  const bool grad = flags & MAL_F_GRAD;
   const int cw = grad ? 60 : 62;
   p.strips = (p.W + cw - 1) / cw;
   int rows = grad ? g_march_rows : (g_march_rows_fwd > 0 ? g_march_rows_fwd : g_march_rows);
@@ -1052,6 +1052,8 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
     if (slots == 0) {
       int dev = 0, cus = 256;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      (void)hipGetLastError();
+      if (cus <= 0) cus = 256;
       slots = cus * 8;
     }
     rows = 8;
@@ -1061,10 +1063,16 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   p.rows = rows;
   p.segs = (p.H + rows - 1) / rows;
   p.ntasks = p.B * p.strips * p.segs;
+  p.per_xcd = (p.ntasks + 7) / 8;
+}
+
+int march_launch(MarchParams& p, int flags, hipStream_t st) {
+  const bool grad = flags & MAL_F_GRAD, automask = flags & MAL_F_AUTOMASK, pose = flags & MAL_F_POSE_GRAD,
+             epi = flags & MAL_F_EPILOGUE;
+  march_decompose(p, flags);
   p.debug = g_debug;
   p.flip_odd = g_march_flip;
   p.packed = ((flags & MAL_F_SRC_PACKED) ? 1 : 0) | ((flags & MAL_F_TGT_PACKED) ? 2 : 0);
-  p.per_xcd = (p.ntasks + 7) / 8;
   dim3 grid(p.per_xcd * 8), block(64);
   if (!p.cam) return MAL_EINVAL;
   if ((long long)p.H * p.W >= (1ll << 24)) return MAL_ESHAPE;  // tap offsets use 24-bit multiplies
@@ -1133,6 +1141,18 @@ using namespace mal;
 
 extern "C" int mal_decisions_next_pass(uint32_t* planes) {
   g_dec_next = planes;
+  return MAL_OK;
+}
+
+extern "C" int mal_march_geometry(int B, int H, int W, int flags, int* strips, int* segs, int* rows, int* iterations) {
+  if (B <= 0 || H < 2 || W < 2) return MAL_ESHAPE;
+  MarchParams p = {};
+  p.B = B; p.H = H; p.W = W;
+  march_decompose(p, flags);
+  if (strips) *strips = p.strips;
+  if (segs) *segs = p.segs;
+  if (rows) *rows = p.rows;
+  if (iterations) *iterations = p.rows + 2 * ((flags & MAL_F_GRAD) ? 2 : 1);  // row-loop iterations of a full task
   return MAL_OK;
 }
 

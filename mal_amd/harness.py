@@ -1,9 +1,10 @@
 """N1: a trainer-compatible harness around the loss path -- ``RepDepth`` (mal_amd.networks),
-``process_batch`` in upstream's order (manydepth/trainer.py:555-644, ``--distil``), the adaptive depth-bin
+``process_batch`` in upstream's order (manydepth/trainer.py:555-644, ``--distil`` [``--temporal``]), the adaptive depth-bin
 tracker (:75-99), ``LossBalancing`` (:640-642), Adam + StepLR / ``WarmupStepLRScheduler``
 (:193-230, lr_scheduler.py:30-70), checkpoints ``model.pth`` / ``track.pth`` / ``adam.pth`` (:1605-1636,
-1667-1730) and the data-parallel exchange: ONE flat-bucket all-reduce of the parameter gradients per step over
-RCCL (mal_amd.dp.FlatGradBucket) instead of accelerate's DDP + per-step barrier.
+1667-1730) and the data-parallel exchange: the parameter gradients live in ONE flat buffer that is all-reduced over RCCL
+in a few large pieces launched from inside the backward as they complete (mal_amd.dp.FlatGradBucket) instead of
+accelerate's DDP + per-step barrier.
 
 The loss half of ``process_batch`` is ``mal_amd.step.loss_step`` (6 HIP kernels); the networks run through
 torch.nn (MIOpen).  Options follow manydepth/options.py names.
@@ -100,8 +101,14 @@ class StageTimer:
 
 
 class TrainHarness:
-    def __init__(self, opt, device, process_group=None):
+    def __init__(self, opt, device, process_group=None, image_synthesis=None, exchange_segments=4):
+        """``image_synthesis(inputs, outputs, scale) -> has_ins``: the temporal hint's producer (``--temporal``; upstream
+        binds dyn_utils.image_synthesis to the segmenter and the matcher, trainer.py:1161-1165).  ``exchange_segments``:
+        pieces of the flat gradient buffer that are all-reduced from inside the backward (1 = one all-reduce after it)."""
         self.opt, self.device = opt, torch.device(device)
+        self.image_synthesis = image_synthesis
+        if getattr(opt, "temporal", False) and image_synthesis is None:
+            raise ValueError("TrainHarness: opt.temporal needs image_synthesis(inputs, outputs, scale) -> has_ins")
         self.model = networks.RepDepth(opt).to(self.device)
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.optimizer = torch.optim.Adam(self.params, opt.learning_rate)
@@ -112,8 +119,9 @@ class TrainHarness:
         self.tracker = DepthBinTracker(opt.min_depth)
         self.loss_blc = loss_utils.LossBalancing(2, opt.num_train_data, opt.batch_size) if opt.loss_blc else None
         # gradients of all trainable parameters as views of one buffer: one all-reduce per step
-        self.bucket = dp.FlatGradBucket(self.params, process_group)
+        self.bucket = dp.FlatGradBucket(self.params, process_group, segments=exchange_segments)
         self.step_count = 0
+        self.issued_inside_backward = 0
 
     # ---- trainer.py:555-644, --distil
     def process_batch(self, inputs, index_iter=0, timer=None):
@@ -123,7 +131,8 @@ class TrainHarness:
             timer.mark("networks_fwd")
         # with --loss_blc the total is bs * sum_i w_i L_i (loss_utils.py:303-318), formed on the device
         w_list = list(self.loss_blc.w_list) if self.loss_blc is not None else None
-        losses, loss_list, maps = loss_step(self.opt, inputs, mono_outputs, outputs, w_list=w_list)
+        losses, loss_list, maps = loss_step(self.opt, inputs, mono_outputs, outputs, w_list=w_list,
+                                            image_synthesis=self.image_synthesis)
         if timer is not None:
             timer.mark("loss_path_fwd")
         if not self.opt.notadabins and not self.model.freeze_tp:
@@ -139,16 +148,21 @@ class TrainHarness:
         mark = timer.mark if timer is not None else (lambda name: None)
         self.model.train()
         mark("start")
-        self.bucket.zero_()
+        self.bucket.begin_step()
         outputs, losses = self.process_batch(inputs, self.step_count, timer)
-        losses["loss"].backward()
+        losses["loss"].backward()  # N>1: the bucket's pieces are all-reduced from inside it as they complete (dp.py)
         mark("loss_path_bwd+networks_bwd")
-        self.bucket.all_reduce_mean()
+        self.issued_inside_backward = self.bucket.finish()
         mark("grad_all_reduce")
         self.optimizer.step()
         mark("adam")
         self.step_count += 1
         return losses
+
+    def exchange_note(self):
+        b = self.bucket
+        return ("%d parameters (%.0f MB fp32) in one flat buffer, %d piece(s); last step: %d issued from inside the backward, "
+                "world size %d" % (b.flat.numel(), b.flat.numel() * 4 / 1e6, len(b.bounds), self.issued_inside_backward, b.world_size))
 
     def end_epoch(self):
         self.scheduler.step()

@@ -172,8 +172,14 @@ class TemporalLossStepFn(Function):
                 # producer's in-place backward gathers from
                 snap = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
                 a.g_syn_region_m1, a.g_syn_region_p1 = snap[0].data_ptr(), snap[1].data_ptr()
-        else:  # no matched instance anywhere: syn == warp ties with it and never wins (first minimum), as if absent
-            syn, syn_data = None, warp
+        else:
+            # no matched instance anywhere (loss_utils.py:84: only the two warped candidates enter the min).  The sweep
+            # indexes its candidates with a sample stride of 3*H*W, so it is handed the CONTIGUOUS second copies the warp
+            # pass wrote (never the batch-strided halves of `pair`), and an all-zero region map: no synthesised candidate
+            # is evaluated anywhere, the running min passes through and d/d syn is zero
+            syn, syn_data = None, pre
+            region = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
+            a.syn_region = region.data_ptr()
         # the cotangents of syn: this node's own buffers, which the producer's backward may turn into its result in place
         g_syn = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
         a.syn_m1, a.syn_p1 = syn_data[0].data_ptr(), syn_data[1].data_ptr()

@@ -113,3 +113,52 @@ def test_bucket_single_process_is_a_noop_and_views_hold():
     assert b.check_views() and b.world_size == 1 and b.all_reduce_mean() is None
     assert float(b.flat.abs().sum()) > 0
     assert list(shard_indices(10, 1, 2)) == [5, 6, 7, 8, 9]
+
+
+class _Deep(torch.nn.Module):
+    """a few layers, so that the flat buffer splits into pieces the backward completes one after the other; `unused`
+    never receives a gradient (a frozen / unreached parameter: its piece must still be exchanged by finish())"""
+
+    def __init__(self):
+        super().__init__()
+        self.a, self.b, self.c = torch.nn.Linear(6, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 3)
+        self.unused = torch.nn.Linear(5, 5)
+
+    def forward(self, x):
+        return self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mal_amd.dp import FlatGradBucket
+        res = {}
+        for segs in (1, 3):
+            torch.manual_seed(0)
+            model = _Deep()
+            bucket = FlatGradBucket(model.parameters(), segments=segs)
+            x = torch.randn(4, 6, generator=torch.Generator().manual_seed(10 + rank))
+            for _ in range(2):  # two steps: the pieces re-arm
+                bucket.begin_step()
+                model(x).square().sum().backward()
+                inside = bucket.finish()
+            assert bucket.check_views()
+            res[segs] = (bucket.flat.numpy().copy(), inside, len(bucket.bounds))
+        if rank == 0:
+            out["res"] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pieces_issued_inside_backward_equal_one_all_reduce():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = out["res"]
+    one, three = res[1], res[3]
+    assert one[2] == 1 and one[1] == 0
+    assert three[2] == 3 and three[1] >= 1        # at least one piece left from inside the backward
+    assert np.array_equal(one[0], three[0])       # element-wise mean either way: bit-identical
+    # the never-used parameters' gradients stay zero and were still exchanged (finish() issued their piece)
+    assert float(np.abs(three[0]).sum()) > 0

@@ -1,0 +1,70 @@
+"""The driver's own command, run as a child process on the GPU box: `python bench.py --gpus 1 --steps K --warmup W` with
+NO other flags must exit 0 and print ONE JSON line that carries the contract fields, the roofline block (HBM fraction
+and the vector-ALU bound) and the CPU baseline.  Round 2 lost its headline to a bench.py edit that was never run with
+the default arguments; this test is that run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, "bench.py %s exited %d\n%s" % (" ".join(args), r.returncode, r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert lines, r.stderr[-2000:]
+    return json.loads(lines[-1])
+
+
+def _contract(d, steps, warmup):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
+    assert d["dtype"] == "f32" and d["unit"] == "images/s" and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert isinstance(d["config"].get("workload"), str) and "model" not in d["config"]
+
+
+def test_driver_command_default_flags():
+    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1"])
+    _contract(d, 2, 1)
+    assert "--temporal --distil" in d["config"]["workload"] and d["config"]["width"] == 640 and d["config"]["global_batch"] == 12
+    assert abs(d["value"] - 12 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert 0.05 < r["frac"] < 1.0 and r["kernel_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - 96 * 12 * 192 * 640 / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    v = r["valu"]
+    assert "error" not in v, v
+    assert 0.2 < v["valu_frac"] < 1.2 and v["shader_clock_mhz"] > 500 and v["tasks"] > 0 and v["pipe_cycles_per_row"] > 0
+    c = d["cpu_baseline"]
+    assert c["value"] > 0 and c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "images/s" and c["sample"]
+    t = d["train_step"]
+    assert "error" not in t, t
+    assert t["value"] > 0 and t["steps"] == 20 and "networks_fwd" in t["breakdown_ms"]
+    assert d["eager_ms_per_step"] >= 0.5 * d["ms_per_step"]
+    assert d["roofline_temporal"]["kernel_ms"] > 0
+
+
+@pytest.mark.parametrize("extra,expect", [(["--mode", "dualrefine"], "DualRefine"), (["--width", "512"], "192x512"),
+                                          (["--mode", "distil"], "--distil")],
+                         ids=["dualrefine", "cityscapes_width", "distil"])
+def test_other_bench_modes_print_a_line(extra, expect):
+    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--train-steps", "0"] + extra)
+    _contract(d, 2, 1)
+    assert expect in d["config"]["workload"], d["config"]["workload"]
+    if extra[0] == "--mode" and extra[1] == "dualrefine":
+        assert d["config"]["global_batch"] == 8 and abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    if extra[0] == "--width":
+        assert d["config"]["width"] == 512 and d["roofline"]["pixels_per_launch"] == 12 * 192 * 512

@@ -31,7 +31,7 @@ def _worker(rank, world, port, same_batch, out_dir):
         random.seed(0)
         # no random matching augmentation / pose dropout: ranks must run the same computation on the same data
         opt = harness.default_options(batch_size=2, height=64, width=128, no_matching_augmentation=True)
-        h = harness.TrainHarness(opt, dev)
+        h = harness.TrainHarness(opt, dev, exchange_segments=1)  # one all-reduce after the backward: the spy sees local grads
         inputs = harness.synthetic_inputs(opt, dev, seed=11 if same_batch else 11 + rank)
         seen = {}
         reduce_ = h.bucket.all_reduce_mean
@@ -72,3 +72,57 @@ def test_train_step_data_parallel_semantics(tmp_path, same_batch):
         assert float((r[0]["reduced"] - r[0]["local"]).abs().max()) <= 1e-4 * scale
     else:
         assert float((r[0]["local"] - r[1]["local"]).abs().max()) > 1e-3 * scale
+
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    import random
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mal_amd import harness
+        dev = torch.device("cuda:0")
+        opt = harness.default_options(batch_size=2, height=64, width=128, no_matching_augmentation=True)
+        inputs = harness.synthetic_inputs(opt, dev, seed=21 + rank)
+        res = {}
+        for segs in (1, 4):
+            torch.manual_seed(0)
+            random.seed(0)
+            h = harness.TrainHarness(opt, dev, exchange_segments=segs)
+            h.model.train()
+            inside = []
+            for it in range(2):  # the second step uses the issue order learnt in the first
+                random.seed(5 + it)
+                torch.manual_seed(5 + it)
+                h.train_step(inputs)
+                inside.append(h.issued_inside_backward)
+                if it == 0:  # compared after the FIRST step: Adam's update would amplify MIOpen's run-to-run differences
+                    torch.cuda.synchronize()
+                    first = h.bucket.flat.detach().cpu()
+            torch.cuda.synchronize()
+            assert h.bucket.check_views()
+            res[segs] = {"flat": first, "inside": inside, "pieces": len(h.bucket.bounds)}
+        torch.save(res, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_from_inside_the_backward_equals_the_single_all_reduce(tmp_path):
+    """TrainHarness with the flat gradient buffer exchanged in four pieces launched from inside the backward (what DDP's
+    buckets do, manydepth/trainer.py:469) against the same two steps with ONE all-reduce after it: same gradients on
+    every rank (up to MIOpen's run-to-run reduction order), and from the second step on pieces really leave early."""
+    import torch.multiprocessing as mp
+    from mal_amd import build
+    build.build(verbose=False)
+    world = 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % k)) for k in range(world)]
+    for k in range(world):
+        assert r[k][1]["pieces"] == 1 and r[k][4]["pieces"] == 4
+        assert r[k][1]["inside"] == [0, 0]
+        assert r[k][4]["inside"][1] >= 2, r[k][4]["inside"]
+    assert torch.equal(r[0][4]["flat"], r[1][4]["flat"])  # every rank holds the same mean
+    scale = float(r[0][1]["flat"].abs().max())
+    assert scale > 0
+    assert float((r[0][4]["flat"] - r[0][1]["flat"]).abs().max()) <= 2e-4 * scale

@@ -141,3 +141,40 @@ def test_loss_step_rejects_unsupported_options():
     opt = trainer.default_options(temporal=True)
     with pytest.raises(_lib.MalError):
         step.loss_step(opt, {("color", 0, 0): torch.zeros(1, 3, 4, 4, device="cuda")}, {}, {})
+
+
+@pytest.mark.parametrize("tag", ["step_b3_37x50_distil", "step_b2_32x64_distil"])
+def test_temporal_step_without_instances_equals_the_distil_step(tag):
+    """opt.temporal with a producer that finds no matched instance (has_ins False): the reference then takes the min
+    over the two warped candidates only (loss_utils.py:84), i.e. the --distil step.  B >= 2, so a sweep that indexed
+    the batch-strided halves of the warped pair as if they were contiguous would read other samples' images."""
+    from mal_amd import step, trainer
+    z = G.load(tag)
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    assert B >= 2
+    n0, _ = G.noises(z, (B, 1, H, W))
+    ref = run_step(b, {}, n0)
+    dev = torch.device("cuda:0")
+    opt = trainer.default_options(height=H, width=W, batch_size=B, temporal=True)
+    inputs, mono_outputs, outputs, leaves = to_dicts(b, lambda a, t, inv: None, device=dev)
+    for f, s in ((-1, "m1"), (1, "p1")):
+        mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + s]
+        mono_outputs[("translation", 0, f)] = leaves["translation_" + s]
+    calls = []
+
+    def no_instances(inputs_, outputs_, scale):
+        calls.append(tuple(outputs_[("color", -1, scale)].shape))
+        return False
+
+    losses, _, maps = step.loss_step(opt, inputs, mono_outputs, outputs, w_list=[0.7, 0.3], noise=n0.to(dev),
+                                     image_synthesis=no_instances)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    assert calls == [(B, 3, H, W)] and mono_outputs["has_ins"] is False and ("syn", -1, 0) not in mono_outputs
+    for k, v in ref["losses"].items():
+        assert abs(float(losses[k]) - v) <= 2e-6 * max(abs(v), 1e-3), (k, float(losses[k]), v)
+    assert np.abs(maps["mono_reproj"].cpu().numpy() - ref["maps"]["mono_reproj"]).max() <= 1e-6
+    for k, t in leaves.items():
+        g = (t.grad if t.grad is not None else torch.zeros_like(t)).cpu().numpy()
+        assert np.abs(g - ref["grads"][k]).max() <= 2e-5 * np.abs(ref["grads"][k]).max(), k
