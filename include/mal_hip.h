@@ -188,6 +188,14 @@ int mal_distil_epilogue(const float* multi_depth, const float* mono_depth, const
                         int B, int H, int W, int flags, double* sums /*f64[8]*/, float* g_multi_cons,
                         float* g_multi_distil, float* g_mono_distil, float* consistency_target,
                         void* ws, size_t ws_bytes, void* stream);
+/* ... with --learn_ens (loss_utils.py:240-241; trainer.py:596-600): the ensemble depth is ens_depth = disp_to_depth of the
+ * learnt head's output instead of (mono + multi) / 2; g_ens_depth (nullable) = d sums[3] / d ens_depth (unnormalised),
+ * non-zero where the ensemble wins the three-way min; ens_reproj is required. */
+int mal_distil_epilogue_learned(const float* multi_depth, const float* mono_depth, const float* ens_depth,
+                                const float* multi_reproj, const float* mono_reproj, const float* ens_reproj,
+                                const float* ext_mask, int B, int H, int W, double* sums /*f64[8]*/, float* g_multi_cons,
+                                float* g_multi_distil, float* g_ens_depth, float* consistency_target,
+                                void* ws, size_t ws_bytes, void* stream);
 
 /* (B,3,H,W) -> (B,H,W,n) texels, n = mal_texel_floats() (3: r,g,b 12 bytes apart): each bilinear tap of the fused
  * pass becomes one per-lane gather instead of three 4-byte ones.  Sources change per batch, not per pass: pack once.

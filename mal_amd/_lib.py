@@ -49,6 +49,7 @@ SIGNATURES = {
                              i32, f32, f32, f32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp, c_pp, c_fp, c_fp, vp, sz, vp]),
     "mal_distil_epilogue": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp,
                                   c_fp, vp, sz, vp]),
+    "mal_distil_epilogue_learned": (i32, [c_fp] * 7 + [i32, i32, i32] + [c_fp] * 5 + [vp, sz, vp]),
     "mal_matching_mask": (i32, [c_fp, c_fp, c_fp, sz, c_fp, vp]),
     "mal_texel_floats": (i32, []),
     "mal_costvol_channel_last": (i32, []),

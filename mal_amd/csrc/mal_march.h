@@ -24,6 +24,10 @@ struct MarchParams {
   int B, H, W; float min_disp, range, eps; int convention;
   float* min_reproj; float* g_reproj; float* g_cons; float* g_distil; float* cons_target; float* depth_out;
   double* block_sums; float* block_gP;
+  // One-row halo of the gradient passes (nullable = two-row halo, every gradient row complete in g_reproj): boundary
+  // scratch rows [B][segs][2][W]; row 0 / 1 of segment s = what the task ABOVE / BELOW contributes to the gradient of the
+  // segment's first / last row (d / d disp, unnormalised like g_reproj).  The consumer adds them: march_boundary_add.
+  float* bnd;
   int strips, segs, rows, ntasks, per_xcd;
   int packed;
   int flip_odd;  // odd row segments walk bottom-up: both tasks that share a segment boundary reach it together (L2 serves the halo)
@@ -32,6 +36,11 @@ struct MarchParams {
   // forward-only pass that precedes the producer: the warped images as planar (B,3,H,W) (what image_synthesis reads,
   // dyn_utils.py:127-128) and the winner among the two warped candidates
   float* color_out[2]; unsigned char* argmin_out;
+  // ... with the automask (MAL_F_AUTOMASK on that pass) it also leaves what the step needs where NO synthesised candidate
+  // can win: second copies of the min / winner (the fused sweep over the synthesised pair overwrites them at the pixels it
+  // re-decides; the first copies stay its read-only inputs) and the automask weight; block_sums = the sums over the two
+  // warped candidates, which the fused sweep corrects by per-task differences
+  float* min_reproj2; unsigned char* argmin_out2; float* weight_out;
   int color_out_stride;  // floats between two samples of color_out (0 = 3*H*W: contiguous (B,3,H,W))
   // a second copy, contiguous (B,3,H,W) each, nullable: the buffers the synthesised images are made in -- the producer
   // then overwrites only the pixels its instances touch instead of copying every sample (dyn_utils.py:127-128)
@@ -76,6 +85,20 @@ MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, 
 // fills the task decomposition for `flags` (MAL_F_*), launches the matching instantiation on `st`
 // (bracketed by the one-shot profile events if armed).  Partials go to p.block_sums / p.block_gP.
 int march_launch(MarchParams& p, int flags, hipStream_t st);
+// the decomposition march_launch picks for (B,H,W) and `flags` on the current device
+void march_geometry(int B, int H, int W, int flags, int* strips, int* segs, int* rows);
+// floats of a boundary scratch buffer (MarchParams::bnd) that fits every decomposition of (B,H,W)
+inline size_t march_bnd_floats(int B, int H, int W) { return (size_t)B * ((size_t)H / 8 + 1) * 2 * (size_t)W; }
+// what the boundary scratch rows add to pixel (b, y, x) of the gradient map (0 away from segment boundaries); y, rows,
+// segs wave-uniform in the callers
+MAL_DEV float march_boundary_term(const float* bnd, int b, int y, int x, int H, int W, int rows, int segs) {
+  const int sq = y / rows, within = y - sq * rows;
+  const int last = min(rows, H - sq * rows) - 1;
+  float v = 0.f;
+  if (within == 0 && sq > 0) v = bnd[((size_t)(b * segs + sq) * 2 + 0) * W + x];
+  else if (within == last && sq < segs - 1) v = bnd[((size_t)(b * segs + sq) * 2 + 1) * W + x];
+  return v;
+}
 // tasks per sample of pack_identity_launch's decomposition (the per-task smoothness partials are laid out by it)
 int pack_identity_tasks_per_sample(int H, int W);
 // min_f r(src_f, target) of the RAW sources -> ident (B,1,H,W) (the identity term of

@@ -326,7 +326,18 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   constexpr int RING = GRAD ? (POSE ? 24 : 12) : 1;  // x, then (du, dv, u/v/rz) or e; the target row is re-read from memory
   __shared__ float s_ring[GRAD ? 3 : 1][RING][64];
   int it = 0;
-  const int r_first = max(y_lo - HALO, -1), r_last = y_hi - 1 + HALO;
+  // One-row halo (p.bnd != nullptr, gradient passes of the whole-step list): a task warps ONE row beyond each end of its
+  // segment and evaluates the statistics / decisions of its OWN rows only.  The gradient of a boundary row then lacks
+  // the window row that belongs to the neighbouring task -- but that neighbour holds everything this row's pixel
+  // contributes to the missing term (its warped values and chain-rule numbers: the neighbour's halo row, in its ring),
+  // so it evaluates the term itself, one gradient row beyond each end of its segment, and leaves it in the boundary
+  // scratch rows p.bnd ([b][segment][first/last row][W]); pose terms go into its own per-task partials.  The assembly
+  // kernel adds the scratch rows to the map in fixed order.  rows+2 warped rows instead of rows+4, no statistics row is
+  // evaluated twice (so no decision can come out differently in two tasks), rows+2 gradient rows instead of rows.
+  // h1e = 1 with the one-row halo (else 0): warped rows [y_lo-HALO+h1e, y_hi-1+HALO-h1e], statistics rows
+  // [y_lo-(HALO-1)+h1e, y_hi-1+(HALO-1)-h1e], gradient rows [y_lo-h1e, y_hi-1+h1e] inside the image
+  const int h1e = (GRAD && p.bnd != nullptr) ? 1 : 0;
+  const int r_first = max(y_lo - HALO + h1e, -1), r_warp_last = y_hi - 1 + HALO - h1e;
   // A wave runs its stages in order and the vector-memory counter retires in order, so a load that is
   // waited for soon after it was issued exposes a full memory round trip (two waves per SIMD hide little),
   // and so does any wait that follows younger loads.  Hence EVERY per-pixel operand except the gathers is
@@ -421,7 +432,159 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   f2 y2rg = bc(0.f);
   float y2b = 0.f;  // target pixel of row r-2
   float dv_1 = 0.f, dv_2 = 0.f;  // disparity of rows r-1, r-2 (the pose terms of the gradient row re-project it)
-  for (int r = r_first; r <= r_last; ++r, ++it) {
+  // ================= epilogue terms of output row (EPI): row q = r-2 with GRAD, c without ===
+  auto epilogue = [&](CParams& p, int r, const PixInfo& pq, float le_disp, float le_mono, float le_mr, float le_er,
+                      unsigned so_c, unsigned so_q, bool has_mdisp, bool has_er) __attribute__((always_inline)) {
+    const int q = GRAD ? r - 2 : r - 1;
+    if (q >= y_lo && q < y_hi && out_x) {
+      const unsigned go = GRAD ? so_q : so_c;
+      const float dm = depth_of(le_disp, p.min_disp, p.range);
+      const float ddepth = -(dm * dm) * p.range;
+      const float dmono = has_mdisp ? depth_of(le_mono, p.min_disp, p.range) : le_mono;
+      const float m = pq.w, cm = 1.0f - m, mm = 1.0f - cm;
+      const float dc = dm - dmono;
+      acc_cons += fabsf(dc) * cm;
+      int idx = 0;
+      float best = le_mr;
+      if (has_er) {
+        const float r_ens = le_er;
+        if (r_ens < best) { best = r_ens; idx = 1; }
+      }
+      if (pq.rp < best) idx = 2;
+      const float ens = (dmono + dm) / 2.0f;
+      const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
+      const float dd = target - dm;
+      acc_dist += fabsf(dd) * mm;
+      if (DBG) dec_store(p.dbg, (unsigned)(p.B * HW), MAL_DEC_DISTIL, go, (unsigned)idx);
+      if (p.cons_target) stf(p.cons_target, go, div_(1.0f, dmono * cm + dm * (1.0f - cm)));
+      if (GRAD) {
+        const float gc = sgnf(dc) * cm * ddepth;
+        const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : -0.5f)) * mm * ddepth;
+        if (p.g_distil) {
+          stf(p.g_cons, go, gc);
+          stf(p.g_distil, go, gd);
+        } else {
+          stf(p.g_cons, go, fma_(p.merge_cons, gc, p.merge_distil * gd));
+        }
+      }
+    }
+  };
+  // ================= the gradient row q = r-2 of iteration r (hc: the horizontal sums of row c = r-1's partial planes)
+  auto gradient_row = [&](CParams& p, int r, int it, const f2* hc, const Ahead& cur, unsigned so_q,
+                          float le_mono) __attribute__((always_inline)) {
+  // ================= stage G: output row q = c-1 = r-2 ======================================
+  const int q = r - 2, c = r - 1;
+  const bool own_q = q >= y_lo && q < y_hi;  // false: a boundary row of the neighbouring task (one-row halo)
+  if (q >= y_lo - h1e && q < y_hi + h1e && (unsigned)q < (unsigned)H && !(p.debug & 4)) {  // wave-uniform
+    WarpRow wq;
+    DerivRow dq;
+    f2 pq_u = bc(0.f), pq_v = bc(0.f), pq_rz = bc(0.f);
+    {
+      float (*slot)[64] = s_ring[(it + 1) % 3];  // written two iterations ago
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        wq.x[k] = (f2){slot[2 * k][lane], slot[2 * k + 1][lane]};
+        if (POSE) {
+          dq.du[k] = (f2){slot[6 + 2 * k][lane], slot[6 + 2 * k + 1][lane]};
+          dq.dv[k] = (f2){slot[12 + 2 * k][lane], slot[12 + 2 * k + 1][lane]};
+        } else {
+          dq.e[k] = (f2){slot[6 + 2 * k][lane], slot[6 + 2 * k + 1][lane]};
+        }
+      }
+      if (POSE) {
+        pq_u = (f2){slot[18][lane], slot[19][lane]}; pq_v = (f2){slot[20][lane], slot[21][lane]};
+        pq_rz = (f2){slot[22][lane], slot[23][lane]};
+      }
+      wq.yrg = y2rg; wq.yb = y2b;  // target of row q = r-2, kept from its own iteration
+    }
+    const float wyd = (q == H - 2) ? 2.0f : 1.0f;  // row q+1 = c is the bottom border row
+    // L1 term of the winner: w * 0.15/3 * sign(x - y)
+    const float lw = pi1.w * (0.15f / 3.0f);
+    const float lw0 = pi1.win == 0 ? lw : 0.f, lw1 = pi1.win != 0 ? lw : 0.f;
+    const f2 lwk[3] = {bc(lw0), bc(lw1), (f2){lw0, lw1}};
+    f2 g[3];
+    // only the winner's L1 term is non-zero: take the sign of the winner's differences and let the zero
+    // weight of the other candidate discard it
+    const bool w1_ = pi1.win != 0;
+    const f2 dwin = (w1_ ? wq.x[1] : wq.x[0]) - wq.yrg;
+    const float dwb = (w1_ ? wq.x[2].y : wq.x[2].x) - wq.yb;
+    const f2 sgrg = (f2){sgnf(dwin.x), sgnf(dwin.y)};
+    const float sgb = sgnf(dwb);
+    if (DBG && out_x && own_q)
+      dec_store(p.dbg, (unsigned)(p.B * HW), MAL_DEC_L1, so_q,
+                (unsigned)(int)(sgrg.x + 1.0f) | ((unsigned)(int)(sgrg.y + 1.0f) << 2) | ((unsigned)(int)(sgb + 1.0f) << 4));
+    const f2 sgk[3] = {sgrg, sgrg, bc(sgb)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f2 SA = fma2(bc(wyd), hc[k * 3], hcA[k * 3]);
+      const f2 SB = fma2(bc(wyd), hc[k * 3 + 1], hcA[k * 3 + 1]);
+      const f2 SC = fma2(bc(wyd), hc[k * 3 + 2], hcA[k * 3 + 2]);
+      const f2 xq = wq.x[k], yq = k < 2 ? wq.yrg : bc(wq.yb);
+      const f2 sg = sgk[k];
+      g[k] = fma2(lwk[k], sg, fma2(SC, yq, fma2(SB, xq, SA)));
+    }
+    if (TEMPORAL) {  // what reaches the warped colours through the synthesised images (own rows only: x 0 on a boundary row)
+      const f2 ownf = bc(own_q ? 1.0f : 0.0f);
+      g[0] = fma2((f2){cur.gc[0], cur.gc[1]}, ownf, g[0]);
+      g[1] = fma2((f2){cur.gc[3], cur.gc[4]}, ownf, g[1]);
+      g[2] = fma2((f2){cur.gc[2], cur.gc[5]}, ownf, g[2]);
+    }
+    float gdisp;
+    if (POSE) {
+      // u, v, 1/z of row q come back from the ring; its point and the depth derivatives are re-derived
+      const float depth = depth_of(dv_2, p.min_disp, p.range);
+      const float ddepth = -(depth * depth) * p.range;
+      float ray[3], ik[9], X[3];
+      f2 P[12];
+      load_cam(cam_b, P, ik);
+      ray_of(ik, (float)gxr, (float)prow(q), ray);
+      X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
+      const f2 c0 = P[0] * bc(ray[0]) + P[1] * bc(ray[1]) + P[2] * bc(ray[2]);
+      const f2 c1 = P[4] * bc(ray[0]) + P[5] * bc(ray[1]) + P[6] * bc(ray[2]);
+      const f2 c2 = P[8] * bc(ray[0]) + P[9] * bc(ray[1]) + P[10] * bc(ray[2]);
+      const f2 alq = (c0 - pq_u * c2) * pq_rz * bc(ddepth);  // d u / d disp (the clip gate is inside du, dv)
+      const f2 beq = (c1 - pq_v * c2) * pq_rz * bc(ddepth);
+      const f2 tu0 = g[0] * dq.du[0], tu1 = g[1] * dq.du[1], tu2 = g[2] * dq.du[2];
+      const f2 tv0 = g[0] * dq.dv[0], tv1 = g[1] * dq.dv[1], tv2 = g[2] * dq.dv[2];
+      const f2 gu = (f2){(tu0.x + tu0.y) + tu2.x, (tu1.x + tu1.y) + tu2.y};
+      const f2 gv = (f2){(tv0.x + tv0.y) + tv2.x, (tv1.x + tv1.y) + tv2.y};
+      const f2 gd = gu * alq + gv * beq;
+      gdisp = gd.x + gd.y;
+      if (out_x) {
+        const f2 a0 = gu * pq_rz, a1 = gv * pq_rz, a2 = -(gu * pq_u + gv * pq_v) * pq_rz;
+        const f2 a[3] = {a0, a1, a2};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) gP[i * 4 + j] = fma2(a[i], bc(X[j]), gP[i * 4 + j]);
+          gP[i * 4 + 3] += a[i];
+        }
+      }
+    } else {
+      const f2 t0 = g[0] * dq.e[0], t1 = g[1] * dq.e[1], t2 = g[2] * dq.e[2];
+      const f2 ts = (t0 + t1) + t2;
+      gdisp = ts.x + ts.y;
+    }
+    if (out_x) {
+      if (!own_q) {  // the neighbour's boundary row: this task's window row of its gradient, into the scratch rows
+        const int py = prow(q), sq = py / p.rows;
+        const unsigned which = (py == sq * p.rows) ? 0u : 1u;
+        stf(p.bnd, ((unsigned)((b * p.segs + sq) * 2) + which) * (unsigned)W * 4u + (unsigned)gxr * 4u, gdisp);
+      } else if (TEMPORAL && p.fin_out) stf(p.fin_out, so_q, fma_(fin_cR, gdisp, fin_cS * (le_mono * fin_inv - fin_corr)));
+      else stf(p.g_reproj, so_q, gdisp);
+    }
+  }
+  // roll the partial-plane sums: (row c: top+mid) <- (row c: top) + hc(c) ; (row c+1: top) <- hc(c)
+  {
+    const float wyu = (c == 0) ? 2.0f : 1.0f;  // hc(c) as the TOP neighbour of row c+1: doubled if c is row 0
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      hcA[i] = hcB[i] + hc[i];
+      hcB[i] = bc(wyu) * hc[i];
+    }
+  }
+  };
+  for (int r = r_first; r <= r_warp_last; ++r, ++it) {
     CParams* kp = kp0;
     asm volatile("" : "+s"(kp));
     CParams& p = *kp;
@@ -493,48 +656,11 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       }
     };
 
-    // ================= epilogue terms of output row (EPI): row q = r-2 with GRAD, c without ===
-    auto epilogue = [&]() {
-      const int q = GRAD ? r - 2 : r - 1;
-      const PixInfo& pq = GRAD ? pi1 : pi0;
-      if (q >= y_lo && q < y_hi && out_x) {
-        const unsigned go = GRAD ? so_q : so_c;
-        const float dm = depth_of(le_disp, wc.min_disp, wc.range);
-        const float ddepth = -(dm * dm) * wc.range;
-        const float dmono = has_mdisp ? depth_of(le_mono, wc.min_disp, wc.range) : le_mono;
-        const float m = pq.w, cm = 1.0f - m, mm = 1.0f - cm;
-        const float dc = dm - dmono;
-        acc_cons += fabsf(dc) * cm;
-        int idx = 0;
-        float best = le_mr;
-        if (has_er) {
-          const float r_ens = le_er;
-          if (r_ens < best) { best = r_ens; idx = 1; }
-        }
-        if (pq.rp < best) idx = 2;
-        const float ens = (dmono + dm) / 2.0f;
-        const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
-        const float dd = target - dm;
-        acc_dist += fabsf(dd) * mm;
-        if (DBG) dec_store(wc.dbg, wc.dbg_n, MAL_DEC_DISTIL, go, (unsigned)idx);
-        if (p.cons_target) stf(p.cons_target, go, div_(1.0f, dmono * cm + dm * (1.0f - cm)));
-        if (GRAD) {
-          const float gc = sgnf(dc) * cm * ddepth;
-          const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : -0.5f)) * mm * ddepth;
-          if (p.g_distil) {
-            stf(p.g_cons, go, gc);
-            stf(p.g_distil, go, gd);
-          } else {
-            stf(p.g_cons, go, fma_(p.merge_cons, gc, p.merge_distil * gd));
-          }
-        }
-      }
-    };
-    if (EPI && GRAD) epilogue();
+    if (EPI && GRAD) epilogue(p, r, pi1, le_disp, le_mono, le_mr, le_er, so_c, so_q, has_mdisp, has_er);
     tick(2);  // epilogue terms
     finish_warp();
     tick(3);  // gather wait, blend, ring write
-    if (!GRAD && !AUTOMASK && !EPI) {  // the pass in front of the temporal-hint producer: the warped images, planar
+    if (!GRAD && !EPI) {  // the pass in front of the temporal-hint producer: the warped images, planar
       float* const c0 = p.color_out[0];
       float* const c1 = p.color_out[1];
       if (c0 && r >= y_lo && r < y_hi && out_x) {
@@ -554,20 +680,43 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     // ================= stage H: horizontal 3-sums of row r ====================================
     f2 h[9], hy[2];
     float hz[2];
-    hy[0] = hsum3(w0.yrg); hy[1] = hsum3(w0.yrg * w0.yrg);
-    hz[0] = hsum3(w0.yb);  hz[1] = hsum3(w0.yb * w0.yb);
+    if (GRAD) {  // 24 values in three written-out blocks of DPP adds (mal_pairs.h: why not left to the compiler)
+      f2 in[12];
+      in[0] = w0.yrg; in[1] = w0.yrg * w0.yrg; in[2] = (f2){w0.yb, w0.yb * w0.yb};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const f2 x = w0.x[k], y = k < 2 ? w0.yrg : bc(w0.yb);
-      h[k * 3 + 0] = hsum3(x);
-      h[k * 3 + 1] = hsum3(x * x);
-      h[k * 3 + 2] = hsum3(x * y);
+      for (int k = 0; k < 3; ++k) {
+        const f2 x = w0.x[k], y = k < 2 ? w0.yrg : bc(w0.yb);
+        in[3 + k * 3 + 0] = x; in[3 + k * 3 + 1] = x * x; in[3 + k * 3 + 2] = x * y;
+      }
+      f2 out[12];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        float v8[8], r8[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v8[2 * i] = in[g * 4 + i].x; v8[2 * i + 1] = in[g * 4 + i].y; }
+        hsum3_block8(v8, r8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[g * 4 + i] = (f2){r8[2 * i], r8[2 * i + 1]};
+      }
+      hy[0] = out[0]; hy[1] = out[1]; hz[0] = out[2].x; hz[1] = out[2].y;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) h[i] = out[3 + i];
+    } else {
+      hy[0] = hsum3(w0.yrg); hy[1] = hsum3(w0.yrg * w0.yrg);
+      hz[0] = hsum3(w0.yb);  hz[1] = hsum3(w0.yb * w0.yb);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f2 x = w0.x[k], y = k < 2 ? w0.yrg : bc(w0.yb);
+        h[k * 3 + 0] = hsum3(x);
+        h[k * 3 + 1] = hsum3(x * x);
+        h[k * 3 + 2] = hsum3(x * y);
+      }
     }
 
     tick(4);  // horizontal sums
     // ================= stage S: statistics of centre row c = r-1 ==============================
     const int c = r - 1;
-    const bool c_valid = c >= 0 && c < H && c >= y_lo - (HALO - 1) && c <= y_hi - 1 + (HALO - 1);
+    const bool c_valid = c >= 0 && c < H && c >= y_lo - (HALO - 1) + h1e && c <= y_hi - 1 + (HALO - 1) - h1e;
     f2 coef[GRAD ? 9 : 1];
     if (GRAD)
 #pragma unroll
@@ -593,9 +742,13 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
       pi0.win = (rr.y < rr.x) ? 1 : 0;
       pi0.rp = pi0.win ? rr.y : rr.x;
-      if (!GRAD && !AUTOMASK && !EPI) {
+      if (!GRAD && !EPI) {  // ... the winner among the two warped candidates, twice: the copy the fused sweep updates
         unsigned char* const am = p.argmin_out;
-        if (am && out_x && c >= y_lo && c < y_hi) am[so_c >> 2] = (unsigned char)pi0.win;
+        if (am && out_x && c >= y_lo && c < y_hi) {
+          am[so_c >> 2] = (unsigned char)pi0.win;
+          unsigned char* const am2 = p.argmin_out2;
+          if (am2) am2[so_c >> 2] = (unsigned char)pi0.win;
+        }
       }
       float w = 1.0f;
       const unsigned go = so_c;
@@ -627,6 +780,10 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       pi0.w = w;
       if (out_x && c >= y_lo && c < y_hi) {
         if (p.min_reproj) stf(p.min_reproj, go, pi0.rp);
+        if (!GRAD && !EPI) {  // the pass in front of the producer: second copy of the min, the automask weight
+          if (p.min_reproj2) stf(p.min_reproj2, go, pi0.rp);
+          if (p.weight_out) stf(p.weight_out, go, w);
+        }
         acc_rw += pi0.rp * w;
         acc_w += w;
       }
@@ -653,119 +810,22 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       // ================= stage HC: horizontal sums of the partial planes of row c ==============
       f2 hc[9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        const f2 vv = coef[i], l = vv * bc(sL), rr = vv * bc(sR);
-        hc[i] = (f2){(dpp_shr1(l.x) + vv.x) + dpp_shl1(rr.x), (dpp_shr1(l.y) + vv.y) + dpp_shl1(rr.y)};
+      for (int g = 0; g < 3; ++g) {  // three planes (six values) per written-out block of DPP adds
+        float l6[6], c6[6], t6[6], r6[6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const f2 vv = coef[g * 3 + i], l = vv * bc(sL), rr = vv * bc(sR);
+          l6[2 * i] = l.x; l6[2 * i + 1] = l.y; c6[2 * i] = vv.x; c6[2 * i + 1] = vv.y; t6[2 * i] = rr.x; t6[2 * i + 1] = rr.y;
+        }
+        hsum3_block6(l6, c6, t6, r6);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) hc[g * 3 + i] = (f2){r6[2 * i], r6[2 * i + 1]};
       }
-      // ================= stage G: output row q = c-1 = r-2 ======================================
-      const int q = r - 2;
-      if (q >= y_lo && q < y_hi && !(wc.debug & 4)) {  // wave-uniform; q is always inside the image
-        WarpRow wq;
-        DerivRow dq;
-        f2 pq_u = bc(0.f), pq_v = bc(0.f), pq_rz = bc(0.f);
-        {
-          float (*slot)[64] = s_ring[(it + 1) % 3];  // written two iterations ago
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            wq.x[k] = (f2){slot[2 * k][lane], slot[2 * k + 1][lane]};
-            if (POSE) {
-              dq.du[k] = (f2){slot[6 + 2 * k][lane], slot[6 + 2 * k + 1][lane]};
-              dq.dv[k] = (f2){slot[12 + 2 * k][lane], slot[12 + 2 * k + 1][lane]};
-            } else {
-              dq.e[k] = (f2){slot[6 + 2 * k][lane], slot[6 + 2 * k + 1][lane]};
-            }
-          }
-          if (POSE) {
-            pq_u = (f2){slot[18][lane], slot[19][lane]}; pq_v = (f2){slot[20][lane], slot[21][lane]};
-            pq_rz = (f2){slot[22][lane], slot[23][lane]};
-          }
-          wq.yrg = y2rg; wq.yb = y2b;  // target of row q = r-2, kept from its own iteration
-        }
-        const float wyd = (q == H - 2) ? 2.0f : 1.0f;  // row q+1 = c is the bottom border row
-        // L1 term of the winner: w * 0.15/3 * sign(x - y)
-        const float lw = pi1.w * (0.15f / 3.0f);
-        const float lw0 = pi1.win == 0 ? lw : 0.f, lw1 = pi1.win != 0 ? lw : 0.f;
-        const f2 lwk[3] = {bc(lw0), bc(lw1), (f2){lw0, lw1}};
-        f2 g[3];
-        // only the winner's L1 term is non-zero: take the sign of the winner's differences and let the zero
-        // weight of the other candidate discard it
-        const bool w1_ = pi1.win != 0;
-        const f2 dwin = (w1_ ? wq.x[1] : wq.x[0]) - wq.yrg;
-        const float dwb = (w1_ ? wq.x[2].y : wq.x[2].x) - wq.yb;
-        const f2 sgrg = (f2){sgnf(dwin.x), sgnf(dwin.y)};
-        const float sgb = sgnf(dwb);
-        if (DBG && out_x)
-          dec_store(wc.dbg, wc.dbg_n, MAL_DEC_L1, so_q,
-                    (unsigned)(int)(sgrg.x + 1.0f) | ((unsigned)(int)(sgrg.y + 1.0f) << 2) | ((unsigned)(int)(sgb + 1.0f) << 4));
-        const f2 sgk[3] = {sgrg, sgrg, bc(sgb)};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const f2 SA = fma2(bc(wyd), hc[k * 3], hcA[k * 3]);
-          const f2 SB = fma2(bc(wyd), hc[k * 3 + 1], hcA[k * 3 + 1]);
-          const f2 SC = fma2(bc(wyd), hc[k * 3 + 2], hcA[k * 3 + 2]);
-          const f2 xq = wq.x[k], yq = k < 2 ? wq.yrg : bc(wq.yb);
-          const f2 sg = sgk[k];
-          g[k] = fma2(lwk[k], sg, fma2(SC, yq, fma2(SB, xq, SA)));
-        }
-        if (TEMPORAL) {  // what reaches the warped colours through the synthesised images
-          g[0] += (f2){cur.gc[0], cur.gc[1]};
-          g[1] += (f2){cur.gc[3], cur.gc[4]};
-          g[2] += (f2){cur.gc[2], cur.gc[5]};
-        }
-        float gdisp;
-        if (POSE) {
-          // u, v, 1/z of row q come back from the ring; its point and the depth derivatives are re-derived
-          const float depth = depth_of(dv_2, wc.min_disp, wc.range);
-          const float ddepth = -(depth * depth) * wc.range;
-          float ray[3], ik[9], X[3];
-          f2 P[12];
-          load_cam(cam_b, P, ik);
-          ray_of(ik, (float)gxr, (float)prow(q), ray);
-          X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
-          const f2 c0 = P[0] * bc(ray[0]) + P[1] * bc(ray[1]) + P[2] * bc(ray[2]);
-          const f2 c1 = P[4] * bc(ray[0]) + P[5] * bc(ray[1]) + P[6] * bc(ray[2]);
-          const f2 c2 = P[8] * bc(ray[0]) + P[9] * bc(ray[1]) + P[10] * bc(ray[2]);
-          const f2 alq = (c0 - pq_u * c2) * pq_rz * bc(ddepth);  // d u / d disp (the clip gate is inside du, dv)
-          const f2 beq = (c1 - pq_v * c2) * pq_rz * bc(ddepth);
-          const f2 tu0 = g[0] * dq.du[0], tu1 = g[1] * dq.du[1], tu2 = g[2] * dq.du[2];
-          const f2 tv0 = g[0] * dq.dv[0], tv1 = g[1] * dq.dv[1], tv2 = g[2] * dq.dv[2];
-          const f2 gu = (f2){(tu0.x + tu0.y) + tu2.x, (tu1.x + tu1.y) + tu2.y};
-          const f2 gv = (f2){(tv0.x + tv0.y) + tv2.x, (tv1.x + tv1.y) + tv2.y};
-          const f2 gd = gu * alq + gv * beq;
-          gdisp = gd.x + gd.y;
-          if (out_x) {
-            const f2 a0 = gu * pq_rz, a1 = gv * pq_rz, a2 = -(gu * pq_u + gv * pq_v) * pq_rz;
-            const f2 a[3] = {a0, a1, a2};
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-              for (int j = 0; j < 3; ++j) gP[i * 4 + j] = fma2(a[i], bc(X[j]), gP[i * 4 + j]);
-              gP[i * 4 + 3] += a[i];
-            }
-          }
-        } else {
-          const f2 t0 = g[0] * dq.e[0], t1 = g[1] * dq.e[1], t2 = g[2] * dq.e[2];
-          const f2 ts = (t0 + t1) + t2;
-          gdisp = ts.x + ts.y;
-        }
-        if (out_x) {
-          if (TEMPORAL && p.fin_out) stf(p.fin_out, so_q, fma_(fin_cR, gdisp, fin_cS * (le_mono * fin_inv - fin_corr)));
-          else stf(p.g_reproj, so_q, gdisp);
-        }
-      }
-      // roll the partial-plane sums: (row c: top+mid) <- (row c: top) + hc(c) ; (row c+1: top) <- hc(c)
-      {
-        const float wyu = (c == 0) ? 2.0f : 1.0f;  // hc(c) as the TOP neighbour of row c+1: doubled if c is row 0
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          hcA[i] = hcB[i] + hc[i];
-          hcB[i] = bc(wyu) * hc[i];
-        }
-      }
+      gradient_row(p, r, it, hc, cur, so_q, le_mono);
     }
 
     tick(6);  // partial-plane sums, gradient row
-    if (EPI && !GRAD) epilogue();
+    if (EPI && !GRAD) epilogue(p, r, pi0, le_disp, le_mono, le_mr, le_er, so_c, so_q, has_mdisp, has_er);
     if (p.depth_out) {
       const int q = r - 1;
       if (q >= y_lo && q < y_hi && out_x)
@@ -788,6 +848,27 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     if (GRAD) pi1 = pi0;
     dv_2 = dv_1; dv_1 = dv_;
     tick(7);  // rolls
+  }
+  // ---- one-row halo: nothing is left to warp, two gradient rows are -- the segment's last own row (its window row below
+  // belongs to the neighbour: zero here) and the neighbour's first row (this task's last statistics row is its window row
+  // above).  Their operands were requested by the last warp iteration (own row) or are not needed (boundary row).
+  if (GRAD) {
+    const int r_last = min(y_hi - 1 + h1e, H - 1) + 2;  // the last gradient row is two iterations behind
+    for (int r = r_warp_last + 1; r <= r_last; ++r, ++it) {
+      CParams* kp = kp0;
+      asm volatile("" : "+s"(kp));
+      CParams& p = *kp;
+      const Ahead cur = nxt;
+      const unsigned so_c = moff(min(max(r - 1, 0), H - 1)), so_q = moff(min(max(r - 2, 0), H - 1));
+      if (EPI) epilogue(p, r, pi1, dv_2, cur.e_mono, cur.e_mr, cur.e_er, so_c, so_q, p.mono_disp != nullptr, p.ens_reproj != nullptr);
+      f2 hc0[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) hc0[i] = bc(0.f);
+      gradient_row(p, r, it, hc0, cur, so_q, cur.e_mono);
+      y2rg = w1.yrg; y2b = w1.yb;
+      pi1.rp = 0.f; pi1.w = 0.f; pi1.win = 0;
+      dv_2 = dv_1;
+    }
   }
 #ifdef MAL_STAGE_TIMERS
   if ((p.debug & 64) && lane < 8 && p.min_reproj) p.min_reproj[(size_t)task * 8 + lane] = (float)tacc[lane];
@@ -829,7 +910,7 @@ __global__ __launch_bounds__(64, 3) void pack_identity_kernel(IdentParams p) {
   const int id = blockIdx.x;
   if (id >= p.per_xcd * 8) {  // whole-step list: poses of both frames and the camera block of sample b
     const int b = id - p.per_xcd * 8, tid = threadIdx.x;
-    if (b == 0 && tid == 0) *p.sp.ticket = 0u;  // completion counter of step_final_kernel
+    if (b == 0 && tid == 0) { p.sp.ticket[0] = 0u; p.sp.ticket[1] = 0u; }  // completion counter of step_final_kernel, task queue of the fused sweep
     if (tid < 2) pose_fwd_one(p.sp.pose, tid, b);
     __syncthreads();  // T of this sample, written by threads 0/1 to global memory, is visible to the block
     cam_fill(p.sp.K, p.sp.pose.T[0], p.sp.pose.T[1], p.sp.invK, p.sp.cam, b, tid);
@@ -1026,7 +1107,9 @@ unsigned* g_dec_next = nullptr;  // mal_decisions_next_pass: decision planes for
 extern int g_photo_impl;  // mal_photo_march.hip
 extern int g_epi_bwd_planes;  // mal_epipolar.hip
 extern int g_syn_rows;        // mal_photo_march.hip
+extern int g_syn_queue;       // mal_photo_march.hip
 extern int g_step_overlap;    // mal_step.hip
+extern int g_march_halo1;     // mal_step.hip
 
 MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, float eps, int convention) {
   MarchParams p = {};
@@ -1064,6 +1147,15 @@ static void march_decompose(MarchParams& p, int flags) {
   p.segs = (p.H + rows - 1) / rows;
   p.ntasks = p.B * p.strips * p.segs;
   p.per_xcd = (p.ntasks + 7) / 8;
+}
+
+void march_geometry(int B, int H, int W, int flags, int* strips, int* segs, int* rows) {
+  MarchParams p = {};
+  p.B = B; p.H = H; p.W = W;
+  march_decompose(p, flags);
+  if (strips) *strips = p.strips;
+  if (segs) *segs = p.segs;
+  if (rows) *rows = p.rows;
 }
 
 int march_launch(MarchParams& p, int flags, hipStream_t st) {
@@ -1153,6 +1245,7 @@ extern "C" int mal_march_geometry(int B, int H, int W, int flags, int* strips, i
   if (segs) *segs = p.segs;
   if (rows) *rows = p.rows;
   if (iterations) *iterations = p.rows + 2 * ((flags & MAL_F_GRAD) ? 2 : 1);  // row-loop iterations of a full task
+  // (with the one-row halo of the whole-step list a gradient task still runs rows + 4 iterations, the last two without a warp)
   return MAL_OK;
 }
 
@@ -1164,6 +1257,8 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("photo_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_photo_impl = value; return MAL_OK; }
   if (eq("costvol_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_costvol_impl = value; return MAL_OK; }
   if (eq("step_overlap")) { if (value < 0 || value > 2) return MAL_EINVAL; g_step_overlap = value; return MAL_OK; }
+  if (eq("march_halo1")) { g_march_halo1 = value != 0; return MAL_OK; }
+  if (eq("syn_queue")) { g_syn_queue = value != 0; return MAL_OK; }
   if (eq("syn_rows")) { if (value < 2 || value > 64) return MAL_EINVAL; g_syn_rows = value; return MAL_OK; }
   if (eq("epi_bwd_planes")) { g_epi_bwd_planes = value != 0; return MAL_OK; }
   if (eq("march_flip")) { g_march_flip = value != 0; return MAL_OK; }

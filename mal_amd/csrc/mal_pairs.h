@@ -23,6 +23,44 @@ MAL_DEV f2 bc(float v) { return (f2){v, v}; }
 MAL_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 MAL_DEV f2 rcp2(f2 a) { return (f2){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
 MAL_DEV f2 hsum3(f2 v) { return (f2){hsum3(v.x), hsum3(v.y)}; }
+
+// ---- the same horizontal sums as ONE block of v_add_f32_dpp per group of values.  The compiler forms v_add_f32_dpp from
+// update_dpp + fadd only when its DPP-combine pass finds the pair within a short scan window of the pre-RA instruction
+// order; in the gradient instantiations of the marching kernel that depends on unrelated code (measured: 0 of 84 combined
+// after a change elsewhere in the loop = +84 VALU instructions per row, +7 %).  Written out, the instruction count is fixed.
+// Hazard: a VGPR written by a VALU instruction must not be read through DPP in the next two wait states (gfx9 family; the
+// compiler's hazard pass does not look inside inline assembly): the block opens with s_nop 1, and inside it no DPP operand
+// is a register the block wrote.  EXEC is not written by VALU instructions in these kernels (no v_cmpx).
+#define MAL_DPP_SHR1 " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define MAL_DPP_SHL1 " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+// r[i] = (shr1(v[i]) + v[i]) + shl1(v[i]), eight values
+MAL_DEV void hsum3_block8(const float (&v)[8], float (&r)[8]) {
+  asm("s_nop 1\n"
+      "v_add_f32_dpp %0, %8, %8" MAL_DPP_SHR1 "v_add_f32_dpp %1, %9, %9" MAL_DPP_SHR1
+      "v_add_f32_dpp %2, %10, %10" MAL_DPP_SHR1 "v_add_f32_dpp %3, %11, %11" MAL_DPP_SHR1
+      "v_add_f32_dpp %4, %12, %12" MAL_DPP_SHR1 "v_add_f32_dpp %5, %13, %13" MAL_DPP_SHR1
+      "v_add_f32_dpp %6, %14, %14" MAL_DPP_SHR1 "v_add_f32_dpp %7, %15, %15" MAL_DPP_SHR1
+      "v_add_f32_dpp %0, %8, %0" MAL_DPP_SHL1 "v_add_f32_dpp %1, %9, %1" MAL_DPP_SHL1
+      "v_add_f32_dpp %2, %10, %2" MAL_DPP_SHL1 "v_add_f32_dpp %3, %11, %3" MAL_DPP_SHL1
+      "v_add_f32_dpp %4, %12, %4" MAL_DPP_SHL1 "v_add_f32_dpp %5, %13, %5" MAL_DPP_SHL1
+      "v_add_f32_dpp %6, %14, %6" MAL_DPP_SHL1 "v_add_f32_dpp %7, %15, %7" MAL_DPP_SHL1
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+// r[i] = (shr1(l[i]) + c[i]) + shl1(t[i]), six values (the adjoint's border weights differ per direction)
+MAL_DEV void hsum3_block6(const float (&l)[6], const float (&c)[6], const float (&t)[6], float (&r)[6]) {
+  asm("s_nop 1\n"
+      "v_add_f32_dpp %0, %6, %12" MAL_DPP_SHR1 "v_add_f32_dpp %1, %7, %13" MAL_DPP_SHR1
+      "v_add_f32_dpp %2, %8, %14" MAL_DPP_SHR1 "v_add_f32_dpp %3, %9, %15" MAL_DPP_SHR1
+      "v_add_f32_dpp %4, %10, %16" MAL_DPP_SHR1 "v_add_f32_dpp %5, %11, %17" MAL_DPP_SHR1
+      "v_add_f32_dpp %0, %18, %0" MAL_DPP_SHL1 "v_add_f32_dpp %1, %19, %1" MAL_DPP_SHL1
+      "v_add_f32_dpp %2, %20, %2" MAL_DPP_SHL1 "v_add_f32_dpp %3, %21, %3" MAL_DPP_SHL1
+      "v_add_f32_dpp %4, %22, %4" MAL_DPP_SHL1 "v_add_f32_dpp %5, %23, %5" MAL_DPP_SHL1
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5])
+      : "v"(l[0]), "v"(l[1]), "v"(l[2]), "v"(l[3]), "v"(l[4]), "v"(l[5]),
+        "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]),
+        "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]));
+}
 // div_ / div_safe_ / div3_ of mal_device.h, element for element
 MAL_DEV f2 div2_(f2 a, f2 b) {
   f2 y = rcp2(b);

@@ -414,6 +414,9 @@ struct DistilParams {
   const float* multi_depth; const float* mono_depth; const float* multi_reproj; const float* mono_reproj;
   const float* ens_reproj; const float* ext_mask; size_t n; int flags;
   double* block_sums; float* g_multi_cons; float* g_multi_distil; float* g_mono_distil; float* cons_target;
+  // --learn_ens (loss_utils.py:240-241): the ensemble depth is a map of its own (disp_to_depth of the learnt head's
+  // output) instead of (mono + multi) / 2, and receives the gradient of the pixels it wins
+  const float* ens_depth; float* g_ens_depth;
 };
 
 __global__ __launch_bounds__(256) void distil_kernel(DistilParams p) {
@@ -432,13 +435,15 @@ __global__ __launch_bounds__(256) void distil_kernel(DistilParams p) {
       if (r_ens < best) { best = r_ens; idx = 1; }
     }
     if (p.multi_reproj[i] < best) idx = 2;
-    const float ens = (dmono + dm) / 2.0f;
+    const float ens = p.ens_depth ? p.ens_depth[i] : (dmono + dm) / 2.0f;
     const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
     const float dd = target - dm;
     acc_d += (double)(fabsf(dd) * mm);
     if (p.cons_target) p.cons_target[i] = div_(1.0f, dmono * cm + dm * (1.0f - cm));
     if (p.g_multi_cons) p.g_multi_cons[i] = sgn(dc) * cm;
-    if (p.g_multi_distil) p.g_multi_distil[i] = sgn(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : -0.5f)) * mm;
+    const float d_ens = p.ens_depth ? -1.0f : -0.5f;  // d (ens - dm) / d dm
+    if (p.g_multi_distil) p.g_multi_distil[i] = sgn(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : d_ens)) * mm;
+    if (p.g_ens_depth) p.g_ens_depth[i] = idx == 1 ? sgn(dd) * mm : 0.0f;
     if (p.g_mono_distil) p.g_mono_distil[i] = (dual && idx == 0) ? sgn(dd) * mm : 0.0f;
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -636,18 +641,20 @@ extern "C" int mal_smooth_loss(const float* disp, const float* img, int B, int C
   return launch_status();
 }
 
-extern "C" int mal_distil_epilogue(const float* multi_depth, const float* mono_depth, const float* multi_reproj,
-                                   const float* mono_reproj, const float* ens_reproj, const float* ext_mask, int B,
-                                   int H, int W, int flags, double* sums, float* g_multi_cons, float* g_multi_distil,
-                                   float* g_mono_distil, float* consistency_target, void* ws, size_t ws_bytes,
-                                   void* stream) {
+static int distil_epilogue_impl(const float* multi_depth, const float* mono_depth, const float* multi_reproj,
+                                const float* mono_reproj, const float* ens_reproj, const float* ext_mask, int B, int H, int W,
+                                int flags, double* sums, float* g_multi_cons, float* g_multi_distil, float* g_mono_distil,
+                                float* consistency_target, const float* ens_depth, float* g_ens_depth, void* ws,
+                                size_t ws_bytes, void* stream) {
   int rc = check_shape(B, H, W);
   if (rc) return rc;
   if (!multi_depth || !mono_depth || !multi_reproj || !mono_reproj || !sums || !ws) return MAL_EINVAL;
+  if (ens_depth && (!ens_reproj || (flags & MAL_F_DUAL_DISTIL))) return MAL_EINVAL;  // the learnt ensemble is a third candidate
+  if (g_ens_depth && !ens_depth) return MAL_EINVAL;
   Workspace w = carve(ws, B, H, W);
   if (ws_bytes < w.bytes) return MAL_EWORKSPACE;
   DistilParams p = {multi_depth, mono_depth, multi_reproj, mono_reproj, ens_reproj, ext_mask, (size_t)B * H * W, flags,
-                    w.scratch, g_multi_cons, g_multi_distil, g_mono_distil, consistency_target};
+                    w.scratch, g_multi_cons, g_multi_distil, g_mono_distil, consistency_target, ens_depth, g_ens_depth};
   const int grid = ew_grid2(p.n, 2048);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(distil_kernel, dim3(grid), dim3(256), 0, st, p);
@@ -655,6 +662,27 @@ extern "C" int mal_distil_epilogue(const float* multi_depth, const float* mono_d
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, w.scratch, grid, 2, 2, sums + 2);
   return launch_status();
+}
+
+extern "C" int mal_distil_epilogue(const float* multi_depth, const float* mono_depth, const float* multi_reproj,
+                                   const float* mono_reproj, const float* ens_reproj, const float* ext_mask, int B,
+                                   int H, int W, int flags, double* sums, float* g_multi_cons, float* g_multi_distil,
+                                   float* g_mono_distil, float* consistency_target, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  return distil_epilogue_impl(multi_depth, mono_depth, multi_reproj, mono_reproj, ens_reproj, ext_mask, B, H, W, flags, sums,
+                              g_multi_cons, g_multi_distil, g_mono_distil, consistency_target, nullptr, nullptr, ws, ws_bytes,
+                              stream);
+}
+
+extern "C" int mal_distil_epilogue_learned(const float* multi_depth, const float* mono_depth, const float* ens_depth,
+                                           const float* multi_reproj, const float* mono_reproj, const float* ens_reproj,
+                                           const float* ext_mask, int B, int H, int W, double* sums, float* g_multi_cons,
+                                           float* g_multi_distil, float* g_ens_depth, float* consistency_target, void* ws,
+                                           size_t ws_bytes, void* stream) {
+  if (!ens_depth) return MAL_EINVAL;
+  return distil_epilogue_impl(multi_depth, mono_depth, multi_reproj, mono_reproj, ens_reproj, ext_mask, B, H, W, 0, sums,
+                              g_multi_cons, g_multi_distil, nullptr, consistency_target, ens_depth, g_ens_depth, ws, ws_bytes,
+                              stream);
 }
 
 extern "C" int mal_axpy_maps(int n_terms, const float* const* maps, const float* const* scale,

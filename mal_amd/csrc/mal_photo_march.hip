@@ -39,6 +39,9 @@ struct PhotoMarchParams {
   // FUSED with a region map, nullable: a second copy of the gradient, written ONLY at region pixels -- the snapshot the
   // producer's in-place backward gathers from while it overwrites g_cand at those very pixels
   float* g_region[2];
+  // FUSED: task queue (a device word the step's first launch resets): wavefronts fetch tasks until it runs out, so the few
+  // tasks that do the full work spread over the chip instead of setting the duration of every resident round
+  unsigned* queue;
 };
 
 struct Px9 { float t[3], a[3], c[3]; };
@@ -165,16 +168,16 @@ __global__ __launch_bounds__(64, 4) void photo_march_fwd_kernel(PhotoMarchParams
 }
 
 // FUSED (the temporal hint inside the whole-step list): the forward of the pair -- r of both candidates, the running min
-// continued from prev_min / prev_arg, the automask, the outputs and the per-task sums of photo_march_fwd_kernel -- is
-// formed in the same sweep instead of being read back from the argmin / weight maps of an earlier launch.  Halo rows
-// and lanes re-decide their pixels (same arithmetic as the owner: the window sums are direction-symmetric and these
-// kernels do not flip), so the outputs must not alias prev_min / prev_arg.
+// continued from prev_min / prev_arg, the automask -- is formed in the same sweep instead of being read back from the
+// argmin / weight maps of an earlier launch.  Halo rows and lanes re-decide their pixels (same arithmetic as the owner:
+// the window sums are direction-symmetric and these kernels do not flip), so the outputs must not alias prev_min /
+// prev_arg.  The outputs (min_reproj / argmin / weight_out) ARRIVE holding the decision over the earlier candidates
+// (the pass in front of the producer wrote them, with its sums): this sweep overwrites them only at the pixels it
+// re-decides and leaves per-task DIFFERENCES of sum(rp*w), sum(w) -- a task the producer's region does not reach
+// writes zero gradients, zero differences and nothing else.
 template <bool FUSED>
-__global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams p) {
+MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
   constexpr int HALO = 2, CW = 60;
-  const int id = blockIdx.x;
-  const int task = (id & 7) * p.per_xcd + (id >> 3);
-  if (task >= p.ntasks) return;
   const int per_b = p.strips * p.segs;
   const int b = task / per_b, tt = task - b * per_b;
   const int seg = tt / p.strips, strip = tt - seg * p.strips;
@@ -214,23 +217,13 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
 #pragma unroll 8
     for (int rr = max(y_lo - 2, 0); rr <= min(y_hi + 1, H - 1); ++rr) any |= rgn[rr * W + gxr];
     if (!__any((any & 1u) && in_x)) {
-      for (int c = y_lo; c < y_hi; ++c) {
-        if (!out_x) continue;
-        const unsigned go = (unsigned)(c * W + gxr);
-        const float pm = ldf(p.prev_min + map_b, go * 4u);
-        float idn = ldf(p.ident + map_b, go * 4u);
-        if (p.noise) idn += ldf(p.noise + map_b, go * 4u) * 0.00001f;
-        const float w = (pm <= idn) ? 1.0f : 0.0f;
-        stf(p.min_reproj + map_b, go * 4u, pm);
-        p.argmin[map_b + go] = p.prev_arg[map_b + go];
-        stf(p.weight_out + map_b, go * 4u, w);
-        acc_rw += pm * w;
-        acc_w += w;
-        stf(ga, go * 4u, 0.f); stf(ga + HW, go * 4u, 0.f); stf(ga + 2 * (size_t)HW, go * 4u, 0.f);
-        if (gb) { stf(gb, go * 4u, 0.f); stf(gb + HW, go * 4u, 0.f); stf(gb + 2 * (size_t)HW, go * 4u, 0.f); }
-      }
-      const double r0 = wave_sum_d((double)acc_rw), r1 = wave_sum_d((double)acc_w);
-      if (lane == 0) { p.block_sums[(size_t)task * 2] = r0; p.block_sums[(size_t)task * 2 + 1] = r1; }
+      if (out_x)
+        for (int c = y_lo; c < y_hi; ++c) {
+          const unsigned go = (unsigned)(c * W + gxr);
+          stf(ga, go * 4u, 0.f); stf(ga + HW, go * 4u, 0.f); stf(ga + 2 * (size_t)HW, go * 4u, 0.f);
+          if (gb) { stf(gb, go * 4u, 0.f); stf(gb + HW, go * 4u, 0.f); stf(gb + 2 * (size_t)HW, go * 4u, 0.f); }
+        }
+      if (lane == 0) { p.block_sums[(size_t)task * 2] = 0.0; p.block_sums[(size_t)task * 2 + 1] = 0.0; }
       return;
     }
   }
@@ -335,8 +328,9 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
           stf(p.min_reproj + map_b, go * 4u, rp);
           p.argmin[map_b + go] = (uint8_t)win0;
           stf(p.weight_out + map_b, go * 4u, w);
-          acc_rw += rp * w;
-          acc_w += w;
+          const float w_old = (pm <= idn) ? 1.0f : 0.0f;  // what the pass over the earlier candidates decided and summed
+          acc_rw += rp * w - pm * w_old;
+          acc_w += w - w_old;
         }
       }
       const float kk = -w0 * (0.85f / 3.0f) * 0.5f;
@@ -406,6 +400,24 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
     const double r0 = wave_sum_d((double)acc_rw), r1 = wave_sum_d((double)acc_w);
     if (lane == 0) { p.block_sums[(size_t)task * 2] = r0; p.block_sums[(size_t)task * 2 + 1] = r1; }
   }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams p) {
+  if (FUSED && p.queue) {
+    // every wavefront reaches the exit: the counter only grows and each fetch is answered
+    for (;;) {
+      unsigned t = 0;
+      if (threadIdx.x == 0) t = atomicAdd(p.queue, 1u);
+      t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+      if (t >= (unsigned)p.ntasks) return;
+      photo_march_bwd_task<FUSED>(p, (int)t);
+    }
+  }
+  const int id = blockIdx.x;
+  const int task = (id & 7) * p.per_xcd + (id >> 3);
+  if (task >= p.ntasks) return;
+  photo_march_bwd_task<FUSED>(p, task);
 }
 
 // ---- get_smooth_loss (manydepth/layers.py:210-223) on the mean-normalised disparity (loss_utils.py:119-121) in one
@@ -575,6 +587,7 @@ static int device_slots() {
   return slots;
 }
 
+int g_syn_queue = 1;  // option "syn_queue": the fused sweep's tasks are fetched from a device counter (0: one task per workgroup)
 int g_syn_rows = 4;  // option "syn_rows": rows per task of the fused sweep when a region map makes most tasks leave early
 static void decompose(PhotoMarchParams& p, int cw, int waves_per_simd, int rows_min = 8) {
   p.strips = (p.W + cw - 1) / cw;
@@ -630,13 +643,15 @@ int photo_march_bwd(const float* target, const float* const* cand, int n_cand, c
 }
 
 // The temporal hint of the whole-step list in ONE sweep: candidates (cand0, cand1) = indices (idx0, idx0+1) join the
-// running min prev_min / prev_arg (which must not alias the outputs), automask against ident (+ noise), outputs
-// min_reproj / argmin / weight_out, per-task partials [task][2], and d sum(rp*w) / d candidate, unnormalised.
+// running min prev_min / prev_arg (read-only; must not alias the outputs), automask against ident (+ noise); the outputs
+// min_reproj / argmin / weight_out arrive holding the decision over the earlier candidates and are overwritten where this
+// pair is re-decided; per-task partials [task][2] = DIFFERENCES of sum(rp*w), sum(w) against that earlier decision; and
+// d sum(rp*w) / d candidate, unnormalised.  queue (nullable): a zeroed device word for the task queue.
 int photo_march_fused_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
                            const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
-                           float* g_region1) {
+                           float* g_region1, unsigned* queue) {
   if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
   PhotoMarchParams p = {};
   p.target = target; p.B = B; p.H = H; p.W = W;
@@ -650,7 +665,13 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
   if (region && g_syn_rows >= 2 && g_syn_rows < 8) decompose(p, 60, 8, g_syn_rows); else
   decompose(p, 60, 2);
   *per_sample_out = p.strips * p.segs;
-  hipLaunchKernelGGL(photo_march_bwd_kernel<true>, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
+  unsigned grid = (unsigned)p.per_xcd * 8u;
+  if (region && queue && g_syn_queue) {  // one resident round of wavefronts draining the task queue
+    p.queue = queue;
+    const unsigned round = (unsigned)device_slots() * 2u;
+    if (grid > round) grid = round;
+  }
+  hipLaunchKernelGGL(photo_march_bwd_kernel<true>, dim3(grid), dim3(64), 0, st, p);
   return launch_status();
 }
 

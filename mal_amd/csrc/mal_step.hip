@@ -26,7 +26,7 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
                            const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
-                           float* g_region1);
+                           float* g_region1, unsigned* queue);
 
 constexpr int kLossSlots = 16;
 
@@ -43,10 +43,11 @@ struct StepWs {
   unsigned char* arg_t; float* w_t; double* bs_ph;
   float* rp_warp; unsigned char* arg_warp;  // ... and min_f r(warp_f) / its winner as the pass in front of the producer leaves them
   double* ps;         // per-sample sums of the teacher's, then the student's partials: [2][B][8]
-  unsigned* ticket;   // completion counter of step_final_kernel
+  unsigned* ticket;   // completion counter of step_final_kernel; ticket[1]: task queue of the fused sweep (temporal hint)
   double* sm_stats;   // [4B]: mean_t[b], mean_s[b], corr_t[b], corr_s[b] of the mean-normalised smoothness
   float* coefs;       // 16 device scalars for the backward
   float* cam;         // [B][40] camera block of the marching kernels
+  float* bnd_t; float* bnd_s;  // boundary scratch rows of the teacher's / student's gradient pass (one-row halo, mal_march.h)
   size_t bytes;
 };
 
@@ -71,10 +72,12 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   w.rp_warp = (float*)take(map);
   w.arg_warp = (unsigned char*)take((size_t)B * HW);
   w.ps = (double*)take((size_t)2 * B * 8 * 8);
-  w.ticket = (unsigned*)take(4);
+  w.ticket = (unsigned*)take(8);
   w.sm_stats = (double*)take((size_t)4 * B * 8);
   w.coefs = (float*)take(16 * 4);
   w.cam = (float*)take((size_t)B * 40 * 4);
+  w.bnd_t = (float*)take(march_bnd_floats(B, H, W) * 4);
+  w.bnd_s = (float*)take(march_bnd_floats(B, H, W) * 4);
   w.bytes = o;
   return w;
 }
@@ -90,7 +93,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
 __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, const double* bs_s, const float* bgP,
                                                          const double* bs_p, int per_sample_p,
                                                          const double* bs_ph, int per_sample_ph,
-                                                         const float* K, int per_sample, int B, int H, int W,
+                                                         const float* K, int per_sample, int per_sample_t, int B, int H, int W,
                                                          float w_main, float w_distil, double* ps, float* gT0, float* gT1,
                                                          double* stats, float* losses, float* coefs, float* loss_total,
                                                          unsigned* ticket, unsigned long long* noise_counter) {
@@ -103,14 +106,21 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
     const int pass = blockIdx.x / B, b = blockIdx.x - pass * B;
     const int j = tid & 7, sub = tid >> 3;  // 32 strided partial sums per quantity
     // temporal hint: the teacher's sum(rp*w), sum(w) come from the materialised-candidate kernel ([task][2])
+    // temporal hint: the teacher's sums are those of the pass in front of the producer (bs_t, its own decomposition:
+    // per_sample_t tasks) plus the fused sweep's per-task differences ([task][2])
     const bool ph = pass == 0 && bs_ph != nullptr;
-    const double* bs = j < 4 ? (ph ? bs_ph + (size_t)b * per_sample_ph * 2 + (j & 1) : (pass ? bs_s : bs_t) + (size_t)b * per_sample * 8 + j)
+    const int ps_pass = pass ? per_sample : per_sample_t;
+    const double* bs = j < 4 ? (pass ? bs_s : bs_t) + (size_t)b * ps_pass * 8 + j
                              : bs_p + (size_t)b * per_sample_p * 8 + pass * 4 + (j - 4);
-    const int n_t = j < 4 ? (ph ? (j < 2 ? per_sample_ph : 0) : per_sample) : per_sample_p;
-    const size_t stride = (j < 4 && ph) ? 2 : 8;
+    const int n_t = j < 4 ? ps_pass : per_sample_p;
     double acc = 0.0;
 #pragma unroll 8
-    for (int t = sub; t < n_t; t += 32) acc += bs[(size_t)t * stride];  // independent loads: issue them together
+    for (int t = sub; t < n_t; t += 32) acc += bs[(size_t)t * 8];  // independent loads: issue them together
+    if (ph && j < 2) {
+      const double* bd = bs_ph + (size_t)b * per_sample_ph * 2 + j;
+#pragma unroll 8
+      for (int t = sub; t < per_sample_ph; t += 32) acc += bd[(size_t)t * 2];
+    }
     s_part[tid] = acc;
     __syncthreads();
     if (tid < 8) {
@@ -226,10 +236,10 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
                                                             int B, int HW, const float* gT0, const float* gT1,
                                                             float* gTs0, float* gTs1, float* g_disp_t, float* g_disp_s,
                                                             PoseParams pp, int pose_bwd, const float* bgP, const float* K,
-                                                            int per_sample) {
+                                                            int per_sample, int W, const float* bnd_t, const float* bnd_s,
+                                                            int rows, int segs, float* fix_t) {
   const float g = g_total ? *g_total : 1.0f;
   const float cRt = coefs[0] * g, cRs = coefs[1] * g, cS = coefs[4] * g;  // coefs[2], [3] are already inside G_cd
-  const size_t n = (size_t)B * HW;
   if (bgP) {
     // temporal hint: the teacher's sweep ran in this backward call, its pose partials are still per task: workgroup b
     // reduces sample b's (step_final_kernel's pose branch), scales and runs that sample's pose backward
@@ -267,12 +277,27 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
     if (pose_bwd)
       for (int i = threadIdx.x; i < B * 2; i += 256) pose_bwd_one(pp, i / B, i % B);
   }
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i / HW);
+  // one image row per workgroup round: the row index is wave-uniform, so is the test for a segment boundary whose
+  // gradient is completed by the neighbouring task's scratch row (one-row halo of the marching passes)
+  const int H = HW / W;
+  for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+    const int b = row / H, y = row - b * H;
     const float inv_t = div_(1.0f, (float)stats[b] + 1e-7f), inv_s = div_(1.0f, (float)stats[B + b] + 1e-7f);
     const float corr_t = (float)stats[2 * B + b], corr_s = (float)stats[3 * B + b];
-    if (g_disp_t) g_disp_t[i] = fma_(cRt, G_r_t[i], cS * (gn_t[i] * inv_t - corr_t));
-    if (g_disp_s) g_disp_s[i] = fma_(cRs, G_r_s[i], fma_(g, G_cd[i], cS * (gn_s[i] * inv_s - corr_s)));
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+      const size_t i = (size_t)row * W + x;
+      if (g_disp_t) {
+        const float G = bnd_t ? G_r_t[i] + march_boundary_term(bnd_t, b, y, x, H, W, rows, segs) : G_r_t[i];
+        g_disp_t[i] = fma_(cRt, G, cS * (gn_t[i] * inv_t - corr_t));
+      } else if (fix_t && bnd_t) {  // the teacher's sweep finished its own rows (temporal hint): add the neighbours' terms
+        const float v = march_boundary_term(bnd_t, b, y, x, H, W, rows, segs);
+        if (v != 0.f) fix_t[i] = fix_t[i] + cRt * v;
+      }
+      if (g_disp_s) {
+        const float G = bnd_s ? G_r_s[i] + march_boundary_term(bnd_s, b, y, x, H, W, rows, segs) : G_r_s[i];
+        g_disp_s[i] = fma_(cRs, G, fma_(g, G_cd[i], cS * (gn_s[i] * inv_s - corr_s)));
+      }
+    }
   }
 }
 
@@ -384,6 +409,7 @@ static int launch_ensemble(const mal_step_args* a, const StepWs& w, float* ens_r
 // warp pass (beside it, two ALU-bound passes only slow each other down: measured) and joined before the student pass,
 // which reads its map.  Fork / join through events: capturable into the caller's HIP graph.
 namespace mal { int g_step_overlap = 1; }  // option "step_overlap"
+namespace mal { int g_march_halo1 = 1; }   // option "march_halo1": one-row halo of the step's gradient passes (0: two rows, A/B)
 struct SideStream { hipStream_t s; hipEvent_t fork, join; bool ok; };
 static SideStream* side_stream() {
   static SideStream ss = {};
@@ -422,11 +448,15 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   if (rc) return rc;
   MarchParams p = teacher_params(a, w, w.rp_warp);
   p.block_sums = w.bs_t;
+  // ... with the automask: where no synthesised candidate can win, this IS the teacher's forward (min, winner, weight,
+  // sums); the fused sweep of mal_loss_step_fwd overwrites the second copies where it re-decides
+  p.ident = w.ident; p.noise = a->noise;
+  p.min_reproj2 = a->mono_reproj ? a->mono_reproj : w.mono_reproj; p.argmin_out2 = w.arg_t; p.weight_out = w.w_t;
   p.color_out[0] = a->warp_m1; p.color_out[1] = a->warp_p1; p.argmin_out = w.arg_warp;
   p.color_out_stride = a->warp_sample_stride;
   p.color_out2[0] = a->warp2_m1; p.color_out2[1] = a->warp2_p1;
   if ((a->warp2_m1 == nullptr) != (a->warp2_p1 == nullptr)) return MAL_EINVAL;
-  rc = march_launch(p, MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+  rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
   if (rc) return rc;
   if (ensemble_forked(a) && g_step_overlap == 1) {
     rc = fork_ensemble(a, w, st);
@@ -448,7 +478,12 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
 
   int per_sample_p = 1, per_sample_ph = 0;
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
-  int per_sample = 1;
+  int per_sample = 1, per_sample_t = 0;
+  {  // tasks per sample of the teacher's sums: its gradient pass, or (temporal hint) the forward pass in front of the producer
+    int strips = 0, segs = 0;
+    march_geometry(B, H, W, temporal ? 0 : MAL_F_GRAD, &strips, &segs, nullptr);
+    per_sample_t = strips * segs;
+  }
   if (!temporal) {
     rc = first_sweep(a, w, st, &per_sample_p);
     if (rc) return rc;
@@ -456,6 +491,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     MarchParams p = teacher_params(a, w, mono_reproj);
     p.ident = w.ident; p.noise = a->noise; p.g_reproj = w.G_r_t;
     p.block_sums = w.bs_t;
+    p.bnd = g_march_halo1 ? w.bnd_t : nullptr;
     p.dbg = a->dec_teacher;
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
     if (rc) return rc;
@@ -472,7 +508,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     per_sample_p = pack_identity_tasks_per_sample(H, W);
     rc = photo_march_fused_more(a->color0, a->syn_m1, a->syn_p1, 2, w.ident, a->noise, w.rp_warp, w.arg_warp, B, H, W,
                                 mono_reproj, w.arg_t, w.w_t, w.bs_ph, a->g_syn_m1, a->g_syn_p1, &per_sample_ph, st, a->syn_region,
-                                a->g_syn_region_m1, a->g_syn_region_p1);
+                                a->g_syn_region_m1, a->g_syn_region_p1, w.ticket + 1);
     if (rc) return rc;
   }
   // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp
@@ -497,6 +533,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.g_cons = w.G_c; p.g_distil = nullptr;  // one merged map: weights as coefs[2], coefs[3] of step_final_kernel
     p.merge_cons = (float)((double)a->w_main / ((double)B * H * W)); p.merge_distil = (float)((double)a->w_distil / ((double)B * H * W));
     p.block_sums = w.bs_s; p.block_gP = w.bgP;
+    p.bnd = g_march_halo1 ? w.bnd_s : nullptr;
     p.cam = w.cam; p.cam_ready = 1;
     p.dbg = a->dec_student;
     rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
@@ -506,7 +543,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   // per-sample sums of both gradient passes, pose gradients (temporal: in _bwd, after the teacher's sweep), scalars
   hipLaunchKernelGGL(step_final_kernel, dim3(temporal ? 2 * B : 3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, temporal ? nullptr : w.bgP,
                      w.bs_p, per_sample_p, temporal ? w.bs_ph : nullptr, per_sample_ph, a->K,
-                     per_sample, B, H, W,
+                     per_sample, per_sample_t, B, H, W,
                      a->w_main, a->w_distil, w.ps, w.gT[0], w.gT[1], w.sm_stats, a->losses, w.coefs, a->loss_total,
                      w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr);
   return launch_status();
@@ -531,14 +568,17 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
     // the loss scalars exist already: the sweep writes d total / d disp_teacher itself (the assembly does the student's)
     p.fin_gn = w.gn_t; p.fin_coefs = w.coefs; p.fin_stats = w.sm_stats; p.fin_g_total = a->g_total; p.fin_out = a->g_disp_teacher;
     teacher_done = a->g_disp_teacher != nullptr;
+    p.bnd = g_march_halo1 ? w.bnd_t : nullptr;
     p.dbg = a->dec_teacher;
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
     if (rc) return rc;
     per_sample_t = p.strips * p.segs;
   }
-  size_t g = ((size_t)B * HW + 255) / 256;
-  if (g > 2048) g = 2048;
+  size_t g = (size_t)B * H;  // a workgroup per image row
+  if (g > 4096) g = 4096;
   if (g < (size_t)B) g = (size_t)B;
+  int segs = 0, rows = 0;
+  march_geometry(B, H, W, MAL_F_GRAD, nullptr, &segs, &rows);  // the decomposition the gradient passes of this step used
   PoseParams pp = {};
   pp.B = B; pp.F = 2;
   pp.axisangle[0] = a->axisangle_m1; pp.axisangle[1] = a->axisangle_p1;
@@ -551,7 +591,8 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.gn_t,
                      w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
                      teacher_done ? nullptr : a->g_disp_teacher, a->g_disp_student, pp, pose_bwd, per_sample_t ? w.bgP : nullptr,
-                     a->K, per_sample_t);
+                     a->K, per_sample_t, W, g_march_halo1 ? w.bnd_t : nullptr, g_march_halo1 ? w.bnd_s : nullptr, rows, segs,
+                     teacher_done ? a->g_disp_teacher : nullptr);
   rc = launch_status();
   return rc;
 }

@@ -282,20 +282,23 @@ class FusedPassFn(Function):
 
 
 class DistilFn(Function):
-    """Consistency + distillation terms on materialised depth maps (loss_utils.py:193-254)."""
+    """Consistency + distillation terms on materialised depth maps (loss_utils.py:193-254).  ``ens_depth`` (--learn_ens,
+    :240-241): the learnt ensemble's depth, which then receives gradient where it wins the three-way min."""
 
     @staticmethod
-    def forward(ctx, multi_depth, mono_depth, multi_reproj, mono_reproj, ens_reproj, ext_mask, dual_distil):
+    def forward(ctx, multi_depth, mono_depth, multi_reproj, mono_reproj, ens_reproj, ext_mask, dual_distil, ens_depth=None):
         flags = L.F_DUAL_DISTIL if dual_distil else 0
-        need = multi_depth.requires_grad or (dual_distil and mono_depth.requires_grad)
-        sums, g_cons, g_dist, g_mono, ct = ops.distil_epilogue(multi_depth, mono_depth, multi_reproj, mono_reproj,
-                                                               ens_reproj, ext_mask, flags, need_grad=need)
+        need = multi_depth.requires_grad or (dual_distil and mono_depth.requires_grad) or \
+            (ens_depth is not None and ens_depth.requires_grad)
+        sums, g_cons, g_dist, g_third, ct = ops.distil_epilogue(multi_depth, mono_depth, multi_reproj, mono_reproj,
+                                                                ens_reproj, ext_mask, flags, need_grad=need, ens_depth=ens_depth)
         n = multi_depth.numel()
         means = ops.finish_scalars(sums[2:4], None, 0.0, 1.0 / float(n))
         e = multi_depth.new_empty(0)
         ctx.save_for_backward(g_cons if g_cons is not None else e, g_dist if g_dist is not None else e,
-                              g_mono if g_mono is not None else e)
+                              g_third if g_third is not None else e)
         ctx.n = n
+        ctx.learned = ens_depth is not None
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(ct)
         return means[0], means[1], ct
@@ -303,12 +306,16 @@ class DistilFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g_c, g_d, _g_ct):
-        G_c, G_d, G_m = ctx.saved_tensors
+        G_c, G_d, G_3 = ctx.saved_tensors
         inv = 1.0 / float(ctx.n)
-        g_multi = g_mono = None
+        g_multi = g_mono = g_ens = None
         terms = [(G, g) for G, g in ((G_c, g_c), (G_d, g_d)) if g is not None]
         if ctx.needs_input_grad[0] and terms and G_c.numel():
             g_multi = ops.axpy_maps([t[0] for t in terms], [_scalar(t[1]) for t in terms], None, [inv] * len(terms))
-        if ctx.needs_input_grad[1] and G_m.numel() and g_d is not None:
-            g_mono = ops.axpy_maps([G_m], [_scalar(g_d)], None, [inv])
-        return g_multi, g_mono, None, None, None, None, None
+        if G_3.numel() and g_d is not None:
+            third = ops.axpy_maps([G_3], [_scalar(g_d)], None, [inv])
+            if ctx.learned and ctx.needs_input_grad[7]:
+                g_ens = third
+            elif not ctx.learned and ctx.needs_input_grad[1]:
+                g_mono = third
+        return g_multi, g_mono, None, None, None, None, None, g_ens

@@ -113,9 +113,10 @@ def compute_main_losses(ssim, inputs, outputs, mono_reproj, ensemble_reproj, opt
     if getattr(opt, "pareto", False):
         raise NotImplementedError("opt.pareto needs manydepth/pareto.py, which upstream never committed "
                                   "(manydepth/loss_utils.py:3,256-265)")
-    if getattr(opt, "learn_ens", False) and ensemble_reproj is not None:
-        raise NotImplementedError("opt.learn_ens (loss_utils.py:240-241) needs a network head producing "
-                                  "outputs['ens_disp']; not part of the shipped RepDepth")
+    learned = bool(getattr(opt, "learn_ens", False)) and ensemble_reproj is not None
+    if learned and "ens_disp" not in outputs:
+        raise KeyError("opt.learn_ens reads outputs['ens_disp'], the learnt ensemble head's disparity (loss_utils.py:240-241; "
+                       "the shipped RepDepth has no such head: the caller's network provides it)")
     target = inputs[("color", 0, 0)]
     sources = [inputs[("color", -1, 0)], inputs[("color", 1, 0)]]
     B, _, H, W = target.shape
@@ -131,7 +132,7 @@ def compute_main_losses(ssim, inputs, outputs, mono_reproj, ensemble_reproj, opt
     with_syn = bool(multi_has_ins)
     ctx = None if with_syn else _ctx(outputs)
     want_ct = config.consistency_target
-    if ctx is not None and not dual:
+    if ctx is not None and not dual and not learned:
         cfg = (ctx.min_depth, ctx.max_depth, ctx.eps, ctx.convention, False, True, want_ct)
         reproj, cons, distil, multi_reproj, ct = Fn.FusedPassFn.apply(
             ctx.disp, ctx.T[0], ctx.T[1], ctx.K, ctx.inv_K, sources[0], sources[1], target, None, None, cmask,
@@ -146,7 +147,12 @@ def compute_main_losses(ssim, inputs, outputs, mono_reproj, ensemble_reproj, opt
         else:
             reproj, multi_reproj, _ = Fn.PhotoLossFn.apply(target, None, None, m, 0, *_candidates(outputs, with_syn))
         teacher = mono_depth if dual else mono_depth.detach()
-        cons, distil, ct = Fn.DistilFn.apply(outputs[("depth", 0, 0)], teacher, multi_reproj, mono_reproj, ens, m, dual)
+        ens_depth = None
+        if learned:  # the learnt ensemble's depth replaces (mono + multi) / 2 and receives gradient where it wins (:240-245)
+            from .layers import disp_to_depth
+            _, ens_depth = disp_to_depth(outputs["ens_disp"], opt.min_depth, opt.max_depth)
+        cons, distil, ct = Fn.DistilFn.apply(outputs[("depth", 0, 0)], teacher, multi_reproj, mono_reproj, ens, m, dual,
+                                             ens_depth)
     if want_ct and ct.numel():
         outputs["consistency_target/0"] = ct
     losses = {"consistency_loss/0": cons, "reproj_loss/0": reproj}

@@ -357,19 +357,31 @@ def pass_fused(disp, K, inv_K, Ts, srcs, target, ident=None, noise=None, ext_mas
 
 
 def distil_epilogue(multi_depth, mono_depth, multi_reproj, mono_reproj, ens_reproj, ext_mask, flags=0, need_grad=True,
-                    want_cons_target=True):
+                    want_cons_target=True, ens_depth=None):
+    """``ens_depth`` (--learn_ens): the learnt ensemble's depth map; then the fourth gradient returned is d/d ens_depth
+    (instead of d/d mono_depth of --dual_distil)."""
     multi_depth, mono_depth = _req(multi_depth, "multi_depth"), _req(mono_depth, "mono_depth")
     multi_reproj, mono_reproj = _req(multi_reproj, "multi_reproj"), _req(mono_reproj, "mono_reproj")
     ens_reproj, ext_mask = _req(ens_reproj, "ens_reproj"), _req(ext_mask, "ext_mask")
+    ens_depth = _req(ens_depth, "ens_depth")
     B, _, H, W = multi_depth.shape
     dev = multi_depth.device
     new = lambda: torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
     sums = torch.zeros(8, dtype=torch.float64, device=dev)
     g_cons = new() if need_grad else None
     g_dist = new() if need_grad else None
-    g_mono = new() if (need_grad and (flags & L.F_DUAL_DISTIL)) else None
     ct = new() if want_cons_target else None
     ws = workspace(dev, B, H, W)
+    if ens_depth is not None:
+        if ens_reproj is None or flags:
+            raise L.MalError("distil_epilogue: ens_depth (--learn_ens) needs ens_reproj and takes no flags")
+        g_ens = new() if need_grad else None
+        L.check(L.load().mal_distil_epilogue_learned(_p(multi_depth), _p(mono_depth), _p(ens_depth), _p(multi_reproj),
+                                                     _p(mono_reproj), _p(ens_reproj), _p(ext_mask), B, H, W, _p(sums), _p(g_cons),
+                                                     _p(g_dist), _p(g_ens), _p(ct), _p(ws), ws.numel(), _stream()),
+                "mal_distil_epilogue_learned")
+        return sums, g_cons, g_dist, g_ens, ct
+    g_mono = new() if (need_grad and (flags & L.F_DUAL_DISTIL)) else None
     L.check(L.load().mal_distil_epilogue(_p(multi_depth), _p(mono_depth), _p(multi_reproj), _p(mono_reproj),
                                          _p(ens_reproj), _p(ext_mask), B, H, W, flags, _p(sums), _p(g_cons), _p(g_dist),
                                          _p(g_mono), _p(ct), _p(ws), ws.numel(), _stream()), "mal_distil_epilogue")

@@ -205,4 +205,7 @@ def to_dicts(batch, pose_fn, device=None, requires_grad=True):
     outputs = {("disp", 0): leaves["disp_student"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1,
                "consistency_mask": mv(batch["consistency_mask"]), "augmentation_mask": mv(batch["augmentation_mask"]),
                "lowest_cost": mv(batch["lowest_cost"])}
+    if "disp_ens" in batch:  # --learn_ens: the ensemble head's disparity (trainer.py:596-597, loss_utils.py:240-241)
+        leaves["disp_ens"] = mv(batch["disp_ens"]).clone().requires_grad_(requires_grad)
+        outputs["ens_disp"] = leaves["disp_ens"]
     return inputs, mono_outputs, outputs, leaves

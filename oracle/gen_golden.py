@@ -149,7 +149,13 @@ def run_reference_step(ML, MLU, q, opt_kw, noise_seed, full, tag):
     # pass B (ensemble): trainer.py:594-600,1172-1207
     ensemble_reproj = None
     if not opt.no_ens:
-        disp_e = (mono_outputs[("disp", 0)].detach() + outputs[("disp", 0)].detach()) / 2.0
+        if opt.learn_ens:  # trainer.py:596-597: the learnt ensemble head's disparity (a leaf here), not detached
+            ens_leaf = q["disp_ens"].clone().requires_grad_(True)
+            outputs["ens_disp"] = ens_leaf
+            leaves["disp_ens"] = ens_leaf
+            disp_e = ens_leaf
+        else:
+            disp_e = (mono_outputs[("disp", 0)].detach() + outputs[("disp", 0)].detach()) / 2.0
         disp_e = F.interpolate(disp_e, [H, W], mode="bilinear", align_corners=False)
         _, depth_e = ML.disp_to_depth(disp_e, opt.min_depth, opt.max_depth)
         rr = []
@@ -201,6 +207,8 @@ def run_reference_step(ML, MLU, q, opt_kw, noise_seed, full, tag):
         g = t.grad if t.grad is not None else torch.zeros_like(t)
         summarize("grad/" + k, g, d, full)
     d.update(pack_inputs(q))
+    if "disp_ens" in q:
+        d["in/disp_ens"] = q["disp_ens"].half().numpy()
     d["opt"] = np.array(repr(sorted(opt_kw.items())))
     path = os.path.join(OUT, tag + ".npz")
     np.savez_compressed(path, **d)
@@ -381,17 +389,25 @@ def main():
     ML, MLU, DL = import_reference()
     from mal_amd.synthetic import make_batch
     torch.set_num_threads(8)
-    run_reference_layers(ML, MLU, DL, "layers_b2_24x40")
-    run_reference_layers(ML, MLU, DL, "layers_b1_19x33", B=1, H=19, W=33, seed=78)
     small = quantize_batch(make_batch(2, 32, 64, seed=1234))
-    run_reference_step(ML, MLU, small, {}, 1000, True, "step_b2_32x64_distil")
-    run_reference_step(ML, MLU, small, {"no_ens": True}, 1001, True, "step_b2_32x64_noens")
-    run_reference_step(ML, MLU, small, {"loss_blc": True}, 1002, True, "step_b2_32x64_lossblc")
-    run_reference_step(ML, MLU, small, {"no_ens": True, "dual_distil": True}, 1003, True, "step_b2_32x64_dual")
-    syn = quantize_batch(make_batch(2, 32, 64, seed=1235, with_syn=True))
-    run_reference_step(ML, MLU, syn, {"temporal": True}, 1004, True, "step_b2_32x64_temporal")
-    run_reference_step(ML, MLU, syn, {"temporal": True, "main_temporal": True}, 1005, True,
-                       "step_b2_32x64_temporal_main")
+    if sys.argv[1:] != ["learnens"]:  # `python -m oracle.gen_golden learnens` writes that one case only
+        run_reference_layers(ML, MLU, DL, "layers_b2_24x40")
+        run_reference_layers(ML, MLU, DL, "layers_b1_19x33", B=1, H=19, W=33, seed=78)
+        run_reference_step(ML, MLU, small, {}, 1000, True, "step_b2_32x64_distil")
+        run_reference_step(ML, MLU, small, {"no_ens": True}, 1001, True, "step_b2_32x64_noens")
+        run_reference_step(ML, MLU, small, {"loss_blc": True}, 1002, True, "step_b2_32x64_lossblc")
+        run_reference_step(ML, MLU, small, {"no_ens": True, "dual_distil": True}, 1003, True, "step_b2_32x64_dual")
+        syn = quantize_batch(make_batch(2, 32, 64, seed=1235, with_syn=True))
+        run_reference_step(ML, MLU, syn, {"temporal": True}, 1004, True, "step_b2_32x64_temporal")
+        run_reference_step(ML, MLU, syn, {"temporal": True, "main_temporal": True}, 1005, True,
+                           "step_b2_32x64_temporal_main")
+    only = sys.argv[1:]
+    le = dict(small)  # --learn_ens (loss_utils.py:240-241, trainer.py:596-597): a third disparity map stands in for the head's output
+    g = torch.Generator().manual_seed(99)
+    le["disp_ens"] = (0.55 * small["disp_teacher"] + 0.45 * small["disp_student"] + 0.01 * torch.randn(small["disp_teacher"].shape, generator=g)).clamp(0.01, 0.99).half().float()
+    run_reference_step(ML, MLU, le, {"learn_ens": True}, 1008, True, "step_b2_32x64_learnens")
+    if only == ["learnens"]:
+        return
     ragged = quantize_batch(make_batch(3, 37, 50, seed=1236))
     run_reference_step(ML, MLU, ragged, {}, 1006, True, "step_b3_37x50_distil")
     big = quantize_batch(make_batch(2, 192, 640, seed=1234))

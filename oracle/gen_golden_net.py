@@ -198,7 +198,7 @@ def run_repdepth(model, inputs, cot, aug_seed, train, min_bin=0.4, max_bin=9.0):
         d["out/cam_T_cam_%d_0" % f] = outputs[("cam_T_cam", f, 0)]
     for f in (0, -1, 1):
         d["grad/color_aug_%d" % f] = leaves[f].grad if leaves[f].grad is not None else torch.zeros_like(leaves[f])
-    return {k: np.asarray(torch.as_tensor(v).detach().float().numpy()) for k, v in d.items()}
+    return {k: np.asarray(torch.as_tensor(v).detach().float().cpu().numpy()) for k, v in d.items()}
 
 
 def main():

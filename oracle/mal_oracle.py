@@ -542,7 +542,10 @@ def mal_loss_step(opt, inputs, mono_outputs, outputs, noise_mono=None, noise_mai
                                    else forced["cmask"].to(outputs["consistency_mask"].dtype))
     ensemble_reproj = None
     if not opt.no_ens:
-        disp_ens = (mono_outputs[("disp", 0)].detach() + outputs[("disp", 0)].detach()) / 2.0
+        if opt.learn_ens:  # trainer.py:596-597: the learnt ensemble head's disparity, not detached
+            disp_ens = outputs["ens_disp"]
+        else:
+            disp_ens = (mono_outputs[("disp", 0)].detach() + outputs[("disp", 0)].detach()) / 2.0
         ensemble_reproj = generate_images_pred_ensemble(
             opt, inputs, outputs[("cam_T_cam", 0, -1)].detach(), outputs[("cam_T_cam", 0, 1)].detach(), disp_ens, aten)
     multi_has_ins = generate_images_pred(opt, inputs, outputs, is_multi=True, synth=synth, aten=aten, forced=fs)

@@ -10,7 +10,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 STEP_CASES = [
     "step_b2_32x64_distil", "step_b2_32x64_noens", "step_b2_32x64_lossblc", "step_b2_32x64_dual",
-    "step_b2_32x64_temporal", "step_b2_32x64_temporal_main", "step_b3_37x50_distil",
+    "step_b2_32x64_temporal", "step_b2_32x64_temporal_main", "step_b3_37x50_distil", "step_b2_32x64_learnens",
 ]
 BIG_CASE = "step_b2_192x640_distil"
 LAYER_CASES = ["layers_b2_24x40", "layers_b1_19x33"]
@@ -31,6 +31,8 @@ def batch_from_golden(z):
         b[k] = torch.from_numpy(z["in/" + k].copy())
     b["consistency_mask"] = torch.from_numpy(z["in/consistency_mask"].astype(np.float32))
     b["augmentation_mask"] = torch.from_numpy(z["in/augmentation_mask"].astype(np.float32))
+    if "in/disp_ens" in z:
+        b["disp_ens"] = torch.from_numpy(z["in/disp_ens"].astype(np.float32))
     if "in/syn_rects" in z:
         b["syn_rects"] = [tuple(int(v) for v in r) for r in z["in/syn_rects"]]
     return b

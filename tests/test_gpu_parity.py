@@ -119,6 +119,31 @@ def test_step_parity(tag, fuse):
     _check_case(tag, fuse, True)
 
 
+def test_learn_ens_gradient_reaches_the_ensemble_head():
+    """--learn_ens (loss_utils.py:240-241, trainer.py:596-600): the ensemble pass warps with outputs["ens_disp"], its depth is
+    the distillation target where the ensemble wins the three-way min, and THAT is where ens_disp receives gradient; held
+    against the reference's own numbers (the golden file) away from the near-tie pixels of the three-way argmin"""
+    z = G.load("step_b2_32x64_learnens")
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    n0, n1 = G.noises(z, (B, 1, H, W))
+    kw = G.opt_kwargs(z)
+    assert kw.get("learn_ens") is True and "disp_ens" in b
+    o = HH.run_oracle(b, kw, n0, n1)
+    assert np.array_equal(o["grads"]["disp_ens"], z["grad/disp_ens"])  # the oracle IS the reference here (bit for bit)
+    for fuse in (True, False):
+        h = HH.run_hip(b, kw, n0, n1, fuse=fuse)
+        amb = HH.near_tie(np.concatenate([o["mono_reproj"], o["ens"], o["multi_cands"].min(1, keepdims=True)], 1), 2e-4)
+        g, r = h["grads"]["disp_ens"], z["grad/disp_ens"]
+        assert np.abs(r).max() > 0 and (r != 0).mean() > 0.02          # the ensemble does win somewhere
+        assert ((g != 0) != (r != 0))[~amb].mean() == 0.0                # ... and the same pixels carry gradient
+        assert np.abs(g - r)[~amb].max() <= 1e-4 * np.abs(r).max(), np.abs(g - r)[~amb].max() / np.abs(r).max()
+        assert amb.mean() <= 0.05
+        gv = float(z["losses/distil_loss"])
+        allow = float((np.abs(o["mono_depth"] - o["multi_depth"]) * amb).sum() / (B * H * W)) * 2
+        assert abs(h["losses"]["distil_loss"] - gv) <= 1e-4 * abs(gv) + allow
+
+
 def test_step_parity_full_size():
     """B=2 192x640 (the size BASELINE.json's metric is quoted on, per sample)."""
     _check_case(G.BIG_CASE, True, False)
