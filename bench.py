@@ -75,15 +75,39 @@ def parse():
 N_GRAD_PARAMS = 41_247_150  # trainable fp32 parameters of RepDepth (tests/test_networks.py): 165 MB
 
 
+def visible_gpus():
+    """GPUs of this node WITHOUT touching HIP (the launcher process must stay free of the runtime): the KFD topology lists
+    every node, GPUs are the ones with SIMDs; ROCR/HIP_VISIBLE_DEVICES narrow it.  None if the topology is unreadable."""
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0  # no amdgpu compute driver on this machine at all
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as fh:
+                props = dict(l.split()[:2] for l in fh if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args):
     """`bench.py --gpus N` on its own: start the N ranks (one process per GPU) as children through
-    torch.distributed.run and relay rank 0's JSON line.  Runs before this process has made any HIP call (a process
-    that has initialised the GPU must not exec or be re-used as a launcher on this pool); a failing rank makes the
-    whole launch exit non-zero."""
+    torch.distributed.run and relay rank 0's JSON line.  This process makes no HIP call at all (the GPUs are counted from
+    the KFD topology in sysfs; a process that has initialised the GPU must not exec or be re-used as a launcher on this
+    pool); a failing rank makes the whole launch exit non-zero."""
     import socket
     import subprocess
-    if os.environ.get("MAL_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < args.gpus:
-        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
+    if os.environ.get("MAL_BENCH_BACKEND", "nccl") == "nccl":
+        n = visible_gpus()
+        if n is not None and n < args.gpus:  # unreadable topology: let the ranks fail with their own message
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, n))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

@@ -306,6 +306,10 @@ typedef struct mal_step_args {
                                              (mal_dyn_item.region_only) */
 } mal_step_args;
 int mal_loss_step_warp(const mal_step_args* args);
+/* A MAL_STEP_TEMPORAL step whose producer failed between mal_loss_step_warp and mal_loss_step_fwd: joins the ensemble
+ * pass that _warp forked onto the library's side stream back into args->stream (no-op when nothing is pending), so the
+ * next step cannot overwrite buffers that pass still reads and a stream capture does not end with unjoined work. */
+int mal_loss_step_abort(const mal_step_args* args);
 /* the same noise map on its own (tests; bit-identical to what the step draws for that seed / step) */
 int mal_tiebreak_noise(uint64_t seed, uint64_t step, int B, int H, int W, float* out, void* stream);
 enum {
@@ -407,6 +411,9 @@ typedef struct mal_dyn_item {
   /* backward, third form: g_ori_* are SNAPSHOTS valid at region pixels only (mal_step_args.g_syn_region_*), g_img_* the
    * buffers that hold the cotangent everywhere: one launch writes the region pixels of g_img_* (no scratch, no move) */
   int region_only;
+  /* rows of mask_last / mask_next (0 = unknown): with them a selection idx_*[i] outside [0, rows) is clamped into the
+   * tensor instead of being dereferenced (the torch indexing it replaces raised IndexError) */
+  int n_last, n_next;
 } mal_dyn_item;
 int mal_dyn_batch_fwd(const mal_dyn_item* items, int n_items, int C, int H, int W, int replace, void* stream);
 int mal_dyn_batch_bwd(const mal_dyn_item* items, int n_items, int C, int H, int W, void* stream);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "mal_loss_step_fwd": (i32, [vp]),
     "mal_loss_step_bwd": (i32, [vp]),
     "mal_loss_step_warp": (i32, [vp]),
+    "mal_loss_step_abort": (i32, [vp]),
     "mal_tiebreak_noise": (i32, [C.c_uint64, C.c_uint64, i32, i32, i32, c_fp, vp]),
     "mal_ms_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mal_loss_multiscale_fwd": (i32, [vp]),
@@ -108,7 +109,7 @@ class DynItem(C.Structure):
     _fields_ = [("mask_last", vp), ("mask_next", vp), ("num", i32), ("img_last", vp), ("img_next", vp),
                 ("ori_last", vp), ("ori_next", vp), ("delta", vp), ("flags", vp), ("ws", vp), ("ws_bytes", sz),
                 ("g_ori_last", vp), ("g_ori_next", vp), ("g_img_last", vp), ("g_img_next", vp), ("idx_last", vp), ("idx_next", vp),
-                ("prefilled", i32), ("g_tmp_last", vp), ("g_tmp_next", vp), ("region_only", i32)]
+                ("prefilled", i32), ("g_tmp_last", vp), ("g_tmp_next", vp), ("region_only", i32), ("n_last", i32), ("n_next", i32)]
 
 
 class StepArgs(C.Structure):

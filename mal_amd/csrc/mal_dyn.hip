@@ -23,11 +23,20 @@
 
 namespace mal {
 
+// row of the mask tensor that holds instance i (the torch indexing this replaces raised IndexError on a bad selection;
+// a kernel cannot: the index is clamped into the tensor, so nothing outside it is ever addressed)
+MAL_DEV size_t dyn_row(const long long* sel, int i, int rows) {
+  long long r = sel ? sel[i] : (long long)i;
+  if (rows > 0) r = r < 0 ? 0 : (r >= rows ? (long long)rows - 1 : r);
+  return (size_t)r;
+}
+
 struct DynParams {
   const uint8_t* mask_last; const uint8_t* mask_next;  // (num,H,W) bytes, non-zero = set
   // instance i is row idx_*[i] of the mask tensor (the matcher's selection, dyn_utils.py:147-150, applied here instead of
   // by one gather launch per sample and frame); nullptr = row i
   const long long* idx_last; const long long* idx_next;
+  int rows_last, rows_next;  // rows of the mask tensors (0 = not given): a selection outside [0, rows) is clamped, never read
   int num, C, H, W, replace;
   const float* img_last; const float* img_next;         // (C,H,W)
   float* ori_last; float* ori_next;
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(1024) void dyn_extents_kernel(DynBatch bt) {
   if (tid < 4) res[tid] = (tid & 1) ? 0x7fffffff : 0;  // low, top, right, left: max / min
   __syncthreads();
   const long long* sel = which ? p.idx_next : p.idx_last;
-  const uint8_t* m = (which ? p.mask_next : p.mask_last) + (size_t)(sel ? sel[i] : i) * ((size_t)H * W);
+  const uint8_t* m = (which ? p.mask_next : p.mask_last) + dyn_row(sel, i, which ? p.rows_next : p.rows_last) * ((size_t)H * W);
   auto mark = [&](int k) { rowf[k / W] = 1; colf[k % W] = 1; };  // same-value stores: benign races
   if ((HW & 15) == 0 && (k_lo & 15) == 0 && (reinterpret_cast<size_t>(m) & 15) == 0) {
     // masks are mostly empty: scan 16 bytes per load, look at the bytes only where a word is non-zero
@@ -106,7 +115,8 @@ __global__ __launch_bounds__(1024) void dyn_extents16_kernel(DynBatch bt) {
   if (tid < 4) res[tid] = (tid & 1) ? 0x7fffffff : 0;  // low, top, right, left: max / min
   __syncthreads();
   const long long* sel = which ? p.idx_next : p.idx_last;
-  const uint4* m16 = reinterpret_cast<const uint4*>((which ? p.mask_next : p.mask_last) + (size_t)(sel ? sel[i] : i) * ((size_t)H * W));
+  const uint4* m16 = reinterpret_cast<const uint4*>((which ? p.mask_next : p.mask_last) +
+                                                    dyn_row(sel, i, which ? p.rows_next : p.rows_last) * ((size_t)H * W));
   int rmax = 0, rmin = 0x7fffffff, cmax = 0, cmin = 0x7fffffff;
   for (int k = r_lo * W16 + tid; k < max(r_hi, r_lo) * W16; k += 1024) {
     const uint4 v = m16[k];
@@ -174,7 +184,7 @@ MAL_DEV void stage_instances(const DynParams& p, int* s_delta, bool from_ext) {
     if (!from_ext) s_delta[k] = p.delta[k];
     const int i = k >> 1;
     const long long* sel = (k & 1) ? p.idx_next : p.idx_last;
-    s_delta[2 * p.num + k] = sel ? (int)sel[i] : i;
+    s_delta[2 * p.num + k] = (int)dyn_row(sel, i, (k & 1) ? p.rows_next : p.rows_last);
   }
   __syncthreads();
 }
@@ -521,6 +531,7 @@ static int dyn_fwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, int
     DynParams& p = bt.s[k];
     p.mask_last = a.mask_last; p.mask_next = a.mask_next; p.num = a.num; p.C = C; p.H = H; p.W = W; p.replace = replace;
     p.idx_last = (const long long*)a.idx_last; p.idx_next = (const long long*)a.idx_next;
+    p.rows_last = a.n_last; p.rows_next = a.n_next;
     p.img_last = a.img_last; p.img_next = a.img_next; p.ori_last = a.ori_last; p.ori_next = a.ori_next;
     p.ext = (int*)a.ws; p.delta = a.delta; p.flags = a.flags; p.prefilled = a.prefilled;
     max_num = a.num > max_num ? a.num : max_num;
@@ -558,6 +569,7 @@ static int dyn_bwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, hip
     DynParams& p = bt.s[k];
     p.mask_last = a.mask_last; p.mask_next = a.mask_next; p.num = a.num; p.C = C; p.H = H; p.W = W;
     p.idx_last = (const long long*)a.idx_last; p.idx_next = (const long long*)a.idx_next;
+    p.rows_last = a.n_last; p.rows_next = a.n_next;
     p.delta = a.delta; p.flags = a.flags;
     p.g_ori_last = a.g_ori_last; p.g_ori_next = a.g_ori_next; p.g_img_last = a.g_img_last; p.g_img_next = a.g_img_next;
     p.g_tmp_last = a.g_tmp_last; p.g_tmp_next = a.g_tmp_next;

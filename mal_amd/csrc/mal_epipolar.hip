@@ -414,6 +414,11 @@ MAL_DEV void fix_add(unsigned long long* cell, float v, float to_fix) {
   atomicAdd(cell, (unsigned long long)q);
 }
 MAL_DEV float fix_value(unsigned long long cell, float lsb) { return (float)((double)(long long)cell * (double)lsb); }
+// The fixed-point scale comes from the largest |cotangent| (its float bits order like unsigned integers, and NaN / Inf
+// order above every finite value): a non-finite scale means a non-finite cotangent somewhere in the sample / plane.  The
+// float-atomic path this replaces (and autograd upstream) would carry it into the result; here the whole plane is
+// poisoned with NaN rather than silently written as zeros.
+MAL_DEV bool fix_scale_bad(float G) { return !(G < __builtin_huge_valf()); }
 
 // gmax[b] = max |x| over sample b's n values (bits of a non-negative float order like unsigned integers)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t n, unsigned* gmax) {
@@ -439,7 +444,8 @@ __global__ __launch_bounds__(kPlaneThreads) void epi_sample_bwd_planes_kernel(Ep
   const int cg = p.C / p.heads, head = c / cg;
   const float inv_cg = 1.0f / (float)cg;
   const float G = __uint_as_float(gmax[b]) * inv_cg;            // no contribution exceeds it (tap weights <= 1)
-  const float to_fix = G > 0.f ? div_(kFixOne, G) : 0.f, lsb = G > 0.f ? div_(G, kFixOne) : 0.f;
+  const bool bad = fix_scale_bad(G);
+  const float to_fix = (G > 0.f && !bad) ? div_(kFixOne, G) : 0.f, lsb = (G > 0.f && !bad) ? div_(G, kFixOne) : 0.f;
   const size_t plane1 = ((size_t)b * p.C + c) * hw;
   for (int pix = tid; pix < hw; pix += kPlaneThreads) {
     const float f1 = p.fmap1[plane1 + pix];
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(kPlaneThreads) void epi_sample_bwd_planes_kernel(Ep
     if (!out) continue;
     const int hwl = (p.h >> level) * (p.w >> level);
     out += ((size_t)b * p.C + c) * hwl;
-    for (int i = tid; i < hwl; i += kPlaneThreads) out[i] += fix_value(s_q[lo[level] + i], lsb);
+    for (int i = tid; i < hwl; i += kPlaneThreads) out[i] += bad ? __builtin_nanf("") : fix_value(s_q[lo[level] + i], lsb);
   }
 }
 
@@ -890,6 +896,7 @@ __global__ __launch_bounds__(kPlaneThreads) void epi_align_bwd_planes_kernel(Epi
   const char* pl = reinterpret_cast<const char*>(p.tgt + po);
   // two walks over the plane's pixels: the largest |d/d sample| first (the fixed-point scale), then the accumulation
   float to_fix = 0.f, lsb = 0.f;
+  bool bad = false;
   unsigned m = 0u;
   for (int pass = 0; pass < 2; ++pass) {
     for (int pix = tid; pix < hw; pix += kPlaneThreads) {
@@ -906,7 +913,8 @@ __global__ __launch_bounds__(kPlaneThreads) void epi_align_bwd_planes_kernel(Epi
       const float dgx = (2.0f * gx * cf[0] + gy * cf[1]) + r * cf[3], dgy = (2.0f * gy * cf[2] + gx * cf[1]) + r * cf[4];
       const float dr = (gx * cf[3] + gy * cf[4]) + 2.0f * r * cf[5];
       if (pass == 0) {
-        m = max(m, __float_as_uint(fmaxf(fabsf(dr), 0.5f * fmaxf(fabsf(dgx), fabsf(dgy)))));
+        // unsigned max of the bit patterns (not fmaxf, which drops a NaN operand): a non-finite term must win
+        m = max(max(m, __float_as_uint(fabsf(dr))), max(__float_as_uint(0.5f * fabsf(dgx)), __float_as_uint(0.5f * fabsf(dgy))));
       } else {
         const float df[5] = {-dr, 0.5f * dgx, -0.5f * dgx, 0.5f * dgy, -0.5f * dgy};
 #pragma unroll
@@ -923,12 +931,13 @@ __global__ __launch_bounds__(kPlaneThreads) void epi_align_bwd_planes_kernel(Epi
       unsigned mm = 0u;
       for (int k = 0; k < kPlaneThreads / 64; ++k) mm = max(mm, s_m[k]);
       const float G = __uint_as_float(mm);
-      to_fix = G > 0.f ? div_(kFixOne, G) : 0.f;
-      lsb = G > 0.f ? div_(G, kFixOne) : 0.f;
+      bad = fix_scale_bad(G);
+      to_fix = (G > 0.f && !bad) ? div_(kFixOne, G) : 0.f;
+      lsb = (G > 0.f && !bad) ? div_(G, kFixOne) : 0.f;
     }
   }
   __syncthreads();
-  for (int i = tid; i < hw; i += kPlaneThreads) p.g_tgt[po + i] += fix_value(s_q[i], lsb);
+  for (int i = tid; i < hw; i += kPlaneThreads) p.g_tgt[po + i] += bad ? __builtin_nanf("") : fix_value(s_q[i], lsb);
 }
 
 // x = A^-1 rhs as PoseUpdate.direct_align does it (utils.py:357-368): Cholesky, else LU with partial pivoting, else failure.
@@ -1180,8 +1189,10 @@ static size_t plane_lds_limit(const void* kernel) {
     else
       limit = 64 * 1024;
   }
-  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit);
-  (void)hipGetLastError();
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit) != hipSuccess) {
+    (void)hipGetLastError();
+    return limit < (size_t)64 * 1024 ? limit : (size_t)64 * 1024;  // the default stays in force: larger planes take the atomic path
+  }
   return limit;
 }
 

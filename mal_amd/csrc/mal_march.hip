@@ -910,7 +910,7 @@ __global__ __launch_bounds__(64, 3) void pack_identity_kernel(IdentParams p) {
   const int id = blockIdx.x;
   if (id >= p.per_xcd * 8) {  // whole-step list: poses of both frames and the camera block of sample b
     const int b = id - p.per_xcd * 8, tid = threadIdx.x;
-    if (b == 0 && tid == 0) { p.sp.ticket[0] = 0u; p.sp.ticket[1] = 0u; }  // completion counter of step_final_kernel, task queue of the fused sweep
+    if (b == 0 && tid < 3) p.sp.ticket[tid] = 0u;  // completion counter of step_final_kernel, [1..2]: counts of the fused sweep's task order
     if (tid < 2) pose_fwd_one(p.sp.pose, tid, b);
     __syncthreads();  // T of this sample, written by threads 0/1 to global memory, is visible to the block
     cam_fill(p.sp.K, p.sp.pose.T[0], p.sp.pose.T[1], p.sp.invK, p.sp.cam, b, tid);

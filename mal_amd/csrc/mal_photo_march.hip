@@ -39,9 +39,12 @@ struct PhotoMarchParams {
   // FUSED with a region map, nullable: a second copy of the gradient, written ONLY at region pixels -- the snapshot the
   // producer's in-place backward gathers from while it overwrites g_cand at those very pixels
   float* g_region[2];
-  // FUSED: task queue (a device word the step's first launch resets): wavefronts fetch tasks until it runs out, so the few
-  // tasks that do the full work spread over the chip instead of setting the duration of every resident round
-  unsigned* queue;
+  // FUSED with a region map: the order the tasks are dispatched in.  A classification launch (one wavefront per task: does
+  // the producer's region come near its tile?) writes the tasks that do the full work to the front of `order` and the
+  // others to its back (order_count[0..1] = how many of each, reset by the step's first launch); workgroup i then takes
+  // task order[i], so the few expensive tasks are all resident from the start instead of each of three rounds of
+  // workgroups waiting for its slowest member.  Which position a task gets depends on timing; what it computes does not.
+  unsigned* order; unsigned* order_count;
 };
 
 struct Px9 { float t[3], a[3], c[3]; };
@@ -404,20 +407,37 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
 
 template <bool FUSED>
 __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams p) {
-  if (FUSED && p.queue) {
-    // every wavefront reaches the exit: the counter only grows and each fetch is answered
-    for (;;) {
-      unsigned t = 0;
-      if (threadIdx.x == 0) t = atomicAdd(p.queue, 1u);
-      t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-      if (t >= (unsigned)p.ntasks) return;
-      photo_march_bwd_task<FUSED>(p, (int)t);
-    }
-  }
   const int id = blockIdx.x;
+  if (FUSED && p.order) {  // grid = ntasks exactly
+    photo_march_bwd_task<FUSED>(p, (int)p.order[id]);
+    return;
+  }
   const int task = (id & 7) * p.per_xcd + (id >> 3);
   if (task >= p.ntasks) return;
   photo_march_bwd_task<FUSED>(p, task);
+}
+
+// one wavefront per task of the fused sweep's decomposition: the test photo_march_bwd_task<true> opens with
+__global__ __launch_bounds__(64) void photo_march_classify_kernel(PhotoMarchParams p) {
+  constexpr int HALO = 2, CW = 60;
+  const int task = blockIdx.x;
+  if (task >= p.ntasks) return;
+  const int per_b = p.strips * p.segs;
+  const int b = task / per_b, tt = task - b * per_b;
+  const int seg = tt / p.strips, strip = tt - seg * p.strips;
+  const int H = p.H, W = p.W, lane = threadIdx.x;
+  const int y_lo = seg * p.rows, y_hi = min(y_lo + p.rows, H);
+  const int gx = strip * CW - HALO + lane;
+  const bool in_x = gx >= 0 && gx < W;
+  const int gxr = min(max(reflect1(gx, W), 0), W - 1);
+  const uint8_t* rgn = p.region + (size_t)b * H * W;
+  unsigned any = 0u;
+  for (int rr = max(y_lo - 2, 0); rr <= min(y_hi + 1, H - 1); ++rr) any |= rgn[rr * W + gxr];
+  const bool active = __any((any & 1u) && in_x);
+  if (lane == 0) {
+    const unsigned pos = atomicAdd(p.order_count + (active ? 0 : 1), 1u);
+    p.order[active ? pos : (unsigned)p.ntasks - 1u - pos] = (unsigned)task;
+  }
 }
 
 // ---- get_smooth_loss (manydepth/layers.py:210-223) on the mean-normalised disparity (loss_utils.py:119-121) in one
@@ -587,7 +607,7 @@ static int device_slots() {
   return slots;
 }
 
-int g_syn_queue = 1;  // option "syn_queue": the fused sweep's tasks are fetched from a device counter (0: one task per workgroup)
+int g_syn_queue = 1;  // option "syn_queue": the fused sweep dispatches the tasks that do the full work first (0: in task order)
 int g_syn_rows = 4;  // option "syn_rows": rows per task of the fused sweep when a region map makes most tasks leave early
 static void decompose(PhotoMarchParams& p, int cw, int waves_per_simd, int rows_min = 8) {
   p.strips = (p.W + cw - 1) / cw;
@@ -646,12 +666,12 @@ int photo_march_bwd(const float* target, const float* const* cand, int n_cand, c
 // running min prev_min / prev_arg (read-only; must not alias the outputs), automask against ident (+ noise); the outputs
 // min_reproj / argmin / weight_out arrive holding the decision over the earlier candidates and are overwritten where this
 // pair is re-decided; per-task partials [task][2] = DIFFERENCES of sum(rp*w), sum(w) against that earlier decision; and
-// d sum(rp*w) / d candidate, unnormalised.  queue (nullable): a zeroed device word for the task queue.
+// d sum(rp*w) / d candidate, unnormalised.  order (nullable): >= ntasks device words, order_count: two zeroed words.
 int photo_march_fused_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
                            const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
-                           float* g_region1, unsigned* queue) {
+                           float* g_region1, unsigned* order, unsigned* order_count) {
   if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
   PhotoMarchParams p = {};
   p.target = target; p.B = B; p.H = H; p.W = W;
@@ -666,10 +686,10 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
   decompose(p, 60, 2);
   *per_sample_out = p.strips * p.segs;
   unsigned grid = (unsigned)p.per_xcd * 8u;
-  if (region && queue && g_syn_queue) {  // one resident round of wavefronts draining the task queue
-    p.queue = queue;
-    const unsigned round = (unsigned)device_slots() * 2u;
-    if (grid > round) grid = round;
+  if (region && order && order_count && g_syn_queue) {  // expensive tasks first (see PhotoMarchParams::order)
+    p.order = order; p.order_count = order_count;
+    grid = (unsigned)p.ntasks;
+    hipLaunchKernelGGL(photo_march_classify_kernel, dim3(grid), dim3(64), 0, st, p);
   }
   hipLaunchKernelGGL(photo_march_bwd_kernel<true>, dim3(grid), dim3(64), 0, st, p);
   return launch_status();

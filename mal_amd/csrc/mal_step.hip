@@ -26,7 +26,7 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
                            const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
-                           float* g_region1, unsigned* queue);
+                           float* g_region1, unsigned* order, unsigned* order_count);
 
 constexpr int kLossSlots = 16;
 
@@ -43,7 +43,8 @@ struct StepWs {
   unsigned char* arg_t; float* w_t; double* bs_ph;
   float* rp_warp; unsigned char* arg_warp;  // ... and min_f r(warp_f) / its winner as the pass in front of the producer leaves them
   double* ps;         // per-sample sums of the teacher's, then the student's partials: [2][B][8]
-  unsigned* ticket;   // completion counter of step_final_kernel; ticket[1]: task queue of the fused sweep (temporal hint)
+  unsigned* ticket;   // completion counter of step_final_kernel; ticket[1..2]: counts of the fused sweep's task order
+  unsigned* order;    // dispatch order of the fused sweep's tasks (temporal hint, region map given)
   double* sm_stats;   // [4B]: mean_t[b], mean_s[b], corr_t[b], corr_s[b] of the mean-normalised smoothness
   float* coefs;       // 16 device scalars for the backward
   float* cam;         // [B][40] camera block of the marching kernels
@@ -72,7 +73,8 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   w.rp_warp = (float*)take(map);
   w.arg_warp = (unsigned char*)take((size_t)B * HW);
   w.ps = (double*)take((size_t)2 * B * 8 * 8);
-  w.ticket = (unsigned*)take(8);
+  w.ticket = (unsigned*)take(16);
+  w.order = (unsigned*)take(nb * 4 * sizeof(unsigned));  // tasks of >= 2 rows, as bs_ph
   w.sm_stats = (double*)take((size_t)4 * B * 8);
   w.coefs = (float*)take(16 * 4);
   w.cam = (float*)take((size_t)B * 40 * 4);
@@ -410,18 +412,29 @@ static int launch_ensemble(const mal_step_args* a, const StepWs& w, float* ens_r
 // which reads its map.  Fork / join through events: capturable into the caller's HIP graph.
 namespace mal { int g_step_overlap = 1; }  // option "step_overlap"
 namespace mal { int g_march_halo1 = 1; }   // option "march_halo1": one-row halo of the step's gradient passes (0: two rows, A/B)
-struct SideStream { hipStream_t s; hipEvent_t fork, join; bool ok; };
+struct SideStream { hipStream_t s; hipEvent_t fork, join; bool ok, init, pending; };
+// one per device (created on first use on THAT device); `pending`: a fork whose join has not been enqueued yet
 static SideStream* side_stream() {
-  static SideStream ss = {};
-  static bool init = false;
-  if (!init) {
-    init = true;
+  constexpr int kMaxDev = 64;
+  static SideStream all[kMaxDev] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return nullptr; }
+  SideStream& ss = all[dev];
+  if (!ss.init) {
+    ss.init = true;
     ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
     (void)hipGetLastError();
   }
   return ss.ok ? &ss : nullptr;
+}
+// the caller's stream waits for the forked ensemble pass; every path that leaves a step after the fork goes through here
+static int join_side(hipStream_t st) {
+  SideStream* ss = side_stream();
+  if (!ss || !ss->pending) return MAL_OK;
+  ss->pending = false;
+  return hipStreamWaitEvent(st, ss->join, 0) == hipSuccess ? MAL_OK : MAL_ELAUNCH;
 }
 static bool ensemble_forked(const mal_step_args* a) {
   return g_step_overlap && (a->flags & MAL_STEP_TEMPORAL) && !(a->flags & MAL_STEP_NO_ENS) && side_stream() != nullptr;
@@ -431,8 +444,17 @@ static int fork_ensemble(const mal_step_args* a, const StepWs& w, hipStream_t st
   SideStream* ss = side_stream();
   if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return MAL_ELAUNCH;
   int rc = launch_ensemble(a, w, a->ens_reproj ? a->ens_reproj : w.ens_reproj, ss->s);
-  if (rc) return rc;
-  return hipEventRecord(ss->join, ss->s) == hipSuccess ? MAL_OK : MAL_ELAUNCH;
+  if (hipEventRecord(ss->join, ss->s) != hipSuccess) return rc ? rc : MAL_ELAUNCH;
+  ss->pending = true;  // whatever was enqueued on the side stream is joined before the step's buffers are reused
+  return rc;
+}
+
+// A step that called mal_loss_step_warp but will not call mal_loss_step_fwd (its producer raised): join the forked
+// ensemble pass, so that the next step's first launch cannot overwrite buffers the pass still reads and a stream
+// capture does not end with unjoined work.
+extern "C" int mal_loss_step_abort(const mal_step_args* a) {
+  if (!a) return MAL_EINVAL;
+  return join_side((hipStream_t)a->stream);
 }
 
 // MAL_STEP_TEMPORAL, first call: the first sweep and the teacher's warped images (forward only: the per-pixel min over
@@ -443,6 +465,8 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   if (!(a->flags & MAL_STEP_TEMPORAL) || !a->warp_m1 || !a->warp_p1) return MAL_EINVAL;
   StepWs w = carve_step(a->ws, a->B, a->H, a->W);
   hipStream_t st = (hipStream_t)a->stream;
+  rc = join_side(st);  // a previous step that was abandoned after its fork (no _fwd, no _abort)
+  if (rc) return rc;
   int per_sample_p = 1;
   rc = first_sweep(a, w, st, &per_sample_p);
   if (rc) return rc;
@@ -500,7 +524,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     // synthesised images join the running min (first minimum wins, as torch.min over [warp-1, warp+1, syn-1, syn+1],
     // loss_utils.py:79-90,103), the automask and the teacher's sums are formed over all four, and the gradient w.r.t.
     // the synthesised images leaves unnormalised
-    if (!a->syn_m1 || !a->syn_p1 || !a->g_syn_m1 || !a->g_syn_p1) return MAL_EINVAL;
+    if (!a->syn_m1 || !a->syn_p1 || !a->g_syn_m1 || !a->g_syn_p1) { (void)join_side(st); return MAL_EINVAL; }
     if (ensemble_forked(a) && g_step_overlap == 2) {
       rc = fork_ensemble(a, w, st);
       if (rc) return rc;
@@ -508,13 +532,14 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     per_sample_p = pack_identity_tasks_per_sample(H, W);
     rc = photo_march_fused_more(a->color0, a->syn_m1, a->syn_p1, 2, w.ident, a->noise, w.rp_warp, w.arg_warp, B, H, W,
                                 mono_reproj, w.arg_t, w.w_t, w.bs_ph, a->g_syn_m1, a->g_syn_p1, &per_sample_ph, st, a->syn_region,
-                                a->g_syn_region_m1, a->g_syn_region_p1, w.ticket + 1);
-    if (rc) return rc;
+                                a->g_syn_region_m1, a->g_syn_region_p1, w.order, w.ticket + 1);
+    if (rc) { (void)join_side(st); return rc; }
   }
   // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp
   if (!no_ens) {
     if (ensemble_forked(a)) {
-      if (hipStreamWaitEvent(st, side_stream()->join, 0) != hipSuccess) return MAL_ELAUNCH;
+      rc = join_side(st);
+      if (rc) return rc;
     } else {
       rc = launch_ensemble(a, w, ens_reproj, st);
       if (rc) return rc;

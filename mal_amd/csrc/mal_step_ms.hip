@@ -54,7 +54,7 @@ static MsWs carve_ms(void* base, int B, int H, int W, int sclm) {
   for (int i = 0; i < 3; ++i) w.packed[i] = (float*)take(B * HW * kTexel * sizeof(float));
   for (int f = 0; f < 2; ++f) { w.T[f] = (float*)take(B * 16 * 4); w.gTs[f] = (float*)take(B * 16 * 4); }
   w.cam = (float*)take((size_t)B * kCamFloats * 4);
-  w.ticket = (unsigned*)take(8);  // [1]: reset by the shared first launch too (the one-call step's task queue)
+  w.ticket = (unsigned*)take(16);  // [1]: reset by the shared first launch too (the one-call step's task queue)
   w.ident = (float*)take(map); w.cmask = (float*)take(map);
   for (int s = 0; s < S; ++s) {
     w.noise[s] = (float*)take(map);

@@ -150,6 +150,7 @@ class BatchSynthesisFn(Function):
             a.img_last, a.img_next, a.ori_last, a.ori_next = p(cl[b]), p(cn[b]), p(syn_last[b]), p(syn_next[b])
             a.delta, a.flags, a.ws, a.ws_bytes = p(delta), p(flags), p(ws), ws.numel()
             a.idx_last, a.idx_next = p(idx_last), p(idx_next)
+            a.n_last, a.n_next = int(ml.shape[0]), int(mn.shape[0])  # a selection outside the tensor is clamped, never read
             a.prefilled = 1 if prefilled is not None else 0
             saved.append((b, ml, mn, num, delta, flags, ws, idx_last, idx_next))
         # all samples in one call: three launches (extents, displacements, synthesis) for up to 16 samples
@@ -185,6 +186,7 @@ class BatchSynthesisFn(Function):
             a = arr[k]
             a.mask_last, a.mask_next, a.num, a.delta, a.flags = p(ml), p(mn), num, p(delta), p(flags)
             a.idx_last, a.idx_next = p(idx_last), p(idx_next)
+            a.n_last, a.n_next = int(ml.shape[0]), int(mn.shape[0])
             a.g_ori_last, a.g_ori_next, a.g_img_last, a.g_img_next = p(g_last[b]), p(g_next[b]), p(gl[b]), p(gn[b])
             if snap_l is not None:
                 a.g_ori_last, a.g_ori_next, a.region_only = p(snap_l[b]), p(snap_n[b]), 1

@@ -154,11 +154,15 @@ class TemporalLossStepFn(Function):
         a.warp2_m1, a.warp2_p1 = pre[0].data_ptr(), pre[1].data_ptr()
         lib = L.load()
         L.check(lib.mal_loss_step_warp(C.byref(a)), "mal_loss_step_warp")
-        with torch.enable_grad():
-            leaf = [w.detach().requires_grad_(True) for w in warp]
-            local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1], ("color_pair", 0): pair,
-                     ("syn_prefilled", 0): (pre[0], pre[1])}
-            has_ins = bool(synth(inputs, local, 0))
+        try:
+            with torch.enable_grad():
+                leaf = [w.detach().requires_grad_(True) for w in warp]
+                local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1], ("color_pair", 0): pair,
+                         ("syn_prefilled", 0): (pre[0], pre[1])}
+                has_ins = bool(synth(inputs, local, 0))
+        except BaseException:  # the producer raised: join what mal_loss_step_warp forked before the buffers are reused
+            lib.mal_loss_step_abort(C.byref(a))
+            raise
         region = snap = None
         if has_ins:
             syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]

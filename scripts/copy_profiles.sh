@@ -5,6 +5,8 @@ R=${1:-r02}
 O=gpurun_out/refresh
 P=profiles
 cp $O/bench.json $P/${R}_bench.json
+[ -f $O/bench_driver.json ] && cp $O/bench_driver.json $P/${R}_bench_driver_command.json
+[ -f mal_amd/lib/valu_cost.json ] && cp mal_amd/lib/valu_cost.json $P/${R}_valu_cost.json
 cp $O/bench_distil.json $P/${R}_bench_distil.json
 cp $O/bench_multiscale.json $P/${R}_bench_multiscale.json
 cp $O/stats/s_kernel_stats.csv $P/${R}_kernel_stats.csv

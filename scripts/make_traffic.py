@@ -1,5 +1,5 @@
 """profiles/traffic.json from the two PMC passes (FETCH_SIZE, WRITE_SIZE; KB per launch) of scripts/gpu_step_target.py.
-usage: make_traffic.py fetch.csv write.csv out.json"""
+usage: make_traffic.py fetch.csv write.csv out.json [bench.json of the same box: stamps its clock and kernel time]"""
 import csv, json, sys, collections
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
@@ -28,5 +28,12 @@ if temporal:
 if teacher:
     out["pass_kernel_teacher_bytes_per_launch"] = out["kernels"][teacher[0]]["hbm_bytes_per_launch"]
 out["algorithmic_teacher_bytes_per_launch"] = 96 * B * H * W
+if len(sys.argv) > 4:  # the bench line measured on the same box in the same refresh: its sustained clock and kernel time
+    try:
+        d = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+        out["same_box"] = {"shader_clock_mhz": d["roofline"].get("valu", {}).get("shader_clock_mhz"),
+                           "teacher_kernel_ms_events": d["roofline"]["kernel_ms"], "ms_per_step": d["ms_per_step"]}
+    except Exception as ex:
+        out["same_box"] = {"error": str(ex)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

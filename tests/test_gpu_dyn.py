@@ -238,3 +238,20 @@ def test_step_with_the_region_map_equals_the_dense_path():
     syn_won = (win_sparse & 3) >= 2
     assert not bool((syn_won & ~near).any())          # with the map: never outside the dilated region
     assert bool((syn_won & near).any())               # ... and the synthesised candidates do win somewhere inside
+
+
+def test_selection_outside_the_mask_tensor_is_clamped():
+    """the matcher's int64 selections are applied inside the kernels; torch indexing raised IndexError on a bad one, a
+    kernel cannot -- the row is clamped into the tensor (mal_dyn_item.n_last / n_next), nothing outside it is addressed"""
+    from mal_amd import dyn_utils
+    from oracle.gen_golden_dyn import make_masks
+    B, H, W = 1, 24, 40
+    g = torch.Generator().manual_seed(3)
+    cl, cn = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    ml, mn = make_masks(3, H, W, seed=5, edge_cases=False)
+    ml, mn = ml.to(DEV), mn.to(DEV)
+    idx = lambda v: torch.tensor(v, dtype=torch.int64, device=DEV)
+    bad = dyn_utils.BatchSynthesisFn.apply(cl, cn, [(0, ml, mn, idx([7, -4, 1]), idx([99, 0, 1]))], False)
+    ok = dyn_utils.BatchSynthesisFn.apply(cl, cn, [(0, ml, mn, idx([2, 0, 1]), idx([2, 0, 1]))], False)
+    torch.cuda.synchronize()
+    assert torch.equal(bad[0], ok[0]) and torch.equal(bad[1], ok[1])

@@ -330,3 +330,23 @@ def test_direct_align_vjp_pieces_dualrefine_size(robust):
         for s in range(B):
             sc = float(ref[k][s].abs().max())
             assert float((got[k][s] - ref[k][s]).abs().max()) <= 2e-3 * sc + 1e-7, (k, s)
+
+
+def test_non_finite_cotangent_poisons_the_feature_gradient():
+    """the feature cotangents are accumulated in fixed point scaled by the largest |cotangent| of the sample: a NaN / Inf
+    there once turned the scale into zero and the result into silent zeros.  Upstream's autograd (and the float-atomic path)
+    carry the non-finite value into the result: the sample whose cotangent holds it must come back non-finite, the other
+    sample untouched."""
+    from tests.test_epi_oracle import GOLDEN
+    import os
+    tag = "epi_grad_b2_c16_12x20_r4_l3"
+    z, K, depth, poses, f1, f2, r, L, heads, delta = load(tag.replace("epi_grad_", "epi_"))
+    zg = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    t = lambda k: torch.from_numpy(zg[k])
+    clean = run_grads(K, depth, poses, f1, f2, r, L, heads, float(delta), t("in/w_corr"), t("in/w_ds"), t("in/w_mx"))
+    for bad_value in (float("nan"), float("inf")):
+        w = t("in/w_corr").clone()
+        w[1, 3, 2, 5] = bad_value
+        got = run_grads(K, depth, poses, f1, f2, r, L, heads, float(delta), w, t("in/w_ds"), t("in/w_mx"))
+        assert not torch.isfinite(got["f2"][1]).all(), bad_value          # not silently zero / finite garbage
+        assert torch.isfinite(got["f2"][0]).all() and torch.equal(got["f2"][0], clean["f2"][0])

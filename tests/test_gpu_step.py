@@ -178,3 +178,38 @@ def test_temporal_step_without_instances_equals_the_distil_step(tag):
     for k, t in leaves.items():
         g = (t.grad if t.grad is not None else torch.zeros_like(t)).cpu().numpy()
         assert np.abs(g - ref["grads"][k]).max() <= 2e-5 * np.abs(ref["grads"][k]).max(), k
+
+
+def test_a_raising_producer_leaves_the_library_usable():
+    """opt.temporal: mal_loss_step_warp forks the ensemble pass onto a side stream; if the producer then raises, the step
+    joins it (mal_loss_step_abort) before the exception travels on, and the next step runs as if nothing had happened"""
+    from mal_amd import step, trainer
+    z = G.load("step_b2_32x64_distil")
+    b = G.batch_from_golden(z)
+    B, _, H, W = b["color0"].shape
+    n0, _ = G.noises(z, (B, 1, H, W))
+    dev = torch.device("cuda:0")
+    opt = trainer.default_options(height=H, width=W, batch_size=B, temporal=True)
+
+    def run(producer):
+        inputs, mono_outputs, outputs, leaves = to_dicts(b, lambda a, t, inv: None, device=dev)
+        for f, s in ((-1, "m1"), (1, "p1")):
+            mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + s]
+            mono_outputs[("translation", 0, f)] = leaves["translation_" + s]
+        losses, _, _ = step.loss_step(opt, inputs, mono_outputs, outputs, w_list=[0.7, 0.3], noise=n0.to(dev), image_synthesis=producer)
+        losses["loss"].backward()
+        torch.cuda.synchronize()
+        return float(losses["loss"]), leaves["disp_teacher"].grad.cpu().numpy()
+
+    class Boom(Exception):
+        pass
+
+    def raising(inputs_, outputs_, scale):
+        raise Boom("segmenter failed")
+
+    ref = run(lambda i, o, s: False)
+    for _ in range(2):
+        with pytest.raises(Boom):
+            run(raising)
+    again = run(lambda i, o, s: False)
+    assert again[0] == ref[0] and np.array_equal(again[1], ref[1])
