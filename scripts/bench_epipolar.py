@@ -108,3 +108,23 @@ print("lookup forward + backward (VJPs w.r.t. depth, pose, delta, both feature m
 print("direct_align: HIP %.0f us (gradcoords + normal equations + solve/se3 update kernel)   CPU checker %.2f s" % (ta * 1e6, tca))
 print("direct_align forward + backward (VJPs w.r.t. poses, depth, both feature maps, the three weight maps; %.2f G lane-adds "
       "into the target features, LDS planes as above): HIP %.0f us, with --robust_pose_loss %.0f us" % (B * h * w * C * 20 / 1e9, tafb * 1e6, tafb_r * 1e6))
+
+# ---- the second pose regime: a forward-moving camera (KITTI's dominant motion: translation along z, a little sideways, none
+# vertically) keeps the epipolar lines of neighbouring pixels close to parallel and almost horizontal, so the 64 lanes of
+# a wave load stay within one or two cache lines; the bench's default poses (0.15 in every direction) spread them over ~4
+poses_fwd = poses.clone()
+poses_fwd[:, 1, 3] = 0.0
+poses_fwd[:, 0, 3] *= 0.2
+poses_fwd[:, 2, 3] = 0.15
+pf = poses_fwd.to(dev)
+with torch.no_grad():
+    def hip_f():
+        c, max_dx, ds = R.depth2epipolarcoords(pf, g[1])
+        return S(c, L, 1)
+    for _ in range(3): hip_f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20): hip_f()
+    torch.cuda.synchronize(); thf = (time.perf_counter() - t) / 20
+print("forward-motion poses (t = (0.03 N, 0, 0.15), same rotation): HIP %.0f us -> %.1f G wave-loads/s = %.2f of the coalesced ceiling, "
+      "%.2f of the 4-line ceiling" % (thf * 1e6, wave_loads / thf / 1e9, wave_loads / thf / WAVE_LOAD_CEILING[1],
+                                      wave_loads / thf / WAVE_LOAD_CEILING[4]))
