@@ -62,10 +62,11 @@ def test_geometry_modules(tag):
     warped = layers.grid_sample(b["color_m1"], grid, padding_mode="border", align_corners=True)
     G.assert_close(warped.detach().cpu(), z["warped_A"], 1e-4, "warped_A", floor=1e-1)
     (warped * _c(z["in/g_warped"])).sum().backward()
+    # against the reference's own gradients AWAY from the pixels where its taps may differ from the kernel's; every pixel
+    # and the pose gradient are held at 1e-4 with the taps forced in test_warp_gradient_with_forced_taps below
     ok = _sample_ok(z["grid_A"], H, W, True)
     sc = np.abs(z["grad_disp_A"]).max()
-    assert (np.abs(disp.grad.cpu().numpy() - z["grad_disp_A"])[ok] > 2e-4 * sc).mean() <= 1e-3
-    assert _l2rel(T.grad.cpu().numpy()[:, :3], z["grad_T_A"][:, :3]) <= 2e-3  # sums over clip/tap-switch pixels too
+    assert (np.abs(disp.grad.cpu().numpy() - z["grad_disp_A"])[ok] > 1e-4 * sc).mean() <= 1e-3
     # DualRefine convention
     disp2 = b["disp_teacher"].clone().requires_grad_(True)
     T2 = _c(z["T_inv1"]).requires_grad_(True)
@@ -77,8 +78,7 @@ def test_geometry_modules(tag):
     (warped2 * _c(z["in/g_warped"])).sum().backward()
     ok = _sample_ok(z["grid_B"], H, W, False)
     sc = np.abs(z["grad_disp_B"]).max()
-    assert (np.abs(disp2.grad.cpu().numpy() - z["grad_disp_B"])[ok] > 2e-4 * sc).mean() <= 1e-3
-    assert _l2rel(T2.grad.cpu().numpy()[:, :3], z["grad_T_B"][:, :3]) <= 2e-3
+    assert (np.abs(disp2.grad.cpu().numpy() - z["grad_disp_B"])[ok] > 1e-4 * sc).mean() <= 1e-3
 
 
 @pytest.mark.parametrize("tag", G.LAYER_CASES)
@@ -112,9 +112,8 @@ def test_photometric_modules(tag):
     sm.backward()
     assert abs(float(sm) - float(z["smooth"])) <= 1e-5 * abs(float(z["smooth"]))
     g, r = disp3.grad.cpu().numpy(), z["grad_smooth"]
-    # |d_q - d_q'| has a kink at equality (fp16-quantised test disparities do tie): compare off the ties
-    assert (np.abs(g - r) > 1e-4 * np.abs(r).max()).mean() <= 2e-2
-    assert _l2rel(g, r) <= 0.2
+    # sign(d_q - d_q') of two fp32 numbers is exact (0 at a tie, as torch.abs's gradient): every pixel, nothing exempted
+    assert np.abs(g - r).max() <= 1e-4 * np.abs(r).max()
 
 
 @pytest.mark.parametrize("invert", [False, True])
