@@ -296,7 +296,7 @@ def shader_clock_mhz(lib, dev):
     return 100.0 * t / r if r > 0 else None
 
 
-def valu_bound(lib, dev, kernel_ms, hbm_frac):
+def valu_bound(lib, dev, kernel_ms, hbm_frac, halo1=True):
     """What actually bounds the north-star kernel: its row loop priced by instruction class from the
     compiler's listing of the shipped sources (mal_amd.build.valu_report -> mal_amd/lib/valu_cost.json; per-class
     cycles measured by scripts/valu_probe.hip), times the row-loop iterations of all tasks, over the chip's SIMDs at the
@@ -314,15 +314,22 @@ def valu_bound(lib, dev, kernel_ms, hbm_frac):
         mhz = shader_clock_mhz(lib, dev)
         if not mhz or kernel_ms <= 0:
             return {"valu": {"error": "no clock / kernel time"}}
-        cycles = k["pipe_cycles"] * iters * tasks / simds
+        drain = k.get("drain", {}).get("pipe_cycles")
+        if halo1 and drain:  # one-row halo of the step's gradient passes: rows + 2 warped rows, then two gradient-only iterations
+            iters_full, iters_drain = rows + 2, 2
+        else:
+            iters_full, iters_drain, drain = iters, 0, 0.0
+        cycles = (k["pipe_cycles"] * iters_full + drain * iters_drain) * tasks / simds
         valu_us = cycles / mhz
         frac = valu_us / (kernel_ms * 1e3)
         return {"bound": "valu" if frac > hbm_frac else "hbm",
                 "valu": {"valu_frac": frac, "valu_us": valu_us, "pipe_cycles_per_row": k["pipe_cycles"],
                          "valu_instructions_per_row": k["valu_instructions"], "classes": k["classes"],
-                         "row_iterations_per_task": iters, "rows_per_task": rows, "tasks": tasks, "simds": simds,
+                         "row_iterations_per_task": iters_full, "gradient_only_iterations_per_task": iters_drain,
+                         "pipe_cycles_per_gradient_only_iteration": drain, "rows_per_task": rows, "tasks": tasks, "simds": simds,
                          "shader_clock_mhz": mhz,
-                         "how": "pipe_cycles_per_row x row_iterations_per_task x tasks / simds / clock; classes from the "
+                         "how": "(pipe_cycles_per_row x row_iterations_per_task + pipe_cycles_per_gradient_only_iteration x "
+                                "gradient_only_iterations_per_task) x tasks / simds / clock; classes from the "
                                 "compiler's listing of the shipped kernel (mal_amd/lib/valu_cost.json, digest %s), cycle "
                                 "prices from scripts/valu_probe.hip (profiles/r02_valu_probe.txt); an upper estimate: the "
                                 "first and last iterations of a task skip the gradient / statistics stages" % rep["digest"][:12]}}
@@ -682,7 +689,8 @@ def main():
                            "alg_bytes_per_px": ALG_BYTES_PER_PX, "pixels_per_launch": n_px,
                            "kernel_ms": kern_ms_plain, "launches_timed": 20 if args.mode == "step" else len(durs),
                            "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None}
-        out["roofline"].update(valu_bound(lib, dev, kern_ms_plain, achieved / HBM_PEAK_GBS))
+        out["roofline"].update(valu_bound(lib, dev, kern_ms_plain, achieved / HBM_PEAK_GBS,
+                                          halo1="march_halo1=0" not in args.opt))
     if args.mode == "step" and kern_ms > 0:
         # the same sweep as the headline step runs it: decisions of the four-way min taken from the materialised-candidate
         # kernels, + 24 B/px of d loss / d warped colour arriving through syn (SURVEY.md 8d counts +24 B/px backward)

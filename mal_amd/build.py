@@ -102,10 +102,11 @@ def _valu_class(op):
     return "plain"
 
 
-def valu_cost_of(asm_text, key):
-    """Instruction classes of the longest backward-branch loop (the row loop) of the kernel whose mangled name contains
-    ``key`` in a ``hipcc -S`` listing: {"loop_instructions", "valu_instructions", "pipe_cycles", "classes": {class:
-    {"instr", "cycles"}}} with VALU_COSTS as prices."""
+def valu_cost_of(asm_text, key, nth=0):
+    """Instruction classes of the longest backward-branch loop (the row loop; ``nth`` = 1: the second longest disjoint one --
+    the gradient-only iterations that follow the row loop in the one-row-halo passes) of the kernel whose mangled name
+    contains ``key`` in a ``hipcc -S`` listing: {"loop_instructions", "valu_instructions", "pipe_cycles", "classes":
+    {class: {"instr", "cycles"}}} with VALU_COSTS as prices."""
     import collections
     import re
     lines = asm_text.split("\n")
@@ -121,13 +122,23 @@ def valu_cost_of(asm_text, key):
         if not t or t.startswith((";", ".")):
             continue
         ins.append(t)
-    best = (0, 0, 0)
+    spans = []
     for i, t in enumerate(ins):
         m = re.match(r"s_cbranch\w*\s+(\.LBB\w+)|s_branch\s+(\.LBB\w+)", t)
         if m:
             tgt = labels.get(m.group(1) or m.group(2))
-            if tgt is not None and tgt < i and i - tgt > best[0]:
-                best = (i - tgt, tgt, i)
+            if tgt is not None and tgt < i:
+                spans.append((i - tgt, tgt, i))
+    spans.sort(reverse=True)
+    picked = []
+    for sp in spans:  # the longest loops that do not overlap an already picked one
+        if all(sp[2] < q[1] or sp[1] > q[2] for q in picked):
+            picked.append(sp)
+        if len(picked) > nth:
+            break
+    if len(picked) <= nth:
+        raise StopIteration("kernel %s has no loop number %d" % (key, nth))
+    best = picked[nth]
     loop = ins[best[1]:best[2] + 1]
     cnt = collections.Counter()
     for t in loop:
@@ -166,6 +177,8 @@ def valu_report(force=False, verbose=False):
     for name, key in VALU_KERNELS.items():
         try:
             out["kernels"][name] = valu_cost_of(text, key)
+            if name != "ensemble":  # gradient passes: the two gradient-only iterations behind the row loop (one-row halo)
+                out["kernels"][name]["drain"] = valu_cost_of(text, key, nth=1)
         except StopIteration:
             pass
     with open(VALU_JSON, "w") as fh:

@@ -99,6 +99,14 @@ MAL_DEV float march_boundary_term(const float* bnd, int b, int y, int x, int H, 
   else if (within == last && sq < segs - 1) v = bnd[((size_t)(b * segs + sq) * 2 + 1) * W + x];
   return v;
 }
+// the scratch row that completes image row y of sample b (nullptr away from segment boundaries); wave-uniform
+MAL_DEV const float* march_boundary_row(const float* bnd, int b, int y, int H, int W, int rows, int segs) {
+  const int sq = y / rows, within = y - sq * rows;
+  const int last = min(rows, H - sq * rows) - 1;
+  if (within == 0 && sq > 0) return bnd + ((size_t)(b * segs + sq) * 2 + 0) * W;
+  if (within == last && sq < segs - 1) return bnd + ((size_t)(b * segs + sq) * 2 + 1) * W;
+  return nullptr;
+}
 // tasks per sample of pack_identity_launch's decomposition (the per-task smoothness partials are laid out by it)
 int pack_identity_tasks_per_sample(int H, int W);
 // min_f r(src_f, target) of the RAW sources -> ident (B,1,H,W) (the identity term of

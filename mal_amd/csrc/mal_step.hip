@@ -282,23 +282,51 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
   // one image row per workgroup round: the row index is wave-uniform, so is the test for a segment boundary whose
   // gradient is completed by the neighbouring task's scratch row (one-row halo of the marching passes)
   const int H = HW / W;
+  const bool vec4 = (W & 3) == 0;  // rows are then 16-byte aligned in every map
   for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
     const int b = row / H, y = row - b * H;
     const float inv_t = div_(1.0f, (float)stats[b] + 1e-7f), inv_s = div_(1.0f, (float)stats[B + b] + 1e-7f);
     const float corr_t = (float)stats[2 * B + b], corr_s = (float)stats[3 * B + b];
-    for (int x = threadIdx.x; x < W; x += blockDim.x) {
-      const size_t i = (size_t)row * W + x;
+    const float* brow_t = bnd_t ? march_boundary_row(bnd_t, b, y, H, W, rows, segs) : nullptr;
+    const float* brow_s = bnd_s ? march_boundary_row(bnd_s, b, y, H, W, rows, segs) : nullptr;
+    const size_t r0 = (size_t)row * W;
+    auto px = [&](size_t i, int x) {
       if (g_disp_t) {
-        const float G = bnd_t ? G_r_t[i] + march_boundary_term(bnd_t, b, y, x, H, W, rows, segs) : G_r_t[i];
+        const float G = brow_t ? G_r_t[i] + brow_t[x] : G_r_t[i];
         g_disp_t[i] = fma_(cRt, G, cS * (gn_t[i] * inv_t - corr_t));
-      } else if (fix_t && bnd_t) {  // the teacher's sweep finished its own rows (temporal hint): add the neighbours' terms
-        const float v = march_boundary_term(bnd_t, b, y, x, H, W, rows, segs);
+      } else if (fix_t && brow_t) {  // the teacher's sweep finished its own rows (temporal hint): add the neighbour's term
+        const float v = brow_t[x];
         if (v != 0.f) fix_t[i] = fix_t[i] + cRt * v;
       }
       if (g_disp_s) {
-        const float G = bnd_s ? G_r_s[i] + march_boundary_term(bnd_s, b, y, x, H, W, rows, segs) : G_r_s[i];
+        const float G = brow_s ? G_r_s[i] + brow_s[x] : G_r_s[i];
         g_disp_s[i] = fma_(cRs, G, fma_(g, G_cd[i], cS * (gn_s[i] * inv_s - corr_s)));
       }
+    };
+    if (vec4 && !brow_t && !brow_s && !(fix_t && bnd_t)) {
+      // four pixels per thread, 16-byte accesses (no boundary row here: the arithmetic per element is px()'s)
+      for (int x = threadIdx.x * 4; x < W; x += blockDim.x * 4) {
+        const size_t i = r0 + x;
+        if (g_disp_t) {
+          const float4 G = *reinterpret_cast<const float4*>(G_r_t + i), n = *reinterpret_cast<const float4*>(gn_t + i);
+          float4 o;
+          o.x = fma_(cRt, G.x, cS * (n.x * inv_t - corr_t)); o.y = fma_(cRt, G.y, cS * (n.y * inv_t - corr_t));
+          o.z = fma_(cRt, G.z, cS * (n.z * inv_t - corr_t)); o.w = fma_(cRt, G.w, cS * (n.w * inv_t - corr_t));
+          *reinterpret_cast<float4*>(g_disp_t + i) = o;
+        }
+        if (g_disp_s) {
+          const float4 G = *reinterpret_cast<const float4*>(G_r_s + i), n = *reinterpret_cast<const float4*>(gn_s + i);
+          const float4 c = *reinterpret_cast<const float4*>(G_cd + i);
+          float4 o;
+          o.x = fma_(cRs, G.x, fma_(g, c.x, cS * (n.x * inv_s - corr_s))); o.y = fma_(cRs, G.y, fma_(g, c.y, cS * (n.y * inv_s - corr_s)));
+          o.z = fma_(cRs, G.z, fma_(g, c.z, cS * (n.z * inv_s - corr_s))); o.w = fma_(cRs, G.w, fma_(g, c.w, cS * (n.w * inv_s - corr_s)));
+          *reinterpret_cast<float4*>(g_disp_s + i) = o;
+        }
+      }
+    } else if (fix_t && bnd_t && !g_disp_t && !brow_t && !g_disp_s) {
+      // nothing to do on this row
+    } else {
+      for (int x = threadIdx.x; x < W; x += blockDim.x) px(r0 + x, x);
     }
   }
 }

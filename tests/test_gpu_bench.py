@@ -68,3 +68,24 @@ def test_other_bench_modes_print_a_line(extra, expect):
         assert d["config"]["global_batch"] == 8 and abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     if extra[0] == "--width":
         assert d["config"]["width"] == 512 and d["roofline"]["pixels_per_launch"] == 12 * 192 * 512
+
+
+def test_two_ranks_over_gloo_print_the_multi_gpu_line():
+    """the N>1 launch exactly as the driver starts it for N=2 -- `python bench.py --gpus 2` spawns the ranks itself -- but with
+    gloo standing in for RCCL (MAL_BENCH_BACKEND=gloo: both ranks share this box's one card).  Covers everything of the
+    multi-GPU line except the RCCL transport: rank spawn, the stand-in 165 MB exchange inside the timed step, the
+    overlapped-exchange block, the whole training step with the gradient pieces issued from inside the backward (no
+    try/except around it at N>1: a failing collective fails the run), max-over-ranks timing, `scaling_metric`."""
+    env = dict(os.environ, MAL_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--train-steps", "2"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 24 and d["scaling"] == "weak"
+    assert d["scaling_metric"] == "train_step" and "cpu_baseline" not in d
+    assert d["breakdown_ms"]["grad_all_reduce"] > 0 and "error" not in d["exchange_overlapped"]
+    t = d["train_step"]
+    assert t["n_gpus"] == 2 and t["value"] > 0 and "4 piece(s)" in t["exchange"] and "world size 2" in t["exchange"]
+    assert abs(d["value"] - 24 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
