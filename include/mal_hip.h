@@ -304,6 +304,11 @@ typedef struct mal_step_args {
   float *g_syn_region_m1, *g_syn_region_p1; /* nullable (with syn_region), (B,3,H,W): g_syn_* once more, written only at
                                              touched pixels -- what a producer's in-place backward gathers from
                                              (mal_dyn_item.region_only) */
+  /* --learn_ens (loss_utils.py:240-241, trainer.py:596-600), nullable: the learnt ensemble head's disparity (B,1,H,W).
+   * The ensemble pass then warps with it instead of (disp_teacher + disp_student) / 2, its depth is the distillation
+   * target where the ensemble wins the three-way min, and g_ens_disp (backward output, nullable) receives
+   * d total / d ens_disp.  Not with MAL_STEP_NO_ENS. */
+  const float *ens_disp; float *g_ens_disp;
 } mal_step_args;
 int mal_loss_step_warp(const mal_step_args* args);
 /* A MAL_STEP_TEMPORAL step whose producer failed between mal_loss_step_warp and mal_loss_step_fwd: joins the ensemble

@@ -126,7 +126,7 @@ class StepArgs(C.Structure):
                  ("noise_seed", C.c_uint64), ("noise_step", C.c_uint64), ("noise_counter", vp), ("noise_out", vp)] +
                 [(n, vp) for n in ("warp_m1", "warp_p1", "syn_m1", "syn_p1", "g_syn_m1", "g_syn_p1", "g_warp_m1", "g_warp_p1")] +
                 [("warp_sample_stride", i32), ("warp2_m1", vp), ("warp2_p1", vp), ("syn_region", vp), ("g_syn_region_m1", vp),
-                 ("g_syn_region_p1", vp)])
+                 ("g_syn_region_p1", vp), ("ens_disp", vp), ("g_ens_disp", vp)])
 
 
 class MsArgs(C.Structure):

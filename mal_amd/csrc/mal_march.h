@@ -18,6 +18,9 @@ struct MarchParams {
   // whole-step list: with g_distil == nullptr the two epilogue gradients leave as ONE map,
   // merge_cons * d cons + merge_distil * d distil (their loss weights do not depend on the data)
   float merge_cons, merge_distil;
+  // --learn_ens (whole-step list, epilogue passes): the learnt ensemble's disparity (its depth replaces (mono + multi) / 2
+  // as the distillation target of the pixels the ensemble wins) and the map that receives merge_distil * d distil / d it
+  const float* ens_disp; float* g_ens;
   // per-sample camera block [B][40]: P_f = (K T_f)[:3,:], inv_K[:3,:3]; march_launch fills it unless cam_ready
   float* cam; int cam_ready;
   int sample_scale_is_mask;  // sample_scale holds the augmentation mask: the scale is 1 - mask

@@ -347,12 +347,13 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   struct Ahead {
     float disp, disp2, y[3];                      // the row to warp
     float ident, noise, ext, mono, cost;          // statistics row c (TEMPORAL: ident = forced weight, noise = forced winner)
-    float e_mono, e_mr, e_er;                     // epilogue row
+    float e_mono, e_mr, e_er, e_ensd;             // epilogue row (e_ensd: the learnt ensemble's disparity, --learn_ens)
     float gc[TEMPORAL ? 6 : 1];                   // TEMPORAL: d loss / d warped colour that arrives through syn, gradient row
   };
   // the map pointers of the parameter block, read together (one scalar-load wait per iteration)
   struct Maps {
     const float *ident, *noise, *ext_mask, *lowest_cost, *mono_disp, *mono_depth, *mono_reproj, *ens_reproj, *target; int packed;
+    const float* ens_disp;                                                           // EPI, --learn_ens
     const float* forced_w; const unsigned char* forced_arg; const float* gcol[2];  // TEMPORAL
     const float* fin_gn;                                                             // TEMPORAL
   };
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     m.forced_w = TEMPORAL ? pp.forced_w : nullptr; m.forced_arg = TEMPORAL ? pp.forced_arg : nullptr;
     m.gcol[0] = TEMPORAL ? pp.g_color[0] : nullptr; m.gcol[1] = TEMPORAL ? pp.g_color[1] : nullptr;
     m.fin_gn = TEMPORAL ? pp.fin_gn : nullptr;
+    m.ens_disp = EPI ? pp.ens_disp : nullptr;
     return m;
   };
   auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
@@ -402,11 +404,12 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     a.mono = opt(pp.lowest_cost ? pp.mono_disp : nullptr, oc, 0.f);
     a.cost = opt(pp.lowest_cost, oc, 1.f);
     const unsigned oq = GRAD ? moff(min(max(rr - 2, 0), H - 1)) : oc;  // epilogue row
-    a.e_mono = 0.f; a.e_mr = 0.f; a.e_er = 0.f;
+    a.e_mono = 0.f; a.e_mr = 0.f; a.e_er = 0.f; a.e_ensd = 0.f;
     if (EPI) {
       a.e_mono = ldf(pp.mono_disp ? pp.mono_disp : pp.mono_depth, oq);
       a.e_mr = ldf(pp.mono_reproj, oq);
       a.e_er = opt(pp.ens_reproj, oq, 0.f);
+      a.e_ensd = opt(pp.ens_disp, oq, 0.f);
     }
     if (TEMPORAL) a.e_mono = opt(pp.fin_gn, oq, 0.f);  // the smoothness gradient of the gradient row (fin_out)
   };
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   float dv_1 = 0.f, dv_2 = 0.f;  // disparity of rows r-1, r-2 (the pose terms of the gradient row re-project it)
   // ================= epilogue terms of output row (EPI): row q = r-2 with GRAD, c without ===
   auto epilogue = [&](CParams& p, int r, const PixInfo& pq, float le_disp, float le_mono, float le_mr, float le_er,
-                      unsigned so_c, unsigned so_q, bool has_mdisp, bool has_er) __attribute__((always_inline)) {
+                      unsigned so_c, unsigned so_q, bool has_mdisp, bool has_er, float le_ensd) __attribute__((always_inline)) {
     const int q = GRAD ? r - 2 : r - 1;
     if (q >= y_lo && q < y_hi && out_x) {
       const unsigned go = GRAD ? so_q : so_c;
@@ -451,7 +454,9 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
         if (r_ens < best) { best = r_ens; idx = 1; }
       }
       if (pq.rp < best) idx = 2;
-      const float ens = (dmono + dm) / 2.0f;
+      const bool learnt = p.ens_disp != nullptr;  // --learn_ens: the ensemble's depth is a map of its own
+      float dens = 0.f, ens = (dmono + dm) / 2.0f;
+      if (learnt) { dens = depth_of(le_ensd, p.min_disp, p.range); ens = dens; }  // wave-uniform
       const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
       const float dd = target - dm;
       acc_dist += fabsf(dd) * mm;
@@ -459,7 +464,9 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       if (p.cons_target) stf(p.cons_target, go, div_(1.0f, dmono * cm + dm * (1.0f - cm)));
       if (GRAD) {
         const float gc = sgnf(dc) * cm * ddepth;
-        const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : -0.5f)) * mm * ddepth;
+        const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : (learnt ? -1.0f : -0.5f))) * mm * ddepth;
+        if (learnt && p.g_ens)  // d |ens - dm| / d ens_disp where the ensemble won, with the distillation term's loss weight
+          stf(p.g_ens, go, idx == 1 ? p.merge_distil * (sgnf(dd) * mm * (-(dens * dens) * p.range)) : 0.0f);
         if (p.g_distil) {
           stf(p.g_cons, go, gc);
           stf(p.g_distil, go, gd);
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       }
     };
 
-    if (EPI && GRAD) epilogue(p, r, pi1, le_disp, le_mono, le_mr, le_er, so_c, so_q, has_mdisp, has_er);
+    if (EPI && GRAD) epilogue(p, r, pi1, le_disp, le_mono, le_mr, le_er, so_c, so_q, has_mdisp, has_er, cur.e_ensd);
     tick(2);  // epilogue terms
     finish_warp();
     tick(3);  // gather wait, blend, ring write
@@ -825,7 +832,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
     }
 
     tick(6);  // partial-plane sums, gradient row
-    if (EPI && !GRAD) epilogue(p, r, pi0, le_disp, le_mono, le_mr, le_er, so_c, so_q, has_mdisp, has_er);
+    if (EPI && !GRAD) epilogue(p, r, pi0, le_disp, le_mono, le_mr, le_er, so_c, so_q, has_mdisp, has_er, cur.e_ensd);
     if (p.depth_out) {
       const int q = r - 1;
       if (q >= y_lo && q < y_hi && out_x)
@@ -860,7 +867,7 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
       CParams& p = *kp;
       const Ahead cur = nxt;
       const unsigned so_c = moff(min(max(r - 1, 0), H - 1)), so_q = moff(min(max(r - 2, 0), H - 1));
-      if (EPI) epilogue(p, r, pi1, dv_2, cur.e_mono, cur.e_mr, cur.e_er, so_c, so_q, p.mono_disp != nullptr, p.ens_reproj != nullptr);
+      if (EPI) epilogue(p, r, pi1, dv_2, cur.e_mono, cur.e_mr, cur.e_er, so_c, so_q, p.mono_disp != nullptr, p.ens_reproj != nullptr, cur.e_ensd);
       f2 hc0[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) hc0[i] = bc(0.f);

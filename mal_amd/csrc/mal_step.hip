@@ -35,6 +35,7 @@ struct StepWs {
   float* T[2]; float* gT[2]; float* gTs[2];
   float* ident; float* mono_reproj; float* ens_reproj;
   float* G_r_t; float* G_r_s; float* G_c; float* gn_t; float* gn_s;
+  float* G_e;         // --learn_ens: merge_distil * d distil / d ens_disp (student pass -> assembly)
   double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
   float* bgP_e;       // the ensemble pass's own (unused) pose-partial sink: it may run beside other launches
   double* bs_p;       // per-task smoothness partials of the first launch: [task][map][4]
@@ -61,7 +62,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   for (int i = 0; i < 3; ++i) w.packed[i] = (float*)take(B * HW * kTexel * sizeof(float));
   for (int f = 0; f < 2; ++f) { w.T[f] = (float*)take(B * 16 * 4); w.gT[f] = (float*)take(B * 16 * 4); w.gTs[f] = (float*)take(B * 16 * 4); }
   float** maps[] = {&w.ident, &w.mono_reproj, &w.ens_reproj, &w.G_r_t, &w.G_r_s, &w.G_c,
-                    &w.gn_t, &w.gn_s};
+                    &w.gn_t, &w.gn_s, &w.G_e};
   for (auto m : maps) *m = (float*)take(map);
   w.bs_t = (double*)take(nb * 8 * 8); w.bs_s = (double*)take(nb * 8 * 8); w.bs_e = (double*)take(nb * 8 * 8);
   w.bgP = (float*)take(nb * 24 * 4);
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
                                                             float* gTs0, float* gTs1, float* g_disp_t, float* g_disp_s,
                                                             PoseParams pp, int pose_bwd, const float* bgP, const float* K,
                                                             int per_sample, int W, const float* bnd_t, const float* bnd_s,
-                                                            int rows, int segs, float* fix_t) {
+                                                            int rows, int segs, float* fix_t, const float* G_e, float* g_ens) {
   const float g = g_total ? *g_total : 1.0f;
   const float cRt = coefs[0] * g, cRs = coefs[1] * g, cS = coefs[4] * g;  // coefs[2], [3] are already inside G_cd
   if (bgP) {
@@ -302,8 +303,9 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
         const float G = brow_s ? G_r_s[i] + brow_s[x] : G_r_s[i];
         g_disp_s[i] = fma_(cRs, G, fma_(g, G_cd[i], cS * (gn_s[i] * inv_s - corr_s)));
       }
+      if (g_ens) g_ens[i] = g * G_e[i];  // --learn_ens: the loss weight is inside G_e already
     };
-    if (vec4 && !brow_t && !brow_s && !(fix_t && bnd_t)) {
+    if (vec4 && !brow_t && !brow_s && !g_ens) {
       // four pixels per thread, 16-byte accesses (no boundary row here: the arithmetic per element is px()'s)
       for (int x = threadIdx.x * 4; x < W; x += blockDim.x * 4) {
         const size_t i = r0 + x;
@@ -323,8 +325,6 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
           *reinterpret_cast<float4*>(g_disp_s + i) = o;
         }
       }
-    } else if (fix_t && bnd_t && !g_disp_t && !brow_t && !g_disp_s) {
-      // nothing to do on this row
     } else {
       for (int x = threadIdx.x; x < W; x += blockDim.x) px(r0 + x, x);
     }
@@ -386,6 +386,8 @@ static int step_check(const mal_step_args* a) {
       !a->augmentation_keep || !a->lowest_cost || !a->losses || !a->ws)
     return MAL_EINVAL;
   if (a->ws_bytes < carve_step(nullptr, a->B, a->H, a->W).bytes) return MAL_EWORKSPACE;
+  if (a->ens_disp && (a->flags & MAL_STEP_NO_ENS)) return MAL_EINVAL;  // the learnt ensemble IS the third candidate
+  if (a->g_ens_disp && !a->ens_disp) return MAL_EINVAL;
   return MAL_OK;
 }
 
@@ -428,6 +430,7 @@ static MarchParams teacher_params(const mal_step_args* a, const StepWs& w, float
 static int launch_ensemble(const mal_step_args* a, const StepWs& w, float* ens_reproj, hipStream_t st) {
   MarchParams p = march_params(a->B, a->H, a->W, a->min_depth, a->max_depth, 1e-7f, 0);
   p.disp = a->disp_teacher; p.disp2 = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+  if (a->ens_disp) { p.disp = a->ens_disp; p.disp2 = nullptr; }  // --learn_ens: the head's disparity (trainer.py:596-597)
   p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
   p.min_reproj = ens_reproj; p.block_sums = w.bs_e; p.block_gP = w.bgP_e;
   p.cam = w.cam; p.cam_ready = 1;
@@ -584,6 +587,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj;
     p.min_reproj = multi_reproj; p.g_reproj = w.G_r_s;
     p.g_cons = w.G_c; p.g_distil = nullptr;  // one merged map: weights as coefs[2], coefs[3] of step_final_kernel
+    p.ens_disp = a->ens_disp; p.g_ens = a->ens_disp ? w.G_e : nullptr;
     p.merge_cons = (float)((double)a->w_main / ((double)B * H * W)); p.merge_distil = (float)((double)a->w_distil / ((double)B * H * W));
     p.block_sums = w.bs_s; p.block_gP = w.bgP;
     p.bnd = g_march_halo1 ? w.bnd_s : nullptr;
@@ -645,7 +649,8 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
                      w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
                      teacher_done ? nullptr : a->g_disp_teacher, a->g_disp_student, pp, pose_bwd, per_sample_t ? w.bgP : nullptr,
                      a->K, per_sample_t, W, g_march_halo1 ? w.bnd_t : nullptr, g_march_halo1 ? w.bnd_s : nullptr, rows, segs,
-                     teacher_done ? a->g_disp_teacher : nullptr);
+                     teacher_done ? a->g_disp_teacher : nullptr, a->ens_disp ? w.G_e : nullptr,
+                     a->ens_disp ? a->g_ens_disp : nullptr);
   rc = launch_status();
   return rc;
 }

@@ -41,13 +41,18 @@ def _workspace(dev, B, H, W):
     return ws
 
 
-def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=False):
-    """the mal_step_args block of one step, the tensors it points to (kept alive by the caller) and the map dict"""
+def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=False, ens_disp=None):
+    """the mal_step_args block of one step, the tensors it points to (kept alive by the caller) and the map dict;
+    ``ens_disp`` (--learn_ens): a seventh leaf, appended to the kept tensors"""
     color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise = consts
     min_depth, max_depth, no_ens, w_main, w_distil, want_maps, aug_is_mask, want_dec, philox = cfg
     req = ops._req
     tens = [req(t, n) for t, n in ((disp_t, "disp_teacher"), (disp_s, "disp_student"), (aa_m1, "axisangle"),
                                    (tr_m1, "translation"), (aa_p1, "axisangle"), (tr_p1, "translation"))]
+    if ens_disp is not None:
+        tens.append(req(ens_disp, "ens_disp"))
+        if tuple(tens[6].shape) != tuple(tens[0].shape):
+            raise L.MalError("loss_step: outputs['ens_disp'] must have the shape of the disparities")
     cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest)]
     cons.append(None if noise is None else req(noise, "input"))
     B, _, H, W = tens[0].shape
@@ -64,7 +69,9 @@ def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, tempora
     a.w_main, a.w_distil = float(w_main), float(w_distil)
     p = ops._p
     a.disp_teacher, a.disp_student = p(tens[0]), p(tens[1])
-    a.axisangle_m1, a.translation_m1, a.axisangle_p1, a.translation_p1 = (p(t) for t in tens[2:])
+    a.axisangle_m1, a.translation_m1, a.axisangle_p1, a.translation_p1 = (p(t) for t in tens[2:6])
+    if ens_disp is not None:
+        a.ens_disp = p(tens[6])
     (a.color0, a.color_m1, a.color_p1, a.K, a.inv_K, a.consistency_mask, a.augmentation_keep, a.lowest_cost,
      a.noise) = (p(t) for t in cons)
     losses = torch.empty(16, dtype=torch.float32, device=dev)
@@ -97,11 +104,16 @@ def _run_bwd(ctx, g_total):
     # only the total is differentiable through this node: the 16 slots are its terms, for logging
     g_total = g_total.reshape(1).contiguous()
     a = ctx.args
-    grads = [torch.empty_like(t) if ctx.needs_input_grad[i] else None for i, t in enumerate(tens)]
+    grads = [torch.empty_like(t) if ctx.needs_input_grad[i] else None for i, t in enumerate(tens[:6])]
     a.g_total = ops._p(g_total)
     (a.g_disp_teacher, a.g_disp_student, a.g_axisangle_m1, a.g_translation_m1, a.g_axisangle_p1,
      a.g_translation_p1) = (ops._p(g) for g in grads)
+    g_ens = None
+    if len(tens) > 6 and ctx.needs_input_grad[ctx.ens_index]:  # --learn_ens: the ensemble head's disparity
+        g_ens = torch.empty_like(tens[6])
+        a.g_ens_disp = ops._p(g_ens)
     L.check(L.load().mal_loss_step_bwd(C.byref(a)), "mal_loss_step_bwd")
+    ctx.g_ens = g_ens
     return grads
 
 
@@ -109,10 +121,11 @@ class LossStepFn(Function):
     """leaves: disp_teacher, disp_student, axisangle_m1, translation_m1, axisangle_p1, translation_p1."""
 
     @staticmethod
-    def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg):
-        a, keep, maps = _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg)
+    def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, ens_disp=None):
+        a, keep, maps = _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, ens_disp=ens_disp)
         L.check(L.load().mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
         ctx.args = a
+        ctx.ens_index = 8
         ctx.keep = keep  # the C struct holds raw pointers: keep the tensors alive
         ctx.set_materialize_grads(False)
         outs = [keep[4], keep[3]] + [maps[k] for k in MAP_NAMES if k in maps]
@@ -123,8 +136,9 @@ class LossStepFn(Function):
     @once_differentiable
     def backward(ctx, g_total, *_):
         if g_total is None:
-            return (None,) * 8
-        return (*_run_bwd(ctx, g_total), None, None)
+            return (None,) * 9
+        grads = _run_bwd(ctx, g_total)
+        return (*grads, None, None, ctx.g_ens)
 
 
 class TemporalLossStepFn(Function):
@@ -137,8 +151,9 @@ class TemporalLossStepFn(Function):
     through syn to d loss / d warped colour before the chain rule through the warp."""
 
     @staticmethod
-    def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, synth, inputs, expose):
-        a, keep, maps = _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=True)
+    def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, synth, inputs, expose, ens_disp=None):
+        a, keep, maps = _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=True, ens_disp=ens_disp)
+        ctx.ens_index = 11
         B, _, H, W = keep[0][0].shape
         dev = keep[0][0].device
         # the two warped images of a sample side by side: the (2,3,H,W) pair the instance segmenter is fed is then a VIEW
@@ -205,7 +220,7 @@ class TemporalLossStepFn(Function):
     @once_differentiable
     def backward(ctx, g_total, *_):
         if g_total is None:
-            return (None,) * 11
+            return (None,) * 12
         leaf, syn, syn_data, g_syn, warp = ctx.graph
         if syn is None:
             g_warp = g_syn  # the identity producer
@@ -223,7 +238,8 @@ class TemporalLossStepFn(Function):
         a = ctx.args
         a.g_warp_m1, a.g_warp_p1 = g_warp[0].data_ptr(), g_warp[1].data_ptr()
         ctx.g_warp = g_warp
-        return (*_run_bwd(ctx, g_total), None, None, None, None, None)
+        grads = _run_bwd(ctx, g_total)
+        return (*grads, None, None, None, None, None, ctx.g_ens)
 
 
 def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=None, noise=None, want_maps=True,
@@ -241,10 +257,17 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
     Returns (losses dict, loss_list or None, maps dict)."""
     from . import config, loss_utils
     if getattr(opt, "main_temporal", False) or getattr(opt, "dual_distil", False) \
-            or getattr(opt, "learn_ens", False) or getattr(opt, "no_ssim", False) or not getattr(opt, "distil", True) \
+            or getattr(opt, "no_ssim", False) or not getattr(opt, "distil", True) \
             or getattr(opt, "sclm", 0) != 0:
-        raise L.MalError("loss_step covers the --distil [--temporal] single-scale configuration; use MALLossPath."
-                         "compute_batch_losses for main_temporal / dual_distil / learn_ens / no_ssim / non-distil runs")
+        raise L.MalError("loss_step covers the --distil [--temporal] [--learn_ens] single-scale configuration; use MALLossPath."
+                         "compute_batch_losses for main_temporal / dual_distil / no_ssim / non-distil runs")
+    ens_disp = None
+    if getattr(opt, "learn_ens", False) and not getattr(opt, "no_ens", False):
+        # the learnt ensemble head's disparity (loss_utils.py:240-241, trainer.py:596-597): warped by the ensemble pass,
+        # distillation target where the ensemble wins, and a leaf that receives gradient there
+        if "ens_disp" not in outputs:
+            raise KeyError("opt.learn_ens reads outputs['ens_disp'] (the shipped RepDepth has no such head: the caller's network provides it)")
+        ens_disp = outputs["ens_disp"]
     temporal = bool(getattr(opt, "temporal", False))
     if temporal and image_synthesis is None:
         raise L.MalError("loss_step with opt.temporal needs image_synthesis(inputs, outputs, scale) -> has_ins "
@@ -277,10 +300,10 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
            aug_is_mask, bool(want_decisions), philox)
     if temporal:
         res = TemporalLossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
-                                       fix(tr[1]), consts, cfg, image_synthesis, inputs, mono_outputs)
+                                       fix(tr[1]), consts, cfg, image_synthesis, inputs, mono_outputs, ens_disp)
     else:
         res = LossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
-                               fix(tr[1]), consts, cfg)
+                               fix(tr[1]), consts, cfg, ens_disp)
     total, v = res[0].reshape(()), res[1]
     maps = {}
     names = (["mono_reproj", "multi_reproj", "consistency_mask"] + ([] if cfg[2] else ["ens_reproj"])) if want_maps else []

@@ -9,7 +9,7 @@ from tests import golden_io as G
 from tests import hip_harness as HH
 
 pytestmark = pytest.mark.gpu
-CASES = ["step_b2_32x64_distil", "step_b2_32x64_noens", "step_b2_32x64_lossblc", "step_b3_37x50_distil"]
+CASES = ["step_b2_32x64_distil", "step_b2_32x64_noens", "step_b2_32x64_lossblc", "step_b3_37x50_distil", "step_b2_32x64_learnens"]
 
 
 @pytest.fixture(scope="session", autouse=True)
@@ -143,9 +143,15 @@ def test_loss_step_equals_operator_route(tag):
         assert abs(want - c["final"]) <= 2e-6 * abs(c["final"]), (want, c["final"])
     else:  # LossBalancing: bs * sum_i w_i L_i is formed on the device by the step, on the host side by the operator route
         assert abs(a["losses"]["loss"] - c["final"]) <= 2e-6 * abs(c["final"]), (a["losses"]["loss"], c["final"])
-    for k in HH.LEAVES:
+    for k in list(HH.LEAVES) + (["disp_ens"] if "disp_ens" in b else []):
         ga, gc = a["grads"][k], c["grads"][k]
         assert np.abs(ga - gc).max() <= 2e-5 * np.abs(gc).max(), (k, np.abs(ga - gc).max() / np.abs(gc).max())
+    if "disp_ens" in b:  # --learn_ens: ... and against the reference's own gradient w.r.t. the ensemble head's disparity
+        from tests import hip_harness as H2
+        o = H2.run_oracle(b, kw, n0, n1)
+        amb = H2.near_tie(np.concatenate([o["mono_reproj"], o["ens"], o["multi_cands"].min(1, keepdims=True)], 1), 2e-4)
+        g, r = a["grads"]["disp_ens"], z["grad/disp_ens"]
+        assert np.abs(r).max() > 0 and np.abs(g - r)[~amb].max() <= 1e-4 * np.abs(r).max()
 
 
 def test_loss_step_rejects_unsupported_options():
