@@ -21,7 +21,8 @@ constexpr int kEpiMaxLevels = 4;
 #define MAL_EPI_G 3  // 2-3: 0.70 ms, 4: 0.77, 6: 0.73 at B=8, 128 channels, 48x160, 51 hypotheses
 #endif
 constexpr int kEpiG = MAL_EPI_G;  // hypotheses per wavefront
-int g_epi_bwd_planes = 1;         // option "epi_bwd_planes": 0 = the global-atomic scatter everywhere (A/B)
+int g_epi_bwd_planes = 1;
+int g_epi_probe = 0;  // option "epi_probe": timing experiments of the plane kernel (wrong results), see EpiSampleBwdParams::probe         // option "epi_bwd_planes": 0 = the global-atomic scatter everywhere (A/B)
 
 struct EpiCoordParams {
   const float* depth; const float* poses; const float* K;
@@ -282,6 +283,9 @@ struct EpiSampleBwdParams {
   const float* coords; const float* g_out;
   int B, C, h, w, L, d1, heads;
   float* g_fmap1; float* g_f2[kEpiMaxLevels]; float* g_coords;  // g_fmap1 / g_f2 zero-initialised by the caller; each nullable
+  // experiments only (mal_set_option("epi_probe"), scripts/epi_bwd_probe.py; results are WRONG with any bit set): what the
+  // plane kernel's time is made of -- bit 0: taps without divisions / validity tests, bit 1: no LDS adds, bit 2: no gathers
+  int probe;
 };
 
 __global__ __launch_bounds__(256) void epi_sample_bwd_kernel(EpiSampleBwdParams p) {
@@ -461,15 +465,24 @@ __global__ __launch_bounds__(kPlaneThreads) void epi_sample_bwd_planes_kernel(Ep
         const size_t o = ((size_t)b * 2 * D + s_) * hw + pix;
         const float u = p.coords[o], v = p.coords[o + (size_t)D * hw];
         const float go = p.g_out[((size_t)b * D * p.heads + (size_t)level * p.heads * p.d1 + (size_t)head * p.d1 + j) * hw + pix] * inv_cg;
-        const LevelTaps t = level_taps(u, v, p.w, p.h, wl, hl);
-        float smp = pl[t.o[0]] * t.w[0];
-        smp = fma_(pl[t.o[1]], t.w[1], smp);
-        smp = fma_(pl[t.o[2]], t.w[2], smp);
-        smp = fma_(pl[t.o[3]], t.w[3], smp);
+        LevelTaps t;
+        if (p.probe & 1) {  // experiment: a tap set that costs next to nothing
+          const unsigned o0 = (unsigned)min(max((int)v, 0), hl - 2) * (unsigned)wl + (unsigned)min(max((int)u, 0), wl - 2);
+          t.o[0] = o0; t.o[1] = o0 + 1; t.o[2] = o0 + wl; t.o[3] = o0 + wl + 1;
+          t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0.25f;
+        } else t = level_taps(u, v, p.w, p.h, wl, hl);
+        float smp;
+        if (p.probe & 4) smp = u * t.w[0];  // experiment: no gathers
+        else {
+          smp = pl[t.o[0]] * t.w[0];
+          smp = fma_(pl[t.o[1]], t.w[1], smp);
+          smp = fma_(pl[t.o[2]], t.w[2], smp);
+          smp = fma_(pl[t.o[3]], t.w[3], smp);
+        }
         const float df = f1 - smp;
         const float k = go * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
         g_f1 += k;
-        if (want && k != 0.f) {
+        if (want && k != 0.f && !(p.probe & 2)) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if (t.w[q] != 0.f) fix_add(sq + t.o[q], -k * t.w[q], to_fix);
@@ -1369,7 +1382,7 @@ extern "C" int mal_coord_sample_l1_bwd(const float* fmap1, const float* const* f
   if (!fmap1 || !f2_pyramid || !coords || !g_out) return MAL_EINVAL;
   EpiSampleBwdParams p = {};
   p.fmap1 = fmap1; p.coords = coords; p.g_out = g_out; p.B = B; p.C = C; p.h = h; p.w = w; p.L = L; p.d1 = d1; p.heads = heads;
-  p.g_fmap1 = g_fmap1; p.g_coords = g_coords;
+  p.g_fmap1 = g_fmap1; p.g_coords = g_coords; p.probe = g_epi_probe;
   for (int l = 0; l < L; ++l) {
     if (!f2_pyramid[l]) return MAL_EINVAL;
     p.f2[l] = f2_pyramid[l];

@@ -1113,6 +1113,7 @@ int g_debug = 0;
 unsigned* g_dec_next = nullptr;  // mal_decisions_next_pass: decision planes for the next instrumentable gradient pass
 extern int g_photo_impl;  // mal_photo_march.hip
 extern int g_epi_bwd_planes;  // mal_epipolar.hip
+extern int g_epi_probe;       // mal_epipolar.hip
 extern int g_syn_rows;        // mal_photo_march.hip
 extern int g_syn_queue;       // mal_photo_march.hip
 extern int g_step_overlap;    // mal_step.hip
@@ -1268,6 +1269,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("syn_queue")) { g_syn_queue = value != 0; return MAL_OK; }
   if (eq("syn_rows")) { if (value < 2 || value > 64) return MAL_EINVAL; g_syn_rows = value; return MAL_OK; }
   if (eq("epi_bwd_planes")) { g_epi_bwd_planes = value != 0; return MAL_OK; }
+  if (eq("epi_probe")) { g_epi_probe = value; return MAL_OK; }
   if (eq("march_flip")) { g_march_flip = value != 0; return MAL_OK; }
   if (eq("pack_rows")) { if (value < 4 || value > 4096) return MAL_EINVAL; g_pack_rows = value; return MAL_OK; }
   if (eq("march_rows_fwd")) { if (value < 0 || value > 4096) return MAL_EINVAL; g_march_rows_fwd = value; return MAL_OK; }

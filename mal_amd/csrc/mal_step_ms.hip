@@ -18,6 +18,7 @@
 #include "mal_pose.h"
 
 namespace mal {
+extern int g_march_halo1;  // mal_step.hip
 
 // mal_photo_march.hip / mal_step.hip
 int smooth_march_sweep_batch(int n, const float* const* disp, const float* const* img, int B, const int* H, const int* W,
@@ -34,6 +35,7 @@ struct MsWs {
   float* noise[kMsS];
   float* up[2][kMsS];    // disparities of scale s >= 1 at full resolution (net 0 teacher, 1 student)
   float* G_r[2][kMsS];   // d (sum rp*w) / d upsampled disparity, unnormalised
+  float* bnd[2][kMsS];   // boundary scratch rows of that pass (one-row halo, mal_march.h), folded into G_r by ms_fold_kernel
   float* G_c[kMsS];      // d consistency_s / d upsampled student disparity, already weighted by 1/((sclm+1) N)
   float* gn[2][kMsS];    // smoothness: d / d normalised disparity at the scale's own size
   double* bs[2][kMsS]; float* bgP[kMsS]; double* sm[2][kMsS];
@@ -61,6 +63,7 @@ static MsWs carve_ms(void* base, int B, int H, int W, int sclm) {
     for (int n = 0; n < 2; ++n) {
       w.up[n][s] = s ? (float*)take(map) : nullptr;
       w.G_r[n][s] = (float*)take(map);
+      w.bnd[n][s] = (float*)take(march_bnd_floats(B, H, W) * sizeof(float));
       w.gn[n][s] = (float*)take(map >> (2 * s));
       w.bs[n][s] = (double*)take(nb * 8 * 8);
       w.sm[n][s] = (double*)take(nb * 4 * 8);
@@ -331,6 +334,19 @@ __global__ __launch_bounds__(256) void ms_final_kernel(MsFinal p) {
   if (p.loss_total) *p.loss_total = p.losses[34];
 }
 
+// One-row halo of the marching gradient passes (MarchParams::bnd): blockIdx.y = pass, blockIdx.x = (sample, segment, first /
+// last row); the scratch row is added to the pass's gradient map in place (one add per element, fixed order).
+struct MsFold { float* G[2 * kMsS]; const float* bnd[2 * kMsS]; int B, H, W, rows, segs; };
+__global__ __launch_bounds__(256) void ms_fold_kernel(MsFold p) {
+  const int which = blockIdx.x & 1, bs = blockIdx.x >> 1, seg = bs % p.segs, b = bs / p.segs;
+  if ((which == 0 && seg == 0) || (which == 1 && seg == p.segs - 1)) return;  // the image's own border: nobody beyond it
+  const int y = which == 0 ? seg * p.rows : min(seg * p.rows + p.rows, p.H) - 1;
+  float* g = p.G[blockIdx.y] + ((size_t)b * p.H + y) * p.W;
+  const float* r = p.bnd[blockIdx.y] + ((size_t)(b * p.segs + seg) * 2 + which) * p.W;
+  for (int x = threadIdx.x; x < p.W; x += 256) g[x] += r[x];
+}
+
+
 // ---------------------------------------------------------------- backward
 struct MsAssemble {
   const float* G_r[2][kMsS]; const float* G_c[kMsS]; const float* gn[2][kMsS]; float* g_disp[2][kMsS];
@@ -514,7 +530,7 @@ extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
       MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
       p.disp = disp_t; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
       p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
-      p.ident = w.ident; p.noise = noise[s]; p.g_reproj = w.G_r[0][s];
+      p.ident = w.ident; p.noise = noise[s]; p.g_reproj = w.G_r[0][s]; p.bnd = g_march_halo1 ? w.bnd[0][s] : nullptr;
       p.block_sums = w.bs[0][s]; p.block_gP = w.bgP[s];
       p.cam = w.cam; p.cam_ready = 1;
       rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
@@ -534,7 +550,7 @@ extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
         p.ext_mask = a->lowest_cost ? (a->consistency_mask_out ? a->consistency_mask_out : w.cmask) : a->consistency_mask;
       }
       p.mono_reproj = w.ident;  // the distillation selection is not part of this loss: any map serves, its term has weight 0
-      p.g_reproj = w.G_r[1][s]; p.g_cons = w.G_c[s]; p.g_distil = nullptr;
+      p.g_reproj = w.G_r[1][s]; p.g_cons = w.G_c[s]; p.g_distil = nullptr; p.bnd = g_march_halo1 ? w.bnd[1][s] : nullptr;
       p.merge_cons = merge_cons; p.merge_distil = 0.f;
       p.block_sums = w.bs[1][s]; p.block_gP = w.bgP[s];
       p.cam = w.cam; p.cam_ready = 1;
@@ -544,6 +560,17 @@ extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
     }
     for (int n = 0; n < 2; ++n) { fin.bs[n][s] = w.bs[n][s]; fin.sm[n][s] = w.sm[n][s]; }
     fin.bgP[s] = w.bgP[s];
+  }
+  if (g_march_halo1) {  // one-row halo of the 2S gradient passes: each boundary row's missing window row, in ONE launch
+    MsFold f = {};
+    int segs = 0, rows = 0;
+    march_geometry(B, H, W, MAL_F_GRAD, nullptr, &segs, &rows);
+    f.B = B; f.H = H; f.W = W; f.rows = rows; f.segs = segs;
+    for (int s = 0; s < S; ++s)
+      for (int n = 0; n < 2; ++n) { f.G[2 * s + n] = w.G_r[n][s]; f.bnd[2 * s + n] = w.bnd[n][s]; }
+    hipLaunchKernelGGL(ms_fold_kernel, dim3((unsigned)(B * segs * 2), (unsigned)(2 * S)), dim3(256), 0, st, f);
+    rc = launch_status();
+    if (rc) return rc;
   }
   {  // smoothness of both disparity maps at every scale's own size against the target at that size (:1469-1471): ONE launch
     const float *sd[2 * kMsS], *si[2 * kMsS];

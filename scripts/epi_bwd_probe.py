@@ -45,5 +45,10 @@ if os.environ.get("DD"):
     L.check(lib.mal_epipolar_coords(p(depth.to(dev)), p(poses.to(dev).reshape(B, 16).contiguous()), p(K.to(dev).reshape(B, 16).contiguous()),
                                     B, h, w, r, Lv, float(os.environ["DD"]), 8.0, p(coords), p(mx), p(ds), ops._stream()), "coords")
 print("LDS planes (fixed point): features only %.2f ms, coords only %.2f ms, everything %.2f ms" % (run(False, True), run(True, False), run(True, True)))
+# what the plane kernel's time is made of (mal_set_option("epi_probe"): results are wrong, timings are the point)
+for bits, what in ((1, "cheap taps (no divisions / validity tests)"), (2, "no LDS adds"), (4, "no gathers"), (7, "none of the three")):
+    lib.mal_set_option(b"epi_probe", bits)
+    print("  features only, %-45s %.2f ms" % (what + ":", run(False, True)))
+lib.mal_set_option(b"epi_probe", 0)
 lib.mal_set_option(b"epi_bwd_planes", 0)
 print("global atomics: everything %.2f ms" % run(True, True))
