@@ -37,8 +37,11 @@ struct Workspace {
   float* block_gP;
   double* scratch;
   float* cam;
+  float* bnd;   // boundary scratch rows of a marching gradient pass with the one-row halo (mal_march.h), [B][H/8+1][2][W]
   size_t bytes;
 };
+// the fold of those scratch rows into the pass's gradient map, done by extra workgroups of pass_finalize_kernel
+struct BoundaryFold { const float* bnd; float* g; int B, H, W, rows, segs; };
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -57,6 +60,7 @@ inline Workspace carve(void* base, int B, int H, int W) {
   w.block_gP = (float*)(p + o);    o += align256(nb * 24 * sizeof(float));
   w.scratch = (double*)(p + o);    o += align256(4096 * sizeof(double));
   w.cam = (float*)(p + o);         o += align256((size_t)B * 40 * sizeof(float));
+  w.bnd = (float*)(p + o);         o += align256((size_t)B * ((size_t)H / 8 + 1) * 2 * (size_t)W * sizeof(float));
   w.bytes = o;
   return w;
 }
@@ -71,7 +75,7 @@ inline int check_shape(int B, int H, int W) {
 // mal_pass.hip: fixed-order second stage shared by both fused-pass formulations
 int launch_pass_finalize(const double* block_sums, const float* block_gP, const float* K, int nblocks,
                          int blocks_per_sample, int B, double* sums, float* gT0, float* gT1, hipStream_t st,
-                         int nsums = 4);
+                         int nsums = 4, const BoundaryFold* fold = nullptr);
 
 inline int launch_status() {
   hipError_t e = hipGetLastError();

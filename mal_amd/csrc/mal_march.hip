@@ -1343,8 +1343,11 @@ extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float
     p.dbg = g_dec_next;  // one-shot (tests): the instrumented instantiation of the same kernel
     g_dec_next = nullptr;
   }
+  // the gradient passes take the one-row halo here too: the scratch rows are folded into g_reproj by the finalize launch
+  if (grad && g_march_halo1) p.bnd = w.bnd;
   rc = march_launch(p, flags, st);
   if (rc) return rc;
+  BoundaryFold fold = {p.bnd, g_reproj, B, H, W, p.rows, p.segs};
   return launch_pass_finalize(w.block_sums, w.block_gP, K, p.ntasks, p.strips * p.segs, B, sums,
-                              pose ? g_T[0] : nullptr, pose ? g_T[1] : nullptr, st);
+                              pose ? g_T[0] : nullptr, pose ? g_T[1] : nullptr, st, 4, p.bnd ? &fold : nullptr);
 }

@@ -418,10 +418,21 @@ __global__ __launch_bounds__(kThreads, 2) void pass_kernel(PassParams p) {
 // blocks 0..7: sums[j] = sum over workgroups (fixed order; j >= nsums -> 0); blocks 8..8+B-1: g_T[f][b] = K_b^T [gP_fb ; 0]
 __global__ __launch_bounds__(256) void pass_finalize_kernel(const double* block_sums, const float* block_gP,
                                                             const float* K, int nblocks, int tiles, int B,
-                                                            double* sums, float* gT0, float* gT1, int nsums) {
+                                                            double* sums, float* gT0, float* gT1, int nsums,
+                                                            BoundaryFold fold, int fold_first) {
   __shared__ double s_part[256];
   __shared__ double s_gP[24];
   const int tid = threadIdx.x;
+  if (fold.bnd && (int)blockIdx.x >= fold_first) {
+    // one-row halo of the marching gradient pass: add the neighbouring task's scratch row to a segment's first / last row
+    const int i = blockIdx.x - fold_first, which = i & 1, bs = i >> 1, seg = bs % fold.segs, b = bs / fold.segs;
+    if ((which == 0 && seg == 0) || (which == 1 && seg == fold.segs - 1)) return;
+    const int y = which == 0 ? seg * fold.rows : min(seg * fold.rows + fold.rows, fold.H) - 1;
+    float* g = fold.g + ((size_t)b * fold.H + y) * fold.W;
+    const float* r = fold.bnd + ((size_t)(b * fold.segs + seg) * 2 + which) * fold.W;
+    for (int x = tid; x < fold.W; x += 256) g[x] += r[x];
+    return;
+  }
   if (blockIdx.x < 8) {
     const int j = blockIdx.x;
     double acc = 0.0;
@@ -463,9 +474,13 @@ __global__ __launch_bounds__(256) void pass_finalize_kernel(const double* block_
 
 int launch_pass_finalize(const double* block_sums, const float* block_gP, const float* K, int nblocks,
                          int blocks_per_sample, int B, double* sums, float* gT0, float* gT1, hipStream_t st,
-                         int nsums) {
-  hipLaunchKernelGGL(pass_finalize_kernel, dim3(gT0 ? 8 + B : 8), dim3(256), 0, st, block_sums, block_gP, K, nblocks,
-                     blocks_per_sample, B, sums, gT0, gT1, nsums);
+                         int nsums, const BoundaryFold* fold) {
+  const int base = gT0 ? 8 + B : 8;
+  BoundaryFold f = {};
+  if (fold && fold->bnd && fold->g) f = *fold;
+  const int extra = f.bnd ? f.B * f.segs * 2 : 0;
+  hipLaunchKernelGGL(pass_finalize_kernel, dim3(base + extra), dim3(256), 0, st, block_sums, block_gP, K, nblocks,
+                     blocks_per_sample, B, sums, gT0, gT1, nsums, f, base);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MAL_OK : MAL_ELAUNCH;
 }
