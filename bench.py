@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a HIP graph (default); 0: eager launches")
-    ap.add_argument("--mode", choices=["step", "distil", "ops", "temporal", "train", "multiscale", "multiscale_ops", "dualrefine"], default="step",
+    ap.add_argument("--mode", choices=["step", "distil", "ops", "temporal", "train", "multiscale", "multiscale_ops", "dualrefine",
+                                       "dualrefine_ops"], default="step",
                     help="step: --temporal --distil through mal_loss_step (BASELINE configs[1], the headline: three library "
                          "calls around the temporal-hint producer); distil: --distil only (one C call per direction); "
                          "ops: the operator-level API; "
@@ -60,7 +61,8 @@ def parse():
                          "manydepth/trainer.py:1248-1475) for both networks through mal_loss_multiscale (one C call per "
                          "direction); multiscale_ops: the same through the operator-level API; dualrefine: BASELINE configs[4], "
                          "DualRefine's loss loops over (scale 0, deq_iter 0..1) at B=8 (dualrefine/trainer.py:395-451,530-633) "
-                         "through DualRefineLossPath")
+                         "through DualRefineLossPath.loss_step (mal_dr_loss_fwd/_bwd, one call per direction); dualrefine_ops: the same through "
+                         "generate_images_pred + compute_losses (operator-level route)")
     ap.add_argument("--width", type=int, default=640, help="image width: 640 (KITTI, the headline) or 512 (CityScapes, "
                                                             "BASELINE configs[3]); the metric string follows it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,13 +164,16 @@ class Step:
         from mal_amd.synthetic import make_batch
         # no host randn / H2D on the step: the whole-step API draws the tie-break noise inside its first
         # kernel (Philox, keyed per rank); the operator-level modes use the device generator
-        config.noise_source = "philox" if mode in ("step", "distil", "multiscale") else "cuda"
+        config.noise_source = "philox" if mode in ("step", "distil", "multiscale", "dualrefine") else "cuda"
         config.noise_seed = 0x4d414c5eed + seed
         config.consistency_target = False  # logging-only map (loss_utils.py:212-215)
         self.one = torch.ones((), dtype=torch.float32, device=dev)  # d(loss)/d(loss): handed to backward, no fill launch
         self.layers = layers
         from mal_amd import ops
         self.ops = ops
+        self.dr_ops = mode == "dualrefine_ops"
+        if self.dr_ops:
+            mode = self.mode = "dualrefine"
         self.B = 8 if mode == "dualrefine" else B  # BASELINE configs[4] is quoted at B=8
         b = make_batch(self.B, H, W, seed=seed)
         mv = lambda t: t.to(dev).contiguous()
@@ -241,9 +246,12 @@ class Step:
         if self.mode == "dualrefine":  # 4-tuple keys: ("disp", 0, deq_iter); iteration 1 refines pose -1
             outputs = {("disp", 0, 0): lv["disp_teacher"], ("disp", 0, 1): lv["disp_student"], ("cam_T_cam", 0, -1): T_m1,
                        ("cam_T_cam", 0, 1): T_p1, ("cam_T_cam", 0, -1, 1): T_m1 * 1.0, "consistency_mask": self.cmask4}
-            self.lp.generate_images_pred(self.inputs, outputs)
-            losses = self.lp.compute_losses(self.inputs, outputs)
-            losses["loss"].backward()
+            if self.dr_ops:  # the operator-level route (two fused passes + glue: ~75 launches)
+                self.lp.generate_images_pred(self.inputs, outputs)
+                losses = self.lp.compute_losses(self.inputs, outputs)
+            else:            # mal_dr_loss_fwd/_bwd: one library call per direction
+                losses = self.lp.loss_step(self.inputs, outputs)
+            losses["loss"].backward(gradient=self.one)
             return losses["loss"]
         mono_outputs = {("disp", 0): lv["disp_teacher"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1}
         outputs = {("disp", 0): lv["disp_student"], ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1,
@@ -709,10 +717,12 @@ def main():
         out["config"]["api"] = "mal_amd.harness.TrainHarness.train_step"
         out["breakdown_ms"] = step.breakdown_ms()
         out["exchange"] = step.h.exchange_note()
-    elif args.mode == "dualrefine":
+    elif args.mode in ("dualrefine", "dualrefine_ops"):
         out["config"]["workload"] = ("DualRefine+MAL loss loops, B=8 per GPU, 192x640 (BASELINE configs[4]): generate_images_pred + "
                                      "compute_losses over (scale 0, deq_iter 0..1), convention B warps (align_corners=False), fwd+bwd "
                                      "to disp/pose leaves; networks not included")
+        out["config"]["api"] = ("mal_dr_loss_fwd/_bwd (one host call per direction)" if args.mode == "dualrefine"
+                                else "operator-level (DualRefineLossPath.generate_images_pred + compute_losses)")
         out["config"]["global_batch"] = step_B * n_ranks
         out["metric"] = "train images/sec at B=8 192x640 KITTI-shaped (DualRefine+MAL loss loops, fwd+bwd)"
     elif args.mode not in ("step", "distil"):

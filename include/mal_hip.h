@@ -373,6 +373,48 @@ typedef struct mal_ms_args {
 size_t mal_ms_workspace_bytes(int B, int H, int W, int sclm);
 int mal_loss_multiscale_fwd(const mal_ms_args* args);
 int mal_loss_multiscale_bwd(const mal_ms_args* args);
+/* ---- DualRefine's loss loops over the deq iterations of scale 0 in one call per direction ------------------------------
+ * dualrefine/trainer.py:395-451 (generate_images_pred, Project3D convention B + align_corners=False) and :530-633
+ * (compute_losses, the per-deq-iteration branch).  Per iteration it = 0..n_iters-1:
+ *   reproj_it = sum(min_f r(warp_f) * mask) / (sum mask + 1e-7),  mask = automask(identity term + 1e-5 noise_it)
+ *               [x consistency_mask for it > 0, :593-597]
+ *   consistency_it = mean |depth_it - depth_0| (1 - mask)  for it > 0 (no gradient to depth_0, :606-618)
+ *   loss_it = reproj_it + consistency_it + smooth_weight * smooth(disp_it / mean disp_it, color)
+ * and upstream's running loss is added to the total once per iteration (:624-631): total = sum_it (n_iters - it) loss_it.
+ * T_m1[it] / T_p1[it] are the 4x4 poses the trainer selects for that iteration (:420-435: the refined pose for frame -1
+ * and it > 0, ...); which of them are detached is the caller's business: a NULL g_T_* output is a detached pose.
+ * losses: [4*it + {0 reproj, 1 consistency, 2 smooth, 3 running loss after it}], [4*MAL_DR_MAX_ITERS] total,
+ * [4*MAL_DR_MAX_ITERS + 1] the final running loss (what every "loss/0_it" entry reads upstream).
+ * --avg_reprojection, --no_ssim, other scales and the pose-update losses (:699-767) stay on the operator-level API. */
+enum { MAL_DR_MAX_ITERS = 4 };
+enum { MAL_DR_NO_AUTOMASK = 1, MAL_DR_NO_MOTION_MASK = 2,
+       MAL_DR_NOISE_PHILOX = 4 /* the tie-break noise of every iteration is drawn in the step's first launch (Philox4x32-10
+                                  keyed by noise_seed, step number = step * MAL_DR_MAX_ITERS + it: mal_tiebreak_noise with
+                                  that step number reproduces iteration it's map); every noise[it] must be NULL */ };
+typedef struct mal_dr_args {
+  int B, H, W, n_iters;
+  float min_depth, max_depth, smooth_weight;
+  int flags;
+  const float *color0, *color_m1, *color_p1;      /* (B,3,H,W) */
+  const float *K, *inv_K;                         /* (B,16) */
+  const float *disp[MAL_DR_MAX_ITERS];            /* (B,1,H,W) */
+  const float *T_m1[MAL_DR_MAX_ITERS], *T_p1[MAL_DR_MAX_ITERS]; /* (B,16) */
+  const float *consistency_mask;                  /* (B,H,W), nullable */
+  const float *noise[MAL_DR_MAX_ITERS];           /* (B,1,H,W) N(0,1) per iteration, nullable */
+  /* MAL_DR_NOISE_PHILOX: key; step = *noise_counter when noise_counter != NULL (a device word the step's last kernel
+   * advances by one, so a replayed HIP graph draws fresh noise every replay), else noise_step */
+  uint64_t noise_seed, noise_step; uint64_t* noise_counter;
+  float *losses;                                  /* 4*MAL_DR_MAX_ITERS + 4 */
+  float *loss_total;                              /* nullable: receives the total */
+  const float *g_total;                           /* backward: device scalar, nullable = 1 */
+  float *g_disp[MAL_DR_MAX_ITERS];                /* backward outputs, nullable each */
+  float *g_T_m1[MAL_DR_MAX_ITERS], *g_T_p1[MAL_DR_MAX_ITERS];
+  void *ws; size_t ws_bytes; void *stream;
+} mal_dr_args;
+size_t mal_dr_workspace_bytes(int B, int H, int W, int n_iters);
+int mal_dr_loss_fwd(const mal_dr_args* args);
+int mal_dr_loss_bwd(const mal_dr_args* args);
+
 /* F.interpolate(x, [H, W], mode="bilinear", align_corners=False) of a (B,1,h,w) map and its adjoint (a gather in a
  * fixed order), as the step uses them (tests) */
 int mal_upsample_bilinear(const float* x, int B, int h, int w, int H, int W, float* out, void* stream);

@@ -92,6 +92,9 @@ SIGNATURES = {
     "mal_ms_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mal_loss_multiscale_fwd": (i32, [vp]),
     "mal_loss_multiscale_bwd": (i32, [vp]),
+    "mal_dr_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "mal_dr_loss_fwd": (i32, [vp]),
+    "mal_dr_loss_bwd": (i32, [vp]),
     "mal_upsample_bilinear": (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, vp]),
     "mal_upsample_bilinear_adjoint": (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, vp]),
     "mal_set_option": (i32, [C.c_char_p, i32]),
@@ -143,6 +146,19 @@ class MsArgs(C.Structure):
                 [("ws_bytes", sz), ("stream", vp)])
 
 
+class DrArgs(C.Structure):
+    """mal_dr_args (include/mal_hip.h)."""
+    _fields_ = ([("B", i32), ("H", i32), ("W", i32), ("n_iters", i32), ("min_depth", f32), ("max_depth", f32),
+                 ("smooth_weight", f32), ("flags", i32)] +
+                [(n, vp) for n in ("color0", "color_m1", "color_p1", "K", "inv_K")] +
+                [("disp", vp * 4), ("T_m1", vp * 4), ("T_p1", vp * 4), ("consistency_mask", vp), ("noise", vp * 4),
+                 ("noise_seed", C.c_uint64), ("noise_step", C.c_uint64), ("noise_counter", vp), ("losses", vp), ("loss_total", vp),
+                 ("g_total", vp), ("g_disp", vp * 4), ("g_T_m1", vp * 4), ("g_T_p1", vp * 4),
+                 ("ws", vp), ("ws_bytes", sz), ("stream", vp)])
+
+
+DR_MAX_ITERS = 4
+DR_NO_AUTOMASK, DR_NO_MOTION_MASK, DR_NOISE_PHILOX = 1, 2, 4
 MS_MAX_SCALES = 4
 STEP_NO_ENS, STEP_AUG_MASK, STEP_NOISE_PHILOX, STEP_TEMPORAL = 1, 2, 4, 8
 # decision planes of mal_step_args.dec_teacher / dec_student (MAL_DEC_*)

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmal_hip.so")
-SOURCES = ["mal_api.hip", "mal_pass.hip", "mal_warp.hip", "mal_photo.hip", "mal_photo_march.hip", "mal_dyn.hip", "mal_costvol.hip", "mal_epipolar.hip", "mal_pose.hip", "mal_march.hip", "mal_tile2.hip", "mal_step.hip", "mal_step_ms.hip"]
+SOURCES = ["mal_api.hip", "mal_pass.hip", "mal_warp.hip", "mal_photo.hip", "mal_photo_march.hip", "mal_dyn.hip", "mal_costvol.hip", "mal_epipolar.hip", "mal_pose.hip", "mal_march.hip", "mal_tile2.hip", "mal_step.hip", "mal_step_ms.hip", "mal_dr_step.hip"]
 HEADERS = ["mal_common.h", "mal_device.h", "mal_march.h", "mal_pose.h", "mal_pairs.h", os.path.join("..", "..", "include", "mal_hip.h")]
 # -amdgpu-sched-strategy=max-ilp: the kernels run at 2-4 waves per SIMD by register count anyway; scheduling for
 # ILP instead of occupancy is worth ~2 % on the marching kernels (measured A/B on MI355X)

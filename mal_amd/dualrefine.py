@@ -18,6 +18,11 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 
+import ctypes as C
+
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
 from . import _lib as L
 from . import config
 from . import functional as Fn
@@ -34,6 +39,74 @@ def default_options(**kw):
              avg_reprojection=False, disable_motion_masking=False, Dstar_T0_pair=False, Tstar_D0_pair=False)
     o.update(kw)
     return SimpleNamespace(**o)
+
+
+_DR_WS = {}
+
+
+def _dr_workspace(dev, B, H, W, n):
+    need = L.load().mal_dr_workspace_bytes(B, H, W, n)
+    key = (dev.index, ops._stream(), B, H, W, n)
+    ws = _DR_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _DR_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    return ws
+
+
+class DrLossStepFn(Function):
+    """generate_images_pred + compute_losses of DualRefine's trainer over the deq iterations of scale 0 as one library call
+    per direction (``mal_dr_loss_fwd/_bwd``).  Leaves: ``disp[it]`` (n of them), then ``T_m1[it]``, then ``T_p1[it]``
+    ((B,4,4) each; a pose the trainer detaches simply arrives without ``requires_grad``)."""
+
+    @staticmethod
+    def forward(ctx, consts, cfg, *leaves):
+        color0, color_m1, color_p1, K, inv_K, cmask, noises = consts
+        min_depth, max_depth, smooth_weight, flags, n, philox = cfg
+        req, p = ops._req, ops._p
+        tens = [req(t, "leaf") for t in leaves]
+        cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K)]
+        cm = None if cmask is None else req(cmask, "consistency_mask")
+        nz = [None if t is None else req(t, "noise") for t in (noises or [None] * n)]
+        B, _, H, W = tens[0].shape
+        dev = tens[0].device
+        a = L.DrArgs()
+        a.B, a.H, a.W, a.n_iters = B, H, W, n
+        a.min_depth, a.max_depth, a.smooth_weight, a.flags = float(min_depth), float(max_depth), float(smooth_weight), int(flags)
+        a.color0, a.color_m1, a.color_p1, a.K, a.inv_K = (p(t) for t in cons)
+        for it in range(n):
+            a.disp[it], a.T_m1[it], a.T_p1[it] = p(tens[it]), p(tens[n + it]), p(tens[2 * n + it])
+            a.noise[it] = p(nz[it])
+        a.consistency_mask = p(cm)
+        if philox is not None:  # drawn in the step's first launch; the device counter advances with every (replayed) step
+            from . import step as _step
+            ctr = _step.noise_counter(dev)
+            a.flags |= L.DR_NOISE_PHILOX
+            a.noise_seed, a.noise_counter = int(philox) & 0xFFFFFFFFFFFFFFFF, ctr.data_ptr()
+        losses = torch.empty(4 * L.DR_MAX_ITERS + 4, dtype=torch.float32, device=dev)
+        total = torch.empty(1, dtype=torch.float32, device=dev)
+        a.losses, a.loss_total = p(losses), p(total)
+        ws = _dr_workspace(dev, B, H, W, n)
+        a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
+        L.check(L.load().mal_dr_loss_fwd(C.byref(a)), "mal_dr_loss_fwd")
+        ctx.args, ctx.keep, ctx.n = a, (tens, cons, cm, nz, ws, losses, total), n
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(losses)
+        return total, losses
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_total, _g_losses=None):
+        n, tens = ctx.n, ctx.keep[0]
+        if g_total is None:
+            return (None,) * (2 + 3 * n)
+        g_total = g_total.reshape(1).contiguous()
+        a = ctx.args
+        grads = [torch.empty_like(t) if ctx.needs_input_grad[2 + i] else None for i, t in enumerate(tens)]
+        a.g_total = ops._p(g_total)
+        for it in range(n):
+            a.g_disp[it], a.g_T_m1[it], a.g_T_p1[it] = ops._p(grads[it]), ops._p(grads[n + it]), ops._p(grads[2 * n + it])
+        L.check(L.load().mal_dr_loss_bwd(C.byref(a)), "mal_dr_loss_bwd")
+        return (None, None, *grads)
 
 
 class DualRefineLossPath:
@@ -198,6 +271,47 @@ class DualRefineLossPath:
             for key in [k for k in losses if k.startswith("loss/{}_".format(scale))]:
                 losses[key] = loss
         losses["loss"] = total / self.num_scales
+        return losses
+
+    def loss_step(self, inputs, outputs, noises=None):
+        """``generate_images_pred`` + ``compute_losses`` (dualrefine/trainer.py:395-451,530-633) in ONE library call per
+        direction for the configuration the shipped options give -- scales [0], min reprojection with SSIM, deq iterations
+        0..n_losses --; same ``losses`` keys and values as the two methods called one after the other (they remain the route
+        for --avg_reprojection / --no_ssim / more scales and for the ("color", ...) / ("sample", ...) outputs, which this
+        call does not materialise).  ``noises``: one (B,1,H,W) N(0,1) map per iteration (default: drawn as
+        ``config.noise_source`` says)."""
+        opt = self.opt
+        n = opt.n_losses + 1
+        if list(opt.scales) != [0] or opt.avg_reprojection or opt.no_ssim or opt.v1_multiscale or n > L.DR_MAX_ITERS \
+                or list(opt.frame_ids) != [0, -1, 1] or self.f_thres <= 0:
+            raise L.MalError("DualRefineLossPath.loss_step covers scales [0], frames [0,-1,1], min reprojection with SSIM and "
+                             "n_losses < %d; use generate_images_pred + compute_losses otherwise" % L.DR_MAX_ITERS)
+        target = inputs[("color", 0, 0)]
+        B, _, H, W = target.shape
+        disps = [outputs[("disp", 0, it)] for it in range(n)]
+        for d in disps:
+            if tuple(d.shape) != (B, 1, H, W):
+                raise L.MalError("loss_step: the disparities must arrive at full resolution (B,1,%d,%d)" % (H, W))
+        T_m1 = [self._pose_for(outputs, -1, it) for it in range(n)]
+        T_p1 = [self._pose_for(outputs, 1, it) for it in range(n)]
+        flags = (L.DR_NO_AUTOMASK if opt.disable_automasking else 0) | (L.DR_NO_MOTION_MASK if opt.disable_motion_masking else 0)
+        philox = None
+        if noises is None and not opt.disable_automasking:
+            if config.noise_source == "philox":  # drawn inside the step's first launch: no RNG launch, no host work
+                philox = config.noise_seed
+            else:
+                noises = [loss_utils.draw_noise((B, 1, H, W), target.device) for _ in range(n)]  # one draw per iteration (:586-587)
+        cmask = None
+        if n > 1 and not opt.disable_motion_masking:
+            cmask = outputs["consistency_mask"].to(torch.float32)
+        consts = (target, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)], cmask, noises)
+        cfg = (opt.min_depth, opt.max_depth, opt.disparity_smoothness, flags, n, philox)
+        total, v = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1)
+        losses = {"reproj_loss/0": v[4 * (n - 1)], "loss": total.reshape(())}
+        for it in range(n):
+            losses["loss/0_%d" % it] = v[4 * L.DR_MAX_ITERS + 1]  # upstream's entries alias the running loss (:624,630)
+            if it > 0:
+                losses["consistency_loss/0_%d" % it] = v[4 * it + 1]
         return losses
 
     def _weight_map(self, inputs, outputs, scale, it, ext, rp_map, noise):

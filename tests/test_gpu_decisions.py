@@ -332,3 +332,83 @@ def test_dualrefine_decision_exact(shape):
     assert np.abs(outputs[("color", -1, 0, 0, 1)].detach().cpu().numpy() - oout[("color", -1, 0, 0, 1)].detach().numpy()).max() <= 5e-5
     for k, v in rp.items():  # two automask pixels at rounding distance of their threshold allowed (see test_gpu_trainer.py)
         assert abs(float(gp[k].detach()) - float(v)) <= 1e-4 * abs(float(v)) + 2.0 / N, (k, float(gp[k].detach()), float(v))
+
+
+@pytest.mark.parametrize("shape,kw_extra", [((2, 40, 72), {}), ((8, 192, 640), {}), ((3, 37, 50), {"n_losses": 2}),
+                                            ((2, 40, 72), {"disable_motion_masking": True}),
+                                            ((2, 40, 72), {"disable_automasking": True})],
+                         ids=["b2_40x72", "b8_192x640", "three_iterations_ragged", "no_motion_mask", "no_automask"])
+def test_dualrefine_one_call_step_equals_the_operator_route(shape, kw_extra):
+    """DualRefineLossPath.loss_step (mal_dr_loss_fwd/_bwd: DualRefine's loops over the deq iterations in one library call
+    per direction) against generate_images_pred + compute_losses of the same class -- the route the decision-exact test
+    above pins to the oracle: same kernels underneath, so losses at 2e-6 and every gradient at 2e-5 of its scale, incl. the
+    upstream quirk that the running loss enters the total once per iteration (iteration it weighs n - it)."""
+    from mal_amd import dualrefine, layers
+    from mal_amd.synthetic import make_batch
+    B, H, W = shape
+    batch = make_batch(B, H, W, seed=322)
+    kw = dict(height=H, width=W, batch_size=B, n_losses=1)
+    kw.update(kw_extra)
+    n = kw["n_losses"] + 1
+    torch.manual_seed(7)
+    noises = [torch.randn(B, 1, H, W).to("cuda:0") for _ in range(n)]
+    res = {}
+    for route in ("ops", "step"):
+        inputs, outputs, gl = _dr_build(batch, "cuda:0", layers.transformation_from_parameters)
+        for it in range(2, n):  # further iterations: their own disparity leaves
+            gl["disp_it%d" % it] = (0.5 * gl["disp_teacher"].detach() + 0.5 * gl["disp_student"].detach()).clone().requires_grad_(True)
+            outputs[("disp", 0, it)] = gl["disp_it%d" % it]
+        lp = dualrefine.DualRefineLossPath(dualrefine.default_options(**kw), fuse=True)
+        if route == "ops":
+            lp.generate_images_pred(inputs, outputs)
+            got = lp.compute_losses(inputs, outputs, noises=noises)
+        else:
+            got = lp.loss_step(inputs, outputs, noises=noises)
+        got["loss"].backward()
+        torch.cuda.synchronize()
+        res[route] = ({k: float(v.detach()) for k, v in got.items()},
+                      {k: (t.grad if t.grad is not None else torch.zeros_like(t)).cpu().numpy() for k, t in gl.items()})
+    assert set(res["ops"][0]) == set(res["step"][0]), (sorted(res["ops"][0]), sorted(res["step"][0]))
+    for k, v in res["ops"][0].items():
+        assert abs(res["step"][0][k] - v) <= 2e-6 * max(abs(v), 1e-3), (k, res["step"][0][k], v)
+    for k, g in res["ops"][1].items():
+        sc = np.abs(g).max()
+        assert sc > 0 or k.endswith("p1") is False
+        assert np.abs(res["step"][1][k] - g).max() <= 2e-5 * max(sc, 1e-12), (k, np.abs(res["step"][1][k] - g).max() / max(sc, 1e-12))
+
+
+def test_dualrefine_step_in_kernel_noise_equals_the_same_noise_handed_in():
+    """MAL_DR_NOISE_PHILOX: iteration it's map is mal_tiebreak_noise(seed, step * MAL_DR_MAX_ITERS + it); the step with the
+    maps drawn in its first launch and the step handed those maps agree to the bit, and the device counter advances once."""
+    import ctypes as C
+    from mal_amd import _lib, config, dualrefine, layers, ops, step
+    from mal_amd.synthetic import make_batch
+    B, H, W = 2, 40, 72
+    batch = make_batch(B, H, W, seed=11)
+    old = config.noise_source, config.noise_seed
+    config.noise_source, config.noise_seed = "philox", 777
+    try:
+        ctr = step.noise_counter(torch.device("cuda:0"))
+        c0 = int(ctr.item())
+        res = []
+        for noises in (None, "same"):
+            if noises == "same":
+                noises = []
+                for it in range(2):
+                    out = torch.empty(B, 1, H, W, device="cuda:0")
+                    _lib.check(_lib.load().mal_tiebreak_noise(C.c_uint64(777), C.c_uint64(c0 * _lib.DR_MAX_ITERS + it), B, H, W,
+                                                              out.data_ptr(), ops._stream()), "mal_tiebreak_noise")
+                    noises.append(out)
+                assert not torch.equal(noises[0], noises[1])
+            inputs, outputs, gl = _dr_build(batch, "cuda:0", layers.transformation_from_parameters)
+            lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=B, n_losses=1), fuse=True)
+            got = lp.loss_step(inputs, outputs, noises=noises)
+            got["loss"].backward()
+            torch.cuda.synchronize()
+            assert int(ctr.item()) == c0 + 1
+            res.append((float(got["loss"].detach()), {k: t.grad.clone() for k, t in gl.items() if t.grad is not None}))
+        assert res[0][0] == res[1][0]
+        for k, g in res[0][1].items():
+            assert torch.equal(g, res[1][1][k]), k
+    finally:
+        config.noise_source, config.noise_seed = old
