@@ -53,6 +53,10 @@ struct MarchParams {
   // gradient that reaches the warped images through syn (dyn_utils.py:145-146,163-164), g_color[f] planar (B,3,H,W),
   // joins d loss / d warped colour before the chain rule through the warp
   const float* forced_w; const unsigned char* forced_arg; const float* g_color[2];
+  // ... as a CORRECTION of what an exporting gradient pass (color_out with MAL_F_GRAD) left: (B,H,W) bytes, bit 0 = the
+  // pixel can differ between syn and the warped image; tasks that keep away from every marked pixel return at once (their
+  // gradient rows, boundary rows and pose partials stand).  nullptr = every task runs.
+  const unsigned char* region;
   // ... and, running in the backward call where the loss scalars exist already, it finishes the teacher's disparity
   // gradient itself instead of leaving the unnormalised map to the assembly kernel (fin_out nullable):
   //   fin_out = coefs[0] g_total * G + coefs[4] g_total * (fin_gn / (mean_b + 1e-7) - corr_b),  mean / corr in fin_stats

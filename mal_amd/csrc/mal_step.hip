@@ -443,6 +443,10 @@ static int launch_ensemble(const mal_step_args* a, const StepWs& w, float* ens_r
 // which reads its map.  Fork / join through events: capturable into the caller's HIP graph.
 namespace mal { int g_step_overlap = 1; }  // option "step_overlap"
 namespace mal { int g_march_halo1 = 1; }   // option "march_halo1": one-row halo of the step's gradient passes (0: two rows, A/B)
+// option "temporal_spec" (--temporal step): 1 = the pass in front of the producer is the teacher's GRADIENT pass (it
+// exports the warped images as well) and the sweep after the producer's backward only corrects the tasks near the region
+// map; 0 = forward-only pass in front, full gradient sweep behind (rounds 2-3, kept for same-box A/B)
+namespace mal { int g_temporal_spec = 0; }
 struct SideStream { hipStream_t s; hipEvent_t fork, join; bool ok, init, pending; };
 // one per device (created on first use on THAT device); `pending`: a fork whose join has not been enqueued yet
 static SideStream* side_stream() {
@@ -506,12 +510,21 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   // ... with the automask: where no synthesised candidate can win, this IS the teacher's forward (min, winner, weight,
   // sums); the fused sweep of mal_loss_step_fwd overwrites the second copies where it re-decides
   p.ident = w.ident; p.noise = a->noise;
+  int flags = MAL_F_AUTOMASK | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
+  if (g_temporal_spec) {
+    // ... and its gradient: away from the region map nothing the producer does can change a decision or add a cotangent,
+    // so the map, boundary rows and pose partials this pass leaves are final there (mal_loss_step_bwd redoes the rest)
+    flags |= MAL_F_GRAD | MAL_F_POSE_GRAD;
+    p.g_reproj = w.G_r_t;
+    p.bnd = g_march_halo1 ? w.bnd_t : nullptr;
+    p.dbg = a->dec_teacher;
+  }
   p.min_reproj2 = a->mono_reproj ? a->mono_reproj : w.mono_reproj; p.argmin_out2 = w.arg_t; p.weight_out = w.w_t;
   p.color_out[0] = a->warp_m1; p.color_out[1] = a->warp_p1; p.argmin_out = w.arg_warp;
   p.color_out_stride = a->warp_sample_stride;
   p.color_out2[0] = a->warp2_m1; p.color_out2[1] = a->warp2_p1;
   if ((a->warp2_m1 == nullptr) != (a->warp2_p1 == nullptr)) return MAL_EINVAL;
-  rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+  rc = march_launch(p, flags, st);
   if (rc) return rc;
   if (ensemble_forked(a) && g_step_overlap == 1) {
     rc = fork_ensemble(a, w, st);
@@ -536,7 +549,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   int per_sample = 1, per_sample_t = 0;
   {  // tasks per sample of the teacher's sums: its gradient pass, or (temporal hint) the forward pass in front of the producer
     int strips = 0, segs = 0;
-    march_geometry(B, H, W, temporal ? 0 : MAL_F_GRAD, &strips, &segs, nullptr);
+    march_geometry(B, H, W, temporal && !g_temporal_spec ? 0 : MAL_F_GRAD, &strips, &segs, nullptr);
     per_sample_t = strips * segs;
   }
   if (!temporal) {
@@ -622,9 +635,16 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
     p.g_reproj = w.G_r_t; p.block_sums = w.bs_t;
     p.ident = w.ident;  // unused by the TEMPORAL instantiation (the launch checks the flag combination only)
     p.forced_w = w.w_t; p.forced_arg = w.arg_t; p.g_color[0] = a->g_warp_m1; p.g_color[1] = a->g_warp_p1;
-    // the loss scalars exist already: the sweep writes d total / d disp_teacher itself (the assembly does the student's)
-    p.fin_gn = w.gn_t; p.fin_coefs = w.coefs; p.fin_stats = w.sm_stats; p.fin_g_total = a->g_total; p.fin_out = a->g_disp_teacher;
-    teacher_done = a->g_disp_teacher != nullptr;
+    if (g_temporal_spec) {
+      // mal_loss_step_warp left the gradient as it is without the synthesised candidates: only the tasks near the region
+      // map are redone (all of them without a map); the assembly finishes the teacher's gradient as in the plain step.
+      // The sums of the redone tasks are not the step's (those are the pass's in front + the fused sweep's differences)
+      p.region = a->syn_region; p.block_sums = w.bs_e;
+    } else {
+      // the loss scalars exist already: the sweep writes d total / d disp_teacher itself (the assembly does the student's)
+      p.fin_gn = w.gn_t; p.fin_coefs = w.coefs; p.fin_stats = w.sm_stats; p.fin_g_total = a->g_total; p.fin_out = a->g_disp_teacher;
+      teacher_done = a->g_disp_teacher != nullptr;
+    }
     p.bnd = g_march_halo1 ? w.bnd_t : nullptr;
     p.dbg = a->dec_teacher;
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);

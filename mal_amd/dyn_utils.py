@@ -157,12 +157,20 @@ class BatchSynthesisFn(Function):
         L.check(lib.mal_dyn_batch_fwd(arr, len(items), C, H, W, 1 if replace else 0, ops._stream()), "mal_dyn_batch_fwd")
         ctx.saved, ctx.dims, ctx.every = saved, (C, H, W), every
         ctx.mark_non_differentiable(flags_all)
+        # no zero-filled stand-in for the cotangent of the byte map (a (B,H,W) fill launch in every backward otherwise)
+        ctx.set_materialize_grads(False)
         return syn_last, syn_next, flags_all
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_last, g_next, _g_flags=None):
         C, H, W = ctx.dims
+        if g_last is None and g_next is None:
+            return None, None, None, None, None
+        if g_last is None:
+            g_last = torch.zeros_like(g_next)
+        if g_next is None:
+            g_next = torch.zeros_like(g_last)
         # cotangent buffers whose owner says they may be overwritten (the whole-step API allocates them for exactly this):
         # outside the instances' regions the gradient IS the cotangent, so only the region pixels are touched, in place
         inplace = g_last.data_ptr() in INPLACE_COTANGENTS and g_next.data_ptr() in INPLACE_COTANGENTS \

@@ -231,3 +231,29 @@ def test_a_raising_producer_leaves_the_library_usable():
             run(raising)
     again = run(lambda i, o, s: False)
     assert again[0] == ref[0] and np.array_equal(again[1], ref[1])
+
+
+@pytest.mark.parametrize("option,temporal", [("march3", False), ("temporal_spec", True)], ids=["march3", "temporal_spec"])
+def test_alternative_teacher_schedules_hold_against_the_oracle(option, temporal):
+    """Two schedules of the teacher's gradient pass that were measured SLOWER and are off by default, kept
+    for same-box A/B -- mal_set_option("march3", 1): three cooperating waves per strip (warp | statistics | gradient row);
+    mal_set_option("temporal_spec", 1): the --temporal step's pass in front of the producer already takes the gradient and
+    the sweep behind it only redoes the tasks near the region map.  Each is held against the oracle by the same
+    decision-exact check as the default schedule."""
+    from mal_amd import _lib
+    from mal_amd.synthetic import make_batch
+    lib = _lib.load()
+    _lib.check(lib.mal_set_option(option.encode(), 1), option)
+    try:
+        if temporal:
+            from tests.test_gpu_decisions import test_temporal_hint_decision_exact, test_temporal_at_baseline_size
+            test_temporal_hint_decision_exact("step_b2_32x64_temporal")
+            test_temporal_at_baseline_size(12, 192, 640)
+        else:
+            for (B, H, W), seed in (((2, 40, 130), 41), ((12, 192, 640), 77), ((1, 16, 61), 31)):
+                b = make_batch(B, H, W, seed=seed)
+                g = torch.Generator().manual_seed(5)
+                n0, n1 = torch.randn(B, 1, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
+                _check_step(b, {}, n0, n1)
+    finally:
+        lib.mal_set_option(option.encode(), 0)
