@@ -687,7 +687,7 @@ def main():
                 traffic = json.load(open(tpath)).get("pass_kernel_teacher_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "mal::march_kernel<true,true,true,false> (teacher pass: warp+SSIM+L1+"
+        out["roofline"] = {"bound": "hbm", "kernel": "mal::march_teacher_kernel<false> (teacher pass: warp+SSIM+L1+"
                                                      "min+automask fwd+bwd, one launch)" +
                                                      ("; timed in this run on eager --distil steps of the same batch" if args.mode == "step" else ""),
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -704,7 +704,7 @@ def main():
         # kernels, + 24 B/px of d loss / d warped colour arriving through syn (SURVEY.md 8d counts +24 B/px backward)
         alg_t = ALG_BYTES_PER_PX + 24
         ach_t = alg_t * n_px / (kern_ms * 1e-3) / 1e9
-        out["roofline_temporal"] = {"bound": "hbm", "kernel": "mal::march_kernel<true,true,true,false,false,true> (the teacher's gradient "
+        out["roofline_temporal"] = {"bound": "hbm", "kernel": "mal::march_teacher_kernel<true> (the teacher's gradient "
                                     "sweep inside the --temporal step)", "achieved": ach_t, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": ach_t / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_px": alg_t,
                                     "pixels_per_launch": n_px, "kernel_ms": kern_ms, "launches_timed": len(durs)}

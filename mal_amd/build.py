@@ -80,8 +80,10 @@ VALU_COSTS = {"plain": 2.7, "packed": 4.2, "dpp": 4.3, "transcendental": 8.0, "m
               "lane": 2.7}
 VALU_JSON = os.path.join(LIBDIR, "valu_cost.json")
 # the instantiations bench.py prices: name -> substring of the mangled symbol
-VALU_KERNELS = {"teacher": "march_kernelILb1ELb1ELb1ELb0ELb0ELb0EE", "teacher_temporal": "march_kernelILb1ELb1ELb1ELb0ELb0ELb1EE",
-                "student": "march_kernelILb1ELb0ELb0ELb1ELb0ELb0EE", "ensemble": "march_kernelILb0ELb0ELb0ELb0ELb0ELb0EE"}
+VALU_KERNELS = {"teacher": "march_teacher_kernelILb0EE", "teacher_temporal": "march_teacher_kernelILb1EE",
+                "teacher_generic": "march_kernelILb1ELb1ELb1ELb0ELb0ELb0EE",
+                "student": "march_student_kernelE", "student_generic": "march_kernelILb1ELb0ELb0ELb1ELb0ELb0EE",
+                "ensemble": "march_kernelILb0ELb0ELb0ELb0ELb0ELb0EE"}
 
 
 def _valu_class(op):
@@ -177,7 +179,7 @@ def valu_report(force=False, verbose=False):
     for name, key in VALU_KERNELS.items():
         try:
             out["kernels"][name] = valu_cost_of(text, key)
-            if name != "ensemble":  # gradient passes: the two gradient-only iterations behind the row loop (one-row halo)
+            if not name.startswith(("ensemble", "warp")):  # gradient passes: the two gradient-only iterations behind the row loop (one-row halo)
                 out["kernels"][name]["drain"] = valu_cost_of(text, key, nth=1)
         except StopIteration:
             pass

@@ -237,8 +237,15 @@ MAL_DEV void warp_finish(PendingWarp& pw, f2 (&x)[3], DerivRow& d) {
 // forward-only pass in front of the producer leaves -- the warped images (twice), min / winner (twice), automask weight.
 // The body is shared; the kernels below instantiate it (EXPORT has its own entry point so that the names and the code of
 // the other instantiations stay what they were).
-template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG, bool TEMPORAL, bool EXPORT>
+// SPEC != 0: specialisations for the passes of the whole-step lists -- packed texels on both sides, no depth map out, no
+// experiment switches, and the optional operands fixed at compile time, so that the operand requests, pointer selects and
+// branches those options cost in every row are compiled out (march_launch checks that a launch qualifies):
+//   1  teacher / the pass in front of the producer: no second disparity, no external or matching mask, no per-sample scale
+//   2  student: external mask, matching mask (lowest cost + teacher disparity) all present, no second disparity
+template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG, bool TEMPORAL, bool EXPORT, int SPEC = 0>
 MAL_DEV void march_body() {
+  constexpr bool LEAN = SPEC != 0;
+  constexpr bool NO_DISP2 = SPEC == 1 || SPEC == 2, NO_MAPS = SPEC == 1, ALL_MAPS = SPEC == 2;
   constexpr bool OUTS = EXPORT || (!GRAD && !EPI);  // the outputs the producer / the fused sweep read
   constexpr int HALO = GRAD ? 2 : 1;
   constexpr int CW = 64 - 2 * HALO;
@@ -304,10 +311,10 @@ MAL_DEV void march_body() {
   // (B,1,H,W) maps are addressed as (kernel-argument pointer) + (32-bit per-lane byte offset that already holds the
   // sample's base): no 64-bit pointer arithmetic per map and row (check_shape bounds a map below 2^31 bytes)
   const float* disp_b = p.disp;
-  const float* disp2_b = p.disp2;
+  const float* disp2_b = NO_DISP2 ? nullptr : p.disp2;
   const unsigned lane_off = (unsigned)gxr * 4u + (unsigned)b * (unsigned)HW * 4u;
   auto moff = [&](int row) { return (unsigned)(prow(row) * W) * 4u + lane_off; };  // row in [0, H-1] (logical)
-  const float sscale = p.sample_scale ? (p.sample_scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
+  const float sscale = (!NO_MAPS && p.sample_scale) ? (p.sample_scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
 
   // ---- running state (pairs as in WarpRow: index k*3 + {x, x^2, xy} for the colour pairs k)
   // The horizontal sums of the two previous rows: A = row r-2, B = row r-1.  The window sum of centre row r-1 is
@@ -379,9 +386,10 @@ MAL_DEV void march_body() {
   auto maps_of = [&](CParams& pp) {
     Maps m;
     m.ident = AUTOMASK ? pp.ident : nullptr; m.noise = AUTOMASK ? pp.noise : nullptr;
-    m.ext_mask = pp.ext_mask; m.lowest_cost = pp.lowest_cost; m.mono_disp = pp.mono_disp;
+    m.ext_mask = NO_MAPS ? nullptr : pp.ext_mask; m.lowest_cost = NO_MAPS ? nullptr : pp.lowest_cost;
+    m.mono_disp = NO_MAPS ? nullptr : pp.mono_disp;
     m.mono_depth = EPI ? pp.mono_depth : nullptr; m.mono_reproj = EPI ? pp.mono_reproj : nullptr;
-    m.ens_reproj = EPI ? pp.ens_reproj : nullptr; m.target = pp.target; m.packed = pp.packed;
+    m.ens_reproj = EPI ? pp.ens_reproj : nullptr; m.target = pp.target; m.packed = LEAN ? 3 : pp.packed;
     m.forced_w = TEMPORAL ? pp.forced_w : nullptr; m.forced_arg = TEMPORAL ? pp.forced_arg : nullptr;
     m.gcol[0] = TEMPORAL ? pp.g_color[0] : nullptr; m.gcol[1] = TEMPORAL ? pp.g_color[1] : nullptr;
     m.fin_gn = TEMPORAL ? pp.fin_gn : nullptr;
@@ -398,7 +406,8 @@ MAL_DEV void march_body() {
     const unsigned pix = (unsigned)(prow(row_of(rr)) * W + gxr);
     const unsigned od = moff(row_of(rr));
     a.disp = ldf(disp_b, od);
-    {
+    a.disp2 = 0.f;
+    if (!NO_DISP2) {
       const float v = ldf(disp2_b ? disp2_b : disp_b, od);
       a.disp2 = disp2_b ? v : 0.f;
     }
@@ -419,13 +428,18 @@ MAL_DEV void march_body() {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) a.gc[f * 3 + ch] = ldf(pp.gcol[f] + ((size_t)b * 3 + ch) * HW, og);
     }
-    a.ext = opt(pp.ext_mask, oc, 1.f);
-    a.mono = opt(pp.lowest_cost ? pp.mono_disp : nullptr, oc, 0.f);
-    a.cost = opt(pp.lowest_cost, oc, 1.f);
+    a.ext = 1.f; a.mono = 0.f; a.cost = 1.f;
+    if (ALL_MAPS) {
+      a.ext = ldf(pp.ext_mask, oc); a.mono = ldf(pp.mono_disp, oc); a.cost = ldf(pp.lowest_cost, oc);
+    } else if (!NO_MAPS) {
+      a.ext = opt(pp.ext_mask, oc, 1.f);
+      a.mono = opt(pp.lowest_cost ? pp.mono_disp : nullptr, oc, 0.f);
+      a.cost = opt(pp.lowest_cost, oc, 1.f);
+    }
     const unsigned oq = GRAD ? moff(min(max(rr - 2, 0), H - 1)) : oc;  // epilogue row
     a.e_mono = 0.f; a.e_mr = 0.f; a.e_er = 0.f; a.e_ensd = 0.f;
     if (EPI) {
-      a.e_mono = ldf(pp.mono_disp ? pp.mono_disp : pp.mono_depth, oq);
+      a.e_mono = ldf(ALL_MAPS ? pp.mono_disp : (pp.mono_disp ? pp.mono_disp : pp.mono_depth), oq);
       a.e_mr = ldf(pp.mono_reproj, oq);
       a.e_er = opt(pp.ens_reproj, oq, 0.f);
       a.e_ensd = opt(pp.ens_disp, oq, 0.f);
@@ -501,7 +515,7 @@ MAL_DEV void march_body() {
   // ================= stage G: output row q = c-1 = r-2 ======================================
   const int q = r - 2, c = r - 1;
   const bool own_q = q >= y_lo && q < y_hi;  // false: a boundary row of the neighbouring task (one-row halo)
-  if (q >= y_lo - h1e && q < y_hi + h1e && (unsigned)q < (unsigned)H && !(p.debug & 4)) {  // wave-uniform
+  if (q >= y_lo - h1e && q < y_hi + h1e && (unsigned)q < (unsigned)H && (LEAN || !(p.debug & 4))) {  // wave-uniform
     WarpRow wq;
     DerivRow dq;
     f2 pq_u = bc(0.f), pq_v = bc(0.f), pq_rz = bc(0.f);
@@ -617,10 +631,11 @@ MAL_DEV void march_body() {
     PixInfo pi0;  // what stage S decides for the centre row c = r-1
     pi0.rp = 0.f; pi0.w = 0.f; pi0.win = 0;
     const Maps mp = maps_of(p);
-    const bool has_noise = mp.noise != nullptr, has_ext = mp.ext_mask != nullptr, has_cost = mp.lowest_cost != nullptr,
-               has_mdisp = mp.mono_disp != nullptr, has_er = mp.ens_reproj != nullptr;
+    const bool has_noise = mp.noise != nullptr, has_ext = ALL_MAPS || mp.ext_mask != nullptr,
+               has_cost = ALL_MAPS || mp.lowest_cost != nullptr, has_mdisp = ALL_MAPS || mp.mono_disp != nullptr,
+               has_er = mp.ens_reproj != nullptr;
     WarpConsts wc;
-    wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = mp.packed; wc.debug = p.debug; wc.W = W; wc.H = H;
+    wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = mp.packed; wc.debug = LEAN ? 0 : p.debug; wc.W = W; wc.H = H;
     wc.convention = p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
     wc.rw = norm_rw; wc.rh = norm_rh;
     wc.dbg = DBG ? p.dbg : nullptr; wc.dbg_n = (unsigned)(p.B * HW);
@@ -852,7 +867,7 @@ MAL_DEV void march_body() {
 
     tick(6);  // partial-plane sums, gradient row
     if (EPI && !GRAD) epilogue(p, r, pi0, le_disp, le_mono, le_mr, le_er, so_c, so_q, has_mdisp, has_er, cur.e_ensd);
-    if (p.depth_out) {
+    if (!LEAN && p.depth_out) {
       const int q = r - 1;
       if (q >= y_lo && q < y_hi && out_x)
         stf(p.depth_out, so_c, depth_of(ldf(disp_b, so_c), wc.min_disp, wc.range));
@@ -924,6 +939,17 @@ __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
 template <bool DBG>
 __global__ __launch_bounds__(64, 2) void march_export_kernel(MarchParams p_kernarg) {
   march_body<true, true, true, false, DBG, false, true>();
+}
+// the teacher's gradient pass of the whole-step lists (the north-star kernel), with / without the temporal hint
+template <bool TEMPORAL>
+__global__ __launch_bounds__(64, 2) void march_teacher_kernel(MarchParams p_kernarg) {
+  march_body<true, true, true, false, false, TEMPORAL, false, 1>();
+}
+// ... and the student's gradient pass with the consistency / distillation epilogue.  (The forward-only passes gain nothing
+// from a specialisation -- same-box: ensemble 35.17 -> 35.12 us, the pass in front of the producer 56.8 -> 58.0 us -- and
+// keep the generic instantiations.)
+__global__ __launch_bounds__(64, 2) void march_student_kernel(MarchParams p_kernarg) {
+  march_body<true, false, false, true, false, false, false, 2>();
 }
 
 // =====================================================================================================================
@@ -1532,6 +1558,7 @@ extern int g_syn_queue;       // mal_photo_march.hip
 extern int g_step_overlap;    // mal_step.hip
 extern int g_march_halo1;     // mal_step.hip
 extern int g_temporal_spec;   // mal_step.hip
+int g_march_lean = 1;         // option "march_lean": the teacher's passes without the optional operands' code (0: generic, A/B)
 int g_march3 = 0;             // option "march3": the teacher's gradient pass as a three-wave pipeline (0: one wave per strip)
 
 MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, float eps, int convention) {
@@ -1601,6 +1628,11 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   hipEvent_t ev0 = named ? g_prof_start : nullptr, ev1 = named ? g_prof_stop : nullptr;
   if (named) g_prof_start = g_prof_stop = nullptr;
   if (ev0) (void)hipEventRecord(ev0, st);
+  // the specialisation without the optional operands (march_body LEAN)
+  const bool lean0 = g_march_lean && p.packed == 3 && !p.depth_out && p.debug == 0 && !p.dbg;
+  const bool no_maps = !p.ext_mask && !p.lowest_cost && !p.sample_scale;
+  const bool lean = lean0 && no_maps && !p.disp2;                                             // SPEC 1
+  const bool lean_student = lean0 && !p.disp2 && p.ext_mask && p.lowest_cost && p.mono_disp;  // SPEC 2
 #define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((march_kernel<G, A, P, E>), grid, block, 0, st, p)
   if (grad && p.color_out[0]) {  // the teacher's pass of the --temporal step in front of the producer
     if (!(pose && automask && !epi) || p.forced_w || !p.color_out[1]) return MAL_EINVAL;
@@ -1617,15 +1649,20 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
     } else hipLaunchKernelGGL(march3_kernel<false>, grid, dim3(192), 0, st, p);
   } else if (p.forced_w) {  // TEMPORAL teacher pass
     if (!(grad && pose && automask && !epi) || !p.forced_arg || !p.g_color[0] || !p.g_color[1]) return MAL_EINVAL;
-    if (p.dbg) {
+    if (lean && !p.dbg) hipLaunchKernelGGL(march_teacher_kernel<true>, grid, block, 0, st, p);
+    else if (p.dbg) {
       if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
       hipLaunchKernelGGL((march_kernel<true, true, true, false, true, true>), grid, block, 0, st, p);
     } else hipLaunchKernelGGL((march_kernel<true, true, true, false, false, true>), grid, block, 0, st, p);
+  } else if (lean && !p.dbg && grad && pose && automask && !epi) {  // the teacher's pass of the whole-step lists
+    hipLaunchKernelGGL(march_teacher_kernel<false>, grid, block, 0, st, p);
   } else if (p.dbg) {  // instrumented instantiations exist for the two gradient passes of the whole-step list
     if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
     if (grad && pose && automask && !epi) hipLaunchKernelGGL((march_kernel<true, true, true, false, true>), grid, block, 0, st, p);
     else if (grad && !pose && !automask && epi) hipLaunchKernelGGL((march_kernel<true, false, false, true, true>), grid, block, 0, st, p);
     else return MAL_EINVAL;
+  } else if (lean_student && grad && !pose && !automask && epi) {
+    hipLaunchKernelGGL(march_student_kernel, grid, block, 0, st, p);
   } else if (!grad) {
     if (automask) { if (epi) MAL_LAUNCH(false, true, false, true); else MAL_LAUNCH(false, true, false, false); }
     else          { if (epi) MAL_LAUNCH(false, false, false, true); else MAL_LAUNCH(false, false, false, false); }
@@ -1696,6 +1733,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("march_halo1")) { g_march_halo1 = value != 0; return MAL_OK; }
   if (eq("temporal_spec")) { g_temporal_spec = value != 0; return MAL_OK; }
   if (eq("march3")) { g_march3 = value != 0; return MAL_OK; }
+  if (eq("march_lean")) { g_march_lean = value != 0; return MAL_OK; }
   if (eq("syn_queue")) { g_syn_queue = value != 0; return MAL_OK; }
   if (eq("syn_rows")) { if (value < 2 || value > 64) return MAL_EINVAL; g_syn_rows = value; return MAL_OK; }
   if (eq("epi_bwd_planes")) { g_epi_bwd_planes = value != 0; return MAL_OK; }
