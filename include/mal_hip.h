@@ -563,7 +563,18 @@ int mal_direct_align_update_bwd(const float* H, const float* b, const float* pos
  * "step_overlap" 1 (default): with MAL_STEP_TEMPORAL the ensemble pass runs on a side stream beside the producer (forked
  *               after the warp pass, joined before the student pass; events, capturable); 0: in line; 2: beside the
  *               fused sweep (slower: kept for A/B);  "syn_rows": rows per task of the fused sweep given a region map;
- * "fwd_waves", "debug": kernel experiments. */
+ * "march_halo1" 1 (default): the gradient passes of the whole-step lists warp ONE row beyond each end of a task's segment
+ *               and hand the boundary rows' missing terms over through scratch rows; 0: two rows, no hand-over (A/B);
+ * "march_lean"  1 (default): the teacher / student passes of the whole-step lists run the instantiations without the code
+ *               of the optional operands they never pass (march_teacher_kernel, march_student_kernel); 0: generic (A/B);
+ * "syn_queue"   1: the fused sweep over the synthesised pair takes its tasks from a classified dispatch order (slower,
+ *               default 0);
+ * "temporal_spec" 1: with MAL_STEP_TEMPORAL the pass in front of the producer already takes the teacher's gradient and the
+ *               sweep behind the producer's backward only redoes the tasks near the region map (slower unless no sample
+ *               has instances; default 0);
+ * "march3"      1: the teacher's gradient pass as three cooperating wavefronts per strip, rows handed over through LDS
+ *               (slower; default 0);
+ * "epi_probe", "fwd_waves", "debug": kernel experiments / timing probes. */
 int mal_set_option(const char* name, int value);
 
 /* ---- measurement hooks (bench.py): HIP events recorded immediately before / after the main
