@@ -238,14 +238,25 @@ MAL_DEV void warp_finish(PendingWarp& pw, f2 (&x)[3], DerivRow& d) {
 // The body is shared; the kernels below instantiate it (EXPORT has its own entry point so that the names and the code of
 // the other instantiations stay what they were).
 // SPEC != 0: specialisations for the passes of the whole-step lists -- packed texels on both sides, no depth map out, no
-// experiment switches, and the optional operands fixed at compile time, so that the operand requests, pointer selects and
-// branches those options cost in every row are compiled out (march_launch checks that a launch qualifies):
-//   1  teacher / the pass in front of the producer: no second disparity, no external or matching mask, no per-sample scale
-//   2  student: external mask, matching mask (lowest cost + teacher disparity) all present, no second disparity
+// experiment switches (kSpecLean), and optional operands fixed at compile time, so that the operand requests, pointer
+// selects and branches those options cost in every row are compiled out (march_launch checks that a launch qualifies).
+enum : int {
+  kSpecLean = 1, kSpecNoDisp2 = 2,
+  kSpecExtNo = 4, kSpecExtYes = 8,      // external mask: absent / present (neither: decided per launch)
+  kSpecCostNo = 16, kSpecCostYes = 32,  // matching mask (lowest cost + the teacher's disparity): absent / present
+  kSpecMonoYes = 64,                    // the teacher's disparity is given as disparity (epilogue)
+  kSpecNoScale = 128,                   // no per-sample scale
+  kSpecTeacher = kSpecLean | kSpecNoDisp2 | kSpecExtNo | kSpecCostNo | kSpecNoScale,
+  kSpecStudent = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostYes | kSpecMonoYes,      // whole-step list, scale 0
+  kSpecStudentNoCost = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostNo | kSpecMonoYes, // four-scale list, scales > 0
+  kSpecRefine = kSpecLean | kSpecNoDisp2 | kSpecCostNo | kSpecMonoYes | kSpecNoScale        // DualRefine, deq iterations > 0
+};
 template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG, bool TEMPORAL, bool EXPORT, int SPEC = 0>
 MAL_DEV void march_body() {
-  constexpr bool LEAN = SPEC != 0;
-  constexpr bool NO_DISP2 = SPEC == 1 || SPEC == 2, NO_MAPS = SPEC == 1, ALL_MAPS = SPEC == 2;
+  constexpr bool LEAN = (SPEC & kSpecLean) != 0, NO_DISP2 = (SPEC & kSpecNoDisp2) != 0;
+  constexpr bool EXT_NO = (SPEC & kSpecExtNo) != 0, EXT_YES = (SPEC & kSpecExtYes) != 0;
+  constexpr bool COST_NO = (SPEC & kSpecCostNo) != 0, COST_YES = (SPEC & kSpecCostYes) != 0;
+  constexpr bool MONO_YES = (SPEC & kSpecMonoYes) != 0, NO_SCALE = (SPEC & kSpecNoScale) != 0;
   constexpr bool OUTS = EXPORT || (!GRAD && !EPI);  // the outputs the producer / the fused sweep read
   constexpr int HALO = GRAD ? 2 : 1;
   constexpr int CW = 64 - 2 * HALO;
@@ -314,7 +325,7 @@ MAL_DEV void march_body() {
   const float* disp2_b = NO_DISP2 ? nullptr : p.disp2;
   const unsigned lane_off = (unsigned)gxr * 4u + (unsigned)b * (unsigned)HW * 4u;
   auto moff = [&](int row) { return (unsigned)(prow(row) * W) * 4u + lane_off; };  // row in [0, H-1] (logical)
-  const float sscale = (!NO_MAPS && p.sample_scale) ? (p.sample_scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
+  const float sscale = (!NO_SCALE && p.sample_scale) ? (p.sample_scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
 
   // ---- running state (pairs as in WarpRow: index k*3 + {x, x^2, xy} for the colour pairs k)
   // The horizontal sums of the two previous rows: A = row r-2, B = row r-1.  The window sum of centre row r-1 is
@@ -386,8 +397,8 @@ MAL_DEV void march_body() {
   auto maps_of = [&](CParams& pp) {
     Maps m;
     m.ident = AUTOMASK ? pp.ident : nullptr; m.noise = AUTOMASK ? pp.noise : nullptr;
-    m.ext_mask = NO_MAPS ? nullptr : pp.ext_mask; m.lowest_cost = NO_MAPS ? nullptr : pp.lowest_cost;
-    m.mono_disp = NO_MAPS ? nullptr : pp.mono_disp;
+    m.ext_mask = EXT_NO ? nullptr : pp.ext_mask; m.lowest_cost = COST_NO ? nullptr : pp.lowest_cost;
+    m.mono_disp = (COST_NO && !EPI) ? nullptr : pp.mono_disp;
     m.mono_depth = EPI ? pp.mono_depth : nullptr; m.mono_reproj = EPI ? pp.mono_reproj : nullptr;
     m.ens_reproj = EPI ? pp.ens_reproj : nullptr; m.target = pp.target; m.packed = LEAN ? 3 : pp.packed;
     m.forced_w = TEMPORAL ? pp.forced_w : nullptr; m.forced_arg = TEMPORAL ? pp.forced_arg : nullptr;
@@ -429,17 +440,18 @@ MAL_DEV void march_body() {
         for (int ch = 0; ch < 3; ++ch) a.gc[f * 3 + ch] = ldf(pp.gcol[f] + ((size_t)b * 3 + ch) * HW, og);
     }
     a.ext = 1.f; a.mono = 0.f; a.cost = 1.f;
-    if (ALL_MAPS) {
-      a.ext = ldf(pp.ext_mask, oc); a.mono = ldf(pp.mono_disp, oc); a.cost = ldf(pp.lowest_cost, oc);
-    } else if (!NO_MAPS) {
-      a.ext = opt(pp.ext_mask, oc, 1.f);
+    if (EXT_YES) a.ext = ldf(pp.ext_mask, oc);
+    else if (!EXT_NO) a.ext = opt(pp.ext_mask, oc, 1.f);
+    if (COST_YES) {
+      a.mono = ldf(pp.mono_disp, oc); a.cost = ldf(pp.lowest_cost, oc);
+    } else if (!COST_NO) {
       a.mono = opt(pp.lowest_cost ? pp.mono_disp : nullptr, oc, 0.f);
       a.cost = opt(pp.lowest_cost, oc, 1.f);
     }
     const unsigned oq = GRAD ? moff(min(max(rr - 2, 0), H - 1)) : oc;  // epilogue row
     a.e_mono = 0.f; a.e_mr = 0.f; a.e_er = 0.f; a.e_ensd = 0.f;
     if (EPI) {
-      a.e_mono = ldf(ALL_MAPS ? pp.mono_disp : (pp.mono_disp ? pp.mono_disp : pp.mono_depth), oq);
+      a.e_mono = ldf(MONO_YES ? pp.mono_disp : (pp.mono_disp ? pp.mono_disp : pp.mono_depth), oq);
       a.e_mr = ldf(pp.mono_reproj, oq);
       a.e_er = opt(pp.ens_reproj, oq, 0.f);
       a.e_ensd = opt(pp.ens_disp, oq, 0.f);
@@ -631,8 +643,8 @@ MAL_DEV void march_body() {
     PixInfo pi0;  // what stage S decides for the centre row c = r-1
     pi0.rp = 0.f; pi0.w = 0.f; pi0.win = 0;
     const Maps mp = maps_of(p);
-    const bool has_noise = mp.noise != nullptr, has_ext = ALL_MAPS || mp.ext_mask != nullptr,
-               has_cost = ALL_MAPS || mp.lowest_cost != nullptr, has_mdisp = ALL_MAPS || mp.mono_disp != nullptr,
+    const bool has_noise = mp.noise != nullptr, has_ext = EXT_YES || mp.ext_mask != nullptr,
+               has_cost = COST_YES || mp.lowest_cost != nullptr, has_mdisp = MONO_YES || mp.mono_disp != nullptr,
                has_er = mp.ens_reproj != nullptr;
     WarpConsts wc;
     wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = mp.packed; wc.debug = LEAN ? 0 : p.debug; wc.W = W; wc.H = H;
@@ -943,13 +955,18 @@ __global__ __launch_bounds__(64, 2) void march_export_kernel(MarchParams p_kerna
 // the teacher's gradient pass of the whole-step lists (the north-star kernel), with / without the temporal hint
 template <bool TEMPORAL>
 __global__ __launch_bounds__(64, 2) void march_teacher_kernel(MarchParams p_kernarg) {
-  march_body<true, true, true, false, false, TEMPORAL, false, 1>();
+  march_body<true, true, true, false, false, TEMPORAL, false, kSpecTeacher>();
 }
 // ... and the student's gradient pass with the consistency / distillation epilogue.  (The forward-only passes gain nothing
 // from a specialisation -- same-box: ensemble 35.17 -> 35.12 us, the pass in front of the producer 56.8 -> 58.0 us -- and
 // keep the generic instantiations.)
+template <int SPEC>
 __global__ __launch_bounds__(64, 2) void march_student_kernel(MarchParams p_kernarg) {
-  march_body<true, false, false, true, false, false, false, 2>();
+  march_body<true, false, false, true, false, false, false, SPEC>();
+}
+// DualRefine's passes of the deq iterations > 0: teacher-style pass (automask, pose gradients) with the consistency epilogue
+__global__ __launch_bounds__(64, 2) void march_refine_kernel(MarchParams p_kernarg) {
+  march_body<true, true, true, true, false, false, false, kSpecRefine>();
 }
 
 // =====================================================================================================================
@@ -1632,7 +1649,9 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   const bool lean0 = g_march_lean && p.packed == 3 && !p.depth_out && p.debug == 0 && !p.dbg;
   const bool no_maps = !p.ext_mask && !p.lowest_cost && !p.sample_scale;
   const bool lean = lean0 && no_maps && !p.disp2;                                             // SPEC 1
-  const bool lean_student = lean0 && !p.disp2 && p.ext_mask && p.lowest_cost && p.mono_disp;  // SPEC 2
+  const bool lean_student = lean0 && !p.disp2 && p.ext_mask && p.lowest_cost && p.mono_disp;          // kSpecStudent
+  const bool lean_student_nc = lean0 && !p.disp2 && p.ext_mask && !p.lowest_cost && p.mono_disp;      // kSpecStudentNoCost
+  const bool lean_refine = lean0 && !p.disp2 && !p.lowest_cost && p.mono_disp && !p.sample_scale;     // kSpecRefine
 #define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((march_kernel<G, A, P, E>), grid, block, 0, st, p)
   if (grad && p.color_out[0]) {  // the teacher's pass of the --temporal step in front of the producer
     if (!(pose && automask && !epi) || p.forced_w || !p.color_out[1]) return MAL_EINVAL;
@@ -1662,7 +1681,11 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
     else if (grad && !pose && !automask && epi) hipLaunchKernelGGL((march_kernel<true, false, false, true, true>), grid, block, 0, st, p);
     else return MAL_EINVAL;
   } else if (lean_student && grad && !pose && !automask && epi) {
-    hipLaunchKernelGGL(march_student_kernel, grid, block, 0, st, p);
+    hipLaunchKernelGGL(march_student_kernel<kSpecStudent>, grid, block, 0, st, p);
+  } else if (lean_student_nc && grad && !pose && !automask && epi) {
+    hipLaunchKernelGGL(march_student_kernel<kSpecStudentNoCost>, grid, block, 0, st, p);
+  } else if (lean_refine && grad && pose && automask && epi && !p.forced_w) {
+    hipLaunchKernelGGL(march_refine_kernel, grid, block, 0, st, p);
   } else if (!grad) {
     if (automask) { if (epi) MAL_LAUNCH(false, true, false, true); else MAL_LAUNCH(false, true, false, false); }
     else          { if (epi) MAL_LAUNCH(false, false, false, true); else MAL_LAUNCH(false, false, false, false); }
