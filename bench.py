@@ -697,6 +697,20 @@ def main():
                            "alg_bytes_per_px": ALG_BYTES_PER_PX, "pixels_per_launch": n_px,
                            "kernel_ms": kern_ms_plain, "launches_timed": 20 if args.mode == "step" else len(durs),
                            "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None}
+        # the same kernel inside the REPLAYED graph, from the rocprofv3 summary committed with the round: HIP events cannot be
+        # recorded inside a captured graph on this stack (the capture aborts), and an eager launch bracketed by events runs
+        # slower than a replayed one by rocprofv3's own timestamps -- the line carries both
+        rpath = os.path.join(ROOT, "profiles", "r03_kernel_stats_distil.csv")
+        try:
+            import csv
+            row = [r for r in csv.DictReader(open(rpath)) if "march_teacher_kernel<false>" in r["Name"]][0]
+            us = float(row["AverageNs"]) * 1e-3
+            out["roofline"]["replayed_rocprof"] = {
+                "kernel_us": us, "calls": int(row["Calls"]), "frac": ALG_BYTES_PER_PX * n_px / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "source": "profiles/r03_kernel_stats_distil.csv (rocprofv3 --kernel-trace --stats of `bench.py --mode distil`, "
+                          "graph-replayed launches), committed with the round; not re-measured in this run"}
+        except Exception:
+            pass
         out["roofline"].update(valu_bound(lib, dev, kern_ms_plain, achieved / HBM_PEAK_GBS,
                                           halo1="march_halo1=0" not in args.opt))
     if args.mode == "step" and kern_ms > 0:
