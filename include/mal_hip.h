@@ -252,9 +252,14 @@ enum {
                               [g_warp_f = producer^T(g_syn_f), linear]
                               mal_loss_step_bwd   g_warp_* in (same scale); runs the teacher's gradient sweep with the
                                                   four-way decisions of _fwd and adds what arrives through syn */
-  MAL_STEP_NOISE_PHILOX = 4 /* the automask tie-break noise (loss_utils.py:105-106: + 1e-5 * randn) is drawn inside the
+  MAL_STEP_NOISE_PHILOX = 4, /* the automask tie-break noise (loss_utils.py:105-106: + 1e-5 * randn) is drawn inside the
                                step's first kernel: N(0,1) by Box-Muller from Philox4x32-10 keyed by noise_seed, counter =
                                (pixel, step); `noise` must be NULL.  No host RNG, no device RNG launch on the step. */
+  MAL_STEP_SYN_SPARSE = 16  /* with MAL_STEP_TEMPORAL and syn_region: syn_* hold the synthesised images ONLY at pixels whose
+                               region byte has bit 0 set (a producer that writes its regions into otherwise untouched
+                               buffers); elsewhere they are by definition the warped images mal_loss_step_warp wrote
+                               (warp_*, still set), which the sweep reads there.  warp2_* may then be NULL: the pass in
+                               front of the producer writes the warped images once instead of twice. */
 };
 typedef struct mal_step_args {
   int B, H, W;

@@ -45,6 +45,11 @@ struct PhotoMarchParams {
   // task order[i], so the few expensive tasks are all resident from the start instead of each of three rounds of
   // workgroups waiting for its slowest member.  Which position a task gets depends on timing; what it computes does not.
   unsigned* order; unsigned* order_count;
+  // FUSED with a region map, nullable (both or none): the candidates hold the pair ONLY at region pixels (bit 0 of the
+  // byte); everywhere else the pixel is read from orig[f] -- the images the pair was made from, planar (3,H,W) per sample,
+  // orig_stride floats between samples.  (The whole-step API: the pass in front of the producer then writes the warped
+  // images once instead of twice, and the producer touches its regions only.)
+  const float* orig[2]; size_t orig_stride;
 };
 
 struct Px9 { float t[3], a[3], c[3]; };
@@ -194,6 +199,9 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
   const float* tb = p.target + (size_t)b * 3 * HW;
   const float* ab = p.cand[0] + (size_t)b * 3 * HW;
   const float* cb = p.cand[1] + (size_t)b * 3 * HW;
+  const bool sparse = FUSED && p.region && p.orig[0];
+  const float* oa = sparse ? p.orig[0] + (size_t)b * p.orig_stride : ab;
+  const float* ob = sparse ? p.orig[1] + (size_t)b * p.orig_stride : cb;
   float* ga = p.g_cand[0] + (size_t)b * 3 * HW;
   float* gb = p.g_cand[1] ? p.g_cand[1] + (size_t)b * 3 * HW : nullptr;
   const size_t map_b = (size_t)b * HW;
@@ -234,6 +242,13 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
   const int r_first = max(y_lo - HALO, -1), r_last = y_hi - 1 + HALO;
   Px9 nxt;
   request9(p, tb, ab, cb, HW, row_of(r_first), gxr, nxt);
+  float on_a[3] = {0.f, 0.f, 0.f}, on_c[3] = {0.f, 0.f, 0.f};  // sparse pair: the same pixel of the images it was made from
+  auto request_orig = [&](int row) {
+    const unsigned bo = (unsigned)(row * W + gxr) * 4u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { on_a[ch] = ldf(oa + (size_t)ch * HW, bo); on_c[ch] = ldf(ob + (size_t)ch * HW, bo); }
+  };
+  if (sparse) request_orig(row_of(r_first));
   unsigned fr_nxt = (FUSED && rgn) ? rgn[row_of(r_first) * W + gxr] : 1u;  // the region byte travels one row ahead, like the planes
   unsigned fr_m0 = 0u, fr_m1 = 0u;  // region bytes of rows r-1 and r-2
   float pm_nxt = 0.f, idn_nxt = 0.f;
@@ -246,11 +261,16 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
     if (p.noise) idn_nxt += ldf(p.noise + map_b, g0 * 4u) * 0.00001f;
   }
   for (int r = r_first; r <= r_last; ++r) {
-    const Px9 cur = nxt;
+    Px9 cur = nxt;
     const unsigned fr_q = fr_m1;  // region byte of the gradient row q = r-2
     fr_m1 = fr_m0; fr_m0 = fr_nxt;
     const unsigned fr_cur = fr_nxt;
+    if (sparse && !(fr_cur & 1u)) {  // outside the region the pair IS the images it was made from
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) { cur.a[ch] = on_a[ch]; cur.c[ch] = on_c[ch]; }
+    }
     request9(p, tb, ab, cb, HW, row_of(r + 1), gxr, nxt);
+    if (sparse) request_orig(row_of(r + 1));
     if (FUSED && rgn) fr_nxt = rgn[row_of(r + 1) * W + gxr];
     const int c = r - 1;
     const bool c_valid = c >= 0 && c < H && c >= y_lo - 1 && c <= y_hi;
@@ -675,14 +695,17 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
                            const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
-                           float* g_region1, unsigned* order, unsigned* order_count) {
+                           float* g_region1, unsigned* order, unsigned* order_count, const float* orig0, const float* orig1,
+                           size_t orig_stride) {
   if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
+  if ((orig0 == nullptr) != (orig1 == nullptr) || (orig0 && !region)) return MAL_EINVAL;
   PhotoMarchParams p = {};
   p.target = target; p.B = B; p.H = H; p.W = W;
   p.cand[0] = cand0; p.cand[1] = cand1; p.idx[0] = idx0; p.idx[1] = idx0 + 1;
   p.prev_min = prev_min; p.prev_arg = prev_arg; p.ident = ident; p.noise = noise;
   p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;
   p.g_cand[0] = g_cand0; p.g_cand[1] = g_cand1; p.region = region;
+  p.orig[0] = orig0; p.orig[1] = orig1; p.orig_stride = orig_stride ? orig_stride : (size_t)3 * H * W;
   if (region && g_region0 && g_region1) { p.g_region[0] = g_region0; p.g_region[1] = g_region1; }
   // with a region map the few tasks that do the full work set the kernel's duration (every task is resident at once, and
   // a wavefront alone on its SIMD marches no faster): shorter tasks, four times as many (the workspace holds 2-row tasks)

@@ -26,7 +26,8 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
                            const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
-                           float* g_region1, unsigned* order, unsigned* order_count);
+                           float* g_region1, unsigned* order, unsigned* order_count, const float* orig0, const float* orig1,
+                           size_t orig_stride);
 
 constexpr int kLossSlots = 16;
 
@@ -569,6 +570,10 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     // loss_utils.py:79-90,103), the automask and the teacher's sums are formed over all four, and the gradient w.r.t.
     // the synthesised images leaves unnormalised
     if (!a->syn_m1 || !a->syn_p1 || !a->g_syn_m1 || !a->g_syn_p1) { (void)join_side(st); return MAL_EINVAL; }
+    // MAL_STEP_SYN_SPARSE: syn_* hold the synthesised images at the region pixels only; elsewhere they are the warped
+    // images mal_loss_step_warp wrote (warp_*), which the sweep then reads instead
+    const bool sparse = (a->flags & MAL_STEP_SYN_SPARSE) != 0;
+    if (sparse && (!a->syn_region || !a->warp_m1 || !a->warp_p1)) { (void)join_side(st); return MAL_EINVAL; }
     if (ensemble_forked(a) && g_step_overlap == 2) {
       rc = fork_ensemble(a, w, st);
       if (rc) return rc;
@@ -576,7 +581,8 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     per_sample_p = pack_identity_tasks_per_sample(H, W);
     rc = photo_march_fused_more(a->color0, a->syn_m1, a->syn_p1, 2, w.ident, a->noise, w.rp_warp, w.arg_warp, B, H, W,
                                 mono_reproj, w.arg_t, w.w_t, w.bs_ph, a->g_syn_m1, a->g_syn_p1, &per_sample_ph, st, a->syn_region,
-                                a->g_syn_region_m1, a->g_syn_region_p1, w.order, w.ticket + 1);
+                                a->g_syn_region_m1, a->g_syn_region_p1, w.order, w.ticket + 1,
+                                sparse ? a->warp_m1 : nullptr, sparse ? a->warp_p1 : nullptr, (size_t)a->warp_sample_stride);
     if (rc) { (void)join_side(st); return rc; }
   }
   // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp

@@ -240,8 +240,13 @@ def image_synthesis(inputs, outputs, scale, thres, ins_model, matcher):
         return False
     # ("syn_prefilled", scale): two (B,3,H,W) buffers that hold the warped images already (the whole-step API's warp pass
     # writes them twice): the synthesised images are made in them, touching only the instances' regions
+    # ("syn_sparse_buffers", scale): two untouched (B,3,H,W) buffers of a consumer that reads syn at region pixels only (the
+    # whole-step API, MAL_STEP_SYN_SPARSE): same kernels, nothing else is written, and ("syn_sparse", scale) says so
+    sparse = outputs.get(("syn_sparse_buffers", scale))
     syn_last, syn_next, region = BatchSynthesisFn.apply(color_last, color_next, items, False,
-                                                        outputs.get(("syn_prefilled", scale)))
+                                                        sparse if sparse is not None else outputs.get(("syn_prefilled", scale)))
+    if sparse is not None:
+        outputs[("syn_sparse", scale)] = True
     outputs[("syn", -1, scale)], outputs[("syn", 1, scale)] = syn_last, syn_next
     # (B,H,W) bytes, bit 0: where syn can differ from the warped images (a consumer may skip the synthesised candidates
     # elsewhere: an exact tie goes to the warped one anyway, loss_utils.py:103)

@@ -162,18 +162,19 @@ class TemporalLossStepFn(Function):
         warp = [pair[:, 0], pair[:, 1]]
         a.warp_m1, a.warp_p1 = warp[0].data_ptr(), warp[1].data_ptr()
         a.warp_sample_stride = 6 * H * W
-        # ... and a second time into the buffers the synthesised images are made in: a producer that knows the key
-        # ("syn_prefilled", scale) -- mal_amd.dyn_utils.image_synthesis -- then overwrites only the pixels of its instances'
-        # regions instead of copying every sample first (dyn_utils.py:127-128)
+        # The buffers the synthesised images are made in are NOT filled: a producer that knows the key
+        # ("syn_sparse_buffers", scale) -- mal_amd.dyn_utils.image_synthesis -- writes only the pixels of its instances'
+        # regions into them instead of cloning every sample first (dyn_utils.py:127-128) and says so (("syn_sparse", scale),
+        # with the region map); the sweep then reads the warped images everywhere else (MAL_STEP_SYN_SPARSE), so the pass in
+        # front of the producer writes them once, not twice
         pre = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
-        a.warp2_m1, a.warp2_p1 = pre[0].data_ptr(), pre[1].data_ptr()
         lib = L.load()
         L.check(lib.mal_loss_step_warp(C.byref(a)), "mal_loss_step_warp")
         try:
             with torch.enable_grad():
                 leaf = [w.detach().requires_grad_(True) for w in warp]
                 local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1], ("color_pair", 0): pair,
-                         ("syn_prefilled", 0): (pre[0], pre[1])}
+                         ("syn_sparse_buffers", 0): (pre[0], pre[1])}
                 has_ins = bool(synth(inputs, local, 0))
         except BaseException:  # the producer raised: join what mal_loss_step_warp forked before the buffers are reused
             lib.mal_loss_step_abort(C.byref(a))
@@ -183,22 +184,27 @@ class TemporalLossStepFn(Function):
             syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
             syn_data = [ops._req(s.detach(), "syn") for s in syn]
             region = local.get(("syn_region", 0))
+            sparse = bool(local.get(("syn_sparse", 0)))
+            if sparse and (region is None or any(s.data_ptr() != q.data_ptr() for s, q in zip(syn_data, pre))):
+                raise L.MalError("loss_step: ('syn_sparse', 0) needs the region map and the buffers of ('syn_sparse_buffers', 0)")
             if region is not None:
                 if not (region.is_cuda and region.dtype == torch.uint8 and tuple(region.shape) == (B, H, W) and region.is_contiguous()):
                     raise L.MalError("loss_step: ('syn_region', 0) must be a contiguous (B,H,W) uint8 device tensor")
                 a.syn_region = region.data_ptr()
+                if sparse:
+                    a.flags |= L.STEP_SYN_SPARSE
                 # ... and with the map the sweep leaves a second copy of d/d syn at the touched pixels: what the
                 # producer's in-place backward gathers from
                 snap = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
                 a.g_syn_region_m1, a.g_syn_region_p1 = snap[0].data_ptr(), snap[1].data_ptr()
         else:
-            # no matched instance anywhere (loss_utils.py:84: only the two warped candidates enter the min).  The sweep
-            # indexes its candidates with a sample stride of 3*H*W, so it is handed the CONTIGUOUS second copies the warp
-            # pass wrote (never the batch-strided halves of `pair`), and an all-zero region map: no synthesised candidate
-            # is evaluated anywhere, the running min passes through and d/d syn is zero
+            # no matched instance anywhere (loss_utils.py:84: only the two warped candidates enter the min): an all-zero
+            # region map over the untouched buffers -- no synthesised candidate is evaluated anywhere (no pixel of them is
+            # read), the running min passes through and d/d syn is zero
             syn, syn_data = None, pre
             region = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
             a.syn_region = region.data_ptr()
+            a.flags |= L.STEP_SYN_SPARSE
         # the cotangents of syn: this node's own buffers, which the producer's backward may turn into its result in place
         g_syn = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
         a.syn_m1, a.syn_p1 = syn_data[0].data_ptr(), syn_data[1].data_ptr()
@@ -210,7 +216,13 @@ class TemporalLossStepFn(Function):
         ctx.set_materialize_grads(False)
         expose[("color", -1, 0)], expose[("color", 1, 0)] = warp
         if has_ins:
-            expose[("syn", -1, 0)], expose[("syn", 1, 0)] = syn_data
+            if a.flags & L.STEP_SYN_SPARSE:
+                # dense images for the caller (logging) only when maps are wanted: outside the regions syn IS the warped image
+                if cfg[5]:
+                    inside = (region & 1).bool().unsqueeze(1)
+                    expose[("syn", -1, 0)], expose[("syn", 1, 0)] = (torch.where(inside, s, w_) for s, w_ in zip(syn_data, warp))
+            else:
+                expose[("syn", -1, 0)], expose[("syn", 1, 0)] = syn_data
         expose["has_ins"] = has_ins
         outs = [keep[4], keep[3]] + [maps[k] for k in MAP_NAMES if k in maps]
         ctx.mark_non_differentiable(*outs[1:])

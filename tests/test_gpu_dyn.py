@@ -187,7 +187,8 @@ def test_prefilled_and_in_place_equal_the_plain_node(shape, listed):
 
 
 def test_step_with_the_region_map_equals_the_dense_path():
-    """loss_step with mal_amd.dyn_utils.image_synthesis (pre-filled syn buffers, in-place producer backward, region map:
+    """loss_step with mal_amd.dyn_utils.image_synthesis (sparse syn buffers -- only the region pixels are written and read,
+    MAL_STEP_SYN_SPARSE --, in-place producer backward, region map:
     synthesised candidates skipped where their window cannot differ) against the same step driven by a producer that
     offers none of that (every candidate evaluated everywhere): same losses, same gradients; and with the map no
     synthesised candidate ever wins outside the dilated region (an exact tie goes to the warped one, loss_utils.py:103)"""
@@ -205,7 +206,7 @@ def test_step_with_the_region_map_equals_the_dense_path():
         def synth(inputs, outputs, scale):
             if not dense:
                 return dyn_utils.image_synthesis(inputs, outputs, scale, 0.5, ins_model, matcher)
-            plain = {k: v for k, v in outputs.items() if k[0] != "syn_prefilled"}
+            plain = {k: v for k, v in outputs.items() if k[0] not in ("syn_prefilled", "syn_sparse_buffers")}
             has = dyn_utils.image_synthesis(inputs, plain, scale, 0.5, ins_model, matcher)
             for k in (("syn", -1, scale), ("syn", 1, scale)):
                 if k in plain:
