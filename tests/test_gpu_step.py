@@ -9,6 +9,7 @@ from tests import golden_io as G
 from tests import hip_harness as HH
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 CASES = ["step_b2_32x64_distil", "step_b2_32x64_noens", "step_b2_32x64_lossblc", "step_b3_37x50_distil", "step_b2_32x64_learnens"]
 
 
@@ -257,3 +258,62 @@ def test_alternative_teacher_schedules_hold_against_the_oracle(option, temporal)
                 _check_step(b, {}, n0, n1)
     finally:
         lib.mal_set_option(option.encode(), 0)
+
+
+@pytest.mark.parametrize("what", ["temporal_step", "four_scales", "dualrefine"])
+def test_specialised_passes_equal_the_generic_ones_bit_for_bit(what):
+    """mal_set_option("march_lean"): the teacher / student / refinement entry points of the whole-step lists only compile
+    out code for operands the lists never pass (march_body SPEC), so every loss and every gradient is the SAME number as
+    with the generic instantiations -- temporal teacher sweep + scale-0 student (headline step), the students of the lower
+    scales (four-scale list), DualRefine's refinement pass; the plain teacher is covered by
+    test_decisions_do_not_change_results (instrumented = generic against production = specialised)."""
+    from mal_amd import _lib, dualrefine, dyn_utils, layers, step, trainer
+    from mal_amd.synthetic import instance_stub, make_batch, to_dicts
+    lib = _lib.load()
+    B, H, W = 3, 48, 136
+    batch = make_batch(B, H, W, seed=53)
+    g = torch.Generator().manual_seed(3)
+    noises = [torch.randn(B, 1, H, W, generator=g).to(DEV) for _ in range(4)]
+
+    def run():
+        if what == "dualrefine":
+            from tests.test_gpu_decisions import _dr_build
+            inputs, outputs, gl = _dr_build(batch, DEV, layers.transformation_from_parameters)
+            lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=B, n_losses=1), fuse=True)
+            losses = lp.loss_step(inputs, outputs, noises=noises[:2])
+            leaves = gl
+        else:
+            inputs, mono_outputs, outputs, leaves = to_dicts(batch, lambda a, t, inv: None, device=DEV)
+            for f, s in ((-1, "m1"), (1, "p1")):
+                mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + s]
+                mono_outputs[("translation", 0, f)] = leaves["translation_" + s]
+            if what == "temporal_step":
+                ins_model, matcher = instance_stub(B, H, W, n_inst=2, seed=5, device=DEV)
+                synth = lambda i, o, sc: dyn_utils.image_synthesis(i, o, sc, 0.5, ins_model, matcher)
+                opt = trainer.default_options(height=H, width=W, batch_size=B, temporal=True)
+                losses, _, _ = step.loss_step(opt, inputs, mono_outputs, outputs, noise=noises[0].clone(), image_synthesis=synth)
+            else:
+                for s in range(1, 4):
+                    inputs[("color", 0, s)] = torch.nn.functional.avg_pool2d(batch["color0"], 2 ** s).to(DEV)
+                    for name, outs in (("disp_teacher", mono_outputs), ("disp_student", outputs)):
+                        leaf = torch.nn.functional.avg_pool2d(batch[name], 2 ** s).to(DEV).clone().requires_grad_(True)
+                        leaves["%s_s%d" % (name, s)] = leaf
+                        outs[("disp", s)] = leaf
+                opt = trainer.default_options(height=H, width=W, batch_size=B, sclm=3, distil=False)
+                losses, _ = step.loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=[n.clone() for n in noises])
+        losses["loss"].backward()
+        torch.cuda.synchronize()
+        return ({k: float(v.detach()) for k, v in losses.items()},
+                {k: t.grad.clone() for k, t in leaves.items() if t.grad is not None})
+
+    res = {}
+    try:
+        for lean in (0, 1):
+            _lib.check(lib.mal_set_option(b"march_lean", lean), "march_lean")
+            res[lean] = run()
+    finally:
+        lib.mal_set_option(b"march_lean", 1)
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) >= 6
+    for k, v in res[0][1].items():
+        assert torch.equal(v, res[1][1][k]), k
