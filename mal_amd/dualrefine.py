@@ -89,6 +89,7 @@ class DrLossStepFn(Function):
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
         L.check(L.load().mal_dr_loss_fwd(C.byref(a)), "mal_dr_loss_fwd")
         ctx.args, ctx.keep, ctx.n = a, (tens, cons, cm, nz, ws, losses, total), n
+        ctx.ws_token = ops.claim_workspace(ws)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(losses)
         return total, losses
@@ -99,6 +100,7 @@ class DrLossStepFn(Function):
         n, tens = ctx.n, ctx.keep[0]
         if g_total is None:
             return (None,) * (2 + 3 * n)
+        ops.check_workspace(ctx.keep[4], ctx.ws_token, "DualRefineLossPath.loss_step backward")
         g_total = g_total.reshape(1).contiguous()
         a = ctx.args
         grads = [torch.empty_like(t) if ctx.needs_input_grad[2 + i] else None for i, t in enumerate(tens)]

@@ -33,6 +33,25 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
+# Which forward owns a cached step workspace: the whole-step calls keep their intermediate maps, per-task sums and
+# coefficients in a workspace that is cached per (device, stream, shape) and reused by the next forward of the same shape.
+# A backward that runs AFTER a later forward has overwritten it would return another step's gradients without a word.
+_WS_OWNER = {}
+
+
+def claim_workspace(ws):
+    """called by a whole-step forward: returns the token its backward must still find in place"""
+    token = object()
+    _WS_OWNER[ws.data_ptr()] = token
+    return token
+
+
+def check_workspace(ws, token, what):
+    if _WS_OWNER.get(ws.data_ptr()) is not token:
+        raise L.MalError("%s: the step's workspace was reused by a later forward of the same shape on this stream; run the "
+                         "backward of a step before the next forward (or put the steps on different streams)" % what)
+
+
 def workspace(dev, B, H, W):
     need = L.load().mal_workspace_bytes(B, H, W)
     key = (dev.index, _stream())

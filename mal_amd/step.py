@@ -101,6 +101,7 @@ def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, tempora
 
 def _run_bwd(ctx, g_total):
     tens = ctx.keep[0]
+    ops.check_workspace(ctx.keep[2], ctx.ws_token, "loss_step backward")
     # only the total is differentiable through this node: the 16 slots are its terms, for logging
     g_total = g_total.reshape(1).contiguous()
     a = ctx.args
@@ -127,6 +128,7 @@ class LossStepFn(Function):
         ctx.args = a
         ctx.ens_index = 8
         ctx.keep = keep  # the C struct holds raw pointers: keep the tensors alive
+        ctx.ws_token = ops.claim_workspace(keep[2])
         ctx.set_materialize_grads(False)
         outs = [keep[4], keep[3]] + [maps[k] for k in MAP_NAMES if k in maps]
         ctx.mark_non_differentiable(*outs[1:])
@@ -211,6 +213,7 @@ class TemporalLossStepFn(Function):
         a.g_syn_m1, a.g_syn_p1 = g_syn[0].data_ptr(), g_syn[1].data_ptr()
         L.check(lib.mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
         ctx.args, ctx.keep = a, keep
+        ctx.ws_token = ops.claim_workspace(keep[2])
         ctx.graph = (leaf, syn, syn_data, g_syn, warp)
         ctx.region, ctx.snap = region, snap  # the C struct holds their pointers
         ctx.set_materialize_grads(False)
@@ -393,6 +396,7 @@ class MultiScaleLossFn(Function):
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
         L.check(L.load().mal_loss_multiscale_fwd(C.byref(a)), "mal_loss_multiscale_fwd")
         ctx.args, ctx.keep, ctx.S = a, (tens, cons, ws, losses, total), S
+        ctx.ws_token = ops.claim_workspace(ws)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(*outs[1:])
         return tuple(outs)
@@ -401,6 +405,8 @@ class MultiScaleLossFn(Function):
     @once_differentiable
     def backward(ctx, g_total, *_):
         tens, S = ctx.keep[0], ctx.S
+        if g_total is not None:
+            ops.check_workspace(ctx.keep[2], ctx.ws_token, "loss_step_multiscale backward")
         if g_total is None:
             return (None,) * (2 + len(tens))
         g_total = g_total.reshape(1).contiguous()

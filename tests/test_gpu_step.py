@@ -317,3 +317,26 @@ def test_specialised_passes_equal_the_generic_ones_bit_for_bit(what):
     assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) >= 6
     for k, v in res[0][1].items():
         assert torch.equal(v, res[1][1][k]), k
+
+
+def test_a_backward_after_a_later_forward_of_the_same_shape_is_refused():
+    """the whole-step calls keep their maps, sums and coefficients in a workspace cached per (device, stream, shape): a
+    backward that runs after a later forward reused it must fail loudly, not return the other step's gradients"""
+    from mal_amd import _lib, step, trainer
+    from mal_amd.synthetic import make_batch
+    B, H, W = 2, 32, 64
+    opt = trainer.default_options(height=H, width=W, batch_size=B)
+    held = []
+    for seed in (3, 4):
+        batch = make_batch(B, H, W, seed=seed)
+        inputs, mono_outputs, outputs, leaves = to_dicts(batch, lambda a, t, inv: None, device=DEV)
+        for f, s in ((-1, "m1"), (1, "p1")):
+            mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + s]
+            mono_outputs[("translation", 0, f)] = leaves["translation_" + s]
+        losses, _, _ = step.loss_step(opt, inputs, mono_outputs, outputs, want_maps=False)
+        held.append((losses["loss"], leaves))
+    with pytest.raises(_lib.MalError):
+        held[0][0].backward()
+    held[1][0].backward()  # the latest forward still owns the workspace
+    torch.cuda.synchronize()
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in held[1][1].values())
