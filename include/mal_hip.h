@@ -404,7 +404,7 @@ typedef struct mal_dr_args {
   const float *K, *inv_K;                         /* (B,16) */
   const float *disp[MAL_DR_MAX_ITERS];            /* (B,1,H,W) */
   const float *T_m1[MAL_DR_MAX_ITERS], *T_p1[MAL_DR_MAX_ITERS]; /* (B,16) */
-  const float *consistency_mask;                  /* (B,H,W), nullable */
+  const float *consistency_mask;                  /* (B,H,W); required when n_iters > 1 unless MAL_DR_NO_MOTION_MASK */
   const float *noise[MAL_DR_MAX_ITERS];           /* (B,1,H,W) N(0,1) per iteration, nullable */
   /* MAL_DR_NOISE_PHILOX: key; step = *noise_counter when noise_counter != NULL (a device word the step's last kernel
    * advances by one, so a replayed HIP graph draws fresh noise every replay), else noise_step */

@@ -258,6 +258,8 @@ static int dr_check(const mal_dr_args* a) {
   if (!a->color0 || !a->color_m1 || !a->color_p1 || !a->K || !a->inv_K || !a->losses || !a->ws) return MAL_EINVAL;
   for (int it = 0; it < a->n_iters; ++it)
     if (!a->disp[it] || !a->T_m1[it] || !a->T_p1[it]) return MAL_EINVAL;
+  // the motion mask multiplies the automask of every iteration > 0 (dualrefine/trainer.py:593-597) unless switched off
+  if (a->n_iters > 1 && !(a->flags & MAL_DR_NO_MOTION_MASK) && !a->consistency_mask) return MAL_EINVAL;
   if (a->flags & MAL_DR_NOISE_PHILOX)
     for (int it = 0; it < a->n_iters; ++it)
       if (a->noise[it]) return MAL_EINVAL;

@@ -91,3 +91,33 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(text), os.path.join(dirpath, f)
+
+
+def test_workspace_ownership_tokens():
+    """ops.claim_workspace / check_workspace: the latest forward owns a cached step workspace; an older token is refused"""
+    import pytest
+    from mal_amd import _lib, ops
+
+    class Ws:  # stands in for the uint8 device tensor: only data_ptr() is read
+        def data_ptr(self):
+            return 0x1234
+
+    ws = Ws()
+    first = ops.claim_workspace(ws)
+    ops.check_workspace(ws, first, "first")
+    second = ops.claim_workspace(ws)
+    ops.check_workspace(ws, second, "second")
+    with pytest.raises(_lib.MalError):
+        ops.check_workspace(ws, first, "first, after the second forward")
+
+
+def test_dualrefine_one_call_step_refuses_what_it_does_not_cover():
+    """DualRefineLossPath.loss_step covers scales [0], min reprojection with SSIM, n_losses < MAL_DR_MAX_ITERS; everything
+    else is refused by name before any device work (the operator-level methods remain the route for it)"""
+    import pytest
+    from mal_amd import _lib, dualrefine
+    for kw in (dict(scales=[0, 1]), dict(avg_reprojection=True), dict(no_ssim=True), dict(n_losses=_lib.DR_MAX_ITERS),
+               dict(frame_ids=[0, -1]), dict(v1_multiscale=True)):
+        lp = dualrefine.DualRefineLossPath(dualrefine.default_options(**kw))
+        with pytest.raises(_lib.MalError):
+            lp.loss_step({("color", 0, 0): torch.zeros(1, 3, 8, 8)}, {})
