@@ -1563,7 +1563,7 @@ int g_pass_impl = 1;   // 1 = marching (this file, fastest); 0 = LDS-tiled v1 (m
 extern int g_costvol_impl;  // mal_costvol.hip
 int g_march_flip = 1;  // odd segments bottom-up (mal_set_option("march_flip", 0|1))
 int g_march_rows = 0;  // output rows per wave task; 0 = pick so that one round of tasks fills the chip
-int g_pack_rows = 9;   // rows per task of the identity / packing sweep: 22 segments x 11 strips x 12 samples = 2904 tasks <= 3072 (three waves per SIMD); measured 9: 31.8 us, 12: 33.8 us
+int g_pack_rows = 10;  // rows per task of the identity / packing sweep: 20 segments x 11 strips x 12 samples = 2640 tasks <= 3072 (three waves per SIMD); same-box steps, round 3: 10: 0.2010 / 0.3270 ms (--distil / headline), 9: 0.2019 / 0.3290, 11: 0.2043 / 0.3291, 12: 0.329 (headline)
 int g_march_rows_fwd = 0;  // the same for the forward-only passes (<= 168 VGPRs: three waves per SIMD); 0 = automatic
 int g_debug = 0;
 unsigned* g_dec_next = nullptr;  // mal_decisions_next_pass: decision planes for the next instrumentable gradient pass
