@@ -703,7 +703,7 @@ def main():
         rpath = os.path.join(ROOT, "profiles", "r03_kernel_stats_distil.csv")
         try:
             import csv
-            row = [r for r in csv.DictReader(open(rpath)) if "march_teacher_kernel<false>" in r["Name"]][0]
+            row = [r for r in csv.DictReader(open(rpath)) if "march_teacher_kernel<false" in r["Name"]][0]
             us = float(row["AverageNs"]) * 1e-3
             out["roofline"]["replayed_rocprof"] = {
                 "kernel_us": us, "calls": int(row["Calls"]), "frac": ALG_BYTES_PER_PX * n_px / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,

@@ -246,6 +246,7 @@ enum : int {
   kSpecCostNo = 16, kSpecCostYes = 32,  // matching mask (lowest cost + the teacher's disparity): absent / present
   kSpecMonoYes = 64,                    // the teacher's disparity is given as disparity (epilogue)
   kSpecNoScale = 128,                   // no per-sample scale
+  kSpecNoNoise = 256,                   // no tie-break noise map (the whole-step lists fold it into the identity map: Philox)
   kSpecTeacher = kSpecLean | kSpecNoDisp2 | kSpecExtNo | kSpecCostNo | kSpecNoScale,
   kSpecStudent = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostYes | kSpecMonoYes,      // whole-step list, scale 0
   kSpecStudentNoCost = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostNo | kSpecMonoYes, // four-scale list, scales > 0
@@ -257,6 +258,7 @@ MAL_DEV void march_body() {
   constexpr bool EXT_NO = (SPEC & kSpecExtNo) != 0, EXT_YES = (SPEC & kSpecExtYes) != 0;
   constexpr bool COST_NO = (SPEC & kSpecCostNo) != 0, COST_YES = (SPEC & kSpecCostYes) != 0;
   constexpr bool MONO_YES = (SPEC & kSpecMonoYes) != 0, NO_SCALE = (SPEC & kSpecNoScale) != 0;
+  constexpr bool NO_NOISE = (SPEC & kSpecNoNoise) != 0;
   constexpr bool OUTS = EXPORT || (!GRAD && !EPI);  // the outputs the producer / the fused sweep read
   constexpr int HALO = GRAD ? 2 : 1;
   constexpr int CW = 64 - 2 * HALO;
@@ -396,7 +398,7 @@ MAL_DEV void march_body() {
   };
   auto maps_of = [&](CParams& pp) {
     Maps m;
-    m.ident = AUTOMASK ? pp.ident : nullptr; m.noise = AUTOMASK ? pp.noise : nullptr;
+    m.ident = AUTOMASK ? pp.ident : nullptr; m.noise = (AUTOMASK && !NO_NOISE) ? pp.noise : nullptr;
     m.ext_mask = EXT_NO ? nullptr : pp.ext_mask; m.lowest_cost = COST_NO ? nullptr : pp.lowest_cost;
     m.mono_disp = (COST_NO && !EPI) ? nullptr : pp.mono_disp;
     m.mono_depth = EPI ? pp.mono_depth : nullptr; m.mono_reproj = EPI ? pp.mono_reproj : nullptr;
@@ -429,7 +431,7 @@ MAL_DEV void march_body() {
       return m ? v : absent;
     };
     a.ident = 0.f; a.noise = 0.f;
-    if (AUTOMASK && !TEMPORAL) { a.ident = ldf(pp.ident, oc); a.noise = opt(pp.noise, oc, 0.f); }
+    if (AUTOMASK && !TEMPORAL) { a.ident = ldf(pp.ident, oc); if (!NO_NOISE) a.noise = opt(pp.noise, oc, 0.f); }
     if (TEMPORAL) {
       a.ident = ldf(pp.forced_w, oc);
       a.noise = (float)*(pp.forced_arg + (oc >> 2));
@@ -953,9 +955,12 @@ __global__ __launch_bounds__(64, 2) void march_export_kernel(MarchParams p_kerna
   march_body<true, true, true, false, DBG, false, true>();
 }
 // the teacher's gradient pass of the whole-step lists (the north-star kernel), with / without the temporal hint
-template <bool TEMPORAL>
+#ifndef MAL_EXP_KEEP_NOISE
+#define MAL_EXP_KEEP_NOISE 0
+#endif
+template <bool TEMPORAL, bool NOISE = false>  // NOISE: a tie-break noise map is given (else it is part of the identity map)
 __global__ __launch_bounds__(64, 2) void march_teacher_kernel(MarchParams p_kernarg) {
-  march_body<true, true, true, false, false, TEMPORAL, false, kSpecTeacher>();
+  march_body<true, true, true, false, false, TEMPORAL, false, kSpecTeacher | (NOISE || TEMPORAL || MAL_EXP_KEEP_NOISE ? 0 : kSpecNoNoise)>();
 }
 // ... and the student's gradient pass with the consistency / distillation epilogue.  (The forward-only passes gain nothing
 // from a specialisation -- same-box: ensemble 35.17 -> 35.12 us, the pass in front of the producer 56.8 -> 58.0 us -- and
@@ -1674,7 +1679,8 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
       hipLaunchKernelGGL((march_kernel<true, true, true, false, true, true>), grid, block, 0, st, p);
     } else hipLaunchKernelGGL((march_kernel<true, true, true, false, false, true>), grid, block, 0, st, p);
   } else if (lean && !p.dbg && grad && pose && automask && !epi) {  // the teacher's pass of the whole-step lists
-    hipLaunchKernelGGL(march_teacher_kernel<false>, grid, block, 0, st, p);
+    if (p.noise) hipLaunchKernelGGL((march_teacher_kernel<false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((march_teacher_kernel<false, false>), grid, block, 0, st, p);
   } else if (p.dbg) {  // instrumented instantiations exist for the two gradient passes of the whole-step list
     if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
     if (grad && pose && automask && !epi) hipLaunchKernelGGL((march_kernel<true, true, true, false, true>), grid, block, 0, st, p);

@@ -20,9 +20,9 @@ for k in sorted(f):
     fb, wb = f[k] * 1024.0, w.get(k, 0.0) * 1024.0
     out["kernels"][k] = {"fetch_kb_raw": round(f[k], 1), "write_kb_raw": round(w.get(k, 0.0), 1),
                          "hbm_bytes_per_launch": int(2 * fb + wb), "bytes_per_px": round((2 * fb + wb) / (B * H * W), 2)}
-teacher = [k for k in out["kernels"] if "march_teacher_kernel<false>" in k or
+teacher = [k for k in out["kernels"] if "march_teacher_kernel<false" in k or
            "march_kernel<true, true, true, false, false, false>" in k or "march_kernel<true, true, true, false>" in k]
-temporal = [k for k in out["kernels"] if "march_teacher_kernel<true>" in k or "march_kernel<true, true, true, false, false, true>" in k]
+temporal = [k for k in out["kernels"] if "march_teacher_kernel<true" in k or "march_kernel<true, true, true, false, false, true>" in k]
 if temporal:
     out["pass_kernel_teacher_temporal_bytes_per_launch"] = out["kernels"][temporal[0]]["hbm_bytes_per_launch"]
 if teacher:

@@ -8,4 +8,4 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_ANY SQ_ACTIV
   timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/g$i -o p -- python3 $R/scripts/gpu_step_target.py > $O/g$i.log 2>&1 || { echo "group $i ($grp) failed"; tail -3 $O/g$i.log; }
   echo "group $i done" >> $O/progress.log
 done
-cd $R && for f in $O/g*/p_counter_collection.csv; do python scripts/pmc_summary.py $f "march_teacher_kernel<false>"; done
+cd $R && for f in $O/g*/p_counter_collection.csv; do python scripts/pmc_summary.py $f "march_teacher_kernel<false"; done

@@ -7,4 +7,4 @@ for grp in "TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE" "TA_ADDR_STALLED_BY_TC_CYCL
   i=$((i+1))
   timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/g$i -o p -- python3 $R/scripts/gpu_step_target.py > $O/g$i.log 2>&1 || { echo "group $i ($grp) failed"; tail -2 $O/g$i.log; }
 done
-cd $R && for f in $O/g*/p_counter_collection.csv; do python scripts/pmc_summary.py $f "march_teacher_kernel<false>" "march_kernel<false, false" "march_student" "pack_identity"; done
+cd $R && for f in $O/g*/p_counter_collection.csv; do python scripts/pmc_summary.py $f "march_teacher_kernel<false" "march_kernel<false, false" "march_student" "pack_identity"; done
