@@ -66,12 +66,16 @@ def test_train_step_data_parallel_semantics(tmp_path, same_batch):
     assert torch.equal(r[0]["reduced"], r[1]["reduced"])
     mean = (r[0]["local"].double() + r[1]["local"].double()) / 2
     assert float((r[0]["reduced"].double() - mean).abs().max()) <= 1e-6 * scale
-    if same_batch:  # ... which is what one process computes on that batch (MIOpen's reductions are not bit-reproducible
-        # between processes: 1e-4 of the largest gradient)
-        assert float((r[0]["local"] - r[1]["local"]).abs().max()) <= 1e-4 * scale
-        assert float((r[0]["reduced"] - r[0]["local"]).abs().max()) <= 1e-4 * scale
+    l2 = lambda x: float(x.double().norm())
+    if same_batch:  # ... which is what one process computes on that batch.  MIOpen's weight-gradient kernels accumulate with
+        # atomics, so two runs of the SAME process already differ by 4e-5 in the norm and up to 1.2e-4 of the largest
+        # gradient on single elements, while the loss path is bit-reproducible (scripts/determinism_probe.py,
+        # profiles/r03_determinism_probe.txt).  A wrong batch or a missed exchange would show at the 1e-2 level (below).
+        assert l2(r[0]["local"] - r[1]["local"]) <= 3e-4 * l2(r[0]["local"])
+        assert float((r[0]["local"] - r[1]["local"]).abs().max()) <= 1e-3 * scale
+        assert float((r[0]["reduced"] - r[0]["local"]).abs().max()) <= 1e-3 * scale
     else:
-        assert float((r[0]["local"] - r[1]["local"]).abs().max()) > 1e-3 * scale
+        assert l2(r[0]["local"] - r[1]["local"]) > 1e-2 * l2(r[0]["local"])
 
 
 
@@ -125,4 +129,8 @@ def test_exchange_from_inside_the_backward_equals_the_single_all_reduce(tmp_path
     assert torch.equal(r[0][4]["flat"], r[1][4]["flat"])  # every rank holds the same mean
     scale = float(r[0][1]["flat"].abs().max())
     assert scale > 0
-    assert float((r[0][4]["flat"] - r[0][1]["flat"]).abs().max()) <= 2e-4 * scale
+    # one piece against four: the same sums up to MIOpen's run-to-run noise (4e-5 in the norm, 1.2e-4 on single elements per
+    # step: profiles/r03_determinism_probe.txt)
+    d = r[0][4]["flat"].double() - r[0][1]["flat"].double()
+    assert float(d.norm()) <= 5e-4 * float(r[0][1]["flat"].double().norm())
+    assert float(d.abs().max()) <= 2e-3 * scale
