@@ -320,6 +320,13 @@ int mal_loss_step_warp(const mal_step_args* args);
  * pass that _warp forked onto the library's side stream back into args->stream (no-op when nothing is pending), so the
  * next step cannot overwrite buffers that pass still reads and a stream capture does not end with unjoined work. */
 int mal_loss_step_abort(const mal_step_args* args);
+/* Measurement hook (bench.py's `roofline` block): enqueues `launches` (1..4096) back-to-back launches of the teacher's
+ * pass -- the fused warp + SSIM + L1 + min + automask forward+backward sweep, manydepth/loss_utils.py:57-113 with
+ * trainer.py:1078-1125 -- exactly as mal_loss_step_fwd enqueues it for a step WITHOUT MAL_STEP_TEMPORAL (same parameter
+ * block, instantiation and task decomposition) and nothing else.  `args->ws` must hold a finished mal_loss_step_fwd of
+ * the same arguments; the launches rewrite what its teacher pass left with the same values.  Captured into a graph and
+ * replayed, two events outside the graph time the kernel alone. */
+int mal_loss_step_teacher_replay(const mal_step_args* args, int launches);
 /* the same noise map on its own (tests; bit-identical to what the step draws for that seed / step) */
 int mal_tiebreak_noise(uint64_t seed, uint64_t step, int B, int H, int W, float* out, void* stream);
 enum {
@@ -581,6 +588,13 @@ int mal_direct_align_update_bwd(const float* H, const float* b, const float* pos
  *               (slower; default 0);
  * "epi_probe", "fwd_waves", "debug": kernel experiments / timing probes. */
 int mal_set_option(const char* name, int value);
+/* Options are PROCESS-WIDE switches for same-box A/B measurements, not per-call configuration: set them before the first
+ * step and leave them; a second trainer in the process sees the same values.  Setting one is serialised by a mutex;
+ * launches read them without further synchronisation.  The formulations that were measured slower (pass_impl 0 / 2,
+ * march3, temporal_spec, syn_queue) are compiled only into a library built with -DMAL_EXPERIMENTS (MAL_EXPERIMENTS=1
+ * python -m mal_amd.build); the default library refuses those switches with MAL_EINVAL.  The one-shot arms below
+ * (mal_profile_next_pass, mal_decisions_next_pass) are per THREAD: armed and consumed by the calling thread's next pass. */
+int mal_build_has_experiments(void); /* 1 when the library contains the -DMAL_EXPERIMENTS formulations */
 
 /* ---- measurement hooks (bench.py): HIP events recorded immediately before / after the main
  * kernel of the NEXT mal_pass_fused call, on its stream (one-shot; cleared by that call). */

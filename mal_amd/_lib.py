@@ -88,6 +88,7 @@ SIGNATURES = {
     "mal_loss_step_bwd": (i32, [vp]),
     "mal_loss_step_warp": (i32, [vp]),
     "mal_loss_step_abort": (i32, [vp]),
+    "mal_loss_step_teacher_replay": (i32, [vp, i32]),
     "mal_tiebreak_noise": (i32, [C.c_uint64, C.c_uint64, i32, i32, i32, c_fp, vp]),
     "mal_ms_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mal_loss_multiscale_fwd": (i32, [vp]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "mal_upsample_bilinear": (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, vp]),
     "mal_upsample_bilinear_adjoint": (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, vp]),
     "mal_set_option": (i32, [C.c_char_p, i32]),
+    "mal_build_has_experiments": (i32, []),
     "mal_event_create": (vp, []),
     "mal_event_destroy": (i32, [vp]),
     "mal_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),

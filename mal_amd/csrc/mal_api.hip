@@ -31,7 +31,7 @@ extern "C" size_t mal_workspace_bytes(int B, int H, int W) {
 // ---- timing hooks used by bench.py: bracket the NEXT mal_pass_fused main kernel with HIP
 // events on the stream it is launched on (kernel only: not the finalize launch, not host time).
 namespace mal {
-hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;  // armed and consumed on the calling thread
 }
 
 extern "C" void* mal_event_create(void) {

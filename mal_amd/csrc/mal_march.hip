@@ -31,10 +31,11 @@
 #include "mal_march.h"
 #include "mal_device.h"
 #include "mal_pairs.h"
+#include <mutex>
 
 namespace mal {
 
-extern hipEvent_t g_prof_start, g_prof_stop;
+extern thread_local hipEvent_t g_prof_start, g_prof_stop;
 
 typedef __attribute__((address_space(4))) const float cfloat;  // constant address space: uniform loads are s_load
 
@@ -950,10 +951,12 @@ template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG = false, bool 
 __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   march_body<GRAD, AUTOMASK, POSE, EPI, DBG, TEMPORAL, false>();
 }
+#ifdef MAL_EXPERIMENTS  // option "temporal_spec" (measured slower): not in the default build
 template <bool DBG>
 __global__ __launch_bounds__(64, 2) void march_export_kernel(MarchParams p_kernarg) {
   march_body<true, true, true, false, DBG, false, true>();
 }
+#endif
 // the teacher's gradient pass of the whole-step lists (the north-star kernel), with / without the temporal hint
 #ifndef MAL_EXP_KEEP_NOISE
 #define MAL_EXP_KEEP_NOISE 0
@@ -974,6 +977,7 @@ __global__ __launch_bounds__(64, 2) void march_refine_kernel(MarchParams p_kerna
   march_body<true, true, true, true, false, false, false, kSpecRefine>();
 }
 
+#ifdef MAL_EXPERIMENTS  // option "march3" (measured slower): not in the default build
 // =====================================================================================================================
 // march3: the teacher's gradient pass (GRAD + AUTOMASK + POSE, one-row halo, packed texels) as a THREE-WAVE PIPELINE per
 // strip.  A lone wave of march_kernel needs 88 % of the time a pair takes: its own dependency chain --
@@ -1358,6 +1362,8 @@ __global__ __launch_bounds__(192, 3) void march3_kernel(MarchParams p) {
   }
 }
 
+#endif  // MAL_EXPERIMENTS
+
 // ---- identity term + texel packing: min over the two raw sources of r(src_f, target)
 // (manydepth/loss_utils.py:92-101, forward only) in the same sweep that turns the two planar (B,3,H,W)
 // sources into the texels (B,H,W,kTexel) the warp gathers from.  Same marching structure and the same
@@ -1571,7 +1577,7 @@ int g_march_rows = 0;  // output rows per wave task; 0 = pick so that one round 
 int g_pack_rows = 10;  // rows per task of the identity / packing sweep: 20 segments x 11 strips x 12 samples = 2640 tasks <= 3072 (three waves per SIMD); same-box steps, round 3: 10: 0.2010 / 0.3270 ms (--distil / headline), 9: 0.2019 / 0.3290, 11: 0.2043 / 0.3291, 12: 0.329 (headline)
 int g_march_rows_fwd = 0;  // the same for the forward-only passes (<= 168 VGPRs: three waves per SIMD); 0 = automatic
 int g_debug = 0;
-unsigned* g_dec_next = nullptr;  // mal_decisions_next_pass: decision planes for the next instrumentable gradient pass
+thread_local unsigned* g_dec_next = nullptr;  // mal_decisions_next_pass (armed and consumed on the calling thread): decision planes for the next instrumentable gradient pass
 extern int g_photo_impl;  // mal_photo_march.hip
 extern int g_epi_bwd_planes;  // mal_epipolar.hip
 extern int g_epi_probe;       // mal_epipolar.hip
@@ -1658,6 +1664,7 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   const bool lean_student_nc = lean0 && !p.disp2 && p.ext_mask && !p.lowest_cost && p.mono_disp;      // kSpecStudentNoCost
   const bool lean_refine = lean0 && !p.disp2 && !p.lowest_cost && p.mono_disp && !p.sample_scale;     // kSpecRefine
 #define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((march_kernel<G, A, P, E>), grid, block, 0, st, p)
+#ifdef MAL_EXPERIMENTS
   if (grad && p.color_out[0]) {  // the teacher's pass of the --temporal step in front of the producer
     if (!(pose && automask && !epi) || p.forced_w || !p.color_out[1]) return MAL_EINVAL;
     if (p.dbg) {
@@ -1671,7 +1678,11 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
       if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
       hipLaunchKernelGGL(march3_kernel<true>, grid, dim3(192), 0, st, p);
     } else hipLaunchKernelGGL(march3_kernel<false>, grid, dim3(192), 0, st, p);
-  } else if (p.forced_w) {  // TEMPORAL teacher pass
+  } else
+#else
+  if (grad && p.color_out[0]) return MAL_EINVAL;  // an exporting gradient pass exists in -DMAL_EXPERIMENTS builds only
+#endif
+  if (p.forced_w) {  // TEMPORAL teacher pass
     if (!(grad && pose && automask && !epi) || !p.forced_arg || !p.g_color[0] || !p.g_color[1]) return MAL_EINVAL;
     if (lean && !p.dbg) hipLaunchKernelGGL(march_teacher_kernel<true>, grid, block, 0, st, p);
     else if (p.dbg) {
@@ -1751,19 +1762,34 @@ extern "C" int mal_march_geometry(int B, int H, int W, int flags, int* strips, i
   return MAL_OK;
 }
 
+static std::mutex g_option_mutex;
+extern "C" int mal_build_has_experiments(void) {
+#ifdef MAL_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 extern "C" int mal_set_option(const char* name, int value) {
   if (!name) return MAL_EINVAL;
   auto eq = [&](const char* s) { const char* a = name; while (*a && *a == *s) { ++a; ++s; } return *a == *s; };
-  if (eq("pass_impl")) { if (value < 0 || value > 2) return MAL_EINVAL; g_pass_impl = value; return MAL_OK; }
+  std::lock_guard<std::mutex> lock(g_option_mutex);
+#ifdef MAL_EXPERIMENTS
+  constexpr bool kExp = true;
+#else
+  constexpr bool kExp = false;  // the losing formulations are not compiled in: their switches accept the default only
+#endif
+  if (eq("pass_impl")) { if (value < 0 || value > 2 || (!kExp && value != 1)) return MAL_EINVAL; g_pass_impl = value; return MAL_OK; }
   if (eq("debug")) { g_debug = value; return MAL_OK; }
   if (eq("photo_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_photo_impl = value; return MAL_OK; }
   if (eq("costvol_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_costvol_impl = value; return MAL_OK; }
   if (eq("step_overlap")) { if (value < 0 || value > 2) return MAL_EINVAL; g_step_overlap = value; return MAL_OK; }
   if (eq("march_halo1")) { g_march_halo1 = value != 0; return MAL_OK; }
-  if (eq("temporal_spec")) { g_temporal_spec = value != 0; return MAL_OK; }
-  if (eq("march3")) { g_march3 = value != 0; return MAL_OK; }
+  if (eq("temporal_spec")) { if (!kExp && value) return MAL_EINVAL; g_temporal_spec = value != 0; return MAL_OK; }
+  if (eq("march3")) { if (!kExp && value) return MAL_EINVAL; g_march3 = value != 0; return MAL_OK; }
   if (eq("march_lean")) { g_march_lean = value != 0; return MAL_OK; }
-  if (eq("syn_queue")) { g_syn_queue = value != 0; return MAL_OK; }
+  if (eq("syn_queue")) { if (!kExp && value) return MAL_EINVAL; g_syn_queue = value != 0; return MAL_OK; }
   if (eq("syn_rows")) { if (value < 2 || value > 64) return MAL_EINVAL; g_syn_rows = value; return MAL_OK; }
   if (eq("epi_bwd_planes")) { g_epi_bwd_planes = value != 0; return MAL_OK; }
   if (eq("epi_probe")) { g_epi_probe = value; return MAL_OK; }
@@ -1774,6 +1800,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   return MAL_EINVAL;
 }
 
+#ifdef MAL_EXPERIMENTS  // the LDS-tiled first formulations (mal_pass.hip, mal_tile2.hip; option "pass_impl")
 extern "C" int mal_pass_fused_tiled(const float* disp, const float* disp2, const float* K, const float* inv_K,
                                     const float* const* T, const float* const* src, const float* target,
                                     const float* ident, const float* noise, const float* ext_mask,
@@ -1793,6 +1820,7 @@ extern "C" int mal_pass_fused_tile2(const float* disp, const float* disp2, const
                                     double* sums, float* g_reproj, float* g_cons, float* g_distil, float* const* g_T,
                                     float* consistency_target, float* depth_out, void* ws, size_t ws_bytes,
                                     void* stream);
+#endif
 
 extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float* K, const float* inv_K,
                               const float* const* T, const float* const* src, const float* target,
@@ -1802,6 +1830,7 @@ extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float
                               float eps, int convention, int flags, float* min_reproj, double* sums, float* g_reproj,
                               float* g_cons, float* g_distil, float* const* g_T, float* consistency_target,
                               float* depth_out, void* ws, size_t ws_bytes, void* stream) {
+#ifdef MAL_EXPERIMENTS
   if (g_pass_impl == 2)
     return mal_pass_fused_tile2(disp, disp2, K, inv_K, T, src, target, ident, noise, ext_mask, sample_scale,
                                 mono_depth, mono_reproj, ens_reproj, B, H, W, F, min_depth, max_depth, eps,
@@ -1812,6 +1841,7 @@ extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float
                                 mono_depth, mono_reproj, ens_reproj, B, H, W, F, min_depth, max_depth, eps,
                                 convention, flags, min_reproj, sums, g_reproj, g_cons, g_distil, g_T,
                                 consistency_target, depth_out, ws, ws_bytes, stream);
+#endif
   int rc = check_shape(B, H, W);
   if (rc) return rc;
   if (F != 2 || !disp || !K || !inv_K || !T || !src || !T[0] || !T[1] || !src[0] || !src[1] || !target || !sums || !ws)

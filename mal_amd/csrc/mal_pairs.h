@@ -28,14 +28,16 @@ MAL_DEV f2 hsum3(f2 v) { return (f2){hsum3(v.x), hsum3(v.y)}; }
 // update_dpp + fadd only when its DPP-combine pass finds the pair within a short scan window of the pre-RA instruction
 // order; in the gradient instantiations of the marching kernel that depends on unrelated code (measured: 0 of 84 combined
 // after a change elsewhere in the loop = +84 VALU instructions per row, +7 %).  Written out, the instruction count is fixed.
-// Hazard: a VGPR written by a VALU instruction must not be read through DPP in the next two wait states (gfx9 family; the
-// compiler's hazard pass does not look inside inline assembly): the block opens with s_nop 1, and inside it no DPP operand
-// is a register the block wrote.  EXEC is not written by VALU instructions in these kernels (no v_cmpx).
+// Hazards (gfx9 family; the compiler's hazard pass does not look inside inline assembly): a VGPR written by a VALU
+// instruction must not be read through DPP in the next two wait states, and a VALU write of EXEC (v_cmpx) needs five before
+// a DPP instruction.  The block opens with s_nop 4 (five wait states: covers both whatever the compiler placed in front of
+// it; +3 idle cycles per block against s_nop 1, nine blocks per row), and inside it no DPP operand is a register the block
+// wrote.
 #define MAL_DPP_SHR1 " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 #define MAL_DPP_SHL1 " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 // r[i] = (shr1(v[i]) + v[i]) + shl1(v[i]), eight values
 MAL_DEV void hsum3_block8(const float (&v)[8], float (&r)[8]) {
-  asm("s_nop 1\n"
+  asm("s_nop 4\n"
       "v_add_f32_dpp %0, %8, %8" MAL_DPP_SHR1 "v_add_f32_dpp %1, %9, %9" MAL_DPP_SHR1
       "v_add_f32_dpp %2, %10, %10" MAL_DPP_SHR1 "v_add_f32_dpp %3, %11, %11" MAL_DPP_SHR1
       "v_add_f32_dpp %4, %12, %12" MAL_DPP_SHR1 "v_add_f32_dpp %5, %13, %13" MAL_DPP_SHR1
@@ -49,7 +51,7 @@ MAL_DEV void hsum3_block8(const float (&v)[8], float (&r)[8]) {
 }
 // r[i] = (shr1(l[i]) + c[i]) + shl1(t[i]), six values (the adjoint's border weights differ per direction)
 MAL_DEV void hsum3_block6(const float (&l)[6], const float (&c)[6], const float (&t)[6], float (&r)[6]) {
-  asm("s_nop 1\n"
+  asm("s_nop 4\n"
       "v_add_f32_dpp %0, %6, %12" MAL_DPP_SHR1 "v_add_f32_dpp %1, %7, %13" MAL_DPP_SHR1
       "v_add_f32_dpp %2, %8, %14" MAL_DPP_SHR1 "v_add_f32_dpp %3, %9, %15" MAL_DPP_SHR1
       "v_add_f32_dpp %4, %10, %16" MAL_DPP_SHR1 "v_add_f32_dpp %5, %11, %17" MAL_DPP_SHR1

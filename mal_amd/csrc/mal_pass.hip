@@ -32,8 +32,9 @@
 
 namespace mal {
 
-extern hipEvent_t g_prof_start, g_prof_stop;  // mal_api.hip: one-shot timing hooks
+extern thread_local hipEvent_t g_prof_start, g_prof_stop;  // mal_api.hip: one-shot timing hooks
 
+#ifdef MAL_EXPERIMENTS  // the LDS-tiled first formulation (option "pass_impl" 0): not in the default build
 constexpr int RW = kTW + 4, RH = kTH + 4, RN = RW * RH;  // 68 x 20 = 1360
 constexpr int SW = kTW + 2, SH = kTH + 2, SN = SW * SH;  // 66 x 18 = 1188
 constexpr int kHalo = RN - kTW * kTH;                    // 336
@@ -415,6 +416,8 @@ __global__ __launch_bounds__(kThreads, 2) void pass_kernel(PassParams p) {
   }
 }
 
+#endif  // MAL_EXPERIMENTS
+
 // blocks 0..7: sums[j] = sum over workgroups (fixed order; j >= nsums -> 0); blocks 8..8+B-1: g_T[f][b] = K_b^T [gP_fb ; 0]
 __global__ __launch_bounds__(256) void pass_finalize_kernel(const double* block_sums, const float* block_gP,
                                                             const float* K, int nblocks, int tiles, int B,
@@ -489,6 +492,7 @@ int launch_pass_finalize(const double* block_sums, const float* block_gP, const 
 
 using namespace mal;
 
+#ifdef MAL_EXPERIMENTS
 // The LDS-tiled formulation (first version); mal_pass_fused (mal_march.hip) dispatches here when
 // mal_set_option("pass_impl", 0).
 extern "C" int mal_pass_fused_tiled(const float* disp, const float* disp2, const float* K, const float* inv_K,
@@ -551,3 +555,4 @@ extern "C" int mal_pass_fused_tiled(const float* disp, const float* disp2, const
   return launch_pass_finalize(w.block_sums, w.block_gP, K, p.nblocks, tg.tiles_x * tg.tiles_y, B, sums,
                               pose ? g_T[0] : nullptr, pose ? g_T[1] : nullptr, st);
 }
+#endif  // MAL_EXPERIMENTS

@@ -428,15 +428,18 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
 template <bool FUSED>
 __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams p) {
   const int id = blockIdx.x;
+#ifdef MAL_EXPERIMENTS
   if (FUSED && p.order) {  // grid = ntasks exactly
     photo_march_bwd_task<FUSED>(p, (int)p.order[id]);
     return;
   }
+#endif
   const int task = (id & 7) * p.per_xcd + (id >> 3);
   if (task >= p.ntasks) return;
   photo_march_bwd_task<FUSED>(p, task);
 }
 
+#ifdef MAL_EXPERIMENTS  // option "syn_queue" (measured slower): not in the default build
 // one wavefront per task of the fused sweep's decomposition: the test photo_march_bwd_task<true> opens with
 __global__ __launch_bounds__(64) void photo_march_classify_kernel(PhotoMarchParams p) {
   constexpr int HALO = 2, CW = 60;
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(64) void photo_march_classify_kernel(PhotoMarchPara
     p.order[active ? pos : (unsigned)p.ntasks - 1u - pos] = (unsigned)task;
   }
 }
+#endif  // MAL_EXPERIMENTS
 
 // ---- get_smooth_loss (manydepth/layers.py:210-223) on the mean-normalised disparity (loss_utils.py:119-121) in one
 // sweep: lane = column, the right edge comes from the neighbouring lane (DPP), the up edge from the previous
@@ -713,11 +717,15 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
   decompose(p, 60, 2);
   *per_sample_out = p.strips * p.segs;
   unsigned grid = (unsigned)p.per_xcd * 8u;
+#ifdef MAL_EXPERIMENTS
   if (region && order && order_count && g_syn_queue) {  // expensive tasks first (see PhotoMarchParams::order)
     p.order = order; p.order_count = order_count;
     grid = (unsigned)p.ntasks;
     hipLaunchKernelGGL(photo_march_classify_kernel, dim3(grid), dim3(64), 0, st, p);
   }
+#else
+  (void)order; (void)order_count;
+#endif
   hipLaunchKernelGGL(photo_march_bwd_kernel<true>, dim3(grid), dim3(64), 0, st, p);
   return launch_status();
 }

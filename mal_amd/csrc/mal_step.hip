@@ -18,6 +18,7 @@
 #include "mal_march.h"
 #include "mal_device.h"
 #include "mal_pose.h"
+#include <mutex>
 
 namespace mal {
 
@@ -418,6 +419,8 @@ static int first_sweep(const mal_step_args* a, const StepWs& w, hipStream_t st, 
                               &sp, &tn, &sm, per_sample_p);
 }
 
+namespace mal { int g_march_halo1 = 1; }   // option "march_halo1": one-row halo of the step's gradient passes (0: two rows, A/B)
+
 static MarchParams teacher_params(const mal_step_args* a, const StepWs& w, float* mono_reproj) {
   MarchParams p = march_params(a->B, a->H, a->W, a->min_depth, a->max_depth, 1e-7f, 0);
   p.disp = a->disp_teacher; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
@@ -425,6 +428,16 @@ static MarchParams teacher_params(const mal_step_args* a, const StepWs& w, float
   p.min_reproj = mono_reproj; p.block_gP = w.bgP;
   p.cam = w.cam; p.cam_ready = 1;  // the first launch filled the camera block
   return p;
+}
+
+// the teacher's pass of the step without the temporal hint: forward and gradient in one sweep (the north-star kernel)
+static int launch_teacher(const mal_step_args* a, const StepWs& w, float* mono_reproj, hipStream_t st) {
+  MarchParams p = teacher_params(a, w, mono_reproj);
+  p.ident = w.ident; p.noise = a->noise; p.g_reproj = w.G_r_t;
+  p.block_sums = w.bs_t;
+  p.bnd = g_march_halo1 ? w.bnd_t : nullptr;
+  p.dbg = a->dec_teacher;
+  return march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
 }
 
 // the ensemble pass (no gradient): the averaged disparity is formed inside the kernel (trainer.py:594-600)
@@ -443,41 +456,62 @@ static int launch_ensemble(const mal_step_args* a, const StepWs& w, float* ens_r
 // warp pass (beside it, two ALU-bound passes only slow each other down: measured) and joined before the student pass,
 // which reads its map.  Fork / join through events: capturable into the caller's HIP graph.
 namespace mal { int g_step_overlap = 1; }  // option "step_overlap"
-namespace mal { int g_march_halo1 = 1; }   // option "march_halo1": one-row halo of the step's gradient passes (0: two rows, A/B)
 // option "temporal_spec" (--temporal step): 1 = the pass in front of the producer is the teacher's GRADIENT pass (it
 // exports the warped images as well) and the sweep after the producer's backward only corrects the tasks near the region
 // map; 0 = forward-only pass in front, full gradient sweep behind (rounds 2-3, kept for same-box A/B)
-namespace mal { int g_temporal_spec = 0; }
-struct SideStream { hipStream_t s; hipEvent_t fork, join; bool ok, init, pending; };
-// one per device (created on first use on THAT device); `pending`: a fork whose join has not been enqueued yet
-static SideStream* side_stream() {
-  constexpr int kMaxDev = 64;
-  static SideStream all[kMaxDev] = {};
+namespace mal { int g_temporal_spec = 0; }  // settable in -DMAL_EXPERIMENTS builds only (mal_set_option refuses it otherwise)
+// One side stream (with its fork / join events) per (device, caller stream): two steps in flight on different streams of a
+// device -- each with its own workspace -- then cannot consume or overwrite each other's pending join (round 3 kept one
+// `pending` flag per device: step B's _warp cleared A's, and B's _fwd could return without waiting for its own ensemble
+// pass).  `pending`: a fork on this caller stream whose join has not been enqueued yet.  The table is small and fixed; a
+// caller stream that finds it full shares slot 0 of its device, and every _fwd of a forked step waits for the slot's join
+// event whatever `pending` says, so sharing costs ordering, never correctness.  Lookups are serialised by a mutex; the
+// launches themselves are the caller's (one thread per stream, as for every HIP stream).
+struct SideStream { hipStream_t caller; hipStream_t s; hipEvent_t fork, join; bool ok, init, pending; int dev; };
+static SideStream* side_stream(hipStream_t caller) {
+  constexpr int kSlots = 64;
+  static SideStream all[kSlots] = {};
+  static std::mutex mu;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return nullptr; }
-  SideStream& ss = all[dev];
-  if (!ss.init) {
-    ss.init = true;
-    ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
-    (void)hipGetLastError();
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lock(mu);
+  SideStream* slot = nullptr;
+  SideStream* first_of_dev = nullptr;
+  for (int i = 0; i < kSlots && !slot; ++i) {
+    if (all[i].init && all[i].dev == dev) {
+      if (!first_of_dev) first_of_dev = &all[i];
+      if (all[i].caller == caller) slot = &all[i];
+    }
   }
-  return ss.ok ? &ss : nullptr;
+  for (int i = 0; i < kSlots && !slot; ++i)
+    if (!all[i].init) {
+      slot = &all[i];
+      slot->init = true; slot->dev = dev; slot->caller = caller; slot->pending = false;
+      slot->ok = hipStreamCreateWithFlags(&slot->s, hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&slot->fork, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&slot->join, hipEventDisableTiming) == hipSuccess;
+      (void)hipGetLastError();
+    }
+  if (!slot) slot = first_of_dev;  // table full: share this device's first slot
+  return (slot && slot->ok) ? slot : nullptr;
 }
-// the caller's stream waits for the forked ensemble pass; every path that leaves a step after the fork goes through here
-static int join_side(hipStream_t st) {
-  SideStream* ss = side_stream();
-  if (!ss || !ss->pending) return MAL_OK;
+// the caller's stream waits for the forked ensemble pass; every path that leaves a step after the fork goes through here.
+// `always`: the step KNOWS it forked (mal_loss_step_fwd of a forked step): wait for the slot's last recorded join even if
+// another step that shares the slot has consumed the flag meanwhile.
+static int join_side(hipStream_t st, bool always = false) {
+  SideStream* ss = side_stream(st);
+  if (!ss || (!ss->pending && !always)) return MAL_OK;
   ss->pending = false;
   return hipStreamWaitEvent(st, ss->join, 0) == hipSuccess ? MAL_OK : MAL_ELAUNCH;
 }
 static bool ensemble_forked(const mal_step_args* a) {
-  return g_step_overlap && (a->flags & MAL_STEP_TEMPORAL) && !(a->flags & MAL_STEP_NO_ENS) && side_stream() != nullptr;
+  return g_step_overlap && (a->flags & MAL_STEP_TEMPORAL) && !(a->flags & MAL_STEP_NO_ENS) &&
+         side_stream((hipStream_t)a->stream) != nullptr;
 }
 
 static int fork_ensemble(const mal_step_args* a, const StepWs& w, hipStream_t st) {
-  SideStream* ss = side_stream();
+  SideStream* ss = side_stream(st);
+  if (!ss) return MAL_ELAUNCH;
   if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return MAL_ELAUNCH;
   int rc = launch_ensemble(a, w, a->ens_reproj ? a->ens_reproj : w.ens_reproj, ss->s);
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return rc ? rc : MAL_ELAUNCH;
@@ -557,12 +591,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     rc = first_sweep(a, w, st, &per_sample_p);
     if (rc) return rc;
     // teacher pass: forward and gradient in one sweep
-    MarchParams p = teacher_params(a, w, mono_reproj);
-    p.ident = w.ident; p.noise = a->noise; p.g_reproj = w.G_r_t;
-    p.block_sums = w.bs_t;
-    p.bnd = g_march_halo1 ? w.bnd_t : nullptr;
-    p.dbg = a->dec_teacher;
-    rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
+    rc = launch_teacher(a, w, mono_reproj, st);
     if (rc) return rc;
   } else {
     // mal_loss_step_warp ran the first sweep and left min_f r(warp_f) / its winner in rp_warp / arg_warp: the two
@@ -588,7 +617,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp
   if (!no_ens) {
     if (ensemble_forked(a)) {
-      rc = join_side(st);
+      rc = join_side(st, true);
       if (rc) return rc;
     } else {
       rc = launch_ensemble(a, w, ens_reproj, st);
@@ -623,6 +652,24 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
                      a->w_main, a->w_distil, w.ps, w.gT[0], w.gT[1], w.sm_stats, a->losses, w.coefs, a->loss_total,
                      w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr);
   return launch_status();
+}
+
+// Measurement hook (bench.py): `launches` back-to-back launches of the teacher's pass exactly as mal_loss_step_fwd enqueues
+// it for a step WITHOUT the temporal hint (same parameter block, same instantiation, same decomposition), and nothing else.
+// The workspace must hold a finished mal_loss_step_fwd of the same arguments (texels, identity map, camera block); the
+// launches overwrite what that call's teacher pass left with the same values.  Captured into a graph and replayed, this
+// times the north-star kernel alone with two events outside the graph.
+extern "C" int mal_loss_step_teacher_replay(const mal_step_args* a, int launches) {
+  int rc = step_check(a);
+  if (rc) return rc;
+  if ((a->flags & MAL_STEP_TEMPORAL) || launches <= 0 || launches > 4096) return MAL_EINVAL;
+  StepWs w = carve_step(a->ws, a->B, a->H, a->W);
+  float* mono_reproj = a->mono_reproj ? a->mono_reproj : w.mono_reproj;
+  for (int i = 0; i < launches; ++i) {
+    rc = launch_teacher(a, w, mono_reproj, (hipStream_t)a->stream);
+    if (rc) return rc;
+  }
+  return MAL_OK;
 }
 
 extern "C" int mal_loss_step_bwd(const mal_step_args* a) {

@@ -13,12 +13,13 @@
 //   * SSIM is evaluated on the window sums (numerator and denominator scaled by 81^2): no
 //     divisions by 9, one reciprocal per candidate-channel.
 // Window sums keep ATen's row-major order (layers.py:243-257 via AvgPool2d).
+#ifdef MAL_EXPERIMENTS  // the 512-thread LDS-tiled formulation (option "pass_impl" 2): not in the default build
 #include "mal_common.h"
 #include "mal_device.h"
 
 namespace mal {
 
-extern hipEvent_t g_prof_start, g_prof_stop;
+extern thread_local hipEvent_t g_prof_start, g_prof_stop;
 
 namespace t2 {
 
@@ -515,3 +516,4 @@ extern "C" int mal_pass_fused_tile2(const float* disp, const float* disp2, const
   return launch_pass_finalize(w.block_sums, w.block_gP, K, p.nblocks, p.tiles_x * p.tiles_y, B, sums,
                               pose ? g_T[0] : nullptr, pose ? g_T[1] : nullptr, st);
 }
+#endif  // MAL_EXPERIMENTS

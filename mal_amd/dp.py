@@ -139,6 +139,13 @@ class FlatGradBucket:
             if not self._armed:
                 return
             self._pending[k] -= 1
+            if self._pending[k] < 0:
+                # a second backward between begin_step() and finish() (gradient accumulation, retain_graph): the piece has
+                # been averaged over the ranks already and this gradient would be added onto the averaged values
+                self._armed = False
+                raise RuntimeError("FlatGradBucket: a parameter of piece %d received a second gradient between begin_step() "
+                                   "and finish(): the overlapped exchange covers exactly ONE backward per step (accumulate "
+                                   "locally and call all_reduce_mean() once, or call begin_step() before every backward)" % k)
             if self._pending[k] == 0:
                 self._seen.append(k)
             while self._next < len(self._order) and self._pending[self._order[self._next]] <= 0:

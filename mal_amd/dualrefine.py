@@ -194,14 +194,17 @@ class DualRefineLossPath:
     def _identity(self, target, sources, flags):
         """min (or mean, :568-573) over the raw sources of r(source, target): a function of the batch only, but upstream's
         loops evaluate it once per (scale, deq_iter) and once more for the consistency weights -- three marching launches
-        per step at n_losses = 1.  Cached per batch (generate_images_pred resets it) on the tensors' identity and version."""
-        key = (flags,) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in [target] + list(sources))
+        per step at n_losses = 1.  Cached per batch (generate_images_pred resets it): the entry HOLDS the tensors it was
+        computed from and is hit only by the very same tensor objects at the same version, so a new batch that the caching
+        allocator happens to place at the old address (with _version 0 again) can never be mistaken for the old one."""
+        tensors = [target] + list(sources)
         hit = getattr(self, "_ident_cache", None)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        if hit is not None and hit[0] == flags and len(hit[1]) == len(tensors) and \
+                all(a is b and v == b._version for (a, v), b in zip(hit[1], tensors)):
+            return hit[2]
         ident, _, _, _ = ops.photo_fwd(target, [s.detach() for s in sources], None, None, None, flags,
                                        want_argmin=False, want_weight=False)
-        self._ident_cache = (key, ident)
+        self._ident_cache = (flags, [(t, t._version) for t in tensors], ident)
         return ident
 
     def _reproj_term(self, inputs, outputs, key_tail, cands_keys, ext_mask, noise):

@@ -125,6 +125,8 @@ class LossStepFn(Function):
     def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, ens_disp=None):
         a, keep, maps = _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, ens_disp=ens_disp)
         L.check(L.load().mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
+        if _CAPTURE is not None:
+            _CAPTURE.append((a, keep))
         ctx.args = a
         ctx.ens_index = 8
         ctx.keep = keep  # the C struct holds raw pointers: keep the tensors alive
@@ -183,15 +185,20 @@ class TemporalLossStepFn(Function):
             raise
         region = snap = None
         if has_ins:
-            syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
-            syn_data = [ops._req(s.detach(), "syn") for s in syn]
-            region = local.get(("syn_region", 0))
-            sparse = bool(local.get(("syn_sparse", 0)))
-            if sparse and (region is None or any(s.data_ptr() != q.data_ptr() for s, q in zip(syn_data, pre))):
-                raise L.MalError("loss_step: ('syn_sparse', 0) needs the region map and the buffers of ('syn_sparse_buffers', 0)")
-            if region is not None:
-                if not (region.is_cuda and region.dtype == torch.uint8 and tuple(region.shape) == (B, H, W) and region.is_contiguous()):
+            try:  # what the producer left is checked AFTER the fork too: join it before the error travels on
+                syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
+                syn_data = [ops._req(s.detach(), "syn") for s in syn]
+                region = local.get(("syn_region", 0))
+                sparse = bool(local.get(("syn_sparse", 0)))
+                if sparse and (region is None or any(s.data_ptr() != q.data_ptr() for s, q in zip(syn_data, pre))):
+                    raise L.MalError("loss_step: ('syn_sparse', 0) needs the region map and the buffers of ('syn_sparse_buffers', 0)")
+                if region is not None and not (region.is_cuda and region.dtype == torch.uint8 and tuple(region.shape) == (B, H, W)
+                                               and region.is_contiguous()):
                     raise L.MalError("loss_step: ('syn_region', 0) must be a contiguous (B,H,W) uint8 device tensor")
+            except BaseException:
+                lib.mal_loss_step_abort(C.byref(a))
+                raise
+            if region is not None:
                 a.syn_region = region.data_ptr()
                 if sparse:
                     a.flags |= L.STEP_SYN_SPARSE
@@ -332,6 +339,37 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
               "smooth_loss/multi": v[5], "main/reproj_loss/0": v[3]}
     loss_list = [v[11], v[6]] if blc else None
     return losses, loss_list, maps
+
+
+_CAPTURE = None  # teacher_pass_replay: receives (argument block, kept tensors) of the next LossStepFn.forward
+
+
+def teacher_pass_replay(opt, inputs, mono_outputs, outputs, **kw):
+    """Measurement hook (bench.py's ``roofline`` block).  Runs ONE forward of the step without the temporal hint on the
+    given dicts (so the workspace holds the texels, the identity map and the camera block) and returns
+    ``enqueue(launches)``: each call enqueues that many back-to-back launches of the teacher's pass -- the fused
+    warp + SSIM + L1 + min + automask forward+backward sweep -- on the current stream, with the argument block of that
+    forward (``mal_loss_step_teacher_replay``).  Capture ``enqueue(64)`` into a graph, replay it, time it with two events
+    outside the graph: the kernel alone, as a replayed step runs it."""
+    global _CAPTURE
+    import copy
+    o = copy.copy(opt)
+    o.temporal = False
+    _CAPTURE = []
+    try:
+        with torch.no_grad():
+            loss_step(o, inputs, mono_outputs, outputs, want_maps=False, **kw)
+        got = list(_CAPTURE)
+    finally:
+        _CAPTURE = None
+    a, keep = got[0]
+
+    def enqueue(launches):
+        a.stream = ops._stream()
+        L.check(L.load().mal_loss_step_teacher_replay(C.byref(a), int(launches)), "mal_loss_step_teacher_replay")
+
+    enqueue.keep = keep  # the block holds raw pointers
+    return enqueue
 
 
 # ---------------------------------------------------------------------------------- sclm > 0, no --distil

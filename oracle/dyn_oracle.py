@@ -89,3 +89,42 @@ def generate_dynamic_instance(mask_last, mask_next, img_last, img_next, replace=
     ori_last = _synth(mask_last, dx, dy, img_last, bg_last, region)
     ori_next = _synth(mask_next, -dx, -dy, img_next, bg_next, region)
     return ori_last, ori_next
+
+
+def image_synthesis(inputs, outputs, scale, thres, ins_model, matcher, replace=False):
+    """manydepth/dyn_utils.py:121-170 restated on the CPU around ``generate_dynamic_instance`` above: the producer of the
+    temporal hint as ``compute_mono_losses`` consumes it (loss_utils.py:84-88).  Same control flow: the segmenter is asked
+    for the target frames' instances (only their scores are read, :131-133), then, per sample with a confident instance,
+    for the (warped last, warped next) pair (:139-143); the matcher picks the instance rows (:144); samples without a
+    match keep the warped images (:146-147).  ``ins_model(images) -> [{"instances": obj with .scores / .pred_masks}]`` and
+    ``matcher(ins_last, ins_next, cur) -> (rows_last, rows_next)`` stand in for Mask2Former and the Hungarian matcher, as
+    in ``mal_amd.dyn_utils.image_synthesis`` (the BGR x 255 conversion of :172-190 belongs to the segmenter's side).
+    Differentiable w.r.t. ``outputs[("color", f, scale)]`` through clone / index assignment like upstream (:127-128,163-164).
+    Writes ``outputs[("syn", f, scale)]`` when any sample matched; returns has_ins."""
+    bs = inputs[("color", 0, 0)].shape[0]
+    instances = ins_model(inputs[("color", 0, 0)])
+    syn_last = outputs[("color", -1, scale)].clone()
+    syn_next = outputs[("color", 1, scale)].clone()
+    has_ins = False
+    for b in range(bs):
+        cur = instances[b]["instances"]
+        instances_cur = cur[cur.scores > thres]
+        if len(instances_cur) == 0:
+            continue
+        img_last = outputs[("color", -1, scale)][b].clone()
+        img_next = outputs[("color", 1, scale)][b].clone()
+        both = ins_model(torch.cat([img_last.detach().unsqueeze(0), img_next.detach().unsqueeze(0)], dim=0))
+        ins_last, ins_next = both[0]["instances"], both[1]["instances"]
+        slice_last, slice_next = matcher(ins_last, ins_next, instances_cur)
+        if len(slice_last) + len(slice_next) == 0:
+            continue
+        has_ins = True
+        mask_last = ins_last.pred_masks[slice_last].bool()
+        mask_next = ins_next.pred_masks[slice_next].bool()
+        tmp_last, tmp_next = generate_dynamic_instance(mask_last, mask_next, img_last, img_next, replace=replace)
+        syn_last[b] = tmp_last
+        syn_next[b] = tmp_next
+    if has_ins:
+        outputs[("syn", -1, scale)] = syn_last
+        outputs[("syn", 1, scale)] = syn_next
+    return has_ins

@@ -72,5 +72,69 @@ def main():
         print(tag, {k: v.shape for k, v in d.items() if k.startswith("out/ori")})
 
 
+class _Inst:
+    """the slice of detectron2's Instances that image_synthesis touches"""
+
+    def __init__(self, scores, masks):
+        self.scores, self.pred_masks = scores, masks
+
+    def __len__(self):
+        return len(self.scores)
+
+    def __getitem__(self, sel):
+        return _Inst(self.scores[sel], self.pred_masks[sel])
+
+
+def synthesis_stubs(B, H, W, seed):
+    """stand-ins for the segmenter and the matcher that drive ``image_synthesis`` (dyn_utils.py:121-170) through every
+    branch: sample 0 has no confident instance in the target frame (:135-136), sample 1 has matched instances, sample 2
+    (if any) a confident target but an empty match (:146-147), further samples are matched."""
+    masks = {b: make_masks(3, H, W, seed + b, edge_cases=False) for b in range(B)}
+    state = {"pairs": [b for b in range(B) if b != 0]}
+
+    def ins_model(images):
+        n = len(images)
+        if n != 2:  # the target frames: only the scores are read
+            state["next"] = list(state["pairs"])
+            return [{"instances": _Inst(torch.tensor([0.2, 0.3, 0.1] if b == 0 else [0.9, 0.95, 0.4]),
+                                        torch.zeros(3, H, W, dtype=torch.bool))} for b in range(n)]
+        b = state["next"].pop(0)
+        state["cur"] = b
+        return [{"instances": _Inst(torch.full((3,), 0.9), masks[b][0])}, {"instances": _Inst(torch.full((3,), 0.9), masks[b][1])}]
+
+    def matcher(ins_last, ins_next, cur):
+        if state["cur"] == 2:
+            return torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64)
+        return torch.tensor([2, 0]), torch.tensor([1, 0])
+
+    return ins_model, matcher, masks
+
+
+def synthesis_case():
+    """the reference's own ``image_synthesis`` (dyn_utils.py:121-170) on a (B,3,H,W) pair of warped images"""
+    import manydepth.dyn_utils as DU
+    B, H, W = 4, 24, 40
+    g = torch.Generator().manual_seed(77)
+    mk = lambda: (torch.round(torch.rand(B, 3, H, W, generator=g) * 255) / 255)
+    tgt, cl, cn = mk(), mk().requires_grad_(True), mk().requires_grad_(True)
+    ins_model, matcher, _ = synthesis_stubs(B, H, W, 40)
+    outputs = {("color", -1, 0): cl, ("color", 1, 0): cn}
+    has = DU.image_synthesis({("color", 0, 0): tgt}, outputs, 0, 0.5, ins_model, matcher)
+    assert has
+    ct_l = torch.round(torch.randn(B, 3, H, W, generator=g) * 64) / 64
+    ct_n = torch.round(torch.randn(B, 3, H, W, generator=g) * 64) / 64
+    sl, sn = outputs[("syn", -1, 0)], outputs[("syn", 1, 0)]
+    gl, gn = torch.autograd.grad((sl * ct_l).sum() + (sn * ct_n).sum(), [cl, cn])
+    u8 = lambda t: (t.detach() * 255).round().to(torch.uint8).numpy()
+    d = {"in/target": u8(tgt), "in/color_last": u8(cl), "in/color_next": u8(cn), "in/ct_last": ct_l.numpy(), "in/ct_next": ct_n.numpy(),
+         "out/syn_last": sl.detach().numpy(), "out/syn_next": sn.detach().numpy(), "out/g_last": gl.numpy(), "out/g_next": gn.numpy(),
+         "in/stub_seed": np.int64(40)}
+    np.savez_compressed(os.path.join(OUT, "dyn_synthesis_b4_24x40.npz"), **d)
+    changed = [bool((sl[b] != cl[b]).any()) for b in range(B)]
+    print("dyn_synthesis_b4_24x40 samples changed:", changed)
+    assert changed == [False, True, False, True]
+
+
 if __name__ == "__main__":
     main()
+    synthesis_case()

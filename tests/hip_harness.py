@@ -9,12 +9,31 @@ from oracle import mal_oracle as O
 LEAVES = ("disp_teacher", "disp_student", "axisangle_m1", "translation_m1", "axisangle_p1", "translation_p1")
 
 
+def producer_of(batch, device=None):
+    """the temporal hint's producer for `batch`: rectangles shifted by torch slicing (``batch["syn_rects"]``: the stand-in
+    of the golden vectors, the same code on both sides), or -- ``batch["syn_instances"] = (n_inst, seed)``, the headline as
+    bench.py runs it -- dyn_utils.image_synthesis itself driven by the stand-in segmenter / matcher of
+    mal_amd.synthetic.instance_stub: the HIP kernels (mal_amd.dyn_utils, sparse syn buffers + region map) on a device, the
+    CPU restatement (oracle.dyn_oracle.image_synthesis, pinned to the reference's own function) for the oracle."""
+    if "syn_instances" in batch:
+        from mal_amd.synthetic import instance_stub
+        n_inst, seed = batch["syn_instances"]
+        B, _, H, W = batch["color0"].shape
+        ins_model, matcher = instance_stub(B, H, W, n_inst=n_inst, seed=seed, device="cpu" if device is None else device)
+        if device is None:
+            from oracle import dyn_oracle
+            return lambda inputs, outputs, scale: dyn_oracle.image_synthesis(inputs, outputs, scale, 0.5, ins_model, matcher)
+        from mal_amd import dyn_utils
+        return lambda inputs, outputs, scale: dyn_utils.image_synthesis(inputs, outputs, scale, 0.5, ins_model, matcher)
+    return fake_image_synthesis(batch["syn_rects"]) if "syn_rects" in batch else None
+
+
 def run_oracle(batch, opt_kw, n0, n1, w_list=(0.7, 0.3), forced=None):
     """``forced``: the per-pixel decisions to take instead of re-deciding them (oracle.mal_oracle.mal_loss_step)."""
     B, _, H, W = batch["color0"].shape
     opt = O.default_opt(height=H, width=W, batch_size=B, **opt_kw)
     inputs, mono_outputs, outputs, leaves = to_dicts(batch, O.transformation_from_parameters)
-    synth = fake_image_synthesis(batch["syn_rects"]) if "syn_rects" in batch else None
+    synth = producer_of(batch)
     losses, loss_list, mono_losses, mono_reproj, ens = O.mal_loss_step(
         opt, inputs, mono_outputs, outputs, n0.clone(), n1.clone(), list(w_list), synth=synth, forced=forced)
     final = B * (w_list[0] * loss_list[0] + w_list[1] * loss_list[1]) if opt.loss_blc else losses["loss"]
@@ -54,7 +73,7 @@ def run_hip(batch, opt_kw, n0, n1, fuse=True, w_list=(0.7, 0.3), device="cuda:0"
     dev = torch.device(device)
     opt = trainer.default_options(height=H, width=W, batch_size=B, **opt_kw)
     inputs, mono_outputs, outputs, leaves = to_dicts(batch, layers.transformation_from_parameters, device=dev)
-    synth = fake_image_synthesis(batch["syn_rects"]) if "syn_rects" in batch else None
+    synth = producer_of(batch, dev)
     lp = trainer.LossPath(opt, fuse=fuse, image_synthesis=synth)
     lp.w_list = list(w_list)
     # the reference draws the two noise tensors inside the loss functions; hand them in

@@ -45,11 +45,15 @@ def test_driver_command_default_flags():
     assert r["bound"] in ("hbm", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert 0.05 < r["frac"] < 1.0 and r["kernel_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["achieved"] - 96 * 12 * 192 * 640 / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    # measured in THIS run from a graph holding only 64 back-to-back launches of the kernel (no committed file is read)
+    assert "64 back-to-back launches" in r["kernel_ms_how"] and r["launches_timed"] == 640, r["kernel_ms_how"]
+    assert r["eager_kernel_ms"] > 0 and 0.5 < r["kernel_ms"] / r["eager_kernel_ms"] < 1.2 and "replayed_rocprof" not in r
     v = r["valu"]
     assert "error" not in v, v
     assert 0.2 < v["valu_frac"] < 1.2 and v["shader_clock_mhz"] > 500 and v["tasks"] > 0 and v["pipe_cycles_per_row"] > 0
     c = d["cpu_baseline"]
     assert c["value"] > 0 and c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "images/s" and c["sample"]
+    assert "--temporal --distil" in c["sample"]  # the same step as the headline, producer included
     t = d["train_step"]
     assert "error" not in t, t
     assert t["value"] > 0 and t["steps"] == 20 and "networks_fwd" in t["breakdown_ms"]
@@ -61,8 +65,12 @@ def test_driver_command_default_flags():
                                           (["--mode", "distil"], "--distil")],
                          ids=["dualrefine", "cityscapes_width", "distil"])
 def test_other_bench_modes_print_a_line(extra, expect):
-    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--train-steps", "0"] + extra)
+    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--train-steps", "0", "--loss-blc"] + extra)
     _contract(d, 2, 1)
+    if extra == ["--mode", "distil"]:  # the reference's own command adds --loss_blc (README.md:22): timed as its own block
+        b = d["loss_blc"]
+        assert "error" not in b, b
+        assert b["ms_per_step"] > 0 and b["launch"] == "eager" and b["w_ori"] > 0 and b["w_distil"] > 0
     assert expect in d["config"]["workload"], d["config"]["workload"]
     if extra[0] == "--mode" and extra[1] == "dualrefine":
         assert d["config"]["global_batch"] == 8 and abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
@@ -73,19 +81,26 @@ def test_other_bench_modes_print_a_line(extra, expect):
 def test_two_ranks_over_gloo_print_the_multi_gpu_line():
     """the N>1 launch exactly as the driver starts it for N=2 -- `python bench.py --gpus 2` spawns the ranks itself -- but with
     gloo standing in for RCCL (MAL_BENCH_BACKEND=gloo: both ranks share this box's one card).  Covers everything of the
-    multi-GPU line except the RCCL transport: rank spawn, the stand-in 165 MB exchange inside the timed step, the
-    overlapped-exchange block, the whole training step with the gradient pieces issued from inside the backward (no
-    try/except around it at N>1: a failing collective fails the run), max-over-ranks timing, `scaling_metric`."""
+    multi-GPU line except the RCCL transport: rank spawn, max-over-ranks timing, and the shape of the N>1 line -- its
+    `value` / `ms_per_step` are the WHOLE TRAINING STEP's (RepDepth + loss path + the gradient pieces issued from inside the
+    backward + Adam; no try/except around it at N>1: a failing collective fails the run), timed over exactly --steps steps;
+    the loss path beside the stand-in 165 MB exchange and its overlapped variant sit in the `loss_path` side block."""
     env = dict(os.environ, MAL_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--train-steps", "2"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 24 and d["scaling"] == "weak"
-    assert d["scaling_metric"] == "train_step" and "cpu_baseline" not in d
-    assert d["breakdown_ms"]["grad_all_reduce"] > 0 and "error" not in d["exchange_overlapped"]
+    assert "whole training step" in d["metric"] and "RepDepth" in d["config"]["workload"] and "Adam" in d["config"]["workload"]
+    assert "scaling_metric" not in d and "cpu_baseline" not in d and d["value_is"].startswith("train_step")
     t = d["train_step"]
     assert t["n_gpus"] == 2 and t["value"] > 0 and "4 piece(s)" in t["exchange"] and "world size 2" in t["exchange"]
+    assert d["steps"] == 2 and d["warmup"] == 1 and t["steps"] == 2
+    assert d["value"] == t["value"] and d["ms_per_step"] == t["ms_per_step"]
     assert abs(d["value"] - 24 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    lp = d["loss_path"]
+    assert lp["breakdown_ms"]["grad_all_reduce"] > 0 and "error" not in lp["exchange_overlapped"]
+    assert abs(lp["value"] - 24 / (lp["ms_per_step"] * 1e-3)) <= 1e-6 * lp["value"] and "--temporal --distil" in lp["workload"]
+    assert d["roofline"]["kernel_ms"] > 0

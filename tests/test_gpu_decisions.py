@@ -45,8 +45,7 @@ def run_step_with_decisions(batch, opt_kw, n0, w_list=(0.7, 0.3), device="cuda:0
     for f, s in ((-1, "m1"), (1, "p1")):
         mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + s]
         mono_outputs[("translation", 0, f)] = leaves["translation_" + s]
-    from mal_amd.synthetic import fake_image_synthesis
-    synth = fake_image_synthesis(batch["syn_rects"]) if "syn_rects" in batch else None
+    synth = HH.producer_of(batch, dev)
     losses, loss_list, maps = step.loss_step(opt, inputs, mono_outputs, outputs, w_list=list(w_list), noise=n0.to(dev),
                                              want_decisions=True, image_synthesis=synth)
     losses["loss"].backward()
@@ -201,6 +200,27 @@ def test_temporal_at_baseline_size(B, H, W):
     n0, n1 = torch.randn(B, 1, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
     counts, report = check_step_decision_exact(b, {"temporal": True}, n0, n1)
     print("temporal: differing decisions", counts, "L2 rel to fp64 (hip, fp32 oracle)", report)
+
+
+def test_headline_as_benchmarked_decision_exact():
+    """The headline configuration exactly as bench.py times it -- B=12 192x640, --temporal --distil, the REAL producer
+    (mal_amd.dyn_utils.image_synthesis: N2's kernels, sparse syn buffers, region map, in-place backward) with the stand-in
+    segmenter / matcher and three matched instances per sample -- through step.loss_step against the CPU oracle driven by
+    the restated producer (oracle.dyn_oracle.image_synthesis, pinned bit for bit to the reference's own image_synthesis) on
+    the same instance masks.  Decision-exact: the kernels' decisions differ from the oracle's at near-ties only, and with
+    the same decisions every loss scalar and every gradient (incl. what reaches disparity and poses through syn) is held at
+    1e-4 / the fp32 oracle's own distance from the exact value."""
+    from mal_amd.synthetic import make_batch
+    B, H, W = 12, 192, 640
+    b = make_batch(B, H, W, seed=1234)
+    b["syn_instances"] = (3, 1234)  # bench.py: instance_stub(B, H, W, n_inst=3, seed=1234 + rank)
+    g = torch.Generator().manual_seed(8)
+    n0, n1 = torch.randn(B, 1, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
+    (h, o), counts, report = check_step_decision_exact(b, {"temporal": True}, n0, n1, return_runs=True)
+    won = HH.kernel_decisions(h["maps"])["teacher"]["win"] >= 2
+    assert 0.001 < float(won.float().mean()) < 0.2, float(won.float().mean())  # synthesised candidates do win somewhere
+    print("headline as benchmarked: differing decisions", counts, "L2 rel to fp64 (hip, fp32 oracle)", report,
+          "syn wins at %.2f %% of the pixels" % (100 * float(won.float().mean())))
 
 
 def test_baseline_size_report():

@@ -223,19 +223,41 @@ def test_step_with_the_region_map_equals_the_dense_path():
         losses["loss"].backward()
         torch.cuda.synchronize()
         return ({k: float(v.detach()) for k, v in losses.items()}, {k: t.grad.cpu() for k, t in leaves.items()},
-                maps["dec_teacher"][_lib.DEC_WIN].cpu())
+                maps["dec_teacher"][_lib.DEC_WIN].cpu(), maps["dec_student"].cpu())
 
     seen = {}
-    l_dense, g_dense, win_dense = run(True)
-    l_sparse, g_sparse, win_sparse = run(False)
+    l_dense, g_dense, win_dense, dec_s_dense = run(True)
+    l_sparse, g_sparse, win_sparse, dec_s_sparse = run(False)
     for k, v in l_dense.items():
         assert abs(l_sparse[k] - v) <= 2e-6 * abs(v) + 1e-9, (k, l_sparse[k], v)
-    for k, r in g_dense.items():
-        sc = float(r.abs().max())
-        bad = ((g_sparse[k] - r).abs() > 1e-4 * sc).float().mean().item()
-        assert bad <= 1e-3, (k, bad)
     region = (seen["region"] & 1).bool().cpu()
     near = torch.nn.functional.max_pool2d(region[:, None].float(), 3, 1, 1)[:, 0] > 0
+    # Decision-exact (round 3 allowed 1e-3 of the elements to be off): away from the dilated region syn_f IS warp_f, so the
+    # dense path's winner 2 / 3 there is the same image as 0 / 1 -- compared modulo 2 --; what then still differs is a
+    # handful of genuine near-ties (two kernels round the synthesised candidates' SSIM differently), and EVERY element of
+    # the teacher's disparity gradient that differs lies within reach of one of them: the 3x3 window of the decision, the
+    # 3x3 window of the partials, and the producer's patch shift (<= 8 px horizontally in this stub) on the way back
+    # through syn.
+    wd, ws_ = win_dense.long(), win_sparse.long()
+    same_image = ~near
+    d = ((wd & 3) != (ws_ & 3)) & ~(same_image & (((wd & 3) % 2) == ((ws_ & 3) % 2)))
+    d |= ((wd >> 2) & 1) != ((ws_ >> 2) & 1)  # the automask bit
+    assert int(d.sum()) <= 3e-4 * d.numel() + 8, int(d.sum())
+    reach = torch.nn.functional.max_pool2d(d[:, None].float(), 2 * 12 + 1, 1, 12) > 0
+    r, g = g_dense["disp_teacher"], g_sparse["disp_teacher"]
+    off = (g - r).abs() > 1e-4 * float(r.abs().max())
+    assert not bool((off & ~reach).any()), ("teacher gradient differs away from every differing decision",
+                                            torch.nonzero(off & ~reach)[:5].tolist())
+    # the student sees the hint only through the teacher's min map (the distillation argmin, pointwise): its decisions
+    # differ where that map moved by a rounding across a three-way near-tie, and its gradient only there
+    ds = (dec_s_dense != dec_s_sparse).any(0)
+    assert int(ds.sum()) <= 3e-4 * ds.numel() + 8, int(ds.sum())
+    rs, gs = g_dense["disp_student"], g_sparse["disp_student"]
+    off_s = (gs - rs).abs() > 1e-4 * float(rs.abs().max())
+    assert not bool((off_s[:, 0] & ~ds).any()), torch.nonzero(off_s[:, 0] & ~ds)[:5].tolist()
+    for k in ("axisangle_m1", "translation_m1", "axisangle_p1", "translation_p1"):  # global sums: a few near-ties move them by
+        sc = float(g_dense[k].abs().max())                                        # their share of the pixels
+        assert float((g_sparse[k] - g_dense[k]).abs().max()) <= (1e-4 + 4.0 * float(d.float().mean())) * sc, k
     syn_won = (win_sparse & 3) >= 2
     assert not bool((syn_won & ~near).any())          # with the map: never outside the dilated region
     assert bool((syn_won & near).any())               # ... and the synthesised candidates do win somewhere inside

@@ -244,6 +244,10 @@ def test_alternative_teacher_schedules_hold_against_the_oracle(option, temporal)
     from mal_amd import _lib
     from mal_amd.synthetic import make_batch
     lib = _lib.load()
+    if not lib.mal_build_has_experiments():
+        # the default library does not contain the losing schedules and says so instead of silently running the default
+        assert lib.mal_set_option(option.encode(), 1) != 0 and lib.mal_set_option(option.encode(), 0) == 0
+        pytest.skip("built without -DMAL_EXPERIMENTS (MAL_EXPERIMENTS=1 python -m mal_amd.build)")
     _lib.check(lib.mal_set_option(option.encode(), 1), option)
     try:
         if temporal:

@@ -121,3 +121,18 @@ def test_dualrefine_one_call_step_refuses_what_it_does_not_cover():
         lp = dualrefine.DualRefineLossPath(dualrefine.default_options(**kw))
         with pytest.raises(_lib.MalError):
             lp.loss_step({("color", 0, 0): torch.zeros(1, 3, 8, 8)}, {})
+
+
+def test_valu_price_list_finds_the_row_loops():
+    """build() treats the vector-ALU price list as best effort (it parses a compiler listing by mangled names); the hard
+    assertion lives here: the shipped sources yield a row loop and a gradient-only loop for the north-star kernel, and the
+    hand-written DPP blocks of that loop open with the five wait states their hazards need (mal_pairs.h)."""
+    from mal_amd import build
+    rep = build.valu_report()
+    for name in ("teacher", "teacher_temporal", "student", "ensemble"):
+        assert name in rep["kernels"], (name, sorted(rep["kernels"]))
+        assert rep["kernels"][name]["pipe_cycles"] > 0 and rep["kernels"][name]["valu_instructions"] > 100
+    assert rep["kernels"]["teacher"]["drain"]["valu_instructions"] > 0
+    assert rep["kernels"]["teacher"]["classes"]["dpp"]["instr"] == 84  # the written-out blocks, not the compiler's peephole
+    src = open(os.path.join(os.path.dirname(build.CSRC), "csrc", "mal_pairs.h")).read()
+    assert src.count('asm("s_nop 4') == 2 and 'asm("s_nop 1' not in src
