@@ -593,7 +593,8 @@ int mal_set_option(const char* name, int value);
  * launches read them without further synchronisation.  The formulations that were measured slower (pass_impl 0 / 2,
  * march3, temporal_spec, syn_queue) are compiled only into a library built with -DMAL_EXPERIMENTS (MAL_EXPERIMENTS=1
  * python -m mal_amd.build); the default library refuses those switches with MAL_EINVAL.  The one-shot arms below
- * (mal_profile_next_pass, mal_decisions_next_pass) are per THREAD: armed and consumed by the calling thread's next pass. */
+ * (mal_profile_next_pass, mal_decisions_next_pass) are process-wide too (a step's backward runs on autograd's worker
+ * thread, not on the arming one) and are taken with an atomic exchange: exactly one pass consumes an arm. */
 int mal_build_has_experiments(void); /* 1 when the library contains the -DMAL_EXPERIMENTS formulations */
 
 /* ---- measurement hooks (bench.py): HIP events recorded immediately before / after the main

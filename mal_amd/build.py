@@ -87,7 +87,7 @@ VALU_JSON = os.path.join(LIBDIR, "valu_cost.json")
 # the instantiations bench.py prices: name -> substring of the mangled symbol
 VALU_KERNELS = {"teacher": "march_teacher_kernelILb0ELb0EE", "teacher_temporal": "march_teacher_kernelILb1ELb0EE",
                 "teacher_generic": "march_kernelILb1ELb1ELb1ELb0ELb0ELb0EE",
-                "student": "march_student_kernelILi107EE", "student_generic": "march_kernelILb1ELb0ELb0ELb1ELb0ELb0EE",
+                "student": "march_student_kernelILi619EE", "student_generic": "march_kernelILb1ELb0ELb0ELb1ELb0ELb0EE",
                 "ensemble": "march_kernelILb0ELb0ELb0ELb0ELb0ELb0EE"}
 
 

@@ -1,5 +1,6 @@
 // Library-level entry points of libmal_hip.so (version, error strings, workspace sizing).
 #include "mal_common.h"
+#include <atomic>
 
 using namespace mal;
 
@@ -31,7 +32,9 @@ extern "C" size_t mal_workspace_bytes(int B, int H, int W) {
 // ---- timing hooks used by bench.py: bracket the NEXT mal_pass_fused main kernel with HIP
 // events on the stream it is launched on (kernel only: not the finalize launch, not host time).
 namespace mal {
-thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;  // armed and consumed on the calling thread
+// process-wide one-shot arm (a step's backward runs on autograd's worker thread, not on the arming one): taken with an
+// atomic exchange, so two launches can never both consume it
+std::atomic<hipEvent_t> g_prof_start{nullptr}, g_prof_stop{nullptr};
 }
 
 extern "C" void* mal_event_create(void) {

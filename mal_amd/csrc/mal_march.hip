@@ -29,13 +29,23 @@
 // / compute_main_losses (loss_utils.py:57-113,131-199), generate_images_pred_ensemble
 // (:1172-1207) and the consistency/distillation terms (loss_utils.py:193-254).
 #include "mal_march.h"
+#include <atomic>
 #include "mal_device.h"
 #include "mal_pairs.h"
 #include <mutex>
 
 namespace mal {
 
-extern thread_local hipEvent_t g_prof_start, g_prof_stop;
+extern std::atomic<hipEvent_t> g_prof_start, g_prof_stop;
+
+// -DMAL_STAGE_MARKS (scripts/valu_budget.py): stage boundaries of the row loop as labelled comments in the compiler's
+// listing, each behind a scheduling barrier so that no instruction crosses one -- the per-stage instruction budget of
+// profiles/r04_valu_budget.json.  The shipped build has neither the comments nor the barriers.
+#ifdef MAL_STAGE_MARKS
+#define MAL_MARK(n) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MAL_STAGE " #n); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MAL_MARK(n) do { } while (0)
+#endif
 
 typedef __attribute__((address_space(4))) const float cfloat;  // constant address space: uniform loads are s_load
 
@@ -110,9 +120,11 @@ MAL_DEV Sample2 project2(const f2 (&P)[12], const float (&X)[3], float eps, int 
     iy = fma2(gy + bc(1.0f), bc(hf * 0.5f), bc(-0.5f));
   }
   const float xmax = (float)(W - 1), ymax = (float)(H - 1);
-  // fmaxf/fminf drop NaNs, so a degenerate projection still yields an in-range index
-  s.ix = (f2){fminf(fmaxf(ix.x, 0.0f), xmax), fminf(fmaxf(ix.y, 0.0f), xmax)};
-  s.iy = (f2){fminf(fmaxf(iy.x, 0.0f), ymax), fminf(fmaxf(iy.y, 0.0f), ymax)};
+  // border clamp as ONE v_med3_f32 per value (fminf(fmaxf()) is canonicalise + max + min: 12 instructions for the four);
+  // a NaN -- a degenerate projection -- still yields an in-range index: med3 of a NaN is the minimum of the other two, 0,
+  // which is what fmaxf made of it
+  s.ix = (f2){__builtin_amdgcn_fmed3f(ix.x, 0.0f, xmax), __builtin_amdgcn_fmed3f(ix.y, 0.0f, xmax)};
+  s.iy = (f2){__builtin_amdgcn_fmed3f(iy.x, 0.0f, ymax), __builtin_amdgcn_fmed3f(iy.y, 0.0f, ymax)};
   // the border itself counts as clipped (ATen)
   s.mx = (f2){(s.ix.x != 0.0f && s.ix.x != xmax) ? 1.0f : 0.0f, (s.ix.y != 0.0f && s.ix.y != xmax) ? 1.0f : 0.0f};
   s.my = (f2){(s.iy.x != 0.0f && s.iy.x != ymax) ? 1.0f : 0.0f, (s.iy.y != 0.0f && s.iy.y != ymax) ? 1.0f : 0.0f};
@@ -140,7 +152,10 @@ MAL_DEV void dec_store(unsigned* dbg, unsigned n, int plane, unsigned boff, unsi
 }
 
 // projection, tap weights and the eight gathers
-template <bool DERIV, bool POSE, bool DBG, class BeforeGathers>
+// LEAN (the specialised passes of the whole-step lists: packed texels, H*W*12 < 2^24 checked by march_launch): the byte
+// offsets of the four taps are formed in fp32 -- every product and sum below 2^24 is exact -- instead of with 32-bit integer
+// multiplies (v_mul_lo_u32 is quarter rate: the compiler does not keep __umul24 for operands it cannot bound)
+template <bool DERIV, bool POSE, bool DBG, bool LEAN, class BeforeGathers>
 MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik)[9], int b, int gyr, int gxr,
                         float dispv, PendingWarp& w, BeforeGathers before_gathers) {
   const int W = p.W, H = p.H, HW = H * W, pix = gyr * W + gxr;
@@ -149,11 +164,24 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
   ray_of(ik, (float)gxr, (float)gyr, ray);
   X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
   const Sample2 s = project2(P, X, p.eps, W, H, p.convention, p.rw, p.rh);
+  MAL_MARK(10);  // projection done; taps, operand requests, gathers follow
   // make_taps of mal_device.h for both frames
   const f2 x0f = (f2){floorf(s.ix.x), floorf(s.ix.y)}, y0f = (f2){floorf(s.iy.x), floorf(s.iy.y)};
   int oo[2][4];
+  unsigned bo12[2][4];  // LEAN: byte offsets of the taps inside the sample's texel image
+  if (LEAN) {
+    const float xm = (float)(W - 1), ym = (float)(H - 1), w12 = (float)(W * kTexel * 4);
+    const f2 x1f = (f2){fminf(x0f.x + 1.0f, xm), fminf(x0f.y + 1.0f, xm)};  // x0+1 == W only with weight 0
+    const f2 y1f = (f2){fminf(y0f.x + 1.0f, ym), fminf(y0f.y + 1.0f, ym)};
+    const f2 r0 = y0f * bc(w12), r1 = y1f * bc(w12), c0 = x0f * bc((float)(kTexel * 4)), c1 = x1f * bc((float)(kTexel * 4));
+    const f2 o00 = r0 + c0, o01 = r0 + c1, o10 = r1 + c0, o11 = r1 + c1;
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < 2; ++f) {
+      bo12[f][0] = (unsigned)o00[f]; bo12[f][1] = (unsigned)o01[f]; bo12[f][2] = (unsigned)o10[f]; bo12[f][3] = (unsigned)o11[f];
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < 2 && !LEAN; ++f) {
     const int x0 = (int)x0f[f], y0 = (int)y0f[f];
     const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);  // x0+1 == W only with weight 0
     // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): rows and H*W are below 2^24 (march_launch checks)
@@ -168,7 +196,11 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int (&o)[4] = oo[f];
-    if (p.packed & 1) {
+    if (LEAN) {
+      const float* sp = p.src[f] + (size_t)b * HW * kTexel;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w.t[f][k] = ldt(sp, bo12[f][k]);
+    } else if (p.packed & 1) {
       const float* sp = p.src[f] + (size_t)b * HW * kTexel;
 #pragma unroll
       for (int k = 0; k < 4; ++k) w.t[f][k] = ldt(sp, __umul24((unsigned)o[k], (unsigned)(kTexel * 4)));
@@ -248,10 +280,11 @@ enum : int {
   kSpecMonoYes = 64,                    // the teacher's disparity is given as disparity (epilogue)
   kSpecNoScale = 128,                   // no per-sample scale
   kSpecNoNoise = 256,                   // no tie-break noise map (the whole-step lists fold it into the identity map: Philox)
-  kSpecTeacher = kSpecLean | kSpecNoDisp2 | kSpecExtNo | kSpecCostNo | kSpecNoScale,
-  kSpecStudent = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostYes | kSpecMonoYes,      // whole-step list, scale 0
-  kSpecStudentNoCost = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostNo | kSpecMonoYes, // four-scale list, scales > 0
-  kSpecRefine = kSpecLean | kSpecNoDisp2 | kSpecCostNo | kSpecMonoYes | kSpecNoScale        // DualRefine, deq iterations > 0
+  kSpecConvA = 512, kSpecConvB = 1024,  // Project3D convention 0 (ManyDepth, align_corners=True) / 1 (DualRefine) known at compile time
+  kSpecTeacher = kSpecLean | kSpecNoDisp2 | kSpecExtNo | kSpecCostNo | kSpecNoScale | kSpecConvA,
+  kSpecStudent = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostYes | kSpecMonoYes | kSpecConvA,      // whole-step list, scale 0
+  kSpecStudentNoCost = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostNo | kSpecMonoYes | kSpecConvA, // four-scale list, scales > 0
+  kSpecRefine = kSpecLean | kSpecNoDisp2 | kSpecCostNo | kSpecMonoYes | kSpecNoScale | kSpecConvB        // DualRefine, deq iterations > 0
 };
 template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG, bool TEMPORAL, bool EXPORT, int SPEC = 0>
 MAL_DEV void march_body() {
@@ -260,6 +293,7 @@ MAL_DEV void march_body() {
   constexpr bool COST_NO = (SPEC & kSpecCostNo) != 0, COST_YES = (SPEC & kSpecCostYes) != 0;
   constexpr bool MONO_YES = (SPEC & kSpecMonoYes) != 0, NO_SCALE = (SPEC & kSpecNoScale) != 0;
   constexpr bool NO_NOISE = (SPEC & kSpecNoNoise) != 0;
+  constexpr int CONV = (SPEC & kSpecConvA) ? 0 : ((SPEC & kSpecConvB) ? 1 : -1);  // Project3D convention fixed at compile time
   constexpr bool OUTS = EXPORT || (!GRAD && !EPI);  // the outputs the producer / the fused sweep read
   constexpr int HALO = GRAD ? 2 : 1;
   constexpr int CW = 64 - 2 * HALO;
@@ -321,6 +355,10 @@ MAL_DEV void march_body() {
 #else
   const float sL = gx == 0 ? 2.0f : 1.0f, sR = gx == W - 1 ? 2.0f : 1.0f;
 #endif
+  // ... the same weights as the RECEIVING lane sees them (horizontal sums through LDS, below): what arrives from the left
+  // neighbour counts twice in column 1, what arrives from the right one in column W-2
+  const float wL = gx == 1 ? 2.0f : 1.0f, wR = gx == W - 2 ? 2.0f : 1.0f;
+  (void)sL; (void)sR; (void)wL; (void)wR;
 
   // (B,1,H,W) maps are addressed as (kernel-argument pointer) + (32-bit per-lane byte offset that already holds the
   // sample's base): no 64-bit pointer arithmetic per map and row (check_shape bounds a map below 2^31 bytes)
@@ -365,6 +403,29 @@ MAL_DEV void march_body() {
   // conflicts: lane-private dwords; no barrier: one wavefront) instead of ~50 registers or a re-warp
   constexpr int RING = GRAD ? (POSE ? 24 : 12) : 1;  // x, then (du, dv, u/v/rz) or e; the target row is re-read from memory
   __shared__ float s_ring[GRAD ? 3 : 1][RING][64];
+  // Horizontal 3-sums of the gradient passes go through LDS instead of DPP (round 4; -DMAL_HSUM_DPP keeps the written-out
+  // v_add_f32_dpp blocks of round 3 for A/B).  scripts/dpp_probe.hip: at two waves per SIMD EVERY cross-lane VALU form
+  // (wave_shr, row_shr, quad_perm, v_mov_dpp, v_fmac_dpp) costs a wave 9.2 cycles of its issue timeline against 5.0 for a
+  // plain instruction, so a 3-sum by two DPP adds costs 18.4 -- and the same sum as one LDS write, two LDS reads and two
+  // plain adds 9.1 (profiles/r04_dpp_probe.txt).  A lane stores four values (16 bytes, lane stride 16: conflict-free
+  // ds_write_b128), reads its two neighbours' four (two ds_read_b128) and adds with packed instructions; 42 sums per row are
+  // 11 writes + 22 reads + 42 packed adds instead of 84 DPP adds + 18 packed multiplies (the adjoint's border weights ride
+  // on the receiving side as fused multiply-adds: x 1 or x 2 is exact, so the rounding is that of the DPP form, bit for
+  // bit).  LDS operations of a wave execute in order, so ONE 1 KB buffer serves all groups without waits in between.
+  // Lanes 0 and 63 take their own value for the missing neighbour (DPP's bound_ctrl gave 0): those are halo lanes whose sums
+  // feed only halo lanes, never an output pixel.
+#ifdef MAL_HSUM_DPP
+  constexpr bool HSUM_LDS = false;
+#else
+  constexpr bool HSUM_LDS = GRAD;
+#endif
+  __shared__ f4 s_stage[HSUM_LDS ? 64 : 1];
+  const int laneL = max(lane - 1, 0), laneR = min(lane + 1, 63);
+  auto nb4 = [&](f4 v, f4& L, f4& R) __attribute__((always_inline)) {
+    s_stage[lane] = v;
+    L = s_stage[laneL];
+    R = s_stage[laneR];
+  };
   int it = 0;
   // One-row halo (p.bnd != nullptr, gradient passes of the whole-step list): a task warps ONE row beyond each end of its
   // segment and evaluates the statistics / decisions of its OWN rows only.  The gradient of a boundary row then lacks
@@ -584,6 +645,7 @@ MAL_DEV void march_body() {
       g[1] = fma2((f2){cur.gc[3], cur.gc[4]}, ownf, g[1]);
       g[2] = fma2((f2){cur.gc[2], cur.gc[5]}, ownf, g[2]);
     }
+    MAL_MARK(61);  // ring read, L1 term, vertical adjoint sums, d loss / d warped colour done
     float gdisp;
     if (POSE) {
       // u, v, 1/z of row q come back from the ring; its point and the depth derivatives are re-derived
@@ -605,6 +667,7 @@ MAL_DEV void march_body() {
       const f2 gv = (f2){(tv0.x + tv0.y) + tv2.x, (tv1.x + tv1.y) + tv2.y};
       const f2 gd = gu * alq + gv * beq;
       gdisp = gd.x + gd.y;
+      MAL_MARK(62);  // chain rule to the disparity done; pose partials follow
       if (out_x) {
         const f2 a0 = gu * pq_rz, a1 = gv * pq_rz, a2 = -(gu * pq_u + gv * pq_v) * pq_rz;
         const f2 a[3] = {a0, a1, a2};
@@ -629,6 +692,7 @@ MAL_DEV void march_body() {
       else stf(p.g_reproj, so_q, gdisp);
     }
   }
+  MAL_MARK(63);  // gradient row stored
   // roll the partial-plane sums: (row c: top+mid) <- (row c: top) + hc(c) ; (row c+1: top) <- hc(c)
   {
     const float wyu = (c == 0) ? 2.0f : 1.0f;  // hc(c) as the TOP neighbour of row c+1: doubled if c is row 0
@@ -651,7 +715,7 @@ MAL_DEV void march_body() {
                has_er = mp.ens_reproj != nullptr;
     WarpConsts wc;
     wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = mp.packed; wc.debug = LEAN ? 0 : p.debug; wc.W = W; wc.H = H;
-    wc.convention = p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
+    wc.convention = CONV >= 0 ? CONV : p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
     wc.rw = norm_rw; wc.rh = norm_rh;
     wc.dbg = DBG ? p.dbg : nullptr; wc.dbg_n = (unsigned)(p.B * HW);
     wc.dbg_off = 0; wc.dbg_on = false;
@@ -663,7 +727,7 @@ MAL_DEV void march_body() {
 #else
     auto tick = [](int) {};
 #endif
-    tick(0);  // loop overhead + parameter loads
+    tick(0); MAL_MARK(0);  // loop overhead + parameter loads
     // byte offsets (sample base included) of this lane's pixel in the rows this iteration writes: c = r-1 and q = r-2
     const unsigned so_c = moff(min(max(r - 1, 0), H - 1)), so_q = GRAD ? moff(min(max(r - 2, 0), H - 1)) : so_c;
     // ---- what the previous iteration requested for this one
@@ -686,10 +750,10 @@ MAL_DEV void march_body() {
       load_cam(cam_b, P, ik);
       // the next iteration's operands go out between the projection and the gathers (measured: behind the
       // gathers is 5 % slower even when the blend then waits for the gathers only)
-      warp_issue<GRAD, POSE, DBG>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
+      warp_issue<GRAD, POSE, DBG, LEAN && !DBG>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
     }
     __builtin_amdgcn_s_setprio(0);
-    tick(1);  // small loads, prefetch, projection, gathers issued
+    tick(1); MAL_MARK(1);  // small loads, prefetch, projection, gathers issued
     auto finish_warp = [&]() {
       DerivRow d0;
       warp_finish<GRAD, POSE>(pw, w0.x, d0);
@@ -713,9 +777,9 @@ MAL_DEV void march_body() {
     };
 
     if (EPI && GRAD) epilogue(p, r, pi1, le_disp, le_mono, le_mr, le_er, so_c, so_q, has_mdisp, has_er, cur.e_ensd);
-    tick(2);  // epilogue terms
+    tick(2); MAL_MARK(2);  // epilogue terms
     finish_warp();
-    tick(3);  // gather wait, blend, ring write
+    tick(3); MAL_MARK(3);  // gather wait, blend, ring write
     if (OUTS) {  // the pass in front of the temporal-hint producer: the warped images, planar
       float* const c0 = p.color_out[0];
       float* const c1 = p.color_out[1];
@@ -745,6 +809,22 @@ MAL_DEV void march_body() {
         in[3 + k * 3 + 0] = x; in[3 + k * 3 + 1] = x * x; in[3 + k * 3 + 2] = x * y;
       }
       f2 out[12];
+      if (HSUM_LDS) {
+        // three groups in flight at a time (24 registers of neighbours; all six at once spilled the pose variants)
+#pragma unroll
+        for (int h0 = 0; h0 < 6; h0 += 3) {
+          f4 L[3], R[3];
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+            nb4((f4){in[2 * (h0 + g)].x, in[2 * (h0 + g)].y, in[2 * (h0 + g) + 1].x, in[2 * (h0 + g) + 1].y}, L[g], R[g]);
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {  // (left + own) + right, as the DPP form
+            out[2 * (h0 + g)] = ((f2){L[g].x, L[g].y} + in[2 * (h0 + g)]) + (f2){R[g].x, R[g].y};
+            out[2 * (h0 + g) + 1] = ((f2){L[g].z, L[g].w} + in[2 * (h0 + g) + 1]) + (f2){R[g].z, R[g].w};
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         float v8[8], r8[8];
@@ -753,6 +833,7 @@ MAL_DEV void march_body() {
         hsum3_block8(v8, r8);
 #pragma unroll
         for (int i = 0; i < 4; ++i) out[g * 4 + i] = (f2){r8[2 * i], r8[2 * i + 1]};
+      }
       }
       hy[0] = out[0]; hy[1] = out[1]; hz[0] = out[2].x; hz[1] = out[2].y;
 #pragma unroll
@@ -769,7 +850,7 @@ MAL_DEV void march_body() {
       }
     }
 
-    tick(4);  // horizontal sums
+    tick(4); MAL_MARK(4);  // horizontal sums
     // ================= stage S: statistics of centre row c = r-1 ==============================
     const int c = r - 1;
     const bool c_valid = c >= 0 && c < H && c >= y_lo - (HALO - 1) + h1e && c <= y_hi - 1 + (HALO - 1) - h1e;
@@ -792,6 +873,7 @@ MAL_DEV void march_body() {
                                 &pa[GRAD ? k : 0], &pb[GRAD ? k : 0], &pcq[GRAD ? k : 0]);
         vc[k] = (f2){clamp01(v[k].x), clamp01(v[k].y)};
       }
+      MAL_MARK(50);  // window sums + SSIM of six values done; L1, min, masks, coefficients follow
       const f2 ssum = (f2){(vc[0].x + vc[0].y) + vc[2].x, (vc[1].x + vc[1].y) + vc[2].y};
       const f2 l0 = w1.yrg - w1.x[0], l1 = w1.yrg - w1.x[1], l2 = bc(w1.yb) - w1.x[2];
       const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
@@ -861,10 +943,29 @@ MAL_DEV void march_body() {
       }
     }
 
-    tick(5);  // statistics, SSIM, masks
+    tick(5); MAL_MARK(5);  // statistics, SSIM, masks
     if (GRAD) {
       // ================= stage HC: horizontal sums of the partial planes of row c ==============
       f2 hc[9];
+      if (HSUM_LDS) {
+        // (w_left * left + own) + w_right * right: the border weights of the adjoint on the receiving side, fused (exact products)
+#pragma unroll
+        for (int h0 = 0; h0 < 5; h0 += 3) {  // groups 0-2, then 3-4 (the last one holds a single pair)
+          f4 L[3], R[3];
+#pragma unroll
+          for (int g = 0; g < 3 && h0 + g < 5; ++g) {
+            const int a = 2 * (h0 + g);
+            nb4(a + 1 < 9 ? (f4){coef[a].x, coef[a].y, coef[a + 1].x, coef[a + 1].y} : (f4){coef[a].x, coef[a].y, 0.f, 0.f}, L[g], R[g]);
+          }
+#pragma unroll
+          for (int g = 0; g < 3 && h0 + g < 5; ++g) {
+            const int a = 2 * (h0 + g);
+            hc[a] = fma2((f2){R[g].x, R[g].y}, bc(wR), fma2((f2){L[g].x, L[g].y}, bc(wL), coef[a]));
+            if (a + 1 < 9) hc[a + 1] = fma2((f2){R[g].z, R[g].w}, bc(wR), fma2((f2){L[g].z, L[g].w}, bc(wL), coef[a + 1]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else
 #pragma unroll
       for (int g = 0; g < 3; ++g) {  // three planes (six values) per written-out block of DPP adds
         float l6[6], c6[6], t6[6], r6[6];
@@ -877,10 +978,11 @@ MAL_DEV void march_body() {
 #pragma unroll
         for (int i = 0; i < 3; ++i) hc[g * 3 + i] = (f2){r6[2 * i], r6[2 * i + 1]};
       }
+      MAL_MARK(60);  // horizontal sums of the 18 partial planes done
       gradient_row(p, r, it, hc, cur, so_q, le_mono);
     }
 
-    tick(6);  // partial-plane sums, gradient row
+    tick(6); MAL_MARK(6);  // partial-plane sums, gradient row
     if (EPI && !GRAD) epilogue(p, r, pi0, le_disp, le_mono, le_mr, le_er, so_c, so_q, has_mdisp, has_er, cur.e_ensd);
     if (!LEAN && p.depth_out) {
       const int q = r - 1;
@@ -903,7 +1005,7 @@ MAL_DEV void march_body() {
     w1 = w0;
     if (GRAD) pi1 = pi0;
     dv_2 = dv_1; dv_1 = dv_;
-    tick(7);  // rolls
+    tick(7); MAL_MARK(7);  // rolls
   }
   // ---- one-row halo: nothing is left to warp, two gradient rows are -- the segment's last own row (its window row below
   // belongs to the neighbour: zero here) and the neighbour's first row (this task's last statistics row is its window row
@@ -1050,7 +1152,7 @@ __global__ __launch_bounds__(192, 3) void march3_kernel(MarchParams p) {
       f2 P[12];
       float ik[9];
       load_cam(cam_b, P, ik);
-      warp_issue<true, true, DBG>(wc, P, ik, b, prow(row_of(r)), gxr, dispv, pw, [&]() { disp_nxt = ldf(disp_b, moff(row_of(r + 1))); });
+      warp_issue<true, true, DBG, false>(wc, P, ik, b, prow(row_of(r)), gxr, dispv, pw, [&]() { disp_nxt = ldf(disp_b, moff(row_of(r + 1))); });
     };
     auto astep = [&](int t, PendingWarp& fin, PendingWarp& iss) __attribute__((always_inline)) {
       const int r = t + 1;
@@ -1577,7 +1679,7 @@ int g_march_rows = 0;  // output rows per wave task; 0 = pick so that one round 
 int g_pack_rows = 10;  // rows per task of the identity / packing sweep: 20 segments x 11 strips x 12 samples = 2640 tasks <= 3072 (three waves per SIMD); same-box steps, round 3: 10: 0.2010 / 0.3270 ms (--distil / headline), 9: 0.2019 / 0.3290, 11: 0.2043 / 0.3291, 12: 0.329 (headline)
 int g_march_rows_fwd = 0;  // the same for the forward-only passes (<= 168 VGPRs: three waves per SIMD); 0 = automatic
 int g_debug = 0;
-thread_local unsigned* g_dec_next = nullptr;  // mal_decisions_next_pass (armed and consumed on the calling thread): decision planes for the next instrumentable gradient pass
+std::atomic<unsigned*> g_dec_next{nullptr};  // mal_decisions_next_pass (one-shot, taken with an atomic exchange): decision planes for the next instrumentable gradient pass
 extern int g_photo_impl;  // mal_photo_march.hip
 extern int g_epi_bwd_planes;  // mal_epipolar.hip
 extern int g_epi_probe;       // mal_epipolar.hip
@@ -1653,16 +1755,17 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   // mal_profile_next_pass times the next TEACHER gradient sweep (GRAD + AUTOMASK + POSE, no epilogue: the north-star
   // kernel, with or without the temporal hint), not whichever marching launch happens to come first
   const bool named = grad && pose && automask && !epi;
-  hipEvent_t ev0 = named ? g_prof_start : nullptr, ev1 = named ? g_prof_stop : nullptr;
-  if (named) g_prof_start = g_prof_stop = nullptr;
+  hipEvent_t ev0 = named ? g_prof_start.exchange(nullptr) : nullptr, ev1 = named ? g_prof_stop.exchange(nullptr) : nullptr;
   if (ev0) (void)hipEventRecord(ev0, st);
   // the specialisation without the optional operands (march_body LEAN)
-  const bool lean0 = g_march_lean && p.packed == 3 && !p.depth_out && p.debug == 0 && !p.dbg;
+  const bool lean0 = g_march_lean && p.packed == 3 && !p.depth_out && p.debug == 0 && !p.dbg &&
+                     (long long)p.H * p.W * (kTexel * 4) < (1ll << 24);  // tap byte offsets are formed in fp32 there
   const bool no_maps = !p.ext_mask && !p.lowest_cost && !p.sample_scale;
-  const bool lean = lean0 && no_maps && !p.disp2;                                             // SPEC 1
-  const bool lean_student = lean0 && !p.disp2 && p.ext_mask && p.lowest_cost && p.mono_disp;          // kSpecStudent
-  const bool lean_student_nc = lean0 && !p.disp2 && p.ext_mask && !p.lowest_cost && p.mono_disp;      // kSpecStudentNoCost
-  const bool lean_refine = lean0 && !p.disp2 && !p.lowest_cost && p.mono_disp && !p.sample_scale;     // kSpecRefine
+  const bool conv_a = p.convention == 0, conv_b = p.convention == 1;
+  const bool lean = lean0 && conv_a && no_maps && !p.disp2;                                                      // kSpecTeacher
+  const bool lean_student = lean0 && conv_a && !p.disp2 && p.ext_mask && p.lowest_cost && p.mono_disp;          // kSpecStudent
+  const bool lean_student_nc = lean0 && conv_a && !p.disp2 && p.ext_mask && !p.lowest_cost && p.mono_disp;      // kSpecStudentNoCost
+  const bool lean_refine = lean0 && conv_b && !p.disp2 && !p.lowest_cost && p.mono_disp && !p.sample_scale;     // kSpecRefine
 #define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((march_kernel<G, A, P, E>), grid, block, 0, st, p)
 #ifdef MAL_EXPERIMENTS
   if (grad && p.color_out[0]) {  // the teacher's pass of the --temporal step in front of the producer
@@ -1866,10 +1969,8 @@ extern "C" int mal_pass_fused(const float* disp, const float* disp2, const float
   p.cons_target = consistency_target; p.depth_out = depth_out; p.block_sums = w.block_sums; p.block_gP = w.block_gP;
   p.cam = w.cam;
   hipStream_t st = (hipStream_t)stream;
-  if (g_dec_next && grad && ((pose && automask && !epi) || (!pose && !automask && epi))) {
-    p.dbg = g_dec_next;  // one-shot (tests): the instrumented instantiation of the same kernel
-    g_dec_next = nullptr;
-  }
+  if (grad && ((pose && automask && !epi) || (!pose && !automask && epi)))
+    p.dbg = g_dec_next.exchange(nullptr);  // one-shot (tests): the instrumented instantiation of the same kernel
   // the gradient passes take the one-row halo here too: the scratch rows are folded into g_reproj by the finalize launch
   if (grad && g_march_halo1) p.bnd = w.bnd;
   rc = march_launch(p, flags, st);

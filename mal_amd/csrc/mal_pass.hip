@@ -28,11 +28,12 @@
 // border neighbours count twice) and chains through the bilinear taps, the perspective
 // divide, the pose and the depth.
 #include "mal_common.h"
+#include <atomic>
 #include "mal_device.h"
 
 namespace mal {
 
-extern thread_local hipEvent_t g_prof_start, g_prof_stop;  // mal_api.hip: one-shot timing hooks
+extern std::atomic<hipEvent_t> g_prof_start, g_prof_stop;  // mal_api.hip: one-shot timing hooks
 
 #ifdef MAL_EXPERIMENTS  // the LDS-tiled first formulation (option "pass_impl" 0): not in the default build
 constexpr int RW = kTW + 4, RH = kTH + 4, RN = RW * RH;  // 68 x 20 = 1360
@@ -534,8 +535,7 @@ extern "C" int mal_pass_fused_tiled(const float* disp, const float* disp2, const
   p.per_xcd = (p.nblocks + 7) / 8;
   dim3 grid(p.per_xcd * 8), block(kThreads);
   hipStream_t st = (hipStream_t)stream;
-  hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
-  g_prof_start = g_prof_stop = nullptr;
+  hipEvent_t ev0 = g_prof_start.exchange(nullptr), ev1 = g_prof_stop.exchange(nullptr);
   if (ev0) (void)hipEventRecord(ev0, st);
 #define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((pass_kernel<G, A, P, E>), grid, block, 0, st, p)
   if (!grad) {

@@ -483,6 +483,12 @@ static SideStream* side_stream(hipStream_t caller) {
       if (all[i].caller == caller) slot = &all[i];
     }
   }
+  // never create a stream or an event while the caller's stream is being captured: share the device's first slot then
+  // (it exists after the eager warm-up steps that precede every capture)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (!slot && first_of_dev && hipStreamIsCapturing(caller, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    slot = first_of_dev;
+  (void)hipGetLastError();
   for (int i = 0; i < kSlots && !slot; ++i)
     if (!all[i].init) {
       slot = &all[i];

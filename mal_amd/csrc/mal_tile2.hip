@@ -15,11 +15,12 @@
 // Window sums keep ATen's row-major order (layers.py:243-257 via AvgPool2d).
 #ifdef MAL_EXPERIMENTS  // the 512-thread LDS-tiled formulation (option "pass_impl" 2): not in the default build
 #include "mal_common.h"
+#include <atomic>
 #include "mal_device.h"
 
 namespace mal {
 
-extern thread_local hipEvent_t g_prof_start, g_prof_stop;
+extern std::atomic<hipEvent_t> g_prof_start, g_prof_stop;
 
 namespace t2 {
 
@@ -495,8 +496,7 @@ extern "C" int mal_pass_fused_tile2(const float* disp, const float* disp2, const
   constexpr int NT = 512;
   dim3 grid(p.per_xcd * 8), block(NT);
   hipStream_t st = (hipStream_t)stream;
-  hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
-  g_prof_start = g_prof_stop = nullptr;
+  hipEvent_t ev0 = g_prof_start.exchange(nullptr), ev1 = g_prof_stop.exchange(nullptr);
   if (ev0) (void)hipEventRecord(ev0, st);
 #define MAL_LAUNCH(G, A, P, E) hipLaunchKernelGGL((t2::tile2_kernel<NT, G, A, P, E>), grid, block, 0, st, p)
   if (!grad) {

@@ -93,8 +93,10 @@ def check_decisions_are_near_ties(diff, o, b, n0, N):
         "win_t": _gap2(o["mono_cands"]) <= 1e-4, "win_s": _gap2(o["multi_cands"]) <= 1e-4,
         "automask": np.abs(o["mono_reproj"] - idn) <= 1e-4, "distil": _gap2(trio) <= 1e-4,
         "tap_t": _frac_dist(o["mono_sample"], H, W) <= 1e-3, "tap_s": _frac_dist(o["multi_sample"], H, W) <= 1e-3,
-        "l1_t": l1_gap(o["mono_preds"], o["mono_cands"]) <= 1e-5,
-        "l1_s": l1_gap([o["multi_color"][-1], o["multi_color"][1]], o["multi_cands"]) <= 1e-5,
+        # the warped value moves by (slope of the source image) x (rounding of the sampling position: an ulp of a coordinate
+        # near 600 is 6e-5 px): |pred - target| below 1e-4 -- the bound the other near-ties use -- is a tie of the sign
+        "l1_t": l1_gap(o["mono_preds"], o["mono_cands"]) <= 1e-4,
+        "l1_s": l1_gap([o["multi_color"][-1], o["multi_color"][1]], o["multi_cands"]) <= 1e-4,
         "cmask": ratio <= 1e-5,
         "smooth_t": HH.smooth_sign_ambiguous(b["disp_teacher"].numpy()), "smooth_s": HH.smooth_sign_ambiguous(b["disp_student"].numpy()),
     }
