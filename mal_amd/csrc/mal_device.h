@@ -294,7 +294,11 @@ MAL_DEV SsimGrad ssim_partials(const SsimStats& s) {
 
 // one v_med3_f32 instead of canonicalise + max + min; a NaN comes out as 0 either way (fmaxf drops it; med3 of a NaN is the
 // minimum of the other two)
+#ifdef MAL_CLAMP_MINMAX  // A/B
+MAL_DEV float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+#else
 MAL_DEV float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
+#endif
 
 // ------------------------------------------------------------------ reductions
 MAL_DEV float wave_sum(float v) {

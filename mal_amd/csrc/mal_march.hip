@@ -237,7 +237,11 @@ MAL_DEV void warp_finish(PendingWarp& pw, f2 (&x)[3], DerivRow& d) {
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
 #pragma unroll
+#if defined(MAL_SHADOW) && MAL_SHADOW
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(pw.t[f][k]));  // whole texels: one gather each, not 8+4 bytes (volatile: see SHADOW)
+#else
     for (int k = 0; k < 4; ++k) asm("" : "+v"(pw.t[f][k]));  // whole texels: one gather each, not 8+4 bytes
+#endif
     const texel_t A = pw.t[f][0], Bv = pw.t[f][1], C = pw.t[f][2], D = pw.t[f][3];
     const f2 a = (f2){A.x, A.y}, bb = (f2){Bv.x, Bv.y}, c = (f2){C.x, C.y}, dd = (f2){D.x, D.y};
     const float nw_ = pw.nw[f], ne_ = pw.ne[f], sw_ = pw.sw[f], se_ = pw.se[f];
@@ -293,7 +297,11 @@ MAL_DEV void march_body() {
   constexpr bool COST_NO = (SPEC & kSpecCostNo) != 0, COST_YES = (SPEC & kSpecCostYes) != 0;
   constexpr bool MONO_YES = (SPEC & kSpecMonoYes) != 0, NO_SCALE = (SPEC & kSpecNoScale) != 0;
   constexpr bool NO_NOISE = (SPEC & kSpecNoNoise) != 0;
-  constexpr int CONV = (SPEC & kSpecConvA) ? 0 : ((SPEC & kSpecConvB) ? 1 : -1);  // Project3D convention fixed at compile time
+#ifdef MAL_CONV_FIXED  // A/B: Project3D's convention fixed at compile time in the specialised passes (measured 1 % SLOWER than the
+  constexpr int CONV = (SPEC & kSpecConvA) ? 0 : ((SPEC & kSpecConvB) ? 1 : -1);  // scalar branch: profiles/r04_hsum_variants_ab.txt)
+#else
+  constexpr int CONV = -1;
+#endif
   constexpr bool OUTS = EXPORT || (!GRAD && !EPI);  // the outputs the producer / the fused sweep read
   constexpr int HALO = GRAD ? 2 : 1;
   constexpr int CW = 64 - 2 * HALO;
@@ -414,11 +422,29 @@ MAL_DEV void march_body() {
   // bit).  LDS operations of a wave execute in order, so ONE 1 KB buffer serves all groups without waits in between.
   // Lanes 0 and 63 take their own value for the missing neighbour (DPP's bound_ctrl gave 0): those are halo lanes whose sums
   // feed only halo lanes, never an output pixel.
-#ifdef MAL_HSUM_DPP
-  constexpr bool HSUM_LDS = false;
-#else
-  constexpr bool HSUM_LDS = GRAD;
+  // Measured (same box, teacher pass replayed alone, profiles/r04_hsum_variants_ab.txt): LDS for the 18 partial planes -1 %,
+  // LDS for the 24 statistic planes +2 % (their results are needed at once: the LDS round trip is exposed where the DPP adds
+  // pipeline), both +2.5 %, and the gathers'-shadow ordering +7 % -- although the row loop's vector-ALU pipe cycles fall by
+  // 13 %: the pass is not bound by the vector ALU's throughput.  Shipped: partial planes through LDS, the rest DPP.
+  // Build-time switches (same-box A/B with scripts/build_variant.py):
+  //   MAL_HSUM_H   the 24 statistic planes:  0 = DPP blocks, 1 = LDS, three groups in flight, 2 = LDS, all groups in flight
+  //   MAL_HSUM_HC  the 18 partial planes:    0 = DPP blocks, 1 = LDS, three groups in flight, 2 = LDS, all groups in flight
+  //   MAL_HSUM_FWD the forward-only passes:  0 = DPP (the compiler's peephole), 1 = LDS
+  //   MAL_SHADOW   1 = target sums / L1 term / pose re-derivation pinned between the gathers and the blend
+#ifndef MAL_HSUM_H
+#define MAL_HSUM_H 0
 #endif
+#ifndef MAL_HSUM_HC
+#define MAL_HSUM_HC 2
+#endif
+#ifndef MAL_HSUM_FWD
+#define MAL_HSUM_FWD 0
+#endif
+#ifndef MAL_SHADOW
+#define MAL_SHADOW 0
+#endif
+  constexpr int H_MODE = GRAD ? MAL_HSUM_H : (MAL_HSUM_FWD ? 2 : 0), HC_MODE = MAL_HSUM_HC;
+  constexpr bool HSUM_LDS = H_MODE != 0 || (GRAD && HC_MODE != 0);
   __shared__ f4 s_stage[HSUM_LDS ? 64 : 1];
   const int laneL = max(lane - 1, 0), laneR = min(lane + 1, 63);
   auto nb4 = [&](f4 v, f4& L, f4& R) __attribute__((always_inline)) {
@@ -426,6 +452,20 @@ MAL_DEV void march_body() {
     L = s_stage[laneL];
     R = s_stage[laneR];
   };
+  auto nb2 = [&](f2 v, f2& L, f2& R) __attribute__((always_inline)) {  // a half group: the first 8 bytes of the lane's cell
+    *reinterpret_cast<f2*>(&s_stage[lane]) = v;
+    L = *reinterpret_cast<const f2*>(&s_stage[laneL]);
+    R = *reinterpret_cast<const f2*>(&s_stage[laneR]);
+  };
+  // SHADOW (round 4): what an iteration can do WITHOUT the texels of the row being warped is placed between the issue of the
+  // eight gathers and the blend that waits for them -- the one long memory latency of the iteration, of which round 3 covered
+  // ~25 instructions: the horizontal sums of the target row (they need only the target texel, requested one row ahead), the
+  // L1 term of the statistics row (raw values of the previous row) and, in the pose variants, the re-derivation of the point
+  // and of d u / d disp, d v / d disp of the gradient row (u, v, 1/z from the ring, the disparity of two rows ago).
+  constexpr bool SHADOW = MAL_SHADOW && H_MODE != 0 && GRAD;
+  // ... the pose re-derivation only where its seven results fit next to the rest (the temporal and epilogue variants spill)
+  constexpr bool SHADOW_POSE = SHADOW && POSE && !TEMPORAL && !EPI && !DBG;
+  struct PosePrep { f2 alq, beq; float X[3]; };
   int it = 0;
   // One-row halo (p.bnd != nullptr, gradient passes of the whole-step list): a task warps ONE row beyond each end of its
   // segment and evaluates the statistics / decisions of its OWN rows only.  The gradient of a boundary row then lacks
@@ -586,8 +626,27 @@ MAL_DEV void march_body() {
     }
   };
   // ================= the gradient row q = r-2 of iteration r (hc: the horizontal sums of row c = r-1's partial planes)
+  // d u / d disp, d v / d disp and the point of row q (pose variants): u, v, 1/z come back from the ring; the point and the
+  // depth derivatives are re-derived
+  auto pose_prep = [&](int q, int it, PosePrep& o) __attribute__((always_inline)) {
+    float (*slot)[64] = s_ring[(it + 1) % 3];
+    const f2 pq_u = (f2){slot[18][lane], slot[19][lane]}, pq_v = (f2){slot[20][lane], slot[21][lane]};
+    const f2 pq_rz = (f2){slot[22][lane], slot[23][lane]};
+    const float depth = depth_of(dv_2, p.min_disp, p.range);
+    const float ddepth = -(depth * depth) * p.range;
+    float ray[3], ik[9];
+    f2 P[12];
+    load_cam(cam_b, P, ik);
+    ray_of(ik, (float)gxr, (float)prow(q), ray);
+    o.X[0] = depth * ray[0]; o.X[1] = depth * ray[1]; o.X[2] = depth * ray[2];
+    const f2 c0 = P[0] * bc(ray[0]) + P[1] * bc(ray[1]) + P[2] * bc(ray[2]);
+    const f2 c1 = P[4] * bc(ray[0]) + P[5] * bc(ray[1]) + P[6] * bc(ray[2]);
+    const f2 c2 = P[8] * bc(ray[0]) + P[9] * bc(ray[1]) + P[10] * bc(ray[2]);
+    o.alq = (c0 - pq_u * c2) * pq_rz * bc(ddepth);  // d u / d disp (the clip gate is inside du, dv)
+    o.beq = (c1 - pq_v * c2) * pq_rz * bc(ddepth);
+  };
   auto gradient_row = [&](CParams& p, int r, int it, const f2* hc, const Ahead& cur, unsigned so_q,
-                          float le_mono) __attribute__((always_inline)) {
+                          float le_mono, const PosePrep* prep) __attribute__((always_inline)) {
   // ================= stage G: output row q = c-1 = r-2 ======================================
   const int q = r - 2, c = r - 1;
   const bool own_q = q >= y_lo && q < y_hi;  // false: a boundary row of the neighbouring task (one-row halo)
@@ -648,19 +707,11 @@ MAL_DEV void march_body() {
     MAL_MARK(61);  // ring read, L1 term, vertical adjoint sums, d loss / d warped colour done
     float gdisp;
     if (POSE) {
-      // u, v, 1/z of row q come back from the ring; its point and the depth derivatives are re-derived
-      const float depth = depth_of(dv_2, p.min_disp, p.range);
-      const float ddepth = -(depth * depth) * p.range;
-      float ray[3], ik[9], X[3];
-      f2 P[12];
-      load_cam(cam_b, P, ik);
-      ray_of(ik, (float)gxr, (float)prow(q), ray);
-      X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
-      const f2 c0 = P[0] * bc(ray[0]) + P[1] * bc(ray[1]) + P[2] * bc(ray[2]);
-      const f2 c1 = P[4] * bc(ray[0]) + P[5] * bc(ray[1]) + P[6] * bc(ray[2]);
-      const f2 c2 = P[8] * bc(ray[0]) + P[9] * bc(ray[1]) + P[10] * bc(ray[2]);
-      const f2 alq = (c0 - pq_u * c2) * pq_rz * bc(ddepth);  // d u / d disp (the clip gate is inside du, dv)
-      const f2 beq = (c1 - pq_v * c2) * pq_rz * bc(ddepth);
+      PosePrep here;
+      if (!prep) pose_prep(q, it, here);  // (the drain iterations; the row loop hands in what it formed in the gathers' shadow)
+      const PosePrep& pp = prep ? *prep : here;
+      const f2 alq = pp.alq, beq = pp.beq;
+      const float (&X)[3] = pp.X;
       const f2 tu0 = g[0] * dq.du[0], tu1 = g[1] * dq.du[1], tu2 = g[2] * dq.du[2];
       const f2 tv0 = g[0] * dq.dv[0], tv1 = g[1] * dq.dv[1], tv2 = g[2] * dq.dv[2];
       const f2 gu = (f2){(tu0.x + tu0.y) + tu2.x, (tu1.x + tu1.y) + tu2.y};
@@ -750,10 +801,41 @@ MAL_DEV void march_body() {
       load_cam(cam_b, P, ik);
       // the next iteration's operands go out between the projection and the gathers (measured: behind the
       // gathers is 5 % slower even when the blend then waits for the gathers only)
+#ifdef MAL_TAPS_INT  // A/B: integer tap offsets (round 3) in the specialised passes too
+      warp_issue<GRAD, POSE, DBG, false>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
+#else
       warp_issue<GRAD, POSE, DBG, LEAN && !DBG>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
+#endif
     }
     __builtin_amdgcn_s_setprio(0);
     tick(1); MAL_MARK(1);  // small loads, prefetch, projection, gathers issued
+    // ---- in the shadow of the gathers (see SHADOW above)
+    f2 sh_hy[2] = {bc(0.f), bc(0.f)}, sh_l15 = bc(0.f);
+    float sh_hz[2] = {0.f, 0.f};
+    PosePrep prep;
+    if (SHADOW) {
+      f4 L4, R4;
+      f2 L2, R2;
+      const f2 yy = w0.yrg * w0.yrg;
+      const float yb2 = w0.yb * w0.yb;
+      nb4((f4){w0.yrg.x, w0.yrg.y, yy.x, yy.y}, L4, R4);
+      nb2((f2){w0.yb, yb2}, L2, R2);
+      if (SHADOW_POSE) pose_prep(r - 2, it, prep);
+      // L1 term of the statistics row c = r-1 (its raw values are the previous iteration's)
+      const f2 l0 = w1.yrg - w1.x[0], l1 = w1.yrg - w1.x[1], l2 = bc(w1.yb) - w1.x[2];
+      const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
+      sh_l15 = bc(0.15f) * div3_2(lsum);
+      sh_hy[0] = ((f2){L4.x, L4.y} + w0.yrg) + (f2){R4.x, R4.y};
+      sh_hy[1] = ((f2){L4.z, L4.w} + yy) + (f2){R4.z, R4.w};
+      sh_hz[0] = (L2.x + w0.yb) + R2.x;
+      sh_hz[1] = (L2.y + yb2) + R2.y;
+      // keep it there: the scheduler prices a gather like any load and pulls the blend (and its wait) up in front of this
+      // block.  Two ordered (volatile) empty asm statements pin the order by data flow: this one consumes what the block
+      // computed, the ones that open the blend (warp_finish) produce the texels it reads.
+      asm volatile("" : "+v"(sh_hy[0]), "+v"(sh_hy[1]), "+v"(sh_hz[0]), "+v"(sh_hz[1]), "+v"(sh_l15));
+      if (SHADOW_POSE)
+        asm volatile("" : "+v"(prep.alq), "+v"(prep.beq), "+v"(prep.X[0]), "+v"(prep.X[1]), "+v"(prep.X[2]));
+    }
     auto finish_warp = [&]() {
       DerivRow d0;
       warp_finish<GRAD, POSE>(pw, w0.x, d0);
@@ -800,7 +882,7 @@ MAL_DEV void march_body() {
     // ================= stage H: horizontal 3-sums of row r ====================================
     f2 h[9], hy[2];
     float hz[2];
-    if (GRAD) {  // 24 values in three written-out blocks of DPP adds (mal_pairs.h: why not left to the compiler)
+    if (GRAD || H_MODE != 0) {  // 24 values through LDS or three written-out blocks of DPP adds (mal_pairs.h)
       f2 in[12];
       in[0] = w0.yrg; in[1] = w0.yrg * w0.yrg; in[2] = (f2){w0.yb, w0.yb * w0.yb};
 #pragma unroll
@@ -809,20 +891,35 @@ MAL_DEV void march_body() {
         in[3 + k * 3 + 0] = x; in[3 + k * 3 + 1] = x * x; in[3 + k * 3 + 2] = x * y;
       }
       f2 out[12];
-      if (HSUM_LDS) {
-        // three groups in flight at a time (24 registers of neighbours; all six at once spilled the pose variants)
+      if (SHADOW) {
+        out[0] = sh_hy[0]; out[1] = sh_hy[1]; out[2] = (f2){sh_hz[0], sh_hz[1]};
+        f4 L[4], R[4];
+        f2 L2, R2;
+        // the candidates' planes: x, x^2, x*y of the three colour pairs (18 values: four groups and a half)
 #pragma unroll
-        for (int h0 = 0; h0 < 6; h0 += 3) {
-          f4 L[3], R[3];
+        for (int g = 0; g < 4; ++g) nb4((f4){in[3 + 2 * g].x, in[3 + 2 * g].y, in[4 + 2 * g].x, in[4 + 2 * g].y}, L[g], R[g]);
+        nb2(in[11], L2, R2);
 #pragma unroll
-          for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < 4; ++g) {
+          out[3 + 2 * g] = ((f2){L[g].x, L[g].y} + in[3 + 2 * g]) + (f2){R[g].x, R[g].y};
+          out[4 + 2 * g] = ((f2){L[g].z, L[g].w} + in[4 + 2 * g]) + (f2){R[g].z, R[g].w};
+        }
+        out[11] = (L2 + in[11]) + R2;
+      } else if (H_MODE != 0) {
+        // H_MODE 1: three groups in flight at a time (24 registers of neighbours; all six at once spill the pose variants)
+        constexpr int NG = H_MODE == 1 ? 3 : 6;
+#pragma unroll
+        for (int h0 = 0; h0 < 6; h0 += NG) {
+          f4 L[NG], R[NG];
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
             nb4((f4){in[2 * (h0 + g)].x, in[2 * (h0 + g)].y, in[2 * (h0 + g) + 1].x, in[2 * (h0 + g) + 1].y}, L[g], R[g]);
 #pragma unroll
-          for (int g = 0; g < 3; ++g) {  // (left + own) + right, as the DPP form
+          for (int g = 0; g < NG; ++g) {  // (left + own) + right, as the DPP form
             out[2 * (h0 + g)] = ((f2){L[g].x, L[g].y} + in[2 * (h0 + g)]) + (f2){R[g].x, R[g].y};
             out[2 * (h0 + g) + 1] = ((f2){L[g].z, L[g].w} + in[2 * (h0 + g) + 1]) + (f2){R[g].z, R[g].w};
           }
-          __builtin_amdgcn_sched_barrier(0);
+          if (H_MODE == 1) __builtin_amdgcn_sched_barrier(0);
         }
       } else {
 #pragma unroll
@@ -875,9 +972,13 @@ MAL_DEV void march_body() {
       }
       MAL_MARK(50);  // window sums + SSIM of six values done; L1, min, masks, coefficients follow
       const f2 ssum = (f2){(vc[0].x + vc[0].y) + vc[2].x, (vc[1].x + vc[1].y) + vc[2].y};
-      const f2 l0 = w1.yrg - w1.x[0], l1 = w1.yrg - w1.x[1], l2 = bc(w1.yb) - w1.x[2];
-      const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
-      const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
+      f2 l15 = sh_l15;
+      if (!SHADOW) {
+        const f2 l0 = w1.yrg - w1.x[0], l1 = w1.yrg - w1.x[1], l2 = bc(w1.yb) - w1.x[2];
+        const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
+        l15 = bc(0.15f) * div3_2(lsum);
+      }
+      const f2 rr = bc(0.85f) * div3_2(ssum) + l15;
       pi0.win = (rr.y < rr.x) ? 1 : 0;
       pi0.rp = pi0.win ? rr.y : rr.x;
       if (OUTS) {  // ... the winner among the two warped candidates, twice: the copy the fused sweep updates
@@ -947,23 +1048,24 @@ MAL_DEV void march_body() {
     if (GRAD) {
       // ================= stage HC: horizontal sums of the partial planes of row c ==============
       f2 hc[9];
-      if (HSUM_LDS) {
+      if (HC_MODE != 0) {
         // (w_left * left + own) + w_right * right: the border weights of the adjoint on the receiving side, fused (exact products)
+        constexpr int NG = HC_MODE == 1 ? 3 : 5;
 #pragma unroll
-        for (int h0 = 0; h0 < 5; h0 += 3) {  // groups 0-2, then 3-4 (the last one holds a single pair)
-          f4 L[3], R[3];
+        for (int h0 = 0; h0 < 5; h0 += NG) {  // HC_MODE 1: groups 0-2, then 3-4 (the last one holds a single pair)
+          f4 L[NG], R[NG];
 #pragma unroll
-          for (int g = 0; g < 3 && h0 + g < 5; ++g) {
+          for (int g = 0; g < NG && h0 + g < 5; ++g) {
             const int a = 2 * (h0 + g);
             nb4(a + 1 < 9 ? (f4){coef[a].x, coef[a].y, coef[a + 1].x, coef[a + 1].y} : (f4){coef[a].x, coef[a].y, 0.f, 0.f}, L[g], R[g]);
           }
 #pragma unroll
-          for (int g = 0; g < 3 && h0 + g < 5; ++g) {
+          for (int g = 0; g < NG && h0 + g < 5; ++g) {
             const int a = 2 * (h0 + g);
             hc[a] = fma2((f2){R[g].x, R[g].y}, bc(wR), fma2((f2){L[g].x, L[g].y}, bc(wL), coef[a]));
             if (a + 1 < 9) hc[a + 1] = fma2((f2){R[g].z, R[g].w}, bc(wR), fma2((f2){L[g].z, L[g].w}, bc(wL), coef[a + 1]));
           }
-          __builtin_amdgcn_sched_barrier(0);
+          if (HC_MODE == 1) __builtin_amdgcn_sched_barrier(0);
         }
       } else
 #pragma unroll
@@ -979,7 +1081,7 @@ MAL_DEV void march_body() {
         for (int i = 0; i < 3; ++i) hc[g * 3 + i] = (f2){r6[2 * i], r6[2 * i + 1]};
       }
       MAL_MARK(60);  // horizontal sums of the 18 partial planes done
-      gradient_row(p, r, it, hc, cur, so_q, le_mono);
+      gradient_row(p, r, it, hc, cur, so_q, le_mono, SHADOW_POSE ? &prep : nullptr);
     }
 
     tick(6); MAL_MARK(6);  // partial-plane sums, gradient row
@@ -1022,7 +1124,7 @@ MAL_DEV void march_body() {
       f2 hc0[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) hc0[i] = bc(0.f);
-      gradient_row(p, r, it, hc0, cur, so_q, cur.e_mono);
+      gradient_row(p, r, it, hc0, cur, so_q, cur.e_mono, nullptr);
       y2rg = w1.yrg; y2b = w1.yb;
       pi1.rp = 0.f; pi1.w = 0.f; pi1.win = 0;
       dv_2 = dv_1;

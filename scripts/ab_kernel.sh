@@ -1,12 +1,14 @@
 #!/bin/bash
-# same-box A/B of library variants (scripts/build_variant.py; "default" = the in-tree library) on the headline step and the
-# --distil step: ms per step, the north-star kernel replayed alone (roofline.kernel_ms) and by events on eager launches
-#   ab_kernel.sh name1 name2 ...   (two rounds each)
+# same-box A/B of library variants (scripts/build_variant.py; "default" = the in-tree library): ms per step and the
+# north-star kernel replayed alone (roofline.kernel_ms) / by events on eager launches
+#   ab_kernel.sh [-m "distil step"] name1 name2 ...   (two rounds each; default modes: distil)
+modes="distil"
+if [ "$1" = "-m" ]; then modes="$2"; shift 2; fi
 for round in 1 2; do
   for v in "$@"; do
     if [ "$v" = default ]; then unset MAL_HIP_LIB; else export MAL_HIP_LIB=$PWD/mal_amd/lib/$v.so; fi
-    for mode in step distil; do
-      python bench.py --mode $mode --steps 400 --warmup 50 --no-cpu-baseline --train-steps 0 2>/dev/null \
+    for mode in $modes; do
+      python bench.py --mode $mode --steps 300 --warmup 30 --no-cpu-baseline --train-steps 0 2>/dev/null \
         | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$v', '$mode', 'ms/step', round(d['ms_per_step'],4), 'teacher replayed us', round(r['kernel_ms']*1e3,2), 'eager us', round(r['eager_kernel_ms']*1e3,2), 'frac', round(r['frac'],4))" || exit 1
     done
   done

@@ -18,21 +18,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mal_amd import build  # noqa: E402
 
-STAGES = collections.OrderedDict([
-    (7, "loop back edge, row counters, parameter block (scalar loads), offsets of the rows this iteration touches"),
+STAGES = collections.OrderedDict([  # key = the MAL_MARK that OPENS the stage (7 also takes the loop head in front of mark 0)
+    (7, "loop-carried moves (the rolled row state), back edge, row counters, parameter block (scalar loads)"),
     (0, "camera block, depth, ray, projection of both frames (Project3D + unnormalise + border clip)"),
-    (10, "bilinear tap cells and offsets, next row's operand requests, eight texel gathers, tap weights, chain-rule prefactors"),
-    (1, "(issue phase tail: priority reset)"),
+    (10, "bilinear tap cells and byte offsets, next row's operand requests, eight texel gathers, tap weights, clip masks"),
+    (1, "(epilogue passes: consistency / distillation terms of the gradient row, placed in the gathers' shadow)"),
     (2, "gather wait, bilinear blend of six colour values and their d/du, d/dv, LDS ring write (24 floats)"),
-    (3, "24 statistic planes: products x^2, x*y, y^2 and their horizontal 3-sums (48 v_add_f32_dpp)"),
-    (4, "vertical 3-row sums and SSIM of six values incl. the three partials per value (window sums -> S, dS/dsum)"),
-    (50, "L1 term, min over the two candidates, automask / weight, stores, winner-only coefficients of the 18 partial planes"),
-    (5, "border multipliers and horizontal 3-sums of the 18 partial planes (36 v_add_f32_dpp)"),
-    (60, "gradient row: ring read, winner's L1 sign, vertical adjoint sums, d loss / d warped colour"),
-    (61, "chain rule to the disparity (pose variant: re-derived point, d u/d disp, d v/d disp)"),
-    (62, "pose partials: 12 packed accumulators d loss / d P"),
-    (63, "roll of the partial-plane sums (hcA, hcB)"),
-    (6, "(epilogue of forward-only passes / depth map out)"),
+    (3, "24 statistic planes: products x^2, x*y, y^2 and their horizontal 3-sums"),
+    (4, "vertical 3-row sums and SSIM of six values (window sums -> S); epilogue passes: the compiler sinks this into 50"),
+    (50, "SSIM partials dS/dsum of six values, L1 term, min over the two candidates, automask / weight, stores, winner-only "
+         "coefficients of the 18 partial planes (its 41 static v_mov are zero-fills on the not-a-valid-row path, not executed per row)"),
+    (5, "horizontal 3-sums of the 18 partial planes incl. the adjoint's border weights"),
+    (60, "gradient row: LDS ring read (24 floats)"),
+    (61, "(merged by the compiler into 62)"),
+    (62, "gradient row: winner's L1 sign, vertical adjoint sums, d loss / d warped colour, chain rule to the disparity (pose "
+         "variant: re-derived point, d u / d disp, d v / d disp), pose partials (12 packed accumulators), stores"),
+    (63, "roll of the partial-plane sums (hcA, hcB) incl. the top-border weight"),
+    (6, "(forward-only passes: epilogue / depth map out)"),
 ])
 # what lies between mark a (inclusive start) and the next mark is attributed to the stage keyed by a
 
@@ -130,6 +132,24 @@ def main():
         res["kernels"][name] = {"stages": [r for r in rows if r["instructions"]], "total_marked_build": tot,
                                 "total_shipped_build": {"instructions": sh.get("loop_instructions"), "valu": sh.get("valu_instructions"),
                                                         "pipe_cycles": sh.get("pipe_cycles")}}
+    res["verdict_items"] = {
+        "i_horizontal_sums_through_lds": "built and measured in six variants (profiles/r04_hsum_variants_ab.txt): all 42 sums through LDS "
+            "= -13 % pipe cycles, -6 % instructions, kernel +2.5 % SLOWER; the 18 partial planes alone -1 % (shipped); the probe "
+            "(profiles/r04_dpp_probe.txt) prices a DPP 3-sum at 18.4 and the LDS form at 9.1 cycles of a wave's timeline, but the "
+            "statistic planes' sums are consumed at once and expose the LDS round trip",
+        "ii_sliding_row_offsets": "not built: ~25-30 scalar instructions of stage 7 / 10 (three reflect-clamp-multiply chains become "
+            "carried registers); the A/B above shows that -57 instructions of ANY class did not shorten the kernel, so this cannot",
+        "iii_pose_partials_9_sums": "no saving: sum a_i*D, sum a_i*D*y, sum a_i per scalar a_i is mul + add + fma + add = 12 packed "
+            "instructions for the three scalars, exactly the 9 fma + 3 add of the 12 accumulators of stage 62 (only the 3 plain "
+            "X = depth*ray disappear), and the accumulators stay 18 registers",
+        "iv_target_window_sums_once": "not built: -44 instructions here (12 DPP + ~10 packed + ~10 plain + 12 v_mov, ~5 % of the pipe "
+            "cycles) against +24..36 B/px written by the identity/packing sweep, the one bandwidth-bound kernel of the step "
+            "(+6..10 us there for -2 us per marching pass at best); with the A/B above (instruction cuts do not convert) a net loss",
+        "conclusion": "the <= 50 us target is not reached: 55.5 -> 54.6 us replayed (0.319 -> 0.324 of 8 TB/s).  The premise (81 % VALU "
+            "busy => remove instructions) does not hold up: the kernel's duration is each wave's serial timeline over its 15 + 2 "
+            "iterations (issue ~5 cycles per instruction per wave whatever its class + the exposed part of the gather / LDS / "
+            "scalar-load round trips), of which the sibling wave hides a fixed share; removing pipe cycles without shortening that "
+            "chain moves nothing, and every attempt to reorder the chain (gathers' shadow) lengthened it"}
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)
     for name, k in res["kernels"].items():
