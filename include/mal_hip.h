@@ -255,6 +255,9 @@ enum {
   MAL_STEP_NOISE_PHILOX = 4, /* the automask tie-break noise (loss_utils.py:105-106: + 1e-5 * randn) is drawn inside the
                                step's first kernel: N(0,1) by Box-Muller from Philox4x32-10 keyed by noise_seed, counter =
                                (pixel, step); `noise` must be NULL.  No host RNG, no device RNG launch on the step. */
+  MAL_STEP_DUAL_DISTIL = 32, /* --dual_distil (loss_utils.py:231-234; only with MAL_STEP_NO_ENS, as upstream: the flag is read on the
+                               two-way branch only): where the teacher wins the distillation argmin its depth is NOT detached --
+                               g_disp_teacher also receives w_distil/N * sign(mono - multi) * (1 - consistency weight) * d mono / d disp */
   MAL_STEP_SYN_SPARSE = 16  /* with MAL_STEP_TEMPORAL and syn_region: syn_* hold the synthesised images ONLY at pixels whose
                                region byte has bit 0 set (a producer that writes its regions into otherwise untouched
                                buffers); elsewhere they are by definition the warped images mal_loss_step_warp wrote
@@ -575,6 +578,9 @@ int mal_direct_align_update_bwd(const float* H, const float* b, const float* pos
  * "step_overlap" 1 (default): with MAL_STEP_TEMPORAL the ensemble pass runs on a side stream beside the producer (forked
  *               after the warp pass, joined before the student pass; events, capturable); 0: in line; 2: beside the
  *               fused sweep (slower: kept for A/B);  "syn_rows": rows per task of the fused sweep given a region map;
+ * "student_overlap" 1 (default): with MAL_STEP_TEMPORAL the student's marching pass (without its consistency / distillation
+ *               epilogue, which becomes a pointwise launch after the join) is forked beside the producer behind the ensemble
+ *               pass; 0: in line after the fused sweep, epilogue inside the pass (round 3, kept for A/B);
  * "march_halo1" 1 (default): the gradient passes of the whole-step lists warp ONE row beyond each end of a task's segment
  *               and hand the boundary rows' missing terms over through scratch rows; 0: two rows, no hand-over (A/B);
  * "march_lean"  1 (default): the teacher / student passes of the whole-step lists run the instantiations without the code

@@ -21,6 +21,9 @@ struct MarchParams {
   // --learn_ens (whole-step list, epilogue passes): the learnt ensemble's disparity (its depth replaces (mono + multi) / 2
   // as the distillation target of the pixels the ensemble wins) and the map that receives merge_distil * d distil / d it
   const float* ens_disp; float* g_ens;
+  // --dual_distil (whole-step list, two-way distillation): g_ens receives merge_distil * d distil / d mono_disp instead
+  // (the teacher's depth keeps its graph where it wins the argmin, loss_utils.py:231-234); ens_disp must be NULL
+  int dual_distil;
   // per-sample camera block [B][40]: P_f = (K T_f)[:3,:], inv_K[:3,:3]; march_launch fills it unless cam_ready
   float* cam; int cam_ready;
   int sample_scale_is_mask;  // sample_scale holds the augmentation mask: the scale is 1 - mask

@@ -288,6 +288,7 @@ enum : int {
   kSpecTeacher = kSpecLean | kSpecNoDisp2 | kSpecExtNo | kSpecCostNo | kSpecNoScale | kSpecConvA,
   kSpecStudent = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostYes | kSpecMonoYes | kSpecConvA,      // whole-step list, scale 0
   kSpecStudentNoCost = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostNo | kSpecMonoYes | kSpecConvA, // four-scale list, scales > 0
+  kSpecStudentNoEpi = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostYes | kSpecConvA,  // --temporal step: the epilogue is its own launch
   kSpecRefine = kSpecLean | kSpecNoDisp2 | kSpecCostNo | kSpecMonoYes | kSpecNoScale | kSpecConvB        // DualRefine, deq iterations > 0
 };
 template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG, bool TEMPORAL, bool EXPORT, int SPEC = 0>
@@ -616,6 +617,8 @@ MAL_DEV void march_body() {
         const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : (learnt ? -1.0f : -0.5f))) * mm * ddepth;
         if (learnt && p.g_ens)  // d |ens - dm| / d ens_disp where the ensemble won, with the distillation term's loss weight
           stf(p.g_ens, go, idx == 1 ? p.merge_distil * (sgnf(dd) * mm * (-(dens * dens) * p.range)) : 0.0f);
+        if (p.dual_distil && p.g_ens)  // --dual_distil: d |mono - dm| / d mono_disp where the teacher won (wave-uniform flag)
+          stf(p.g_ens, go, (idx == 0 && has_mdisp) ? p.merge_distil * (sgnf(dd) * mm * (-(dmono * dmono) * p.range)) : 0.0f);
         if (p.g_distil) {
           stf(p.g_cons, go, gc);
           stf(p.g_distil, go, gd);
@@ -1175,6 +1178,11 @@ __global__ __launch_bounds__(64, 2) void march_teacher_kernel(MarchParams p_kern
 template <int SPEC>
 __global__ __launch_bounds__(64, 2) void march_student_kernel(MarchParams p_kernarg) {
   march_body<true, false, false, true, false, false, false, SPEC>();
+}
+// ... and without the epilogue (the --temporal step forms the consistency / distillation terms in step_epilogue_kernel, so
+// that this pass depends on nothing the teacher's side produces and runs beside the temporal hint's producer)
+__global__ __launch_bounds__(64, 2) void march_student_noepi_kernel(MarchParams p_kernarg) {
+  march_body<true, false, false, false, false, false, false, kSpecStudentNoEpi>();
 }
 // DualRefine's passes of the deq iterations > 0: teacher-style pass (automask, pose gradients) with the consistency epilogue
 __global__ __launch_bounds__(64, 2) void march_refine_kernel(MarchParams p_kernarg) {
@@ -1788,6 +1796,7 @@ extern int g_epi_probe;       // mal_epipolar.hip
 extern int g_syn_rows;        // mal_photo_march.hip
 extern int g_syn_queue;       // mal_photo_march.hip
 extern int g_step_overlap;    // mal_step.hip
+extern int g_student_overlap; // mal_step.hip
 extern int g_march_halo1;     // mal_step.hip
 extern int g_temporal_spec;   // mal_step.hip
 int g_march_lean = 1;         // option "march_lean": the teacher's passes without the optional operands' code (0: generic, A/B)
@@ -1901,9 +1910,12 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
     if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
     if (grad && pose && automask && !epi) hipLaunchKernelGGL((march_kernel<true, true, true, false, true>), grid, block, 0, st, p);
     else if (grad && !pose && !automask && epi) hipLaunchKernelGGL((march_kernel<true, false, false, true, true>), grid, block, 0, st, p);
+    else if (grad && !pose && !automask && !epi) hipLaunchKernelGGL((march_kernel<true, false, false, false, true>), grid, block, 0, st, p);
     else return MAL_EINVAL;
   } else if (lean_student && grad && !pose && !automask && epi) {
     hipLaunchKernelGGL(march_student_kernel<kSpecStudent>, grid, block, 0, st, p);
+  } else if (lean0 && conv_a && !p.disp2 && p.ext_mask && p.lowest_cost && p.mono_disp && grad && !pose && !automask && !epi) {
+    hipLaunchKernelGGL(march_student_noepi_kernel, grid, block, 0, st, p);
   } else if (lean_student_nc && grad && !pose && !automask && epi) {
     hipLaunchKernelGGL(march_student_kernel<kSpecStudentNoCost>, grid, block, 0, st, p);
   } else if (lean_refine && grad && pose && automask && epi && !p.forced_w) {
@@ -1991,6 +2003,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("costvol_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_costvol_impl = value; return MAL_OK; }
   if (eq("step_overlap")) { if (value < 0 || value > 2) return MAL_EINVAL; g_step_overlap = value; return MAL_OK; }
   if (eq("march_halo1")) { g_march_halo1 = value != 0; return MAL_OK; }
+  if (eq("student_overlap")) { g_student_overlap = value != 0; return MAL_OK; }
   if (eq("temporal_spec")) { if (!kExp && value) return MAL_EINVAL; g_temporal_spec = value != 0; return MAL_OK; }
   if (eq("march3")) { if (!kExp && value) return MAL_EINVAL; g_march3 = value != 0; return MAL_OK; }
   if (eq("march_lean")) { g_march_lean = value != 0; return MAL_OK; }

@@ -18,6 +18,7 @@
 #include "mal_march.h"
 #include "mal_device.h"
 #include "mal_pose.h"
+#include "mal_pairs.h"
 #include <mutex>
 
 namespace mal {
@@ -31,6 +32,7 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
                            size_t orig_stride);
 
 constexpr int kLossSlots = 16;
+constexpr int kEpiBlocks = 64;  // workgroups per sample of step_epilogue_kernel (its per-block partials are summed in block order)
 
 struct StepWs {
   float* packed[3];   // target, src-1, src+1 as (B,H,W,kTexel) texels
@@ -38,6 +40,8 @@ struct StepWs {
   float* ident; float* mono_reproj; float* ens_reproj;
   float* G_r_t; float* G_r_s; float* G_c; float* gn_t; float* gn_s;
   float* G_e;         // --learn_ens: merge_distil * d distil / d ens_disp (student pass -> assembly)
+  float* multi_reproj;  // --temporal step: the student's per-pixel min (its pass runs beside the producer, the epilogue after it)
+  double* bs_d;       // ... and the epilogue launch's per-block partials [B][kEpiBlocks][2] = sum |d cons|, sum |d distil|
   double* bs_t; double* bs_s; double* bs_e; float* bgP;  // per-task partials of the three passes
   float* bgP_e;       // the ensemble pass's own (unused) pose-partial sink: it may run beside other launches
   double* bs_p;       // per-task smoothness partials of the first launch: [task][map][4]
@@ -64,8 +68,9 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   for (int i = 0; i < 3; ++i) w.packed[i] = (float*)take(B * HW * kTexel * sizeof(float));
   for (int f = 0; f < 2; ++f) { w.T[f] = (float*)take(B * 16 * 4); w.gT[f] = (float*)take(B * 16 * 4); w.gTs[f] = (float*)take(B * 16 * 4); }
   float** maps[] = {&w.ident, &w.mono_reproj, &w.ens_reproj, &w.G_r_t, &w.G_r_s, &w.G_c,
-                    &w.gn_t, &w.gn_s, &w.G_e};
+                    &w.gn_t, &w.gn_s, &w.G_e, &w.multi_reproj};
   for (auto m : maps) *m = (float*)take(map);
+  w.bs_d = (double*)take((size_t)B * kEpiBlocks * 2 * 8);
   w.bs_t = (double*)take(nb * 8 * 8); w.bs_s = (double*)take(nb * 8 * 8); w.bs_e = (double*)take(nb * 8 * 8);
   w.bgP = (float*)take(nb * 24 * 4);
   w.bgP_e = (float*)take(nb * 24 * 4);
@@ -97,7 +102,7 @@ static StepWs carve_step(void* base, int B, int H, int W) {
 // coefficients of the backward.
 __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, const double* bs_s, const float* bgP,
                                                          const double* bs_p, int per_sample_p,
-                                                         const double* bs_ph, int per_sample_ph,
+                                                         const double* bs_ph, int per_sample_ph, const double* bs_d,
                                                          const float* K, int per_sample, int per_sample_t, int B, int H, int W,
                                                          float w_main, float w_distil, double* ps, float* gT0, float* gT1,
                                                          double* stats, float* losses, float* coefs, float* loss_total,
@@ -119,8 +124,15 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
                              : bs_p + (size_t)b * per_sample_p * 8 + pass * 4 + (j - 4);
     const int n_t = j < 4 ? ps_pass : per_sample_p;
     double acc = 0.0;
+    if (bs_d && pass == 1 && (j == 2 || j == 3)) {
+      // the consistency / distillation sums of the student come from step_epilogue_kernel's per-block partials (fixed order)
+      const double* bd = bs_d + (size_t)b * kEpiBlocks * 2 + (j - 2);
+#pragma unroll 8
+      for (int t = sub; t < kEpiBlocks; t += 32) acc += bd[(size_t)t * 2];
+    } else {
 #pragma unroll 8
     for (int t = sub; t < n_t; t += 32) acc += bs[(size_t)t * 8];  // independent loads: issue them together
+    }
     if (ph && j < 2) {
       const double* bd = bs_ph + (size_t)b * per_sample_ph * 2 + j;
 #pragma unroll 8
@@ -232,6 +244,71 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
   coefs[4] = w_main * 1e-3f;                                // smoothness
 }
 
+// The consistency / distillation terms of the student (loss_utils.py:193-254) as a launch of their own -- the --temporal step:
+// they are pointwise in the two depths and in the three per-pixel minima (the distillation index is not differentiable, the
+// gradient reaches multi_depth directly, not through the warp), so the student's marching pass need not wait for the
+// teacher's four-way min and runs beside the temporal hint's producer; this launch follows the join.  The arithmetic is the
+// epilogue of march_body, statement for statement (weight = consistency mask x matching mask x (1 - augmentation), as the
+// pass forms it; depth_of, the argmin's first-minimum rule, sign conventions); sums leave as per-block partials.
+struct EpiParams {
+  const float *disp_s, *disp_t, *mono_reproj, *ens_reproj, *multi_reproj, *ext_mask, *lowest_cost, *sample_scale, *ens_disp;
+  int scale_is_mask, dual;
+  float min_disp, range, merge_cons, merge_distil;
+  float *G_c, *G_e; double* partials; unsigned* dbg; int B, HW;
+};
+__global__ __launch_bounds__(256) void step_epilogue_kernel(EpiParams p) {
+  __shared__ double s_red[2][4];
+  const int b = blockIdx.x / kEpiBlocks, blk = blockIdx.x - b * kEpiBlocks, tid = threadIdx.x;
+  const int per = (p.HW + kEpiBlocks - 1) / kEpiBlocks, lo = blk * per, hi = min(lo + per, p.HW);
+  const float sscale = p.sample_scale ? (p.scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
+  const bool has_er = p.ens_reproj != nullptr, learnt = p.ens_disp != nullptr;
+  float acc_cons = 0.f, acc_dist = 0.f;
+  for (int i0 = lo + tid; i0 < hi; i0 += 256) {
+    const size_t i = (size_t)b * p.HW + i0;
+    // the weight of the student's masked reprojection term, as its pass forms it (march_body, stage S)
+    float em = p.ext_mask[i];
+    {
+      const float mono = depth_of(p.disp_t[i], p.min_disp, p.range);
+      const float matching = div_safe_(1.0f, p.lowest_cost[i]);
+      const bool ok = (div_safe_(matching - mono, mono) < 1.0f) && (div_safe_(mono - matching, matching) < 1.0f);
+      em = ok ? em : em * 0.0f;
+    }
+    float w = 1.0f;
+    w *= em;
+    w *= sscale;
+    const float rp = p.multi_reproj[i];
+    // march_body::epilogue
+    const float dm = depth_of(p.disp_s[i], p.min_disp, p.range);
+    const float ddepth = -(dm * dm) * p.range;
+    const float dmono = depth_of(p.disp_t[i], p.min_disp, p.range);
+    const float m = w, cm = 1.0f - m, mm = 1.0f - cm;
+    const float dc = dm - dmono;
+    acc_cons += fabsf(dc) * cm;
+    int idx = 0;
+    float best = p.mono_reproj[i];
+    if (has_er) {
+      const float r_ens = p.ens_reproj[i];
+      if (r_ens < best) { best = r_ens; idx = 1; }
+    }
+    if (rp < best) idx = 2;
+    float dens = 0.f, ens = (dmono + dm) / 2.0f;
+    if (learnt) { dens = depth_of(p.ens_disp[i], p.min_disp, p.range); ens = dens; }
+    const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
+    const float dd = target - dm;
+    acc_dist += fabsf(dd) * mm;
+    if (p.dbg) p.dbg[(size_t)MAL_DEC_DISTIL * ((size_t)p.B * p.HW) + i] = (unsigned)idx;
+    const float gc = sgnf(dc) * cm * ddepth;
+    const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : (learnt ? -1.0f : -0.5f))) * mm * ddepth;
+    if (learnt && p.G_e) p.G_e[i] = idx == 1 ? p.merge_distil * (sgnf(dd) * mm * (-(dens * dens) * p.range)) : 0.0f;
+    if (p.dual && p.G_e) p.G_e[i] = idx == 0 ? p.merge_distil * (sgnf(dd) * mm * (-(dmono * dmono) * p.range)) : 0.0f;
+    p.G_c[i] = fma_(p.merge_cons, gc, p.merge_distil * gd);
+  }
+  const double r0 = wave_sum_d((double)acc_cons), r1 = wave_sum_d((double)acc_dist);
+  if ((tid & 63) == 0) { s_red[0][tid >> 6] = r0; s_red[1][tid >> 6] = r1; }
+  __syncthreads();
+  if (tid < 2) p.partials[((size_t)b * kEpiBlocks + blk) * 2 + tid] = (s_red[tid][0] + s_red[tid][1]) + (s_red[tid][2] + s_red[tid][3]);
+}
+
 // d total / d disp for both maps; block 0 also scales the pose gradients and runs the backward of
 // transformation_from_parameters (pp.gT = the scaled gradients, pp.g_axisangle / g_translation nullable).  With the
 // temporal hint (bgP != nullptr) the first B workgroups reduce their sample's pose partials first.
@@ -242,7 +319,8 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
                                                             float* gTs0, float* gTs1, float* g_disp_t, float* g_disp_s,
                                                             PoseParams pp, int pose_bwd, const float* bgP, const float* K,
                                                             int per_sample, int W, const float* bnd_t, const float* bnd_s,
-                                                            int rows, int segs, float* fix_t, const float* G_e, float* g_ens) {
+                                                            int rows, int segs, float* fix_t, const float* G_e, float* g_ens,
+                                                            const float* G_dual) {
   const float g = g_total ? *g_total : 1.0f;
   const float cRt = coefs[0] * g, cRs = coefs[1] * g, cS = coefs[4] * g;  // coefs[2], [3] are already inside G_cd
   if (bgP) {
@@ -296,10 +374,13 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
     auto px = [&](size_t i, int x) {
       if (g_disp_t) {
         const float G = brow_t ? G_r_t[i] + brow_t[x] : G_r_t[i];
-        g_disp_t[i] = fma_(cRt, G, cS * (gn_t[i] * inv_t - corr_t));
-      } else if (fix_t && brow_t) {  // the teacher's sweep finished its own rows (temporal hint): add the neighbour's term
-        const float v = brow_t[x];
-        if (v != 0.f) fix_t[i] = fix_t[i] + cRt * v;
+        float v = fma_(cRt, G, cS * (gn_t[i] * inv_t - corr_t));
+        if (G_dual) v += g * G_dual[i];  // --dual_distil: what the distillation term sends to the teacher's disparity
+        g_disp_t[i] = v;
+      } else if (fix_t && (brow_t || G_dual)) {  // the teacher's sweep finished its own rows (temporal hint): add the neighbour's term
+        float v = brow_t ? cRt * brow_t[x] : 0.f;
+        if (G_dual) v += g * G_dual[i];
+        if (v != 0.f) fix_t[i] = fix_t[i] + v;
       }
       if (g_disp_s) {
         const float G = brow_s ? G_r_s[i] + brow_s[x] : G_r_s[i];
@@ -307,7 +388,7 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
       }
       if (g_ens) g_ens[i] = g * G_e[i];  // --learn_ens: the loss weight is inside G_e already
     };
-    if (vec4 && !brow_t && !brow_s && !g_ens) {
+    if (vec4 && !brow_t && !brow_s && !g_ens && !G_dual) {
       // four pixels per thread, 16-byte accesses (no boundary row here: the arithmetic per element is px()'s)
       for (int x = threadIdx.x * 4; x < W; x += blockDim.x * 4) {
         const size_t i = r0 + x;
@@ -389,6 +470,7 @@ static int step_check(const mal_step_args* a) {
     return MAL_EINVAL;
   if (a->ws_bytes < carve_step(nullptr, a->B, a->H, a->W).bytes) return MAL_EWORKSPACE;
   if (a->ens_disp && (a->flags & MAL_STEP_NO_ENS)) return MAL_EINVAL;  // the learnt ensemble IS the third candidate
+  if ((a->flags & MAL_STEP_DUAL_DISTIL) && !(a->flags & MAL_STEP_NO_ENS)) return MAL_EINVAL;  // upstream reads it on the two-way branch only
   if (a->g_ens_disp && !a->ens_disp) return MAL_EINVAL;
   return MAL_OK;
 }
@@ -451,6 +533,49 @@ static int launch_ensemble(const mal_step_args* a, const StepWs& w, float* ens_r
   return march_launch(p, MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
 }
 
+// the student's pass (trainer.py:592-612): with `epi` the consistency / distillation epilogue rides in it (the step without the
+// temporal hint); without, it leaves its per-pixel min in multi_reproj and step_epilogue_kernel forms those terms later
+static int launch_student(const mal_step_args* a, const StepWs& w, float* mono_reproj, float* ens_reproj, float* multi_reproj,
+                          bool epi, hipStream_t st, int* per_sample) {
+  const int B = a->B, H = a->H, W = a->W;
+  MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
+  p.disp = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+  p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+  p.ext_mask = a->consistency_mask; p.sample_scale = a->augmentation_keep;
+  p.sample_scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0;
+  p.mono_disp = a->disp_teacher; p.lowest_cost = a->lowest_cost; p.cmask_out = a->consistency_mask_out;
+  p.min_reproj = multi_reproj; p.g_reproj = w.G_r_s;
+  if (epi) {
+    p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj;
+    p.g_cons = w.G_c; p.g_distil = nullptr;  // one merged map: weights as coefs[2], coefs[3] of step_final_kernel
+    p.ens_disp = a->ens_disp; p.g_ens = a->ens_disp ? w.G_e : nullptr;
+    if (a->flags & MAL_STEP_DUAL_DISTIL) { p.dual_distil = 1; p.g_ens = w.G_e; }  // G_e = merge_distil * d distil / d disp_teacher
+    p.merge_cons = (float)((double)a->w_main / ((double)B * H * W)); p.merge_distil = (float)((double)a->w_distil / ((double)B * H * W));
+  }
+  p.block_sums = w.bs_s; p.block_gP = w.bgP_e;  // (no pose gradient in this pass: the sink is never written)
+  p.bnd = g_march_halo1 ? w.bnd_s : nullptr;
+  p.cam = w.cam; p.cam_ready = 1;
+  p.dbg = a->dec_student;
+  int rc = march_launch(p, MAL_F_GRAD | (epi ? MAL_F_EPILOGUE : 0) | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+  if (per_sample) *per_sample = p.strips * p.segs;
+  return rc;
+}
+static int launch_epilogue(const mal_step_args* a, const StepWs& w, const float* mono_reproj, const float* ens_reproj,
+                           const float* multi_reproj, hipStream_t st) {
+  const int B = a->B, H = a->H, W = a->W;
+  MarchParams mp = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
+  EpiParams e = {};
+  e.disp_s = a->disp_student; e.disp_t = a->disp_teacher; e.mono_reproj = mono_reproj; e.ens_reproj = ens_reproj;
+  e.multi_reproj = multi_reproj; e.ext_mask = a->consistency_mask; e.lowest_cost = a->lowest_cost;
+  e.sample_scale = a->augmentation_keep; e.scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0;
+  e.ens_disp = a->ens_disp; e.dual = (a->flags & MAL_STEP_DUAL_DISTIL) ? 1 : 0;
+  e.min_disp = mp.min_disp; e.range = mp.range;
+  e.merge_cons = (float)((double)a->w_main / ((double)B * H * W)); e.merge_distil = (float)((double)a->w_distil / ((double)B * H * W));
+  e.G_c = w.G_c; e.G_e = (a->ens_disp || e.dual) ? w.G_e : nullptr; e.partials = w.bs_d; e.dbg = a->dec_student; e.B = B; e.HW = H * W;
+  hipLaunchKernelGGL(step_epilogue_kernel, dim3((unsigned)(B * kEpiBlocks)), dim3(256), 0, st, e);
+  return launch_status();
+}
+
 // Temporal hint: between the warp pass and the fused sweep the device runs the producer's small, latency-bound kernels
 // (and whatever the segmenter does) -- the ensemble pass depends on none of it.  It is forked onto a side stream AFTER the
 // warp pass (beside it, two ALU-bound passes only slow each other down: measured) and joined before the student pass,
@@ -510,16 +635,25 @@ static int join_side(hipStream_t st, bool always = false) {
   ss->pending = false;
   return hipStreamWaitEvent(st, ss->join, 0) == hipSuccess ? MAL_OK : MAL_ELAUNCH;
 }
+// what is forked beside the producer: the ensemble pass (unless --no_ens) and, with option "student_overlap" (default), the
+// student's marching pass without its epilogue
+namespace mal { int g_student_overlap = 1; }
+static bool side_forked(const mal_step_args* a) {
+  return g_step_overlap && (a->flags & MAL_STEP_TEMPORAL) && side_stream((hipStream_t)a->stream) != nullptr;
+}
+static bool student_forked(const mal_step_args* a) { return side_forked(a) && g_student_overlap && g_step_overlap == 1; }
 static bool ensemble_forked(const mal_step_args* a) {
-  return g_step_overlap && (a->flags & MAL_STEP_TEMPORAL) && !(a->flags & MAL_STEP_NO_ENS) &&
-         side_stream((hipStream_t)a->stream) != nullptr;
+  return side_forked(a) && !(a->flags & MAL_STEP_NO_ENS);
 }
 
 static int fork_ensemble(const mal_step_args* a, const StepWs& w, hipStream_t st) {
   SideStream* ss = side_stream(st);
   if (!ss) return MAL_ELAUNCH;
   if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return MAL_ELAUNCH;
-  int rc = launch_ensemble(a, w, a->ens_reproj ? a->ens_reproj : w.ens_reproj, ss->s);
+  int rc = MAL_OK;
+  if (!(a->flags & MAL_STEP_NO_ENS)) rc = launch_ensemble(a, w, a->ens_reproj ? a->ens_reproj : w.ens_reproj, ss->s);
+  if (!rc && student_forked(a))
+    rc = launch_student(a, w, nullptr, nullptr, a->multi_reproj ? a->multi_reproj : w.multi_reproj, false, ss->s, nullptr);
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return rc ? rc : MAL_ELAUNCH;
   ss->pending = true;  // whatever was enqueued on the side stream is joined before the step's buffers are reused
   return rc;
@@ -567,7 +701,7 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   if ((a->warp2_m1 == nullptr) != (a->warp2_p1 == nullptr)) return MAL_EINVAL;
   rc = march_launch(p, flags, st);
   if (rc) return rc;
-  if (ensemble_forked(a) && g_step_overlap == 1) {
+  if ((ensemble_forked(a) || student_forked(a)) && g_step_overlap == 1) {
     rc = fork_ensemble(a, w, st);
     if (rc) return rc;
   }
@@ -586,7 +720,6 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   float* multi_reproj = a->multi_reproj;  // only written when the caller wants the map
 
   int per_sample_p = 1, per_sample_ph = 0;
-  const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
   int per_sample = 1, per_sample_t = 0;
   {  // tasks per sample of the teacher's sums: its gradient pass, or (temporal hint) the forward pass in front of the producer
     int strips = 0, segs = 0;
@@ -620,40 +753,32 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
                                 sparse ? a->warp_m1 : nullptr, sparse ? a->warp_p1 : nullptr, (size_t)a->warp_sample_stride);
     if (rc) { (void)join_side(st); return rc; }
   }
-  // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp
-  if (!no_ens) {
-    if (ensemble_forked(a)) {
-      rc = join_side(st, true);
-      if (rc) return rc;
-    } else {
-      rc = launch_ensemble(a, w, ens_reproj, st);
-      if (rc) return rc;
-    }
-  }
-  // student pass with the consistency / distillation epilogue
-  {
-    MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
-    p.disp = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
-    p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
-    p.ext_mask = a->consistency_mask; p.sample_scale = a->augmentation_keep;
-    p.sample_scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0;
-    p.mono_disp = a->disp_teacher; p.lowest_cost = a->lowest_cost; p.cmask_out = a->consistency_mask_out;
-    p.mono_reproj = mono_reproj; p.ens_reproj = ens_reproj;
-    p.min_reproj = multi_reproj; p.g_reproj = w.G_r_s;
-    p.g_cons = w.G_c; p.g_distil = nullptr;  // one merged map: weights as coefs[2], coefs[3] of step_final_kernel
-    p.ens_disp = a->ens_disp; p.g_ens = a->ens_disp ? w.G_e : nullptr;
-    p.merge_cons = (float)((double)a->w_main / ((double)B * H * W)); p.merge_distil = (float)((double)a->w_distil / ((double)B * H * W));
-    p.block_sums = w.bs_s; p.block_gP = w.bgP;
-    p.bnd = g_march_halo1 ? w.bnd_s : nullptr;
-    p.cam = w.cam; p.cam_ready = 1;
-    p.dbg = a->dec_student;
-    rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
+  // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp -- and so
+  // was the student's marching pass (without its epilogue)
+  const bool ens_forked = temporal && ensemble_forked(a), stu_forked = temporal && student_forked(a);
+  if (ens_forked || stu_forked) {
+    rc = join_side(st, true);
     if (rc) return rc;
-    per_sample = p.strips * p.segs;
+  }
+  if (!no_ens && !ens_forked) {
+    rc = launch_ensemble(a, w, ens_reproj, st);
+    if (rc) return rc;
+  }
+  if (stu_forked) {
+    // the student's pass ran beside the producer: its consistency / distillation terms now, from the three per-pixel minima
+    int strips = 0, segs = 0;
+    march_geometry(B, H, W, MAL_F_GRAD, &strips, &segs, nullptr);
+    per_sample = strips * segs;
+    rc = launch_epilogue(a, w, mono_reproj, ens_reproj, a->multi_reproj ? a->multi_reproj : w.multi_reproj, st);
+    if (rc) return rc;
+  } else {
+    // student pass with the consistency / distillation epilogue
+    rc = launch_student(a, w, mono_reproj, ens_reproj, multi_reproj, true, st, &per_sample);
+    if (rc) return rc;
   }
   // per-sample sums of both gradient passes, pose gradients (temporal: in _bwd, after the teacher's sweep), scalars
   hipLaunchKernelGGL(step_final_kernel, dim3(temporal ? 2 * B : 3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, temporal ? nullptr : w.bgP,
-                     w.bs_p, per_sample_p, temporal ? w.bs_ph : nullptr, per_sample_ph, a->K,
+                     w.bs_p, per_sample_p, temporal ? w.bs_ph : nullptr, per_sample_ph, stu_forked ? w.bs_d : nullptr, a->K,
                      per_sample, per_sample_t, B, H, W,
                      a->w_main, a->w_distil, w.ps, w.gT[0], w.gT[1], w.sm_stats, a->losses, w.coefs, a->loss_total,
                      w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr);
@@ -729,7 +854,7 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
                      teacher_done ? nullptr : a->g_disp_teacher, a->g_disp_student, pp, pose_bwd, per_sample_t ? w.bgP : nullptr,
                      a->K, per_sample_t, W, g_march_halo1 ? w.bnd_t : nullptr, g_march_halo1 ? w.bnd_s : nullptr, rows, segs,
                      teacher_done ? a->g_disp_teacher : nullptr, a->ens_disp ? w.G_e : nullptr,
-                     a->ens_disp ? a->g_ens_disp : nullptr);
+                     a->ens_disp ? a->g_ens_disp : nullptr, (a->flags & MAL_STEP_DUAL_DISTIL) ? w.G_e : nullptr);
   rc = launch_status();
   return rc;
 }

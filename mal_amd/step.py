@@ -45,7 +45,8 @@ def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, tempora
     """the mal_step_args block of one step, the tensors it points to (kept alive by the caller) and the map dict;
     ``ens_disp`` (--learn_ens): a seventh leaf, appended to the kept tensors"""
     color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise = consts
-    min_depth, max_depth, no_ens, w_main, w_distil, want_maps, aug_is_mask, want_dec, philox = cfg
+    min_depth, max_depth, no_ens, w_main, w_distil, want_maps, aug_is_mask, want_dec, philox = cfg[:9]
+    dual = len(cfg) > 9 and cfg[9]
     req = ops._req
     tens = [req(t, n) for t, n in ((disp_t, "disp_teacher"), (disp_s, "disp_student"), (aa_m1, "axisangle"),
                                    (tr_m1, "translation"), (aa_p1, "axisangle"), (tr_p1, "translation"))]
@@ -60,7 +61,8 @@ def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, tempora
     a = L.StepArgs()
     a.B, a.H, a.W = B, H, W
     a.min_depth, a.max_depth = float(min_depth), float(max_depth)
-    a.flags = (L.STEP_NO_ENS if no_ens else 0) | (L.STEP_AUG_MASK if aug_is_mask else 0) | (L.STEP_TEMPORAL if temporal else 0)
+    a.flags = (L.STEP_NO_ENS if no_ens else 0) | (L.STEP_AUG_MASK if aug_is_mask else 0) | (L.STEP_TEMPORAL if temporal else 0) | \
+              (L.STEP_DUAL_DISTIL if (dual and no_ens) else 0)  # upstream reads dual_distil on the two-way branch only
     if philox is not None:  # (seed, want the drawn values back)
         a.flags |= L.STEP_NOISE_PHILOX
         a.noise_seed = int(philox[0]) & 0xFFFFFFFFFFFFFFFF
@@ -278,11 +280,10 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
     gradient passes (int32 (MAL_DEC_PLANES,B,H,W), include/mal_hip.h).
     Returns (losses dict, loss_list or None, maps dict)."""
     from . import config, loss_utils
-    if getattr(opt, "main_temporal", False) or getattr(opt, "dual_distil", False) \
-            or getattr(opt, "no_ssim", False) or not getattr(opt, "distil", True) \
+    if getattr(opt, "main_temporal", False) or getattr(opt, "no_ssim", False) or not getattr(opt, "distil", True) \
             or getattr(opt, "sclm", 0) != 0:
-        raise L.MalError("loss_step covers the --distil [--temporal] [--learn_ens] single-scale configuration; use MALLossPath."
-                         "compute_batch_losses for main_temporal / dual_distil / no_ssim / non-distil runs")
+        raise L.MalError("loss_step covers the --distil [--temporal] [--learn_ens] [--no_ens [--dual_distil]] single-scale "
+                         "configuration; use MALLossPath.compute_batch_losses for main_temporal / no_ssim / non-distil runs")
     ens_disp = None
     if getattr(opt, "learn_ens", False) and not getattr(opt, "no_ens", False):
         # the learnt ensemble head's disparity (loss_utils.py:240-241, trainer.py:596-597): warped by the ensemble pass,
@@ -319,7 +320,7 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
     consts = (color0, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)],
               outputs["consistency_mask"].to(torch.float32), keep, outputs["lowest_cost"], noise)
     cfg = (opt.min_depth, opt.max_depth, bool(getattr(opt, "no_ens", False)), w_main, w_distil, bool(want_maps),
-           aug_is_mask, bool(want_decisions), philox)
+           aug_is_mask, bool(want_decisions), philox, bool(getattr(opt, "dual_distil", False)))
     if temporal:
         res = TemporalLossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
                                        fix(tr[1]), consts, cfg, image_synthesis, inputs, mono_outputs, ens_disp)

@@ -10,7 +10,8 @@ from tests import hip_harness as HH
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-CASES = ["step_b2_32x64_distil", "step_b2_32x64_noens", "step_b2_32x64_lossblc", "step_b3_37x50_distil", "step_b2_32x64_learnens"]
+CASES = ["step_b2_32x64_distil", "step_b2_32x64_noens", "step_b2_32x64_lossblc", "step_b3_37x50_distil", "step_b2_32x64_learnens",
+         "step_b2_32x64_dual"]
 
 
 @pytest.fixture(scope="session", autouse=True)
