@@ -71,6 +71,10 @@ def parse():
                          "manydepth/loss_utils.py:303-345, trainer.py:640-642): LossBalancing's weights enter the step as host "
                          "scalars that change every step and its score table needs the two loss scalars on the host, so the "
                          "steps are eager launches with one device->host read each")
+    ap.add_argument("--channels-last", action="store_true",
+                    help="hand the three (B,3,H,W) images over in torch.channels_last memory format: they ARE the texel images the "
+                         "passes gather from, the step skips its re-layout (MAL_STEP_TEXEL_INPUTS).  The default (the headline) "
+                         "keeps the reference's NCHW tensors and reports this variant in the `channels_last` side block")
     ap.add_argument("--value", choices=["auto", "loss", "train"], default="auto",
                     help="what the line's `value` is: loss = the loss path (the default at N=1), train = the whole training "
                          "step of the harness (the default at N>1: the quantity the >= 6x DP target is about); auto picks by N")
@@ -166,7 +170,7 @@ class TrainStep:
 class Step:
     """Everything a step needs, resident on the device."""
 
-    def __init__(self, dev, seed, mode="step"):
+    def __init__(self, dev, seed, mode="step", channels_last=False):
         from mal_amd import config, layers, trainer, step as step_mod
         self.mode, self.step_mod = mode, step_mod
         from mal_amd.synthetic import make_batch
@@ -187,6 +191,9 @@ class Step:
         mv = lambda t: t.to(dev).contiguous()
         self.inputs = {("color", 0, 0): mv(b["color0"]), ("color", -1, 0): mv(b["color_m1"]),
                        ("color", 1, 0): mv(b["color_p1"]), ("K", 0): mv(b["K"]), ("inv_K", 0): mv(b["inv_K"])}
+        if channels_last:  # same values, the texel layout: (B,3,H,W) with strides (3HW, 1, 3W, 3)
+            for f in (0, -1, 1):
+                self.inputs[("color", f, 0)] = self.inputs[("color", f, 0)].contiguous(memory_format=torch.channels_last)
         self.leaves = {k: mv(b[k]).requires_grad_(True) for k in
                        ("disp_teacher", "disp_student", "axisangle_m1", "translation_m1", "axisangle_p1",
                         "translation_p1")}
@@ -440,6 +447,32 @@ def replayed_kernel_ms(dev, seed, launches=64, replays=10):
     return e0.elapsed_time(e1) / (launches * replays), launches * replays
 
 
+def channels_last_block(dev, seed, mode, steps=200):
+    """the same step with the three images in torch.channels_last (zero-copy texels), graph-replayed like the headline"""
+    st = Step(dev, seed, mode, channels_last=True)
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        for _ in range(3):
+            st()
+    torch.cuda.current_stream().wait_stream(s_)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        st()
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    return {"ms_per_step": ms, "value": B / (ms * 1e-3), "unit": "images/s", "steps": steps, "launch": "hip-graph",
+            "what": "the same step with inputs[('color', f, 0)] in torch.channels_last memory format: the (B,H,W,3) texel images "
+                    "themselves, no re-layout in the first sweep (MAL_STEP_TEXEL_INPUTS); a loader gets there with "
+                    ".contiguous(memory_format=torch.channels_last) on the host tensor (INTEGRATION.md)"}
+
+
 def loss_blc_block(dev, seed, mode, steps):
     """--loss-blc: the same step with the reference's --loss_blc (README.md:22): total = bs * (w0 * L0 + w1 * L1) with
     LossBalancing's weights (loss_utils.py:303-318), re-weighted every step from its running score table (:320-345,
@@ -520,7 +553,7 @@ def main():
         args.graph = 0  # host-side RNG, optimizer and collective in the step
         args.no_cpu_baseline = True
     else:
-        step = Step(dev, 1234 + rank, args.mode)
+        step = Step(dev, 1234 + rank, args.mode, channels_last=args.channels_last)
     batch_cpu = step.batch_cpu
     step_B = getattr(step, "B", B)  # images per rank and step (read here: the train_step block below frees `step`)
 
@@ -706,6 +739,13 @@ def main():
             replayed = ("%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:200]),)
             torch.cuda.synchronize()
 
+    cl_block = None
+    if args.mode in ("step", "distil") and not args.channels_last and rank == 0:
+        try:
+            cl_block = channels_last_block(dev, 1234 + rank, args.mode)
+        except Exception as ex:
+            cl_block = {"error": "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:200])}
+            torch.cuda.synchronize()
     # --loss-blc: the reference's own KITTI command (README.md:22) adds LossBalancing to the step
     blc_block = None
     if args.loss_blc and args.mode in ("step", "distil"):
@@ -787,6 +827,9 @@ def main():
         out["eager_value"] = n_ranks * step_B / (eager_ms * 1e-3)
     if blc_block is not None:
         out["loss_blc"] = blc_block
+    if cl_block is not None:
+        out["channels_last"] = cl_block
+    out["config"]["input_layout"] = "channels_last (zero-copy texels)" if args.channels_last else "NCHW (the reference's tensors)"
     if breakdown is not None:
         out["breakdown_ms"] = breakdown
     if overlapped is not None:

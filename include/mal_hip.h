@@ -255,6 +255,9 @@ enum {
   MAL_STEP_NOISE_PHILOX = 4, /* the automask tie-break noise (loss_utils.py:105-106: + 1e-5 * randn) is drawn inside the
                                step's first kernel: N(0,1) by Box-Muller from Philox4x32-10 keyed by noise_seed, counter =
                                (pixel, step); `noise` must be NULL.  No host RNG, no device RNG launch on the step. */
+  MAL_STEP_TEXEL_INPUTS = 64, /* color0 / color_m1 / color_p1 are (B,H,W,3) texel images -- a (B,3,H,W) tensor in torch.channels_last
+                                memory format is exactly that --: the step gathers from them directly and skips the re-layout of
+                                its first sweep (53 MB of stores per step at B=12 192x640); results are bit-identical */
   MAL_STEP_DUAL_DISTIL = 32, /* --dual_distil (loss_utils.py:231-234; only with MAL_STEP_NO_ENS, as upstream: the flag is read on the
                                two-way branch only): where the teacher wins the distillation argmin its depth is NOT detached --
                                g_disp_teacher also receives w_distil/N * sign(mono - multi) * (1 - consistency weight) * d mono / d disp */
@@ -573,8 +576,10 @@ int mal_direct_align_update_bwd(const float* H, const float* b, const float* pos
  * "costvol_impl" 1 (default): cost volume with planar features, lane = pixel; 0: channel-last, lane = channel;
  * "photo_impl"  mal_photo_fwd/bwd: 1 = marching kernels, two candidates per launch (default for SSIM + min);
  *               0 = one pixel per thread (ATen's summation order; always used for MAL_F_NO_SSIM / MAL_F_AVG);
- * "epi_bwd_planes" 1 (default): the feature-map cotangents of the N4 VJPs are accumulated per (sample, channel) plane in
- *               LDS when the planes fit; 0: global float atomics everywhere (the first formulation, kept for A/B);
+ * "epi_bwd_planes" 2 (default): the feature-map cotangents of the N4 VJPs are accumulated per (sample, channel) plane in
+ *               LDS when the planes fit, the lookup's with TWO channel planes per workgroup where 2 x the planes fit (round 4:
+ *               coordinates, cotangent and tap set of a (pixel, hypothesis) pair serve both); 1: one plane per workgroup
+ *               (round 3); 0: global float atomics everywhere (the first formulation, kept for A/B);
  * "step_overlap" 1 (default): with MAL_STEP_TEMPORAL the ensemble pass runs on a side stream beside the producer (forked
  *               after the warp pass, joined before the student pass; events, capturable); 0: in line; 2: beside the
  *               fused sweep (slower: kept for A/B);  "syn_rows": rows per task of the fused sweep given a region map;

@@ -21,7 +21,7 @@ constexpr int kEpiMaxLevels = 4;
 #define MAL_EPI_G 3  // 2-3: 0.70 ms, 4: 0.77, 6: 0.73 at B=8, 128 channels, 48x160, 51 hypotheses
 #endif
 constexpr int kEpiG = MAL_EPI_G;  // hypotheses per wavefront
-int g_epi_bwd_planes = 1;
+int g_epi_bwd_planes = 2;  // 2: two channel planes per workgroup where they fit (round 4); 1: one (round 3); 0: global atomics
 int g_epi_probe = 0;  // option "epi_probe": timing experiments of the plane kernel (wrong results), see EpiSampleBwdParams::probe         // option "epi_bwd_planes": 0 = the global-atomic scatter everywhere (A/B)
 
 struct EpiCoordParams {
@@ -436,68 +436,88 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t n, u
   if (threadIdx.x == 0) atomicMax(gmax + blockIdx.y, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));
 }
 
-__global__ __launch_bounds__(kPlaneThreads) void epi_sample_bwd_planes_kernel(EpiSampleBwdParams p, const unsigned* gmax) {
-  extern __shared__ unsigned long long s_q[];  // the level planes of d/d fmap2[b, c], back to back, fixed point
-  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+// NC channel planes per workgroup (round 4: NC = 2 where 2 x the planes fit the 160 KB of LDS): the coordinates, the cotangent
+// and the tap set of a (pixel, hypothesis) pair are read and derived ONCE for NC channels -- the 128-fold re-read of
+// coordinates and cotangent that was 45 % of the one-plane kernel (profiles/r03_epi_bwd_probe.txt) halves.
+template <int NC, int THREADS>
+__global__ __launch_bounds__(THREADS) void epi_sample_bwd_planes_kernel(EpiSampleBwdParams p, const unsigned* gmax) {
+  extern __shared__ unsigned long long s_q[];  // NC x the level planes of d/d fmap2[b, c], back to back, fixed point
+  const int c0 = blockIdx.x * NC, b = blockIdx.y, tid = threadIdx.x;
   const int hw = p.h * p.w, D = p.L * p.d1;
   int lo[kEpiMaxLevels + 1];
   lo[0] = 0;
   for (int l = 0; l < p.L; ++l) lo[l + 1] = lo[l] + (p.h >> l) * (p.w >> l);
-  for (int i = tid; i < lo[p.L]; i += kPlaneThreads) s_q[i] = 0ull;
+  const int plane = lo[p.L];
+  for (int i = tid; i < NC * plane; i += THREADS) s_q[i] = 0ull;
   __syncthreads();
-  const int cg = p.C / p.heads, head = c / cg;
+  const int cg = p.C / p.heads;
   const float inv_cg = 1.0f / (float)cg;
   const float G = __uint_as_float(gmax[b]) * inv_cg;            // no contribution exceeds it (tap weights <= 1)
   const bool bad = fix_scale_bad(G);
   const float to_fix = (G > 0.f && !bad) ? div_(kFixOne, G) : 0.f, lsb = (G > 0.f && !bad) ? div_(G, kFixOne) : 0.f;
-  const size_t plane1 = ((size_t)b * p.C + c) * hw;
-  for (int pix = tid; pix < hw; pix += kPlaneThreads) {
-    const float f1 = p.fmap1[plane1 + pix];
-    float g_f1 = 0.f;
+  for (int pix = tid; pix < hw; pix += THREADS) {
+    float f1[NC], g_f1[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { f1[k] = p.fmap1[((size_t)b * p.C + c0 + k) * hw + pix]; g_f1[k] = 0.f; }
     for (int level = 0; level < p.L; ++level) {
       const int hl = p.h >> level, wl = p.w >> level;
-      const float* pl = p.f2[level] + ((size_t)b * p.C + c) * (size_t)(hl * wl);
-      unsigned long long* sq = s_q + lo[level];
+      const float* pl[NC];
+      int head[NC];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) { pl[k] = p.f2[level] + ((size_t)b * p.C + c0 + k) * (size_t)(hl * wl); head[k] = (c0 + k) / cg; }
       const bool want = p.g_f2[level] != nullptr;
 #pragma unroll 3
       for (int j = 0; j < p.d1; ++j) {
         const int s_ = level * p.d1 + j;
         const size_t o = ((size_t)b * 2 * D + s_) * hw + pix;
         const float u = p.coords[o], v = p.coords[o + (size_t)D * hw];
-        const float go = p.g_out[((size_t)b * D * p.heads + (size_t)level * p.heads * p.d1 + (size_t)head * p.d1 + j) * hw + pix] * inv_cg;
         LevelTaps t;
         if (p.probe & 1) {  // experiment: a tap set that costs next to nothing
           const unsigned o0 = (unsigned)min(max((int)v, 0), hl - 2) * (unsigned)wl + (unsigned)min(max((int)u, 0), wl - 2);
           t.o[0] = o0; t.o[1] = o0 + 1; t.o[2] = o0 + wl; t.o[3] = o0 + wl + 1;
           t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0.25f;
         } else t = level_taps(u, v, p.w, p.h, wl, hl);
-        float smp;
-        if (p.probe & 4) smp = u * t.w[0];  // experiment: no gathers
-        else {
-          smp = pl[t.o[0]] * t.w[0];
-          smp = fma_(pl[t.o[1]], t.w[1], smp);
-          smp = fma_(pl[t.o[2]], t.w[2], smp);
-          smp = fma_(pl[t.o[3]], t.w[3], smp);
-        }
-        const float df = f1 - smp;
-        const float k = go * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
-        g_f1 += k;
-        if (want && k != 0.f && !(p.probe & 2)) {
+        float go_prev = 0.f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (t.w[q] != 0.f) fix_add(sq + t.o[q], -k * t.w[q], to_fix);
+        for (int k = 0; k < NC; ++k) {
+          // (two channels of one head share the cotangent: one load)
+          const float go = (k > 0 && head[k] == head[k - 1]) ? go_prev :
+              p.g_out[((size_t)b * D * p.heads + (size_t)level * p.heads * p.d1 + (size_t)head[k] * p.d1 + j) * hw + pix] * inv_cg;
+          go_prev = go;
+          float smp;
+          if (p.probe & 4) smp = u * t.w[0];  // experiment: no gathers
+          else {
+            smp = pl[k][t.o[0]] * t.w[0];
+            smp = fma_(pl[k][t.o[1]], t.w[1], smp);
+            smp = fma_(pl[k][t.o[2]], t.w[2], smp);
+            smp = fma_(pl[k][t.o[3]], t.w[3], smp);
+          }
+          const float df = f1[k] - smp;
+          const float kk = go * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+          g_f1[k] += kk;
+          if (want && kk != 0.f && !(p.probe & 2)) {
+            unsigned long long* sq = s_q + (size_t)k * plane + lo[level];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (t.w[q] != 0.f) fix_add(sq + t.o[q], -kk * t.w[q], to_fix);
+          }
         }
       }
     }
-    if (p.g_fmap1) p.g_fmap1[plane1 + pix] += g_f1;
+    if (p.g_fmap1)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) p.g_fmap1[((size_t)b * p.C + c0 + k) * hw + pix] += g_f1[k];
   }
   __syncthreads();
   for (int level = 0; level < p.L; ++level) {
-    float* out = p.g_f2[level];
-    if (!out) continue;
+    float* out0 = p.g_f2[level];
+    if (!out0) continue;
     const int hwl = (p.h >> level) * (p.w >> level);
-    out += ((size_t)b * p.C + c) * hwl;
-    for (int i = tid; i < hwl; i += kPlaneThreads) out[i] += bad ? __builtin_nanf("") : fix_value(s_q[lo[level] + i], lsb);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      float* out = out0 + ((size_t)b * p.C + c0 + k) * hwl;
+      for (int i = tid; i < hwl; i += THREADS) out[i] += bad ? __builtin_nanf("") : fix_value(s_q[(size_t)k * plane + lo[level] + i], lsb);
+    }
   }
 }
 
@@ -1394,14 +1414,18 @@ extern "C" int mal_coord_sample_l1_bwd(const float* fmap1, const float* const* f
   for (int l = 0; l < L; ++l) { plane_floats += (size_t)(h >> l) * (w >> l); any_f2 = any_f2 || p.g_f2[l]; }
   const size_t lds = plane_floats * sizeof(unsigned long long);
   const bool planes = g_epi_bwd_planes && (g_fmap1 || any_f2) && ws && ws_bytes >= (size_t)B * sizeof(unsigned) &&
-                      lds <= plane_lds_limit((const void*)epi_sample_bwd_planes_kernel);
+                      lds <= plane_lds_limit((const void*)epi_sample_bwd_planes_kernel<1, kPlaneThreads>);
+  // two channel planes per workgroup where both fit (option "epi_bwd_planes" 2, default; 1: one plane, round 3)
+  const bool planes2 = planes && g_epi_bwd_planes >= 2 && (C % 2) == 0 &&
+                       2 * lds <= plane_lds_limit((const void*)epi_sample_bwd_planes_kernel<2, 1024>);
   if (planes) {
     // d/d fmap1, d/d fmap2 levels: one workgroup per (sample, channel), LDS accumulation; d/d coords: the sweep below
     unsigned* gmax = (unsigned*)ws;
     (void)hipMemsetAsync(gmax, 0, (size_t)B * sizeof(unsigned), st);
     const size_t n = (size_t)L * heads * d1 * h * w;
     hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, g_out, n, gmax);
-    hipLaunchKernelGGL(epi_sample_bwd_planes_kernel, dim3(C, B), dim3(kPlaneThreads), lds, st, p, gmax);
+    if (planes2) hipLaunchKernelGGL((epi_sample_bwd_planes_kernel<2, 1024>), dim3(C / 2, B), dim3(1024), 2 * lds, st, p, gmax);
+    else hipLaunchKernelGGL((epi_sample_bwd_planes_kernel<1, kPlaneThreads>), dim3(C, B), dim3(kPlaneThreads), lds, st, p, gmax);
     if (!g_coords) return launch_status();
     p.g_fmap1 = nullptr;
     for (int l = 0; l < L; ++l) p.g_f2[l] = nullptr;

@@ -137,7 +137,7 @@ struct SmoothParams { int n; const float* disp[2]; float* gn[2]; double* partial
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
                          const StepPoses* poses = nullptr, const TieNoise* noise = nullptr,
-                         const SmoothParams* smooth = nullptr, int* tasks_per_sample = nullptr);
+                         const SmoothParams* smooth = nullptr, int* tasks_per_sample = nullptr, bool texel_in = false);
 
 // Philox4x32-10 (Salmon et al., SC'11; the generator behind torch's device randn), one block of four 32-bit words
 MAL_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {

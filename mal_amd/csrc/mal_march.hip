@@ -1591,6 +1591,10 @@ struct IdentParams {
   SmoothParams sm;                            // edge-aware smoothness of up to two disparity maps in the same sweep
 };
 
+// TEXIN: the three images arrive as (B,H,W,3) texels already -- a (B,3,H,W) tensor in torch.channels_last IS that layout --:
+// one 12-byte load per image and pixel instead of three 4-byte ones, and no texel copy is written (p.packed* are NULL: the
+// passes gather from the caller's tensors).
+template <bool TEXIN>
 __global__ __launch_bounds__(64, 3) void pack_identity_kernel(IdentParams p) {
   constexpr int HALO = 1, CW = 62;
   const int id = blockIdx.x;
@@ -1650,6 +1654,11 @@ __global__ __launch_bounds__(64, 3) void pack_identity_kernel(IdentParams p) {
   struct Px { float t[3], a[3], c[3]; };
   auto request = [&](int rr, Px& q) {
     const unsigned bo = (unsigned)(row_of(rr) * W + gxr) * 4u;
+    if (TEXIN) {
+      const texel_t t = ldt(tb, bo * (unsigned)kTexel), a = ldt(s0, bo * (unsigned)kTexel), c = ldt(s1, bo * (unsigned)kTexel);
+      q.t[0] = t.x; q.t[1] = t.y; q.t[2] = t.z; q.a[0] = a.x; q.a[1] = a.y; q.a[2] = a.z; q.c[0] = c.x; q.c[1] = c.y; q.c[2] = c.z;
+      return;
+    }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       q.t[ch] = ldf(tb + (size_t)ch * HW, bo); q.a[ch] = ldf(s0 + (size_t)ch * HW, bo); q.c[ch] = ldf(s1 + (size_t)ch * HW, bo);
@@ -1797,6 +1806,7 @@ extern int g_syn_rows;        // mal_photo_march.hip
 extern int g_syn_queue;       // mal_photo_march.hip
 extern int g_step_overlap;    // mal_step.hip
 extern int g_student_overlap; // mal_step.hip
+extern int g_side_priority;   // mal_step.hip
 extern int g_march_halo1;     // mal_step.hip
 extern int g_temporal_spec;   // mal_step.hip
 int g_march_lean = 1;         // option "march_lean": the teacher's passes without the optional operands' code (0: generic, A/B)
@@ -1939,7 +1949,8 @@ int pack_identity_tasks_per_sample(int H, int W) { return ((W + 61) / 62) * ((H 
 
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
-                         const StepPoses* poses, const TieNoise* noise, const SmoothParams* smooth, int* tasks_per_sample) {
+                         const StepPoses* poses, const TieNoise* noise, const SmoothParams* smooth, int* tasks_per_sample,
+                         bool texel_in) {
   IdentParams p = {};
   if (noise) p.tn = *noise;
   if (smooth) p.sm = *smooth;
@@ -1953,7 +1964,11 @@ int pack_identity_launch(const float* target, const float* src0, const float* sr
   p.ntasks = B * p.strips * p.segs;
   p.per_xcd = (p.ntasks + 7) / 8;
   if (tasks_per_sample) *tasks_per_sample = p.strips * p.segs;
-  hipLaunchKernelGGL(pack_identity_kernel, dim3(p.per_xcd * 8 + p.pose_blocks), dim3(64), 0, st, p);
+  if (texel_in) {
+    if (packed0 || packed1 || packed_target) return MAL_EINVAL;  // nothing to repack: the inputs are the texels
+    hipLaunchKernelGGL(pack_identity_kernel<true>, dim3(p.per_xcd * 8 + p.pose_blocks), dim3(64), 0, st, p);
+  } else
+  hipLaunchKernelGGL(pack_identity_kernel<false>, dim3(p.per_xcd * 8 + p.pose_blocks), dim3(64), 0, st, p);
   return launch_status();
 }
 
@@ -2004,12 +2019,13 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("step_overlap")) { if (value < 0 || value > 2) return MAL_EINVAL; g_step_overlap = value; return MAL_OK; }
   if (eq("march_halo1")) { g_march_halo1 = value != 0; return MAL_OK; }
   if (eq("student_overlap")) { g_student_overlap = value != 0; return MAL_OK; }
+  if (eq("side_priority")) { g_side_priority = value != 0; return MAL_OK; }  // read when a side stream is first created
   if (eq("temporal_spec")) { if (!kExp && value) return MAL_EINVAL; g_temporal_spec = value != 0; return MAL_OK; }
   if (eq("march3")) { if (!kExp && value) return MAL_EINVAL; g_march3 = value != 0; return MAL_OK; }
   if (eq("march_lean")) { g_march_lean = value != 0; return MAL_OK; }
   if (eq("syn_queue")) { if (!kExp && value) return MAL_EINVAL; g_syn_queue = value != 0; return MAL_OK; }
   if (eq("syn_rows")) { if (value < 2 || value > 64) return MAL_EINVAL; g_syn_rows = value; return MAL_OK; }
-  if (eq("epi_bwd_planes")) { g_epi_bwd_planes = value != 0; return MAL_OK; }
+  if (eq("epi_bwd_planes")) { if (value < 0 || value > 2) return MAL_EINVAL; g_epi_bwd_planes = value; return MAL_OK; }
   if (eq("epi_probe")) { g_epi_probe = value; return MAL_OK; }
   if (eq("march_flip")) { g_march_flip = value != 0; return MAL_OK; }
   if (eq("pack_rows")) { if (value < 4 || value > 4096) return MAL_EINVAL; g_pack_rows = value; return MAL_OK; }

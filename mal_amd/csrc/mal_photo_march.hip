@@ -22,6 +22,7 @@ namespace mal {
 
 struct PhotoMarchParams {
   const float* target; const float* cand[2];   // planar (B,3,H,W)
+  int target_texels;                            // the target is (B,H,W,3) texels instead (request9)
   int idx[2];                                   // the candidates' indices in the caller's list; idx[1] < 0: single candidate
   const float* ident; const float* noise; const float* ext_mask;
   const float* prev_min; const uint8_t* prev_arg;   // running min / argmin of earlier pairs (nullable)
@@ -58,6 +59,13 @@ struct Px9 { float t[3], a[3], c[3]; };
 MAL_DEV void request9(const PhotoMarchParams& p, const float* tb, const float* ab, const float* cb, int HW, int row,
                       int gxr, Px9& q) {
   const unsigned bo = (unsigned)(row * p.W + gxr) * 4u;
+  if (p.target_texels) {  // wave-uniform: the target as (B,H,W,3) texels (the step's packed copy / a channels_last input)
+    const texel_t t = ldt(tb, bo * (unsigned)kTexel);
+    q.t[0] = t.x; q.t[1] = t.y; q.t[2] = t.z;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { q.a[ch] = ldf(ab + (size_t)ch * HW, bo); q.c[ch] = ldf(cb + (size_t)ch * HW, bo); }
+    return;
+  }
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
     q.t[ch] = ldf(tb + (size_t)ch * HW, bo); q.a[ch] = ldf(ab + (size_t)ch * HW, bo); q.c[ch] = ldf(cb + (size_t)ch * HW, bo);
@@ -700,11 +708,11 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
                            float* g_region1, unsigned* order, unsigned* order_count, const float* orig0, const float* orig1,
-                           size_t orig_stride) {
+                           size_t orig_stride, int target_texels) {
   if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
   if ((orig0 == nullptr) != (orig1 == nullptr) || (orig0 && !region)) return MAL_EINVAL;
   PhotoMarchParams p = {};
-  p.target = target; p.B = B; p.H = H; p.W = W;
+  p.target = target; p.target_texels = target_texels; p.B = B; p.H = H; p.W = W;
   p.cand[0] = cand0; p.cand[1] = cand1; p.idx[0] = idx0; p.idx[1] = idx0 + 1;
   p.prev_min = prev_min; p.prev_arg = prev_arg; p.ident = ident; p.noise = noise;
   p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;

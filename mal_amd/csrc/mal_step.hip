@@ -29,10 +29,10 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
                            float* g_region1, unsigned* order, unsigned* order_count, const float* orig0, const float* orig1,
-                           size_t orig_stride);
+                           size_t orig_stride, int target_texels);
 
 constexpr int kLossSlots = 16;
-constexpr int kEpiBlocks = 64;  // workgroups per sample of step_epilogue_kernel (its per-block partials are summed in block order)
+constexpr int kEpiBlocks = 64;  // epilogue workgroups per sample in the final launch (their partials are summed in block order)
 
 struct StepWs {
   float* packed[3];   // target, src-1, src+1 as (B,H,W,kTexel) texels
@@ -92,6 +92,75 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   return w;
 }
 
+// The consistency / distillation terms of the student (loss_utils.py:193-254) as a launch of their own -- the --temporal step:
+// they are pointwise in the two depths and in the three per-pixel minima (the distillation index is not differentiable, the
+// gradient reaches multi_depth directly, not through the warp), so the student's marching pass need not wait for the
+// teacher's four-way min and runs beside the temporal hint's producer; this launch follows the join.  The arithmetic is the
+// epilogue of march_body, statement for statement (weight = consistency mask x matching mask x (1 - augmentation), as the
+// pass forms it; depth_of, the argmin's first-minimum rule, sign conventions); sums leave as per-block partials.  (Riding as
+// leading workgroups of step_final_kernel -- one launch less -- was built and measured SLOWER, 0.330 against 0.3255 ms: 768 more
+// workgroups each pay an agent-scope release and a ticket atomic where a kernel boundary publishes for free; n_epi = 0 now.)
+struct EpiParams {
+  const float *disp_s, *disp_t, *mono_reproj, *ens_reproj, *multi_reproj, *ext_mask, *lowest_cost, *sample_scale, *ens_disp;
+  int scale_is_mask, dual;
+  float min_disp, range, merge_cons, merge_distil;
+  float *G_c, *G_e; double* partials; unsigned* dbg; int B, HW;
+};
+MAL_DEV void step_epilogue_block(const EpiParams& p, int bid) {
+  __shared__ double s_red[2][4];
+  const int b = bid / kEpiBlocks, blk = bid - b * kEpiBlocks, tid = threadIdx.x;
+  const int per = (p.HW + kEpiBlocks - 1) / kEpiBlocks, lo = blk * per, hi = min(lo + per, p.HW);
+  const float sscale = p.sample_scale ? (p.scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
+  const bool has_er = p.ens_reproj != nullptr, learnt = p.ens_disp != nullptr;
+  float acc_cons = 0.f, acc_dist = 0.f;
+  for (int i0 = lo + tid; i0 < hi; i0 += 256) {
+    const size_t i = (size_t)b * p.HW + i0;
+    // the weight of the student's masked reprojection term, as its pass forms it (march_body, stage S)
+    float em = p.ext_mask[i];
+    {
+      const float mono = depth_of(p.disp_t[i], p.min_disp, p.range);
+      const float matching = div_safe_(1.0f, p.lowest_cost[i]);
+      const bool ok = (div_safe_(matching - mono, mono) < 1.0f) && (div_safe_(mono - matching, matching) < 1.0f);
+      em = ok ? em : em * 0.0f;
+    }
+    float w = 1.0f;
+    w *= em;
+    w *= sscale;
+    const float rp = p.multi_reproj[i];
+    // march_body::epilogue
+    const float dm = depth_of(p.disp_s[i], p.min_disp, p.range);
+    const float ddepth = -(dm * dm) * p.range;
+    const float dmono = depth_of(p.disp_t[i], p.min_disp, p.range);
+    const float m = w, cm = 1.0f - m, mm = 1.0f - cm;
+    const float dc = dm - dmono;
+    acc_cons += fabsf(dc) * cm;
+    int idx = 0;
+    float best = p.mono_reproj[i];
+    if (has_er) {
+      const float r_ens = p.ens_reproj[i];
+      if (r_ens < best) { best = r_ens; idx = 1; }
+    }
+    if (rp < best) idx = 2;
+    float dens = 0.f, ens = (dmono + dm) / 2.0f;
+    if (learnt) { dens = depth_of(p.ens_disp[i], p.min_disp, p.range); ens = dens; }
+    const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
+    const float dd = target - dm;
+    acc_dist += fabsf(dd) * mm;
+    if (p.dbg) p.dbg[(size_t)MAL_DEC_DISTIL * ((size_t)p.B * p.HW) + i] = (unsigned)idx;
+    const float gc = sgnf(dc) * cm * ddepth;
+    const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : (learnt ? -1.0f : -0.5f))) * mm * ddepth;
+    if (learnt && p.G_e) p.G_e[i] = idx == 1 ? p.merge_distil * (sgnf(dd) * mm * (-(dens * dens) * p.range)) : 0.0f;
+    if (p.dual && p.G_e) p.G_e[i] = idx == 0 ? p.merge_distil * (sgnf(dd) * mm * (-(dmono * dmono) * p.range)) : 0.0f;
+    p.G_c[i] = fma_(p.merge_cons, gc, p.merge_distil * gd);
+  }
+  const double r0 = wave_sum_d((double)acc_cons), r1 = wave_sum_d((double)acc_dist);
+  if ((tid & 63) == 0) { s_red[0][tid >> 6] = r0; s_red[1][tid >> 6] = r1; }
+  __syncthreads();
+  if (tid < 2) p.partials[((size_t)b * kEpiBlocks + blk) * 2 + tid] = (s_red[tid][0] + s_red[tid][1]) + (s_red[tid][2] + s_red[tid][3]);
+}
+
+__global__ __launch_bounds__(256) void step_epilogue_kernel(EpiParams p) { step_epilogue_block(p, (int)blockIdx.x); }
+
 // ---------------------------------------------------------------- small kernels
 // Everything after the three passes, fixed summation order, no floating-point atomics.  3B blocks:
 //   blocks [0, 2B):  ps[pass][b][j] = sum over the sample's tasks (contiguous) of the per-task partials: j < 4 from the
@@ -106,14 +175,18 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
                                                          const float* K, int per_sample, int per_sample_t, int B, int H, int W,
                                                          float w_main, float w_distil, double* ps, float* gT0, float* gT1,
                                                          double* stats, float* losses, float* coefs, float* loss_total,
-                                                         unsigned* ticket, unsigned long long* noise_counter) {
+                                                         unsigned* ticket, unsigned long long* noise_counter, EpiParams epi,
+                                                         int n_epi) {
   __shared__ double s_part[256];
   __shared__ double s_gP[24];
   __shared__ double sh_tot[2][8];
   __shared__ unsigned s_last;
   const int tid = threadIdx.x, HW = H * W;
-  if ((int)blockIdx.x < 2 * B) {
-    const int pass = blockIdx.x / B, b = blockIdx.x - pass * B;
+  const int bid = (int)blockIdx.x - n_epi;  // the first n_epi workgroups: the student's consistency / distillation terms
+  if (bid < 0) {
+    step_epilogue_block(epi, (int)blockIdx.x);
+  } else if (bid < 2 * B) {
+    const int pass = bid / B, b = bid - pass * B;
     const int j = tid & 7, sub = tid >> 3;  // 32 strided partial sums per quantity
     // temporal hint: the teacher's sum(rp*w), sum(w) come from the materialised-candidate kernel ([task][2])
     // temporal hint: the teacher's sums are those of the pass in front of the producer (bs_t, its own decomposition:
@@ -124,11 +197,13 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
                              : bs_p + (size_t)b * per_sample_p * 8 + pass * 4 + (j - 4);
     const int n_t = j < 4 ? ps_pass : per_sample_p;
     double acc = 0.0;
-    if (bs_d && pass == 1 && (j == 2 || j == 3)) {
-      // the consistency / distillation sums of the student come from step_epilogue_kernel's per-block partials (fixed order)
+    if (bs_d && n_epi == 0 && pass == 1 && (j == 2 || j == 3)) {
+      // the consistency / distillation sums of the student come from step_epilogue_kernel's per-block partials (block order)
       const double* bd = bs_d + (size_t)b * kEpiBlocks * 2 + (j - 2);
 #pragma unroll 8
       for (int t = sub; t < kEpiBlocks; t += 32) acc += bd[(size_t)t * 2];
+    } else if (bs_d && pass == 1 && (j == 2 || j == 3)) {
+      // (n_epi > 0: the epilogue blocks belong to this launch; the block that finishes last adds their partials, below)
     } else {
 #pragma unroll 8
     for (int t = sub; t < n_t; t += 32) acc += bs[(size_t)t * 8];  // independent loads: issue them together
@@ -146,7 +221,7 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
       ps[((size_t)pass * B + b) * 8 + tid] = a;
     }
   } else if (bgP != nullptr) {
-    const int b = blockIdx.x - 2 * B;
+    const int b = bid - 2 * B;
     // 24 sums of per_sample partials: 10 threads per value (240 of 256), then a 10-term sum (fixed order)
     const int v = tid % 24, sub = tid / 24;
     double acc = 0.0;
@@ -170,23 +245,42 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
       (f ? gT1 : gT0)[b * 16 + e] = (float)a;
     }
   }
-  // ---- the last block to get here does the scalar epilogue
-  __threadfence();
+  // ---- the last block to get here does the scalar epilogue.  Publishing: every wave waits for its own stores, the workgroup
+  // meets, ONE lane releases at agent scope and takes the ticket (with the 768 epilogue workgroups in this launch a
+  // __threadfence() by all 256 threads of every workgroup -- an L2 write-back plus an invalidate each -- cost 40 us).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) s_last = atomicAdd(ticket, 1u);
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(ticket, 1u);
+  }
   __syncthreads();
   if (s_last != gridDim.x - 1) return;
-  __threadfence();
+  __threadfence();  // (the one workgroup that continues: acquire what the others published)
   // sums over samples, fixed order; slots 4, 5 (smoothness) are weighted by the sample's 1/(mean+1e-7).  One
   // thread per (pass, sample, slot) fetches and weighs its term (a single round trip for all of them), 16 threads
   // then add the B terms in sample order.
   constexpr int kMaxStepB = 64;  // beyond this the terms are re-fetched by the summing threads instead of staged in LDS
   __shared__ double s_term[2 * kMaxStepB * 8];
+  __shared__ double s_epi[2 * kMaxStepB];
   const bool staged = B <= kMaxStepB;
+  if (bs_d && n_epi > 0) {  // per-sample sums of the epilogue blocks' partials, block order (thread 2b+jj: sample b, jj = consistency / distillation)
+    for (int i = tid; i < 2 * B; i += 256) {
+      const double* bd = bs_d + (size_t)(i >> 1) * kEpiBlocks * 2 + (i & 1);
+      double a = 0.0;
+      for (int t = 0; t < kEpiBlocks; ++t) a += bd[(size_t)t * 2];
+      ps[((size_t)B + (i >> 1)) * 8 + 2 + (i & 1)] = a;
+      if (staged) s_epi[i] = a;  // (read back from LDS below, not through the vector cache)
+    }
+    __threadfence();
+    __syncthreads();
+  }
   for (int i = tid; staged && i < 2 * B * 8; i += 256) {
     const int j = i & 7;
     const double* q = ps + (size_t)(i >> 3) * 8;
     double v = q[j];
+    if (bs_d && n_epi > 0 && (i >> 3) >= B && (j == 2 || j == 3)) v = s_epi[((i >> 3) - B) * 2 + (j - 2)];
     if (j == 4 || j == 5) {
       const float m = (float)(q[7] / (double)HW) + 1e-7f;
       v = v * (double)div_(1.0f, m);
@@ -242,71 +336,6 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
   coefs[2] = (float)((double)w_main / N);                   // consistency map
   coefs[3] = (float)((double)w_distil / N);                 // distillation map
   coefs[4] = w_main * 1e-3f;                                // smoothness
-}
-
-// The consistency / distillation terms of the student (loss_utils.py:193-254) as a launch of their own -- the --temporal step:
-// they are pointwise in the two depths and in the three per-pixel minima (the distillation index is not differentiable, the
-// gradient reaches multi_depth directly, not through the warp), so the student's marching pass need not wait for the
-// teacher's four-way min and runs beside the temporal hint's producer; this launch follows the join.  The arithmetic is the
-// epilogue of march_body, statement for statement (weight = consistency mask x matching mask x (1 - augmentation), as the
-// pass forms it; depth_of, the argmin's first-minimum rule, sign conventions); sums leave as per-block partials.
-struct EpiParams {
-  const float *disp_s, *disp_t, *mono_reproj, *ens_reproj, *multi_reproj, *ext_mask, *lowest_cost, *sample_scale, *ens_disp;
-  int scale_is_mask, dual;
-  float min_disp, range, merge_cons, merge_distil;
-  float *G_c, *G_e; double* partials; unsigned* dbg; int B, HW;
-};
-__global__ __launch_bounds__(256) void step_epilogue_kernel(EpiParams p) {
-  __shared__ double s_red[2][4];
-  const int b = blockIdx.x / kEpiBlocks, blk = blockIdx.x - b * kEpiBlocks, tid = threadIdx.x;
-  const int per = (p.HW + kEpiBlocks - 1) / kEpiBlocks, lo = blk * per, hi = min(lo + per, p.HW);
-  const float sscale = p.sample_scale ? (p.scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
-  const bool has_er = p.ens_reproj != nullptr, learnt = p.ens_disp != nullptr;
-  float acc_cons = 0.f, acc_dist = 0.f;
-  for (int i0 = lo + tid; i0 < hi; i0 += 256) {
-    const size_t i = (size_t)b * p.HW + i0;
-    // the weight of the student's masked reprojection term, as its pass forms it (march_body, stage S)
-    float em = p.ext_mask[i];
-    {
-      const float mono = depth_of(p.disp_t[i], p.min_disp, p.range);
-      const float matching = div_safe_(1.0f, p.lowest_cost[i]);
-      const bool ok = (div_safe_(matching - mono, mono) < 1.0f) && (div_safe_(mono - matching, matching) < 1.0f);
-      em = ok ? em : em * 0.0f;
-    }
-    float w = 1.0f;
-    w *= em;
-    w *= sscale;
-    const float rp = p.multi_reproj[i];
-    // march_body::epilogue
-    const float dm = depth_of(p.disp_s[i], p.min_disp, p.range);
-    const float ddepth = -(dm * dm) * p.range;
-    const float dmono = depth_of(p.disp_t[i], p.min_disp, p.range);
-    const float m = w, cm = 1.0f - m, mm = 1.0f - cm;
-    const float dc = dm - dmono;
-    acc_cons += fabsf(dc) * cm;
-    int idx = 0;
-    float best = p.mono_reproj[i];
-    if (has_er) {
-      const float r_ens = p.ens_reproj[i];
-      if (r_ens < best) { best = r_ens; idx = 1; }
-    }
-    if (rp < best) idx = 2;
-    float dens = 0.f, ens = (dmono + dm) / 2.0f;
-    if (learnt) { dens = depth_of(p.ens_disp[i], p.min_disp, p.range); ens = dens; }
-    const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
-    const float dd = target - dm;
-    acc_dist += fabsf(dd) * mm;
-    if (p.dbg) p.dbg[(size_t)MAL_DEC_DISTIL * ((size_t)p.B * p.HW) + i] = (unsigned)idx;
-    const float gc = sgnf(dc) * cm * ddepth;
-    const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : (learnt ? -1.0f : -0.5f))) * mm * ddepth;
-    if (learnt && p.G_e) p.G_e[i] = idx == 1 ? p.merge_distil * (sgnf(dd) * mm * (-(dens * dens) * p.range)) : 0.0f;
-    if (p.dual && p.G_e) p.G_e[i] = idx == 0 ? p.merge_distil * (sgnf(dd) * mm * (-(dmono * dmono) * p.range)) : 0.0f;
-    p.G_c[i] = fma_(p.merge_cons, gc, p.merge_distil * gd);
-  }
-  const double r0 = wave_sum_d((double)acc_cons), r1 = wave_sum_d((double)acc_dist);
-  if ((tid & 63) == 0) { s_red[0][tid >> 6] = r0; s_red[1][tid >> 6] = r1; }
-  __syncthreads();
-  if (tid < 2) p.partials[((size_t)b * kEpiBlocks + blk) * 2 + tid] = (s_red[tid][0] + s_red[tid][1]) + (s_red[tid][2] + s_red[tid][3]);
 }
 
 // d total / d disp for both maps; block 0 also scales the pose gradients and runs the backward of
@@ -460,6 +489,13 @@ extern "C" size_t mal_step_workspace_bytes(int B, int H, int W) {
   return carve_step(nullptr, B, H, W).bytes;
 }
 
+// MAL_STEP_TEXEL_INPUTS: the caller's three images ARE the (B,H,W,3) texel images (torch.channels_last): nothing is repacked
+static void use_texel_inputs(const mal_step_args* a, StepWs& w) {
+  if (a->flags & MAL_STEP_TEXEL_INPUTS) {
+    w.packed[0] = const_cast<float*>(a->color0); w.packed[1] = const_cast<float*>(a->color_m1); w.packed[2] = const_cast<float*>(a->color_p1);
+  }
+}
+
 static int step_check(const mal_step_args* a) {
   if (!a) return MAL_EINVAL;
   int rc = check_shape(a->B, a->H, a->W);
@@ -497,8 +533,9 @@ static int first_sweep(const mal_step_args* a, const StepWs& w, hipStream_t st, 
   SmoothParams sm = {};
   sm.n = 2; sm.disp[0] = a->disp_teacher; sm.disp[1] = a->disp_student; sm.gn[0] = w.gn_t; sm.gn[1] = w.gn_s;
   sm.partials = w.bs_p; sm.dec[0] = a->dec_teacher; sm.dec[1] = a->dec_student;
-  return pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
-                              &sp, &tn, &sm, per_sample_p);
+  const bool tex = (a->flags & MAL_STEP_TEXEL_INPUTS) != 0;
+  return pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, tex ? nullptr : w.packed[1], tex ? nullptr : w.packed[2],
+                              tex ? nullptr : w.packed[0], w.ident, st, &sp, &tn, &sm, per_sample_p, tex);
 }
 
 namespace mal { int g_march_halo1 = 1; }   // option "march_halo1": one-row halo of the step's gradient passes (0: two rows, A/B)
@@ -534,7 +571,7 @@ static int launch_ensemble(const mal_step_args* a, const StepWs& w, float* ens_r
 }
 
 // the student's pass (trainer.py:592-612): with `epi` the consistency / distillation epilogue rides in it (the step without the
-// temporal hint); without, it leaves its per-pixel min in multi_reproj and step_epilogue_kernel forms those terms later
+// temporal hint); without, it leaves its per-pixel min in multi_reproj and the final launch forms those terms later
 static int launch_student(const mal_step_args* a, const StepWs& w, float* mono_reproj, float* ens_reproj, float* multi_reproj,
                           bool epi, hipStream_t st, int* per_sample) {
   const int B = a->B, H = a->H, W = a->W;
@@ -560,8 +597,8 @@ static int launch_student(const mal_step_args* a, const StepWs& w, float* mono_r
   if (per_sample) *per_sample = p.strips * p.segs;
   return rc;
 }
-static int launch_epilogue(const mal_step_args* a, const StepWs& w, const float* mono_reproj, const float* ens_reproj,
-                           const float* multi_reproj, hipStream_t st) {
+static EpiParams epilogue_params(const mal_step_args* a, const StepWs& w, const float* mono_reproj, const float* ens_reproj,
+                                 const float* multi_reproj) {
   const int B = a->B, H = a->H, W = a->W;
   MarchParams mp = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
   EpiParams e = {};
@@ -572,8 +609,7 @@ static int launch_epilogue(const mal_step_args* a, const StepWs& w, const float*
   e.min_disp = mp.min_disp; e.range = mp.range;
   e.merge_cons = (float)((double)a->w_main / ((double)B * H * W)); e.merge_distil = (float)((double)a->w_distil / ((double)B * H * W));
   e.G_c = w.G_c; e.G_e = (a->ens_disp || e.dual) ? w.G_e : nullptr; e.partials = w.bs_d; e.dbg = a->dec_student; e.B = B; e.HW = H * W;
-  hipLaunchKernelGGL(step_epilogue_kernel, dim3((unsigned)(B * kEpiBlocks)), dim3(256), 0, st, e);
-  return launch_status();
+  return e;
 }
 
 // Temporal hint: between the warp pass and the fused sweep the device runs the producer's small, latency-bound kernels
@@ -592,6 +628,7 @@ namespace mal { int g_temporal_spec = 0; }  // settable in -DMAL_EXPERIMENTS bui
 // caller stream that finds it full shares slot 0 of its device, and every _fwd of a forked step waits for the slot's join
 // event whatever `pending` says, so sharing costs ordering, never correctness.  Lookups are serialised by a mutex; the
 // launches themselves are the caller's (one thread per stream, as for every HIP stream).
+namespace mal { int g_side_priority = 1; }
 struct SideStream { hipStream_t caller; hipStream_t s; hipEvent_t fork, join; bool ok, init, pending; int dev; };
 static SideStream* side_stream(hipStream_t caller) {
   constexpr int kSlots = 64;
@@ -618,7 +655,12 @@ static SideStream* side_stream(hipStream_t caller) {
     if (!all[i].init) {
       slot = &all[i];
       slot->init = true; slot->dev = dev; slot->caller = caller; slot->pending = false;
-      slot->ok = hipStreamCreateWithFlags(&slot->s, hipStreamNonBlocking) == hipSuccess &&
+      // lowest priority: what is forked here (ensemble + student marching passes) should yield wave slots to the producer
+      // chain and the fused sweep on the caller's stream, which are the critical path (option "side_priority" 0: default priority)
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      slot->ok = (g_side_priority ? hipStreamCreateWithPriority(&slot->s, hipStreamNonBlocking, least)
+                                  : hipStreamCreateWithFlags(&slot->s, hipStreamNonBlocking)) == hipSuccess &&
                  hipEventCreateWithFlags(&slot->fork, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&slot->join, hipEventDisableTiming) == hipSuccess;
       (void)hipGetLastError();
@@ -674,6 +716,7 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   if (rc) return rc;
   if (!(a->flags & MAL_STEP_TEMPORAL) || !a->warp_m1 || !a->warp_p1) return MAL_EINVAL;
   StepWs w = carve_step(a->ws, a->B, a->H, a->W);
+  use_texel_inputs(a, w);
   hipStream_t st = (hipStream_t)a->stream;
   rc = join_side(st);  // a previous step that was abandoned after its fork (no _fwd, no _abort)
   if (rc) return rc;
@@ -713,6 +756,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   if (rc) return rc;
   const int B = a->B, H = a->H, W = a->W;
   StepWs w = carve_step(a->ws, B, H, W);
+  use_texel_inputs(a, w);
   hipStream_t st = (hipStream_t)a->stream;
   const bool no_ens = a->flags & MAL_STEP_NO_ENS, temporal = a->flags & MAL_STEP_TEMPORAL;
   float* mono_reproj = a->mono_reproj ? a->mono_reproj : w.mono_reproj;
@@ -747,15 +791,18 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
       if (rc) return rc;
     }
     per_sample_p = pack_identity_tasks_per_sample(H, W);
-    rc = photo_march_fused_more(a->color0, a->syn_m1, a->syn_p1, 2, w.ident, a->noise, w.rp_warp, w.arg_warp, B, H, W,
+    rc = photo_march_fused_more(w.packed[0], a->syn_m1, a->syn_p1, 2, w.ident, a->noise, w.rp_warp, w.arg_warp, B, H, W,
                                 mono_reproj, w.arg_t, w.w_t, w.bs_ph, a->g_syn_m1, a->g_syn_p1, &per_sample_ph, st, a->syn_region,
                                 a->g_syn_region_m1, a->g_syn_region_p1, w.order, w.ticket + 1,
-                                sparse ? a->warp_m1 : nullptr, sparse ? a->warp_p1 : nullptr, (size_t)a->warp_sample_stride);
+                                sparse ? a->warp_m1 : nullptr, sparse ? a->warp_p1 : nullptr, (size_t)a->warp_sample_stride,
+                                1 /* the target as texels: one 12-byte load instead of three planes */);
     if (rc) { (void)join_side(st); return rc; }
   }
   // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp -- and so
   // was the student's marching pass (without its epilogue)
   const bool ens_forked = temporal && ensemble_forked(a), stu_forked = temporal && student_forked(a);
+  EpiParams epi = {};
+  int n_epi = 0;
   if (ens_forked || stu_forked) {
     rc = join_side(st, true);
     if (rc) return rc;
@@ -769,7 +816,9 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     int strips = 0, segs = 0;
     march_geometry(B, H, W, MAL_F_GRAD, &strips, &segs, nullptr);
     per_sample = strips * segs;
-    rc = launch_epilogue(a, w, mono_reproj, ens_reproj, a->multi_reproj ? a->multi_reproj : w.multi_reproj, st);
+    epi = epilogue_params(a, w, mono_reproj, ens_reproj, a->multi_reproj ? a->multi_reproj : w.multi_reproj);
+    hipLaunchKernelGGL(step_epilogue_kernel, dim3((unsigned)(B * kEpiBlocks)), dim3(256), 0, st, epi);
+    rc = launch_status();
     if (rc) return rc;
   } else {
     // student pass with the consistency / distillation epilogue
@@ -777,11 +826,11 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     if (rc) return rc;
   }
   // per-sample sums of both gradient passes, pose gradients (temporal: in _bwd, after the teacher's sweep), scalars
-  hipLaunchKernelGGL(step_final_kernel, dim3(temporal ? 2 * B : 3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, temporal ? nullptr : w.bgP,
+  hipLaunchKernelGGL(step_final_kernel, dim3(n_epi + (temporal ? 2 * B : 3 * B)), dim3(256), 0, st, w.bs_t, w.bs_s, temporal ? nullptr : w.bgP,
                      w.bs_p, per_sample_p, temporal ? w.bs_ph : nullptr, per_sample_ph, stu_forked ? w.bs_d : nullptr, a->K,
                      per_sample, per_sample_t, B, H, W,
                      a->w_main, a->w_distil, w.ps, w.gT[0], w.gT[1], w.sm_stats, a->losses, w.coefs, a->loss_total,
-                     w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr);
+                     w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr, epi, n_epi);
   return launch_status();
 }
 
@@ -795,6 +844,7 @@ extern "C" int mal_loss_step_teacher_replay(const mal_step_args* a, int launches
   if (rc) return rc;
   if ((a->flags & MAL_STEP_TEMPORAL) || launches <= 0 || launches > 4096) return MAL_EINVAL;
   StepWs w = carve_step(a->ws, a->B, a->H, a->W);
+  use_texel_inputs(a, w);
   float* mono_reproj = a->mono_reproj ? a->mono_reproj : w.mono_reproj;
   for (int i = 0; i < launches; ++i) {
     rc = launch_teacher(a, w, mono_reproj, (hipStream_t)a->stream);
@@ -808,6 +858,7 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   if (rc) return rc;
   const int B = a->B, H = a->H, W = a->W, HW = H * W;
   StepWs w = carve_step(a->ws, B, H, W);
+  use_texel_inputs(a, w);
   hipStream_t st = (hipStream_t)a->stream;
   int per_sample_t = 0;
   bool teacher_done = false;

@@ -54,7 +54,13 @@ def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, tempora
         tens.append(req(ens_disp, "ens_disp"))
         if tuple(tens[6].shape) != tuple(tens[0].shape):
             raise L.MalError("loss_step: outputs['ens_disp'] must have the shape of the disparities")
-    cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest)]
+    # Zero-copy texels: three (B,3,H,W) images in torch.channels_last memory format ARE the (B,H,W,3) texel images the passes
+    # gather from -- the step then skips the re-layout of its first sweep (MAL_STEP_TEXEL_INPUTS; same results bit for bit).
+    # A loader gets there with `.contiguous(memory_format=torch.channels_last)` on the host tensor.
+    texel_inputs = all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.shape[1] == 3 and not t.is_contiguous()
+                       and t.is_contiguous(memory_format=torch.channels_last) for t in (color0, color_m1, color_p1))
+    cons = [t if texel_inputs else req(t, "input") for t in (color0, color_m1, color_p1)]
+    cons += [req(t, "input") for t in (K, inv_K, cmask, keep, lowest)]
     cons.append(None if noise is None else req(noise, "input"))
     B, _, H, W = tens[0].shape
     dev = tens[0].device
@@ -62,7 +68,8 @@ def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, tempora
     a.B, a.H, a.W = B, H, W
     a.min_depth, a.max_depth = float(min_depth), float(max_depth)
     a.flags = (L.STEP_NO_ENS if no_ens else 0) | (L.STEP_AUG_MASK if aug_is_mask else 0) | (L.STEP_TEMPORAL if temporal else 0) | \
-              (L.STEP_DUAL_DISTIL if (dual and no_ens) else 0)  # upstream reads dual_distil on the two-way branch only
+              (L.STEP_DUAL_DISTIL if (dual and no_ens) else 0) | \
+              (L.STEP_TEXEL_INPUTS if texel_inputs else 0)  # (upstream reads dual_distil on the two-way branch only)
     if philox is not None:  # (seed, want the drawn values back)
         a.flags |= L.STEP_NOISE_PHILOX
         a.noise_seed = int(philox[0]) & 0xFFFFFFFFFFFFFFFF

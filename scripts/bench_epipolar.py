@@ -128,3 +128,17 @@ with torch.no_grad():
 print("forward-motion poses (t = (0.03 N, 0, 0.15), same rotation): HIP %.0f us -> %.1f G wave-loads/s = %.2f of the coalesced ceiling, "
       "%.2f of the 4-line ceiling" % (thf * 1e6, wave_loads / thf / 1e9, wave_loads / thf / WAVE_LOAD_CEILING[1],
                                       wave_loads / thf / WAVE_LOAD_CEILING[4]))
+
+# ---- round 4: two channel planes per workgroup in the lookup's backward (option "epi_bwd_planes" 2, default) against one
+from mal_amd import _lib
+lib = _lib.load()
+for mode in (1, 2, 1, 2):
+    lib.mal_set_option(b"epi_bwd_planes", mode)
+    for _ in range(3): hip_fb()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10): hip_fb()
+    torch.cuda.synchronize()
+    print("lookup forward + backward, epi_bwd_planes=%d (%s): %.0f us" %
+          (mode, "two channel planes per workgroup, 1024 threads" if mode == 2 else "one plane per workgroup, 512 threads",
+           (time.perf_counter() - t) / 10 * 1e6))
+lib.mal_set_option(b"epi_bwd_planes", 2)

@@ -345,3 +345,41 @@ def test_a_backward_after_a_later_forward_of_the_same_shape_is_refused():
     held[1][0].backward()  # the latest forward still owns the workspace
     torch.cuda.synchronize()
     assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in held[1][1].values())
+
+
+@pytest.mark.parametrize("temporal", [False, True], ids=["distil", "temporal"])
+def test_channels_last_inputs_are_the_texels(temporal):
+    """Zero-copy texels: the three images handed over in torch.channels_last memory format are used as the (B,H,W,3) texel
+    images directly (MAL_STEP_TEXEL_INPUTS: the first sweep writes no texel copy) -- losses and every gradient are
+    bit-identical to the NCHW step (the same loads, in another place)."""
+    from mal_amd import step, trainer
+    from mal_amd.synthetic import make_batch
+    B, H, W = 3, 40, 130
+    batch = make_batch(B, H, W, seed=17, with_syn=temporal)
+    g = torch.Generator().manual_seed(4)
+    noise = torch.randn(B, 1, H, W, generator=g).to(DEV)
+    opt = trainer.default_options(height=H, width=W, batch_size=B, temporal=temporal)
+    synth = HH.producer_of(batch, torch.device(DEV)) if temporal else None
+
+    def run(channels_last):
+        inputs, mono_outputs, outputs, leaves = to_dicts(batch, lambda a, t, inv: None, device=torch.device(DEV))
+        for f, s in ((-1, "m1"), (1, "p1")):
+            mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + s]
+            mono_outputs[("translation", 0, f)] = leaves["translation_" + s]
+        if channels_last:
+            for f in (0, -1, 1):
+                inputs[("color", f, 0)] = inputs[("color", f, 0)].contiguous(memory_format=torch.channels_last)
+                assert not inputs[("color", f, 0)].is_contiguous()
+        losses, _, maps = step.loss_step(opt, inputs, mono_outputs, outputs, noise=noise.clone(), image_synthesis=synth)
+        losses["loss"].backward()
+        torch.cuda.synchronize()
+        return ({k: float(v.detach()) for k, v in losses.items()}, {k: t.grad.cpu() for k, t in leaves.items()},
+                {k: v.cpu() for k, v in maps.items()})
+
+    la, ga, ma = run(False)
+    lb, gb, mb = run(True)
+    assert la == lb, (la, lb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    for k in ma:
+        assert torch.equal(ma[k], mb[k]), k
