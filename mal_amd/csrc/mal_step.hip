@@ -113,45 +113,77 @@ MAL_DEV void step_epilogue_block(const EpiParams& p, int bid) {
   const float sscale = p.sample_scale ? (p.scale_is_mask ? 1.0f - p.sample_scale[b] : p.sample_scale[b]) : 1.0f;
   const bool has_er = p.ens_reproj != nullptr, learnt = p.ens_disp != nullptr;
   float acc_cons = 0.f, acc_dist = 0.f;
-  for (int i0 = lo + tid; i0 < hi; i0 += 256) {
-    const size_t i = (size_t)b * p.HW + i0;
+  // one pixel: -> merged gradient, the extra map's value (learnt ensemble / dual distillation), the distillation index
+  auto one = [&](float ext, float dt, float cost, float rp, float ds, float mr, float er, float ensd, float& g_c, float& g_e,
+                 unsigned& idx_out) __attribute__((always_inline)) {
     // the weight of the student's masked reprojection term, as its pass forms it (march_body, stage S)
-    float em = p.ext_mask[i];
+    float em = ext;
+    const float mono = depth_of(dt, p.min_disp, p.range);
     {
-      const float mono = depth_of(p.disp_t[i], p.min_disp, p.range);
-      const float matching = div_safe_(1.0f, p.lowest_cost[i]);
+      const float matching = div_safe_(1.0f, cost);
       const bool ok = (div_safe_(matching - mono, mono) < 1.0f) && (div_safe_(mono - matching, matching) < 1.0f);
       em = ok ? em : em * 0.0f;
     }
     float w = 1.0f;
     w *= em;
     w *= sscale;
-    const float rp = p.multi_reproj[i];
     // march_body::epilogue
-    const float dm = depth_of(p.disp_s[i], p.min_disp, p.range);
+    const float dm = depth_of(ds, p.min_disp, p.range);
     const float ddepth = -(dm * dm) * p.range;
-    const float dmono = depth_of(p.disp_t[i], p.min_disp, p.range);
+    const float dmono = mono;
     const float m = w, cm = 1.0f - m, mm = 1.0f - cm;
     const float dc = dm - dmono;
     acc_cons += fabsf(dc) * cm;
     int idx = 0;
-    float best = p.mono_reproj[i];
+    float best = mr;
     if (has_er) {
-      const float r_ens = p.ens_reproj[i];
-      if (r_ens < best) { best = r_ens; idx = 1; }
+      if (er < best) { best = er; idx = 1; }
     }
     if (rp < best) idx = 2;
     float dens = 0.f, ens = (dmono + dm) / 2.0f;
-    if (learnt) { dens = depth_of(p.ens_disp[i], p.min_disp, p.range); ens = dens; }
+    if (learnt) { dens = depth_of(ensd, p.min_disp, p.range); ens = dens; }
     const float target = idx == 0 ? dmono : (idx == 2 ? dm : ens);
     const float dd = target - dm;
     acc_dist += fabsf(dd) * mm;
-    if (p.dbg) p.dbg[(size_t)MAL_DEC_DISTIL * ((size_t)p.B * p.HW) + i] = (unsigned)idx;
     const float gc = sgnf(dc) * cm * ddepth;
     const float gd = sgnf(dd) * (idx == 0 ? -1.0f : (idx == 2 ? 0.0f : (learnt ? -1.0f : -0.5f))) * mm * ddepth;
-    if (learnt && p.G_e) p.G_e[i] = idx == 1 ? p.merge_distil * (sgnf(dd) * mm * (-(dens * dens) * p.range)) : 0.0f;
-    if (p.dual && p.G_e) p.G_e[i] = idx == 0 ? p.merge_distil * (sgnf(dd) * mm * (-(dmono * dmono) * p.range)) : 0.0f;
-    p.G_c[i] = fma_(p.merge_cons, gc, p.merge_distil * gd);
+    g_e = 0.f;
+    if (learnt) g_e = idx == 1 ? p.merge_distil * (sgnf(dd) * mm * (-(dens * dens) * p.range)) : 0.0f;
+    if (p.dual) g_e = idx == 0 ? p.merge_distil * (sgnf(dd) * mm * (-(dmono * dmono) * p.range)) : 0.0f;
+    g_c = fma_(p.merge_cons, gc, p.merge_distil * gd);
+    idx_out = (unsigned)idx;
+  };
+  const size_t base = (size_t)b * p.HW;
+  if (((per | p.HW) & 3) == 0) {
+    // four consecutive pixels per thread, 16-byte accesses (every map's sample and every block's range start 16-byte aligned)
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    for (int i0 = lo + tid * 4; i0 < hi; i0 += 1024) {
+      const size_t i = base + i0;
+      auto ld = [&](const float* m) { return *reinterpret_cast<const v4*>(m + i); };
+      const v4 ext = ld(p.ext_mask), dt = ld(p.disp_t), cost = ld(p.lowest_cost), rp = ld(p.multi_reproj), ds = ld(p.disp_s),
+               mr = ld(p.mono_reproj), er = has_er ? ld(p.ens_reproj) : (v4){0.f, 0.f, 0.f, 0.f},
+               ensd = learnt ? ld(p.ens_disp) : (v4){0.f, 0.f, 0.f, 0.f};
+      v4 gc, ge;
+      unsigned idx[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { float a, e; one(ext[k], dt[k], cost[k], rp[k], ds[k], mr[k], er[k], ensd[k], a, e, idx[k]); gc[k] = a; ge[k] = e; }
+      *reinterpret_cast<v4*>(p.G_c + i) = gc;
+      if (p.G_e && (learnt || p.dual)) *reinterpret_cast<v4*>(p.G_e + i) = ge;
+      if (p.dbg)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p.dbg[(size_t)MAL_DEC_DISTIL * ((size_t)p.B * p.HW) + i + k] = idx[k];
+    }
+  } else {
+    for (int i0 = lo + tid; i0 < hi; i0 += 256) {
+      const size_t i = base + i0;
+      float a, e;
+      unsigned idx;
+      one(p.ext_mask[i], p.disp_t[i], p.lowest_cost[i], p.multi_reproj[i], p.disp_s[i], p.mono_reproj[i],
+          has_er ? p.ens_reproj[i] : 0.f, learnt ? p.ens_disp[i] : 0.f, a, e, idx);
+      p.G_c[i] = a;
+      if (p.G_e && (learnt || p.dual)) p.G_e[i] = e;
+      if (p.dbg) p.dbg[(size_t)MAL_DEC_DISTIL * ((size_t)p.B * p.HW) + i] = idx;
+    }
   }
   const double r0 = wave_sum_d((double)acc_cons), r1 = wave_sum_d((double)acc_dist);
   if ((tid & 63) == 0) { s_red[0][tid >> 6] = r0; s_red[1][tid >> 6] = r1; }
@@ -628,7 +660,9 @@ namespace mal { int g_temporal_spec = 0; }  // settable in -DMAL_EXPERIMENTS bui
 // caller stream that finds it full shares slot 0 of its device, and every _fwd of a forked step waits for the slot's join
 // event whatever `pending` says, so sharing costs ordering, never correctness.  Lookups are serialised by a mutex; the
 // launches themselves are the caller's (one thread per stream, as for every HIP stream).
-namespace mal { int g_side_priority = 1; }
+// option "side_priority": 1 = the side stream is created with the device's LOWEST priority.  Measured: every kernel of the
+// replayed step slows down -- 0.566 ms per step against 0.323 (profiles/r04_step_timelines.txt) --, so the default stays 0.
+namespace mal { int g_side_priority = 0; }
 struct SideStream { hipStream_t caller; hipStream_t s; hipEvent_t fork, join; bool ok, init, pending; int dev; };
 static SideStream* side_stream(hipStream_t caller) {
   constexpr int kSlots = 64;

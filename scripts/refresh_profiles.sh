@@ -7,7 +7,7 @@ O=$R/gpurun_out/refresh
 mkdir -p $O
 # the driver's own command, default flags (round 2 lost its headline because this exact line was never run after an edit)
 cd $R && python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err || exit 1
-python bench.py > $O/bench.json 2> $O/bench.err || exit 1
+python bench.py --loss-blc > $O/bench.json 2> $O/bench.err || exit 1
 python bench.py --mode distil --train-steps 0 > $O/bench_distil.json 2> $O/bench_distil.err || exit 1
 python bench.py --mode multiscale --train-steps 0 --no-cpu-baseline > $O/bench_multiscale.json 2> $O/bench_multiscale.err || exit 1
 cd /tmp && export TMPDIR=/tmp
