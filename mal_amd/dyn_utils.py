@@ -125,34 +125,54 @@ class BatchSynthesisFn(Function):
         flags_all = (torch.empty if every else torch.zeros)((B, H, W), dtype=torch.uint8, device=dev)
         arr = (L.DynItem * len(items))()
         saved = []
-        for k, item in enumerate(items):
-            b, mask_last, mask_next = item[:3]
-            idx_last, idx_next = (item[3], item[4]) if len(item) == 5 else (None, None)
+        # Host cost matters here: with the real producer the step cannot be graph-captured, and round 3 spent ~30 tensor
+        # operations per listed sample on slices, views and small allocations.  Per-sample addresses are pointer arithmetic on
+        # the batch tensors; the displacement tables and the extents' scratch of all items are ONE allocation each.
+        nums = []
+        for item in items:
+            mask_last, mask_next = item[1], item[2]
             if mask_last.dim() != 3 or mask_next.dim() != 3 or tuple(mask_last.shape[1:]) != (H, W) or \
                     tuple(mask_next.shape[1:]) != (H, W):
                 raise L.MalError("image_synthesis: masks must be two (n,H,W) tensors matching the images")
-            if idx_last is None:
+            if len(item) == 5:
+                if item[3].numel() != item[4].numel():
+                    raise L.MalError("image_synthesis: the two frames must hold the same number of matched instances")
+                nums.append(int(item[3].numel()))
+            else:
                 if mask_last.shape != mask_next.shape:
                     raise L.MalError("image_synthesis: the two frames must hold the same number of matched instances")
-                num = mask_last.shape[0]
-            else:  # the matcher's row selections travel to the kernels as they are (device int64)
-                idx_last = idx_last.to(device=dev, dtype=torch.int64).contiguous()
-                idx_next = idx_next.to(device=dev, dtype=torch.int64).contiguous()
-                num = idx_last.numel()
-                if idx_next.numel() != num:
-                    raise L.MalError("image_synthesis: the two frames must hold the same number of matched instances")
-            ml, mn = _as_u8(mask_last, dev), _as_u8(mask_next, dev)
-            delta = torch.empty(num, 2, dtype=torch.int32, device=dev)
-            flags = flags_all[b]
-            ws = torch.empty(lib.mal_dyn_workspace_bytes(num), dtype=torch.uint8, device=dev)
+                nums.append(int(mask_last.shape[0]))
+        max_num = max(nums)
+        ws_each = (int(lib.mal_dyn_workspace_bytes(max_num)) + 255) & ~255
+        delta_all = torch.empty((len(items), max_num, 2), dtype=torch.int32, device=dev)
+        ws_all = torch.empty(len(items) * ws_each, dtype=torch.uint8, device=dev)
+        p_cl, p_cn, p_sl, p_sn = p(cl), p(cn), p(syn_last), p(syn_next)
+        s_cl, s_cn, s_sl, s_sn = (4 * t.stride(0) for t in (cl, cn, syn_last, syn_next))
+        p_delta, p_ws, p_flags = p(delta_all), p(ws_all), p(flags_all)
+        keep = [delta_all, ws_all]
+        for k, item in enumerate(items):
+            b, mask_last, mask_next = item[:3]
+            idx_last, idx_next = (item[3], item[4]) if len(item) == 5 else (None, None)
+            num = nums[k]
+            if idx_last is not None:  # the matcher's row selections travel to the kernels as they are (device int64)
+                if not (idx_last.is_cuda and idx_last.dtype == torch.int64 and idx_last.is_contiguous()):
+                    idx_last = idx_last.to(device=dev, dtype=torch.int64).contiguous()
+                if not (idx_next.is_cuda and idx_next.dtype == torch.int64 and idx_next.is_contiguous()):
+                    idx_next = idx_next.to(device=dev, dtype=torch.int64).contiguous()
+            # bool masks are one byte per element already: their storage is handed over as it is
+            ok_m = lambda m: m.is_cuda and m.is_contiguous() and m.dtype in (torch.bool, torch.uint8)
+            ml = mask_last if ok_m(mask_last) else _as_u8(mask_last, dev)
+            mn = mask_next if ok_m(mask_next) else _as_u8(mask_next, dev)
             a = arr[k]
             a.mask_last, a.mask_next, a.num = p(ml), p(mn), num
-            a.img_last, a.img_next, a.ori_last, a.ori_next = p(cl[b]), p(cn[b]), p(syn_last[b]), p(syn_next[b])
-            a.delta, a.flags, a.ws, a.ws_bytes = p(delta), p(flags), p(ws), ws.numel()
+            a.img_last, a.img_next, a.ori_last, a.ori_next = p_cl + b * s_cl, p_cn + b * s_cn, p_sl + b * s_sl, p_sn + b * s_sn
+            d_ptr, f_ptr = p_delta + k * max_num * 8, p_flags + b * H * W
+            a.delta, a.flags, a.ws, a.ws_bytes = d_ptr, f_ptr, p_ws + k * ws_each, ws_each
             a.idx_last, a.idx_next = p(idx_last), p(idx_next)
             a.n_last, a.n_next = int(ml.shape[0]), int(mn.shape[0])  # a selection outside the tensor is clamped, never read
             a.prefilled = 1 if prefilled is not None else 0
-            saved.append((b, ml, mn, num, delta, flags, ws, idx_last, idx_next))
+            saved.append((b, ml, mn, num, d_ptr, f_ptr, None, idx_last, idx_next))
+        ctx.keep = keep + [flags_all]
         # all samples in one call: three launches (extents, displacements, synthesis) for up to 16 samples
         L.check(lib.mal_dyn_batch_fwd(arr, len(items), C, H, W, 1 if replace else 0, ops._stream()), "mal_dyn_batch_fwd")
         ctx.saved, ctx.dims, ctx.every = saved, (C, H, W), every
@@ -190,16 +210,22 @@ class BatchSynthesisFn(Function):
             # samples without instances: the identity (a copy); the kernel writes every pixel of the listed ones
             gl, gn = (torch.empty_like(g_last), torch.empty_like(g_next)) if ctx.every else (g_last.clone(), g_next.clone())
         arr = (L.DynItem * len(ctx.saved))()
+        at = lambda t: (p(t), 4 * t.stride(0))  # per-sample addresses by pointer arithmetic (samples are contiguous)
+        (q_gl, s_gl), (q_gn, s_gn), (q_ol, s_ol), (q_on, s_on) = at(g_last), at(g_next), at(gl), at(gn)
+        if snap_l is not None:
+            (q_sl, s_sl), (q_sn, s_sn) = at(snap_l), at(snap_n)
+        elif inplace:
+            (q_tl, s_tl), (q_tn, s_tn) = at(tmp_l), at(tmp_n)
         for k, (b, ml, mn, num, delta, flags, ws, idx_last, idx_next) in enumerate(ctx.saved):
             a = arr[k]
-            a.mask_last, a.mask_next, a.num, a.delta, a.flags = p(ml), p(mn), num, p(delta), p(flags)
+            a.mask_last, a.mask_next, a.num, a.delta, a.flags = p(ml), p(mn), num, delta, flags  # (delta, flags: addresses)
             a.idx_last, a.idx_next = p(idx_last), p(idx_next)
             a.n_last, a.n_next = int(ml.shape[0]), int(mn.shape[0])
-            a.g_ori_last, a.g_ori_next, a.g_img_last, a.g_img_next = p(g_last[b]), p(g_next[b]), p(gl[b]), p(gn[b])
+            a.g_ori_last, a.g_ori_next, a.g_img_last, a.g_img_next = q_gl + b * s_gl, q_gn + b * s_gn, q_ol + b * s_ol, q_on + b * s_on
             if snap_l is not None:
-                a.g_ori_last, a.g_ori_next, a.region_only = p(snap_l[b]), p(snap_n[b]), 1
+                a.g_ori_last, a.g_ori_next, a.region_only = q_sl + b * s_sl, q_sn + b * s_sn, 1
             elif inplace:
-                a.g_tmp_last, a.g_tmp_next = p(tmp_l[b]), p(tmp_n[b])
+                a.g_tmp_last, a.g_tmp_next = q_tl + b * s_tl, q_tn + b * s_tn
         L.check(lib.mal_dyn_batch_bwd(arr, len(ctx.saved), C, H, W, ops._stream()), "mal_dyn_batch_bwd")
         return gl, gn, None, None, None
 
