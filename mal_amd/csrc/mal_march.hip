@@ -1807,6 +1807,7 @@ extern int g_syn_queue;       // mal_photo_march.hip
 extern int g_step_overlap;    // mal_step.hip
 extern int g_student_overlap; // mal_step.hip
 extern int g_side_priority;   // mal_step.hip
+extern int g_side_order;      // mal_step.hip
 extern int g_march_halo1;     // mal_step.hip
 extern int g_temporal_spec;   // mal_step.hip
 int g_march_lean = 1;         // option "march_lean": the teacher's passes without the optional operands' code (0: generic, A/B)
@@ -2019,6 +2020,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("step_overlap")) { if (value < 0 || value > 2) return MAL_EINVAL; g_step_overlap = value; return MAL_OK; }
   if (eq("march_halo1")) { g_march_halo1 = value != 0; return MAL_OK; }
   if (eq("student_overlap")) { g_student_overlap = value != 0; return MAL_OK; }
+  if (eq("side_order")) { g_side_order = value != 0; return MAL_OK; }
   if (eq("side_priority")) { g_side_priority = value != 0; return MAL_OK; }  // read when a side stream is first created
   if (eq("temporal_spec")) { if (!kExp && value) return MAL_EINVAL; g_temporal_spec = value != 0; return MAL_OK; }
   if (eq("march3")) { if (!kExp && value) return MAL_EINVAL; g_march3 = value != 0; return MAL_OK; }
