@@ -261,11 +261,20 @@ enum {
   MAL_STEP_DUAL_DISTIL = 32, /* --dual_distil (loss_utils.py:231-234; only with MAL_STEP_NO_ENS, as upstream: the flag is read on the
                                two-way branch only): where the teacher wins the distillation argmin its depth is NOT detached --
                                g_disp_teacher also receives w_distil/N * sign(mono - multi) * (1 - consistency weight) * d mono / d disp */
-  MAL_STEP_SYN_SPARSE = 16  /* with MAL_STEP_TEMPORAL and syn_region: syn_* hold the synthesised images ONLY at pixels whose
+  MAL_STEP_SYN_SPARSE = 16, /* with MAL_STEP_TEMPORAL and syn_region: syn_* hold the synthesised images ONLY at pixels whose
                                region byte has bit 0 set (a producer that writes its regions into otherwise untouched
                                buffers); elsewhere they are by definition the warped images mal_loss_step_warp wrote
                                (warp_*, still set), which the sweep reads there.  warp2_* may then be NULL: the pass in
                                front of the producer writes the warped images once instead of twice. */
+  MAL_STEP_MAIN_TEMPORAL = 128, /* --main_temporal (manydepth/trainer.py:1164, loss_utils.py:152-155): the STUDENT's pass takes the
+                               hint as well -- its own warped images go through the producer and r(syn_f, target) joins the
+                               student's per-pixel min (weight: consistency x matching x (1 - augmentation), unchanged).  With
+                               or without MAL_STEP_TEMPORAL; the same three calls, the exchange through the *_s_* members:
+                                 mal_loss_step_warp  also writes warp_s_m1 / warp_s_p1 (student's disparity, the teacher's poses)
+                                 mal_loss_step_fwd   syn_s_* in, g_syn_s_* out (unnormalised, as g_syn_*)
+                                 mal_loss_step_bwd   g_warp_s_* in: the student's gradient sweep takes the four-way decisions
+                                                     of _fwd and adds what arrives through syn */
+  MAL_STEP_SYN_S_SPARSE = 256  /* MAL_STEP_SYN_SPARSE for the student's pair (syn_s_* / syn_s_region / warp_s_*) */
 };
 typedef struct mal_step_args {
   int B, H, W;
@@ -320,6 +329,13 @@ typedef struct mal_step_args {
    * target where the ensemble wins the three-way min, and g_ens_disp (backward output, nullable) receives
    * d total / d ens_disp.  Not with MAL_STEP_NO_ENS. */
   const float *ens_disp; float *g_ens_disp;
+  /* MAL_STEP_MAIN_TEMPORAL: the members above once more for the student's pass (same shapes; warp_s_* use warp_sample_stride) */
+  float *warp_s_m1, *warp_s_p1;
+  const float *syn_s_m1, *syn_s_p1;
+  float *g_syn_s_m1, *g_syn_s_p1;
+  const float *g_warp_s_m1, *g_warp_s_p1;
+  const uint8_t *syn_s_region;
+  float *g_syn_s_region_m1, *g_syn_s_region_p1;
 } mal_step_args;
 int mal_loss_step_warp(const mal_step_args* args);
 /* A MAL_STEP_TEMPORAL step whose producer failed between mal_loss_step_warp and mal_loss_step_fwd: joins the ensemble
@@ -607,6 +623,9 @@ int mal_set_option(const char* name, int value);
  * (mal_profile_next_pass, mal_decisions_next_pass) are process-wide too (a step's backward runs on autograd's worker
  * thread, not on the arming one) and are taken with an atomic exchange: exactly one pass consumes an arm. */
 int mal_build_has_experiments(void); /* 1 when the library contains the -DMAL_EXPERIMENTS formulations */
+/* sizeof of the argument blocks as THIS library was compiled (0 mal_step_args, 1 mal_ms_args, 2 mal_dr_args, 3 mal_dyn_item;
+ * else 0): a binding in another language checks its own layout against it once, at load (mal_amd/_lib.py does). */
+size_t mal_struct_bytes(int which);
 
 /* ---- measurement hooks (bench.py): HIP events recorded immediately before / after the main
  * kernel of the NEXT mal_pass_fused call, on its stream (one-shot; cleared by that call). */

@@ -100,6 +100,7 @@ SIGNATURES = {
     "mal_upsample_bilinear_adjoint": (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, vp]),
     "mal_set_option": (i32, [C.c_char_p, i32]),
     "mal_build_has_experiments": (i32, []),
+    "mal_struct_bytes": (sz, [i32]),
     "mal_event_create": (vp, []),
     "mal_event_destroy": (i32, [vp]),
     "mal_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
@@ -131,7 +132,9 @@ class StepArgs(C.Structure):
                  ("noise_seed", C.c_uint64), ("noise_step", C.c_uint64), ("noise_counter", vp), ("noise_out", vp)] +
                 [(n, vp) for n in ("warp_m1", "warp_p1", "syn_m1", "syn_p1", "g_syn_m1", "g_syn_p1", "g_warp_m1", "g_warp_p1")] +
                 [("warp_sample_stride", i32), ("warp2_m1", vp), ("warp2_p1", vp), ("syn_region", vp), ("g_syn_region_m1", vp),
-                 ("g_syn_region_p1", vp), ("ens_disp", vp), ("g_ens_disp", vp)])
+                 ("g_syn_region_p1", vp), ("ens_disp", vp), ("g_ens_disp", vp)] +
+                [(n, vp) for n in ("warp_s_m1", "warp_s_p1", "syn_s_m1", "syn_s_p1", "g_syn_s_m1", "g_syn_s_p1", "g_warp_s_m1",
+                                   "g_warp_s_p1", "syn_s_region", "g_syn_s_region_m1", "g_syn_s_region_p1")])
 
 
 class MsArgs(C.Structure):
@@ -163,6 +166,7 @@ DR_MAX_ITERS = 4
 DR_NO_AUTOMASK, DR_NO_MOTION_MASK, DR_NOISE_PHILOX = 1, 2, 4
 MS_MAX_SCALES = 4
 STEP_NO_ENS, STEP_AUG_MASK, STEP_NOISE_PHILOX, STEP_TEMPORAL, STEP_SYN_SPARSE, STEP_DUAL_DISTIL, STEP_TEXEL_INPUTS = 1, 2, 4, 8, 16, 32, 64
+STEP_MAIN_TEMPORAL, STEP_SYN_S_SPARSE = 128, 256
 # decision planes of mal_step_args.dec_teacher / dec_student (MAL_DEC_*)
 DEC_WIN, DEC_DISTIL, DEC_SMOOTH_X, DEC_SMOOTH_Y, DEC_TAP0, DEC_TAP1, DEC_L1, DEC_PLANES = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -189,6 +193,12 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    # the argument blocks are laid out twice (include/mal_hip.h, the ctypes Structures above): a stale library or a field added on
+    # one side only must not get as far as a kernel launch
+    for which, cls in enumerate((StepArgs, MsArgs, DrArgs, DynItem)):
+        if lib.mal_struct_bytes(which) != C.sizeof(cls):
+            raise MalError("%s: sizeof(%s) is %d in the library, %d in mal_amd/_lib.py -- rebuild (python -m mal_amd.build)"
+                           % (LIB_PATH, cls.__name__, lib.mal_struct_bytes(which), C.sizeof(cls)))
     _lib = lib
     return lib
 

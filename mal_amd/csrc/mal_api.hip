@@ -18,6 +18,16 @@ extern "C" const char* mal_strerror(int code) {
   }
 }
 
+extern "C" size_t mal_struct_bytes(int which) {
+  switch (which) {
+    case 0: return sizeof(mal_step_args);
+    case 1: return sizeof(mal_ms_args);
+    case 2: return sizeof(mal_dr_args);
+    case 3: return sizeof(mal_dyn_item);
+    default: return 0;
+  }
+}
+
 extern "C" int mal_device_check(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MAL_ENODEVICE;

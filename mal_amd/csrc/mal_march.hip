@@ -1907,7 +1907,15 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
 #else
   if (grad && p.color_out[0]) return MAL_EINVAL;  // an exporting gradient pass exists in -DMAL_EXPERIMENTS builds only
 #endif
-  if (p.forced_w) {  // TEMPORAL teacher pass
+  if (p.forced_w && grad && !pose && !automask && !epi) {
+    // TEMPORAL student pass (--main_temporal): forced_w is the pass's whole weight (consistency x matching x (1 - augmentation),
+    // as the forward pass in front of the producer formed it), so no mask operand is read again
+    if (!p.forced_arg || !p.g_color[0] || !p.g_color[1] || p.ext_mask || p.lowest_cost || p.sample_scale) return MAL_EINVAL;
+    if (p.dbg) {
+      if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
+      hipLaunchKernelGGL((march_kernel<true, false, false, false, true, true>), grid, block, 0, st, p);
+    } else hipLaunchKernelGGL((march_kernel<true, false, false, false, false, true>), grid, block, 0, st, p);
+  } else if (p.forced_w) {  // TEMPORAL teacher pass
     if (!(grad && pose && automask && !epi) || !p.forced_arg || !p.g_color[0] || !p.g_color[1]) return MAL_EINVAL;
     if (lean && !p.dbg) hipLaunchKernelGGL(march_teacher_kernel<true>, grid, block, 0, st, p);
     else if (p.dbg) {

@@ -23,6 +23,8 @@ namespace mal {
 struct PhotoMarchParams {
   const float* target; const float* cand[2];   // planar (B,3,H,W)
   int target_texels;                            // the target is (B,H,W,3) texels instead (request9)
+  int weight_given;                             // FUSED: `ident` holds the pixel's WEIGHT (the student's mask, --main_temporal) instead of
+                                                // the automask's identity term: the min changes, the weight does not
   int idx[2];                                   // the candidates' indices in the caller's list; idx[1] < 0: single candidate
   const float* ident; const float* noise; const float* ext_mask;
   const float* prev_min; const uint8_t* prev_arg;   // running min / argmin of earlier pairs (nullable)
@@ -352,14 +354,14 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
           if (rr.x < rp) { rp = rr.x; win0 = p.idx[0]; }
           if (rr.y < rp) { rp = rr.y; win0 = p.idx[1]; }
         }
-        const float w = (rp <= idn) ? 1.0f : 0.0f;
+        const float w = p.weight_given ? idn : ((rp <= idn) ? 1.0f : 0.0f);
         w0 = in_x ? w : 0.f;
         if (out_x && c >= y_lo && c < y_hi) {
           const unsigned go = (unsigned)(c * W + gxr);
           stf(p.min_reproj + map_b, go * 4u, rp);
           p.argmin[map_b + go] = (uint8_t)win0;
-          stf(p.weight_out + map_b, go * 4u, w);
-          const float w_old = (pm <= idn) ? 1.0f : 0.0f;  // what the pass over the earlier candidates decided and summed
+          if (!p.weight_given) stf(p.weight_out + map_b, go * 4u, w);
+          const float w_old = p.weight_given ? idn : ((pm <= idn) ? 1.0f : 0.0f);  // what the pass over the earlier candidates decided and summed
           acc_rw += rp * w - pm * w_old;
           acc_w += w - w_old;
         }
@@ -708,11 +710,12 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
                            float* g_region1, unsigned* order, unsigned* order_count, const float* orig0, const float* orig1,
-                           size_t orig_stride, int target_texels) {
+                           size_t orig_stride, int target_texels, int weight_given) {
   if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
+  if (weight_given && noise) return MAL_EINVAL;
   if ((orig0 == nullptr) != (orig1 == nullptr) || (orig0 && !region)) return MAL_EINVAL;
   PhotoMarchParams p = {};
-  p.target = target; p.target_texels = target_texels; p.B = B; p.H = H; p.W = W;
+  p.target = target; p.target_texels = target_texels; p.weight_given = weight_given; p.B = B; p.H = H; p.W = W;
   p.cand[0] = cand0; p.cand[1] = cand1; p.idx[0] = idx0; p.idx[1] = idx0 + 1;
   p.prev_min = prev_min; p.prev_arg = prev_arg; p.ident = ident; p.noise = noise;
   p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;

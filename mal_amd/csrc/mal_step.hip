@@ -29,7 +29,7 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
                            float* g_region1, unsigned* order, unsigned* order_count, const float* orig0, const float* orig1,
-                           size_t orig_stride, int target_texels);
+                           size_t orig_stride, int target_texels, int weight_given);
 
 constexpr int kLossSlots = 16;
 constexpr int kEpiBlocks = 64;  // epilogue workgroups per sample in the final launch (their partials are summed in block order)
@@ -49,6 +49,9 @@ struct StepWs {
   // materialised-candidate kernel's per-task partials [task][2], what the step remembers between its calls
   unsigned char* arg_t; float* w_t; double* bs_ph;
   float* rp_warp; unsigned char* arg_warp;  // ... and min_f r(warp_f) / its winner as the pass in front of the producer leaves them
+  // --main_temporal: the same for the student's pass (w_s: its weight = consistency x matching x (1 - augmentation), constant
+  // under the four-way min; bs_s then holds the sums of the forward pass in front of the producer, bs_sh the sweep's differences)
+  unsigned char* arg_s; float* w_s; double* bs_sh; float* rp_warp_s; unsigned char* arg_warp_s;
   double* ps;         // per-sample sums of the teacher's, then the student's partials: [2][B][8]
   unsigned* ticket;   // completion counter of step_final_kernel; ticket[1..2]: counts of the fused sweep's task order
   unsigned* order;    // dispatch order of the fused sweep's tasks (temporal hint, region map given)
@@ -80,6 +83,11 @@ static StepWs carve_step(void* base, int B, int H, int W) {
   w.bs_ph = (double*)take(nb * 4 * 2 * 8);  // tasks of >= 2 rows (the fused sweep shortens them when a region map is given)
   w.rp_warp = (float*)take(map);
   w.arg_warp = (unsigned char*)take((size_t)B * HW);
+  w.arg_s = (unsigned char*)take((size_t)B * HW);
+  w.w_s = (float*)take(map);
+  w.bs_sh = (double*)take(nb * 4 * 2 * 8);
+  w.rp_warp_s = (float*)take(map);
+  w.arg_warp_s = (unsigned char*)take((size_t)B * HW);
   w.ps = (double*)take((size_t)2 * B * 8 * 8);
   w.ticket = (unsigned*)take(16);
   w.order = (unsigned*)take(nb * 4 * sizeof(unsigned));  // tasks of >= 2 rows, as bs_ph
@@ -203,7 +211,8 @@ __global__ __launch_bounds__(256) void step_epilogue_kernel(EpiParams p) { step_
 // coefficients of the backward.
 __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, const double* bs_s, const float* bgP,
                                                          const double* bs_p, int per_sample_p,
-                                                         const double* bs_ph, int per_sample_ph, const double* bs_d,
+                                                         const double* bs_ph, int per_sample_ph, const double* bs_sh,
+                                                         int per_sample_sh, const double* bs_d,
                                                          const float* K, int per_sample, int per_sample_t, int B, int H, int W,
                                                          float w_main, float w_distil, double* ps, float* gT0, float* gT1,
                                                          double* stats, float* losses, float* coefs, float* loss_total,
@@ -245,6 +254,11 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
 #pragma unroll 8
       for (int t = sub; t < per_sample_ph; t += 32) acc += bd[(size_t)t * 2];
     }
+    if (pass == 1 && bs_sh != nullptr && j < 2) {  // --main_temporal: the student's sums likewise
+      const double* bd = bs_sh + (size_t)b * per_sample_sh * 2 + j;
+#pragma unroll 8
+      for (int t = sub; t < per_sample_sh; t += 32) acc += bd[(size_t)t * 2];
+    }
     s_part[tid] = acc;
     __syncthreads();
     if (tid < 8) {
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
     double acc = 0.0;
     if (sub < 10) {
 #pragma unroll 8
-      for (int t = sub; t < per_sample; t += 10) acc += (double)bgP[((size_t)b * per_sample + t) * 24 + v];
+      for (int t = sub; t < per_sample_t; t += 10) acc += (double)bgP[((size_t)b * per_sample_t + t) * 24 + v];  // the teacher's gradient pass
     }
     s_part[tid] = acc;
     __syncthreads();
@@ -629,6 +643,35 @@ static int launch_student(const mal_step_args* a, const StepWs& w, float* mono_r
   if (per_sample) *per_sample = p.strips * p.segs;
   return rc;
 }
+// --main_temporal: the student's forward pass in front of its producer -- warped images out; the min over the two warped
+// candidates, its winner and the pass's weight (consistency x matching x (1 - augmentation): the four-way min does not change it)
+// stay in the workspace, with the sums, for mal_loss_step_fwd
+static int launch_student_warp(const mal_step_args* a, const StepWs& w, hipStream_t st) {
+  MarchParams p = march_params(a->B, a->H, a->W, a->min_depth, a->max_depth, 1e-7f, 0);
+  p.disp = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+  p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+  p.ext_mask = a->consistency_mask; p.sample_scale = a->augmentation_keep;
+  p.sample_scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0;
+  p.mono_disp = a->disp_teacher; p.lowest_cost = a->lowest_cost; p.cmask_out = a->consistency_mask_out;
+  p.min_reproj = w.rp_warp_s; p.min_reproj2 = a->multi_reproj ? a->multi_reproj : w.multi_reproj;
+  p.argmin_out = w.arg_warp_s; p.argmin_out2 = w.arg_s; p.weight_out = w.w_s;
+  p.color_out[0] = a->warp_s_m1; p.color_out[1] = a->warp_s_p1; p.color_out_stride = a->warp_sample_stride;
+  p.block_sums = w.bs_s; p.block_gP = w.bgP_e;
+  p.cam = w.cam; p.cam_ready = 1;
+  return march_launch(p, MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+}
+// ... and its gradient sweep in mal_loss_step_bwd: the four-way decisions of _fwd, what arrives through syn added
+static int launch_student_temporal(const mal_step_args* a, const StepWs& w, hipStream_t st) {
+  MarchParams p = march_params(a->B, a->H, a->W, a->min_depth, a->max_depth, 1e-7f, 0);
+  p.disp = a->disp_student; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+  p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+  p.g_reproj = w.G_r_s; p.block_sums = w.bs_e; p.block_gP = w.bgP_e;  // (the sums were taken by _fwd: a sink here)
+  p.forced_w = w.w_s; p.forced_arg = w.arg_s; p.g_color[0] = a->g_warp_s_m1; p.g_color[1] = a->g_warp_s_p1;
+  p.bnd = g_march_halo1 ? w.bnd_s : nullptr;
+  p.cam = w.cam; p.cam_ready = 1;
+  p.dbg = a->dec_student;
+  return march_launch(p, MAL_F_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+}
 static EpiParams epilogue_params(const mal_step_args* a, const StepWs& w, const float* mono_reproj, const float* ens_reproj,
                                  const float* multi_reproj) {
   const int B = a->B, H = a->H, W = a->W;
@@ -715,9 +758,12 @@ static int join_side(hipStream_t st, bool always = false) {
 // student's marching pass without its epilogue
 namespace mal { int g_student_overlap = 1; int g_side_order = 0; }  // side_order 1 (student first) measured slower: 0.3265 vs 0.3200 ms -- the producer's small kernels starve beside a pass that holds every wave slot and all of the LDS
 static bool side_forked(const mal_step_args* a) {
-  return g_step_overlap && (a->flags & MAL_STEP_TEMPORAL) && side_stream((hipStream_t)a->stream) != nullptr;
+  return g_step_overlap && (a->flags & (MAL_STEP_TEMPORAL | MAL_STEP_MAIN_TEMPORAL)) && side_stream((hipStream_t)a->stream) != nullptr;
 }
-static bool student_forked(const mal_step_args* a) { return side_forked(a) && g_student_overlap && g_step_overlap == 1; }
+// (--main_temporal: the student's pass has its own producer to wait for; only the ensemble pass is forked then)
+static bool student_forked(const mal_step_args* a) {
+  return side_forked(a) && g_student_overlap && g_step_overlap == 1 && !(a->flags & MAL_STEP_MAIN_TEMPORAL);
+}
 static bool ensemble_forked(const mal_step_args* a) {
   return side_forked(a) && !(a->flags & MAL_STEP_NO_ENS);
 }
@@ -752,7 +798,11 @@ extern "C" int mal_loss_step_abort(const mal_step_args* a) {
 extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   int rc = step_check(a);
   if (rc) return rc;
-  if (!(a->flags & MAL_STEP_TEMPORAL) || !a->warp_m1 || !a->warp_p1) return MAL_EINVAL;
+  const bool temporal = a->flags & MAL_STEP_TEMPORAL, main_t = a->flags & MAL_STEP_MAIN_TEMPORAL;
+  if (!temporal && !main_t) return MAL_EINVAL;
+  if (temporal && (!a->warp_m1 || !a->warp_p1)) return MAL_EINVAL;
+  if (main_t && (!a->warp_s_m1 || !a->warp_s_p1)) return MAL_EINVAL;
+  if ((a->warp2_m1 == nullptr) != (a->warp2_p1 == nullptr)) return MAL_EINVAL;
   StepWs w = carve_step(a->ws, a->B, a->H, a->W);
   use_texel_inputs(a, w);
   hipStream_t st = (hipStream_t)a->stream;
@@ -761,6 +811,7 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   int per_sample_p = 1;
   rc = first_sweep(a, w, st, &per_sample_p);
   if (rc) return rc;
+  if (temporal) {
   MarchParams p = teacher_params(a, w, w.rp_warp);
   p.block_sums = w.bs_t;
   // ... with the automask: where no synthesised candidate can win, this IS the teacher's forward (min, winner, weight,
@@ -779,9 +830,13 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   p.color_out[0] = a->warp_m1; p.color_out[1] = a->warp_p1; p.argmin_out = w.arg_warp;
   p.color_out_stride = a->warp_sample_stride;
   p.color_out2[0] = a->warp2_m1; p.color_out2[1] = a->warp2_p1;
-  if ((a->warp2_m1 == nullptr) != (a->warp2_p1 == nullptr)) return MAL_EINVAL;
   rc = march_launch(p, flags, st);
   if (rc) return rc;
+  }
+  if (main_t) {
+    rc = launch_student_warp(a, w, st);
+    if (rc) return rc;
+  }
   if ((ensemble_forked(a) || student_forked(a)) && g_step_overlap == 1) {
     rc = fork_ensemble(a, w, st);
     if (rc) return rc;
@@ -796,7 +851,8 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   StepWs w = carve_step(a->ws, B, H, W);
   use_texel_inputs(a, w);
   hipStream_t st = (hipStream_t)a->stream;
-  const bool no_ens = a->flags & MAL_STEP_NO_ENS, temporal = a->flags & MAL_STEP_TEMPORAL;
+  const bool no_ens = a->flags & MAL_STEP_NO_ENS, temporal = a->flags & MAL_STEP_TEMPORAL,
+             main_t = a->flags & MAL_STEP_MAIN_TEMPORAL, hinted = temporal || main_t;
   float* mono_reproj = a->mono_reproj ? a->mono_reproj : w.mono_reproj;
   float* ens_reproj = no_ens ? nullptr : (a->ens_reproj ? a->ens_reproj : w.ens_reproj);
   float* multi_reproj = a->multi_reproj;  // only written when the caller wants the map
@@ -808,12 +864,17 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     march_geometry(B, H, W, temporal && !g_temporal_spec ? 0 : MAL_F_GRAD, &strips, &segs, nullptr);
     per_sample_t = strips * segs;
   }
+  if (hinted && ensemble_forked(a) && g_step_overlap == 2) {  // option "step_overlap" 2: the ensemble pass beside the sweeps of this call
+    rc = fork_ensemble(a, w, st);
+    if (rc) return rc;
+  }
   if (!temporal) {
-    rc = first_sweep(a, w, st, &per_sample_p);
+    if (main_t) per_sample_p = pack_identity_tasks_per_sample(H, W);  // (mal_loss_step_warp ran the first sweep)
+    else rc = first_sweep(a, w, st, &per_sample_p);
     if (rc) return rc;
     // teacher pass: forward and gradient in one sweep
     rc = launch_teacher(a, w, mono_reproj, st);
-    if (rc) return rc;
+    if (rc) { if (main_t) (void)join_side(st); return rc; }
   } else {
     // mal_loss_step_warp ran the first sweep and left min_f r(warp_f) / its winner in rp_warp / arg_warp: the two
     // synthesised images join the running min (first minimum wins, as torch.min over [warp-1, warp+1, syn-1, syn+1],
@@ -824,21 +885,31 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     // images mal_loss_step_warp wrote (warp_*), which the sweep then reads instead
     const bool sparse = (a->flags & MAL_STEP_SYN_SPARSE) != 0;
     if (sparse && (!a->syn_region || !a->warp_m1 || !a->warp_p1)) { (void)join_side(st); return MAL_EINVAL; }
-    if (ensemble_forked(a) && g_step_overlap == 2) {
-      rc = fork_ensemble(a, w, st);
-      if (rc) return rc;
-    }
     per_sample_p = pack_identity_tasks_per_sample(H, W);
     rc = photo_march_fused_more(w.packed[0], a->syn_m1, a->syn_p1, 2, w.ident, a->noise, w.rp_warp, w.arg_warp, B, H, W,
                                 mono_reproj, w.arg_t, w.w_t, w.bs_ph, a->g_syn_m1, a->g_syn_p1, &per_sample_ph, st, a->syn_region,
                                 a->g_syn_region_m1, a->g_syn_region_p1, w.order, w.ticket + 1,
                                 sparse ? a->warp_m1 : nullptr, sparse ? a->warp_p1 : nullptr, (size_t)a->warp_sample_stride,
-                                1 /* the target as texels: one 12-byte load instead of three planes */);
+                                1 /* the target as texels: one 12-byte load instead of three planes */, 0);
+    if (rc) { (void)join_side(st); return rc; }
+  }
+  int per_sample_sh = 0;
+  if (main_t) {
+    // --main_temporal: the student's pair joins ITS running min the same way; the weight is the pass's mask (w_s), whatever wins
+    if (!a->syn_s_m1 || !a->syn_s_p1 || !a->g_syn_s_m1 || !a->g_syn_s_p1) { (void)join_side(st); return MAL_EINVAL; }
+    const bool sparse = (a->flags & MAL_STEP_SYN_S_SPARSE) != 0;
+    if (sparse && (!a->syn_s_region || !a->warp_s_m1 || !a->warp_s_p1)) { (void)join_side(st); return MAL_EINVAL; }
+    rc = photo_march_fused_more(w.packed[0], a->syn_s_m1, a->syn_s_p1, 2, w.w_s, nullptr, w.rp_warp_s, w.arg_warp_s, B, H, W,
+                                a->multi_reproj ? a->multi_reproj : w.multi_reproj, w.arg_s, w.w_s, w.bs_sh, a->g_syn_s_m1,
+                                a->g_syn_s_p1, &per_sample_sh, st, a->syn_s_region, a->g_syn_s_region_m1, a->g_syn_s_region_p1,
+                                nullptr, nullptr, sparse ? a->warp_s_m1 : nullptr, sparse ? a->warp_s_p1 : nullptr,
+                                (size_t)a->warp_sample_stride, 1, 1 /* `ident` is the weight */);
     if (rc) { (void)join_side(st); return rc; }
   }
   // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp -- and so
   // was the student's marching pass (without its epilogue)
-  const bool ens_forked = temporal && ensemble_forked(a), stu_forked = temporal && student_forked(a);
+  const bool ens_forked = hinted && ensemble_forked(a), stu_forked = temporal && student_forked(a);
+  const bool stu_deferred = stu_forked || main_t;  // the student's marching pass has run: its epilogue is a launch of its own
   EpiParams epi = {};
   int n_epi = 0;
   if (ens_forked || stu_forked) {
@@ -849,10 +920,10 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     rc = launch_ensemble(a, w, ens_reproj, st);
     if (rc) return rc;
   }
-  if (stu_forked) {
+  if (stu_deferred) {
     // the student's pass ran beside the producer: its consistency / distillation terms now, from the three per-pixel minima
     int strips = 0, segs = 0;
-    march_geometry(B, H, W, MAL_F_GRAD, &strips, &segs, nullptr);
+    march_geometry(B, H, W, main_t ? 0 : MAL_F_GRAD, &strips, &segs, nullptr);  // the pass that left the student's sums
     per_sample = strips * segs;
     epi = epilogue_params(a, w, mono_reproj, ens_reproj, a->multi_reproj ? a->multi_reproj : w.multi_reproj);
     hipLaunchKernelGGL(step_epilogue_kernel, dim3((unsigned)(B * kEpiBlocks)), dim3(256), 0, st, epi);
@@ -865,7 +936,8 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   }
   // per-sample sums of both gradient passes, pose gradients (temporal: in _bwd, after the teacher's sweep), scalars
   hipLaunchKernelGGL(step_final_kernel, dim3(n_epi + (temporal ? 2 * B : 3 * B)), dim3(256), 0, st, w.bs_t, w.bs_s, temporal ? nullptr : w.bgP,
-                     w.bs_p, per_sample_p, temporal ? w.bs_ph : nullptr, per_sample_ph, stu_forked ? w.bs_d : nullptr, a->K,
+                     w.bs_p, per_sample_p, temporal ? w.bs_ph : nullptr, per_sample_ph, main_t ? w.bs_sh : nullptr, per_sample_sh,
+                     stu_deferred ? w.bs_d : nullptr, a->K,
                      per_sample, per_sample_t, B, H, W,
                      a->w_main, a->w_distil, w.ps, w.gT[0], w.gT[1], w.sm_stats, a->losses, w.coefs, a->loss_total,
                      w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr, epi, n_epi);
@@ -880,7 +952,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
 extern "C" int mal_loss_step_teacher_replay(const mal_step_args* a, int launches) {
   int rc = step_check(a);
   if (rc) return rc;
-  if ((a->flags & MAL_STEP_TEMPORAL) || launches <= 0 || launches > 4096) return MAL_EINVAL;
+  if ((a->flags & (MAL_STEP_TEMPORAL | MAL_STEP_MAIN_TEMPORAL)) || launches <= 0 || launches > 4096) return MAL_EINVAL;
   StepWs w = carve_step(a->ws, a->B, a->H, a->W);
   use_texel_inputs(a, w);
   float* mono_reproj = a->mono_reproj ? a->mono_reproj : w.mono_reproj;
@@ -923,6 +995,11 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
     rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
     if (rc) return rc;
     per_sample_t = p.strips * p.segs;
+  }
+  if (a->flags & MAL_STEP_MAIN_TEMPORAL) {
+    if (!a->g_warp_s_m1 || !a->g_warp_s_p1) return MAL_EINVAL;
+    rc = launch_student_temporal(a, w, st);
+    if (rc) return rc;
   }
   size_t g = (size_t)B * H;  // a workgroup per image row
   if (g > 4096) g = 4096;

@@ -41,7 +41,7 @@ def _workspace(dev, B, H, W):
     return ws
 
 
-def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=False, ens_disp=None):
+def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=False, ens_disp=None, main_temporal=False):
     """the mal_step_args block of one step, the tensors it points to (kept alive by the caller) and the map dict;
     ``ens_disp`` (--learn_ens): a seventh leaf, appended to the kept tensors"""
     color0, color_m1, color_p1, K, inv_K, cmask, keep, lowest, noise = consts
@@ -68,7 +68,7 @@ def _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, tempora
     a.B, a.H, a.W = B, H, W
     a.min_depth, a.max_depth = float(min_depth), float(max_depth)
     a.flags = (L.STEP_NO_ENS if no_ens else 0) | (L.STEP_AUG_MASK if aug_is_mask else 0) | (L.STEP_TEMPORAL if temporal else 0) | \
-              (L.STEP_DUAL_DISTIL if (dual and no_ens) else 0) | \
+              (L.STEP_DUAL_DISTIL if (dual and no_ens) else 0) | (L.STEP_MAIN_TEMPORAL if main_temporal else 0) | \
               (L.STEP_TEXEL_INPUTS if texel_inputs else 0)  # (upstream reads dual_distil on the two-way branch only)
     if philox is not None:  # (seed, want the drawn values back)
         a.flags |= L.STEP_NOISE_PHILOX
@@ -154,95 +154,138 @@ class LossStepFn(Function):
         return (*grads, None, None, ctx.g_ens)
 
 
-class TemporalLossStepFn(Function):
-    """The step with the temporal hint (``--temporal``, loss_utils.py:84-88): three library calls around the producer
-    ``synth(inputs, outputs, scale) -> has_ins`` (upstream: dyn_utils.image_synthesis), which reads the teacher's
-    warped images ``outputs[("color", f, 0)]`` and writes ``outputs[("syn", f, 0)]`` with ordinary autograd ops
-    (dyn_utils.py:127-128,145-146,163-168).  Forward: mal_loss_step_warp -> producer (recorded by autograd on a
-    private copy of the warped images) -> mal_loss_step_fwd (hands back d loss / d syn); backward: the producer's own
-    backward (torch.autograd.grad on that private graph), then mal_loss_step_bwd, whose teacher sweep adds what arrives
-    through syn to d loss / d warped colour before the chain rule through the warp."""
+class _Hint:
+    """One pass's exchange with the temporal hint's producer: the teacher's (``--temporal``, mal_step_args.warp_* / syn_* /
+    g_syn_* / g_warp_* / syn_region) or the student's (``--main_temporal``, the ``*_s_*`` members)."""
 
-    @staticmethod
-    def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, synth, inputs, expose, ens_disp=None):
-        a, keep, maps = _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=True, ens_disp=ens_disp)
-        ctx.ens_index = 11
-        B, _, H, W = keep[0][0].shape
-        dev = keep[0][0].device
+    def __init__(self, a, student, B, H, W, dev):
+        self.a, self.tag, self.student = a, "_s" if student else "", student
+        self.sparse_flag = L.STEP_SYN_S_SPARSE if student else L.STEP_SYN_SPARSE
+        self.shape, self.dev = (B, 3, H, W), dev
         # the two warped images of a sample side by side: the (2,3,H,W) pair the instance segmenter is fed is then a VIEW
         # (upstream stacks it per sample, dyn_utils.py:139-140); ("color", f, 0) are the two batch-strided halves
-        pair = torch.empty((B, 2, 3, H, W), dtype=torch.float32, device=dev)
-        warp = [pair[:, 0], pair[:, 1]]
-        a.warp_m1, a.warp_p1 = warp[0].data_ptr(), warp[1].data_ptr()
-        a.warp_sample_stride = 6 * H * W
+        self.pair = torch.empty((B, 2, 3, H, W), dtype=torch.float32, device=dev)
+        self.warp = [self.pair[:, 0], self.pair[:, 1]]
+        self._set("warp", self.warp)
         # The buffers the synthesised images are made in are NOT filled: a producer that knows the key
         # ("syn_sparse_buffers", scale) -- mal_amd.dyn_utils.image_synthesis -- writes only the pixels of its instances'
         # regions into them instead of cloning every sample first (dyn_utils.py:127-128) and says so (("syn_sparse", scale),
         # with the region map); the sweep then reads the warped images everywhere else (MAL_STEP_SYN_SPARSE), so the pass in
         # front of the producer writes them once, not twice
-        pre = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
-        lib = L.load()
-        L.check(lib.mal_loss_step_warp(C.byref(a)), "mal_loss_step_warp")
-        try:
-            with torch.enable_grad():
-                leaf = [w.detach().requires_grad_(True) for w in warp]
-                local = {("color", -1, 0): leaf[0], ("color", 1, 0): leaf[1], ("color_pair", 0): pair,
-                         ("syn_sparse_buffers", 0): (pre[0], pre[1])}
-                has_ins = bool(synth(inputs, local, 0))
-        except BaseException:  # the producer raised: join what mal_loss_step_warp forked before the buffers are reused
-            lib.mal_loss_step_abort(C.byref(a))
-            raise
-        region = snap = None
-        if has_ins:
-            try:  # what the producer left is checked AFTER the fork too: join it before the error travels on
-                syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
-                syn_data = [ops._req(s.detach(), "syn") for s in syn]
-                region = local.get(("syn_region", 0))
-                sparse = bool(local.get(("syn_sparse", 0)))
-                if sparse and (region is None or any(s.data_ptr() != q.data_ptr() for s, q in zip(syn_data, pre))):
-                    raise L.MalError("loss_step: ('syn_sparse', 0) needs the region map and the buffers of ('syn_sparse_buffers', 0)")
-                if region is not None and not (region.is_cuda and region.dtype == torch.uint8 and tuple(region.shape) == (B, H, W)
-                                               and region.is_contiguous()):
-                    raise L.MalError("loss_step: ('syn_region', 0) must be a contiguous (B,H,W) uint8 device tensor")
-            except BaseException:
-                lib.mal_loss_step_abort(C.byref(a))
-                raise
+        self.pre = [torch.empty(self.shape, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.has_ins, self.region, self.snap, self.syn, self.syn_data, self.leaf, self.g_syn = False, None, None, None, None, None, None
+
+    def _set(self, base, tensors, tail=("_m1", "_p1")):
+        for t, sfx in zip(tensors, tail):
+            setattr(self.a, base + self.tag + sfx, t.data_ptr())
+
+    def produce(self, synth, inputs):
+        """between mal_loss_step_warp and mal_loss_step_fwd; anything raised here is the caller's to abort the step on"""
+        B, _, H, W = self.shape
+        with torch.enable_grad():
+            self.leaf = [w.detach().requires_grad_(True) for w in self.warp]
+            local = {("color", -1, 0): self.leaf[0], ("color", 1, 0): self.leaf[1], ("color_pair", 0): self.pair,
+                     ("syn_sparse_buffers", 0): (self.pre[0], self.pre[1])}
+            self.has_ins = bool(synth(inputs, local, 0))
+        a = self.a
+        if self.has_ins:
+            self.syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
+            self.syn_data = [ops._req(t.detach(), "syn") for t in self.syn]
+            region = local.get(("syn_region", 0))
+            sparse = bool(local.get(("syn_sparse", 0)))
+            if sparse and (region is None or any(t.data_ptr() != q.data_ptr() for t, q in zip(self.syn_data, self.pre))):
+                raise L.MalError("loss_step: ('syn_sparse', 0) needs the region map and the buffers of ('syn_sparse_buffers', 0)")
+            if region is not None and not (region.is_cuda and region.dtype == torch.uint8 and tuple(region.shape) == (B, H, W)
+                                           and region.is_contiguous()):
+                raise L.MalError("loss_step: ('syn_region', 0) must be a contiguous (B,H,W) uint8 device tensor")
+            self.region = region
             if region is not None:
-                a.syn_region = region.data_ptr()
+                setattr(a, "syn" + self.tag + "_region", region.data_ptr())
                 if sparse:
-                    a.flags |= L.STEP_SYN_SPARSE
+                    a.flags |= self.sparse_flag
                 # ... and with the map the sweep leaves a second copy of d/d syn at the touched pixels: what the
                 # producer's in-place backward gathers from
-                snap = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
-                a.g_syn_region_m1, a.g_syn_region_p1 = snap[0].data_ptr(), snap[1].data_ptr()
+                self.snap = [torch.empty(self.shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
+                self._set("g_syn", self.snap, ("_region_m1", "_region_p1"))
         else:
-            # no matched instance anywhere (loss_utils.py:84: only the two warped candidates enter the min): an all-zero
+            # no matched instance anywhere (loss_utils.py:84,152: only the two warped candidates enter the min): an all-zero
             # region map over the untouched buffers -- no synthesised candidate is evaluated anywhere (no pixel of them is
             # read), the running min passes through and d/d syn is zero
-            syn, syn_data = None, pre
-            region = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
-            a.syn_region = region.data_ptr()
-            a.flags |= L.STEP_SYN_SPARSE
+            self.syn, self.syn_data = None, self.pre
+            self.region = torch.zeros((B, H, W), dtype=torch.uint8, device=self.dev)
+            setattr(a, "syn" + self.tag + "_region", self.region.data_ptr())
+            a.flags |= self.sparse_flag
         # the cotangents of syn: this node's own buffers, which the producer's backward may turn into its result in place
-        g_syn = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
-        a.syn_m1, a.syn_p1 = syn_data[0].data_ptr(), syn_data[1].data_ptr()
-        a.g_syn_m1, a.g_syn_p1 = g_syn[0].data_ptr(), g_syn[1].data_ptr()
+        self.g_syn = [torch.empty(self.shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self._set("syn", self.syn_data)
+        self._set("g_syn", self.g_syn)
+
+    def expose(self, out, dense):
+        """what the reference's generate_images_pred leaves in the pass's outputs dict (trainer.py:1122-1125,1161-1165)"""
+        out[("color", -1, 0)], out[("color", 1, 0)] = self.warp
+        if self.has_ins:
+            if self.a.flags & self.sparse_flag:
+                # dense images for the caller (logging) only when maps are wanted: outside the regions syn IS the warped image
+                if dense:
+                    inside = (self.region & 1).bool().unsqueeze(1)
+                    out[("syn", -1, 0)], out[("syn", 1, 0)] = (torch.where(inside, t, w_) for t, w_ in zip(self.syn_data, self.warp))
+            else:
+                out[("syn", -1, 0)], out[("syn", 1, 0)] = self.syn_data
+        out["multi_has_ins" if self.student else "has_ins"] = self.has_ins
+
+    def backward(self):
+        """the producer's own backward (linear): g_syn -> g_warp, handed to mal_loss_step_bwd"""
+        if self.syn is None:
+            g_warp = self.g_syn  # the identity producer
+        else:
+            from . import dyn_utils
+            # mal_amd.dyn_utils.image_synthesis turns the cotangent buffers into its result in place
+            reg = {g.data_ptr(): (self.snap[i] if self.snap is not None else None) for i, g in enumerate(self.g_syn)}
+            dyn_utils.INPLACE_COTANGENTS.update(reg)
+            try:
+                g_warp = torch.autograd.grad(self.syn, self.leaf, self.g_syn, allow_unused=True)
+            finally:
+                for k in reg:
+                    dyn_utils.INPLACE_COTANGENTS.pop(k, None)
+            g_warp = [torch.zeros_like(w) if g is None else g.contiguous() for g, w in zip(g_warp, self.warp)]
+        self.g_warp = g_warp
+        self._set("g_warp", g_warp)
+
+
+class TemporalLossStepFn(Function):
+    """The step with the temporal hint (``--temporal``, loss_utils.py:84-88; ``--main_temporal``, :152-155): three library
+    calls around the producer ``synth(inputs, outputs, scale) -> has_ins`` (upstream: dyn_utils.image_synthesis), which
+    reads a pass's warped images ``outputs[("color", f, 0)]`` and writes ``outputs[("syn", f, 0)]`` with ordinary autograd
+    ops (dyn_utils.py:127-128,145-146,163-168).  Forward: mal_loss_step_warp -> producer, once per hinted pass, the
+    teacher's first as upstream calls them (recorded by autograd on a private copy of the warped images) ->
+    mal_loss_step_fwd (hands back d loss / d syn); backward: the producer's own backward (torch.autograd.grad on that
+    private graph), then mal_loss_step_bwd, whose gradient sweeps add what arrives through syn to d loss / d warped colour
+    before the chain rule through the warp.  ``which`` = (teacher hinted, student hinted); ``expose`` = (mono_outputs, outputs)."""
+
+    @staticmethod
+    def forward(ctx, disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, synth, inputs, expose, which, ens_disp=None):
+        a, keep, maps = _build_args(disp_t, disp_s, aa_m1, tr_m1, aa_p1, tr_p1, consts, cfg, temporal=which[0],
+                                    main_temporal=which[1], ens_disp=ens_disp)
+        ctx.ens_index = 12
+        B, _, H, W = keep[0][0].shape
+        dev = keep[0][0].device
+        hints = [_Hint(a, student, B, H, W, dev) for student, on in ((False, which[0]), (True, which[1])) if on]
+        a.warp_sample_stride = 6 * H * W
+        lib = L.load()
+        L.check(lib.mal_loss_step_warp(C.byref(a)), "mal_loss_step_warp")
+        try:  # the producer raised, or left something unusable: join what mal_loss_step_warp forked before the buffers are reused
+            for h in hints:
+                h.produce(synth, inputs)
+        except BaseException:
+            lib.mal_loss_step_abort(C.byref(a))
+            raise
         L.check(lib.mal_loss_step_fwd(C.byref(a)), "mal_loss_step_fwd")
         ctx.args, ctx.keep = a, keep
         ctx.ws_token = ops.claim_workspace(keep[2])
-        ctx.graph = (leaf, syn, syn_data, g_syn, warp)
-        ctx.region, ctx.snap = region, snap  # the C struct holds their pointers
+        ctx.hints = hints  # the C struct holds their buffers' pointers
         ctx.set_materialize_grads(False)
-        expose[("color", -1, 0)], expose[("color", 1, 0)] = warp
-        if has_ins:
-            if a.flags & L.STEP_SYN_SPARSE:
-                # dense images for the caller (logging) only when maps are wanted: outside the regions syn IS the warped image
-                if cfg[5]:
-                    inside = (region & 1).bool().unsqueeze(1)
-                    expose[("syn", -1, 0)], expose[("syn", 1, 0)] = (torch.where(inside, s, w_) for s, w_ in zip(syn_data, warp))
-            else:
-                expose[("syn", -1, 0)], expose[("syn", 1, 0)] = syn_data
-        expose["has_ins"] = has_ins
+        for h in hints:
+            h.expose(expose[1] if h.student else expose[0], cfg[5])
         outs = [keep[4], keep[3]] + [maps[k] for k in MAP_NAMES if k in maps]
         ctx.mark_non_differentiable(*outs[1:])
         return tuple(outs)
@@ -251,26 +294,11 @@ class TemporalLossStepFn(Function):
     @once_differentiable
     def backward(ctx, g_total, *_):
         if g_total is None:
-            return (None,) * 12
-        leaf, syn, syn_data, g_syn, warp = ctx.graph
-        if syn is None:
-            g_warp = g_syn  # the identity producer
-        else:
-            from . import dyn_utils
-            # mal_amd.dyn_utils.image_synthesis turns the cotangent buffers into its result in place
-            reg = {g.data_ptr(): (ctx.snap[i] if ctx.snap is not None else None) for i, g in enumerate(g_syn)}
-            dyn_utils.INPLACE_COTANGENTS.update(reg)
-            try:
-                g_warp = torch.autograd.grad(syn, leaf, g_syn, allow_unused=True)
-            finally:
-                for k in reg:
-                    dyn_utils.INPLACE_COTANGENTS.pop(k, None)
-            g_warp = [torch.zeros_like(w) if g is None else g.contiguous() for g, w in zip(g_warp, warp)]
-        a = ctx.args
-        a.g_warp_m1, a.g_warp_p1 = g_warp[0].data_ptr(), g_warp[1].data_ptr()
-        ctx.g_warp = g_warp
+            return (None,) * 13
+        for h in ctx.hints:
+            h.backward()
         grads = _run_bwd(ctx, g_total)
-        return (*grads, None, None, None, None, None, ctx.g_ens)
+        return (*grads, None, None, None, None, None, None, ctx.g_ens)
 
 
 def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=None, noise=None, want_maps=True,
@@ -281,16 +309,20 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
     ``outputs[("disp", 0)]``, ``"consistency_mask"``, ``"augmentation_mask"``, ``"lowest_cost"``.
     With ``opt.temporal`` the producer ``image_synthesis(inputs, outputs, scale) -> has_ins`` is called between the
     library calls (``TemporalLossStepFn``); ``mono_outputs`` then receives ``("color", f, 0)``, ``("syn", f, 0)`` and
-    ``"has_ins"`` as the reference's generate_images_pred leaves them (trainer.py:1122-1125,1161-1165).
+    ``"has_ins"`` as the reference's generate_images_pred leaves them (trainer.py:1122-1125,1161-1165).  With
+    ``opt.main_temporal`` (trainer.py:1164, loss_utils.py:152-155) it is called for the student's pass as well -- after the
+    teacher's, as upstream -- and ``outputs`` receives the same keys and ``"multi_has_ins"``.
     Writes ``outputs["consistency_mask"]`` (x matching mask, trainer.py:592-593) when ``want_maps``.
     ``want_decisions`` (tests) adds ``maps["dec_teacher"]`` / ``["dec_student"]``: the per-pixel decisions of the two
     gradient passes (int32 (MAL_DEC_PLANES,B,H,W), include/mal_hip.h).
     Returns (losses dict, loss_list or None, maps dict)."""
     from . import config, loss_utils
-    if getattr(opt, "main_temporal", False) or getattr(opt, "no_ssim", False) or not getattr(opt, "distil", True) \
-            or getattr(opt, "sclm", 0) != 0:
-        raise L.MalError("loss_step covers the --distil [--temporal] [--learn_ens] [--no_ens [--dual_distil]] single-scale "
-                         "configuration; use MALLossPath.compute_batch_losses for main_temporal / no_ssim / non-distil runs")
+    if getattr(opt, "no_ssim", False) or not getattr(opt, "distil", True) or getattr(opt, "sclm", 0) != 0:
+        # (--no_ssim is read by Trainer.compute_reprojection_loss, trainer.py:1217, i.e. on the non-distil route only: the
+        # distillation losses call loss_utils.compute_reprojection_loss, :46-55, which has no such branch -- and Trainer.ssim
+        # does not exist then, trainer.py:318)
+        raise L.MalError("loss_step covers the --distil [--temporal] [--main_temporal] [--learn_ens] [--no_ens [--dual_distil]] "
+                         "single-scale configuration; use MALLossPath.compute_batch_losses for no_ssim / non-distil runs")
     ens_disp = None
     if getattr(opt, "learn_ens", False) and not getattr(opt, "no_ens", False):
         # the learnt ensemble head's disparity (loss_utils.py:240-241, trainer.py:596-597): warped by the ensemble pass,
@@ -298,9 +330,9 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
         if "ens_disp" not in outputs:
             raise KeyError("opt.learn_ens reads outputs['ens_disp'] (the shipped RepDepth has no such head: the caller's network provides it)")
         ens_disp = outputs["ens_disp"]
-    temporal = bool(getattr(opt, "temporal", False))
-    if temporal and image_synthesis is None:
-        raise L.MalError("loss_step with opt.temporal needs image_synthesis(inputs, outputs, scale) -> has_ins "
+    temporal, main_temporal = bool(getattr(opt, "temporal", False)), bool(getattr(opt, "main_temporal", False))
+    if (temporal or main_temporal) and image_synthesis is None:
+        raise L.MalError("loss_step with opt.temporal / opt.main_temporal needs image_synthesis(inputs, outputs, scale) -> has_ins "
                          "(upstream: dyn_utils.image_synthesis bound to the segmenter and the matcher, trainer.py:1161-1165)")
     color0 = inputs[("color", 0, 0)]
     B, _, H, W = color0.shape
@@ -328,9 +360,10 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
               outputs["consistency_mask"].to(torch.float32), keep, outputs["lowest_cost"], noise)
     cfg = (opt.min_depth, opt.max_depth, bool(getattr(opt, "no_ens", False)), w_main, w_distil, bool(want_maps),
            aug_is_mask, bool(want_decisions), philox, bool(getattr(opt, "dual_distil", False)))
-    if temporal:
+    if temporal or main_temporal:
         res = TemporalLossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
-                                       fix(tr[1]), consts, cfg, image_synthesis, inputs, mono_outputs, ens_disp)
+                                       fix(tr[1]), consts, cfg, image_synthesis, inputs, (mono_outputs, outputs),
+                                       (temporal, main_temporal), ens_disp)
     else:
         res = LossStepFn.apply(mono_outputs[("disp", 0)], outputs[("disp", 0)], fix(aa[-1]), fix(tr[-1]), fix(aa[1]),
                                fix(tr[1]), consts, cfg, ens_disp)

@@ -61,6 +61,7 @@ def run_oracle(batch, opt_kw, n0, n1, w_list=(0.7, 0.3), forced=None):
                 cons_target=outputs["consistency_target/0"].numpy(),
                 mono_color={f: mono_outputs[("color", f, 0)].detach().numpy() for f in (-1, 1)},
                 mono_preds=[c.detach().numpy() for c in mono_pred],
+                multi_preds=[c.detach().numpy() for c in multi_pred],
                 multi_color={f: outputs[("color", f, 0)].detach().numpy() for f in (-1, 1)},
                 mono_sample={f: mono_outputs[("sample", f, 0)].detach().numpy() for f in (-1, 1)},
                 multi_sample={f: outputs[("sample", f, 0)].detach().numpy() for f in (-1, 1)},
@@ -155,7 +156,7 @@ def oracle_decisions(o, batch, n0, no_ens=False):
     idx = torch.cat(trio, 1).argmin(1, keepdim=True)
     if len(trio) == 2:
         idx = idx * 2  # numbered as the kernels do: 0 teacher, 2 student
-    student = dict(win=win_s, distil=idx, l1=l1_signs([o["multi_color"][-1], o["multi_color"][1]], win_s),
+    student = dict(win=win_s, distil=idx, l1=l1_signs(o["multi_preds"], win_s),
                    smooth=_smooth_signs(batch["disp_student"]),
                    taps={f: AR.taps_of(t(o["multi_sample"][f]), H, W) for f in (-1, 1)})
     return dict(teacher=teacher, student=student, cmask=t(o["consistency_mask"]))

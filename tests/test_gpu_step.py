@@ -124,7 +124,7 @@ def _check_step(b, kw, n0, n1):
     assert (h["maps"]["consistency_mask"].numpy() != o["consistency_mask"]).mean() <= 1e-5
 
 
-@pytest.mark.parametrize("tag", CASES + ["step_b2_32x64_temporal", G.BIG_CASE])
+@pytest.mark.parametrize("tag", CASES + ["step_b2_32x64_temporal", "step_b2_32x64_temporal_main", G.BIG_CASE])
 def test_loss_step_equals_operator_route(tag):
     """one C call vs ~60 operator launches: same kernels underneath, same numbers -- so the decision-exact parity shown
     for the one-call step (tests/test_gpu_decisions.py) carries over to the operator-level drop-ins (mal_amd.loss_utils /
