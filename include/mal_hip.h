@@ -377,13 +377,13 @@ int mal_loss_step_bwd(const mal_step_args* args);
  *   both     + 1e-3 * smooth(disp_s / mean disp_s, color_s) / 2**s        (disp_s, color_s at the scale's own size)
  * total = (sum_s loss_teacher_s + sum_s loss_student_s) / (sclm + 1).  One host call forward (first sweep, upsampling,
  * 2 marching launches + 2 smoothness sweeps per scale, one reduction), one backward (adjoint upsampling, gathered in a
- * fixed order: no atomics).  --v1_multiscale, --ensemble, --no_ssim and the temporal hint are not covered (MAL_EINVAL
- * is not how they fail: the Python mirror routes them through the operator-level API).                              */
+ * fixed order: no atomics).  --v1_multiscale, --ensemble, --no_ssim are not covered (MAL_EINVAL is not how they fail: the
+ * Python mirror routes them through the operator-level API); the temporal hint: MAL_STEP_TEMPORAL, below.           */
 enum { MAL_MS_MAX_SCALES = 4 };
 typedef struct mal_ms_args {
   int B, H, W, sclm;                              /* scale s is (H >> s, W >> s); H, W divisible by 2**sclm */
   float min_depth, max_depth;
-  int flags;                                      /* MAL_STEP_AUG_MASK, MAL_STEP_NOISE_PHILOX */
+  int flags;                                      /* MAL_STEP_AUG_MASK, MAL_STEP_NOISE_PHILOX, MAL_STEP_TEMPORAL */
   const float *color0, *color_m1, *color_p1;      /* (B,3,H,W) */
   const float *color0_s[MAL_MS_MAX_SCALES];       /* inputs[("color",0,s)]: (B,3,H>>s,W>>s); [0] NULL = color0 */
   const float *K, *inv_K;                         /* (B,16) */
@@ -403,8 +403,24 @@ typedef struct mal_ms_args {
   float *g_disp_teacher[MAL_MS_MAX_SCALES], *g_disp_student[MAL_MS_MAX_SCALES];   /* backward outputs, nullable */
   float *g_axisangle_m1, *g_translation_m1, *g_axisangle_p1, *g_translation_p1;
   void *ws; size_t ws_bytes; void *stream;
+  /* MAL_STEP_TEMPORAL in `flags` (--temporal on this path, trainer.py:1161-1162 + 1279-1283): generate_images_pred calls the
+   * producer once PER SCALE on that scale's full-resolution warp of the teacher, and compute_losses adds r(syn_f^s, target)
+   * to scale s's per-pixel min when the LAST call reported instances (has_ins is overwritten per scale, :1162).  Three calls
+   * around the producers, as mal_loss_step_*: mal_loss_multiscale_warp (everything that does not wait for them: first
+   * sweep, upsampling, the teacher's forward pass per scale -> warp_*[s], the student's passes, smoothness),
+   * [syn^s = producer(warp^s)], mal_loss_multiscale_fwd (syn_*[s] in; losses, g_syn_*[s] out, unnormalised),
+   * [g_warp^s = producer^T(g_syn^s)], mal_loss_multiscale_bwd (g_warp_*[s] in).  Members per scale s <= sclm, all (B,3,H,W)
+   * planar, with the meaning of their mal_step_args namesakes; bit s of syn_sparse = MAL_STEP_SYN_SPARSE for scale s. */
+  float *warp_m1[MAL_MS_MAX_SCALES], *warp_p1[MAL_MS_MAX_SCALES];
+  const float *syn_m1[MAL_MS_MAX_SCALES], *syn_p1[MAL_MS_MAX_SCALES];
+  float *g_syn_m1[MAL_MS_MAX_SCALES], *g_syn_p1[MAL_MS_MAX_SCALES];
+  const float *g_warp_m1[MAL_MS_MAX_SCALES], *g_warp_p1[MAL_MS_MAX_SCALES];
+  const uint8_t *syn_region[MAL_MS_MAX_SCALES];
+  float *g_syn_region_m1[MAL_MS_MAX_SCALES], *g_syn_region_p1[MAL_MS_MAX_SCALES];
+  int warp_sample_stride, syn_sparse;
 } mal_ms_args;
 size_t mal_ms_workspace_bytes(int B, int H, int W, int sclm);
+int mal_loss_multiscale_warp(const mal_ms_args* args); /* MAL_STEP_TEMPORAL only */
 int mal_loss_multiscale_fwd(const mal_ms_args* args);
 int mal_loss_multiscale_bwd(const mal_ms_args* args);
 /* ---- DualRefine's loss loops over the deq iterations of scale 0 in one call per direction ------------------------------

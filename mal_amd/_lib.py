@@ -91,6 +91,7 @@ SIGNATURES = {
     "mal_loss_step_teacher_replay": (i32, [vp, i32]),
     "mal_tiebreak_noise": (i32, [C.c_uint64, C.c_uint64, i32, i32, i32, c_fp, vp]),
     "mal_ms_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "mal_loss_multiscale_warp": (i32, [vp]),
     "mal_loss_multiscale_fwd": (i32, [vp]),
     "mal_loss_multiscale_bwd": (i32, [vp]),
     "mal_dr_workspace_bytes": (sz, [i32, i32, i32, i32]),
@@ -148,7 +149,10 @@ class MsArgs(C.Structure):
                  ("losses", vp), ("loss_total", vp), ("consistency_mask_out", vp), ("g_total", vp),
                  ("g_disp_teacher", vp * 4), ("g_disp_student", vp * 4)] +
                 [(n, vp) for n in ("g_axisangle_m1", "g_translation_m1", "g_axisangle_p1", "g_translation_p1", "ws")] +
-                [("ws_bytes", sz), ("stream", vp)])
+                [("ws_bytes", sz), ("stream", vp)] +
+                [(n, vp * 4) for n in ("warp_m1", "warp_p1", "syn_m1", "syn_p1", "g_syn_m1", "g_syn_p1", "g_warp_m1", "g_warp_p1",
+                                       "syn_region", "g_syn_region_m1", "g_syn_region_p1")] +
+                [("warp_sample_stride", i32), ("syn_sparse", i32)])
 
 
 class DrArgs(C.Structure):

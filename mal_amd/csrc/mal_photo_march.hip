@@ -599,6 +599,8 @@ int smooth_march_sweep(const float* disp, const float* img, int B, int H, int W,
   hipLaunchKernelGGL(smooth_march_kernel, dim3(p.per_xcd * 8), dim3(64), 0, st, p);
   return launch_status();
 }
+// tasks per sample of one (H, W) map in smooth_march_sweep_batch's decomposition
+int smooth_march_batch_tasks(int H, int W) { return ((W + 61) / 62) * ((H + 11) / 12); }
 // n <= 8 maps in one launch; per_sample[k] receives the tasks per sample of map k
 int smooth_march_sweep_batch(int n, const float* const* disp, const float* const* img, int B, const int* H, const int* W,
                              float* const* gn, double* const* partial, hipStream_t st, int* per_sample) {
@@ -613,7 +615,7 @@ int smooth_march_sweep_batch(int n, const float* const* disp, const float* const
     p.segs = (H[k] + p.rows - 1) / p.rows;
     p.ntasks = B * p.strips * p.segs;
     q.first[k + 1] = q.first[k] + p.ntasks;
-    if (per_sample) per_sample[k] = p.strips * p.segs;
+    if (per_sample) per_sample[k] = smooth_march_batch_tasks(H[k], W[k]);  // (= p.strips * p.segs)
   }
   q.per_xcd = (q.first[n] + 7) / 8;
   hipLaunchKernelGGL(smooth_march_batch_kernel, dim3(q.per_xcd * 8), dim3(64), 0, st, q);

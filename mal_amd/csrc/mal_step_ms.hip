@@ -23,6 +23,13 @@ extern int g_march_halo1;  // mal_step.hip
 // mal_photo_march.hip / mal_step.hip
 int smooth_march_sweep_batch(int n, const float* const* disp, const float* const* img, int B, const int* H, const int* W,
                              float* const* gn, double* const* partial, hipStream_t st, int* per_sample);
+int photo_march_fused_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
+                           const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
+                           float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
+                           float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
+                           float* g_region1, unsigned* order, unsigned* order_count, const float* orig0, const float* orig1,
+                           size_t orig_stride, int target_texels, int weight_given);
+int smooth_march_batch_tasks(int H, int W);
 int tiebreak_noise_launch(unsigned long long seed, unsigned long long step, const unsigned long long* counter, unsigned mult,
                           int n, int B, int H, int W, float* const* out, hipStream_t st);
 
@@ -43,6 +50,10 @@ struct MsWs {
   double* stats;         // [2][2S][B]: mean, mean-coupling term
   float* gT;             // [S][2][B*16]
   float* coefs;          // [3S]: cR[net*S + s], cS[s]
+  // temporal hint, per scale: what the teacher's forward pass in front of the producer leaves (min over the two warped candidates,
+  // its winner), the four-way decision of the fused sweep (winner, automask weight, min) and that sweep's per-task differences
+  float* rp_warp[kMsS]; unsigned char* arg_warp[kMsS]; float* rp4[kMsS]; unsigned char* arg_t[kMsS]; float* w_t[kMsS];
+  double* bs_ph[kMsS];
   size_t bytes;
 };
 
@@ -75,6 +86,11 @@ static MsWs carve_ms(void* base, int B, int H, int W, int sclm) {
   w.stats = (double*)take((size_t)2 * 2 * S * B * 8);
   w.gT = (float*)take((size_t)S * 2 * B * 16 * 4);
   w.coefs = (float*)take(3 * kMsS * 4);
+  for (int s = 0; s < S; ++s) {
+    w.rp_warp[s] = (float*)take(map); w.rp4[s] = (float*)take(map); w.w_t[s] = (float*)take(map);
+    w.arg_warp[s] = (unsigned char*)take((size_t)B * HW); w.arg_t[s] = (unsigned char*)take((size_t)B * HW);
+    w.bs_ph[s] = (double*)take(nb * 4 * 2 * 8);  // tasks of >= 2 rows, as the one-call step's
+  }
   w.bytes = o;
   return w;
 }
@@ -194,10 +210,48 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* g_ou
 // ---------------------------------------------------------------- reduction + scalars
 struct MsFinal {
   const double* bs[2][kMsS]; const double* sm[2][kMsS]; const float* bgP[kMsS]; int per_sample_sm[kMsS];
+  // temporal hint: the teacher's sums are those of its forward pass (per_sample_t tasks) + the fused sweep's differences; its
+  // pose partials do not exist yet (bgP all null: no pose blocks in this launch, ms_pose_kernel follows the backward's sweeps)
+  const double* bs_ph[kMsS]; int per_sample_ph[kMsS]; int per_sample_t;
   const float* K; int per_sample, B, H, W, S;
   double* ps; double* stats; float* gT; float* losses; float* coefs; float* loss_total; unsigned* ticket;
   unsigned long long* noise_counter;
 };
+
+// g_T[s][f][b] = K_b^T [gP ; 0] from the teacher's per-task pose partials of scale s (one workgroup of 256)
+MAL_DEV void ms_pose_block(const float* bgP, int per_sample, const float* K, float* gT, int s, int b, int B, double* s_part,
+                           double* s_gP) {
+  const int tid = threadIdx.x;
+  const int v = tid % 24, sub = tid / 24;
+  double acc = 0.0;
+  if (sub < 10) {
+#pragma unroll 8
+    for (int t = sub; t < per_sample; t += 10) acc += (double)bgP[((size_t)b * per_sample + t) * 24 + v];
+  }
+  s_part[tid] = acc;
+  __syncthreads();
+  if (tid < 24) {
+    double a = 0.0;
+    for (int k = 0; k < 10; ++k) a += s_part[k * 24 + tid];
+    s_gP[tid] = a;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int f = tid >> 4, e = tid & 15, k = e >> 2, j = e & 3;
+    const float* Kb = K + b * 16;
+    double a = 0.0;
+    for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
+    gT[((size_t)(s * 2 + f) * B + b) * 16 + e] = (float)a;
+  }
+}
+struct MsPose { const float* bgP[kMsS]; const float* K; float* gT; int per_sample, B; };
+// temporal hint: the teacher's gradient sweeps run in the backward call; S*B workgroups reduce their pose partials there
+__global__ __launch_bounds__(256) void ms_pose_kernel(MsPose p) {
+  __shared__ double s_part[256];
+  __shared__ double s_gP[24];
+  const int s = blockIdx.x / p.B, b = blockIdx.x - s * p.B;
+  ms_pose_block(p.bgP[s], p.per_sample, p.K, p.gT, s, b, p.B, s_part, s_gP);
+}
 
 // 2S*B blocks: ps[pass][b][j], pass = net*S + s: j < 4 from the marching pass's partials, j >= 4 the smoothness sweep's;
 // S*B blocks: g_T[s][f][b] = K_b^T [gP ; 0] from the teacher's per-task pose partials of scale s;
@@ -211,13 +265,19 @@ __global__ __launch_bounds__(256) void ms_final_kernel(MsFinal p) {
   if ((int)blockIdx.x < 2 * S * B) {
     const int pass = blockIdx.x / B, b = blockIdx.x - pass * B, net = pass / S, s = pass - net * S;
     const int j = tid & 7, sub = tid >> 3;
-    const int n_t = j < 4 ? p.per_sample : p.per_sample_sm[s];
+    const int ps_n = net ? p.per_sample : p.per_sample_t;
+    const int n_t = j < 4 ? ps_n : p.per_sample_sm[s];
     const size_t stride = j < 4 ? 8 : 4;
-    const double* q = j < 4 ? p.bs[net][s] + (size_t)b * p.per_sample * 8 + j
+    const double* q = j < 4 ? p.bs[net][s] + (size_t)b * ps_n * 8 + j
                             : p.sm[net][s] + (size_t)b * p.per_sample_sm[s] * 4 + (j - 4);
     double acc = 0.0;
 #pragma unroll 8
     for (int t = sub; t < n_t; t += 32) acc += q[(size_t)t * stride];
+    if (net == 0 && p.bs_ph[s] && j < 2) {
+      const double* bd = p.bs_ph[s] + (size_t)b * p.per_sample_ph[s] * 2 + j;
+#pragma unroll 8
+      for (int t = sub; t < p.per_sample_ph[s]; t += 32) acc += bd[(size_t)t * 2];
+    }
     s_part[tid] = acc;
     __syncthreads();
     if (tid < 8) {
@@ -227,27 +287,7 @@ __global__ __launch_bounds__(256) void ms_final_kernel(MsFinal p) {
     }
   } else {
     const int r = blockIdx.x - 2 * S * B, s = r / B, b = r - s * B;
-    const int v = tid % 24, sub = tid / 24;
-    double acc = 0.0;
-    if (sub < 10) {
-#pragma unroll 8
-      for (int t = sub; t < p.per_sample; t += 10) acc += (double)p.bgP[s][((size_t)b * p.per_sample + t) * 24 + v];
-    }
-    s_part[tid] = acc;
-    __syncthreads();
-    if (tid < 24) {
-      double a = 0.0;
-      for (int k = 0; k < 10; ++k) a += s_part[k * 24 + tid];
-      s_gP[tid] = a;
-    }
-    __syncthreads();
-    if (tid < 32) {
-      const int f = tid >> 4, e = tid & 15, k = e >> 2, j = e & 3;
-      const float* Kb = p.K + b * 16;
-      double a = 0.0;
-      for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_gP[f * 12 + i * 4 + j];
-      p.gT[((size_t)(s * 2 + f) * B + b) * 16 + e] = (float)a;
-    }
+    ms_pose_block(p.bgP[s], p.per_sample, p.K, p.gT, s, b, B, s_part, s_gP);
   }
   __threadfence();
   __syncthreads();
@@ -479,12 +519,32 @@ extern "C" int mal_upsample_bilinear_adjoint(const float* g_out, int B, int h, i
   return launch_status();
 }
 
-extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
-  int rc = ms_check(a);
-  if (rc) return rc;
+static const float* ms_noise(const mal_ms_args* a, const MsWs& w, int s) {
+  return (a->flags & MAL_STEP_NOISE_PHILOX) ? w.noise[s] : a->noise[s];
+}
+static MarchParams ms_teacher_params(const mal_ms_args* a, const MsWs& w, int s) {
+  MarchParams p = march_params(a->B, a->H, a->W, a->min_depth, a->max_depth, 1e-7f, 0);
+  p.disp = s ? w.up[0][s] : a->disp_teacher[0]; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+  p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+  p.block_sums = w.bs[0][s]; p.block_gP = w.bgP[s];
+  p.cam = w.cam; p.cam_ready = 1;
+  return p;
+}
+static void ms_fold_launch(const MsWs& w, int B, int H, int W, int S, bool teachers, bool students, hipStream_t st) {
+  MsFold f = {};
+  int segs = 0, rows = 0, n = 0;
+  march_geometry(B, H, W, MAL_F_GRAD, nullptr, &segs, &rows);
+  f.B = B; f.H = H; f.W = W; f.rows = rows; f.segs = segs;
+  for (int s = 0; s < S; ++s)
+    for (int net = 0; net < 2; ++net)
+      if (net ? students : teachers) { f.G[n] = w.G_r[net][s]; f.bnd[n] = w.bnd[net][s]; ++n; }
+  if (n) hipLaunchKernelGGL(ms_fold_kernel, dim3((unsigned)(B * segs * 2), (unsigned)n), dim3(256), 0, st, f);
+}
+
+// everything that does not wait for a temporal-hint producer
+static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool temporal, int* per_sample_sm /*[S]*/) {
   const int B = a->B, H = a->H, W = a->W, S = a->sclm + 1;
-  MsWs w = carve_ms(a->ws, B, H, W, a->sclm);
-  hipStream_t st = (hipStream_t)a->stream;
+  int rc;
   // 1. first sweep: identity term (no noise: every scale adds its own), texel packing, poses, camera block
   {
     StepPoses sp = {};
@@ -498,13 +558,10 @@ extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
                               &sp, nullptr, nullptr, nullptr);
     if (rc) return rc;
   }
-  const float* noise[kMsS];
-  for (int s = 0; s < S; ++s) noise[s] = a->noise[s];
   if (a->flags & MAL_STEP_NOISE_PHILOX) {
     rc = tiebreak_noise_launch(a->noise_seed, a->noise_step, (const unsigned long long*)a->noise_counter, (unsigned)S, S, B, H, W,
                                w.noise, st);
     if (rc) return rc;
-    for (int s = 0; s < S; ++s) noise[s] = w.noise[s];
   }
   // 2. every scale's disparity at full resolution (trainer.py:1094-1096)
   if (S > 1) {
@@ -521,19 +578,23 @@ extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
   }
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
   const float merge_cons = (float)(1.0 / ((double)S * (double)B * H * W));
-  int per_sample = 1;
-  MsFinal fin = {};
   for (int s = 0; s < S; ++s) {
     const float* disp_t = s ? w.up[0][s] : a->disp_teacher[0];
     const float* disp_s = s ? w.up[1][s] : a->disp_student[0];
     {  // teacher: automask against the identity term + this scale's noise (trainer.py:1296-1311)
-      MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
-      p.disp = disp_t; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
-      p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
-      p.ident = w.ident; p.noise = noise[s]; p.g_reproj = w.G_r[0][s]; p.bnd = g_march_halo1 ? w.bnd[0][s] : nullptr;
-      p.block_sums = w.bs[0][s]; p.block_gP = w.bgP[s];
-      p.cam = w.cam; p.cam_ready = 1;
-      rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
+      MarchParams p = ms_teacher_params(a, w, s);
+      p.ident = w.ident; p.noise = ms_noise(a, w, s);
+      if (temporal) {
+        // forward only, in front of the producer: the warped images out; min over the two warped candidates, its winner, the
+        // automask weight and the sums stay for the fused sweep of mal_loss_multiscale_fwd (second copies: what it re-decides)
+        p.min_reproj = w.rp_warp[s]; p.argmin_out = w.arg_warp[s];
+        p.min_reproj2 = w.rp4[s]; p.argmin_out2 = w.arg_t[s]; p.weight_out = w.w_t[s];
+        p.color_out[0] = a->warp_m1[s]; p.color_out[1] = a->warp_p1[s]; p.color_out_stride = a->warp_sample_stride;
+        rc = march_launch(p, MAL_F_AUTOMASK | packed, st);
+      } else {
+        p.g_reproj = w.G_r[0][s]; p.bnd = g_march_halo1 ? w.bnd[0][s] : nullptr;
+        rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
+      }
       if (rc) return rc;
     }
     {  // student: mask = consistency (x matching, formed at scale 0 from the teacher's scale-0 depth, trainer.py:592-593)
@@ -556,19 +617,10 @@ extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
       p.cam = w.cam; p.cam_ready = 1;
       rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
       if (rc) return rc;
-      per_sample = p.strips * p.segs;
     }
-    for (int n = 0; n < 2; ++n) { fin.bs[n][s] = w.bs[n][s]; fin.sm[n][s] = w.sm[n][s]; }
-    fin.bgP[s] = w.bgP[s];
   }
-  if (g_march_halo1) {  // one-row halo of the 2S gradient passes: each boundary row's missing window row, in ONE launch
-    MsFold f = {};
-    int segs = 0, rows = 0;
-    march_geometry(B, H, W, MAL_F_GRAD, nullptr, &segs, &rows);
-    f.B = B; f.H = H; f.W = W; f.rows = rows; f.segs = segs;
-    for (int s = 0; s < S; ++s)
-      for (int n = 0; n < 2; ++n) { f.G[2 * s + n] = w.G_r[n][s]; f.bnd[2 * s + n] = w.bnd[n][s]; }
-    hipLaunchKernelGGL(ms_fold_kernel, dim3((unsigned)(B * segs * 2), (unsigned)(2 * S)), dim3(256), 0, st, f);
+  if (g_march_halo1) {  // one-row halo of the gradient passes: each boundary row's missing window row, in ONE launch
+    ms_fold_launch(w, B, H, W, S, !temporal, true, st);
     rc = launch_status();
     if (rc) return rc;
   }
@@ -586,14 +638,75 @@ extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
       }
     rc = smooth_march_sweep_batch(2 * S, sd, si, B, sh, sw, sg, sp, st, per);
     if (rc) return rc;
-    for (int s = 0; s < S; ++s) fin.per_sample_sm[s] = per[2 * s];
+    for (int s = 0; s < S; ++s) per_sample_sm[s] = per[2 * s];
   }
-  fin.K = a->K; fin.per_sample = per_sample; fin.B = B; fin.H = H; fin.W = W; fin.S = S;
+  return MAL_OK;
+}
+
+// tasks per sample of the smoothness sweep of scale s (the sweep ran in an earlier call: mal_loss_multiscale_warp)
+static int ms_smooth_tasks(int H, int W, int s) { return smooth_march_batch_tasks(H >> s, W >> s); }
+
+// the fused sweeps of the temporal hint (one per scale) and the reduction
+static int ms_back(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool temporal, const int* per_sample_sm) {
+  const int B = a->B, H = a->H, W = a->W, S = a->sclm + 1;
+  MsFinal fin = {};
+  int strips = 0, segs = 0;
+  march_geometry(B, H, W, MAL_F_GRAD, &strips, &segs, nullptr);
+  fin.per_sample = strips * segs; fin.per_sample_t = fin.per_sample;
+  if (temporal) {
+    march_geometry(B, H, W, 0, &strips, &segs, nullptr);
+    fin.per_sample_t = strips * segs;
+    for (int s = 0; s < S; ++s) {
+      if (!a->syn_m1[s] || !a->syn_p1[s] || !a->g_syn_m1[s] || !a->g_syn_p1[s]) return MAL_EINVAL;
+      const bool sparse = (a->syn_sparse >> s) & 1;
+      if (sparse && (!a->syn_region[s] || !a->warp_m1[s] || !a->warp_p1[s])) return MAL_EINVAL;
+      int rc = photo_march_fused_more(w.packed[0], a->syn_m1[s], a->syn_p1[s], 2, w.ident, ms_noise(a, w, s), w.rp_warp[s],
+                                      w.arg_warp[s], B, H, W, w.rp4[s], w.arg_t[s], w.w_t[s], w.bs_ph[s], a->g_syn_m1[s],
+                                      a->g_syn_p1[s], &fin.per_sample_ph[s], st, a->syn_region[s], a->g_syn_region_m1[s],
+                                      a->g_syn_region_p1[s], nullptr, nullptr, sparse ? a->warp_m1[s] : nullptr,
+                                      sparse ? a->warp_p1[s] : nullptr, (size_t)a->warp_sample_stride, 1, 0);
+      if (rc) return rc;
+      fin.bs_ph[s] = w.bs_ph[s];
+    }
+  }
+  for (int s = 0; s < S; ++s) {
+    for (int n = 0; n < 2; ++n) { fin.bs[n][s] = w.bs[n][s]; fin.sm[n][s] = w.sm[n][s]; }
+    fin.bgP[s] = temporal ? nullptr : w.bgP[s];
+    fin.per_sample_sm[s] = per_sample_sm[s];
+  }
+  fin.K = a->K; fin.B = B; fin.H = H; fin.W = W; fin.S = S;
   fin.ps = w.ps; fin.stats = w.stats; fin.gT = w.gT; fin.losses = a->losses; fin.coefs = w.coefs;
   fin.loss_total = a->loss_total; fin.ticket = w.ticket;
   fin.noise_counter = (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr;
-  hipLaunchKernelGGL(ms_final_kernel, dim3(3 * S * B), dim3(256), 0, st, fin);
+  hipLaunchKernelGGL(ms_final_kernel, dim3((temporal ? 2 : 3) * S * B), dim3(256), 0, st, fin);
   return launch_status();
+}
+
+extern "C" int mal_loss_multiscale_warp(const mal_ms_args* a) {
+  int rc = ms_check(a);
+  if (rc) return rc;
+  if (!(a->flags & MAL_STEP_TEMPORAL)) return MAL_EINVAL;
+  for (int s = 0; s <= a->sclm; ++s)
+    if (!a->warp_m1[s] || !a->warp_p1[s]) return MAL_EINVAL;
+  MsWs w = carve_ms(a->ws, a->B, a->H, a->W, a->sclm);
+  int per_sm[kMsS];
+  return ms_front(a, w, (hipStream_t)a->stream, true, per_sm);
+}
+
+extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
+  int rc = ms_check(a);
+  if (rc) return rc;
+  MsWs w = carve_ms(a->ws, a->B, a->H, a->W, a->sclm);
+  hipStream_t st = (hipStream_t)a->stream;
+  const bool temporal = (a->flags & MAL_STEP_TEMPORAL) != 0;
+  int per_sm[kMsS] = {};
+  if (!temporal) {
+    rc = ms_front(a, w, st, false, per_sm);
+    if (rc) return rc;
+  } else {
+    for (int s = 0; s <= a->sclm; ++s) per_sm[s] = ms_smooth_tasks(a->H, a->W, s);
+  }
+  return ms_back(a, w, st, temporal, per_sm);
 }
 
 extern "C" int mal_loss_multiscale_bwd(const mal_ms_args* a) {
@@ -601,6 +714,31 @@ extern "C" int mal_loss_multiscale_bwd(const mal_ms_args* a) {
   if (rc) return rc;
   const int B = a->B, H = a->H, W = a->W, S = a->sclm + 1;
   MsWs w = carve_ms(a->ws, B, H, W, a->sclm);
+  if (a->flags & MAL_STEP_TEMPORAL) {
+    // the teacher's gradient sweep per scale, with the four-way decisions of _fwd and what reaches the warped images through
+    // syn added before the chain rule through the warp; then the boundary rows and the pose partials it left
+    hipStream_t st = (hipStream_t)a->stream;
+    MsPose mp = {};
+    for (int s = 0; s < S; ++s) {
+      if (!a->g_warp_m1[s] || !a->g_warp_p1[s]) return MAL_EINVAL;
+      MarchParams p = ms_teacher_params(a, w, s);
+      p.ident = w.ident;  // unused by the TEMPORAL instantiation (the launch checks the flag combination only)
+      p.g_reproj = w.G_r[0][s]; p.bnd = g_march_halo1 ? w.bnd[0][s] : nullptr;
+      p.forced_w = w.w_t[s]; p.forced_arg = w.arg_t[s]; p.g_color[0] = a->g_warp_m1[s]; p.g_color[1] = a->g_warp_p1[s];
+      rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+      if (rc) return rc;
+      mp.bgP[s] = w.bgP[s]; mp.per_sample = p.strips * p.segs;
+    }
+    if (g_march_halo1) {
+      ms_fold_launch(w, B, H, W, S, true, false, st);
+      rc = launch_status();
+      if (rc) return rc;
+    }
+    mp.K = a->K; mp.gT = w.gT; mp.B = B;
+    hipLaunchKernelGGL(ms_pose_kernel, dim3((unsigned)(S * B)), dim3(256), 0, st, mp);
+    rc = launch_status();
+    if (rc) return rc;
+  }
   MsAssemble p = {};
   for (int s = 0; s < S; ++s) {
     for (int n = 0; n < 2; ++n) { p.G_r[n][s] = w.G_r[n][s]; p.gn[n][s] = w.gn[n][s]; }

@@ -158,9 +158,12 @@ class _Hint:
     """One pass's exchange with the temporal hint's producer: the teacher's (``--temporal``, mal_step_args.warp_* / syn_* /
     g_syn_* / g_warp_* / syn_region) or the student's (``--main_temporal``, the ``*_s_*`` members)."""
 
-    def __init__(self, a, student, B, H, W, dev):
-        self.a, self.tag, self.student = a, "_s" if student else "", student
+    def __init__(self, a, student, B, H, W, dev, scale=None):
+        """``scale`` (mal_ms_args, one hint per scale): the members are arrays indexed by it and the sparse bit lives in
+        ``syn_sparse``; None: mal_step_args"""
+        self.a, self.tag, self.student, self.scale = a, "_s" if student else "", student, scale
         self.sparse_flag = L.STEP_SYN_S_SPARSE if student else L.STEP_SYN_SPARSE
+        self.sparse = False
         self.shape, self.dev = (B, 3, H, W), dev
         # the two warped images of a sample side by side: the (2,3,H,W) pair the instance segmenter is fed is then a VIEW
         # (upstream stacks it per sample, dyn_utils.py:139-140); ("color", f, 0) are the two batch-strided halves
@@ -175,24 +178,51 @@ class _Hint:
         self.pre = [torch.empty(self.shape, dtype=torch.float32, device=dev) for _ in range(2)]
         self.has_ins, self.region, self.snap, self.syn, self.syn_data, self.leaf, self.g_syn = False, None, None, None, None, None, None
 
+    def _put(self, name, ptr):
+        if self.scale is None:
+            setattr(self.a, name, ptr)
+        else:
+            getattr(self.a, name)[self.scale] = ptr
+
     def _set(self, base, tensors, tail=("_m1", "_p1")):
         for t, sfx in zip(tensors, tail):
-            setattr(self.a, base + self.tag + sfx, t.data_ptr())
+            self._put(base + self.tag + sfx, t.data_ptr())
 
-    def produce(self, synth, inputs):
-        """between mal_loss_step_warp and mal_loss_step_fwd; anything raised here is the caller's to abort the step on"""
+    def _mark_sparse(self):
+        self.sparse = True
+        if self.scale is None:
+            self.a.flags |= self.sparse_flag
+        else:
+            self.a.syn_sparse |= 1 << self.scale
+
+    def produce(self, synth, inputs, defer=False):
+        """between mal_loss_step_warp and mal_loss_step_fwd; anything raised here is the caller's to abort the step on.
+        ``defer``: the caller calls ``finish`` itself (with the has_ins every scale is to use)"""
         B, _, H, W = self.shape
+        sc = self.scale or 0
         with torch.enable_grad():
             self.leaf = [w.detach().requires_grad_(True) for w in self.warp]
-            local = {("color", -1, 0): self.leaf[0], ("color", 1, 0): self.leaf[1], ("color_pair", 0): self.pair,
-                     ("syn_sparse_buffers", 0): (self.pre[0], self.pre[1])}
-            self.has_ins = bool(synth(inputs, local, 0))
-        a = self.a
+            local = {("color", -1, sc): self.leaf[0], ("color", 1, sc): self.leaf[1], ("color_pair", sc): self.pair,
+                     ("syn_sparse_buffers", sc): (self.pre[0], self.pre[1])}
+            self.has_ins = bool(synth(inputs, local, sc))
+        self.local = local
+        if not defer:
+            self.finish()
+
+    def finish(self, has_ins=None):
+        """what the producer left -> the argument block (``has_ins``: overrides the producer's own answer -- the multi-scale
+        path keeps the LAST scale's for all of them, trainer.py:1162)"""
+        B, _, H, W = self.shape
+        sc, local = self.scale or 0, self.local
+        if has_ins is not None:
+            if has_ins and not self.has_ins:
+                raise KeyError(("syn", -1, sc))  # as upstream: compute_losses reads a key this scale's producer call never wrote
+            self.has_ins = bool(has_ins)
         if self.has_ins:
-            self.syn = [local[("syn", -1, 0)], local[("syn", 1, 0)]]
+            self.syn = [local[("syn", -1, sc)], local[("syn", 1, sc)]]
             self.syn_data = [ops._req(t.detach(), "syn") for t in self.syn]
-            region = local.get(("syn_region", 0))
-            sparse = bool(local.get(("syn_sparse", 0)))
+            region = local.get(("syn_region", sc))
+            sparse = bool(local.get(("syn_sparse", sc)))
             if sparse and (region is None or any(t.data_ptr() != q.data_ptr() for t, q in zip(self.syn_data, self.pre))):
                 raise L.MalError("loss_step: ('syn_sparse', 0) needs the region map and the buffers of ('syn_sparse_buffers', 0)")
             if region is not None and not (region.is_cuda and region.dtype == torch.uint8 and tuple(region.shape) == (B, H, W)
@@ -200,9 +230,9 @@ class _Hint:
                 raise L.MalError("loss_step: ('syn_region', 0) must be a contiguous (B,H,W) uint8 device tensor")
             self.region = region
             if region is not None:
-                setattr(a, "syn" + self.tag + "_region", region.data_ptr())
+                self._put("syn" + self.tag + "_region", region.data_ptr())
                 if sparse:
-                    a.flags |= self.sparse_flag
+                    self._mark_sparse()
                 # ... and with the map the sweep leaves a second copy of d/d syn at the touched pixels: what the
                 # producer's in-place backward gathers from
                 self.snap = [torch.empty(self.shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
@@ -213,8 +243,8 @@ class _Hint:
             # read), the running min passes through and d/d syn is zero
             self.syn, self.syn_data = None, self.pre
             self.region = torch.zeros((B, H, W), dtype=torch.uint8, device=self.dev)
-            setattr(a, "syn" + self.tag + "_region", self.region.data_ptr())
-            a.flags |= self.sparse_flag
+            self._put("syn" + self.tag + "_region", self.region.data_ptr())
+            self._mark_sparse()
         # the cotangents of syn: this node's own buffers, which the producer's backward may turn into its result in place
         self.g_syn = [torch.empty(self.shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
         self._set("syn", self.syn_data)
@@ -222,15 +252,16 @@ class _Hint:
 
     def expose(self, out, dense):
         """what the reference's generate_images_pred leaves in the pass's outputs dict (trainer.py:1122-1125,1161-1165)"""
-        out[("color", -1, 0)], out[("color", 1, 0)] = self.warp
+        sc = self.scale or 0
+        out[("color", -1, sc)], out[("color", 1, sc)] = self.warp
         if self.has_ins:
-            if self.a.flags & self.sparse_flag:
+            if self.sparse:
                 # dense images for the caller (logging) only when maps are wanted: outside the regions syn IS the warped image
                 if dense:
                     inside = (self.region & 1).bool().unsqueeze(1)
-                    out[("syn", -1, 0)], out[("syn", 1, 0)] = (torch.where(inside, t, w_) for t, w_ in zip(self.syn_data, self.warp))
+                    out[("syn", -1, sc)], out[("syn", 1, sc)] = (torch.where(inside, t, w_) for t, w_ in zip(self.syn_data, self.warp))
             else:
-                out[("syn", -1, 0)], out[("syn", 1, 0)] = self.syn_data
+                out[("syn", -1, sc)], out[("syn", 1, sc)] = self.syn_data
         out["multi_has_ins" if self.student else "has_ins"] = self.has_ins
 
     def backward(self):
@@ -432,7 +463,8 @@ class MultiScaleLossFn(Function):
     @staticmethod
     def forward(ctx, consts, cfg, *leaves):
         colors, colors_s, K, inv_K, cmask, keep, lowest, noises = consts
-        min_depth, max_depth, sclm, aug_is_mask, philox, want_maps = cfg
+        min_depth, max_depth, sclm, aug_is_mask, philox, want_maps = cfg[:6]
+        hint = cfg[6] if len(cfg) > 6 else None  # --temporal: (image_synthesis, inputs, mono_outputs)
         S = sclm + 1
         req, p = ops._req, ops._p
         tens = [req(t, "leaf") for t in leaves]
@@ -473,7 +505,24 @@ class MultiScaleLossFn(Function):
             outs.append(cm)
         ws = _workspace_ms(dev, B, H, W, sclm)
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
+        hints = []
+        if hint is not None:
+            # the temporal hint on this path (trainer.py:1161-1162,1279-1283): the producer once per scale, on that scale's
+            # full-resolution warp of the teacher, between mal_loss_multiscale_warp and _fwd; has_ins is the LAST call's
+            synth, inputs, expose = hint
+            a.flags |= L.STEP_TEMPORAL
+            a.warp_sample_stride = 6 * H * W
+            hints = [_Hint(a, False, B, H, W, dev, scale=s_) for s_ in range(S)]
+            L.check(L.load().mal_loss_multiscale_warp(C.byref(a)), "mal_loss_multiscale_warp")
+            for h in hints:
+                h.produce(synth, inputs, defer=True)
+            has_ins = hints[-1].has_ins
+            for h in hints:
+                h.finish(has_ins)
         L.check(L.load().mal_loss_multiscale_fwd(C.byref(a)), "mal_loss_multiscale_fwd")
+        for h in hints:
+            h.expose(hint[2], want_maps)
+        ctx.hints = hints  # the argument block holds their buffers' pointers
         ctx.args, ctx.keep, ctx.S = a, (tens, cons, ws, losses, total), S
         ctx.ws_token = ops.claim_workspace(ws)
         ctx.set_materialize_grads(False)
@@ -495,22 +544,31 @@ class MultiScaleLossFn(Function):
         for s in range(S):
             a.g_disp_teacher[s], a.g_disp_student[s] = ops._p(grads[s]), ops._p(grads[S + s])
         a.g_axisangle_m1, a.g_translation_m1, a.g_axisangle_p1, a.g_translation_p1 = (ops._p(g) for g in grads[2 * S:])
+        for h in ctx.hints:
+            h.backward()  # the producer's own backward: g_syn -> g_warp of that scale
         L.check(L.load().mal_loss_multiscale_bwd(C.byref(a)), "mal_loss_multiscale_bwd")
         return (None, None, *grads)
 
 
-def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_maps=True):
+def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_maps=True, image_synthesis=None):
     """process_batch's loss half WITHOUT ``--distil`` (manydepth/trainer.py:573-612 with ``compute_losses``, :1248-1475,
     for both networks) over scales 0..``opt.sclm`` in one call per direction.  Reads ``inputs[("color", f, 0)]``,
     ``("color", 0, s)``, ``("K", 0)``, ``("inv_K", 0)``; ``mono_outputs[("disp", s)]``, ``("axisangle", 0, f)``,
     ``("translation", 0, f)``; ``outputs[("disp", s)]``, ``"consistency_mask"``, ``"augmentation_mask"`` and, when present,
     ``"lowest_cost"`` (then the matching mask of trainer.py:592-593 is applied and ``outputs["consistency_mask"]``
     rewritten).  ``noises``: one (B,1,H,W) N(0,1) map per scale (default: drawn as ``config.noise_source`` says).
+    With ``opt.temporal`` the producer ``image_synthesis(inputs, outputs, scale) -> has_ins`` is called once per scale on the
+    teacher's full-resolution warp of that scale (trainer.py:1161-1162) and, when the LAST call reported instances, every
+    scale's min takes the two synthesised candidates in (:1279-1283; a scale whose own call reported none then raises the
+    ``KeyError`` upstream raises); ``mono_outputs`` receives ``("color", f, s)``, ``("syn", f, s)`` and ``"has_ins"``.
     Returns (losses, mono_losses): ``losses`` as process_batch leaves it (the teacher's entries added to the
     student's, :614-616; ``losses["loss"]`` carries the gradient), ``mono_losses`` the teacher's own."""
     from . import config, loss_utils
     sclm = int(getattr(opt, "sclm", 0))
-    unsupported = [k for k in ("distil", "temporal", "v1_multiscale", "ensemble", "no_ssim", "disable_automasking",
+    temporal = bool(getattr(opt, "temporal", False))
+    if temporal and image_synthesis is None:
+        raise L.MalError("loss_step_multiscale with opt.temporal needs image_synthesis(inputs, outputs, scale) -> has_ins")
+    unsupported = [k for k in ("distil", "v1_multiscale", "ensemble", "no_ssim", "disable_automasking",
                                "disable_motion_masking", "no_matching_augmentation") if getattr(opt, k, False)]
     if unsupported or sclm >= L.MS_MAX_SCALES or list(opt.frame_ids) != [0, -1, 1]:
         raise L.MalError("loss_step_multiscale covers the non-distil sclm <= 3 configuration with frames [0,-1,1]; %s: use "
@@ -536,7 +594,8 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
     consts = ((color0, inputs[("color", -1, 0)], inputs[("color", 1, 0)]), [inputs[("color", 0, s)] for s in range(1, sclm + 1)],
               inputs[("K", 0)], inputs[("inv_K", 0)], outputs["consistency_mask"].to(torch.float32), keep,
               outputs.get("lowest_cost"), noises)
-    cfg = (opt.min_depth, opt.max_depth, sclm, aug_is_mask, philox, bool(want_maps))
+    cfg = (opt.min_depth, opt.max_depth, sclm, aug_is_mask, philox, bool(want_maps),
+           (image_synthesis, inputs, mono_outputs) if temporal else None)
     leaves = [mono_outputs[("disp", s)] for s in range(sclm + 1)] + [outputs[("disp", s)] for s in range(sclm + 1)] + \
              [aa[-1], tr[-1], aa[1], tr[1]]
     res = MultiScaleLossFn.apply(consts, cfg, *leaves)

@@ -225,17 +225,22 @@ def multiscale_inputs(q, sclm):
     return color, disp
 
 
-def run_reference_multiscale(ML, MLU, q, sclm, noise_seed, tag):
+def run_reference_multiscale(ML, MLU, q, sclm, noise_seed, tag, temporal=False):
     """The non-distillation ``Trainer.compute_losses`` over ``sclm+1`` disparity scales for both networks
     (manydepth/trainer.py:1078-1170 per-scale upsample + warp, :1248-1475 per-scale loss / 2**scale, total / (sclm+1)):
     the glue restated here, every arithmetic step through the reference's own objects (``SSIM``,
     ``compute_reprojection_loss``, ``compute_loss_masks``, ``get_smooth_loss``, ``disp_to_depth``, ``BackprojectDepth``,
-    ``Project3D``) and ATen's ``interpolate`` / ``grid_sample``."""
-    from mal_amd.synthetic import to_dicts
+    ``Project3D``) and ATen's ``interpolate`` / ``grid_sample``.  ``temporal`` (--temporal on this path): the producer is
+    called once per scale on the teacher's warp of that scale, has_ins is the last call's (trainer.py:1161-1162), and the
+    teacher's min of every scale takes r(syn_f, target) in (:1279-1283); the producer is the rectangle stand-in of
+    ``q["syn_rects"]`` (mal_amd.synthetic.fake_image_synthesis: Mask2Former is out of scope)."""
+    from mal_amd.synthetic import to_dicts, fake_image_synthesis
     from oracle.mal_oracle import default_opt
     B, _, H, W = q["color0"].shape
     opt = default_opt(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
     inputs, mono_outputs, outputs, leaves = to_dicts(q, ML.transformation_from_parameters)
+    synth = fake_image_synthesis(q["syn_rects"]) if temporal else None
+    state = {"has_ins": False}
     color_s, disp_s = multiscale_inputs(q, sclm)
     for s in range(1, sclm + 1):
         inputs[("color", 0, s)] = color_s[s]
@@ -259,13 +264,18 @@ def run_reference_multiscale(ML, MLU, q, sclm, noise_seed, tag):
                 grid = project(pts, inputs[("K", 0)], T)
                 outs[("color", f, scale)] = F.grid_sample(inputs[("color", f, 0)], grid, padding_mode="border",
                                                           align_corners=True)
+            if not is_multi and temporal:  # trainer.py:1161-1162
+                state["has_ins"] = synth(inputs, outs, scale)
 
     def losses_of(outs, is_multi, noises):  # trainer.py:1248-1475
         losses, total = {}, 0
         target = inputs[("color", 0, 0)]
         for scale in range(sclm + 1):
             disp, color = outs[("disp", scale)], inputs[("color", 0, scale)]
-            R = torch.cat([MLU.compute_reprojection_loss(ssim, outs[("color", f, scale)], target) for f in (-1, 1)], 1)
+            R = [MLU.compute_reprojection_loss(ssim, outs[("color", f, scale)], target) for f in (-1, 1)]
+            if not is_multi and temporal and state["has_ins"]:  # trainer.py:1279-1283
+                R += [MLU.compute_reprojection_loss(ssim, outs[("syn", f, scale)], target) for f in (-1, 1)]
+            R = torch.cat(R, 1)
             I = torch.cat([MLU.compute_reprojection_loss(ssim, inputs[("color", f, 0)], target) for f in (-1, 1)], 1)
             ident, _ = torch.min(I, dim=1, keepdim=True)
             rp, _ = torch.min(R, dim=1, keepdim=True)
@@ -313,7 +323,7 @@ def run_reference_multiscale(ML, MLU, q, sclm, noise_seed, tag):
         for name in ("disp_teacher", "disp_student"):
             d["in/%s_s%d" % (name, s)] = disp_s[name][s].half().numpy()
     d.update(pack_inputs(q))
-    d["opt"] = np.array(repr(sorted({"sclm": sclm, "distil": False}.items())))
+    d["opt"] = np.array(repr(sorted(dict({"sclm": sclm, "distil": False}, **({"temporal": True} if temporal else {})).items())))
     path = os.path.join(OUT, tag + ".npz")
     np.savez_compressed(path, **d)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", "teacher", d["teacher/loss"], "student", d["student/loss"])
@@ -390,6 +400,10 @@ def main():
     from mal_amd.synthetic import make_batch
     torch.set_num_threads(8)
     small = quantize_batch(make_batch(2, 32, 64, seed=1234))
+    if sys.argv[1:] == ["ms_temporal"]:  # `python -m oracle.gen_golden ms_temporal` writes that one case only
+        run_reference_multiscale(ML, MLU, quantize_batch(make_batch(2, 48, 96, seed=1238, with_syn=True)), 3, 1009,
+                                 "multiscale_b2_48x96_sclm3_temporal", temporal=True)
+        return
     if sys.argv[1:] != ["learnens"]:  # `python -m oracle.gen_golden learnens` writes that one case only
         run_reference_layers(ML, MLU, DL, "layers_b2_24x40")
         run_reference_layers(ML, MLU, DL, "layers_b1_19x33", B=1, H=19, W=33, seed=78)
@@ -413,6 +427,8 @@ def main():
     big = quantize_batch(make_batch(2, 192, 640, seed=1234))
     run_reference_step(ML, MLU, big, {}, 2000, False, "step_b2_192x640_distil")
     run_reference_multiscale(ML, MLU, quantize_batch(make_batch(2, 48, 96, seed=1237)), 3, 1007, "multiscale_b2_48x96_sclm3")
+    run_reference_multiscale(ML, MLU, quantize_batch(make_batch(2, 48, 96, seed=1238, with_syn=True)), 3, 1009,
+                             "multiscale_b2_48x96_sclm3_temporal", temporal=True)
 
 
 if __name__ == "__main__":

@@ -39,6 +39,7 @@ def batch_from_golden(z):
 
 
 MULTISCALE_CASE = "multiscale_b2_48x96_sclm3"
+MULTISCALE_TEMPORAL_CASE = "multiscale_b2_48x96_sclm3_temporal"  # --temporal on the non-distil path (trainer.py:1161-1162,1279-1283)
 
 
 def multiscale_dicts(z, pose_fn, device="cpu"):

@@ -46,22 +46,23 @@ def test_upsampling_is_atens(shape):
     assert torch.equal(got, again)  # deterministic
 
 
-def _hip_step(inputs, mono_outputs, outputs, leaves, kw, noises):
+def _hip_step(inputs, mono_outputs, outputs, leaves, kw, noises, synth=None):
     from mal_amd import step, trainer
     for f, s in ((-1, "m1"), (1, "p1")):
         mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + s]
         mono_outputs[("translation", 0, f)] = leaves["translation_" + s]
     losses, mono_losses = step.loss_step_multiscale(trainer.default_options(**kw), inputs, mono_outputs, outputs,
-                                                    noises=None if noises is None else [n.to(DEV) for n in noises])
+                                                    noises=None if noises is None else [n.to(DEV) for n in noises],
+                                                    image_synthesis=synth)
     losses["loss"].backward()
     torch.cuda.synchronize()
     return losses, mono_losses
 
 
-def _oracle_step(inputs, mono_outputs, outputs, kw, nt, ns, matching=False):
+def _oracle_step(inputs, mono_outputs, outputs, kw, nt, ns, matching=False, synth=None):
     opt = O.default_opt(**kw)
-    O.generate_images_pred(opt, inputs, mono_outputs)
-    lt = O.compute_losses(opt, inputs, mono_outputs, is_multi=False, noises=[n.clone() for n in nt])
+    has_ins = O.generate_images_pred(opt, inputs, mono_outputs, synth=synth)
+    lt = O.compute_losses(opt, inputs, mono_outputs, is_multi=False, has_ins=has_ins, noises=[n.clone() for n in nt])
     for key in list(mono_outputs.keys()):
         if isinstance(key, tuple) and key[0] in ("depth", "disp"):
             outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
@@ -73,17 +74,24 @@ def _oracle_step(inputs, mono_outputs, outputs, kw, nt, ns, matching=False):
     return lt, ls
 
 
-def test_four_scales_against_the_reference_fixture():
+@pytest.mark.parametrize("temporal", [False, True], ids=["plain", "temporal"])
+def test_four_scales_against_the_reference_fixture(temporal):
     """sclm=3 (BASELINE configs[1]'s "4 scales"): the reference's own numbers for both networks' compute_losses over four
-    disparity scales (oracle/gen_golden.py run_reference_multiscale)"""
+    disparity scales (oracle/gen_golden.py run_reference_multiscale); ``temporal``: with --temporal on this path
+    (trainer.py:1161-1162,1279-1283) -- the producer once per scale between mal_loss_multiscale_warp and _fwd, the
+    synthesised candidates in every scale's min of the teacher, their gradient back through the producer in _bwd"""
     from tests import golden_io as G
-    z = G.load(G.MULTISCALE_CASE)
+    from mal_amd.synthetic import fake_image_synthesis
+    z = G.load(G.MULTISCALE_TEMPORAL_CASE if temporal else G.MULTISCALE_CASE)
     b, sclm, inputs, mono_outputs, outputs, leaves = G.multiscale_dicts(z, lambda a, t, inv: None, DEV)
     outputs.pop("lowest_cost", None)  # the fixture calls compute_losses directly: no matching mask
     B, _, H, W = b["color0"].shape
     nt, _ = G.multiscale_noises(z, (B, 1, H, W), sclm)
-    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
-    losses, mono_losses = _hip_step(inputs, mono_outputs, outputs, leaves, kw, nt)
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False, temporal=temporal)
+    losses, mono_losses = _hip_step(inputs, mono_outputs, outputs, leaves, kw, nt,
+                                    synth=fake_image_synthesis(b["syn_rects"]) if temporal else None)
+    if temporal:
+        assert mono_outputs["has_ins"] is True and all(("syn", f, s_) in mono_outputs for f in (-1, 1) for s_ in range(sclm + 1))
     N = B * H * W
     got = {"teacher": mono_losses, "student": {k.replace("main/", ""): v for k, v in losses.items() if k.startswith("main/")}}
     for s in range(sclm + 1):
@@ -123,20 +131,24 @@ def _build(batch, dev, sclm):
     return inputs, mono_outputs, outputs, leaves
 
 
-@pytest.mark.parametrize("case", [(12, 192, 640, 3, True), (3, 40, 72, 2, False), (2, 32, 64, 0, True)],
-                         ids=["baseline-b12-192x640-sclm3", "b3-40x72-sclm2", "b2-32x64-sclm0"])
+@pytest.mark.parametrize("case", [(12, 192, 640, 3, True, False), (3, 40, 72, 2, False, False), (2, 32, 64, 0, True, False),
+                                  (12, 192, 640, 3, True, True), (3, 40, 72, 2, False, True)],
+                         ids=["baseline-b12-192x640-sclm3", "b3-40x72-sclm2", "b2-32x64-sclm0",
+                              "baseline-b12-192x640-sclm3-temporal", "b3-40x72-sclm2-temporal"])
 def test_against_the_oracle(case):
-    B, H, W, sclm, matching = case
-    batch = make_batch(B, H, W, seed=79)
+    from mal_amd.synthetic import fake_image_synthesis
+    B, H, W, sclm, matching, temporal = case
+    batch = make_batch(B, H, W, seed=79, with_syn=temporal)
     g = torch.Generator().manual_seed(12)
     nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
-    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False, temporal=temporal)
+    synth = fake_image_synthesis(batch["syn_rects"]) if temporal else None
     oi, om, oo, ol = _build(batch, "cpu", sclm)
-    rt, rs = _oracle_step(oi, om, oo, kw, nt, nt, matching=matching)
+    rt, rs = _oracle_step(oi, om, oo, kw, nt, nt, matching=matching, synth=synth)
     hi, hm, ho, hl = _build(batch, DEV, sclm)
     if not matching:
         ho.pop("lowest_cost")
-    losses, mono_losses = _hip_step(hi, hm, ho, hl, kw, nt)
+    losses, mono_losses = _hip_step(hi, hm, ho, hl, kw, nt, synth=synth)
     N = B * H * W
     tie_t = 40.0 * (sclm + 1) / N
     for k, v in rt.items():
@@ -192,6 +204,89 @@ def test_in_kernel_noise_equals_the_same_noise_handed_in():
             assert torch.equal(hl[k].grad, hl2[k].grad), k
     finally:
         config.noise_source, config.noise_seed = old
+
+
+def test_temporal_equals_operator_route():
+    """--temporal with sclm > 0 through the three library calls vs the operator-level route (MALLossPath: materialising warp,
+    producer, materialised-candidate kernels, per scale): same kernels underneath, same numbers"""
+    from mal_amd import config, layers, trainer
+    from mal_amd.synthetic import fake_image_synthesis
+    B, H, W, sclm = 3, 40, 72, 2
+    batch = make_batch(B, H, W, seed=79, with_syn=True)
+    g = torch.Generator().manual_seed(12)
+    nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False, temporal=True)
+    synth = fake_image_synthesis(batch["syn_rects"])
+    hi, hm, ho, hl = _build(batch, DEV, sclm)
+    ho.pop("lowest_cost")
+    losses, mono_losses = _hip_step(hi, hm, ho, hl, kw, nt, synth=synth)
+    inputs, mono_outputs, outputs, leaves = to_dicts(batch, layers.transformation_from_parameters, device=DEV)
+    for s in range(1, sclm + 1):
+        inputs[("color", 0, s)] = torch.nn.functional.avg_pool2d(batch["color0"], 2 ** s).to(DEV)
+        for name, outs in (("disp_teacher", mono_outputs), ("disp_student", outputs)):
+            leaf = torch.nn.functional.avg_pool2d(batch[name], 2 ** s).to(DEV).clone().requires_grad_(True)
+            leaves["%s_s%d" % (name, s)] = leaf
+            outs[("disp", s)] = leaf
+    lp = trainer.LossPath(trainer.default_options(**kw), fuse=True, image_synthesis=synth)
+    old = config.noise_source
+    config.noise_source = "given"
+    try:
+        lp.generate_images_pred(inputs, mono_outputs)
+        lt, _ = lp.compute_losses(inputs, mono_outputs, is_multi=False, noises=[n.to(DEV) for n in nt])
+        for key in list(mono_outputs.keys()):
+            if isinstance(key, tuple) and key[0] in ("depth", "disp"):
+                outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
+        lp.generate_images_pred(inputs, outputs, is_multi=True)
+        ls, _ = lp.compute_losses(inputs, outputs, is_multi=True)
+    finally:
+        config.noise_source = old
+    (lt["loss"] + ls["loss"]).backward()
+    torch.cuda.synchronize()
+    total = float((lt["loss"] + ls["loss"]).detach())
+    assert abs(float(losses["loss"].detach()) - total) <= 2e-6 * abs(total), (float(losses["loss"].detach()), total)
+    for k, v in lt.items():
+        assert abs(float(mono_losses[k]) - float(v.detach())) <= 2e-6 * max(abs(float(v.detach())), 1e-3), k
+    for k in hl:
+        a_, b_ = hl[k].grad.cpu().numpy(), leaves[k].grad.cpu().numpy().reshape(hl[k].grad.shape)
+        assert np.abs(a_ - b_).max() <= 2e-5 * np.abs(b_).max(), (k, np.abs(a_ - b_).max() / np.abs(b_).max())
+
+
+def test_temporal_last_scale_decides_for_all():
+    """has_ins is overwritten per scale (trainer.py:1162): the LAST scale's answer switches the synthesised candidates on or off
+    for every scale -- off: the plain four-scale loss (other task decomposition of the teacher's sums: 2e-6); on while an
+    earlier scale produced nothing: upstream's KeyError"""
+    from mal_amd.synthetic import fake_image_synthesis
+    B, H, W, sclm = 2, 48, 96, 2
+    batch = make_batch(B, H, W, seed=83, with_syn=True)
+    g = torch.Generator().manual_seed(13)
+    nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+    real = fake_image_synthesis(batch["syn_rects"])
+    hi, hm, ho, hl = _build(batch, DEV, sclm)
+    ref, ref_m = _hip_step(hi, hm, ho, hl, kw, nt)
+    calls = []
+
+    def last_says_no(inputs, outputs, scale):
+        calls.append(scale)
+        real(inputs, outputs, scale)
+        return scale != sclm
+
+    hi2, hm2, ho2, hl2 = _build(batch, DEV, sclm)
+    got, got_m = _hip_step(hi2, hm2, ho2, hl2, dict(kw, temporal=True), nt, synth=last_says_no)
+    assert calls == list(range(sclm + 1)) and hm2["has_ins"] is False
+    assert abs(float(got["loss"]) - float(ref["loss"])) <= 2e-6 * abs(float(ref["loss"]))
+    for k in hl:
+        a_, b_ = hl2[k].grad.cpu().numpy(), hl[k].grad.cpu().numpy()
+        assert np.abs(a_ - b_).max() <= 2e-5 * np.abs(b_).max(), k
+
+    def first_says_no(inputs, outputs, scale):
+        if scale == 0:
+            return False
+        return real(inputs, outputs, scale)
+
+    hi3, hm3, ho3, hl3 = _build(batch, DEV, sclm)
+    with pytest.raises(KeyError):
+        _hip_step(hi3, hm3, ho3, hl3, dict(kw, temporal=True), nt, synth=first_says_no)
 
 
 def test_unsupported_configurations_are_refused():

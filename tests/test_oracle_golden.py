@@ -116,18 +116,26 @@ def test_step_against_reference(tag):
         G.assert_close(r["loss_list"][1].item(), z["loss_list1"], 0)
 
 
-def test_multiscale_compute_losses_against_reference():
+@pytest.mark.parametrize("tag", [G.MULTISCALE_CASE, G.MULTISCALE_TEMPORAL_CASE])
+def test_multiscale_compute_losses_against_reference(tag):
     """sclm=3 (BASELINE configs[1]'s "4 scales"): the non-distillation compute_losses of both networks over four disparity
     scales (manydepth/trainer.py:1088-1125,1248-1475) -- per-scale upsample + warp, loss / 2**scale, total / (sclm+1) --
     reproduces the fixture generated through the reference's own SSIM / compute_reprojection_loss / compute_loss_masks /
-    get_smooth_loss / geometry objects, bit for bit."""
-    z = G.load(G.MULTISCALE_CASE)
+    get_smooth_loss / geometry objects, bit for bit.  The second fixture adds --temporal on this path (:1161-1162,1279-1283:
+    the producer once per scale, the synthesised candidates in every scale's min of the teacher)."""
+    z = G.load(tag)
     b, sclm, inputs, mono_outputs, outputs, leaves = G.multiscale_dicts(z, O.transformation_from_parameters)
     B, _, H, W = b["color0"].shape
     nt, ns = G.multiscale_noises(z, (B, 1, H, W), sclm)
-    opt = O.default_opt(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
-    O.generate_images_pred(opt, inputs, mono_outputs)
-    lt = O.compute_losses(opt, inputs, mono_outputs, is_multi=False, noises=nt)
+    kw = G.opt_kwargs(z)
+    opt = O.default_opt(height=H, width=W, batch_size=B, **kw)
+    synth = None
+    if kw.get("temporal"):
+        from mal_amd.synthetic import fake_image_synthesis
+        synth = fake_image_synthesis(b["syn_rects"])
+    has_ins = O.generate_images_pred(opt, inputs, mono_outputs, synth=synth)
+    assert has_ins == bool(kw.get("temporal"))
+    lt = O.compute_losses(opt, inputs, mono_outputs, is_multi=False, has_ins=has_ins, noises=nt)
     for key in list(mono_outputs.keys()):
         if isinstance(key, tuple) and key[0] in ("depth", "disp"):
             outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
