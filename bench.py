@@ -75,6 +75,12 @@ def parse():
                     help="hand the three (B,3,H,W) images over in torch.channels_last memory format: they ARE the texel images the "
                          "passes gather from, the step skips its re-layout (MAL_STEP_TEXEL_INPUTS).  The default (the headline) "
                          "keeps the reference's NCHW tensors and reports this variant in the `channels_last` side block")
+    ap.add_argument("--main-temporal", action="store_true",
+                    help="--mode step with --main_temporal as well (manydepth/trainer.py:1164, loss_utils.py:152-155): the student's "
+                         "warped images go through the producer too (MAL_STEP_MAIN_TEMPORAL); a variant run, not the headline")
+    ap.add_argument("--ms-temporal", action="store_true",
+                    help="--mode multiscale with --temporal (trainer.py:1161-1162,1279-1283): the producer once per scale between "
+                         "mal_loss_multiscale_warp and _fwd; a variant run")
     ap.add_argument("--value", choices=["auto", "loss", "train"], default="auto",
                     help="what the line's `value` is: loss = the loss path (the default at N=1), train = the whole training "
                          "step of the harness (the default at N>1: the quantity the >= 6x DP target is about); auto picks by N")
@@ -170,7 +176,7 @@ class TrainStep:
 class Step:
     """Everything a step needs, resident on the device."""
 
-    def __init__(self, dev, seed, mode="step", channels_last=False):
+    def __init__(self, dev, seed, mode="step", channels_last=False, main_temporal=False, ms_temporal=False):
         from mal_amd import config, layers, trainer, step as step_mod
         self.mode, self.step_mod = mode, step_mod
         from mal_amd.synthetic import make_batch
@@ -207,7 +213,8 @@ class Step:
             ins_model, matcher = instance_stub(B, H, W, n_inst=3, seed=seed, device=dev)
             synth = lambda inputs, outputs, scale: dyn_utils.image_synthesis(inputs, outputs, scale, 0.5, ins_model, matcher)
             self.synth = synth
-            self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, temporal=True), fuse=True,
+            self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, temporal=True,
+                                                               main_temporal=bool(main_temporal and mode == "step")), fuse=True,
                                        image_synthesis=synth)
         elif mode == "dualrefine":
             from mal_amd import dualrefine
@@ -217,7 +224,13 @@ class Step:
         elif mode in ("multiscale", "multiscale_ops"):
             # --scales 0..3 semantics (sclm=3): per-scale disparities upsampled to full resolution, loss
             # / 2**scale, total / (sclm+1); the shipped decoder only feeds scale 0, so the lower scales are pooled copies
-            self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, sclm=3, distil=False), fuse=True)
+            self.lp = trainer.LossPath(trainer.default_options(height=H, width=W, batch_size=B, sclm=3, distil=False,
+                                                               temporal=bool(ms_temporal and mode == "multiscale")), fuse=True)
+            if ms_temporal and mode == "multiscale":
+                from mal_amd import dyn_utils
+                from mal_amd.synthetic import instance_stub
+                ins_model, matcher = instance_stub(B, H, W, n_inst=3, seed=seed, device=dev)
+                self.synth = lambda inputs, outputs, scale: dyn_utils.image_synthesis(inputs, outputs, scale, 0.5, ins_model, matcher)
             for sc in (1, 2, 3):
                 k = 2 ** sc
                 self.inputs[("color", 0, sc)] = torch.nn.functional.avg_pool2d(self.inputs[("color", 0, 0)], k)
@@ -252,7 +265,8 @@ class Step:
             for sc in (1, 2, 3):
                 mono_outputs[("disp", sc)] = lv["disp_teacher_s%d" % sc]
                 outputs[("disp", sc)] = lv["disp_student_s%d" % sc]
-            losses, _ = self.step_mod.loss_step_multiscale(self.lp.opt, self.inputs, mono_outputs, outputs, want_maps=False)
+            losses, _ = self.step_mod.loss_step_multiscale(self.lp.opt, self.inputs, mono_outputs, outputs, want_maps=False,
+                                                           image_synthesis=self.synth)
             losses["loss"].backward(gradient=self.one)
             return losses["loss"]
         self.ops.clear_packed_sources()  # a real step sees new images: repack them every step
@@ -553,7 +567,8 @@ def main():
         args.graph = 0  # host-side RNG, optimizer and collective in the step
         args.no_cpu_baseline = True
     else:
-        step = Step(dev, 1234 + rank, args.mode, channels_last=args.channels_last)
+        step = Step(dev, 1234 + rank, args.mode, channels_last=args.channels_last, main_temporal=args.main_temporal,
+                    ms_temporal=args.ms_temporal)
     batch_cpu = step.batch_cpu
     step_B = getattr(step, "B", B)  # images per rank and step (read here: the train_step block below frees `step`)
 
@@ -829,6 +844,10 @@ def main():
         out["loss_blc"] = blc_block
     if cl_block is not None:
         out["channels_last"] = cl_block
+    if args.main_temporal and args.mode == "step":
+        out["config"]["variant"] = "--main_temporal as well: the producer also runs on the student's warped images (MAL_STEP_MAIN_TEMPORAL)"
+    if args.ms_temporal and args.mode == "multiscale":
+        out["config"]["variant"] = "--temporal on the non-distil four-scale path: the producer once per scale (mal_loss_multiscale_warp)"
     out["config"]["input_layout"] = "channels_last (zero-copy texels)" if args.channels_last else "NCHW (the reference's tensors)"
     if breakdown is not None:
         out["breakdown_ms"] = breakdown
