@@ -33,7 +33,11 @@ from .trainer import WarpContext
 
 
 def default_options(**kw):
-    """The fields these methods read, with dualrefine/options.py defaults."""
+    """The fields these methods read, with dualrefine/options.py defaults -- except ``scales``: upstream's default is
+    [0, 1, 2, 3] (options.py:65-69; the loops then visit scale 0 and 2 with n_losses+1 iterations, skip scale 1 and take
+    iteration 0 of scale 3, trainer.py:403-407,536-547); this helper defaults to [0], the refinement iterations of the full
+    resolution, which is what ``loss_step`` (one library call per direction) covers and bench.py's dualrefine mode times.
+    Pass ``scales=[0, 1, 2, 3]`` for upstream's list: ``generate_images_pred`` + ``compute_losses`` take any."""
     o = dict(height=192, width=640, batch_size=8, min_depth=0.1, max_depth=100.0, frame_ids=[0, -1, 1], scales=[0],
              n_losses=1, v1_multiscale=False, disable_automasking=False, no_ssim=False, disparity_smoothness=1e-3,
              avg_reprojection=False, disable_motion_masking=False, Dstar_T0_pair=False, Tstar_D0_pair=False)
@@ -280,8 +284,8 @@ class DualRefineLossPath:
 
     def loss_step(self, inputs, outputs, noises=None):
         """``generate_images_pred`` + ``compute_losses`` (dualrefine/trainer.py:395-451,530-633) in ONE library call per
-        direction for the configuration the shipped options give -- scales [0], min reprojection with SSIM, deq iterations
-        0..n_losses --; same ``losses`` keys and values as the two methods called one after the other (they remain the route
+        direction for scales [0] (upstream's default list is [0,1,2,3], see ``default_options``), min reprojection with SSIM,
+        deq iterations 0..n_losses --; same ``losses`` keys and values as the two methods called one after the other (they remain the route
         for --avg_reprojection / --no_ssim / more scales and for the ("color", ...) / ("sample", ...) outputs, which this
         call does not materialise).  ``noises``: one (B,1,H,W) N(0,1) map per iteration (default: drawn as
         ``config.noise_source`` says)."""
