@@ -24,6 +24,7 @@ import types
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -51,7 +52,10 @@ def import_trainer():
     return DL, DT.Trainer
 
 
-def main():
+def case(tag, scales):
+    """``scales`` [0]: the refinement iterations of the full resolution; [0, 1, 2, 3]: upstream's default list
+    (dualrefine/options.py:65-69) -- the loops visit scale 0 and 2 with n_losses+1 iterations, skip scale 1 and take iteration 0
+    of scale 3 (trainer.py:403-407,536-547), every disparity upsampled to full resolution, total / 4."""
     sys.path.insert(0, ROOT)
     from mal_amd.synthetic import make_batch
     from oracle.gen_golden import quantize_batch, pack_inputs
@@ -60,7 +64,7 @@ def main():
     torch.set_num_threads(8)
     B, H, W = 2, 40, 72
     q = quantize_batch(make_batch(B, H, W, seed=321))
-    opt = dr_default_opt(height=H, width=W, batch_size=B, n_losses=1)
+    opt = dr_default_opt(height=H, width=W, batch_size=B, n_losses=1, scales=list(scales))
     me = types.SimpleNamespace(opt=opt, device="cpu", f_thres=1, num_scales=len(opt.scales), ssim=DL.SSIM(),
                                backproject_depth={0: DL.BackprojectDepth(B, H, W)}, project_3d={0: DL.Project3D(B, H, W)})
     me.compute_reprojection_loss = types.MethodType(Trainer.compute_reprojection_loss, me)
@@ -74,6 +78,18 @@ def main():
     outputs = {("disp", 0, 0): leaves["disp_teacher"], ("disp", 0, 1): leaves["disp_student"],
                ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1, ("cam_T_cam", 0, -1, 1): T_m1 * 1.0,
                "consistency_mask": q["consistency_mask"].unsqueeze(1)}
+    extra = {}
+    for s in scales:
+        if s == 0:
+            continue
+        inputs[("color", 0, s)] = F.avg_pool2d(q["color0"], 2 ** s)
+        for it, name in ((0, "disp_teacher"), (1, "disp_student")):
+            if s == 1 or (s == 3 and it > 0):
+                continue  # never read (trainer.py:404-407)
+            leaf = F.avg_pool2d(q[name], 2 ** s).half().float().clone().requires_grad_(True)
+            extra["disp_s%d_it%d" % (s, it)] = leaf
+            outputs[("disp", s, it)] = leaf
+    leaves.update(extra)
     noise_seed = 4321
     sink = io.StringIO()
     with contextlib.redirect_stdout(sink):  # the shipped methods print debug values
@@ -97,11 +113,21 @@ def main():
         d["grad/" + k] = g.numpy()
     d["color_m1_pose"] = outputs[("color", -1, 0, 0, 1)].detach().numpy()
     d["depth_0_1"] = outputs[("depth", 0, 0, 1)].detach().numpy()
+    for k, t in extra.items():
+        d["in/" + k] = t.detach().half().numpy()
+    d["scales"] = np.array(list(scales), dtype=np.int64)
     d.update(pack_inputs(q))
-    path = os.path.join(OUT, "dualrefine_b2_40x72.npz")
+    path = os.path.join(OUT, tag + ".npz")
     np.savez_compressed(path, **d)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", {k: round(v.item(), 6) for k, v in losses.items()},
           {k: round(v.item(), 6) for k, v in pl.items()})
+
+
+
+def main():
+    if sys.argv[1:] != ["scales"]:  # `python -m oracle.gen_golden_dr scales` writes the four-scale case only
+        case("dualrefine_b2_40x72", [0])
+    case("dualrefine_b2_40x72_scales0123", [0, 1, 2, 3])
 
 
 if __name__ == "__main__":

@@ -58,6 +58,41 @@ def multiscale_dicts(z, pose_fn, device="cpu"):
     return b, sclm, inputs, mono_outputs, outputs, leaves
 
 
+DUALREFINE_CASES = ["dualrefine_b2_40x72", "dualrefine_b2_40x72_scales0123"]
+
+
+def dualrefine_dicts(z, pose_fn, device="cpu"):
+    """a DualRefine fixture (oracle/gen_golden_dr.py: the reference's own Trainer methods called unbound) as that trainer's
+    dicts: 4-tuple keys ("disp", scale, deq_iter); the second case carries upstream's default scales [0, 1, 2, 3]
+    (scale 1 is never read, scale 3 has iteration 0 only: dualrefine/trainer.py:403-407).  Returns
+    (batch, scales, units, inputs, outputs, leaves); units = the (scale, iteration) pairs in the order the loops visit them."""
+    b = batch_from_golden(z)
+    mv = lambda t: t.to(device)
+    scales = [int(v) for v in z["scales"]] if "scales" in z else [0]
+    inputs = {("color", f, 0): mv(b[k]) for f, k in ((0, "color0"), (-1, "color_m1"), (1, "color_p1"))}
+    inputs[("K", 0)], inputs[("inv_K", 0)] = mv(b["K"]), mv(b["inv_K"])
+    leaves = {k: mv(b[k]).clone().requires_grad_(True) for k in ("disp_teacher", "disp_student", "axisangle_m1", "translation_m1",
+                                                                 "axisangle_p1", "translation_p1")}
+    T_m1 = pose_fn(leaves["axisangle_m1"], leaves["translation_m1"], True)
+    T_p1 = pose_fn(leaves["axisangle_p1"], leaves["translation_p1"], False)
+    outputs = {("disp", 0, 0): leaves["disp_teacher"], ("disp", 0, 1): leaves["disp_student"],
+               ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1, ("cam_T_cam", 0, -1, 1): T_m1 * 1.0,
+               "consistency_mask": mv(b["consistency_mask"]).unsqueeze(1)}
+    units = [(0, 0), (0, 1)]
+    for s in scales:
+        if s == 0:
+            continue
+        inputs[("color", 0, s)] = torch.nn.functional.avg_pool2d(b["color0"], 2 ** s).to(device)
+        for it in (0, 1):
+            key = "in/disp_s%d_it%d" % (s, it)
+            if key in z:
+                leaf = torch.from_numpy(z[key].astype(np.float32)).to(device).requires_grad_(True)
+                leaves["disp_s%d_it%d" % (s, it)] = leaf
+                outputs[("disp", s, it)] = leaf
+                units.append((s, it))
+    return b, scales, units, inputs, outputs, leaves
+
+
 def multiscale_noises(z, shape, sclm):
     torch.manual_seed(int(z["in/noise_seed"]))
     return [torch.randn(shape) for _ in range(sclm + 1)], [torch.randn(shape) for _ in range(sclm + 1)]

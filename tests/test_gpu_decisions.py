@@ -399,6 +399,37 @@ def test_dualrefine_decision_exact(shape):
         assert abs(float(gp[k].detach()) - float(v)) <= 1e-4 * abs(float(v)) + 2.0 / N, (k, float(gp[k].detach()), float(v))
 
 
+def test_dualrefine_upstream_default_scales_against_the_reference_fixture():
+    """upstream's default scale list [0, 1, 2, 3] (dualrefine/options.py:65-69): the loops visit scale 0 and 2 with both
+    iterations, skip scale 1, take iteration 0 of scale 3 (trainer.py:403-407,536-547), every disparity upsampled to full
+    resolution, smoothness at the scale's own size / 2**scale, total / 4 -- generate_images_pred + compute_losses of
+    DualRefineLossPath against the numbers the reference's own Trainer methods produced (oracle/gen_golden_dr.py)."""
+    from mal_amd import dualrefine, layers
+    z = G.load("dualrefine_b2_40x72_scales0123")
+    b, scales, units, inputs, outputs, leaves = G.dualrefine_dicts(z, layers.transformation_from_parameters, "cuda:0")
+    B, _, H, W = b["color0"].shape
+    N = B * H * W
+    torch.manual_seed(int(z["in/noise_seed"]))
+    noises = [torch.randn(B, 1, H, W).to("cuda:0") for _ in units]
+    lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=B, n_losses=1, scales=scales), fuse=True)
+    lp.generate_images_pred(inputs, outputs)
+    got = lp.compute_losses(inputs, outputs, noises=noises)
+    got["loss"].backward()
+    torch.cuda.synchronize()
+    assert set("losses/" + k for k in got) == set(k for k in z if k.startswith("losses/"))
+    for k, v in got.items():
+        ref = float(z["losses/" + k])
+        # an automask pixel at rounding distance of its threshold moves a masked mean by <~ 1/N: two allowed per visited unit
+        assert abs(float(v.detach()) - ref) <= 2e-4 * abs(ref) + 1e-6 + 2.0 * len(units) / N, (k, float(v.detach()), ref)
+    for k, t in leaves.items():
+        g, r = t.grad.cpu().numpy(), z["grad/" + k].reshape(t.shape)
+        if g.ndim == 4:
+            bad = (np.abs(g - r) > (2e-4 + 4.0 / N) * np.abs(r).max()).mean()
+            assert bad <= (3e-2 if k[-3:-2].isdigit() or "_s" in k else 5e-3), (k, bad)
+        else:
+            assert _l2rel(g, r) <= 2e-2, (k, _l2rel(g, r))
+
+
 @pytest.mark.parametrize("shape,kw_extra", [((2, 40, 72), {}), ((8, 192, 640), {}), ((3, 37, 50), {"n_losses": 2}),
                                             ((2, 40, 72), {"disable_motion_masking": True}),
                                             ((2, 40, 72), {"disable_automasking": True})],

@@ -150,30 +150,24 @@ def test_multiscale_compute_losses_against_reference(tag):
         G.assert_close(g, z["grad/" + k], 0, "grad/" + k)
 
 
-def test_dualrefine_loops_against_reference_trainer_methods():
-    """a17: the fixture was produced by the reference's OWN ``Trainer.generate_images_pred`` / ``compute_losses`` /
+@pytest.mark.parametrize("tag", G.DUALREFINE_CASES)
+def test_dualrefine_loops_against_reference_trainer_methods(tag):
+    """a17: the fixtures were produced by the reference's OWN ``Trainer.generate_images_pred`` / ``compute_losses`` /
     ``pose_update_generate_images_pred`` / ``compute_pose_update_losses`` (dualrefine/trainer.py:395-767) called unbound
-    (oracle/gen_golden_dr.py); the oracle's restatement of those loops reproduces losses and gradients bit for bit."""
-    z = G.load("dualrefine_b2_40x72")
-    b = G.batch_from_golden(z)
+    (oracle/gen_golden_dr.py); the oracle's restatement of those loops reproduces losses and gradients bit for bit -- for the
+    iterations of scale 0 and for upstream's default scale list [0, 1, 2, 3]."""
+    z = G.load(tag)
+    b, scales, units, inputs, outputs, leaves = G.dualrefine_dicts(z, O.transformation_from_parameters)
     B, _, H, W = b["color0"].shape
     torch.manual_seed(int(z["in/noise_seed"]))
-    noises = [torch.randn(B, 1, H, W) for _ in range(2)]
+    noises = [torch.randn(B, 1, H, W) for _ in units]  # one draw per visited (scale, iteration), in loop order
     torch.manual_seed(int(z["in/noise_seed"]) + 1)
     nz_pose = torch.randn(B, 1, H, W)
-    inputs = {("color", f, 0): b[k] for f, k in ((0, "color0"), (-1, "color_m1"), (1, "color_p1"))}
-    inputs[("K", 0)], inputs[("inv_K", 0)] = b["K"], b["inv_K"]
-    leaves = {k: b[k].clone().requires_grad_(True) for k in ("disp_teacher", "disp_student", "axisangle_m1", "translation_m1",
-                                                            "axisangle_p1", "translation_p1")}
-    T_m1 = O.transformation_from_parameters(leaves["axisangle_m1"], leaves["translation_m1"], True)
-    T_p1 = O.transformation_from_parameters(leaves["axisangle_p1"], leaves["translation_p1"], False)
-    outputs = {("disp", 0, 0): leaves["disp_teacher"], ("disp", 0, 1): leaves["disp_student"],
-               ("cam_T_cam", 0, -1): T_m1, ("cam_T_cam", 0, 1): T_p1, ("cam_T_cam", 0, -1, 1): T_m1 * 1.0,
-               "consistency_mask": b["consistency_mask"].unsqueeze(1)}
-    opt = O.dr_default_opt(height=H, width=W, batch_size=B, n_losses=1)
+    opt = O.dr_default_opt(height=H, width=W, batch_size=B, n_losses=1, scales=scales)
     O.dr_generate_images_pred(opt, inputs, outputs)
     losses = O.dr_compute_losses(opt, inputs, outputs, noises=noises)
     losses["loss"].backward()
+    assert set("losses/" + k for k in losses) == set(k for k in z if k.startswith("losses/"))
     for k, v in losses.items():
         G.assert_close(v.item(), z["losses/" + k], 0, k)
     for k, t in leaves.items():
