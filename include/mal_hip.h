@@ -435,7 +435,8 @@ int mal_loss_multiscale_bwd(const mal_ms_args* args);
  * and it > 0, ...); which of them are detached is the caller's business: a NULL g_T_* output is a detached pose.
  * losses: [4*it + {0 reproj, 1 consistency, 2 smooth, 3 running loss after it}], [4*MAL_DR_MAX_ITERS] total,
  * [4*MAL_DR_MAX_ITERS + 1] the final running loss (what every "loss/0_it" entry reads upstream).
- * --avg_reprojection, --no_ssim, other scales and the pose-update losses (:699-767) stay on the operator-level API. */
+ * One call = the iterations of ONE scale (`scale`, below); --avg_reprojection, --no_ssim and the pose-update losses
+ * (:699-767) stay on the operator-level API. */
 enum { MAL_DR_MAX_ITERS = 4 };
 enum { MAL_DR_NO_AUTOMASK = 1, MAL_DR_NO_MOTION_MASK = 2,
        MAL_DR_NOISE_PHILOX = 4 /* the tie-break noise of every iteration is drawn in the step's first launch (Philox4x32-10
@@ -460,6 +461,18 @@ typedef struct mal_dr_args {
   float *g_disp[MAL_DR_MAX_ITERS];                /* backward outputs, nullable each */
   float *g_T_m1[MAL_DR_MAX_ITERS], *g_T_p1[MAL_DR_MAX_ITERS];
   void *ws; size_t ws_bytes; void *stream;
+  /* One call covers the iterations of ONE scale of opt.scales (upstream's default list is [0,1,2,3]: scale 0 and 2 with
+   * n_losses+1 iterations, scale 1 skipped, scale 3 iteration 0 only, dualrefine/trainer.py:403-407,536-547; the caller sums
+   * the calls' totals and divides by len(scales), :694).  scale > 0: disp[it] is the iteration's disparity UPSAMPLED to
+   * (H,W) (trainer.py:411-412; mal_upsample_bilinear) -- what is warped and what the consistency term reads --, while the
+   * smoothness term (:620-624) is taken on disp_lo[it], (B,1,H>>scale,W>>scale), against color0_s = inputs[("color",0,scale)],
+   * (B,3,H>>scale,W>>scale); pass smooth_weight = disparity_smoothness / 2**scale.  Backward then writes g_disp[it] =
+   * d total / d (upsampled disparity) WITHOUT the smoothness term and g_disp_lo[it] = the smoothness term's gradient at the
+   * scale's own size (the caller adds the adjoint upsampling of the first: mal_upsample_bilinear_adjoint). */
+  int scale;
+  const float *color0_s;
+  const float *disp_lo[MAL_DR_MAX_ITERS];
+  float *g_disp_lo[MAL_DR_MAX_ITERS];
 } mal_dr_args;
 size_t mal_dr_workspace_bytes(int B, int H, int W, int n_iters);
 int mal_dr_loss_fwd(const mal_dr_args* args);

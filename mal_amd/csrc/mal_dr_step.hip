@@ -66,6 +66,7 @@ struct DrFinal {
   const double* bs[kDrIt]; const float* bgP[kDrIt]; const double* sm[kDrIt];
   const float* K;
   int per_sample, per_sample_sm, sm_stride, B, H, W, n;
+  int hs, ws;  // size of the maps the smoothness term is taken on (H >> scale, W >> scale)
   float smooth_weight;
   double* ps; double* stats; float* gT; float* losses; float* coefs; float* loss_total; unsigned* ticket;
   unsigned long long* noise_counter;  // nullable: advanced by one when every reader of this step has finished
@@ -159,12 +160,13 @@ __global__ __launch_bounds__(256) void dr_final_kernel(DrFinal p) {
   if (s_last != gridDim.x - 1) return;
   __threadfence();
   // per-sample statistics of the smoothness gradient (mean and the mean-coupling term), then the scalars: thread it
+  const int HWs = p.hs * p.ws;
   for (int s = tid; s < nB; s += 256) {
     const double* q = p.ps + (size_t)s * 8;
-    const double mean = q[7] / (double)HW;
+    const double mean = q[7] / (double)HWs;
     const double m = (double)((float)mean + 1e-7f);
     p.stats[s] = mean;
-    p.stats[kDrIt * B + s] = q[6] / ((double)HW * m * m);
+    p.stats[kDrIt * B + s] = q[6] / ((double)HWs * m * m);
   }
   __syncthreads();
   if (tid < p.n) {
@@ -174,11 +176,11 @@ __global__ __launch_bounds__(256) void dr_final_kernel(DrFinal p) {
       const double* q = p.ps + ((size_t)it * B + b) * 8;
       for (int j = 0; j < 8; ++j) {
         double v = q[j];
-        if (j == 4 || j == 5) v = v * (double)div_(1.0f, (float)(q[7] / (double)HW) + 1e-7f);
+        if (j == 4 || j == 5) v = v * (double)div_(1.0f, (float)(q[7] / (double)HWs) + 1e-7f);
         tot[j] += v;
       }
     }
-    const double N = (double)B * HW, Nx = (double)B * p.H * (p.W - 1), Ny = (double)B * (p.H - 1) * p.W;
+    const double N = (double)B * HW, Nx = (double)B * p.hs * (p.ws - 1), Ny = (double)B * (p.hs - 1) * p.ws;
     p.losses[it * 4 + 0] = (float)(tot[0] / (tot[1] + 1e-7));
     p.losses[it * 4 + 1] = it > 0 ? (float)(tot[2] / N) : 0.0f;
     p.losses[it * 4 + 2] = (float)(tot[4] / Nx + tot[5] / Ny);
@@ -208,8 +210,9 @@ __global__ __launch_bounds__(256) void dr_final_kernel(DrFinal p) {
 struct DrAssemble {
   const float* G_r[kDrIt]; const float* G_c[kDrIt]; const float* gn[kDrIt]; const float* bnd[kDrIt];
   float* g_disp[kDrIt]; float* g_T[kDrIt][2];
+  float* g_disp_lo[kDrIt];  // scale > 0: the smoothness term's gradient at the scale's own size (then not part of g_disp)
   const float* gT; const float* coefs; const double* stats; const float* g_total;
-  int B, H, W, n, rows, segs;
+  int B, H, W, n, rows, segs, hs, ws;
 };
 
 // blockIdx.y = iteration; one image row per workgroup round (the boundary test of the one-row halo is wave-uniform);
@@ -227,10 +230,20 @@ __global__ __launch_bounds__(256) void dr_assemble_kernel(DrAssemble p) {
     }
   }
   float* out = p.g_disp[it];
+  float* lo = p.g_disp_lo[it];
+  const float* gn = p.gn[it];
+  if (lo) {  // the smoothness term of a lower scale: its own, smaller map
+    for (int row = blockIdx.x; row < B * p.hs; row += gridDim.x) {
+      const int b = row / p.hs;
+      const float inv = div_(1.0f, (float)p.stats[it * B + b] + 1e-7f), corr = (float)p.stats[kDrIt * B + it * B + b];
+      const size_t r0 = (size_t)row * p.ws;
+      for (int x = threadIdx.x; x < p.ws; x += 256) lo[r0 + x] = cS * (gn[r0 + x] * inv - corr);
+    }
+  }
   if (!out) return;
+  const bool with_smooth = p.hs == H && p.ws == W;  // scale 0: all three terms live on the same map
   const float* G_r = p.G_r[it];
   const float* G_c = it > 0 ? p.G_c[it] : nullptr;
-  const float* gn = p.gn[it];
   for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
     const int b = row / H, y = row - b * H;
     const float inv = div_(1.0f, (float)p.stats[it * B + b] + 1e-7f), corr = (float)p.stats[kDrIt * B + it * B + b];
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(256) void dr_assemble_kernel(DrAssemble p) {
     for (int x = threadIdx.x; x < W; x += 256) {
       const size_t i = r0 + x;
       const float G = brow ? G_r[i] + brow[x] : G_r[i];
-      float v = cS * (gn[i] * inv - corr);
+      float v = with_smooth ? cS * (gn[i] * inv - corr) : 0.f;
       if (G_c) v = fma_(cC, G_c[i], v);
       out[i] = fma_(cR, G, v);
     }
@@ -255,6 +268,14 @@ static int dr_check(const mal_dr_args* a) {
   int rc = check_shape(a->B, a->H, a->W);
   if (rc) return rc;
   if (a->n_iters < 1 || a->n_iters > kDrIt) return MAL_EINVAL;
+  if (a->scale < 0 || a->scale > 3) return MAL_EINVAL;
+  if (a->scale > 0) {
+    const int f = 1 << a->scale;
+    if (a->H % f || a->W % f || (a->H >> a->scale) < 2 || (a->W >> a->scale) < 2) return MAL_ESHAPE;
+    if (!a->color0_s) return MAL_EINVAL;
+    for (int it = 0; it < a->n_iters; ++it)
+      if (!a->disp_lo[it]) return MAL_EINVAL;
+  }
   if (!a->color0 || !a->color_m1 || !a->color_p1 || !a->K || !a->inv_K || !a->losses || !a->ws) return MAL_EINVAL;
   for (int it = 0; it < a->n_iters; ++it)
     if (!a->disp[it] || !a->T_m1[it] || !a->T_p1[it]) return MAL_EINVAL;
@@ -282,7 +303,8 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
   // identity term + texel packing (no noise here: every iteration adds its own).  Up to two iterations (the shipped
   // n_losses = 1): their edge-aware smoothness rides on this sweep, which holds the target rows anyway; more: one batched
   // smoothness sweep below
-  const bool smooth_fused = n <= 2;
+  const int hs = H >> a->scale, wsz = W >> a->scale;
+  const bool smooth_fused = n <= 2 && a->scale == 0;
   int per_sample_sm = 1;
   {
     SmoothParams sm = {};
@@ -332,7 +354,10 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
     float* sg[kDrIt];
     double* sp[kDrIt];
     int sh[kDrIt], sw[kDrIt], per[kDrIt];
-    for (int it = 0; it < n; ++it) { sd[it] = a->disp[it]; si[it] = a->color0; sg[it] = w.gn[it]; sp[it] = w.sm[it]; sh[it] = H; sw[it] = W; }
+    for (int it = 0; it < n; ++it) {
+      sd[it] = a->scale ? a->disp_lo[it] : a->disp[it]; si[it] = a->scale ? a->color0_s : a->color0;
+      sg[it] = w.gn[it]; sp[it] = w.sm[it]; sh[it] = hs; sw[it] = wsz;
+    }
     rc = smooth_march_sweep_batch(n, sd, si, B, sh, sw, sg, sp, st, per);
     if (rc) return rc;
     fin.per_sample_sm = per[0]; fin.sm_stride = 4;
@@ -343,6 +368,7 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
   }
   for (int it = 0; it < n; ++it) { fin.bs[it] = w.bs[it]; fin.bgP[it] = w.bgP[it]; }
   fin.K = a->K; fin.per_sample = per_sample; fin.B = B; fin.H = H; fin.W = W; fin.n = n; fin.smooth_weight = a->smooth_weight;
+  fin.hs = hs; fin.ws = wsz;
   fin.ps = w.ps; fin.stats = w.stats; fin.gT = w.gT; fin.losses = a->losses; fin.coefs = w.coefs; fin.loss_total = a->loss_total;
   fin.ticket = w.ticket;
   fin.noise_counter = philox ? (unsigned long long*)a->noise_counter : nullptr;
@@ -359,7 +385,9 @@ extern "C" int mal_dr_loss_bwd(const mal_dr_args* a) {
   for (int it = 0; it < n; ++it) {
     p.G_r[it] = w.G_r[it]; p.G_c[it] = w.G_c[it]; p.gn[it] = w.gn[it]; p.bnd[it] = g_march_halo1 ? w.bnd[it] : nullptr;
     p.g_disp[it] = a->g_disp[it]; p.g_T[it][0] = a->g_T_m1[it]; p.g_T[it][1] = a->g_T_p1[it];
+    p.g_disp_lo[it] = a->scale ? a->g_disp_lo[it] : nullptr;
   }
+  p.hs = H >> a->scale; p.ws = W >> a->scale;
   p.gT = w.gT; p.coefs = w.coefs; p.stats = w.stats; p.g_total = a->g_total;
   p.B = B; p.H = H; p.W = W; p.n = n;
   march_geometry(B, H, W, MAL_F_GRAD, nullptr, &p.segs, &p.rows);

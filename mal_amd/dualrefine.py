@@ -48,9 +48,10 @@ def default_options(**kw):
 _DR_WS = {}
 
 
-def _dr_workspace(dev, B, H, W, n):
+def _dr_workspace(dev, B, H, W, n, slot=0):
+    """``slot``: the scale of opt.scales the call belongs to -- every scale's call keeps its own maps until its backward"""
     need = L.load().mal_dr_workspace_bytes(B, H, W, n)
-    key = (dev.index, ops._stream(), B, H, W, n)
+    key = (dev.index, ops._stream(), B, H, W, n, slot)
     ws = _DR_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = _DR_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -58,27 +59,38 @@ def _dr_workspace(dev, B, H, W, n):
 
 
 class DrLossStepFn(Function):
-    """generate_images_pred + compute_losses of DualRefine's trainer over the deq iterations of scale 0 as one library call
-    per direction (``mal_dr_loss_fwd/_bwd``).  Leaves: ``disp[it]`` (n of them), then ``T_m1[it]``, then ``T_p1[it]``
-    ((B,4,4) each; a pose the trainer detaches simply arrives without ``requires_grad``)."""
+    """generate_images_pred + compute_losses of DualRefine's trainer over the deq iterations of ONE scale as one library call
+    per direction (``mal_dr_loss_fwd/_bwd``).  Leaves: ``disp[it]`` (n of them, at the scale's own size), then ``T_m1[it]``,
+    then ``T_p1[it]`` ((B,4,4) each; a pose the trainer detaches simply arrives without ``requires_grad``).  For a scale > 0
+    the disparities are upsampled here (trainer.py:411-412) and the adjoint is applied to what the library hands back."""
 
     @staticmethod
     def forward(ctx, consts, cfg, *leaves):
-        color0, color_m1, color_p1, K, inv_K, cmask, noises = consts
-        min_depth, max_depth, smooth_weight, flags, n, philox = cfg
+        color0, color_m1, color_p1, K, inv_K, cmask, noises = consts[:7]
+        color0_s = consts[7] if len(consts) > 7 else None
+        min_depth, max_depth, smooth_weight, flags, n, philox = cfg[:6]
+        scale = cfg[6] if len(cfg) > 6 else 0
         req, p = ops._req, ops._p
         tens = [req(t, "leaf") for t in leaves]
         cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K)]
         cm = None if cmask is None else req(cmask, "consistency_mask")
         nz = [None if t is None else req(t, "noise") for t in (noises or [None] * n)]
-        B, _, H, W = tens[0].shape
+        B, _, H, W = cons[0].shape
         dev = tens[0].device
         a = L.DrArgs()
-        a.B, a.H, a.W, a.n_iters = B, H, W, n
+        a.B, a.H, a.W, a.n_iters, a.scale = B, H, W, n, int(scale)
         a.min_depth, a.max_depth, a.smooth_weight, a.flags = float(min_depth), float(max_depth), float(smooth_weight), int(flags)
         a.color0, a.color_m1, a.color_p1, a.K, a.inv_K = (p(t) for t in cons)
+        up = []
+        if scale:
+            cs = req(color0_s, "inputs[('color', 0, scale)]")
+            cons.append(cs)
+            a.color0_s = p(cs)
+            up = [ops.upsample_bilinear(t, H, W) for t in tens[:n]]
         for it in range(n):
-            a.disp[it], a.T_m1[it], a.T_p1[it] = p(tens[it]), p(tens[n + it]), p(tens[2 * n + it])
+            a.disp[it], a.T_m1[it], a.T_p1[it] = p(up[it] if scale else tens[it]), p(tens[n + it]), p(tens[2 * n + it])
+            if scale:
+                a.disp_lo[it] = p(tens[it])
             a.noise[it] = p(nz[it])
         a.consistency_mask = p(cm)
         if philox is not None:  # drawn in the step's first launch; the device counter advances with every (replayed) step
@@ -89,10 +101,10 @@ class DrLossStepFn(Function):
         losses = torch.empty(4 * L.DR_MAX_ITERS + 4, dtype=torch.float32, device=dev)
         total = torch.empty(1, dtype=torch.float32, device=dev)
         a.losses, a.loss_total = p(losses), p(total)
-        ws = _dr_workspace(dev, B, H, W, n)
+        ws = _dr_workspace(dev, B, H, W, n, slot=int(scale))
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
         L.check(L.load().mal_dr_loss_fwd(C.byref(a)), "mal_dr_loss_fwd")
-        ctx.args, ctx.keep, ctx.n = a, (tens, cons, cm, nz, ws, losses, total), n
+        ctx.args, ctx.keep, ctx.n, ctx.scale, ctx.up = a, (tens, cons, cm, nz, ws, losses, total), n, int(scale), up
         ctx.ws_token = ops.claim_workspace(ws)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(losses)
@@ -109,9 +121,18 @@ class DrLossStepFn(Function):
         a = ctx.args
         grads = [torch.empty_like(t) if ctx.needs_input_grad[2 + i] else None for i, t in enumerate(tens)]
         a.g_total = ops._p(g_total)
+        full = [None] * n  # scale > 0: d total / d (upsampled disparity) without the smoothness term, which arrives in grads[it]
         for it in range(n):
-            a.g_disp[it], a.g_T_m1[it], a.g_T_p1[it] = ops._p(grads[it]), ops._p(grads[n + it]), ops._p(grads[2 * n + it])
+            if ctx.scale and grads[it] is not None:
+                full[it] = torch.empty_like(ctx.up[it])
+                a.g_disp[it], a.g_disp_lo[it] = ops._p(full[it]), ops._p(grads[it])
+            else:
+                a.g_disp[it] = ops._p(grads[it])
+            a.g_T_m1[it], a.g_T_p1[it] = ops._p(grads[n + it]), ops._p(grads[2 * n + it])
         L.check(L.load().mal_dr_loss_bwd(C.byref(a)), "mal_dr_loss_bwd")
+        for it in range(n):
+            if full[it] is not None:
+                grads[it].add_(ops.upsample_bilinear_adjoint(full[it], tens[it].shape[-2], tens[it].shape[-1]))
         return (None, None, *grads)
 
 
@@ -284,43 +305,57 @@ class DualRefineLossPath:
 
     def loss_step(self, inputs, outputs, noises=None):
         """``generate_images_pred`` + ``compute_losses`` (dualrefine/trainer.py:395-451,530-633) in ONE library call per
-        direction for scales [0] (upstream's default list is [0,1,2,3], see ``default_options``), min reprojection with SSIM,
-        deq iterations 0..n_losses --; same ``losses`` keys and values as the two methods called one after the other (they remain the route
-        for --avg_reprojection / --no_ssim / more scales and for the ("color", ...) / ("sample", ...) outputs, which this
-        call does not materialise).  ``noises``: one (B,1,H,W) N(0,1) map per iteration (default: drawn as
-        ``config.noise_source`` says)."""
+        direction AND scale of ``opt.scales`` (upstream's default list is [0,1,2,3]: scale 0 and 2 with the deq iterations
+        0..n_losses, scale 1 skipped, scale 3 iteration 0 only, :403-407,536-547; a lower scale's disparities are upsampled
+        around the call), min reprojection with SSIM; same ``losses`` keys and values as the two methods called one after
+        the other (they remain the route for --avg_reprojection / --no_ssim / --v1_multiscale and for the ("color", ...) /
+        ("sample", ...) outputs, which this call does not materialise).  ``noises``: one (B,1,H,W) N(0,1) map per visited
+        (scale, iteration), in loop order (default: drawn as ``config.noise_source`` says)."""
         opt = self.opt
-        n = opt.n_losses + 1
-        if list(opt.scales) != [0] or opt.avg_reprojection or opt.no_ssim or opt.v1_multiscale or n > L.DR_MAX_ITERS \
+        n_full = opt.n_losses + 1
+        scales = list(opt.scales)
+        if any(s_ not in (0, 1, 2, 3) for s_ in scales) or len(set(scales)) != len(scales) or not scales \
+                or opt.avg_reprojection or opt.no_ssim or opt.v1_multiscale or n_full > L.DR_MAX_ITERS \
                 or list(opt.frame_ids) != [0, -1, 1] or self.f_thres <= 0:
-            raise L.MalError("DualRefineLossPath.loss_step covers scales [0], frames [0,-1,1], min reprojection with SSIM and "
-                             "n_losses < %d; use generate_images_pred + compute_losses otherwise" % L.DR_MAX_ITERS)
+            raise L.MalError("DualRefineLossPath.loss_step covers scales out of [0,1,2,3], frames [0,-1,1], min reprojection with "
+                             "SSIM and n_losses < %d; use generate_images_pred + compute_losses otherwise" % L.DR_MAX_ITERS)
         target = inputs[("color", 0, 0)]
         B, _, H, W = target.shape
-        disps = [outputs[("disp", 0, it)] for it in range(n)]
-        for d in disps:
-            if tuple(d.shape) != (B, 1, H, W):
-                raise L.MalError("loss_step: the disparities must arrive at full resolution (B,1,%d,%d)" % (H, W))
-        T_m1 = [self._pose_for(outputs, -1, it) for it in range(n)]
-        T_p1 = [self._pose_for(outputs, 1, it) for it in range(n)]
         flags = (L.DR_NO_AUTOMASK if opt.disable_automasking else 0) | (L.DR_NO_MOTION_MASK if opt.disable_motion_masking else 0)
+        units = [(s_, it) for s_ in scales if s_ != 1 for it in range(n_full if s_ in (0, 1, 2) else 1)]
         philox = None
         if noises is None and not opt.disable_automasking:
-            if config.noise_source == "philox":  # drawn inside the step's first launch: no RNG launch, no host work
+            if config.noise_source == "philox":  # drawn inside each call's first launch: no RNG launch, no host work
                 philox = config.noise_seed
             else:
-                noises = [loss_utils.draw_noise((B, 1, H, W), target.device) for _ in range(n)]  # one draw per iteration (:586-587)
-        cmask = None
-        if n > 1 and not opt.disable_motion_masking:
-            cmask = outputs["consistency_mask"].to(torch.float32)
-        consts = (target, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)], cmask, noises)
-        cfg = (opt.min_depth, opt.max_depth, opt.disparity_smoothness, flags, n, philox)
-        total, v = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1)
-        losses = {"reproj_loss/0": v[4 * (n - 1)], "loss": total.reshape(())}
-        for it in range(n):
-            losses["loss/0_%d" % it] = v[4 * L.DR_MAX_ITERS + 1]  # upstream's entries alias the running loss (:624,630)
-            if it > 0:
-                losses["consistency_loss/0_%d" % it] = v[4 * it + 1]
+                noises = [loss_utils.draw_noise((B, 1, H, W), target.device) for _ in units]  # one draw per visit (:586-587)
+        losses, total, k = {}, None, 0
+        for scale in scales:
+            if scale == 1:
+                continue  # trainer.py:406-407,546-547
+            n = n_full if scale in (0, 1, 2) else 1
+            disps = [outputs[("disp", scale, it)] for it in range(n)]
+            for d in disps:
+                if tuple(d.shape) != (B, 1, H >> scale, W >> scale):
+                    raise L.MalError("loss_step: the disparities of scale %d must be (B,1,%d,%d)" % (scale, H >> scale, W >> scale))
+            T_m1 = [self._pose_for(outputs, -1, it) for it in range(n)]
+            T_p1 = [self._pose_for(outputs, 1, it) for it in range(n)]
+            cmask = None
+            if n > 1 and not opt.disable_motion_masking:
+                cmask = outputs["consistency_mask"].to(torch.float32)
+            nz = None if noises is None else list(noises[k:k + n])
+            k += n
+            consts = (target, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)], cmask, nz,
+                      inputs[("color", 0, scale)] if scale else None)
+            cfg = (opt.min_depth, opt.max_depth, opt.disparity_smoothness / (2 ** scale), flags, n, philox, scale)
+            tot_s, v = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1)
+            total = tot_s.reshape(()) if total is None else total + tot_s.reshape(())
+            losses["reproj_loss/%d" % scale] = v[4 * (n - 1)]
+            for it in range(n):
+                losses["loss/%d_%d" % (scale, it)] = v[4 * L.DR_MAX_ITERS + 1]  # upstream's entries alias the running loss (:624,630)
+                if it > 0:
+                    losses["consistency_loss/%d_%d" % (scale, it)] = v[4 * it + 1]
+        losses["loss"] = total / self.num_scales if self.num_scales != 1 else total
         return losses
 
     def _weight_map(self, inputs, outputs, scale, it, ext, rp_map, noise):

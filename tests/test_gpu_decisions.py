@@ -473,6 +473,39 @@ def test_dualrefine_one_call_step_equals_the_operator_route(shape, kw_extra):
         assert np.abs(res["step"][1][k] - g).max() <= 2e-5 * max(sc, 1e-12), (k, np.abs(res["step"][1][k] - g).max() / max(sc, 1e-12))
 
 
+def test_dualrefine_one_call_step_with_upstream_default_scales():
+    """DualRefineLossPath.loss_step over upstream's default scale list [0, 1, 2, 3]: one library call per direction and visited
+    scale (0 and 2 with both iterations, 3 with iteration 0; the lower scales' disparities upsampled around the call, their
+    smoothness at the scale's own size) -- against the numbers of the reference's own Trainer methods (the fixture) and
+    against the operator route of the same class."""
+    from mal_amd import dualrefine, layers
+    z = G.load("dualrefine_b2_40x72_scales0123")
+    res = {}
+    for route in ("ops", "step"):
+        b, scales, units, inputs, outputs, leaves = G.dualrefine_dicts(z, layers.transformation_from_parameters, "cuda:0")
+        B, _, H, W = b["color0"].shape
+        torch.manual_seed(int(z["in/noise_seed"]))
+        noises = [torch.randn(B, 1, H, W).to("cuda:0") for _ in units]
+        lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=B, n_losses=1, scales=scales), fuse=True)
+        if route == "ops":
+            lp.generate_images_pred(inputs, outputs)
+            got = lp.compute_losses(inputs, outputs, noises=noises)
+        else:
+            got = lp.loss_step(inputs, outputs, noises=noises)
+        got["loss"].backward()
+        torch.cuda.synchronize()
+        res[route] = ({k: float(v.detach()) for k, v in got.items()}, {k: t.grad.cpu().numpy() for k, t in leaves.items()})
+    N = B * H * W
+    assert set(res["ops"][0]) == set(res["step"][0]) == set(k[len("losses/"):] for k in z if k.startswith("losses/"))
+    for k, v in res["ops"][0].items():
+        assert abs(res["step"][0][k] - v) <= 2e-6 * max(abs(v), 1e-3), (k, res["step"][0][k], v)
+        ref = float(z["losses/" + k])
+        assert abs(res["step"][0][k] - ref) <= 2e-4 * abs(ref) + 1e-6 + 2.0 * len(units) / N, (k, res["step"][0][k], ref)
+    for k, g in res["ops"][1].items():
+        sc = np.abs(g).max()
+        assert np.abs(res["step"][1][k] - g).max() <= 2e-5 * max(sc, 1e-12), (k, np.abs(res["step"][1][k] - g).max() / max(sc, 1e-12))
+
+
 def test_dualrefine_step_in_kernel_noise_equals_the_same_noise_handed_in():
     """MAL_DR_NOISE_PHILOX: iteration it's map is mal_tiebreak_noise(seed, step * MAL_DR_MAX_ITERS + it); the step with the
     maps drawn in its first launch and the step handed those maps agree to the bit, and the device counter advances once."""
