@@ -274,7 +274,9 @@ enum {
                                  mal_loss_step_fwd   syn_s_* in, g_syn_s_* out (unnormalised, as g_syn_*)
                                  mal_loss_step_bwd   g_warp_s_* in: the student's gradient sweep takes the four-way decisions
                                                      of _fwd and adds what arrives through syn */
-  MAL_STEP_SYN_S_SPARSE = 256  /* MAL_STEP_SYN_SPARSE for the student's pair (syn_s_* / syn_s_region / warp_s_*) */
+  MAL_STEP_SYN_S_SPARSE = 256, /* MAL_STEP_SYN_SPARSE for the student's pair (syn_s_* / syn_s_region / warp_s_*) */
+  MAL_STEP_NO_SSIM = 512       /* mal_loss_multiscale_* only: --no_ssim, r = mean_c |target - pred| (manydepth/trainer.py:1217-1218 --
+                                  upstream reads the flag on this, the non-distillation, route only); not with MAL_STEP_TEMPORAL */
 };
 typedef struct mal_step_args {
   int B, H, W;
@@ -377,13 +379,13 @@ int mal_loss_step_bwd(const mal_step_args* args);
  *   both     + 1e-3 * smooth(disp_s / mean disp_s, color_s) / 2**s        (disp_s, color_s at the scale's own size)
  * total = (sum_s loss_teacher_s + sum_s loss_student_s) / (sclm + 1).  One host call forward (first sweep, upsampling,
  * 2 marching launches + 2 smoothness sweeps per scale, one reduction), one backward (adjoint upsampling, gathered in a
- * fixed order: no atomics).  --v1_multiscale, --ensemble, --no_ssim are not covered (MAL_EINVAL is not how they fail: the
- * Python mirror routes them through the operator-level API); the temporal hint: MAL_STEP_TEMPORAL, below.           */
+ * fixed order: no atomics).  --v1_multiscale, --ensemble are not covered (MAL_EINVAL is not how they fail: the Python
+ * mirror routes them through the operator-level API); --no_ssim: MAL_STEP_NO_SSIM; the temporal hint: MAL_STEP_TEMPORAL. */
 enum { MAL_MS_MAX_SCALES = 4 };
 typedef struct mal_ms_args {
   int B, H, W, sclm;                              /* scale s is (H >> s, W >> s); H, W divisible by 2**sclm */
   float min_depth, max_depth;
-  int flags;                                      /* MAL_STEP_AUG_MASK, MAL_STEP_NOISE_PHILOX, MAL_STEP_TEMPORAL */
+  int flags;                                      /* MAL_STEP_AUG_MASK, MAL_STEP_NOISE_PHILOX, MAL_STEP_TEMPORAL, MAL_STEP_NO_SSIM */
   const float *color0, *color_m1, *color_p1;      /* (B,3,H,W) */
   const float *color0_s[MAL_MS_MAX_SCALES];       /* inputs[("color",0,s)]: (B,3,H>>s,W>>s); [0] NULL = color0 */
   const float *K, *inv_K;                         /* (B,16) */
@@ -435,10 +437,13 @@ int mal_loss_multiscale_bwd(const mal_ms_args* args);
  * and it > 0, ...); which of them are detached is the caller's business: a NULL g_T_* output is a detached pose.
  * losses: [4*it + {0 reproj, 1 consistency, 2 smooth, 3 running loss after it}], [4*MAL_DR_MAX_ITERS] total,
  * [4*MAL_DR_MAX_ITERS + 1] the final running loss (what every "loss/0_it" entry reads upstream).
- * One call = the iterations of ONE scale (`scale`, below); --avg_reprojection, --no_ssim and the pose-update losses
- * (:699-767) stay on the operator-level API. */
+ * One call = the iterations of ONE scale (`scale`, below); --avg_reprojection / --no_ssim: MAL_DR_AVG / MAL_DR_NO_SSIM; the
+ * pose-update losses (:699-767) stay on the operator-level API. */
 enum { MAL_DR_MAX_ITERS = 4 };
-enum { MAL_DR_NO_AUTOMASK = 1, MAL_DR_NO_MOTION_MASK = 2,
+enum { MAL_DR_AVG = 8,      /* --avg_reprojection (dualrefine/trainer.py:569-583): the MEAN over the two frames of r and of the
+                               identity term instead of their min; both frames take half of every gradient */
+       MAL_DR_NO_SSIM = 16, /* --no_ssim (:493-494): r = mean_c |target - pred| */
+       MAL_DR_NO_AUTOMASK = 1, MAL_DR_NO_MOTION_MASK = 2,
        MAL_DR_NOISE_PHILOX = 4 /* the tie-break noise of every iteration is drawn in the step's first launch (Philox4x32-10
                                   keyed by noise_seed, step number = step * MAL_DR_MAX_ITERS + it: mal_tiebreak_noise with
                                   that step number reproduces iteration it's map); every noise[it] must be NULL */ };

@@ -305,13 +305,14 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
   // smoothness sweep below
   const int hs = H >> a->scale, wsz = W >> a->scale;
   const bool smooth_fused = n <= 2 && a->scale == 0;
+  const int variant = ((a->flags & MAL_DR_NO_SSIM) ? 1 : 0) | ((a->flags & MAL_DR_AVG) ? 2 : 0);
   int per_sample_sm = 1;
   {
     SmoothParams sm = {};
     sm.n = n; sm.partials = w.sm[0];
     for (int it = 0; it < n && smooth_fused; ++it) { sm.disp[it] = a->disp[it]; sm.gn[it] = w.gn[it]; }
     rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
-                              nullptr, nullptr, smooth_fused ? &sm : nullptr, &per_sample_sm);
+                              nullptr, nullptr, smooth_fused ? &sm : nullptr, &per_sample_sm, false, variant);
     if (rc) return rc;
   }
   const bool philox = automask && (a->flags & MAL_DR_NOISE_PHILOX);
@@ -337,6 +338,7 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
     p.g_reproj = w.G_r[it]; p.block_sums = w.bs[it]; p.block_gP = w.bgP[it];
     p.bnd = g_march_halo1 ? w.bnd[it] : nullptr;
     p.cam = w.cam[it]; p.cam_ready = 1;  // the poses differ per iteration: its own camera block (dr_prologue_kernel)
+    p.avg = (a->flags & MAL_DR_AVG) ? 1 : 0; p.no_ssim = (a->flags & MAL_DR_NO_SSIM) ? 1 : 0;
     int flags = MAL_F_GRAD | MAL_F_POSE_GRAD | (automask ? MAL_F_AUTOMASK : 0) | packed;
     if (it > 0) {  // x consistency_mask, consistency term against iteration 0's depth (its disparity, no gradient to it)
       p.ext_mask = (a->flags & MAL_DR_NO_MOTION_MASK) ? nullptr : a->consistency_mask;

@@ -24,6 +24,10 @@ struct MarchParams {
   // --dual_distil (whole-step list, two-way distillation): g_ens receives merge_distil * d distil / d mono_disp instead
   // (the teacher's depth keeps its graph where it wins the argmin, loss_utils.py:231-234); ens_disp must be NULL
   int dual_distil;
+  // generic gradient passes only (march_launch leaves the specialisations when either is set): avg = --avg_reprojection, the
+  // MEAN over the two candidates instead of their min (dualrefine/trainer.py:579-583; both take half of every gradient);
+  // no_ssim = --no_ssim, r = mean_c |t - p| (manydepth/trainer.py:1217-1218, dualrefine/trainer.py:493-494)
+  int avg, no_ssim;
   // per-sample camera block [B][40]: P_f = (K T_f)[:3,:], inv_K[:3,:3]; march_launch fills it unless cam_ready
   float* cam; int cam_ready;
   int sample_scale_is_mask;  // sample_scale holds the augmentation mask: the scale is 1 - mask
@@ -137,7 +141,8 @@ struct SmoothParams { int n; const float* disp[2]; float* gn[2]; double* partial
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
                          const StepPoses* poses = nullptr, const TieNoise* noise = nullptr,
-                         const SmoothParams* smooth = nullptr, int* tasks_per_sample = nullptr, bool texel_in = false);
+                         const SmoothParams* smooth = nullptr, int* tasks_per_sample = nullptr, bool texel_in = false,
+                         int variant = 0 /* bit 0 --no_ssim, bit 1 --avg_reprojection: the identity term follows */);
 
 // Philox4x32-10 (Salmon et al., SC'11; the generator behind torch's device randn), one block of four 32-bit words
 MAL_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {

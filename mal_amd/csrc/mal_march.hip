@@ -294,6 +294,9 @@ enum : int {
 template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG, bool TEMPORAL, bool EXPORT, int SPEC = 0>
 MAL_DEV void march_body() {
   constexpr bool LEAN = (SPEC & kSpecLean) != 0, NO_DISP2 = (SPEC & kSpecNoDisp2) != 0;
+  // --avg_reprojection / --no_ssim (MarchParams::avg, ::no_ssim, wave-uniform): in the generic gradient passes only, so that
+  // no instantiation a whole-step list of the default options launches carries the tests
+  constexpr bool VARIANTS = GRAD && !LEAN && !TEMPORAL && !EXPORT;
   constexpr bool EXT_NO = (SPEC & kSpecExtNo) != 0, EXT_YES = (SPEC & kSpecExtYes) != 0;
   constexpr bool COST_NO = (SPEC & kSpecCostNo) != 0, COST_YES = (SPEC & kSpecCostYes) != 0;
   constexpr bool MONO_YES = (SPEC & kSpecMonoYes) != 0, NO_SCALE = (SPEC & kSpecNoScale) != 0;
@@ -677,8 +680,10 @@ MAL_DEV void march_body() {
     }
     const float wyd = (q == H - 2) ? 2.0f : 1.0f;  // row q+1 = c is the bottom border row
     // L1 term of the winner: w * 0.15/3 * sign(x - y)
-    const float lw = pi1.w * (0.15f / 3.0f);
-    const float lw0 = pi1.win == 0 ? lw : 0.f, lw1 = pi1.win != 0 ? lw : 0.f;
+    float lw = pi1.w * (0.15f / 3.0f);
+    if (VARIANTS && p.no_ssim) lw = pi1.w * (1.0f / 3.0f);
+    float lw0 = pi1.win == 0 ? lw : 0.f, lw1 = pi1.win != 0 ? lw : 0.f;
+    if (VARIANTS && pi1.win == 2) { lw0 = 0.5f * lw; lw1 = lw0; }
     const f2 lwk[3] = {bc(lw0), bc(lw1), (f2){lw0, lw1}};
     f2 g[3];
     // only the winner's L1 term is non-zero: take the sign of the winner's differences and let the zero
@@ -691,7 +696,11 @@ MAL_DEV void march_body() {
     if (DBG && out_x && own_q)
       dec_store(p.dbg, (unsigned)(p.B * HW), MAL_DEC_L1, so_q,
                 (unsigned)(int)(sgrg.x + 1.0f) | ((unsigned)(int)(sgrg.y + 1.0f) << 2) | ((unsigned)(int)(sgb + 1.0f) << 4));
-    const f2 sgk[3] = {sgrg, sgrg, bc(sgb)};
+    f2 sgk[3] = {sgrg, sgrg, bc(sgb)};
+    if (VARIANTS && pi1.win == 2) {  // both candidates carry an L1 term: each channel pair its own signs
+      const f2 d0 = wq.x[0] - wq.yrg, d1 = wq.x[1] - wq.yrg, d2 = wq.x[2] - bc(wq.yb);
+      sgk[0] = (f2){sgnf(d0.x), sgnf(d0.y)}; sgk[1] = (f2){sgnf(d1.x), sgnf(d1.y)}; sgk[2] = (f2){sgnf(d2.x), sgnf(d2.y)};
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const f2 SA = fma2(bc(wyd), hc[k * 3], hcA[k * 3]);
@@ -975,15 +984,18 @@ MAL_DEV void march_body() {
       }
       MAL_MARK(50);  // window sums + SSIM of six values done; L1, min, masks, coefficients follow
       const f2 ssum = (f2){(vc[0].x + vc[0].y) + vc[2].x, (vc[1].x + vc[1].y) + vc[2].y};
-      f2 l15 = sh_l15;
+      f2 l15 = sh_l15, lmean = bc(0.f);
       if (!SHADOW) {
         const f2 l0 = w1.yrg - w1.x[0], l1 = w1.yrg - w1.x[1], l2 = bc(w1.yb) - w1.x[2];
         const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
-        l15 = bc(0.15f) * div3_2(lsum);
+        lmean = div3_2(lsum);
+        l15 = bc(0.15f) * lmean;
       }
-      const f2 rr = bc(0.85f) * div3_2(ssum) + l15;
+      f2 rr = bc(0.85f) * div3_2(ssum) + l15;
+      if (VARIANTS && p.no_ssim) rr = lmean;  // --no_ssim: r = mean_c |t - p| (not in MAL_SHADOW builds, whose shadow code forms l15 only)
       pi0.win = (rr.y < rr.x) ? 1 : 0;
       pi0.rp = pi0.win ? rr.y : rr.x;
+      if (VARIANTS && p.avg) { pi0.win = 2; pi0.rp = (rr.x + rr.y) * 0.5f; }  // winner "2": both candidates, half each
       if (OUTS) {  // ... the winner among the two warped candidates, twice: the copy the fused sweep updates
         unsigned char* const am = p.argmin_out;
         if (am && out_x && c >= y_lo && c < y_hi) {
@@ -1033,7 +1045,9 @@ MAL_DEV void march_body() {
         // partials of the WINNING candidate only: w * 0.85/3 (channel mean) * -1/2 (v = (1-S)/2); the box
         // mean's 1/9 lives in the sums; torch.clamp passes gradient on [0,1] inclusive (clamped == raw)
         const float kk = -w * (0.85f / 3.0f) * 0.5f;
-        const float kk0 = pi0.win == 0 ? kk : 0.f, kk1 = pi0.win != 0 ? kk : 0.f;
+        float kk0 = pi0.win == 0 ? kk : 0.f, kk1 = pi0.win != 0 ? kk : 0.f;
+        if (VARIANTS && pi0.win == 2) { kk0 = 0.5f * kk; kk1 = kk0; }  // --avg_reprojection: d mean / d r_f = 1/2
+        if (VARIANTS && p.no_ssim) { kk0 = 0.f; kk1 = 0.f; }
         const f2 g0 = (f2){vc[0].x == v[0].x ? kk0 : 0.f, vc[0].y == v[0].y ? kk0 : 0.f};
         const f2 g1 = (f2){vc[1].x == v[1].x ? kk1 : 0.f, vc[1].y == v[1].y ? kk1 : 0.f};
         const f2 g2 = (f2){vc[2].x == v[2].x ? kk0 : 0.f, vc[2].y == v[2].y ? kk1 : 0.f};
@@ -1589,12 +1603,13 @@ struct IdentParams {
   int pose_blocks; StepPoses sp;              // the last pose_blocks workgroups: poses + camera block of sample b
   TieNoise tn;                                // ident += 1e-5 * N(0,1) (Philox), see mal_march.h
   SmoothParams sm;                            // edge-aware smoothness of up to two disparity maps in the same sweep
+  int variant;                                // VARIANTS instantiation only: bit 0 --no_ssim, bit 1 --avg_reprojection
 };
 
 // TEXIN: the three images arrive as (B,H,W,3) texels already -- a (B,3,H,W) tensor in torch.channels_last IS that layout --:
 // one 12-byte load per image and pixel instead of three 4-byte ones, and no texel copy is written (p.packed* are NULL: the
 // passes gather from the caller's tensors).
-template <bool TEXIN>
+template <bool TEXIN, bool VARIANTS = false>
 __global__ __launch_bounds__(64, 3) void pack_identity_kernel(IdentParams p) {
   constexpr int HALO = 1, CW = 62;
   const int id = blockIdx.x;
@@ -1750,8 +1765,10 @@ __global__ __launch_bounds__(64, 3) void pack_identity_kernel(IdentParams p) {
       const f2 ssum = (f2){(vc[0].x + vc[0].y) + vc[2].x, (vc[1].x + vc[1].y) + vc[2].y};
       const f2 l0 = y1rg - x1[0], l1 = y1rg - x1[1], l2 = bc(y1b) - x1[2];
       const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
-      const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
+      f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
+      if (VARIANTS && (p.variant & 1)) rr = div3_2(lsum);  // --no_ssim
       float idn = fminf(rr.x, rr.y);
+      if (VARIANTS && (p.variant & 2)) idn = (rr.x + rr.y) * 0.5f;  // --avg_reprojection (dualrefine/trainer.py:569-570)
       if (p.tn.on) {  // wave-uniform
         if ((c & 3) == 0 || c == y_lo) tie_noise4(p.tn.seed, tn_step, (unsigned)(b * HW + (c & ~3) * W + gxr), tn4);
         const int j = c & 3;
@@ -1880,7 +1897,8 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   hipEvent_t ev0 = named ? g_prof_start.exchange(nullptr) : nullptr, ev1 = named ? g_prof_stop.exchange(nullptr) : nullptr;
   if (ev0) (void)hipEventRecord(ev0, st);
   // the specialisation without the optional operands (march_body LEAN)
-  const bool lean0 = g_march_lean && p.packed == 3 && !p.depth_out && p.debug == 0 && !p.dbg &&
+  if ((p.avg || p.no_ssim) && (!grad || p.forced_w || p.color_out[0])) return MAL_EINVAL;  // generic gradient passes only
+  const bool lean0 = g_march_lean && p.packed == 3 && !p.depth_out && p.debug == 0 && !p.dbg && !p.avg && !p.no_ssim &&
                      (long long)p.H * p.W * (kTexel * 4) < (1ll << 24);  // tap byte offsets are formed in fp32 there
   const bool no_maps = !p.ext_mask && !p.lowest_cost && !p.sample_scale;
   const bool conv_a = p.convention == 0, conv_b = p.convention == 1;
@@ -1959,8 +1977,9 @@ int pack_identity_tasks_per_sample(int H, int W) { return ((W + 61) / 62) * ((H 
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
                          const StepPoses* poses, const TieNoise* noise, const SmoothParams* smooth, int* tasks_per_sample,
-                         bool texel_in) {
+                         bool texel_in, int variant) {
   IdentParams p = {};
+  p.variant = variant;
   if (noise) p.tn = *noise;
   if (smooth) p.sm = *smooth;
   p.pose_blocks = poses ? B : 0;
@@ -1973,7 +1992,10 @@ int pack_identity_launch(const float* target, const float* src0, const float* sr
   p.ntasks = B * p.strips * p.segs;
   p.per_xcd = (p.ntasks + 7) / 8;
   if (tasks_per_sample) *tasks_per_sample = p.strips * p.segs;
-  if (texel_in) {
+  if (variant) {  // --no_ssim / --avg_reprojection identity term: its own instantiation (the default one stays as it is)
+    if (texel_in) return MAL_EINVAL;
+    hipLaunchKernelGGL((pack_identity_kernel<false, true>), dim3(p.per_xcd * 8 + p.pose_blocks), dim3(64), 0, st, p);
+  } else if (texel_in) {
     if (packed0 || packed1 || packed_target) return MAL_EINVAL;  // nothing to repack: the inputs are the texels
     hipLaunchKernelGGL(pack_identity_kernel<true>, dim3(p.per_xcd * 8 + p.pose_blocks), dim3(64), 0, st, p);
   } else

@@ -483,6 +483,7 @@ static int ms_check(const mal_ms_args* a) {
   int rc = check_shape(a->B, a->H, a->W);
   if (rc) return rc;
   if (a->sclm < 0 || a->sclm >= kMsS) return MAL_EINVAL;
+  if ((a->flags & MAL_STEP_NO_SSIM) && (a->flags & MAL_STEP_TEMPORAL)) return MAL_EINVAL;
   const int f = 1 << a->sclm;
   if (a->H % f || a->W % f || (a->H >> a->sclm) < 2 || (a->W >> a->sclm) < 2) return MAL_ESHAPE;
   if (!a->color0 || !a->color_m1 || !a->color_p1 || !a->K || !a->inv_K || !a->axisangle_m1 || !a->translation_m1 ||
@@ -528,6 +529,7 @@ static MarchParams ms_teacher_params(const mal_ms_args* a, const MsWs& w, int s)
   p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
   p.block_sums = w.bs[0][s]; p.block_gP = w.bgP[s];
   p.cam = w.cam; p.cam_ready = 1;
+  p.no_ssim = (a->flags & MAL_STEP_NO_SSIM) ? 1 : 0;
   return p;
 }
 static void ms_fold_launch(const MsWs& w, int B, int H, int W, int S, bool teachers, bool students, hipStream_t st) {
@@ -555,7 +557,7 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
     sp.pose.T[0] = w.T[0]; sp.pose.T[1] = w.T[1];
     sp.K = a->K; sp.invK = a->inv_K; sp.cam = w.cam; sp.ticket = w.ticket;
     rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
-                              &sp, nullptr, nullptr, nullptr);
+                              &sp, nullptr, nullptr, nullptr, false, (a->flags & MAL_STEP_NO_SSIM) ? 1 : 0);
     if (rc) return rc;
   }
   if (a->flags & MAL_STEP_NOISE_PHILOX) {
@@ -615,6 +617,7 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
       p.merge_cons = merge_cons; p.merge_distil = 0.f;
       p.block_sums = w.bs[1][s]; p.block_gP = w.bgP[s];
       p.cam = w.cam; p.cam_ready = 1;
+      p.no_ssim = (a->flags & MAL_STEP_NO_SSIM) ? 1 : 0;
       rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
       if (rc) return rc;
     }

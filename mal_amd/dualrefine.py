@@ -307,21 +307,22 @@ class DualRefineLossPath:
         """``generate_images_pred`` + ``compute_losses`` (dualrefine/trainer.py:395-451,530-633) in ONE library call per
         direction AND scale of ``opt.scales`` (upstream's default list is [0,1,2,3]: scale 0 and 2 with the deq iterations
         0..n_losses, scale 1 skipped, scale 3 iteration 0 only, :403-407,536-547; a lower scale's disparities are upsampled
-        around the call), min reprojection with SSIM; same ``losses`` keys and values as the two methods called one after
-        the other (they remain the route for --avg_reprojection / --no_ssim / --v1_multiscale and for the ("color", ...) /
-        ("sample", ...) outputs, which this call does not materialise).  ``noises``: one (B,1,H,W) N(0,1) map per visited
+        around the call), with --avg_reprojection / --no_ssim when set; same ``losses`` keys and values as the two methods
+        called one after the other (they remain the route for --v1_multiscale and for the ("color", ...) / ("sample", ...)
+        outputs, which this call does not materialise).  ``noises``: one (B,1,H,W) N(0,1) map per visited
         (scale, iteration), in loop order (default: drawn as ``config.noise_source`` says)."""
         opt = self.opt
         n_full = opt.n_losses + 1
         scales = list(opt.scales)
         if any(s_ not in (0, 1, 2, 3) for s_ in scales) or len(set(scales)) != len(scales) or not scales \
-                or opt.avg_reprojection or opt.no_ssim or opt.v1_multiscale or n_full > L.DR_MAX_ITERS \
+                or opt.v1_multiscale or n_full > L.DR_MAX_ITERS \
                 or list(opt.frame_ids) != [0, -1, 1] or self.f_thres <= 0:
-            raise L.MalError("DualRefineLossPath.loss_step covers scales out of [0,1,2,3], frames [0,-1,1], min reprojection with "
-                             "SSIM and n_losses < %d; use generate_images_pred + compute_losses otherwise" % L.DR_MAX_ITERS)
+            raise L.MalError("DualRefineLossPath.loss_step covers scales out of [0,1,2,3], frames [0,-1,1], not --v1_multiscale, "
+                             "n_losses < %d; use generate_images_pred + compute_losses otherwise" % L.DR_MAX_ITERS)
         target = inputs[("color", 0, 0)]
         B, _, H, W = target.shape
-        flags = (L.DR_NO_AUTOMASK if opt.disable_automasking else 0) | (L.DR_NO_MOTION_MASK if opt.disable_motion_masking else 0)
+        flags = (L.DR_NO_AUTOMASK if opt.disable_automasking else 0) | (L.DR_NO_MOTION_MASK if opt.disable_motion_masking else 0) | \
+                (L.DR_AVG if opt.avg_reprojection else 0) | (L.DR_NO_SSIM if opt.no_ssim else 0)
         units = [(s_, it) for s_ in scales if s_ != 1 for it in range(n_full if s_ in (0, 1, 2) else 1)]
         philox = None
         if noises is None and not opt.disable_automasking:

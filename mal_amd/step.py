@@ -479,7 +479,7 @@ class MultiScaleLossFn(Function):
         a = L.MsArgs()
         a.B, a.H, a.W, a.sclm = B, H, W, sclm
         a.min_depth, a.max_depth = float(min_depth), float(max_depth)
-        a.flags = L.STEP_AUG_MASK if aug_is_mask else 0
+        a.flags = (L.STEP_AUG_MASK if aug_is_mask else 0) | (L.STEP_NO_SSIM if (len(cfg) > 7 and cfg[7]) else 0)
         a.color0, a.color_m1, a.color_p1 = (p(t) for t in cons[:3])
         for s in range(1, S):
             a.color0_s[s] = p(cons[3 + s - 1])
@@ -568,8 +568,10 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
     temporal = bool(getattr(opt, "temporal", False))
     if temporal and image_synthesis is None:
         raise L.MalError("loss_step_multiscale with opt.temporal needs image_synthesis(inputs, outputs, scale) -> has_ins")
-    unsupported = [k for k in ("distil", "v1_multiscale", "ensemble", "no_ssim", "disable_automasking",
+    unsupported = [k for k in ("distil", "v1_multiscale", "ensemble", "disable_automasking",
                                "disable_motion_masking", "no_matching_augmentation") if getattr(opt, k, False)]
+    if getattr(opt, "no_ssim", False) and getattr(opt, "temporal", False):
+        unsupported.append("no_ssim with temporal")
     if unsupported or sclm >= L.MS_MAX_SCALES or list(opt.frame_ids) != [0, -1, 1]:
         raise L.MalError("loss_step_multiscale covers the non-distil sclm <= 3 configuration with frames [0,-1,1]; %s: use "
                          "MALLossPath.compute_batch_losses" % (", ".join(unsupported) or "this configuration"))
@@ -595,7 +597,7 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
               inputs[("K", 0)], inputs[("inv_K", 0)], outputs["consistency_mask"].to(torch.float32), keep,
               outputs.get("lowest_cost"), noises)
     cfg = (opt.min_depth, opt.max_depth, sclm, aug_is_mask, philox, bool(want_maps),
-           (image_synthesis, inputs, mono_outputs) if temporal else None)
+           (image_synthesis, inputs, mono_outputs) if temporal else None, bool(getattr(opt, "no_ssim", False)))
     leaves = [mono_outputs[("disp", s)] for s in range(sclm + 1)] + [outputs[("disp", s)] for s in range(sclm + 1)] + \
              [aa[-1], tr[-1], aa[1], tr[1]]
     res = MultiScaleLossFn.apply(consts, cfg, *leaves)

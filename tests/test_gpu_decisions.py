@@ -473,6 +473,53 @@ def test_dualrefine_one_call_step_equals_the_operator_route(shape, kw_extra):
         assert np.abs(res["step"][1][k] - g).max() <= 2e-5 * max(sc, 1e-12), (k, np.abs(res["step"][1][k] - g).max() / max(sc, 1e-12))
 
 
+@pytest.mark.parametrize("kw_extra", [{"avg_reprojection": True}, {"no_ssim": True}, {"avg_reprojection": True, "no_ssim": True}],
+                         ids=["avg", "no_ssim", "avg_no_ssim"])
+def test_dualrefine_one_call_step_avg_and_no_ssim(kw_extra):
+    """--avg_reprojection (the MEAN over the two frames of r and of the identity term, dualrefine/trainer.py:569-583) and
+    --no_ssim (r = mean_c |t - p|, :493-494) in the one-call step (MAL_DR_AVG / MAL_DR_NO_SSIM: the generic marching pass with
+    both candidates carrying half of every gradient / without the SSIM planes) against the oracle's restatement of those lines
+    (free-running: a decision within rounding of a tie may fall either way, so per-pixel gradients are held on all but a
+    handful of pixels) and against the operator route (materialised candidates, other kernels)."""
+    from mal_amd import dualrefine, layers
+    from mal_amd.synthetic import make_batch
+    B, H, W = 3, 40, 72
+    N = B * H * W
+    batch = make_batch(B, H, W, seed=323)
+    kw = dict(height=H, width=W, batch_size=B, n_losses=1)
+    kw.update(kw_extra)
+    torch.manual_seed(9)
+    noises = [torch.randn(B, 1, H, W) for _ in range(2)]
+    ref, gref, _, _ = _dr_oracle(batch, kw, noises)
+    res = {}
+    for route in ("ops", "step"):
+        inputs, outputs, gl = _dr_build(batch, "cuda:0", layers.transformation_from_parameters)
+        lp = dualrefine.DualRefineLossPath(dualrefine.default_options(**kw), fuse=True)
+        nz = [n.to("cuda:0") for n in noises]
+        if route == "ops":
+            lp.generate_images_pred(inputs, outputs)
+            got = lp.compute_losses(inputs, outputs, noises=nz)
+        else:
+            got = lp.loss_step(inputs, outputs, noises=nz)
+        got["loss"].backward()
+        torch.cuda.synchronize()
+        res[route] = ({k: float(v.detach()) for k, v in got.items()},
+                      {k: (t.grad if t.grad is not None else torch.zeros_like(t)).cpu().numpy() for k, t in gl.items()})
+    assert set(res["step"][0]) == set(ref) == set(res["ops"][0])
+    for k, v in ref.items():
+        tie = 4.0 / N  # two automask pixels per iteration at rounding distance of their threshold
+        assert abs(res["step"][0][k] - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + tie, (k, res["step"][0][k], float(v))
+        assert abs(res["step"][0][k] - res["ops"][0][k]) <= 2e-5 * abs(float(v)) + tie, (k, res["step"][0][k], res["ops"][0][k])
+    for k in HH.LEAVES:
+        g, r, o = res["step"][1][k], gref[k], res["ops"][1][k]
+        if g.ndim == 4:
+            for other, what in ((r, "oracle"), (o, "operator route")):
+                bad = (np.abs(g - other) > 3e-4 * np.abs(other).max()).mean()
+                assert bad <= max(2e-3, 40.0 / g.size), (k, what, bad)
+        else:
+            assert _l2rel(g, r) <= 2e-2 and _l2rel(g, o) <= 2e-2, (k, _l2rel(g, r), _l2rel(g, o))
+
+
 def test_dualrefine_one_call_step_with_upstream_default_scales():
     """DualRefineLossPath.loss_step over upstream's default scale list [0, 1, 2, 3]: one library call per direction and visited
     scale (0 and 2 with both iterations, 3 with iteration 0; the lower scales' disparities upsampled around the call, their

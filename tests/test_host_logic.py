@@ -112,11 +112,11 @@ def test_workspace_ownership_tokens():
 
 
 def test_dualrefine_one_call_step_refuses_what_it_does_not_cover():
-    """DualRefineLossPath.loss_step covers scales out of [0,1,2,3], min reprojection with SSIM, n_losses < MAL_DR_MAX_ITERS;
-    everything else is refused by name before any device work (the operator-level methods remain the route for it)"""
+    """DualRefineLossPath.loss_step covers scales out of [0,1,2,3] and n_losses < MAL_DR_MAX_ITERS; everything else is
+    refused by name before any device work (the operator-level methods remain the route for it)"""
     import pytest
     from mal_amd import _lib, dualrefine
-    for kw in (dict(scales=[0, 4]), dict(scales=[0, 0]), dict(scales=[]), dict(avg_reprojection=True), dict(no_ssim=True), dict(n_losses=_lib.DR_MAX_ITERS),
+    for kw in (dict(scales=[0, 4]), dict(scales=[0, 0]), dict(scales=[]), dict(n_losses=_lib.DR_MAX_ITERS),
                dict(frame_ids=[0, -1]), dict(v1_multiscale=True)):
         lp = dualrefine.DualRefineLossPath(dualrefine.default_options(**kw))
         with pytest.raises(_lib.MalError):
