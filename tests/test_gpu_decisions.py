@@ -218,6 +218,21 @@ def test_main_temporal_decision_exact(kw):
                 assert _l2rel(g, r.reshape(g.shape)) <= 1e-4, (key, _l2rel(g, r.reshape(g.shape)))
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 37, 50), (1, 16, 61), (2, 10, 121), (1, 24, 8)],
+                         ids=["ragged_b3_37x50", "strip_edge_61", "three_strips_ragged", "narrow_8"])
+@pytest.mark.parametrize("kw", [{"temporal": True}, {"temporal": True, "main_temporal": True}], ids=["temporal", "both"])
+def test_temporal_hints_small_and_ragged_shapes(B, H, W, kw):
+    """strip / segment boundaries of the passes the temporal hint adds (exporting forward passes, materialised-candidate sweeps,
+    TEMPORAL gradient sweeps of teacher and student): widths just past a 60-column strip, a few rows only, images narrower than
+    one wavefront, odd sizes -- decision-exact against the oracle"""
+    from mal_amd.synthetic import make_batch
+    b = make_batch(B, H, W, seed=57, with_syn=True)
+    g = torch.Generator().manual_seed(11)
+    n0, n1 = torch.randn(B, 1, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
+    counts, report = check_step_decision_exact(b, kw, n0, n1)
+    assert all(v[0] <= 1e-4 for v in report.values()), report
+
+
 def test_main_temporal_at_baseline_size():
     """--temporal --main_temporal --distil at B=12 192x640 with the real producer (N2's kernels, sparse syn buffers, region maps)
     on both passes"""
