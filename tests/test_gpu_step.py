@@ -156,6 +156,65 @@ def test_loss_step_equals_operator_route(tag):
         assert np.abs(r).max() > 0 and np.abs(g - r)[~amb].max() <= 1e-4 * np.abs(r).max()
 
 
+@pytest.mark.parametrize("kw", [{"temporal": True}, {"temporal": True, "main_temporal": True}, {"main_temporal": True}],
+                         ids=["temporal", "both", "student_only"])
+def test_temporal_hint_steps_replay_from_a_graph(kw):
+    """the three library calls around the producer(s), forward and backward, captured into one HIP graph (as bench.py replays the
+    headline; the side stream's fork / join are event-based and capturable): a replay leaves the same loss and gradients as
+    the eager step, bit for bit"""
+    from mal_amd import step, trainer
+    from mal_amd.synthetic import make_batch
+    B, H, W = 2, 40, 130
+    b = make_batch(B, H, W, seed=43, with_syn=True)
+    g_ = torch.Generator().manual_seed(9)
+    n0 = torch.randn(B, 1, H, W, generator=g_).to(DEV)
+    dev = torch.device(DEV)
+    opt = trainer.default_options(height=H, width=W, batch_size=B, **kw)
+    inputs, mono_outputs, outputs, leaves = to_dicts(b, lambda a, t, inv: None, device=dev)
+    for f, sfx in ((-1, "m1"), (1, "p1")):
+        mono_outputs[("axisangle", 0, f)] = leaves["axisangle_" + sfx]
+        mono_outputs[("translation", 0, f)] = leaves["translation_" + sfx]
+    synth = HH.producer_of(b, dev)
+    one_ = torch.ones((), device=dev)
+    hold = {}
+
+    def one():
+        for t in leaves.values():
+            t.grad = None
+        losses, _, _ = step.loss_step(opt, inputs, dict(mono_outputs), dict(outputs), w_list=[0.7, 0.3], noise=n0, want_maps=False,
+                                      image_synthesis=synth)
+        losses["loss"].backward(gradient=one_)
+        hold["loss"] = losses["loss"].detach()
+
+    # every eager step on a side stream, as PyTorch's capture rules ask (and bench.py does): a leaf's gradient accumulator
+    # remembers the stream of the leaf's first use and the backward synchronises with it -- were that the legacy default stream,
+    # the captured backward would try to pull it into the capture, which invalidates the capture (and this runtime then dies
+    # in capture_end instead of raising)
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        one()
+        one()
+    torch.cuda.current_stream().wait_stream(s_)
+    torch.cuda.synchronize()
+    ref_loss = float(hold["loss"])
+    ref = {k: t.grad.clone() for k, t in leaves.items()}
+    graph = torch.cuda.CUDAGraph()
+    # thread_local, as bench.py captures: the backward's nodes run on autograd's device thread, whose allocations a capture in
+    # "global" mode forbids (the runtime then dies in capture_end instead of raising)
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        one()
+    grads = {k: t.grad for k, t in leaves.items()}  # the buffers the captured backward writes
+    for _ in range(2):
+        for t in grads.values():
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert float(hold["loss"]) == ref_loss
+        for k, t in grads.items():
+            assert torch.equal(t, ref[k]), k
+
+
 def test_loss_step_rejects_unsupported_options():
     from mal_amd import step, trainer, _lib
     opt = trainer.default_options(temporal=True)
