@@ -275,6 +275,10 @@ enum {
                                  mal_loss_step_bwd   g_warp_s_* in: the student's gradient sweep takes the four-way decisions
                                                      of _fwd and adds what arrives through syn */
   MAL_STEP_SYN_S_SPARSE = 256, /* MAL_STEP_SYN_SPARSE for the student's pair (syn_s_* / syn_s_region / warp_s_*) */
+  MAL_STEP_NO_MOTION_MASK = 1024, /* mal_loss_multiscale_* only: --disable_motion_masking (manydepth/trainer.py:1321-1323): the student's
+                                  weight leaves the consistency mask out (no matching mask is formed either: consistency_mask_out
+                                  is not written) */
+  MAL_STEP_NO_AUG = 2048,      /* mal_loss_multiscale_* only: --no_matching_augmentation (:1324-1326): ... and (1 - augmentation_mask) */
   MAL_STEP_NO_SSIM = 512       /* mal_loss_multiscale_* only: --no_ssim, r = mean_c |target - pred| (manydepth/trainer.py:1217-1218 --
                                   upstream reads the flag on this, the non-distillation, route only); not with MAL_STEP_TEMPORAL */
 };
@@ -385,7 +389,9 @@ enum { MAL_MS_MAX_SCALES = 4 };
 typedef struct mal_ms_args {
   int B, H, W, sclm;                              /* scale s is (H >> s, W >> s); H, W divisible by 2**sclm */
   float min_depth, max_depth;
-  int flags;                                      /* MAL_STEP_AUG_MASK, MAL_STEP_NOISE_PHILOX, MAL_STEP_TEMPORAL, MAL_STEP_NO_SSIM */
+  int flags;                                      /* MAL_STEP_AUG_MASK, _NOISE_PHILOX, _TEMPORAL, _NO_SSIM, _NO_MOTION_MASK, _NO_AUG;
+                                                     --disable_automasking: pass no noise (upstream compares against the identity
+                                                     term even then, manydepth/trainer.py:1296-1311: only the noise goes) */
   const float *color0, *color_m1, *color_p1;      /* (B,3,H,W) */
   const float *color0_s[MAL_MS_MAX_SCALES];       /* inputs[("color",0,s)]: (B,3,H>>s,W>>s); [0] NULL = color0 */
   const float *K, *inv_K;                         /* (B,16) */

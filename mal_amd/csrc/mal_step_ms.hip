@@ -604,9 +604,11 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
       MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
       p.disp = disp_s; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
       p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
-      p.sample_scale = a->augmentation_keep; p.sample_scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0;
+      if (!(a->flags & MAL_STEP_NO_AUG)) { p.sample_scale = a->augmentation_keep; p.sample_scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0; }
       p.mono_disp = disp_t;
-      if (s == 0) {
+      if (a->flags & MAL_STEP_NO_MOTION_MASK) {
+        // the weight is 1 (x augmentation): no mask operand at all
+      } else if (s == 0) {
         p.ext_mask = a->consistency_mask; p.lowest_cost = a->lowest_cost;
         if (a->lowest_cost) p.cmask_out = a->consistency_mask_out ? a->consistency_mask_out : w.cmask;
       } else {

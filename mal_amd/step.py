@@ -372,7 +372,7 @@ def loss_step(opt, inputs, mono_outputs, outputs, w_list=None, batch_size_scale=
     tr = {f: mono_outputs[("translation", 0, f)] for f in (-1, 1)}
     fix = lambda t: t[:, 0] if t.dim() == 4 else t  # the pose decoder emits (B,2,1,3); frame 0 of it is used
     philox = None
-    if noise is None and not getattr(opt, "disable_automasking", False):
+    if noise is None:  # (loss_utils.compute_mono_losses adds the noise whatever --disable_automasking says, loss_utils.py:105-106)
         if config.noise_source == "philox":  # drawn inside the step's first kernel: no RNG launch, no host work
             philox = (config.noise_seed, bool(want_noise))
         else:
@@ -479,7 +479,8 @@ class MultiScaleLossFn(Function):
         a = L.MsArgs()
         a.B, a.H, a.W, a.sclm = B, H, W, sclm
         a.min_depth, a.max_depth = float(min_depth), float(max_depth)
-        a.flags = (L.STEP_AUG_MASK if aug_is_mask else 0) | (L.STEP_NO_SSIM if (len(cfg) > 7 and cfg[7]) else 0)
+        a.flags = (L.STEP_AUG_MASK if aug_is_mask else 0) | (L.STEP_NO_SSIM if (len(cfg) > 7 and cfg[7]) else 0) | \
+                  (int(cfg[8]) if len(cfg) > 8 else 0)
         a.color0, a.color_m1, a.color_p1 = (p(t) for t in cons[:3])
         for s in range(1, S):
             a.color0_s[s] = p(cons[3 + s - 1])
@@ -499,7 +500,7 @@ class MultiScaleLossFn(Function):
         total = torch.empty(1, dtype=torch.float32, device=dev)
         a.losses, a.loss_total = p(losses), p(total)
         outs = [total, losses]
-        if want_maps and lowest is not None:
+        if want_maps and lowest is not None and not (a.flags & L.STEP_NO_MOTION_MASK):
             cm = torch.empty((B, H, W), dtype=torch.float32, device=dev)
             a.consistency_mask_out = p(cm)
             outs.append(cm)
@@ -568,8 +569,7 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
     temporal = bool(getattr(opt, "temporal", False))
     if temporal and image_synthesis is None:
         raise L.MalError("loss_step_multiscale with opt.temporal needs image_synthesis(inputs, outputs, scale) -> has_ins")
-    unsupported = [k for k in ("distil", "v1_multiscale", "ensemble", "disable_automasking",
-                               "disable_motion_masking", "no_matching_augmentation") if getattr(opt, k, False)]
+    unsupported = [k for k in ("distil", "v1_multiscale", "ensemble") if getattr(opt, k, False)]
     if getattr(opt, "no_ssim", False) and getattr(opt, "temporal", False):
         unsupported.append("no_ssim with temporal")
     if unsupported or sclm >= L.MS_MAX_SCALES or list(opt.frame_ids) != [0, -1, 1]:
@@ -582,7 +582,9 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
     aa = {f: fix(mono_outputs[("axisangle", 0, f)]) for f in (-1, 1)}
     tr = {f: fix(mono_outputs[("translation", 0, f)]) for f in (-1, 1)}
     philox = None
-    if noises is None:
+    if getattr(opt, "disable_automasking", False):
+        noises = None  # upstream still compares against the identity term (trainer.py:1296-1311): only the tie-break noise goes
+    elif noises is None:
         if config.noise_source == "philox":
             philox = config.noise_seed
         else:
@@ -597,13 +599,23 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
               inputs[("K", 0)], inputs[("inv_K", 0)], outputs["consistency_mask"].to(torch.float32), keep,
               outputs.get("lowest_cost"), noises)
     cfg = (opt.min_depth, opt.max_depth, sclm, aug_is_mask, philox, bool(want_maps),
-           (image_synthesis, inputs, mono_outputs) if temporal else None, bool(getattr(opt, "no_ssim", False)))
+           (image_synthesis, inputs, mono_outputs) if temporal else None, bool(getattr(opt, "no_ssim", False)),
+           (L.STEP_NO_MOTION_MASK if getattr(opt, "disable_motion_masking", False) else 0) |
+           (L.STEP_NO_AUG if getattr(opt, "no_matching_augmentation", False) else 0))
     leaves = [mono_outputs[("disp", s)] for s in range(sclm + 1)] + [outputs[("disp", s)] for s in range(sclm + 1)] + \
              [aa[-1], tr[-1], aa[1], tr[1]]
     res = MultiScaleLossFn.apply(consts, cfg, *leaves)
     total, v = res[0].reshape(()), res[1]
     if len(res) > 2:
         outputs["consistency_mask"] = res[2]
+    elif want_maps and outputs.get("lowest_cost") is not None and getattr(opt, "disable_motion_masking", False):
+        # process_batch multiplies the matching mask in whatever the loss does with it (trainer.py:592-593); the passes did not
+        # form it (their weight leaves the mask out): one operator launch
+        from . import layers
+        with torch.no_grad():
+            _, mono_depth = layers.disp_to_depth(mono_outputs[("disp", 0)].detach(), opt.min_depth, opt.max_depth)
+            outputs["consistency_mask"] = ops.matching_mask(outputs["lowest_cost"], mono_depth[:, 0].contiguous(),
+                                                            outputs["consistency_mask"].to(torch.float32))
     losses, mono_losses = {"loss": total}, {"loss": v[32]}
     for s in range(sclm + 1):
         losses["reproj_loss/%d" % s], losses["loss/%d" % s] = v[36 + s], v[40 + s]

@@ -251,6 +251,42 @@ def test_no_ssim_against_the_oracle(case):
             assert _l2rel(gq[keep], r[keep]) <= 2e-2, (k, _l2rel(gq[keep], r[keep]), keep)
 
 
+@pytest.mark.parametrize("kw_extra", [{"disable_automasking": True}, {"disable_motion_masking": True},
+                                      {"no_matching_augmentation": True},
+                                      {"disable_motion_masking": True, "no_matching_augmentation": True, "disable_automasking": True}],
+                         ids=["no_automask_noise", "no_motion_mask", "no_augmentation", "all_three"])
+def test_mask_switches_against_the_oracle(kw_extra):
+    """--disable_automasking (upstream still compares against the identity term, trainer.py:1296-1311: only the noise goes),
+    --disable_motion_masking, --no_matching_augmentation (:1321-1326: the student's weight leaves the consistency mask / the
+    (1 - augmentation) factor out) on the four-scale path"""
+    B, H, W, sclm = 3, 40, 72, 2
+    batch = make_batch(B, H, W, seed=85)
+    batch["augmentation_mask"][0] = 1.0  # one augmented sample, so that the switch shows
+    g = torch.Generator().manual_seed(15)
+    nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+    kw.update(kw_extra)
+    oi, om, oo, ol = _build(batch, "cpu", sclm)
+    rt, rs = _oracle_step(oi, om, oo, kw, nt, nt, matching=True)
+    hi, hm, ho, hl = _build(batch, DEV, sclm)
+    losses, mono_losses = _hip_step(hi, hm, ho, hl, kw, nt)
+    N = B * H * W
+    for k, v in rt.items():
+        assert abs(float(mono_losses[k]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + 12.0 / N, ("teacher", k, float(mono_losses[k]), float(v))
+    for k, v in rs.items():
+        name = k if k.startswith("consistency") else "main/" + k
+        assert abs(float(losses[name]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + 4.0 / N, ("student", k, float(losses[name]), float(v))
+    assert (ho["consistency_mask"].cpu().numpy() != oo["consistency_mask"].numpy()).mean() <= 1e-3  # x matching mask, either way
+    for k in hl:
+        gq, r = hl[k].grad.cpu().numpy(), ol[k].grad.numpy()
+        if gq.ndim == 4:
+            bad = (np.abs(gq - r) > 3e-4 * np.abs(r).max()).mean()
+            sc = int(k[-1]) if k[-1].isdigit() else 0
+            assert bad <= max(2e-3 * (1 + 4 ** sc / 8.0), 40.0 / gq.size), (k, bad)
+        else:
+            assert _l2rel(gq, r) <= 3e-2, (k, _l2rel(gq, r))
+
+
 def test_temporal_equals_operator_route():
     """--temporal with sclm > 0 through the three library calls vs the operator-level route (MALLossPath: materialising warp,
     producer, materialised-candidate kernels, per scale): same kernels underneath, same numbers"""
@@ -342,4 +378,7 @@ def test_unsupported_configurations_are_refused():
         step.loss_step_multiscale(trainer.default_options(height=32, width=64, batch_size=2, sclm=1, distil=True), hi, hm, ho)
     with pytest.raises(_lib.MalError):
         step.loss_step_multiscale(trainer.default_options(height=32, width=64, batch_size=2, sclm=1, distil=False, ensemble=True),
+                                  hi, hm, ho)
+    with pytest.raises(_lib.MalError):
+        step.loss_step_multiscale(trainer.default_options(height=32, width=64, batch_size=2, sclm=1, distil=False, v1_multiscale=True),
                                   hi, hm, ho)
