@@ -279,6 +279,9 @@ enum {
                                   weight leaves the consistency mask out (no matching mask is formed either: consistency_mask_out
                                   is not written) */
   MAL_STEP_NO_AUG = 2048,      /* mal_loss_multiscale_* only: --no_matching_augmentation (:1324-1326): ... and (1 - augmentation_mask) */
+  MAL_STEP_ENSEMBLE = 4096,    /* mal_loss_multiscale_* only: --ensemble on the non-distillation route (manydepth/trainer.py:1346-1351):
+                                  + mean(|(depth_teacher.detach() + depth_student)/2 - depth_student| * mask) per scale for the student;
+                                  losses[44 + s] */
   MAL_STEP_NO_SSIM = 512       /* mal_loss_multiscale_* only: --no_ssim, r = mean_c |target - pred| (manydepth/trainer.py:1217-1218 --
                                   upstream reads the flag on this, the non-distillation, route only); not with MAL_STEP_TEMPORAL */
 };
@@ -404,7 +407,8 @@ typedef struct mal_ms_args {
   uint64_t noise_seed, noise_step; uint64_t* noise_counter;
   float *losses;                                  /* 48: [net][scale][reproj, consistency, smooth, loss] (net 0 teacher),
                                                      [32] teacher total, [33] student total, [34] their sum,
-                                                     [36+s] reproj student+teacher, [40+s] loss student+teacher */
+                                                     [36+s] reproj student+teacher, [40+s] loss student+teacher,
+                                                     [44+s] the student's ensemble term (MAL_STEP_ENSEMBLE, else 0) */
   float *loss_total;                              /* nullable: receives losses[34] */
   float *consistency_mask_out;                    /* (B,H,W) nullable */
   const float *g_total;                           /* backward: device scalar, nullable = 1 */

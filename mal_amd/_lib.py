@@ -171,7 +171,7 @@ DR_MAX_ITERS = 4
 DR_NO_AUTOMASK, DR_NO_MOTION_MASK, DR_NOISE_PHILOX, DR_AVG, DR_NO_SSIM = 1, 2, 4, 8, 16
 MS_MAX_SCALES = 4
 STEP_NO_ENS, STEP_AUG_MASK, STEP_NOISE_PHILOX, STEP_TEMPORAL, STEP_SYN_SPARSE, STEP_DUAL_DISTIL, STEP_TEXEL_INPUTS = 1, 2, 4, 8, 16, 32, 64
-STEP_MAIN_TEMPORAL, STEP_SYN_S_SPARSE, STEP_NO_SSIM, STEP_NO_MOTION_MASK, STEP_NO_AUG = 128, 256, 512, 1024, 2048
+STEP_MAIN_TEMPORAL, STEP_SYN_S_SPARSE, STEP_NO_SSIM, STEP_NO_MOTION_MASK, STEP_NO_AUG, STEP_ENSEMBLE = 128, 256, 512, 1024, 2048, 4096
 # decision planes of mal_step_args.dec_teacher / dec_student (MAL_DEC_*)
 DEC_WIN, DEC_DISTIL, DEC_SMOOTH_X, DEC_SMOOTH_Y, DEC_TAP0, DEC_TAP1, DEC_L1, DEC_PLANES = 0, 1, 2, 3, 4, 5, 6, 7
 

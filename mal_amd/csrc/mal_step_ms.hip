@@ -50,6 +50,8 @@ struct MsWs {
   double* stats;         // [2][2S][B]: mean, mean-coupling term
   float* gT;             // [S][2][B*16]
   float* coefs;          // [3S]: cR[net*S + s], cS[s]
+  float* neg_inf;        // MAL_STEP_ENSEMBLE: a map of -inf -- handed to the student's epilogue as the "ensemble reprojection", it makes
+                         // the ensemble win the distillation argmin at every pixel: that term IS upstream's ensemble loss then
   // temporal hint, per scale: what the teacher's forward pass in front of the producer leaves (min over the two warped candidates,
   // its winner), the four-way decision of the fused sweep (winner, automask weight, min) and that sweep's per-task differences
   float* rp_warp[kMsS]; unsigned char* arg_warp[kMsS]; float* rp4[kMsS]; unsigned char* arg_t[kMsS]; float* w_t[kMsS];
@@ -86,6 +88,7 @@ static MsWs carve_ms(void* base, int B, int H, int W, int sclm) {
   w.stats = (double*)take((size_t)2 * 2 * S * B * 8);
   w.gT = (float*)take((size_t)S * 2 * B * 16 * 4);
   w.coefs = (float*)take(3 * kMsS * 4);
+  w.neg_inf = (float*)take(map);
   for (int s = 0; s < S; ++s) {
     w.rp_warp[s] = (float*)take(map); w.rp4[s] = (float*)take(map); w.w_t[s] = (float*)take(map);
     w.arg_warp[s] = (unsigned char*)take((size_t)B * HW); w.arg_t[s] = (unsigned char*)take((size_t)B * HW);
@@ -214,6 +217,7 @@ struct MsFinal {
   // pose partials do not exist yet (bgP all null: no pose blocks in this launch, ms_pose_kernel follows the backward's sweeps)
   const double* bs_ph[kMsS]; int per_sample_ph[kMsS]; int per_sample_t;
   const float* K; int per_sample, B, H, W, S;
+  int ensemble;          // MAL_STEP_ENSEMBLE: slot 3 of the student's sums is the ensemble term
   double* ps; double* stats; float* gT; float* losses; float* coefs; float* loss_total; unsigned* ticket;
   unsigned long long* noise_counter;
 };
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256) void ms_final_kernel(MsFinal p) {
   }
   __syncthreads();
   // one thread per (network, scale): its four scalars and its coefficient (double divisions: not on one thread in a row)
-  __shared__ float s_loss[2 * kMsS], s_rep[2 * kMsS];
+  __shared__ float s_loss[2 * kMsS], s_rep[2 * kMsS], s_ens[2 * kMsS];
   if (tid < 2 * S) {
     const int net = tid / S, s = tid - net * S;
     const double N = (double)B * p.H * p.W;
@@ -345,11 +349,12 @@ __global__ __launch_bounds__(256) void ms_final_kernel(MsFinal p) {
     const double Nx = (double)B * h * (w - 1), Ny = (double)B * (h - 1) * w;
     const float reproj = (float)(t[0] / (t[1] + 1e-7));
     const float cons = net ? (float)(t[2] / N) : 0.f;
+    const float ens = (net && p.ensemble) ? (float)(t[3] / N) : 0.f;
     const float smooth = (float)(t[4] / Nx + t[5] / Ny);
-    const float loss = (net ? reproj + cons : reproj) + (1e-3f * smooth) / (float)(1 << s);
+    const float loss = (net ? (reproj + cons) + ens : reproj) + (1e-3f * smooth) / (float)(1 << s);
     float* o = p.losses + (net * kMsS + s) * 4;
     o[0] = reproj; o[1] = cons; o[2] = smooth; o[3] = loss;
-    s_loss[tid] = loss; s_rep[tid] = reproj;
+    s_loss[tid] = loss; s_rep[tid] = reproj; s_ens[tid] = ens;
     p.coefs[tid] = (float)(1.0 / ((double)S * (t[1] + 1e-7)));
     if (net == 0) p.coefs[2 * S + s] = (float)(1e-3 / ((double)(1 << s) * (double)S));
   }
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256) void ms_final_kernel(MsFinal p) {
     p.losses[36 + s] = s < S ? s_rep[S + s] + s_rep[s] : 0.f;
     p.losses[40 + s] = s < S ? s_loss[S + s] + s_loss[s] : 0.f;
   }
-  for (int i = 44; i < kMsLossSlots; ++i) p.losses[i] = 0.f;
+  for (int s = 0; s < kMsS; ++s) p.losses[44 + s] = s < S ? s_ens[S + s] : 0.f;
   if (p.loss_total) *p.loss_total = p.losses[34];
 }
 
@@ -580,6 +585,9 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
   }
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
   const float merge_cons = (float)(1.0 / ((double)S * (double)B * H * W));
+  if (a->flags & MAL_STEP_ENSEMBLE) {
+    if (hipMemsetD32Async((hipDeviceptr_t)w.neg_inf, (int)0xff800000u, (size_t)B * H * W, st) != hipSuccess) return MAL_ELAUNCH;
+  }
   for (int s = 0; s < S; ++s) {
     const float* disp_t = s ? w.up[0][s] : a->disp_teacher[0];
     const float* disp_s = s ? w.up[1][s] : a->disp_student[0];
@@ -617,6 +625,11 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
       p.mono_reproj = w.ident;  // the distillation selection is not part of this loss: any map serves, its term has weight 0
       p.g_reproj = w.G_r[1][s]; p.g_cons = w.G_c[s]; p.g_distil = nullptr; p.bnd = g_march_halo1 ? w.bnd[1][s] : nullptr;
       p.merge_cons = merge_cons; p.merge_distil = 0.f;
+      if (a->flags & MAL_STEP_ENSEMBLE) {
+        // --ensemble (trainer.py:1346-1351): |(mono + multi)/2 - multi| * mask IS the distillation term with the ensemble winning
+        // everywhere (index 1: target (mono + multi)/2, mono detached, weight = the mask), same 1/N as the consistency term
+        p.ens_reproj = w.neg_inf; p.merge_distil = merge_cons;
+      }
       p.block_sums = w.bs[1][s]; p.block_gP = w.bgP[s];
       p.cam = w.cam; p.cam_ready = 1;
       p.no_ssim = (a->flags & MAL_STEP_NO_SSIM) ? 1 : 0;
@@ -679,7 +692,7 @@ static int ms_back(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool tem
     fin.bgP[s] = temporal ? nullptr : w.bgP[s];
     fin.per_sample_sm[s] = per_sample_sm[s];
   }
-  fin.K = a->K; fin.B = B; fin.H = H; fin.W = W; fin.S = S;
+  fin.K = a->K; fin.B = B; fin.H = H; fin.W = W; fin.S = S; fin.ensemble = (a->flags & MAL_STEP_ENSEMBLE) ? 1 : 0;
   fin.ps = w.ps; fin.stats = w.stats; fin.gT = w.gT; fin.losses = a->losses; fin.coefs = w.coefs;
   fin.loss_total = a->loss_total; fin.ticket = w.ticket;
   fin.noise_counter = (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr;

@@ -569,7 +569,7 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
     temporal = bool(getattr(opt, "temporal", False))
     if temporal and image_synthesis is None:
         raise L.MalError("loss_step_multiscale with opt.temporal needs image_synthesis(inputs, outputs, scale) -> has_ins")
-    unsupported = [k for k in ("distil", "v1_multiscale", "ensemble") if getattr(opt, k, False)]
+    unsupported = [k for k in ("distil", "v1_multiscale") if getattr(opt, k, False)]
     if getattr(opt, "no_ssim", False) and getattr(opt, "temporal", False):
         unsupported.append("no_ssim with temporal")
     if unsupported or sclm >= L.MS_MAX_SCALES or list(opt.frame_ids) != [0, -1, 1]:
@@ -601,7 +601,8 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
     cfg = (opt.min_depth, opt.max_depth, sclm, aug_is_mask, philox, bool(want_maps),
            (image_synthesis, inputs, mono_outputs) if temporal else None, bool(getattr(opt, "no_ssim", False)),
            (L.STEP_NO_MOTION_MASK if getattr(opt, "disable_motion_masking", False) else 0) |
-           (L.STEP_NO_AUG if getattr(opt, "no_matching_augmentation", False) else 0))
+           (L.STEP_NO_AUG if getattr(opt, "no_matching_augmentation", False) else 0) |
+           (L.STEP_ENSEMBLE if getattr(opt, "ensemble", False) else 0))
     leaves = [mono_outputs[("disp", s)] for s in range(sclm + 1)] + [outputs[("disp", s)] for s in range(sclm + 1)] + \
              [aa[-1], tr[-1], aa[1], tr[1]]
     res = MultiScaleLossFn.apply(consts, cfg, *leaves)
@@ -622,6 +623,8 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
         losses["consistency_loss/%d" % s] = v[(4 + s) * 4 + 1]
         losses["main/reproj_loss/%d" % s], losses["main/loss/%d" % s] = v[(4 + s) * 4], v[(4 + s) * 4 + 3]
         losses["smooth_loss/multi/%d" % s], mono_losses["smooth_loss/%d" % s] = v[(4 + s) * 4 + 2], v[s * 4 + 2]
+        if getattr(opt, "ensemble", False):
+            losses["ensemble_loss/%d" % s] = v[44 + s]
         mono_losses["reproj_loss/%d" % s], mono_losses["loss/%d" % s] = v[s * 4], v[s * 4 + 3]
     losses["main/loss"] = v[33]
     return losses, mono_losses

@@ -253,12 +253,14 @@ def test_no_ssim_against_the_oracle(case):
 
 @pytest.mark.parametrize("kw_extra", [{"disable_automasking": True}, {"disable_motion_masking": True},
                                       {"no_matching_augmentation": True},
-                                      {"disable_motion_masking": True, "no_matching_augmentation": True, "disable_automasking": True}],
-                         ids=["no_automask_noise", "no_motion_mask", "no_augmentation", "all_three"])
+                                      {"disable_motion_masking": True, "no_matching_augmentation": True, "disable_automasking": True},
+                                      {"ensemble": True}],
+                         ids=["no_automask_noise", "no_motion_mask", "no_augmentation", "all_three", "ensemble"])
 def test_mask_switches_against_the_oracle(kw_extra):
     """--disable_automasking (upstream still compares against the identity term, trainer.py:1296-1311: only the noise goes),
     --disable_motion_masking, --no_matching_augmentation (:1321-1326: the student's weight leaves the consistency mask / the
-    (1 - augmentation) factor out) on the four-scale path"""
+    (1 - augmentation) factor out), --ensemble (:1346-1351: + mean |(mono + multi)/2 - multi| * mask for the student) on the
+    four-scale path"""
     B, H, W, sclm = 3, 40, 72, 2
     batch = make_batch(B, H, W, seed=85)
     batch["augmentation_mask"][0] = 1.0  # one augmented sample, so that the switch shows
@@ -274,7 +276,7 @@ def test_mask_switches_against_the_oracle(kw_extra):
     for k, v in rt.items():
         assert abs(float(mono_losses[k]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + 12.0 / N, ("teacher", k, float(mono_losses[k]), float(v))
     for k, v in rs.items():
-        name = k if k.startswith("consistency") else "main/" + k
+        name = k if k.startswith(("consistency", "ensemble")) else "main/" + k
         assert abs(float(losses[name]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + 4.0 / N, ("student", k, float(losses[name]), float(v))
     assert (ho["consistency_mask"].cpu().numpy() != oo["consistency_mask"].numpy()).mean() <= 1e-3  # x matching mask, either way
     for k in hl:
@@ -376,9 +378,6 @@ def test_unsupported_configurations_are_refused():
     hi, hm, ho, hl = _build(batch, DEV, 1)
     with pytest.raises(_lib.MalError):
         step.loss_step_multiscale(trainer.default_options(height=32, width=64, batch_size=2, sclm=1, distil=True), hi, hm, ho)
-    with pytest.raises(_lib.MalError):
-        step.loss_step_multiscale(trainer.default_options(height=32, width=64, batch_size=2, sclm=1, distil=False, ensemble=True),
-                                  hi, hm, ho)
     with pytest.raises(_lib.MalError):
         step.loss_step_multiscale(trainer.default_options(height=32, width=64, batch_size=2, sclm=1, distil=False, v1_multiscale=True),
                                   hi, hm, ho)
