@@ -573,6 +573,8 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
     if getattr(opt, "no_ssim", False) and getattr(opt, "temporal", False):
         unsupported.append("no_ssim with temporal")
     if unsupported or sclm >= L.MS_MAX_SCALES or list(opt.frame_ids) != [0, -1, 1]:
+        # (--v1_multiscale with sclm > 0 cannot run upstream for the student either: its (B,1,H>>s,W>>s) mask is multiplied
+        # by the full-resolution consistency mask, manydepth/trainer.py:1322)
         raise L.MalError("loss_step_multiscale covers the non-distil sclm <= 3 configuration with frames [0,-1,1]; %s: use "
                          "MALLossPath.compute_batch_losses" % (", ".join(unsupported) or "this configuration"))
     color0 = inputs[("color", 0, 0)]
