@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void ms_final_kernel(MsFinal p) {
     p.losses[36 + s] = s < S ? s_rep[S + s] + s_rep[s] : 0.f;
     p.losses[40 + s] = s < S ? s_loss[S + s] + s_loss[s] : 0.f;
   }
+  static_assert(kMsLossSlots == 44 + kMsS, "losses[]: the ensemble terms are its last kMsS slots");
   for (int s = 0; s < kMsS; ++s) p.losses[44 + s] = s < S ? s_ens[S + s] : 0.f;
   if (p.loss_total) *p.loss_total = p.losses[34];
 }
