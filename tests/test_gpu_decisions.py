@@ -233,6 +233,28 @@ def test_temporal_hints_small_and_ragged_shapes(B, H, W, kw):
     assert all(v[0] <= 1e-4 for v in report.values()), report
 
 
+def test_random_shapes_sweep():
+    """a fixed-seed sweep over odd sizes (1-3 samples, 6-60 rows, 6-200 columns: zero to three strip boundaries, one to five row
+    segments, single-strip images narrower than a wavefront) and the step's configurations, decision-exact against the oracle:
+    indexing at sizes nobody chose by hand"""
+    import random
+    from mal_amd.synthetic import make_batch
+    rng = random.Random(20240607)
+    kws = [{}, {"temporal": True}, {"temporal": True, "main_temporal": True}, {"no_ens": True}, {"main_temporal": True},
+           {"no_ens": True, "dual_distil": True}]
+    for i in range(12):
+        B, H, W = rng.randint(1, 3), rng.randint(6, 60), rng.randint(6, 200)
+        kw = kws[i % len(kws)]
+        b = make_batch(B, H, W, seed=900 + i, with_syn=bool(kw.get("temporal") or kw.get("main_temporal")))
+        g = torch.Generator().manual_seed(300 + i)
+        n0, n1 = torch.randn(B, 1, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
+        try:
+            counts, report = check_step_decision_exact(b, kw, n0, n1)
+        except AssertionError as ex:
+            raise AssertionError("case %d: B=%d H=%d W=%d %s: %s" % (i, B, H, W, kw, ex)) from ex
+        assert all(v[0] <= 1e-4 for v in report.values()), (i, B, H, W, kw, report)
+
+
 def test_main_temporal_at_baseline_size():
     """--temporal --main_temporal --distil at B=12 192x640 with the real producer (N2's kernels, sparse syn buffers, region maps)
     on both passes"""
