@@ -289,17 +289,14 @@ def test_mask_switches_against_the_oracle(kw_extra):
             assert _l2rel(gq, r) <= 3e-2, (k, _l2rel(gq, r))
 
 
-def test_temporal_equals_operator_route():
-    """--temporal with sclm > 0 through the three library calls vs the operator-level route (MALLossPath: materialising warp,
-    producer, materialised-candidate kernels, per scale): same kernels underneath, same numbers"""
+def _compare_with_operator_route(B, H, W, sclm, temporal, seed):
     from mal_amd import config, layers, trainer
     from mal_amd.synthetic import fake_image_synthesis
-    B, H, W, sclm = 3, 40, 72, 2
-    batch = make_batch(B, H, W, seed=79, with_syn=True)
+    batch = make_batch(B, H, W, seed=seed, with_syn=temporal)
     g = torch.Generator().manual_seed(12)
     nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
-    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False, temporal=True)
-    synth = fake_image_synthesis(batch["syn_rects"])
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False, temporal=temporal)
+    synth = fake_image_synthesis(batch["syn_rects"]) if temporal else None
     hi, hm, ho, hl = _build(batch, DEV, sclm)
     ho.pop("lowest_cost")
     losses, mono_losses = _hip_step(hi, hm, ho, hl, kw, nt, synth=synth)
@@ -326,12 +323,31 @@ def test_temporal_equals_operator_route():
     (lt["loss"] + ls["loss"]).backward()
     torch.cuda.synchronize()
     total = float((lt["loss"] + ls["loss"]).detach())
-    assert abs(float(losses["loss"].detach()) - total) <= 2e-6 * abs(total), (float(losses["loss"].detach()), total)
+    tag = (B, H, W, sclm, temporal)
+    assert abs(float(losses["loss"].detach()) - total) <= 2e-6 * abs(total), (tag, float(losses["loss"].detach()), total)
     for k, v in lt.items():
-        assert abs(float(mono_losses[k]) - float(v.detach())) <= 2e-6 * max(abs(float(v.detach())), 1e-3), k
+        assert abs(float(mono_losses[k]) - float(v.detach())) <= 2e-6 * max(abs(float(v.detach())), 1e-3), (tag, k)
     for k in hl:
         a_, b_ = hl[k].grad.cpu().numpy(), leaves[k].grad.cpu().numpy().reshape(hl[k].grad.shape)
-        assert np.abs(a_ - b_).max() <= 2e-5 * np.abs(b_).max(), (k, np.abs(a_ - b_).max() / np.abs(b_).max())
+        assert np.abs(a_ - b_).max() <= 2e-5 * np.abs(b_).max(), (tag, k, np.abs(a_ - b_).max() / np.abs(b_).max())
+
+
+def test_temporal_equals_operator_route():
+    """--temporal with sclm > 0 through the three library calls vs the operator-level route (MALLossPath: materialising warp,
+    producer, materialised-candidate kernels, per scale): same kernels underneath, same numbers"""
+    _compare_with_operator_route(3, 40, 72, 2, True, 79)
+
+
+def test_random_shapes_sweep_against_the_operator_route():
+    """a fixed-seed sweep over odd sizes (multiples of 2**sclm) with and without the temporal hint: the one-call path and the
+    operator route run the same marching kernels, so they must agree to rounding at sizes nobody chose by hand"""
+    import random
+    rng = random.Random(7311)
+    for i in range(8):
+        sclm = rng.randint(1, 3)
+        f = 2 ** sclm
+        B, H, W = rng.randint(1, 3), f * rng.randint(max(2, 16 // f), 64 // f), f * rng.randint(max(2, 16 // f), 208 // f)
+        _compare_with_operator_route(B, H, W, sclm, bool(i % 2), 700 + i)
 
 
 def test_temporal_last_scale_decides_for_all():
