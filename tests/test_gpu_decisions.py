@@ -590,6 +590,54 @@ def test_dualrefine_one_call_step_with_upstream_default_scales():
         assert np.abs(res["step"][1][k] - g).max() <= 2e-5 * max(sc, 1e-12), (k, np.abs(res["step"][1][k] - g).max() / max(sc, 1e-12))
 
 
+def test_dualrefine_scales_sweep_against_the_operator_route():
+    """fixed-seed sweep over odd sizes (multiples of 8) and scale lists: the per-scale calls of loss_step against
+    generate_images_pred + compute_losses (same kernels underneath: losses at 2e-6, gradients at 2e-5 of their scale)"""
+    import random
+    from mal_amd import dualrefine, layers
+    from mal_amd.synthetic import make_batch
+    rng = random.Random(4099)
+    for i, scales in enumerate(([0, 1, 2, 3], [0, 2], [0, 3], [2, 3], [0, 1, 2, 3])):
+        B, H, W = rng.randint(1, 3), 8 * rng.randint(2, 8), 8 * rng.randint(2, 26)
+        batch = make_batch(B, H, W, seed=500 + i)
+        units = [(s_, it) for s_ in scales if s_ != 1 for it in range(2 if s_ in (0, 1, 2) else 1)]
+        torch.manual_seed(40 + i)
+        noises = [torch.randn(B, 1, H, W).to("cuda:0") for _ in units]
+        res = {}
+        for route in ("ops", "step"):
+            inputs, outputs, gl = _dr_build(batch, "cuda:0", layers.transformation_from_parameters)
+            if 0 not in scales:
+                for k in ("disp_teacher", "disp_student"):
+                    gl.pop(k)
+                outputs.pop(("disp", 0, 0)), outputs.pop(("disp", 0, 1))
+            for s_ in scales:
+                if s_ == 0:
+                    continue
+                inputs[("color", 0, s_)] = torch.nn.functional.avg_pool2d(batch["color0"], 2 ** s_).to("cuda:0")
+                for it, name in ((0, "disp_teacher"), (1, "disp_student")):
+                    if (s_, it) in units:
+                        leaf = torch.nn.functional.avg_pool2d(batch[name], 2 ** s_).to("cuda:0").clone().requires_grad_(True)
+                        gl["disp_s%d_it%d" % (s_, it)] = leaf
+                        outputs[("disp", s_, it)] = leaf
+            lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=B, n_losses=1, scales=scales), fuse=True)
+            if route == "ops":
+                lp.generate_images_pred(inputs, outputs)
+                got = lp.compute_losses(inputs, outputs, noises=noises)
+            else:
+                got = lp.loss_step(inputs, outputs, noises=noises)
+            got["loss"].backward()
+            torch.cuda.synchronize()
+            res[route] = ({k: float(v.detach()) for k, v in got.items()},
+                          {k: (t.grad if t.grad is not None else torch.zeros_like(t)).cpu().numpy() for k, t in gl.items()})
+        tag = (B, H, W, scales)
+        assert set(res["ops"][0]) == set(res["step"][0]), (tag, sorted(res["ops"][0]), sorted(res["step"][0]))
+        for k, v in res["ops"][0].items():
+            assert abs(res["step"][0][k] - v) <= 2e-6 * max(abs(v), 1e-3), (tag, k, res["step"][0][k], v)
+        for k, g in res["ops"][1].items():
+            sc = np.abs(g).max()
+            assert np.abs(res["step"][1][k] - g).max() <= 2e-5 * max(sc, 1e-12), (tag, k, np.abs(res["step"][1][k] - g).max() / max(sc, 1e-12))
+
+
 def test_dualrefine_step_in_kernel_noise_equals_the_same_noise_handed_in():
     """MAL_DR_NOISE_PHILOX: iteration it's map is mal_tiebreak_noise(seed, step * MAL_DR_MAX_ITERS + it); the step with the
     maps drawn in its first launch and the step handed those maps agree to the bit, and the device counter advances once."""
