@@ -1198,6 +1198,10 @@ __global__ __launch_bounds__(64, 2) void march_student_kernel(MarchParams p_kern
 __global__ __launch_bounds__(64, 2) void march_student_noepi_kernel(MarchParams p_kernarg) {
   march_body<true, false, false, false, false, false, false, kSpecStudentNoEpi>();
 }
+// ... and the student's TEMPORAL gradient sweep of the --main_temporal step: no mask operand at all (forced_w is the whole weight)
+__global__ __launch_bounds__(64, 2) void march_student_temporal_kernel(MarchParams p_kernarg) {
+  march_body<true, false, false, false, false, true, false, kSpecTeacher>();
+}
 // DualRefine's passes of the deq iterations > 0: teacher-style pass (automask, pose gradients) with the consistency epilogue
 __global__ __launch_bounds__(64, 2) void march_refine_kernel(MarchParams p_kernarg) {
   march_body<true, true, true, true, false, false, false, kSpecRefine>();
@@ -1932,7 +1936,8 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
     if (p.dbg) {
       if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
       hipLaunchKernelGGL((march_kernel<true, false, false, false, true, true>), grid, block, 0, st, p);
-    } else hipLaunchKernelGGL((march_kernel<true, false, false, false, false, true>), grid, block, 0, st, p);
+    } else if (lean0 && conv_a && !p.disp2) hipLaunchKernelGGL(march_student_temporal_kernel, grid, block, 0, st, p);
+    else hipLaunchKernelGGL((march_kernel<true, false, false, false, false, true>), grid, block, 0, st, p);
   } else if (p.forced_w) {  // TEMPORAL teacher pass
     if (!(grad && pose && automask && !epi) || !p.forced_arg || !p.g_color[0] || !p.g_color[1]) return MAL_EINVAL;
     if (lean && !p.dbg) hipLaunchKernelGGL(march_teacher_kernel<true>, grid, block, 0, st, p);
