@@ -270,7 +270,8 @@ enum {
                                hint as well -- its own warped images go through the producer and r(syn_f, target) joins the
                                student's per-pixel min (weight: consistency x matching x (1 - augmentation), unchanged).  With
                                or without MAL_STEP_TEMPORAL; the same three calls, the exchange through the *_s_* members:
-                                 mal_loss_step_warp  also writes warp_s_m1 / warp_s_p1 (student's disparity, the teacher's poses)
+                                 mal_loss_step_warp  also writes warp_s_m1 / warp_s_p1 (student's disparity, the teacher's poses);
+                                                     mal_loss_step_student_ready before the student's producer reads them
                                  mal_loss_step_fwd   syn_s_* in, g_syn_s_* out (unnormalised, as g_syn_*)
                                  mal_loss_step_bwd   g_warp_s_* in: the student's gradient sweep takes the four-way decisions
                                                      of _fwd and adds what arrives through syn */
@@ -351,6 +352,10 @@ int mal_loss_step_warp(const mal_step_args* args);
  * pass that _warp forked onto the library's side stream back into args->stream (no-op when nothing is pending), so the
  * next step cannot overwrite buffers that pass still reads and a stream capture does not end with unjoined work. */
 int mal_loss_step_abort(const mal_step_args* args);
+/* MAL_STEP_MAIN_TEMPORAL: call after mal_loss_step_warp (and after the teacher's producer, with MAL_STEP_TEMPORAL) and BEFORE the
+ * student's producer reads warp_s_*: with both hints the student's forward pass runs on the library's side stream beside the
+ * teacher's producer chain, and args->stream waits for it here (a no-op when the pass ran on args->stream itself). */
+int mal_loss_step_student_ready(const mal_step_args* args);
 /* Measurement hook (bench.py's `roofline` block): enqueues `launches` (1..4096) back-to-back launches of the teacher's
  * pass -- the fused warp + SSIM + L1 + min + automask forward+backward sweep, manydepth/loss_utils.py:57-113 with
  * trainer.py:1078-1125 -- exactly as mal_loss_step_fwd enqueues it for a step WITHOUT MAL_STEP_TEMPORAL (same parameter

@@ -706,7 +706,7 @@ namespace mal { int g_temporal_spec = 0; }  // settable in -DMAL_EXPERIMENTS bui
 // option "side_priority": 1 = the side stream is created with the device's LOWEST priority.  Measured: every kernel of the
 // replayed step slows down -- 0.566 ms per step against 0.323 (profiles/r04_step_timelines.txt) --, so the default stays 0.
 namespace mal { int g_side_priority = 0; }
-struct SideStream { hipStream_t caller; hipStream_t s; hipEvent_t fork, join; bool ok, init, pending; int dev; };
+struct SideStream { hipStream_t caller; hipStream_t s; hipEvent_t fork, join, mid; bool ok, init, pending; int dev; };
 static SideStream* side_stream(hipStream_t caller) {
   constexpr int kSlots = 64;
   static SideStream all[kSlots] = {};
@@ -739,7 +739,8 @@ static SideStream* side_stream(hipStream_t caller) {
       slot->ok = (g_side_priority ? hipStreamCreateWithPriority(&slot->s, hipStreamNonBlocking, least)
                                   : hipStreamCreateWithFlags(&slot->s, hipStreamNonBlocking)) == hipSuccess &&
                  hipEventCreateWithFlags(&slot->fork, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&slot->join, hipEventDisableTiming) == hipSuccess;
+                 hipEventCreateWithFlags(&slot->join, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&slot->mid, hipEventDisableTiming) == hipSuccess;
       (void)hipGetLastError();
     }
   if (!slot) slot = first_of_dev;  // table full: share this device's first slot
@@ -767,17 +768,26 @@ static bool student_forked(const mal_step_args* a) {
 static bool ensemble_forked(const mal_step_args* a) {
   return side_forked(a) && !(a->flags & MAL_STEP_NO_ENS);
 }
+// --temporal --main_temporal: the student's forward pass in front of ITS producer runs on the side stream, beside the teacher's
+// producer chain (small, latency-bound kernels); mal_loss_step_student_ready orders the student's producer behind it
+static bool student_warp_forked(const mal_step_args* a) {
+  return side_forked(a) && g_step_overlap == 1 && (a->flags & MAL_STEP_TEMPORAL) && (a->flags & MAL_STEP_MAIN_TEMPORAL);
+}
 
 static int fork_ensemble(const mal_step_args* a, const StepWs& w, hipStream_t st) {
   SideStream* ss = side_stream(st);
   if (!ss) return MAL_ELAUNCH;
   if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return MAL_ELAUNCH;
   int rc = MAL_OK;
+  if (student_warp_forked(a)) {
+    rc = launch_student_warp(a, w, ss->s);
+    if (hipEventRecord(ss->mid, ss->s) != hipSuccess && !rc) rc = MAL_ELAUNCH;
+  }
   // option "side_order" 1: the student's pass first, the (lighter, forward-only) ensemble pass behind it -- the one that ends up
   // beside the fused sweep; 0: ensemble first
   if (g_side_order && student_forked(a))
     rc = launch_student(a, w, nullptr, nullptr, a->multi_reproj ? a->multi_reproj : w.multi_reproj, false, ss->s, nullptr);
-  if (!rc && !(a->flags & MAL_STEP_NO_ENS)) rc = launch_ensemble(a, w, a->ens_reproj ? a->ens_reproj : w.ens_reproj, ss->s);
+  if (!rc && ensemble_forked(a)) rc = launch_ensemble(a, w, a->ens_reproj ? a->ens_reproj : w.ens_reproj, ss->s);
   if (!rc && !g_side_order && student_forked(a))
     rc = launch_student(a, w, nullptr, nullptr, a->multi_reproj ? a->multi_reproj : w.multi_reproj, false, ss->s, nullptr);
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return rc ? rc : MAL_ELAUNCH;
@@ -791,6 +801,17 @@ static int fork_ensemble(const mal_step_args* a, const StepWs& w, hipStream_t st
 extern "C" int mal_loss_step_abort(const mal_step_args* a) {
   if (!a) return MAL_EINVAL;
   return join_side((hipStream_t)a->stream);
+}
+
+// MAL_STEP_MAIN_TEMPORAL: call between mal_loss_step_warp and the STUDENT's producer (after the teacher's, if any): the student's
+// warped images (warp_s_*) may have been written on the library's side stream; args->stream waits for them here.  A no-op when
+// they were written on args->stream itself.
+extern "C" int mal_loss_step_student_ready(const mal_step_args* a) {
+  if (!a) return MAL_EINVAL;
+  if (!(a->flags & MAL_STEP_MAIN_TEMPORAL) || !student_warp_forked(a)) return MAL_OK;
+  SideStream* ss = side_stream((hipStream_t)a->stream);
+  if (!ss) return MAL_ELAUNCH;
+  return hipStreamWaitEvent((hipStream_t)a->stream, ss->mid, 0) == hipSuccess ? MAL_OK : MAL_ELAUNCH;
 }
 
 // MAL_STEP_TEMPORAL, first call: the first sweep and the teacher's warped images (forward only: the per-pixel min over
@@ -833,11 +854,11 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
   rc = march_launch(p, flags, st);
   if (rc) return rc;
   }
-  if (main_t) {
+  if (main_t && !student_warp_forked(a)) {
     rc = launch_student_warp(a, w, st);
     if (rc) return rc;
   }
-  if ((ensemble_forked(a) || student_forked(a)) && g_step_overlap == 1) {
+  if ((ensemble_forked(a) || student_forked(a) || student_warp_forked(a)) && g_step_overlap == 1) {
     rc = fork_ensemble(a, w, st);
     if (rc) return rc;
   }
@@ -912,7 +933,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   const bool stu_deferred = stu_forked || main_t;  // the student's marching pass has run: its epilogue is a launch of its own
   EpiParams epi = {};
   int n_epi = 0;
-  if (ens_forked || stu_forked) {
+  if (ens_forked || stu_forked || (hinted && student_warp_forked(a))) {
     rc = join_side(st, true);
     if (rc) return rc;
   }

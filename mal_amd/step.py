@@ -306,6 +306,8 @@ class TemporalLossStepFn(Function):
         L.check(lib.mal_loss_step_warp(C.byref(a)), "mal_loss_step_warp")
         try:  # the producer raised, or left something unusable: join what mal_loss_step_warp forked before the buffers are reused
             for h in hints:
+                if h.student:  # its warped images may have been written on the library's side stream
+                    L.check(lib.mal_loss_step_student_ready(C.byref(a)), "mal_loss_step_student_ready")
                 h.produce(synth, inputs)
         except BaseException:
             lib.mal_loss_step_abort(C.byref(a))
