@@ -438,6 +438,9 @@ typedef struct mal_ms_args {
 } mal_ms_args;
 size_t mal_ms_workspace_bytes(int B, int H, int W, int sclm);
 int mal_loss_multiscale_warp(const mal_ms_args* args); /* MAL_STEP_TEMPORAL only */
+/* a MAL_STEP_TEMPORAL step whose producer failed between _warp and _fwd: joins the library's side stream (the students' passes
+ * run there beside the producers) back into args->stream; a no-op when nothing is pending */
+int mal_loss_multiscale_abort(const mal_ms_args* args);
 int mal_loss_multiscale_fwd(const mal_ms_args* args);
 int mal_loss_multiscale_bwd(const mal_ms_args* args);
 /* ---- DualRefine's loss loops over the deq iterations of scale 0 in one call per direction ------------------------------

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mal_tiebreak_noise": (i32, [C.c_uint64, C.c_uint64, i32, i32, i32, c_fp, vp]),
     "mal_ms_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mal_loss_multiscale_warp": (i32, [vp]),
+    "mal_loss_multiscale_abort": (i32, [vp]),
     "mal_loss_multiscale_fwd": (i32, [vp]),
     "mal_loss_multiscale_bwd": (i32, [vp]),
     "mal_dr_workspace_bytes": (sz, [i32, i32, i32, i32]),

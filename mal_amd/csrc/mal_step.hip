@@ -755,6 +755,24 @@ static int join_side(hipStream_t st, bool always = false) {
   ss->pending = false;
   return hipStreamWaitEvent(st, ss->join, 0) == hipSuccess ? MAL_OK : MAL_ELAUNCH;
 }
+namespace mal {
+// the same side stream for the other whole-step lists (mal_step_ms.hip): side_begin forks it off `st` (nullptr: no side stream
+// here -- the caller keeps everything on `st`), side_end records the join and marks it pending, side_wait joins it back
+hipStream_t side_begin(hipStream_t st) {
+  if (!g_step_overlap) return nullptr;
+  SideStream* ss = side_stream(st);
+  if (!ss) return nullptr;
+  if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return ss->s;
+}
+int side_end(hipStream_t st) {
+  SideStream* ss = side_stream(st);
+  if (!ss || hipEventRecord(ss->join, ss->s) != hipSuccess) return MAL_ELAUNCH;
+  ss->pending = true;
+  return MAL_OK;
+}
+int side_wait(hipStream_t st, bool always) { return join_side(st, always); }
+}
 // what is forked beside the producer: the ensemble pass (unless --no_ens) and, with option "student_overlap" (default), the
 // student's marching pass without its epilogue
 namespace mal { int g_student_overlap = 1; int g_side_order = 0; }  // side_order 1 (student first) measured slower: 0.3265 vs 0.3200 ms -- the producer's small kernels starve beside a pass that holds every wave slot and all of the LDS

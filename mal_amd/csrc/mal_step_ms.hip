@@ -30,6 +30,10 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
                            float* g_region1, unsigned* order, unsigned* order_count, const float* orig0, const float* orig1,
                            size_t orig_stride, int target_texels, int weight_given);
 int smooth_march_batch_tasks(int H, int W);
+// mal_step.hip: the library's side stream of the caller's stream (fork / join through events: capturable)
+hipStream_t side_begin(hipStream_t st);
+int side_end(hipStream_t st);
+int side_wait(hipStream_t st, bool always);
 int tiebreak_noise_launch(unsigned long long seed, unsigned long long step, const unsigned long long* counter, unsigned mult,
                           int n, int B, int H, int W, float* const* out, hipStream_t st);
 
@@ -550,7 +554,8 @@ static void ms_fold_launch(const MsWs& w, int B, int H, int W, int S, bool teach
 }
 
 // everything that does not wait for a temporal-hint producer
-static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool temporal, int* per_sample_sm /*[S]*/) {
+static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool temporal, int* per_sample_sm /*[S]*/, int* forked) {
+  *forked = 0;
   const int B = a->B, H = a->H, W = a->W, S = a->sclm + 1;
   int rc;
   // 1. first sweep: identity term (no noise: every scale adds its own), texel packing, poses, camera block
@@ -589,59 +594,74 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
   if (a->flags & MAL_STEP_ENSEMBLE) {
     if (hipMemsetD32Async((hipDeviceptr_t)w.neg_inf, (int)0xff800000u, (size_t)B * H * W, st) != hipSuccess) return MAL_ELAUNCH;
   }
-  for (int s = 0; s < S; ++s) {
-    const float* disp_t = s ? w.up[0][s] : a->disp_teacher[0];
-    const float* disp_s = s ? w.up[1][s] : a->disp_student[0];
-    {  // teacher: automask against the identity term + this scale's noise (trainer.py:1296-1311)
-      MarchParams p = ms_teacher_params(a, w, s);
-      p.ident = w.ident; p.noise = ms_noise(a, w, s);
-      if (temporal) {
-        // forward only, in front of the producer: the warped images out; min over the two warped candidates, its winner, the
-        // automask weight and the sums stay for the fused sweep of mal_loss_multiscale_fwd (second copies: what it re-decides)
-        p.min_reproj = w.rp_warp[s]; p.argmin_out = w.arg_warp[s];
-        p.min_reproj2 = w.rp4[s]; p.argmin_out2 = w.arg_t[s]; p.weight_out = w.w_t[s];
-        p.color_out[0] = a->warp_m1[s]; p.color_out[1] = a->warp_p1[s]; p.color_out_stride = a->warp_sample_stride;
-        rc = march_launch(p, MAL_F_AUTOMASK | packed, st);
-      } else {
-        p.g_reproj = w.G_r[0][s]; p.bnd = g_march_halo1 ? w.bnd[0][s] : nullptr;
-        rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
-      }
+  auto teacher = [&](int s) -> int {  // automask against the identity term + this scale's noise (trainer.py:1296-1311)
+    MarchParams p = ms_teacher_params(a, w, s);
+    p.ident = w.ident; p.noise = ms_noise(a, w, s);
+    if (temporal) {
+      // forward only, in front of the producer: the warped images out; min over the two warped candidates, its winner, the
+      // automask weight and the sums stay for the fused sweep of mal_loss_multiscale_fwd (second copies: what it re-decides)
+      p.min_reproj = w.rp_warp[s]; p.argmin_out = w.arg_warp[s];
+      p.min_reproj2 = w.rp4[s]; p.argmin_out2 = w.arg_t[s]; p.weight_out = w.w_t[s];
+      p.color_out[0] = a->warp_m1[s]; p.color_out[1] = a->warp_p1[s]; p.color_out_stride = a->warp_sample_stride;
+      return march_launch(p, MAL_F_AUTOMASK | packed, st);
+    }
+    p.g_reproj = w.G_r[0][s]; p.bnd = g_march_halo1 ? w.bnd[0][s] : nullptr;
+    return march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
+  };
+  auto student = [&](int s, hipStream_t q) -> int {
+    // mask = consistency (x matching, formed at scale 0 from the teacher's scale-0 depth, trainer.py:592-593)
+    // x (1 - augmentation); consistency term against the teacher's depth of the same scale (:1330-1336)
+    MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
+    p.disp = s ? w.up[1][s] : a->disp_student[0]; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
+    p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+    if (!(a->flags & MAL_STEP_NO_AUG)) { p.sample_scale = a->augmentation_keep; p.sample_scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0; }
+    p.mono_disp = s ? w.up[0][s] : a->disp_teacher[0];
+    if (a->flags & MAL_STEP_NO_MOTION_MASK) {
+      // the weight is 1 (x augmentation): no mask operand at all
+    } else if (s == 0) {
+      p.ext_mask = a->consistency_mask; p.lowest_cost = a->lowest_cost;
+      if (a->lowest_cost) p.cmask_out = a->consistency_mask_out ? a->consistency_mask_out : w.cmask;
+    } else {
+      p.ext_mask = a->lowest_cost ? (a->consistency_mask_out ? a->consistency_mask_out : w.cmask) : a->consistency_mask;
+    }
+    p.mono_reproj = w.ident;  // the distillation selection is not part of this loss: any map serves, its term has weight 0
+    p.g_reproj = w.G_r[1][s]; p.g_cons = w.G_c[s]; p.g_distil = nullptr; p.bnd = g_march_halo1 ? w.bnd[1][s] : nullptr;
+    p.merge_cons = merge_cons; p.merge_distil = 0.f;
+    if (a->flags & MAL_STEP_ENSEMBLE) {
+      // --ensemble (trainer.py:1346-1351): |(mono + multi)/2 - multi| * mask IS the distillation term with the ensemble winning
+      // everywhere (index 1: target (mono + multi)/2, mono detached, weight = the mask), same 1/N as the consistency term
+      p.ens_reproj = w.neg_inf; p.merge_distil = merge_cons;
+    }
+    p.block_sums = w.bs[1][s]; p.block_gP = w.bgP[s];
+    p.cam = w.cam; p.cam_ready = 1;
+    p.no_ssim = (a->flags & MAL_STEP_NO_SSIM) ? 1 : 0;
+    return march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, q);
+  };
+  // Without the hint the two networks' passes of a scale stay next to each other.  With it: the teachers' forward passes first;
+  // everything else that does not wait for a producer -- the students' passes, their boundary rows, the smoothness sweeps --
+  // goes onto the library's side stream, beside the producers' small kernels that the host enqueues on `st` between this call
+  // and mal_loss_multiscale_fwd (which joins)
+  hipStream_t st2 = st;
+  if (!temporal) {
+    for (int s = 0; s < S; ++s) {
+      rc = teacher(s);
+      if (!rc) rc = student(s, st);
       if (rc) return rc;
     }
-    {  // student: mask = consistency (x matching, formed at scale 0 from the teacher's scale-0 depth, trainer.py:592-593)
-       // x (1 - augmentation); consistency term against the teacher's depth of the same scale (:1330-1336)
-      MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 0);
-      p.disp = disp_s; p.K = a->K; p.invK = a->inv_K; p.T[0] = w.T[0]; p.T[1] = w.T[1];
-      p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
-      if (!(a->flags & MAL_STEP_NO_AUG)) { p.sample_scale = a->augmentation_keep; p.sample_scale_is_mask = (a->flags & MAL_STEP_AUG_MASK) ? 1 : 0; }
-      p.mono_disp = disp_t;
-      if (a->flags & MAL_STEP_NO_MOTION_MASK) {
-        // the weight is 1 (x augmentation): no mask operand at all
-      } else if (s == 0) {
-        p.ext_mask = a->consistency_mask; p.lowest_cost = a->lowest_cost;
-        if (a->lowest_cost) p.cmask_out = a->consistency_mask_out ? a->consistency_mask_out : w.cmask;
-      } else {
-        p.ext_mask = a->lowest_cost ? (a->consistency_mask_out ? a->consistency_mask_out : w.cmask) : a->consistency_mask;
-      }
-      p.mono_reproj = w.ident;  // the distillation selection is not part of this loss: any map serves, its term has weight 0
-      p.g_reproj = w.G_r[1][s]; p.g_cons = w.G_c[s]; p.g_distil = nullptr; p.bnd = g_march_halo1 ? w.bnd[1][s] : nullptr;
-      p.merge_cons = merge_cons; p.merge_distil = 0.f;
-      if (a->flags & MAL_STEP_ENSEMBLE) {
-        // --ensemble (trainer.py:1346-1351): |(mono + multi)/2 - multi| * mask IS the distillation term with the ensemble winning
-        // everywhere (index 1: target (mono + multi)/2, mono detached, weight = the mask), same 1/N as the consistency term
-        p.ens_reproj = w.neg_inf; p.merge_distil = merge_cons;
-      }
-      p.block_sums = w.bs[1][s]; p.block_gP = w.bgP[s];
-      p.cam = w.cam; p.cam_ready = 1;
-      p.no_ssim = (a->flags & MAL_STEP_NO_SSIM) ? 1 : 0;
-      rc = march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, st);
+  } else {
+    for (int s = 0; s < S; ++s) {
+      rc = teacher(s);
       if (rc) return rc;
     }
+    hipStream_t side = side_begin(st);
+    if (side) { st2 = side; *forked = 1; }
+    for (int s = 0; s < S && !rc; ++s) rc = student(s, st2);
+    if (rc) { if (*forked) (void)side_end(st); return rc; }
   }
   if (g_march_halo1) {  // one-row halo of the gradient passes: each boundary row's missing window row, in ONE launch
-    ms_fold_launch(w, B, H, W, S, !temporal, true, st);
+    ms_fold_launch(w, B, H, W, S, !temporal, true, st2);
     rc = launch_status();
-    if (rc) return rc;
+    if (rc) { if (*forked) (void)side_end(st); return rc; }
   }
   {  // smoothness of both disparity maps at every scale's own size against the target at that size (:1469-1471): ONE launch
     const float *sd[2 * kMsS], *si[2 * kMsS];
@@ -655,10 +675,11 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
         si[k] = (s == 0 && !a->color0_s[0]) ? a->color0 : a->color0_s[s];
         sg[k] = w.gn[n][s]; sp[k] = w.sm[n][s]; sh[k] = H >> s; sw[k] = W >> s;
       }
-    rc = smooth_march_sweep_batch(2 * S, sd, si, B, sh, sw, sg, sp, st, per);
-    if (rc) return rc;
+    rc = smooth_march_sweep_batch(2 * S, sd, si, B, sh, sw, sg, sp, st2, per);
+    if (rc) { if (*forked) (void)side_end(st); return rc; }
     for (int s = 0; s < S; ++s) per_sample_sm[s] = per[2 * s];
   }
+  if (*forked) return side_end(st);
   return MAL_OK;
 }
 
@@ -676,17 +697,20 @@ static int ms_back(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool tem
     march_geometry(B, H, W, 0, &strips, &segs, nullptr);
     fin.per_sample_t = strips * segs;
     for (int s = 0; s < S; ++s) {
-      if (!a->syn_m1[s] || !a->syn_p1[s] || !a->g_syn_m1[s] || !a->g_syn_p1[s]) return MAL_EINVAL;
+      if (!a->syn_m1[s] || !a->syn_p1[s] || !a->g_syn_m1[s] || !a->g_syn_p1[s]) { (void)side_wait(st, false); return MAL_EINVAL; }
       const bool sparse = (a->syn_sparse >> s) & 1;
-      if (sparse && (!a->syn_region[s] || !a->warp_m1[s] || !a->warp_p1[s])) return MAL_EINVAL;
+      if (sparse && (!a->syn_region[s] || !a->warp_m1[s] || !a->warp_p1[s])) { (void)side_wait(st, false); return MAL_EINVAL; }
       int rc = photo_march_fused_more(w.packed[0], a->syn_m1[s], a->syn_p1[s], 2, w.ident, ms_noise(a, w, s), w.rp_warp[s],
                                       w.arg_warp[s], B, H, W, w.rp4[s], w.arg_t[s], w.w_t[s], w.bs_ph[s], a->g_syn_m1[s],
                                       a->g_syn_p1[s], &fin.per_sample_ph[s], st, a->syn_region[s], a->g_syn_region_m1[s],
                                       a->g_syn_region_p1[s], nullptr, nullptr, sparse ? a->warp_m1[s] : nullptr,
                                       sparse ? a->warp_p1[s] : nullptr, (size_t)a->warp_sample_stride, 1, 0);
-      if (rc) return rc;
+      if (rc) { (void)side_wait(st, false); return rc; }
       fin.bs_ph[s] = w.bs_ph[s];
     }
+    // the students' passes and the smoothness sweeps ran on the side stream beside the producers (mal_loss_multiscale_warp)
+    int rc = side_wait(st, false);
+    if (rc) return rc;
   }
   for (int s = 0; s < S; ++s) {
     for (int n = 0; n < 2; ++n) { fin.bs[n][s] = w.bs[n][s]; fin.sm[n][s] = w.sm[n][s]; }
@@ -708,8 +732,16 @@ extern "C" int mal_loss_multiscale_warp(const mal_ms_args* a) {
   for (int s = 0; s <= a->sclm; ++s)
     if (!a->warp_m1[s] || !a->warp_p1[s]) return MAL_EINVAL;
   MsWs w = carve_ms(a->ws, a->B, a->H, a->W, a->sclm);
-  int per_sm[kMsS];
-  return ms_front(a, w, (hipStream_t)a->stream, true, per_sm);
+  int per_sm[kMsS], forked = 0;
+  rc = side_wait((hipStream_t)a->stream, false);  // a previous step that was abandoned after its fork
+  if (rc) return rc;
+  return ms_front(a, w, (hipStream_t)a->stream, true, per_sm, &forked);
+}
+
+// A MAL_STEP_TEMPORAL step that called mal_loss_multiscale_warp but will not call _fwd (a producer raised): joins the side stream
+extern "C" int mal_loss_multiscale_abort(const mal_ms_args* a) {
+  if (!a) return MAL_EINVAL;
+  return side_wait((hipStream_t)a->stream, false);
 }
 
 extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
@@ -720,7 +752,8 @@ extern "C" int mal_loss_multiscale_fwd(const mal_ms_args* a) {
   const bool temporal = (a->flags & MAL_STEP_TEMPORAL) != 0;
   int per_sm[kMsS] = {};
   if (!temporal) {
-    rc = ms_front(a, w, st, false, per_sm);
+    int forked = 0;
+    rc = ms_front(a, w, st, false, per_sm, &forked);
     if (rc) return rc;
   } else {
     for (int s = 0; s <= a->sclm; ++s) per_sm[s] = ms_smooth_tasks(a->H, a->W, s);

@@ -517,11 +517,15 @@ class MultiScaleLossFn(Function):
             a.warp_sample_stride = 6 * H * W
             hints = [_Hint(a, False, B, H, W, dev, scale=s_) for s_ in range(S)]
             L.check(L.load().mal_loss_multiscale_warp(C.byref(a)), "mal_loss_multiscale_warp")
-            for h in hints:
-                h.produce(synth, inputs, defer=True)
-            has_ins = hints[-1].has_ins
-            for h in hints:
-                h.finish(has_ins)
+            try:  # a producer raised, or left something unusable: join what _warp forked before the buffers are reused
+                for h in hints:
+                    h.produce(synth, inputs, defer=True)
+                has_ins = hints[-1].has_ins
+                for h in hints:
+                    h.finish(has_ins)
+            except BaseException:
+                L.load().mal_loss_multiscale_abort(C.byref(a))
+                raise
         L.check(L.load().mal_loss_multiscale_fwd(C.byref(a)), "mal_loss_multiscale_fwd")
         for h in hints:
             h.expose(hint[2], want_maps)
