@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--main-temporal", action="store_true",
                     help="--mode step with --main_temporal as well (manydepth/trainer.py:1164, loss_utils.py:152-155): the student's "
                          "warped images go through the producer too (MAL_STEP_MAIN_TEMPORAL); a variant run, not the headline")
+    ap.add_argument("--dr-default-scales", action="store_true",
+                    help="--mode dualrefine / dualrefine_ops with upstream's default scale list [0,1,2,3] (dualrefine/options.py:65-69: "
+                         "scale 0 and 2 with both deq iterations, scale 1 skipped, scale 3 iteration 0) instead of [0]; a variant run")
     ap.add_argument("--ms-temporal", action="store_true",
                     help="--mode multiscale with --temporal (trainer.py:1161-1162,1279-1283): the producer once per scale between "
                          "mal_loss_multiscale_warp and _fwd; a variant run")
@@ -176,7 +179,7 @@ class TrainStep:
 class Step:
     """Everything a step needs, resident on the device."""
 
-    def __init__(self, dev, seed, mode="step", channels_last=False, main_temporal=False, ms_temporal=False):
+    def __init__(self, dev, seed, mode="step", channels_last=False, main_temporal=False, ms_temporal=False, dr_scales=None):
         from mal_amd import config, layers, trainer, step as step_mod
         self.mode, self.step_mod = mode, step_mod
         from mal_amd.synthetic import make_batch
@@ -218,9 +221,18 @@ class Step:
                                        image_synthesis=synth)
         elif mode == "dualrefine":
             from mal_amd import dualrefine
-            self.lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=self.B, n_losses=1),
-                                                    fuse=True)
+            self.dr_scales = list(dr_scales or [0])
+            self.lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=self.B, n_losses=1,
+                                                                               scales=self.dr_scales), fuse=True)
             self.cmask4 = self.cmask.unsqueeze(1)
+            for sc in self.dr_scales:  # lower scales: pooled copies (the DEQ decoder is not part of this package)
+                if sc in (0, 1):
+                    continue
+                self.inputs[("color", 0, sc)] = torch.nn.functional.avg_pool2d(self.inputs[("color", 0, 0)], 2 ** sc)
+                for it, name in ((0, "disp_teacher"), (1, "disp_student")):
+                    if sc == 3 and it > 0:
+                        continue
+                    self.leaves["disp_s%d_it%d" % (sc, it)] = torch.nn.functional.avg_pool2d(mv(b[name]), 2 ** sc).clone().requires_grad_(True)
         elif mode in ("multiscale", "multiscale_ops"):
             # --scales 0..3 semantics (sclm=3): per-scale disparities upsampled to full resolution, loss
             # / 2**scale, total / (sclm+1); the shipped decoder only feeds scale 0, so the lower scales are pooled copies
@@ -275,6 +287,9 @@ class Step:
         if self.mode == "dualrefine":  # 4-tuple keys: ("disp", 0, deq_iter); iteration 1 refines pose -1
             outputs = {("disp", 0, 0): lv["disp_teacher"], ("disp", 0, 1): lv["disp_student"], ("cam_T_cam", 0, -1): T_m1,
                        ("cam_T_cam", 0, 1): T_p1, ("cam_T_cam", 0, -1, 1): T_m1 * 1.0, "consistency_mask": self.cmask4}
+            for k, t in lv.items():
+                if k.startswith("disp_s") and k[6].isdigit():  # "disp_s<scale>_it<iteration>"
+                    outputs[("disp", int(k[6]), int(k[-1]))] = t
             if self.dr_ops:  # the operator-level route (two fused passes + glue: ~75 launches)
                 self.lp.generate_images_pred(self.inputs, outputs)
                 losses = self.lp.compute_losses(self.inputs, outputs)
@@ -568,7 +583,7 @@ def main():
         args.no_cpu_baseline = True
     else:
         step = Step(dev, 1234 + rank, args.mode, channels_last=args.channels_last, main_temporal=args.main_temporal,
-                    ms_temporal=args.ms_temporal)
+                    ms_temporal=args.ms_temporal, dr_scales=[0, 1, 2, 3] if args.dr_default_scales else None)
     batch_cpu = step.batch_cpu
     step_B = getattr(step, "B", B)  # images per rank and step (read here: the train_step block below frees `step`)
 
@@ -915,6 +930,9 @@ def main():
                                 else "operator-level (DualRefineLossPath.generate_images_pred + compute_losses)")
         out["config"]["global_batch"] = step_B * n_ranks
         out["metric"] = "train images/sec at B=8 192x640 KITTI-shaped (DualRefine+MAL loss loops, fwd+bwd)"
+        if args.dr_default_scales:
+            out["config"]["variant"] = ("upstream's default scale list [0,1,2,3]: scale 0 and 2 with deq iterations 0..1, scale 1 skipped, "
+                                        "scale 3 iteration 0 (one mal_dr_loss call per visited scale on the one-call route)")
     elif args.mode not in ("step", "distil"):
         out["config"]["workload"] += " [mode %s]" % args.mode
     if train_block is not None:
