@@ -496,6 +496,10 @@ typedef struct mal_dr_args {
   const float *color0_s;
   const float *disp_lo[MAL_DR_MAX_ITERS];
   float *g_disp_lo[MAL_DR_MAX_ITERS];
+  /* nullable: the workspace of an earlier mal_dr_loss_fwd call of the SAME step (same images, B, H, W, flags) -- the texel
+   * copies of the three images and the identity term are taken from it instead of being formed again (a step over several
+   * scales packs once).  Honoured when this call's smoothness term does not ride on that sweep (scale > 0 or n_iters > 2). */
+  const void *texels_from;
 } mal_dr_args;
 size_t mal_dr_workspace_bytes(int B, int H, int W, int n_iters);
 int mal_dr_loss_fwd(const mal_dr_args* args);

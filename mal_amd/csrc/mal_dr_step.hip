@@ -307,7 +307,12 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
   const bool smooth_fused = n <= 2 && a->scale == 0;
   const int variant = ((a->flags & MAL_DR_NO_SSIM) ? 1 : 0) | ((a->flags & MAL_DR_AVG) ? 2 : 0);
   int per_sample_sm = 1;
-  {
+  const bool reuse = a->texels_from != nullptr && !smooth_fused;
+  if (reuse) {  // texels and identity term of an earlier call of this step (its workspace starts with them, whatever its n_iters)
+    const DrWs w0 = carve_dr(const_cast<void*>(a->texels_from), B, H, W, 1);
+    for (int i = 0; i < 3; ++i) w.packed[i] = w0.packed[i];
+    w.ident = w0.ident;
+  } else {
     SmoothParams sm = {};
     sm.n = n; sm.partials = w.sm[0];
     for (int it = 0; it < n && smooth_fused; ++it) { sm.disp[it] = a->disp[it]; sm.gn[it] = w.gn[it]; }

@@ -70,6 +70,7 @@ class DrLossStepFn(Function):
         color0_s = consts[7] if len(consts) > 7 else None
         min_depth, max_depth, smooth_weight, flags, n, philox = cfg[:6]
         scale = cfg[6] if len(cfg) > 6 else 0
+        texels_from = cfg[7] if len(cfg) > 7 else None  # the workspace of the step's first call (texels + identity term)
         req, p = ops._req, ops._p
         tens = [req(t, "leaf") for t in leaves]
         cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K)]
@@ -103,8 +104,12 @@ class DrLossStepFn(Function):
         a.losses, a.loss_total = p(losses), p(total)
         ws = _dr_workspace(dev, B, H, W, n, slot=int(scale))
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
+        if texels_from is not None:
+            a.texels_from = p(texels_from)
         L.check(L.load().mal_dr_loss_fwd(C.byref(a)), "mal_dr_loss_fwd")
         ctx.args, ctx.keep, ctx.n, ctx.scale, ctx.up = a, (tens, cons, cm, nz, ws, losses, total), n, int(scale), up
+        ctx.texels_from = texels_from  # (kept alive: the passes of this call read it)
+        DrLossStepFn.last_ws = ws
         ctx.ws_token = ops.claim_workspace(ws)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(losses)
@@ -331,6 +336,7 @@ class DualRefineLossPath:
             else:
                 noises = [loss_utils.draw_noise((B, 1, H, W), target.device) for _ in units]  # one draw per visit (:586-587)
         losses, total, k = {}, None, 0
+        first_ws = None  # the first call's workspace: later scales of this step take the texels and the identity term from it
         for scale in scales:
             if scale == 1:
                 continue  # trainer.py:406-407,546-547
@@ -348,8 +354,10 @@ class DualRefineLossPath:
             k += n
             consts = (target, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)], cmask, nz,
                       inputs[("color", 0, scale)] if scale else None)
-            cfg = (opt.min_depth, opt.max_depth, opt.disparity_smoothness / (2 ** scale), flags, n, philox, scale)
+            cfg = (opt.min_depth, opt.max_depth, opt.disparity_smoothness / (2 ** scale), flags, n, philox, scale, first_ws)
             tot_s, v = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1)
+            if first_ws is None:
+                first_ws = DrLossStepFn.last_ws
             total = tot_s.reshape(()) if total is None else total + tot_s.reshape(())
             losses["reproj_loss/%d" % scale] = v[4 * (n - 1)]
             for it in range(n):
