@@ -109,15 +109,14 @@ class DrLossStepFn(Function):
         L.check(L.load().mal_dr_loss_fwd(C.byref(a)), "mal_dr_loss_fwd")
         ctx.args, ctx.keep, ctx.n, ctx.scale, ctx.up = a, (tens, cons, cm, nz, ws, losses, total), n, int(scale), up
         ctx.texels_from = texels_from  # (kept alive: the passes of this call read it)
-        DrLossStepFn.last_ws = ws
         ctx.ws_token = ops.claim_workspace(ws)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(losses)
-        return total, losses
+        ctx.mark_non_differentiable(losses, ws)
+        return total, losses, ws  # (ws: what a later scale's call of the same step takes the texels from)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_total, _g_losses=None):
+    def backward(ctx, g_total, _g_losses=None, _g_ws=None):
         n, tens = ctx.n, ctx.keep[0]
         if g_total is None:
             return (None,) * (2 + 3 * n)
@@ -355,9 +354,9 @@ class DualRefineLossPath:
             consts = (target, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)], cmask, nz,
                       inputs[("color", 0, scale)] if scale else None)
             cfg = (opt.min_depth, opt.max_depth, opt.disparity_smoothness / (2 ** scale), flags, n, philox, scale, first_ws)
-            tot_s, v = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1)
+            tot_s, v, ws_s = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1)
             if first_ws is None:
-                first_ws = DrLossStepFn.last_ws
+                first_ws = ws_s
             total = tot_s.reshape(()) if total is None else total + tot_s.reshape(())
             losses["reproj_loss/%d" % scale] = v[4 * (n - 1)]
             for it in range(n):
