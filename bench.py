@@ -877,13 +877,14 @@ def main():
         achieved = ALG_BYTES_PER_PX * n_px / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         eager_ach = ALG_BYTES_PER_PX * n_px / (kern_ms_plain * 1e-3) / 1e9 if kern_ms_plain > 0 else 0.0
         copy_gbs = measured_copy_ceiling(dev)
-        traffic = None
+        traffic = traffic_temporal = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("pass_kernel_teacher_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic, traffic_temporal = tj.get("pass_kernel_teacher_bytes_per_launch"), tj.get("pass_kernel_teacher_temporal_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic = traffic_temporal = None
         out["roofline"] = {"bound": "hbm", "kernel": "mal::march_teacher_kernel<false> (teacher pass: warp+SSIM+L1+"
                                                      "min+automask fwd+bwd, one launch = the whole B=12 pass)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -911,7 +912,7 @@ def main():
         ach_t = alg_t * n_px / (kern_ms * 1e-3) / 1e9
         out["roofline_temporal"] = {"bound": "hbm", "kernel": "mal::march_teacher_kernel<true> (the teacher's gradient "
                                     "sweep inside the --temporal step)", "achieved": ach_t, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": ach_t / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_px": alg_t,
+                                    "frac": ach_t / HBM_PEAK_GBS, "traffic": traffic_temporal, "alg_bytes_per_px": alg_t,
                                     "pixels_per_launch": n_px, "kernel_ms": kern_ms, "launches_timed": len(durs)}
     if args.mode == "train":
         out["metric"] = "train images/sec at B=12 192x640 KITTI-shaped (whole training step of the harness)"
