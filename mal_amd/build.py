@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -87,7 +88,7 @@ VALU_JSON = os.path.join(LIBDIR, "valu_cost.json")
 # the instantiations bench.py prices: name -> substring of the mangled symbol
 VALU_KERNELS = {"teacher": "march_teacher_kernelILb0ELb0EE", "teacher_temporal": "march_teacher_kernelILb1ELb0EE",
                 "teacher_generic": "march_kernelILb1ELb1ELb1ELb0ELb0ELb0EE",
-                "student": "march_student_kernelILi619EE", "student_generic": "march_kernelILb1ELb0ELb0ELb1ELb0ELb0EE",
+                "student": re.compile(r"march_student_kernelILi\d+EE"), "student_generic": "march_kernelILb1ELb0ELb0ELb1ELb0ELb0EE",
                 "ensemble": "march_kernelILb0ELb0ELb0ELb0ELb0ELb0EE"}
 
 
@@ -117,7 +118,8 @@ def valu_cost_of(asm_text, key, nth=0):
     import collections
     import re
     lines = asm_text.split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and l.rstrip().split(":")[0].endswith("E"))
+    has = (lambda l: key.search(l) is not None) if hasattr(key, "search") else (lambda l: key in l)  # substring or compiled pattern
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and has(l) and l.rstrip().split(":")[0].endswith("E"))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     labels, ins = {}, []
     for l in lines[start + 1:end]:

@@ -291,6 +291,21 @@ enum : int {
   kSpecStudentNoEpi = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostYes | kSpecConvA,  // --temporal step: the epilogue is its own launch
   kSpecRefine = kSpecLean | kSpecNoDisp2 | kSpecCostNo | kSpecMonoYes | kSpecNoScale | kSpecConvB        // DualRefine, deq iterations > 0
 };
+// -DMAL_PROBE_W3 (scripts/w3_probe.sh; NOT a product build -- its results are wrong on purpose): what would a third wave per
+// SIMD buy the teacher's gradient pass?  The pass holds 246 VGPRs and 19.4 KB of LDS per wave; three waves need <= 168 and
+// <= 13.6 KB.  The probe compiles the SAME row loop under the 168-register cap (the compiler spills the rest to scratch) and
+// folds the ring's 24 floats per slot onto 16 (slots 16..23 alias 8..15: same LDS instructions, colliding values), and is
+// timed against the shipped kernel: if three waves WITH spill traffic are not faster than two without, no restructuring of
+// the row state that reaches 168 registers without spills can be expected to pay either.
+#ifdef MAL_PROBE_W3
+#define MAL_RI(j) ((j) < 16 ? (j) : (j) - 8)
+#define MAL_RING_POSE 16
+#define MAL_TEACHER_WAVES 3
+#else
+#define MAL_RI(j) (j)
+#define MAL_RING_POSE 24
+#define MAL_TEACHER_WAVES 2
+#endif
 template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG, bool TEMPORAL, bool EXPORT, int SPEC = 0>
 MAL_DEV void march_body() {
   constexpr bool LEAN = (SPEC & kSpecLean) != 0, NO_DISP2 = (SPEC & kSpecNoDisp2) != 0;
@@ -413,7 +428,7 @@ MAL_DEV void march_body() {
   // what the gradient row (two iterations behind the warped row) needs of its pixel -- the warped
   // values, the target and the chain-rule numbers -- waits in a 3-slot per-lane LDS ring (no bank
   // conflicts: lane-private dwords; no barrier: one wavefront) instead of ~50 registers or a re-warp
-  constexpr int RING = GRAD ? (POSE ? 24 : 12) : 1;  // x, then (du, dv, u/v/rz) or e; the target row is re-read from memory
+  constexpr int RING = GRAD ? (POSE ? MAL_RING_POSE : 12) : 1;  // x, then (du, dv, u/v/rz) or e; the target row is re-read from memory
   __shared__ float s_ring[GRAD ? 3 : 1][RING][64];
   // Horizontal 3-sums of the gradient passes go through LDS instead of DPP (round 4; -DMAL_HSUM_DPP keeps the written-out
   // v_add_f32_dpp blocks of round 3 for A/B).  scripts/dpp_probe.hip: at two waves per SIMD EVERY cross-lane VALU form
@@ -451,15 +466,23 @@ MAL_DEV void march_body() {
   constexpr bool HSUM_LDS = H_MODE != 0 || (GRAD && HC_MODE != 0);
   __shared__ f4 s_stage[HSUM_LDS ? 64 : 1];
   const int laneL = max(lane - 1, 0), laneR = min(lane + 1, 63);
+  // The exchange is a cross-lane communication through memory: lane i's store must be visible to lanes i-1 / i+1 before their
+  // loads, and the loads must be done before the next group's stores reuse the cell.  The hardware gives that for free (a
+  // wave's LDS operations execute in order); __builtin_amdgcn_wave_barrier() -- no instruction, a convergent scheduling
+  // barrier -- makes the compiler keep it too, whatever a later version can prove about the addresses (advisor, round 4).
   auto nb4 = [&](f4 v, f4& L, f4& R) __attribute__((always_inline)) {
     s_stage[lane] = v;
+    __builtin_amdgcn_wave_barrier();
     L = s_stage[laneL];
     R = s_stage[laneR];
+    __builtin_amdgcn_wave_barrier();
   };
   auto nb2 = [&](f2 v, f2& L, f2& R) __attribute__((always_inline)) {  // a half group: the first 8 bytes of the lane's cell
     *reinterpret_cast<f2*>(&s_stage[lane]) = v;
+    __builtin_amdgcn_wave_barrier();
     L = *reinterpret_cast<const f2*>(&s_stage[laneL]);
     R = *reinterpret_cast<const f2*>(&s_stage[laneR]);
+    __builtin_amdgcn_wave_barrier();
   };
   // SHADOW (round 4): what an iteration can do WITHOUT the texels of the row being warped is placed between the issue of the
   // eight gathers and the blend that waits for them -- the one long memory latency of the iteration, of which round 3 covered
@@ -636,8 +659,8 @@ MAL_DEV void march_body() {
   // depth derivatives are re-derived
   auto pose_prep = [&](int q, int it, PosePrep& o) __attribute__((always_inline)) {
     float (*slot)[64] = s_ring[(it + 1) % 3];
-    const f2 pq_u = (f2){slot[18][lane], slot[19][lane]}, pq_v = (f2){slot[20][lane], slot[21][lane]};
-    const f2 pq_rz = (f2){slot[22][lane], slot[23][lane]};
+    const f2 pq_u = (f2){slot[MAL_RI(18)][lane], slot[MAL_RI(19)][lane]}, pq_v = (f2){slot[MAL_RI(20)][lane], slot[MAL_RI(21)][lane]};
+    const f2 pq_rz = (f2){slot[MAL_RI(22)][lane], slot[MAL_RI(23)][lane]};
     const float depth = depth_of(dv_2, p.min_disp, p.range);
     const float ddepth = -(depth * depth) * p.range;
     float ray[3], ik[9];
@@ -664,17 +687,17 @@ MAL_DEV void march_body() {
       float (*slot)[64] = s_ring[(it + 1) % 3];  // written two iterations ago
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        wq.x[k] = (f2){slot[2 * k][lane], slot[2 * k + 1][lane]};
+        wq.x[k] = (f2){slot[MAL_RI(2 * k)][lane], slot[MAL_RI(2 * k + 1)][lane]};
         if (POSE) {
-          dq.du[k] = (f2){slot[6 + 2 * k][lane], slot[6 + 2 * k + 1][lane]};
-          dq.dv[k] = (f2){slot[12 + 2 * k][lane], slot[12 + 2 * k + 1][lane]};
+          dq.du[k] = (f2){slot[MAL_RI(6 + 2 * k)][lane], slot[MAL_RI(6 + 2 * k + 1)][lane]};
+          dq.dv[k] = (f2){slot[MAL_RI(12 + 2 * k)][lane], slot[MAL_RI(12 + 2 * k + 1)][lane]};
         } else {
-          dq.e[k] = (f2){slot[6 + 2 * k][lane], slot[6 + 2 * k + 1][lane]};
+          dq.e[k] = (f2){slot[MAL_RI(6 + 2 * k)][lane], slot[MAL_RI(6 + 2 * k + 1)][lane]};
         }
       }
       if (POSE) {
-        pq_u = (f2){slot[18][lane], slot[19][lane]}; pq_v = (f2){slot[20][lane], slot[21][lane]};
-        pq_rz = (f2){slot[22][lane], slot[23][lane]};
+        pq_u = (f2){slot[MAL_RI(18)][lane], slot[MAL_RI(19)][lane]}; pq_v = (f2){slot[MAL_RI(20)][lane], slot[MAL_RI(21)][lane]};
+        pq_rz = (f2){slot[MAL_RI(22)][lane], slot[MAL_RI(23)][lane]};
       }
       wq.yrg = y2rg; wq.yb = y2b;  // target of row q = r-2, kept from its own iteration
     }
@@ -855,17 +878,17 @@ MAL_DEV void march_body() {
         float (*slot)[64] = s_ring[it % 3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          slot[2 * k][lane] = w0.x[k].x; slot[2 * k + 1][lane] = w0.x[k].y;
+          slot[MAL_RI(2 * k)][lane] = w0.x[k].x; slot[MAL_RI(2 * k + 1)][lane] = w0.x[k].y;
           if (POSE) {
-            slot[6 + 2 * k][lane] = d0.du[k].x; slot[6 + 2 * k + 1][lane] = d0.du[k].y;
-            slot[12 + 2 * k][lane] = d0.dv[k].x; slot[12 + 2 * k + 1][lane] = d0.dv[k].y;
+            slot[MAL_RI(6 + 2 * k)][lane] = d0.du[k].x; slot[MAL_RI(6 + 2 * k + 1)][lane] = d0.du[k].y;
+            slot[MAL_RI(12 + 2 * k)][lane] = d0.dv[k].x; slot[MAL_RI(12 + 2 * k + 1)][lane] = d0.dv[k].y;
           } else {
-            slot[6 + 2 * k][lane] = d0.e[k].x; slot[6 + 2 * k + 1][lane] = d0.e[k].y;
+            slot[MAL_RI(6 + 2 * k)][lane] = d0.e[k].x; slot[MAL_RI(6 + 2 * k + 1)][lane] = d0.e[k].y;
           }
         }
         if (POSE) {
-          slot[18][lane] = pw.u.x; slot[19][lane] = pw.u.y; slot[20][lane] = pw.v.x; slot[21][lane] = pw.v.y;
-          slot[22][lane] = pw.rz.x; slot[23][lane] = pw.rz.y;
+          slot[MAL_RI(18)][lane] = pw.u.x; slot[MAL_RI(19)][lane] = pw.u.y; slot[MAL_RI(20)][lane] = pw.v.x; slot[MAL_RI(21)][lane] = pw.v.y;
+          slot[MAL_RI(22)][lane] = pw.rz.x; slot[MAL_RI(23)][lane] = pw.rz.y;
         }
       }
     };
@@ -1183,7 +1206,7 @@ __global__ __launch_bounds__(64, 2) void march_export_kernel(MarchParams p_kerna
 #define MAL_EXP_KEEP_NOISE 0
 #endif
 template <bool TEMPORAL, bool NOISE = false>  // NOISE: a tie-break noise map is given (else it is part of the identity map)
-__global__ __launch_bounds__(64, 2) void march_teacher_kernel(MarchParams p_kernarg) {
+__global__ __launch_bounds__(64, MAL_TEACHER_WAVES) void march_teacher_kernel(MarchParams p_kernarg) {
   march_body<true, true, true, false, false, TEMPORAL, false, kSpecTeacher | (NOISE || TEMPORAL || MAL_EXP_KEEP_NOISE ? 0 : kSpecNoNoise)>();
 }
 // ... and the student's gradient pass with the consistency / distillation epilogue.  (The forward-only passes gain nothing

@@ -106,8 +106,8 @@ static StepWs carve_step(void* base, int B, int H, int W) {
 // teacher's four-way min and runs beside the temporal hint's producer; this launch follows the join.  The arithmetic is the
 // epilogue of march_body, statement for statement (weight = consistency mask x matching mask x (1 - augmentation), as the
 // pass forms it; depth_of, the argmin's first-minimum rule, sign conventions); sums leave as per-block partials.  (Riding as
-// leading workgroups of step_final_kernel -- one launch less -- was built and measured SLOWER, 0.330 against 0.3255 ms: 768 more
-// workgroups each pay an agent-scope release and a ticket atomic where a kernel boundary publishes for free; n_epi = 0 now.)
+// leading workgroups of step_final_kernel -- one launch less -- was built in round 4 and measured SLOWER, 0.330 against 0.3255 ms:
+// 768 more workgroups each pay an agent-scope release and a ticket atomic where a kernel boundary publishes for free; removed.)
 struct EpiParams {
   const float *disp_s, *disp_t, *mono_reproj, *ens_reproj, *multi_reproj, *ext_mask, *lowest_cost, *sample_scale, *ens_disp;
   int scale_is_mask, dual;
@@ -162,7 +162,11 @@ MAL_DEV void step_epilogue_block(const EpiParams& p, int bid) {
     idx_out = (unsigned)idx;
   };
   const size_t base = (size_t)b * p.HW;
-  if (((per | p.HW) & 3) == 0) {
+  // the 16-byte path needs every map it touches 16-byte aligned (torch's allocations are; a caller's view at an odd offset is not)
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  const bool aligned = al16(p.ext_mask) && al16(p.disp_t) && al16(p.lowest_cost) && al16(p.multi_reproj) && al16(p.disp_s) &&
+                       al16(p.mono_reproj) && al16(p.ens_reproj) && al16(p.ens_disp) && al16(p.G_c) && al16(p.G_e);
+  if (((per | p.HW) & 3) == 0 && aligned) {
     // four consecutive pixels per thread, 16-byte accesses (every map's sample and every block's range start 16-byte aligned)
     typedef float v4 __attribute__((ext_vector_type(4)));
     for (int i0 = lo + tid * 4; i0 < hi; i0 += 1024) {
@@ -216,17 +220,14 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
                                                          const float* K, int per_sample, int per_sample_t, int B, int H, int W,
                                                          float w_main, float w_distil, double* ps, float* gT0, float* gT1,
                                                          double* stats, float* losses, float* coefs, float* loss_total,
-                                                         unsigned* ticket, unsigned long long* noise_counter, EpiParams epi,
-                                                         int n_epi) {
+                                                         unsigned* ticket, unsigned long long* noise_counter) {
   __shared__ double s_part[256];
   __shared__ double s_gP[24];
   __shared__ double sh_tot[2][8];
   __shared__ unsigned s_last;
   const int tid = threadIdx.x, HW = H * W;
-  const int bid = (int)blockIdx.x - n_epi;  // the first n_epi workgroups: the student's consistency / distillation terms
-  if (bid < 0) {
-    step_epilogue_block(epi, (int)blockIdx.x);
-  } else if (bid < 2 * B) {
+  const int bid = (int)blockIdx.x;
+  if (bid < 2 * B) {
     const int pass = bid / B, b = bid - pass * B;
     const int j = tid & 7, sub = tid >> 3;  // 32 strided partial sums per quantity
     // temporal hint: the teacher's sum(rp*w), sum(w) come from the materialised-candidate kernel ([task][2])
@@ -238,13 +239,11 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
                              : bs_p + (size_t)b * per_sample_p * 8 + pass * 4 + (j - 4);
     const int n_t = j < 4 ? ps_pass : per_sample_p;
     double acc = 0.0;
-    if (bs_d && n_epi == 0 && pass == 1 && (j == 2 || j == 3)) {
+    if (bs_d && pass == 1 && (j == 2 || j == 3)) {
       // the consistency / distillation sums of the student come from step_epilogue_kernel's per-block partials (block order)
       const double* bd = bs_d + (size_t)b * kEpiBlocks * 2 + (j - 2);
 #pragma unroll 8
       for (int t = sub; t < kEpiBlocks; t += 32) acc += bd[(size_t)t * 2];
-    } else if (bs_d && pass == 1 && (j == 2 || j == 3)) {
-      // (n_epi > 0: the epilogue blocks belong to this launch; the block that finishes last adds their partials, below)
     } else {
 #pragma unroll 8
     for (int t = sub; t < n_t; t += 32) acc += bs[(size_t)t * 8];  // independent loads: issue them together
@@ -291,14 +290,14 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
       (f ? gT1 : gT0)[b * 16 + e] = (float)a;
     }
   }
-  // ---- the last block to get here does the scalar epilogue.  Publishing: every wave waits for its own stores, the workgroup
-  // meets, ONE lane releases at agent scope and takes the ticket (with the 768 epilogue workgroups in this launch a
-  // __threadfence() by all 256 threads of every workgroup -- an L2 write-back plus an invalidate each -- cost 40 us).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- the last block to get here does the scalar epilogue.  Publishing relies on this order: (1) the workgroup barrier --
+  // __syncthreads() is a workgroup-scope release/acquire, so every thread's stores above happen-before lane 0's fence (barrier
+  // cumulativity); (2) ONE agent-scope release fence by lane 0 (an L2 write-back: cheap once per workgroup, 40 us when all 256
+  // threads of 768 workgroups issued a __threadfence() each); (3) the ticket atomic; (4) an agent-scope acquire in the one
+  // workgroup that continues.
   __syncthreads();
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     s_last = atomicAdd(ticket, 1u);
   }
   __syncthreads();
@@ -309,24 +308,11 @@ __global__ __launch_bounds__(256) void step_final_kernel(const double* bs_t, con
   // then add the B terms in sample order.
   constexpr int kMaxStepB = 64;  // beyond this the terms are re-fetched by the summing threads instead of staged in LDS
   __shared__ double s_term[2 * kMaxStepB * 8];
-  __shared__ double s_epi[2 * kMaxStepB];
   const bool staged = B <= kMaxStepB;
-  if (bs_d && n_epi > 0) {  // per-sample sums of the epilogue blocks' partials, block order (thread 2b+jj: sample b, jj = consistency / distillation)
-    for (int i = tid; i < 2 * B; i += 256) {
-      const double* bd = bs_d + (size_t)(i >> 1) * kEpiBlocks * 2 + (i & 1);
-      double a = 0.0;
-      for (int t = 0; t < kEpiBlocks; ++t) a += bd[(size_t)t * 2];
-      ps[((size_t)B + (i >> 1)) * 8 + 2 + (i & 1)] = a;
-      if (staged) s_epi[i] = a;  // (read back from LDS below, not through the vector cache)
-    }
-    __threadfence();
-    __syncthreads();
-  }
   for (int i = tid; staged && i < 2 * B * 8; i += 256) {
     const int j = i & 7;
     const double* q = ps + (size_t)(i >> 3) * 8;
     double v = q[j];
-    if (bs_d && n_epi > 0 && (i >> 3) >= B && (j == 2 || j == 3)) v = s_epi[((i >> 3) - B) * 2 + (j - 2)];
     if (j == 4 || j == 5) {
       const float m = (float)(q[7] / (double)HW) + 1e-7f;
       v = v * (double)div_(1.0f, m);
@@ -554,6 +540,9 @@ static int step_check(const mal_step_args* a) {
   if (a->ens_disp && (a->flags & MAL_STEP_NO_ENS)) return MAL_EINVAL;  // the learnt ensemble IS the third candidate
   if ((a->flags & MAL_STEP_DUAL_DISTIL) && !(a->flags & MAL_STEP_NO_ENS)) return MAL_EINVAL;  // upstream reads it on the two-way branch only
   if (a->g_ens_disp && !a->ens_disp) return MAL_EINVAL;
+  // zero-copy texels: the caller's channels_last images are gathered as 12-byte texels -- a -DMAL_TEXEL_FLOATS=4 A/B build
+  // strides its gathers by 16 bytes and must take the packed path (advisor, round 4)
+  if ((a->flags & MAL_STEP_TEXEL_INPUTS) && kTexel != 3) return MAL_EINVAL;
   return MAL_OK;
 }
 
@@ -950,7 +939,6 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
   const bool ens_forked = hinted && ensemble_forked(a), stu_forked = temporal && student_forked(a);
   const bool stu_deferred = stu_forked || main_t;  // the student's marching pass has run: its epilogue is a launch of its own
   EpiParams epi = {};
-  int n_epi = 0;
   if (ens_forked || stu_forked || (hinted && student_warp_forked(a))) {
     rc = join_side(st, true);
     if (rc) return rc;
@@ -974,12 +962,12 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     if (rc) return rc;
   }
   // per-sample sums of both gradient passes, pose gradients (temporal: in _bwd, after the teacher's sweep), scalars
-  hipLaunchKernelGGL(step_final_kernel, dim3(n_epi + (temporal ? 2 * B : 3 * B)), dim3(256), 0, st, w.bs_t, w.bs_s, temporal ? nullptr : w.bgP,
+  hipLaunchKernelGGL(step_final_kernel, dim3(temporal ? 2 * B : 3 * B), dim3(256), 0, st, w.bs_t, w.bs_s, temporal ? nullptr : w.bgP,
                      w.bs_p, per_sample_p, temporal ? w.bs_ph : nullptr, per_sample_ph, main_t ? w.bs_sh : nullptr, per_sample_sh,
                      stu_deferred ? w.bs_d : nullptr, a->K,
                      per_sample, per_sample_t, B, H, W,
                      a->w_main, a->w_distil, w.ps, w.gT[0], w.gT[1], w.sm_stats, a->losses, w.coefs, a->loss_total,
-                     w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr, epi, n_epi);
+                     w.ticket, (a->flags & MAL_STEP_NOISE_PHILOX) ? (unsigned long long*)a->noise_counter : nullptr);
   return launch_status();
 }
 

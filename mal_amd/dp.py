@@ -87,15 +87,15 @@ class FlatGradBucket:
         return True
 
     def _use_avg(self):
-        if self._avg is None:  # decided once: does this backend take ReduceOp.AVG?
-            self._avg = False
-            if self.flat.is_cuda and dist.get_backend(self.group) == "nccl":
-                try:
-                    probe = torch.zeros(1, dtype=self.flat.dtype, device=self.flat.device)
-                    dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.group)
-                    self._avg = True
-                except Exception:
-                    self._avg = False
+        """does the exchange average inside the collective (``ReduceOp.AVG``: RCCL/NCCL on device buffers)?  Decided once,
+        and by ALL ranks together: every rank states what its own backend offers (no probing collective whose failure on one
+        rank alone would leave the others inside it) and the minimum over the ranks is taken -- a MIN all-reduce, which every
+        backend has -- so that no two ranks can ever issue different collectives.  If AVG then fails, it fails on every rank."""
+        if self._avg is None:
+            mine = int(self.flat.is_cuda and dist.get_backend(self.group) == "nccl" and hasattr(dist.ReduceOp, "AVG"))
+            flag = torch.tensor([mine], dtype=torch.int32, device=self.flat.device if self.flat.is_cuda else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            self._avg = bool(int(flag.item()))
         return self._avg
 
     def all_reduce_mean(self, async_op=False):

@@ -51,7 +51,8 @@ _DR_WS = {}
 def _dr_workspace(dev, B, H, W, n, slot=0):
     """``slot``: the scale of opt.scales the call belongs to -- every scale's call keeps its own maps until its backward"""
     need = L.load().mal_dr_workspace_bytes(B, H, W, n)
-    key = (dev.index, ops._stream(), B, H, W, n, slot)
+    from . import step as _step
+    key = (dev.index, ops._stream(), B, H, W, n, slot, _step._WS_SLOT)  # (step.workspace_slot: see there)
     ws = _DR_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = _DR_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)

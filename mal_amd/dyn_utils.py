@@ -171,7 +171,11 @@ class BatchSynthesisFn(Function):
             a.idx_last, a.idx_next = p(idx_last), p(idx_next)
             a.n_last, a.n_next = int(ml.shape[0]), int(mn.shape[0])  # a selection outside the tensor is clamped, never read
             a.prefilled = 1 if prefilled is not None else 0
-            saved.append((b, ml, mn, num, d_ptr, f_ptr, None, idx_last, idx_next))
+            # masks and selections are handed to the kernels BY REFERENCE and read again in the backward: remember their
+            # version counters -- a segmenter / matcher that re-uses its output buffers (a second producer call before this
+            # backward, --temporal with --main_temporal) would otherwise scatter gradients through the wrong regions silently
+            vers = tuple(None if t is None else t._version for t in (ml, mn, idx_last, idx_next))
+            saved.append((b, ml, mn, num, d_ptr, f_ptr, vers, idx_last, idx_next))
         ctx.keep = keep + [flags_all]
         # all samples in one call: three launches (extents, displacements, synthesis) for up to 16 samples
         L.check(lib.mal_dyn_batch_fwd(arr, len(items), C, H, W, 1 if replace else 0, ops._stream()), "mal_dyn_batch_fwd")
@@ -216,7 +220,11 @@ class BatchSynthesisFn(Function):
             (q_sl, s_sl), (q_sn, s_sn) = at(snap_l), at(snap_n)
         elif inplace:
             (q_tl, s_tl), (q_tn, s_tn) = at(tmp_l), at(tmp_n)
-        for k, (b, ml, mn, num, delta, flags, ws, idx_last, idx_next) in enumerate(ctx.saved):
+        for k, (b, ml, mn, num, delta, flags, vers, idx_last, idx_next) in enumerate(ctx.saved):
+            if vers is not None and vers != tuple(None if t is None else t._version for t in (ml, mn, idx_last, idx_next)):
+                raise L.MalError("image_synthesis backward: the instance masks / matched indices of sample %d were modified in place "
+                                 "after the forward (a segmenter or matcher that re-uses its output buffers?): hand the producer "
+                                 "private copies (mask.clone()) when it is called again before this backward" % b)
             a = arr[k]
             a.mask_last, a.mask_next, a.num, a.delta, a.flags = p(ml), p(mn), num, delta, flags  # (delta, flags: addresses)
             a.idx_last, a.idx_next = p(idx_last), p(idx_next)

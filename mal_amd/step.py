@@ -31,9 +31,32 @@ def noise_counter(dev):
     return t
 
 
+_WS_SLOT = 0
+
+
+class workspace_slot:
+    """``with workspace_slot(k): loss_step(...)``: the steps issued inside keep their intermediate maps in workspace number
+    ``k`` of this (device, stream, shape) instead of the shared one -- k steps in flight on ONE stream then do not overwrite
+    each other's maps (a trainer that runs the backward of a step before the next forward never needs it; bench.py rotates
+    over several batches with it, so that no step finds the previous replay's working set in the Infinity Cache)."""
+
+    def __init__(self, slot):
+        self.slot = int(slot)
+
+    def __enter__(self):
+        global _WS_SLOT
+        self.prev, _WS_SLOT = _WS_SLOT, self.slot
+        return self
+
+    def __exit__(self, *exc):
+        global _WS_SLOT
+        _WS_SLOT = self.prev
+        return False
+
+
 def _workspace(dev, B, H, W):
     need = L.load().mal_step_workspace_bytes(B, H, W)
-    key = (dev.index, ops._stream(), B, H, W)
+    key = (dev.index, ops._stream(), B, H, W, _WS_SLOT)
     ws = _WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -224,10 +247,10 @@ class _Hint:
             region = local.get(("syn_region", sc))
             sparse = bool(local.get(("syn_sparse", sc)))
             if sparse and (region is None or any(t.data_ptr() != q.data_ptr() for t, q in zip(self.syn_data, self.pre))):
-                raise L.MalError("loss_step: ('syn_sparse', 0) needs the region map and the buffers of ('syn_sparse_buffers', 0)")
+                raise L.MalError("loss_step: ('syn_sparse', %d) needs the region map and the buffers of ('syn_sparse_buffers', %d)" % (sc, sc))
             if region is not None and not (region.is_cuda and region.dtype == torch.uint8 and tuple(region.shape) == (B, H, W)
                                            and region.is_contiguous()):
-                raise L.MalError("loss_step: ('syn_region', 0) must be a contiguous (B,H,W) uint8 device tensor")
+                raise L.MalError("loss_step: ('syn_region', %d) must be a contiguous (B,H,W) uint8 device tensor" % sc)
             self.region = region
             if region is not None:
                 self._put("syn" + self.tag + "_region", region.data_ptr())
@@ -452,7 +475,7 @@ _WS_MS = {}
 
 def _workspace_ms(dev, B, H, W, sclm):
     need = L.load().mal_ms_workspace_bytes(B, H, W, sclm)
-    key = (dev.index, ops._stream(), B, H, W, sclm)
+    key = (dev.index, ops._stream(), B, H, W, sclm, _WS_SLOT)
     ws = _WS_MS.get(key)
     if ws is None or ws.numel() < need:
         ws = _WS_MS[key] = torch.empty(need, dtype=torch.uint8, device=dev)

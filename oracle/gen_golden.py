@@ -393,6 +393,37 @@ def run_reference_layers(ML, MLU, DL, tag, B=2, H=24, W=40, seed=77):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_reference_loss_balancing(MLU, tag="loss_balancing"):
+    """a15: the reference's OWN ``LossBalancing`` (manydepth/loss_utils.py:283-345) on the CPU.  ``compute_loss`` cannot run
+    there (hard-coded ``.cuda("cuda:0")``, :304), so its one side effect on the object -- the two loss scalars of a step
+    written into ``train_scores`` for the step's bs records, :311-316 -- is applied directly, exactly as that loop writes them;
+    ``update_weight`` (:320-345) is plain numpy and runs as is.  Recorded: a score sequence that takes the initialisation
+    branch, ordinary re-weightings, both clamps (adjust term held at 2.0 and at 0.5), an update over a step that runs off
+    the end of the dataset (records beyond ``num_data`` are never written), and the running state after every update."""
+    bs, num_data, num_loss = 4, 30, 2
+    lb = MLU.LossBalancing(num_loss, num_data, bs)
+    rng = np.random.RandomState(20261005)
+    # (L0, L1) per step and the lambda handed to update_weight after it (options.py: lambda_for_adjust_* ~ 0.1 .. 3)
+    scores = np.stack([0.30 + 0.05 * rng.rand(8), 0.020 + 0.004 * rng.rand(8)], axis=1)
+    scores[3] = (0.02, 0.30)    # the main term collapses: its adjust term would exceed 2.0 -> clamped to 2.0, the other to 0.5
+    scores[5] = (3.00, 0.001)   # ... and the other way round
+    lambdas = np.array([0.1, 0.3, 0.3, 3.0, 0.1, 3.0, 1.0, 0.2])
+    w, prev_total, prev_loss = [], [], []
+    for it in range(len(scores)):
+        for b in range(bs):  # compute_loss's record loop (:306-316)
+            rec = bs * it + b
+            if rec < lb.num_data:
+                lb.train_scores[rec, :] = scores[it]
+        w.append(lb.update_weight(it, float(lambdas[it])))
+        prev_total.append(float(lb.previous_total_loss))
+        prev_loss.append(np.array(lb.previous_loss, dtype=np.float64))
+    out = dict(bs=np.int64(bs), num_data=np.int64(num_data), num_loss=np.int64(num_loss), scores=scores, lambdas=lambdas,
+               weights=np.array(w, dtype=np.float64), previous_total_loss=np.array(prev_total), previous_loss=np.stack(prev_loss),
+               train_scores=np.array(lb.train_scores), initial_w=np.array([1.0 / num_loss] * num_loss))
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **out)
+    print(tag, "weights", np.array(w)[:, 0].round(5).tolist(), np.array(w)[:, 1].round(5).tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.path.insert(0, ROOT)
@@ -400,6 +431,9 @@ def main():
     from mal_amd.synthetic import make_batch
     torch.set_num_threads(8)
     small = quantize_batch(make_batch(2, 32, 64, seed=1234))
+    if sys.argv[1:] == ["blc"]:  # `python -m oracle.gen_golden blc` writes that one case only
+        run_reference_loss_balancing(MLU)
+        return
     if sys.argv[1:] == ["ms_temporal"]:  # `python -m oracle.gen_golden ms_temporal` writes that one case only
         run_reference_multiscale(ML, MLU, quantize_batch(make_batch(2, 48, 96, seed=1238, with_syn=True)), 3, 1009,
                                  "multiscale_b2_48x96_sclm3_temporal", temporal=True)
@@ -429,6 +463,7 @@ def main():
     run_reference_multiscale(ML, MLU, quantize_batch(make_batch(2, 48, 96, seed=1237)), 3, 1007, "multiscale_b2_48x96_sclm3")
     run_reference_multiscale(ML, MLU, quantize_batch(make_batch(2, 48, 96, seed=1238, with_syn=True)), 3, 1009,
                              "multiscale_b2_48x96_sclm3_temporal", temporal=True)
+    run_reference_loss_balancing(MLU)
 
 
 if __name__ == "__main__":

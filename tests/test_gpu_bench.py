@@ -45,9 +45,20 @@ def test_driver_command_default_flags():
     assert r["bound"] in ("hbm", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert 0.05 < r["frac"] < 1.0 and r["kernel_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["achieved"] - 96 * 12 * 192 * 640 / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
-    # measured in THIS run from a graph holding only 64 back-to-back launches of the kernel (no committed file is read)
+    # measured in THIS run from a graph holding only 64 back-to-back launches of the kernel (no committed file is read), in the
+    # COLD regime: launch i works on batch i % 8, so no launch finds its operands in the Infinity Cache; the warm figure
+    # (one batch replayed: what rounds 1-4 reported) sits beside it
     assert "64 back-to-back launches" in r["kernel_ms_how"] and r["launches_timed"] == 640, r["kernel_ms_how"]
+    assert r["regime"] == "cold" and r["batches_rotated"] == 8 and "batch i % 8" in r["kernel_ms_how"]
+    assert r["cold_kernel_ms"] == r["kernel_ms"] and abs(r["cold_frac"] - r["frac"]) < 1e-12
+    assert r["warm_kernel_ms"] > 0 and 0.5 < r["warm_kernel_ms"] / r["cold_kernel_ms"] < 1.1 and 0.05 < r["warm_frac"] < 1.0
     assert r["eager_kernel_ms"] > 0 and 0.5 < r["kernel_ms"] / r["eager_kernel_ms"] < 1.2 and "replayed_rocprof" not in r
+    # ... and so is the step: the timed steps rotate over 6 batches (value = the cold regime's), the warm replay beside it
+    assert d["batches_rotated"] == 6 and d["config"]["regime"].startswith("cold")
+    assert d["cold_ms_per_step"] == d["ms_per_step"] and d["cold_value"] == d["value"]
+    assert d["warm_ms_per_step"] > 0 and 0.5 < d["warm_ms_per_step"] / d["cold_ms_per_step"] < 1.2
+    assert "parity_gate" in d["config"] and d["scaling_quantity"] == "train_step.value" and d["world_size"] == 1
+    assert d["channels_last"]["batches_rotated"] == 6
     v = r["valu"]
     assert "error" not in v, v
     assert 0.2 < v["valu_frac"] < 1.2 and v["shader_clock_mhz"] > 500 and v["tasks"] > 0 and v["pipe_cycles_per_row"] > 0
@@ -81,10 +92,9 @@ def test_other_bench_modes_print_a_line(extra, expect):
 def test_two_ranks_over_gloo_print_the_multi_gpu_line():
     """the N>1 launch exactly as the driver starts it for N=2 -- `python bench.py --gpus 2` spawns the ranks itself -- but with
     gloo standing in for RCCL (MAL_BENCH_BACKEND=gloo: both ranks share this box's one card).  Covers everything of the
-    multi-GPU line except the RCCL transport: rank spawn, max-over-ranks timing, and the shape of the N>1 line -- its
-    `value` / `ms_per_step` are the WHOLE TRAINING STEP's (RepDepth + loss path + the gradient pieces issued from inside the
-    backward + Adam; no try/except around it at N>1: a failing collective fails the run), timed over exactly --steps steps;
-    the loss path beside the stand-in 165 MB exchange and its overlapped variant sit in the `loss_path` side block."""
+    multi-GPU line except the RCCL transport: rank spawn, max-over-ranks timing, and the shape of the N>1 line -- the SAME
+    quantities as at N=1 (`value` = the loss path, `train_step` = RepDepth + loss path + the gradient pieces issued from inside
+    the backward + Adam; no try/except around it at N>1: a failing collective fails the run)."""
     env = dict(os.environ, MAL_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -93,14 +103,29 @@ def test_two_ranks_over_gloo_print_the_multi_gpu_line():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 24 and d["scaling"] == "weak"
-    assert "whole training step" in d["metric"] and "RepDepth" in d["config"]["workload"] and "Adam" in d["config"]["workload"]
-    assert "scaling_metric" not in d and "cpu_baseline" not in d and d["value_is"].startswith("train_step")
-    t = d["train_step"]
-    assert t["n_gpus"] == 2 and t["value"] > 0 and "4 piece(s)" in t["exchange"] and "world size 2" in t["exchange"]
-    assert d["steps"] == 2 and d["warmup"] == 1 and t["steps"] == 2
-    assert d["value"] == t["value"] and d["ms_per_step"] == t["ms_per_step"]
+    # ONE quantity at every N: `value` is the loss path (here beside the stand-in 165 MB exchange after every step), the whole
+    # training step sits in `train_step`, and `scaling_quantity` names the field the DP-scaling ratio is taken from
+    assert "MAL loss path" in d["metric"] and "--temporal --distil" in d["config"]["workload"]
+    assert "value_is" not in d and "loss_path" not in d and "cpu_baseline" not in d
+    assert d["scaling_quantity"] == "train_step.value" and d["world_size"] == 2
+    assert d["steps"] == 2 and d["warmup"] == 1
     assert abs(d["value"] - 24 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
-    lp = d["loss_path"]
-    assert lp["breakdown_ms"]["grad_all_reduce"] > 0 and "error" not in lp["exchange_overlapped"]
-    assert abs(lp["value"] - 24 / (lp["ms_per_step"] * 1e-3)) <= 1e-6 * lp["value"] and "--temporal --distil" in lp["workload"]
+    assert d["breakdown_ms"]["grad_all_reduce"] > 0 and "error" not in d["exchange_overlapped"]
+    t = d["train_step"]
+    assert "error" not in t, t
+    assert t["n_gpus"] == 2 and t["world_size"] == 2 and t["value"] > 0 and t["steps"] == 20
+    assert "4 piece(s)" in t["exchange"] and "world size 2" in t["exchange"] and t["exchange_pieces"] == 4
+    assert 0 <= t["pieces_issued_inside_backward"] <= 4
+    assert abs(t["value"] - 24 / (t["ms_per_step"] * 1e-3)) <= 1e-6 * t["value"]
     assert d["roofline"]["kernel_ms"] > 0
+
+
+def test_value_train_makes_the_training_step_the_line():
+    """`--value train`: the line's value / ms_per_step are the whole training step's, timed over exactly --steps steps; the
+    loss-path measurement moves to the `loss_path` side block"""
+    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--value", "train", "--no-cpu-baseline", "--regime", "warm"])
+    t = d["train_step"]
+    assert "whole training step" in d["metric"] and d["value_is"].startswith("train_step")
+    assert d["value"] == t["value"] and d["ms_per_step"] == t["ms_per_step"] and d["steps"] == 2 and t["steps"] == 2
+    assert d["loss_path"]["value"] > 0 and d["scaling_quantity"] == "train_step.value"
+    assert d["roofline"]["regime"] == "warm" and d["batches_rotated"] == 1

@@ -186,6 +186,23 @@ def test_prefilled_and_in_place_equal_the_plain_node(shape, listed):
         assert torch.equal(sl[b][:, ~want], cl[b][:, ~want])  # syn differs from the warped image only there
 
 
+def test_masks_overwritten_before_the_backward_are_refused():
+    """the node keeps the matcher's masks by reference (no copy per step); a producer that writes into the same mask storage
+    again before the backward (a segmenter with static output buffers, called for the student's pass) must not lead to
+    gradients through the wrong regions: the backward sees the changed version counter and raises"""
+    from mal_amd import dyn_utils
+    from mal_amd._lib import MalError
+    B, H, W = 2, 24, 40
+    g = torch.Generator().manual_seed(5)
+    cl, cn = (torch.rand(B, 3, H, W, generator=g).to(DEV).requires_grad_(True) for _ in range(2))
+    items = _stub_items(B, H, W, (0, 1), 70)
+    sl, sn, _ = dyn_utils.BatchSynthesisFn.apply(cl, cn, items, False, None)
+    torch.autograd.grad([sl, sn], [cl, cn], [torch.ones_like(sl), torch.ones_like(sn)], retain_graph=True)  # untouched: fine
+    items[1][1].zero_()  # the "next call" of the segmenter lands in the same buffer
+    with pytest.raises(MalError, match="modified in place"):
+        torch.autograd.grad([sl, sn], [cl, cn], [torch.ones_like(sl), torch.ones_like(sn)])
+
+
 def test_step_with_the_region_map_equals_the_dense_path():
     """loss_step with mal_amd.dyn_utils.image_synthesis (sparse syn buffers -- only the region pixels are written and read,
     MAL_STEP_SYN_SPARSE --, in-place producer backward, region map:

