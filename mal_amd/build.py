@@ -19,18 +19,24 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmal_hip.so")
-SOURCES = ["mal_api.hip", "mal_pass.hip", "mal_warp.hip", "mal_photo.hip", "mal_photo_march.hip", "mal_dyn.hip", "mal_costvol.hip", "mal_epipolar.hip", "mal_pose.hip", "mal_march.hip", "mal_tile2.hip", "mal_step.hip", "mal_step_ms.hip", "mal_dr_step.hip"]
+SOURCES = ["mal_api.hip", "mal_pass.hip", "mal_warp.hip", "mal_photo.hip", "mal_photo_march.hip", "mal_dyn.hip", "mal_costvol.hip", "mal_epipolar.hip", "mal_pose.hip", "mal_march.hip", "mal_step.hip", "mal_step_ms.hip", "mal_dr_step.hip"]
 HEADERS = ["mal_common.h", "mal_device.h", "mal_march.h", "mal_pose.h", "mal_pairs.h", os.path.join("..", "..", "include", "mal_hip.h")]
+# csrc/experiments/: formulations that lost their same-box A/Bs (LABBOOK.md) -- whole sources and the .inc halves the shipped
+# sources include under #ifdef MAL_EXPERIMENTS.  Not part of the product: compiled only with MAL_EXPERIMENTS=1 in the environment.
+EXPERIMENT_SOURCES = [os.path.join("experiments", "mal_tile2.hip")]
+EXPERIMENT_INCLUDES = [os.path.join("experiments", f) for f in ("pass_tiled.inc", "pass_tiled_launch.inc", "march3.inc")]
 # -amdgpu-sched-strategy=max-ilp: the kernels run at 2-4 waves per SIMD by register count anyway; scheduling for
 # ILP instead of occupancy is worth ~2 % on the marching kernels (measured A/B on MI355X)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
          "-mllvm", "-amdgpu-sched-strategy=max-ilp",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-I", CSRC]
 # MAL_EXPERIMENTS=1 in the environment builds the formulations that were measured slower and are kept for same-box A/B
 # only (LDS-tiled passes, three-wave pipeline, exporting gradient pass, classified dispatch order); the
 # default library does not contain them and mal_set_option refuses their switches
 if os.environ.get("MAL_EXPERIMENTS", "0") not in ("", "0"):
     FLAGS = FLAGS + ["-DMAL_EXPERIMENTS"]
+    SOURCES = SOURCES + EXPERIMENT_SOURCES
+    HEADERS = HEADERS + EXPERIMENT_INCLUDES
 
 
 def _hipcc():
@@ -58,7 +64,7 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        o = os.path.join(LIBDIR, os.path.basename(s).replace(".hip", ".o"))
         objs.append(o)
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:

@@ -139,18 +139,23 @@ struct PendingWarp {
   f2 ex, ey, tx, ty;           // DERIV
   f2 mx, my, du_ddisp, dv_ddisp;
   f2 u, v, rz;                 // POSE: the projection, kept for the pose terms of the gradient row
+  float pf[2];                 // MAL_GATHER_PREFETCH: a dword of the source row the NEXT iteration's taps will newly touch
 };
 
 // the parameter-block fields the warp needs, read together at the top of an iteration (one scalar-load wait)
 struct WarpConsts {
   const float* src[2]; int packed, debug, W, H, convention; float min_disp, range, eps, rw, rh;
   unsigned* dbg; unsigned dbg_n, dbg_off; bool dbg_on;  // DBG: decision planes, plane stride, this pixel's byte offset, lane writes
+  bool walk_up;                                         // the task walks its rows bottom-up (odd segments): the next row is the one above
 };
 // decision plane `plane` (mal_hip.h MAL_DEC_*), byte offset `boff` of the pixel inside a (B,1,H,W) map
 MAL_DEV void dec_store(unsigned* dbg, unsigned n, int plane, unsigned boff, unsigned v) {
   *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dbg + (size_t)plane * n) + boff) = v;
 }
 
+#ifndef MAL_GATHER_PREFETCH
+#define MAL_GATHER_PREFETCH 0
+#endif
 // projection, tap weights and the eight gathers
 // LEAN (the specialised passes of the whole-step lists: packed texels, H*W*12 < 2^24 checked by march_launch): the byte
 // offsets of the four taps are formed in fp32 -- every product and sum below 2^24 is exact -- instead of with 32-bit integer
@@ -169,6 +174,7 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
   const f2 x0f = (f2){floorf(s.ix.x), floorf(s.ix.y)}, y0f = (f2){floorf(s.iy.x), floorf(s.iy.y)};
   int oo[2][4];
   unsigned bo12[2][4];  // LEAN: byte offsets of the taps inside the sample's texel image
+  unsigned bopf[2] = {0u, 0u};
   if (LEAN) {
     const float xm = (float)(W - 1), ym = (float)(H - 1), w12 = (float)(W * kTexel * 4);
     const f2 x1f = (f2){fminf(x0f.x + 1.0f, xm), fminf(x0f.y + 1.0f, xm)};  // x0+1 == W only with weight 0
@@ -178,6 +184,17 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       bo12[f][0] = (unsigned)o00[f]; bo12[f][1] = (unsigned)o01[f]; bo12[f][2] = (unsigned)o10[f]; bo12[f][3] = (unsigned)o11[f];
+    }
+    if (MAL_GATHER_PREFETCH) {
+      // The warp is smooth: the taps of the next image row land one source row further along -- its top tap row is this
+      // iteration's bottom one (an L2 hit by then), its bottom tap row is NEW and would be fetched from HBM while the wave sits
+      // in the blend's wait (two waves per SIMD hide little of a DRAM round trip).  One dword per frame of that row, at this
+      // lane's column, requested now and consumed (dropped) at the top of the next iteration, brings its lines into the L2 a
+      // whole iteration early.  Clamped to the image: a valid address always, a useless but harmless load at the border.
+      const f2 ypf = p.walk_up ? (f2){fmaxf(y0f.x - 1.0f, 0.0f), fmaxf(y0f.y - 1.0f, 0.0f)}
+                               : (f2){fminf(y1f.x + 1.0f, ym), fminf(y1f.y + 1.0f, ym)};
+      const f2 opf = ypf * bc(w12) + c0;
+      bopf[0] = (unsigned)opf.x; bopf[1] = (unsigned)opf.y;
     }
   }
 #pragma unroll
@@ -214,6 +231,14 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
         w.t[f][k] = make_texel(ldf(p0, bo), ldf(p1, bo), ldf(p2, bo));
       }
     }
+  }
+  w.pf[0] = 0.f; w.pf[1] = 0.f;
+  if (LEAN && MAL_GATHER_PREFETCH) {  // behind the gathers: the blend's wait counts them as younger and does not wait for them
+    // (the scheduler otherwise hoists them in FRONT of the gathers -- in-order retirement then makes the blend wait for these
+    // HBM misses too; the mask lets ALU and LDS instructions cross, no vector-memory one)
+    __builtin_amdgcn_sched_barrier(0x0387);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) w.pf[f] = ldf(p.src[f] + (size_t)b * HW * kTexel, bopf[f]);
   }
   w.tx = s.ix - x0f; w.ex = bc(1.0f) - w.tx; w.ty = s.iy - y0f; w.ey = bc(1.0f) - w.ty;
   w.nw = w.ey * w.ex; w.ne = w.ey * w.tx; w.sw = w.ty * w.ex; w.se = w.ty * w.tx;
@@ -611,6 +636,7 @@ MAL_DEV void march_body() {
   f2 y2rg = bc(0.f);
   float y2b = 0.f;  // target pixel of row r-2
   float dv_1 = 0.f, dv_2 = 0.f;  // disparity of rows r-1, r-2 (the pose terms of the gradient row re-project it)
+  float pf_prev[2] = {0.f, 0.f};  // MAL_GATHER_PREFETCH: last iteration's prefetched dwords (see warp_issue)
   // ================= epilogue terms of output row (EPI): row q = r-2 with GRAD, c without ===
   auto epilogue = [&](CParams& p, int r, const PixInfo& pq, float le_disp, float le_mono, float le_mr, float le_er,
                       unsigned so_c, unsigned so_q, bool has_mdisp, bool has_er, float le_ensd) __attribute__((always_inline)) {
@@ -804,7 +830,7 @@ MAL_DEV void march_body() {
     wc.convention = CONV >= 0 ? CONV : p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
     wc.rw = norm_rw; wc.rh = norm_rh;
     wc.dbg = DBG ? p.dbg : nullptr; wc.dbg_n = (unsigned)(p.B * HW);
-    wc.dbg_off = 0; wc.dbg_on = false;
+    wc.dbg_off = 0; wc.dbg_on = false; wc.walk_up = flip;
     if (DBG) { wc.dbg_on = r >= y_lo && r < y_hi && out_x; wc.dbg_off = moff(row_of(r)); }
 #ifdef MAL_STAGE_TIMERS
     auto tick = [&](int i) {
@@ -829,6 +855,7 @@ MAL_DEV void march_body() {
     // the issue phase (projection, operand requests, gathers) is what the rest of the iteration waits for:
     // run it at raised wave priority so the sibling wave's arithmetic does not delay it (measured -1.7 %)
     __builtin_amdgcn_s_setprio(3);
+    if (LEAN && MAL_GATHER_PREFETCH) asm volatile("" : : "v"(pf_prev[0]), "v"(pf_prev[1]));  // the prefetched dwords: waited for, dropped
     PendingWarp pw;
     {
       f2 P[12];
@@ -843,6 +870,7 @@ MAL_DEV void march_body() {
 #endif
     }
     __builtin_amdgcn_s_setprio(0);
+    if (LEAN && MAL_GATHER_PREFETCH) { pf_prev[0] = pw.pf[0]; pf_prev[1] = pw.pf[1]; }
     tick(1); MAL_MARK(1);  // small loads, prefetch, projection, gathers issued
     // ---- in the shadow of the gathers (see SHADOW above)
     f2 sh_hy[2] = {bc(0.f), bc(0.f)}, sh_l15 = bc(0.f);
@@ -1231,390 +1259,7 @@ __global__ __launch_bounds__(64, 2) void march_refine_kernel(MarchParams p_kerna
 }
 
 #ifdef MAL_EXPERIMENTS  // option "march3" (measured slower): not in the default build
-// =====================================================================================================================
-// march3: the teacher's gradient pass (GRAD + AUTOMASK + POSE, one-row halo, packed texels) as a THREE-WAVE PIPELINE per
-// strip.  A lone wave of march_kernel needs 88 % of the time a pair takes: its own dependency chain --
-// projection -> gathers -> blend -> horizontal sums -> statistics -> partial planes -> gradient row -- sets the pace, and the
-// ~240 registers that chain keeps alive allow two waves per SIMD.  Here the chain is cut into three roles that run
-// concurrently on three waves of one workgroup, one pipeline step per image row, rows handed over through LDS:
-//   wave 0 (A)  warps row t+1: projection, 8 gathers, blend, chain-rule data          -> ring slot of row t+1 (24 floats/lane)
-//   wave 1 (S)  row t: horizontal sums of the 24 planes, vertical running sums, SSIM + L1 + min + automask of row t-1,
-//               partial planes and their horizontal sums                                -> hc(t-1) (18 floats), decision of t-1
-//   wave 2 (G)  gradient row t-3 from ring(t-3), hc(t-2) and its running sums: d loss / d disp, pose partials
-// Every role keeps ~100-150 registers, so three waves fit per SIMD; one s_barrier per step.  LDS per workgroup: 5 ring
-// slots + 2 hc slots + 4 decision slots = 40 KB (four workgroups per CU).  Arithmetic, summation order, decisions and
-// outputs are those of march_body<true,true,true,false,DBG,false,false> with p.bnd set.
-constexpr int kM3Ring = 5;
-template <bool DBG>
-__global__ __launch_bounds__(192, 3) void march3_kernel(MarchParams p) {
-  constexpr int HALO = 2, CW = 64 - 2 * HALO;
-  __shared__ float s_ring[kM3Ring][18][64];  // x, d x / d u, d x / d v (u, v, 1/z are re-derived by G)
-  __shared__ float s_hc[2][18][64];
-  __shared__ unsigned s_pi[4][64];
-  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = (int)(threadIdx.x & 63u);
-  const int id = blockIdx.x;
-  const int task = (id & 7) * p.per_xcd + (id >> 3);
-  if (task >= p.ntasks) return;  // whole workgroup
-  const int per_b = p.strips * p.segs;
-  const int b = task / per_b;
-  const int tt = task - b * per_b;
-  const int seg = tt / p.strips, strip = tt - seg * p.strips;
-  const int H = p.H, W = p.W, HW = H * W;
-  const int ph_lo = seg * p.rows, ph_hi = min(ph_lo + p.rows, H);
-  const bool flip = (seg & 1) != 0 && p.flip_odd != 0;
-  const int y_lo = flip ? H - ph_hi : ph_lo, y_hi = flip ? H - ph_lo : ph_hi;
-  const int yf = flip ? H - 1 : 0;
-  auto prow = [&](int y) { return abs(y - yf); };
-  const int gx = strip * CW - HALO + lane;
-  const bool in_x = gx >= 0 && gx < W;
-  const int gxr = min(max(reflect1(gx, W), 0), W - 1);
-  const bool out_x = in_x && lane >= HALO && lane < 64 - HALO;
-  const unsigned lane_off = (unsigned)gxr * 4u + (unsigned)b * (unsigned)HW * 4u;
-  auto moff = [&](int row) { return (unsigned)(prow(row) * W) * 4u + lane_off; };
-  auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
-  auto slot_of = [&](int row) { return (row + 2 * kM3Ring) % kM3Ring; };
-  // rows warped: r_first .. r_warp_last; gradient rows are two iterations behind (march_body with h1e = 1)
-  const int r_first = max(y_lo - 1, -1), r_warp_last = y_hi, r_last = min(y_hi, H - 1) + 2;
-  // an even number of steps for every role (A's loop is unrolled by two; the odd one out only meets the barrier)
-  const int t_first = r_first - 1, t_last = r_last + 1 + ((r_last + 1 - (r_first - 1) + 1) & 1);
-  // LDS writes of this step are complete and visible, LDS reads of this step have returned, before any wave goes on
-  auto step_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  const float* disp_b = p.disp;
-  const unsigned dbg_n = (unsigned)(p.B * HW);
-
-  if (role == 0) {
-    // ================================================= A: warp
-    const cfloat* cam_b = (const cfloat*)(p.cam + (size_t)b * kCamFloats);
-    const float norm_rw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
-        int, refined_rcp(p.convention == 0 ? (float)(W - 1) : (float)W))));
-    const float norm_rh = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
-        int, refined_rcp(p.convention == 0 ? (float)(H - 1) : (float)H))));
-    // The gathers of row r+1 are issued BEFORE the blend of row r (two pending sets, alternating, no register copies: the
-    // step loop is unrolled by two), so a step does not contain a full gather round trip.
-    WarpConsts wc;
-    wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = 3; wc.debug = 0; wc.W = W; wc.H = H;
-    wc.convention = p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
-    wc.rw = norm_rw; wc.rh = norm_rh;
-    wc.dbg = DBG ? p.dbg : nullptr; wc.dbg_n = dbg_n; wc.dbg_off = 0; wc.dbg_on = false;
-    float disp_nxt = 0.f;
-    auto issue = [&](int r, float dispv, PendingWarp& pw) __attribute__((always_inline)) {
-      if (DBG) { wc.dbg_on = r >= y_lo && r < y_hi && out_x && r <= r_warp_last; wc.dbg_off = moff(row_of(r)); }
-      f2 P[12];
-      float ik[9];
-      load_cam(cam_b, P, ik);
-      warp_issue<true, true, DBG, false>(wc, P, ik, b, prow(row_of(r)), gxr, dispv, pw, [&]() { disp_nxt = ldf(disp_b, moff(row_of(r + 1))); });
-    };
-    auto astep = [&](int t, PendingWarp& fin, PendingWarp& iss) __attribute__((always_inline)) {
-      const int r = t + 1;
-      if (r >= r_first && r <= r_warp_last && !(p.debug & 256)) {  // wave-uniform
-        issue(r + 1, disp_nxt, iss);  // one row beyond the last is clamped into the image and dropped
-        f2 x[3];
-        DerivRow d0;
-        warp_finish<true, true>(fin, x, d0);
-        float (*slot)[64] = s_ring[slot_of(r)];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          slot[2 * k][lane] = x[k].x; slot[2 * k + 1][lane] = x[k].y;
-          slot[6 + 2 * k][lane] = d0.du[k].x; slot[6 + 2 * k + 1][lane] = d0.du[k].y;
-          slot[12 + 2 * k][lane] = d0.dv[k].x; slot[12 + 2 * k + 1][lane] = d0.dv[k].y;
-        }
-      }
-      step_barrier();
-    };
-    PendingWarp pwA, pwB;
-    issue(r_first, ldf(disp_b, moff(row_of(r_first))), pwA);
-    for (int t = t_first; t <= t_last; t += 2) {
-      astep(t, pwA, pwB);
-      astep(t + 1, pwB, pwA);
-    }
-    return;
-  }
-
-  if (role == 1) {
-    // ================================================= S: sums, statistics, decisions, partial planes
-    const float sL = gx == 0 ? 2.0f : 1.0f, sR = gx == W - 1 ? 2.0f : 1.0f;
-    f2 hsA[9], hsB[9], hyA[2], hyB[2];
-    float hzA[2], hzB[2];
-    WarpRow w1;
-    float acc_rw = 0.f, acc_w = 0.f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { hsA[i] = bc(0.f); hsB[i] = bc(0.f); }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { hyA[i] = bc(0.f); hyB[i] = bc(0.f); hzA[i] = 0.f; hzB[i] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) w1.x[k] = bc(0.f);
-    w1.yrg = bc(0.f); w1.yb = 0.f;
-    struct AheadS { float y[3], ident, noise; };
-    const bool has_noise = p.noise != nullptr;
-    auto request = [&](int rr, AheadS& a) {
-      const unsigned pix = (unsigned)(prow(row_of(rr)) * W + gxr);
-      load_rgb(p.target, 1, b, HW, pix, a.y);
-      const unsigned oc = moff(min(max(rr - 1, 0), H - 1));
-      a.ident = ldf(p.ident, oc);
-      const float v = ldf(p.noise ? p.noise : disp_b, oc);
-      a.noise = p.noise ? v : 0.f;
-    };
-    AheadS nxt;
-    request(r_first, nxt);
-    for (int t = t_first; t <= t_last; ++t) {
-      const int r = t;
-      if (r >= r_first && r <= r_warp_last && !(p.debug & 512)) {  // wave-uniform
-        const AheadS cur = nxt;
-        request(r + 1, nxt);
-        const unsigned so_c = moff(min(max(r - 1, 0), H - 1));
-        WarpRow w0;
-        {
-          float (*slot)[64] = s_ring[slot_of(r)];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) w0.x[k] = (f2){slot[2 * k][lane], slot[2 * k + 1][lane]};
-        }
-        w0.yrg = (f2){cur.y[0], cur.y[1]}; w0.yb = cur.y[2];
-        // ---- stage H
-        f2 h[9], hy[2];
-        float hz[2];
-        {
-          f2 in[12];
-          in[0] = w0.yrg; in[1] = w0.yrg * w0.yrg; in[2] = (f2){w0.yb, w0.yb * w0.yb};
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const f2 x = w0.x[k], y = k < 2 ? w0.yrg : bc(w0.yb);
-            in[3 + k * 3 + 0] = x; in[3 + k * 3 + 1] = x * x; in[3 + k * 3 + 2] = x * y;
-          }
-          f2 out[12];
-#pragma unroll
-          for (int g = 0; g < 3; ++g) {
-            float v8[8], r8[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { v8[2 * i] = in[g * 4 + i].x; v8[2 * i + 1] = in[g * 4 + i].y; }
-            hsum3_block8(v8, r8);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) out[g * 4 + i] = (f2){r8[2 * i], r8[2 * i + 1]};
-          }
-          hy[0] = out[0]; hy[1] = out[1]; hz[0] = out[2].x; hz[1] = out[2].y;
-#pragma unroll
-          for (int i = 0; i < 9; ++i) h[i] = out[3 + i];
-        }
-        // ---- stage S: centre row c = r-1
-        const int c = r - 1;
-        const bool c_valid = c >= 0 && c < H && c >= y_lo && c <= y_hi - 1;
-        f2 coef[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) coef[i] = bc(0.f);
-        PixInfo pi0;
-        pi0.rp = 0.f; pi0.w = 0.f; pi0.win = 0;
-        if (c_valid) {  // wave-uniform
-          const f2 syq = (hyA[0] + hy[0]) + hyB[0], syyq = (hyA[1] + hy[1]) + hyB[1];
-          const float syz = (hzA[0] + hz[0]) + hzB[0], syyz = (hzA[1] + hz[1]) + hzB[1];
-          const f2 vyq = fma2(-syq, syq, bc(9.0f) * syyq), d1yq = fma2(syq, syq, bc(kC1s));
-          const float vyz = fma_(-syz, syz, 9.0f * syyz), d1yz = fma_(syz, syz, kC1s);
-          f2 v[3], vc[3], pa[3], pb[3], pcq[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const f2 sx = (hsA[k * 3] + h[k * 3]) + hsB[k * 3], sxx = (hsA[k * 3 + 1] + h[k * 3 + 1]) + hsB[k * 3 + 1],
-                     sxy = (hsA[k * 3 + 2] + h[k * 3 + 2]) + hsB[k * 3 + 2];
-            v[k] = ssim_sums2<true>(sx, k < 2 ? syq : bc(syz), sxx, k < 2 ? vyq : bc(vyz), k < 2 ? d1yq : bc(d1yz), sxy,
-                                    &pa[k], &pb[k], &pcq[k]);
-            vc[k] = (f2){clamp01(v[k].x), clamp01(v[k].y)};
-          }
-          const f2 ssum = (f2){(vc[0].x + vc[0].y) + vc[2].x, (vc[1].x + vc[1].y) + vc[2].y};
-          const f2 l0 = w1.yrg - w1.x[0], l1 = w1.yrg - w1.x[1], l2 = bc(w1.yb) - w1.x[2];
-          const f2 lsum = (f2){(fabsf(l0.x) + fabsf(l0.y)) + fabsf(l2.x), (fabsf(l1.x) + fabsf(l1.y)) + fabsf(l2.y)};
-          const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
-          pi0.win = (rr.y < rr.x) ? 1 : 0;
-          pi0.rp = pi0.win ? rr.y : rr.x;
-          float idn = cur.ident;
-          if (has_noise) idn += cur.noise * 0.00001f;
-          float w = (pi0.rp <= idn) ? 1.0f : 0.0f;
-          if (DBG && out_x && c >= y_lo && c < y_hi)
-            dec_store(p.dbg, dbg_n, MAL_DEC_WIN, so_c, (unsigned)pi0.win | (w != 0.f ? 4u : 0u));
-          if (!in_x) w = 0.f;
-          pi0.w = w;
-          if (out_x && c >= y_lo && c < y_hi) {
-            if (p.min_reproj) stf(p.min_reproj, so_c, pi0.rp);
-            acc_rw += pi0.rp * w;
-            acc_w += w;
-          }
-          const float kk = -w * (0.85f / 3.0f) * 0.5f;
-          const float kk0 = pi0.win == 0 ? kk : 0.f, kk1 = pi0.win != 0 ? kk : 0.f;
-          const f2 g0 = (f2){vc[0].x == v[0].x ? kk0 : 0.f, vc[0].y == v[0].y ? kk0 : 0.f};
-          const f2 g1 = (f2){vc[1].x == v[1].x ? kk1 : 0.f, vc[1].y == v[1].y ? kk1 : 0.f};
-          const f2 g2 = (f2){vc[2].x == v[2].x ? kk0 : 0.f, vc[2].y == v[2].y ? kk1 : 0.f};
-          const f2 gk[3] = {g0, g1, g2};
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            coef[k * 3 + 0] = gk[k] * pa[k];
-            coef[k * 3 + 1] = gk[k] * pb[k];
-            coef[k * 3 + 2] = gk[k] * pcq[k];
-          }
-        }
-        // ---- stage HC: horizontal sums of the partial planes of row c -> LDS, with the row's decision
-        {
-          float (*hslot)[64] = s_hc[r & 1];
-#pragma unroll
-          for (int g = 0; g < 3; ++g) {
-            float l6[6], c6[6], t6[6], r6[6];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              const f2 vv = coef[g * 3 + i], l = vv * bc(sL), rr = vv * bc(sR);
-              l6[2 * i] = l.x; l6[2 * i + 1] = l.y; c6[2 * i] = vv.x; c6[2 * i + 1] = vv.y; t6[2 * i] = rr.x; t6[2 * i + 1] = rr.y;
-            }
-            hsum3_block6(l6, c6, t6, r6);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) hslot[g * 6 + i][lane] = r6[i];
-          }
-          // w is 0 or 1 here (automask, no external mask): the winner rides in the low mantissa bit
-          s_pi[(c + 8) & 3][lane] = __builtin_bit_cast(unsigned, pi0.w) | (unsigned)pi0.win;
-        }
-        // ---- roll
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { hsA[i] = hsB[i]; hsB[i] = h[i]; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { hyA[i] = hyB[i]; hyB[i] = hy[i]; hzA[i] = hzB[i]; hzB[i] = hz[i]; }
-        w1 = w0;
-      }
-      step_barrier();
-    }
-    const double r0 = wave_sum_d((double)acc_rw), r1 = wave_sum_d((double)acc_w);
-    if (lane == 0) {
-      double* o = p.block_sums + (size_t)task * 8;
-      o[0] = r0; o[1] = r1; o[2] = 0.0; o[3] = 0.0;
-    }
-    return;
-  }
-
-  // =================================================== G: gradient rows
-  {
-    const cfloat* cam_b = (const cfloat*)(p.cam + (size_t)b * kCamFloats);
-    f2 hcA[9], hcB[9], gP[12];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { hcA[i] = bc(0.f); hcB[i] = bc(0.f); }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) gP[i] = bc(0.f);
-    struct AheadG { float y[3], disp; };
-    auto request = [&](int q, AheadG& a) {  // target and disparity of gradient row q
-      const int rq = row_of(q);
-      load_rgb(p.target, 1, b, HW, (unsigned)(prow(rq) * W + gxr), a.y);
-      a.disp = ldf(disp_b, moff(rq));
-    };
-    AheadG nxt;
-    request(r_first - 2, nxt);
-    for (int t = t_first; t <= t_last; ++t) {
-      const int r = t - 1;  // march_body's iteration: gradient row q = r-2, partial planes of row c = r-1
-      if (r >= r_first && r <= r_last && !(p.debug & 1024)) {  // wave-uniform
-        const AheadG cur = nxt;
-        request(r - 1, nxt);
-        const int q = r - 2, c = r - 1;
-        f2 hc[9];
-        if (r <= r_warp_last) {
-          float (*hslot)[64] = s_hc[r & 1];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) hc[i] = (f2){hslot[2 * i][lane], hslot[2 * i + 1][lane]};
-        } else {
-#pragma unroll
-          for (int i = 0; i < 9; ++i) hc[i] = bc(0.f);
-        }
-        const bool own_q = q >= y_lo && q < y_hi;
-        if (q >= y_lo - 1 && q < y_hi + 1 && (unsigned)q < (unsigned)H) {  // wave-uniform
-          PixInfo pq;
-          pq.rp = 0.f; pq.w = 0.f; pq.win = 0;
-          if (q <= y_hi - 1) {
-            const unsigned u = s_pi[(q + 8) & 3][lane];
-            pq.win = (int)(u & 1u);
-            pq.w = __builtin_bit_cast(float, u & ~1u);
-          }
-          const unsigned so_q = moff(q);
-          WarpRow wq;
-          DerivRow dq;
-          {
-            float (*slot)[64] = s_ring[slot_of(q)];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              wq.x[k] = (f2){slot[2 * k][lane], slot[2 * k + 1][lane]};
-              dq.du[k] = (f2){slot[6 + 2 * k][lane], slot[6 + 2 * k + 1][lane]};
-              dq.dv[k] = (f2){slot[12 + 2 * k][lane], slot[12 + 2 * k + 1][lane]};
-            }
-          }
-          wq.yrg = (f2){cur.y[0], cur.y[1]}; wq.yb = cur.y[2];
-          const float wyd = (q == H - 2) ? 2.0f : 1.0f;
-          const float lw = pq.w * (0.15f / 3.0f);
-          const float lw0 = pq.win == 0 ? lw : 0.f, lw1 = pq.win != 0 ? lw : 0.f;
-          const f2 lwk[3] = {bc(lw0), bc(lw1), (f2){lw0, lw1}};
-          f2 g[3];
-          const bool w1_ = pq.win != 0;
-          const f2 dwin = (w1_ ? wq.x[1] : wq.x[0]) - wq.yrg;
-          const float dwb = (w1_ ? wq.x[2].y : wq.x[2].x) - wq.yb;
-          const f2 sgrg = (f2){sgnf(dwin.x), sgnf(dwin.y)};
-          const float sgb = sgnf(dwb);
-          if (DBG && out_x && own_q)
-            dec_store(p.dbg, dbg_n, MAL_DEC_L1, so_q,
-                      (unsigned)(int)(sgrg.x + 1.0f) | ((unsigned)(int)(sgrg.y + 1.0f) << 2) | ((unsigned)(int)(sgb + 1.0f) << 4));
-          const f2 sgk[3] = {sgrg, sgrg, bc(sgb)};
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const f2 SA = fma2(bc(wyd), hc[k * 3], hcA[k * 3]);
-            const f2 SB = fma2(bc(wyd), hc[k * 3 + 1], hcA[k * 3 + 1]);
-            const f2 SC = fma2(bc(wyd), hc[k * 3 + 2], hcA[k * 3 + 2]);
-            const f2 xq = wq.x[k], yq = k < 2 ? wq.yrg : bc(wq.yb);
-            g[k] = fma2(lwk[k], sgk[k], fma2(SC, yq, fma2(SB, xq, SA)));
-          }
-          // the point, its projection (u, v, 1/z: the same instructions as in the warp) and the depth derivatives are re-derived
-          const float depth = depth_of(cur.disp, p.min_disp, p.range);
-          const float ddepth = -(depth * depth) * p.range;
-          float ray[3], ik[9], X[3];
-          f2 P[12];
-          load_cam(cam_b, P, ik);
-          ray_of(ik, (float)gxr, (float)prow(q), ray);
-          X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
-          const Sample2 sq = project2(P, X, p.eps, W, H, p.convention, 0.f, 0.f);  // only u, v, rz are used
-          const f2 pq_u = sq.u, pq_v = sq.v, pq_rz = sq.rz;
-          const f2 c0 = P[0] * bc(ray[0]) + P[1] * bc(ray[1]) + P[2] * bc(ray[2]);
-          const f2 c1 = P[4] * bc(ray[0]) + P[5] * bc(ray[1]) + P[6] * bc(ray[2]);
-          const f2 c2 = P[8] * bc(ray[0]) + P[9] * bc(ray[1]) + P[10] * bc(ray[2]);
-          const f2 alq = (c0 - pq_u * c2) * pq_rz * bc(ddepth);
-          const f2 beq = (c1 - pq_v * c2) * pq_rz * bc(ddepth);
-          const f2 tu0 = g[0] * dq.du[0], tu1 = g[1] * dq.du[1], tu2 = g[2] * dq.du[2];
-          const f2 tv0 = g[0] * dq.dv[0], tv1 = g[1] * dq.dv[1], tv2 = g[2] * dq.dv[2];
-          const f2 gu = (f2){(tu0.x + tu0.y) + tu2.x, (tu1.x + tu1.y) + tu2.y};
-          const f2 gv = (f2){(tv0.x + tv0.y) + tv2.x, (tv1.x + tv1.y) + tv2.y};
-          const f2 gd = gu * alq + gv * beq;
-          const float gdisp = gd.x + gd.y;
-          if (out_x) {
-            const f2 a0 = gu * pq_rz, a1 = gv * pq_rz, a2 = -(gu * pq_u + gv * pq_v) * pq_rz;
-            const f2 a[3] = {a0, a1, a2};
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-              for (int j = 0; j < 3; ++j) gP[i * 4 + j] = fma2(a[i], bc(X[j]), gP[i * 4 + j]);
-              gP[i * 4 + 3] += a[i];
-            }
-            if (!own_q) {
-              const int py = prow(q), sq = py / p.rows;
-              const unsigned which = (py == sq * p.rows) ? 0u : 1u;
-              stf(p.bnd, ((unsigned)((b * p.segs + sq) * 2) + which) * (unsigned)W * 4u + (unsigned)gxr * 4u, gdisp);
-            } else stf(p.g_reproj, so_q, gdisp);
-          }
-        }
-        // roll the partial-plane sums
-        {
-          const float wyu = (c == 0) ? 2.0f : 1.0f;
-#pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            hcA[i] = hcB[i] + hc[i];
-            hcB[i] = bc(wyu) * hc[i];
-          }
-        }
-      }
-      step_barrier();
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const float v0 = wave_sum(gP[i].x), v1 = wave_sum(gP[i].y);
-      if (lane == 0) { p.block_gP[(size_t)task * 24 + i] = v0; p.block_gP[(size_t)task * 24 + 12 + i] = v1; }
-    }
-  }
-}
-
+#include "experiments/march3.inc"
 #endif  // MAL_EXPERIMENTS
 
 // ---- identity term + texel packing: min over the two raw sources of r(src_f, target)

@@ -10,7 +10,7 @@ procs = []
 tmp = os.path.join(B.LIBDIR, "_" + name)
 os.makedirs(tmp, exist_ok=True)
 for s in B.SOURCES:
-    o = os.path.join(tmp, s.replace(".hip", ".o"))
+    o = os.path.join(tmp, os.path.basename(s).replace(".hip", ".o"))
     objs.append(o)
     procs.append(subprocess.Popen([hipcc] + B.FLAGS + extra + ["-c", os.path.join(B.CSRC, s), "-o", o]))
 for p in procs:
