@@ -435,6 +435,11 @@ typedef struct mal_ms_args {
   const uint8_t *syn_region[MAL_MS_MAX_SCALES];
   float *g_syn_region_m1[MAL_MS_MAX_SCALES], *g_syn_region_p1[MAL_MS_MAX_SCALES];
   int warp_sample_stride, syn_sparse;
+  /* parity instrumentation (tests), per scale: the per-pixel decisions of that scale's gradient passes, as mal_step_args.
+   * dec_teacher / dec_student (int32 (MAL_DEC_PLANES,B,H,W) each; MAL_DEC_WIN, _TAP0/1, _L1 are written -- the smoothness signs of
+   * this path are those of the raw disparity differences at the scale's own size, which a checker forms from the inputs
+   * exactly).  NULL (the default): the specialised, uninstrumented kernels run; results are bit-identical either way. */
+  uint32_t *dec_teacher[MAL_MS_MAX_SCALES], *dec_student[MAL_MS_MAX_SCALES];
 } mal_ms_args;
 size_t mal_ms_workspace_bytes(int B, int H, int W, int sclm);
 int mal_loss_multiscale_warp(const mal_ms_args* args); /* MAL_STEP_TEMPORAL only */

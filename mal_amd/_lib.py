@@ -154,7 +154,7 @@ class MsArgs(C.Structure):
                 [("ws_bytes", sz), ("stream", vp)] +
                 [(n, vp * 4) for n in ("warp_m1", "warp_p1", "syn_m1", "syn_p1", "g_syn_m1", "g_syn_p1", "g_warp_m1", "g_warp_p1",
                                        "syn_region", "g_syn_region_m1", "g_syn_region_p1")] +
-                [("warp_sample_stride", i32), ("syn_sparse", i32)])
+                [("warp_sample_stride", i32), ("syn_sparse", i32), ("dec_teacher", vp * 4), ("dec_student", vp * 4)])
 
 
 class DrArgs(C.Structure):

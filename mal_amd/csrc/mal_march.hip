@@ -139,24 +139,22 @@ struct PendingWarp {
   f2 ex, ey, tx, ty;           // DERIV
   f2 mx, my, du_ddisp, dv_ddisp;
   f2 u, v, rz;                 // POSE: the projection, kept for the pose terms of the gradient row
-  float pf[2];                 // MAL_GATHER_PREFETCH: a dword of the source row the NEXT iteration's taps will newly touch
 };
 
 // the parameter-block fields the warp needs, read together at the top of an iteration (one scalar-load wait)
 struct WarpConsts {
   const float* src[2]; int packed, debug, W, H, convention; float min_disp, range, eps, rw, rh;
   unsigned* dbg; unsigned dbg_n, dbg_off; bool dbg_on;  // DBG: decision planes, plane stride, this pixel's byte offset, lane writes
-  bool walk_up;                                         // the task walks its rows bottom-up (odd segments): the next row is the one above
 };
 // decision plane `plane` (mal_hip.h MAL_DEC_*), byte offset `boff` of the pixel inside a (B,1,H,W) map
 MAL_DEV void dec_store(unsigned* dbg, unsigned n, int plane, unsigned boff, unsigned v) {
   *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dbg + (size_t)plane * n) + boff) = v;
 }
 
-#ifndef MAL_GATHER_PREFETCH
-#define MAL_GATHER_PREFETCH 0
-#endif
 // projection, tap weights and the eight gathers
+// (Round 5 tried a next-row PREFETCH here for the cold regime -- one dword per frame of the source row the next iteration's taps
+// will newly touch, issued behind the gathers, dropped at the top of the next iteration: +2 vector-memory instructions per row
+// made the teacher's pass 9 % slower warm and 12 % slower cold, profiles/r05_gather_prefetch_ab.txt; removed.)
 // LEAN (the specialised passes of the whole-step lists: packed texels, H*W*12 < 2^24 checked by march_launch): the byte
 // offsets of the four taps are formed in fp32 -- every product and sum below 2^24 is exact -- instead of with 32-bit integer
 // multiplies (v_mul_lo_u32 is quarter rate: the compiler does not keep __umul24 for operands it cannot bound)
@@ -174,7 +172,6 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
   const f2 x0f = (f2){floorf(s.ix.x), floorf(s.ix.y)}, y0f = (f2){floorf(s.iy.x), floorf(s.iy.y)};
   int oo[2][4];
   unsigned bo12[2][4];  // LEAN: byte offsets of the taps inside the sample's texel image
-  unsigned bopf[2] = {0u, 0u};
   if (LEAN) {
     const float xm = (float)(W - 1), ym = (float)(H - 1), w12 = (float)(W * kTexel * 4);
     const f2 x1f = (f2){fminf(x0f.x + 1.0f, xm), fminf(x0f.y + 1.0f, xm)};  // x0+1 == W only with weight 0
@@ -184,17 +181,6 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       bo12[f][0] = (unsigned)o00[f]; bo12[f][1] = (unsigned)o01[f]; bo12[f][2] = (unsigned)o10[f]; bo12[f][3] = (unsigned)o11[f];
-    }
-    if (MAL_GATHER_PREFETCH) {
-      // The warp is smooth: the taps of the next image row land one source row further along -- its top tap row is this
-      // iteration's bottom one (an L2 hit by then), its bottom tap row is NEW and would be fetched from HBM while the wave sits
-      // in the blend's wait (two waves per SIMD hide little of a DRAM round trip).  One dword per frame of that row, at this
-      // lane's column, requested now and consumed (dropped) at the top of the next iteration, brings its lines into the L2 a
-      // whole iteration early.  Clamped to the image: a valid address always, a useless but harmless load at the border.
-      const f2 ypf = p.walk_up ? (f2){fmaxf(y0f.x - 1.0f, 0.0f), fmaxf(y0f.y - 1.0f, 0.0f)}
-                               : (f2){fminf(y1f.x + 1.0f, ym), fminf(y1f.y + 1.0f, ym)};
-      const f2 opf = ypf * bc(w12) + c0;
-      bopf[0] = (unsigned)opf.x; bopf[1] = (unsigned)opf.y;
     }
   }
 #pragma unroll
@@ -231,14 +217,6 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
         w.t[f][k] = make_texel(ldf(p0, bo), ldf(p1, bo), ldf(p2, bo));
       }
     }
-  }
-  w.pf[0] = 0.f; w.pf[1] = 0.f;
-  if (LEAN && MAL_GATHER_PREFETCH) {  // behind the gathers: the blend's wait counts them as younger and does not wait for them
-    // (the scheduler otherwise hoists them in FRONT of the gathers -- in-order retirement then makes the blend wait for these
-    // HBM misses too; the mask lets ALU and LDS instructions cross, no vector-memory one)
-    __builtin_amdgcn_sched_barrier(0x0387);
-#pragma unroll
-    for (int f = 0; f < 2; ++f) w.pf[f] = ldf(p.src[f] + (size_t)b * HW * kTexel, bopf[f]);
   }
   w.tx = s.ix - x0f; w.ex = bc(1.0f) - w.tx; w.ty = s.iy - y0f; w.ey = bc(1.0f) - w.ty;
   w.nw = w.ey * w.ex; w.ne = w.ey * w.tx; w.sw = w.ty * w.ex; w.se = w.ty * w.tx;
@@ -636,7 +614,6 @@ MAL_DEV void march_body() {
   f2 y2rg = bc(0.f);
   float y2b = 0.f;  // target pixel of row r-2
   float dv_1 = 0.f, dv_2 = 0.f;  // disparity of rows r-1, r-2 (the pose terms of the gradient row re-project it)
-  float pf_prev[2] = {0.f, 0.f};  // MAL_GATHER_PREFETCH: last iteration's prefetched dwords (see warp_issue)
   // ================= epilogue terms of output row (EPI): row q = r-2 with GRAD, c without ===
   auto epilogue = [&](CParams& p, int r, const PixInfo& pq, float le_disp, float le_mono, float le_mr, float le_er,
                       unsigned so_c, unsigned so_q, bool has_mdisp, bool has_er, float le_ensd) __attribute__((always_inline)) {
@@ -830,7 +807,7 @@ MAL_DEV void march_body() {
     wc.convention = CONV >= 0 ? CONV : p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
     wc.rw = norm_rw; wc.rh = norm_rh;
     wc.dbg = DBG ? p.dbg : nullptr; wc.dbg_n = (unsigned)(p.B * HW);
-    wc.dbg_off = 0; wc.dbg_on = false; wc.walk_up = flip;
+    wc.dbg_off = 0; wc.dbg_on = false;
     if (DBG) { wc.dbg_on = r >= y_lo && r < y_hi && out_x; wc.dbg_off = moff(row_of(r)); }
 #ifdef MAL_STAGE_TIMERS
     auto tick = [&](int i) {
@@ -855,7 +832,6 @@ MAL_DEV void march_body() {
     // the issue phase (projection, operand requests, gathers) is what the rest of the iteration waits for:
     // run it at raised wave priority so the sibling wave's arithmetic does not delay it (measured -1.7 %)
     __builtin_amdgcn_s_setprio(3);
-    if (LEAN && MAL_GATHER_PREFETCH) asm volatile("" : : "v"(pf_prev[0]), "v"(pf_prev[1]));  // the prefetched dwords: waited for, dropped
     PendingWarp pw;
     {
       f2 P[12];
@@ -870,7 +846,6 @@ MAL_DEV void march_body() {
 #endif
     }
     __builtin_amdgcn_s_setprio(0);
-    if (LEAN && MAL_GATHER_PREFETCH) { pf_prev[0] = pw.pf[0]; pf_prev[1] = pw.pf[1]; }
     tick(1); MAL_MARK(1);  // small loads, prefetch, projection, gathers issued
     // ---- in the shadow of the gathers (see SHADOW above)
     f2 sh_hy[2] = {bc(0.f), bc(0.f)}, sh_l15 = bc(0.f);

@@ -606,6 +606,7 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
       return march_launch(p, MAL_F_AUTOMASK | packed, st);
     }
     p.g_reproj = w.G_r[0][s]; p.bnd = g_march_halo1 ? w.bnd[0][s] : nullptr;
+    p.dbg = a->dec_teacher[s];
     return march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | packed, st);
   };
   auto student = [&](int s, hipStream_t q) -> int {
@@ -635,6 +636,7 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
     p.block_sums = w.bs[1][s]; p.block_gP = w.bgP[s];
     p.cam = w.cam; p.cam_ready = 1;
     p.no_ssim = (a->flags & MAL_STEP_NO_SSIM) ? 1 : 0;
+    p.dbg = a->dec_student[s];
     return march_launch(p, MAL_F_GRAD | MAL_F_EPILOGUE | packed, q);
   };
   // Without the hint the two networks' passes of a scale stay next to each other.  With it: the teachers' forward passes first;
@@ -777,6 +779,7 @@ extern "C" int mal_loss_multiscale_bwd(const mal_ms_args* a) {
       p.ident = w.ident;  // unused by the TEMPORAL instantiation (the launch checks the flag combination only)
       p.g_reproj = w.G_r[0][s]; p.bnd = g_march_halo1 ? w.bnd[0][s] : nullptr;
       p.forced_w = w.w_t[s]; p.forced_arg = w.arg_t[s]; p.g_color[0] = a->g_warp_m1[s]; p.g_color[1] = a->g_warp_p1[s];
+      p.dbg = a->dec_teacher[s];
       rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
       if (rc) return rc;
       mp.bgP[s] = w.bgP[s]; mp.per_sample = p.strips * p.segs;

@@ -490,6 +490,7 @@ class MultiScaleLossFn(Function):
         colors, colors_s, K, inv_K, cmask, keep, lowest, noises = consts
         min_depth, max_depth, sclm, aug_is_mask, philox, want_maps = cfg[:6]
         hint = cfg[6] if len(cfg) > 6 else None  # --temporal: (image_synthesis, inputs, mono_outputs)
+        want_dec = len(cfg) > 9 and cfg[9]         # parity instrumentation (tests): per-scale decision planes
         S = sclm + 1
         req, p = ops._req, ops._p
         tens = [req(t, "leaf") for t in leaves]
@@ -529,6 +530,13 @@ class MultiScaleLossFn(Function):
             cm = torch.empty((B, H, W), dtype=torch.float32, device=dev)
             a.consistency_mask_out = p(cm)
             outs.append(cm)
+        decs = []
+        if want_dec:  # one (MAL_DEC_PLANES,B,H,W) int32 block per network and scale (include/mal_hip.h MAL_DEC_*)
+            decs = [torch.zeros((L.DEC_PLANES, B, H, W), dtype=torch.int32, device=dev) for _ in range(2 * S)]
+            for s in range(S):
+                a.dec_teacher[s], a.dec_student[s] = p(decs[s]), p(decs[S + s])
+            outs += decs
+        ctx.n_dec = len(decs)
         ws = _workspace_ms(dev, B, H, W, sclm)
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
         hints = []
@@ -580,7 +588,8 @@ class MultiScaleLossFn(Function):
         return (None, None, *grads)
 
 
-def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_maps=True, image_synthesis=None):
+def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_maps=True, image_synthesis=None,
+                         want_decisions=False):
     """process_batch's loss half WITHOUT ``--distil`` (manydepth/trainer.py:573-612 with ``compute_losses``, :1248-1475,
     for both networks) over scales 0..``opt.sclm`` in one call per direction.  Reads ``inputs[("color", f, 0)]``,
     ``("color", 0, s)``, ``("K", 0)``, ``("inv_K", 0)``; ``mono_outputs[("disp", s)]``, ``("axisangle", 0, f)``,
@@ -592,7 +601,9 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
     scale's min takes the two synthesised candidates in (:1279-1283; a scale whose own call reported none then raises the
     ``KeyError`` upstream raises); ``mono_outputs`` receives ``("color", f, s)``, ``("syn", f, s)`` and ``"has_ins"``.
     Returns (losses, mono_losses): ``losses`` as process_batch leaves it (the teacher's entries added to the
-    student's, :614-616; ``losses["loss"]`` carries the gradient), ``mono_losses`` the teacher's own."""
+    student's, :614-616; ``losses["loss"]`` carries the gradient), ``mono_losses`` the teacher's own.
+    ``want_decisions`` (tests): a third value ``{"dec_teacher": [per scale], "dec_student": [per scale]}`` -- the per-pixel
+    decisions of every scale's gradient passes (int32 (MAL_DEC_PLANES,B,H,W) each, include/mal_hip.h)."""
     from . import config, loss_utils
     sclm = int(getattr(opt, "sclm", 0))
     temporal = bool(getattr(opt, "temporal", False))
@@ -633,12 +644,14 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
            (image_synthesis, inputs, mono_outputs) if temporal else None, bool(getattr(opt, "no_ssim", False)),
            (L.STEP_NO_MOTION_MASK if getattr(opt, "disable_motion_masking", False) else 0) |
            (L.STEP_NO_AUG if getattr(opt, "no_matching_augmentation", False) else 0) |
-           (L.STEP_ENSEMBLE if getattr(opt, "ensemble", False) else 0))
+           (L.STEP_ENSEMBLE if getattr(opt, "ensemble", False) else 0), bool(want_decisions))
     leaves = [mono_outputs[("disp", s)] for s in range(sclm + 1)] + [outputs[("disp", s)] for s in range(sclm + 1)] + \
              [aa[-1], tr[-1], aa[1], tr[1]]
     res = MultiScaleLossFn.apply(consts, cfg, *leaves)
     total, v = res[0].reshape(()), res[1]
-    if len(res) > 2:
+    n_dec = 2 * (sclm + 1) if want_decisions else 0
+    decs = res[len(res) - n_dec:] if n_dec else ()
+    if len(res) - n_dec > 2:
         outputs["consistency_mask"] = res[2]
     elif want_maps and outputs.get("lowest_cost") is not None and getattr(opt, "disable_motion_masking", False):
         # process_batch multiplies the matching mask in whatever the loss does with it (trainer.py:592-593); the passes did not
@@ -658,4 +671,6 @@ def loss_step_multiscale(opt, inputs, mono_outputs, outputs, noises=None, want_m
             losses["ensemble_loss/%d" % s] = v[44 + s]
         mono_losses["reproj_loss/%d" % s], mono_losses["loss/%d" % s] = v[s * 4], v[s * 4 + 3]
     losses["main/loss"] = v[33]
+    if want_decisions:
+        return losses, mono_losses, {"dec_teacher": list(decs[:sclm + 1]), "dec_student": list(decs[sclm + 1:])}
     return losses, mono_losses

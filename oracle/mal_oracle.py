@@ -247,8 +247,9 @@ def generate_images_pred(opt, inputs, outputs, is_multi=False, synth=None, aten=
     v1_multiscale, a1, then for f in frame_ids[1:]: a2 -> a3 -> a4.  T is detached for
     the multi-frame (student) pass (:1107-1109).  ``synth(inputs, outputs, scale) ->
     bool`` stands in for dyn_utils.image_synthesis (:1161-1165); returns has_ins.
-    ``forced`` (decision-forced parity tests, scale 0 only): {"taps": {f: (x0, y0, clipx, clipy)}} -- the bilinear
-    taps and border clips are taken as given (aten_restated.grid_sample_forced_taps).
+    ``forced`` (decision-forced parity tests): {"taps": {f: (x0, y0, clipx, clipy)}} -- the bilinear taps and border
+    clips are taken as given (aten_restated.grid_sample_forced_taps) -- for scale 0, or a list of such dicts, one per scale
+    (the four-scale path: every scale warps the full-resolution sources with its own upsampled disparity).
     """
     has_ins = False
     for scale in range(opt.sclm + 1):
@@ -269,8 +270,9 @@ def generate_images_pred(opt, inputs, outputs, is_multi=False, synth=None, aten=
             grid = project_3d(pts, inputs[("K", src_scale)], T, H, W)
             outputs[("sample", f, scale)] = grid
             if forced is not None:
+                fs = forced[scale] if isinstance(forced, (list, tuple)) else forced
                 outputs[("color", f, scale)] = AR.grid_sample_forced_taps(inputs[("color", f, src_scale)], grid,
-                                                                          *forced["taps"][f])
+                                                                          *fs["taps"][f])
             else:
                 outputs[("color", f, scale)] = grid_sample_border(inputs[("color", f, src_scale)], grid, aten=aten)
             if not opt.disable_automasking:
@@ -405,9 +407,12 @@ def compute_main_losses(inputs, outputs, mono_reproj, ensemble_reproj, opt, w_li
     return losses, new_w, loss_list
 
 
-def compute_losses(opt, inputs, outputs, is_multi=False, has_ins=False, noises=None, aten=True):
+def compute_losses(opt, inputs, outputs, is_multi=False, has_ins=False, noises=None, aten=True, forced=None):
     """manydepth/trainer.py:1248-1475: the non-distillation fallback, looping scales
-    0..sclm; per-scale loss / 2**scale for smoothness, total / (sclm+1)."""
+    0..sclm; per-scale loss / 2**scale for smoothness, total / (sclm+1).
+    ``forced`` (decision-forced parity tests): one dict per scale, {"win": long (B,1,H,W), "l1": (B,3,H,W), "smooth": (sx, sy)
+    at the scale's own size, and for the teacher "automask": (B,1,H,W)} -- the argmin over the candidates, the signs inside
+    the winner's L1 term and inside the smoothness term, and the automask comparison are taken as given."""
     losses = {}
     total = 0
     for scale in range(opt.sclm + 1):
@@ -416,19 +421,21 @@ def compute_losses(opt, inputs, outputs, is_multi=False, has_ins=False, noises=N
         color = inputs[("color", 0, scale)]
         target = inputs[("color", 0, src_scale)]
         fids = opt.frame_ids[1:]
-        R = [compute_reprojection_loss(outputs[("color", f, scale)], target, opt.no_ssim, aten) for f in fids]
+        fd = None if forced is None else forced[scale]
+        l1s = None if fd is None else fd.get("l1")  # the winner's signs, applied to every candidate: the forced argmin picks the winner's value only
+        R = [compute_reprojection_loss(outputs[("color", f, scale)], target, opt.no_ssim, aten, l1s) for f in fids]
         if (not is_multi) and opt.temporal and has_ins:
-            R += [compute_reprojection_loss(outputs[("syn", f, scale)], target, opt.no_ssim, aten) for f in fids]
+            R += [compute_reprojection_loss(outputs[("syn", f, scale)], target, opt.no_ssim, aten, l1s) for f in fids]
         R = torch.cat(R, 1)
         I = torch.cat([compute_reprojection_loss(inputs[("color", f, src_scale)], target, opt.no_ssim, aten)
                        for f in fids], 1)
         ident = torch.min(I, dim=1, keepdim=True)[0]
-        rp = torch.min(R, dim=1, keepdim=True)[0]
+        rp = torch.min(R, dim=1, keepdim=True)[0] if fd is None else torch.gather(R, 1, fd["win"])
         if not opt.disable_automasking:
             nz = None if noises is None else noises[scale]
             ident = ident + _draw_noise(ident.shape, nz) * 0.00001
         # NB (:1309-1310) the identity term is passed even with disable_automasking
-        mask = compute_loss_masks(rp, ident)
+        mask = compute_loss_masks(rp, ident) if (fd is None or is_multi) else fd["automask"].to(rp.dtype)
         if is_multi:
             mask = torch.ones_like(mask)
             if not opt.disable_motion_masking:
@@ -452,7 +459,7 @@ def compute_losses(opt, inputs, outputs, is_multi=False, has_ins=False, noises=N
                 losses["ensemble_loss/{}".format(scale)] = ensemble
         losses["reproj_loss/{}".format(scale)] = reproj
         loss = reproj + consistency + ensemble
-        loss = loss + opt.disparity_smoothness * normalized_smooth_loss(disp, color) / (2 ** scale)
+        loss = loss + opt.disparity_smoothness * normalized_smooth_loss(disp, color, None if fd is None else fd["smooth"]) / (2 ** scale)
         total = total + loss
         losses["loss/{}".format(scale)] = loss
     losses["loss"] = total / (opt.sclm + 1)

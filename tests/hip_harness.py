@@ -281,3 +281,134 @@ def sample_ambiguous(sample, H, W, tol=5e-4):
 def oracle_fp64_grads(batch, opt_kw, n0, n1):
     b64 = {k: (v.double() if torch.is_tensor(v) and v.dtype == torch.float32 else v) for k, v in batch.items()}
     return run_oracle(b64, opt_kw, n0.double(), n1.double())["grads"]
+
+
+# ------------------------------------------------------------------ the four-scale path (mal_loss_multiscale_*), decision-exact
+def ms_build(batch, dev, sclm, double=False):
+    """the reference's dict contract for ``sclm`` + 1 scales: lower scales are pooled copies (the shipped decoder emits scale 0
+    only); leaves: disp_teacher / disp_student per scale and the four pose vectors"""
+    cast = (lambda t: t.double()) if double else (lambda t: t)
+    b = {k: (cast(v) if torch.is_tensor(v) and v.dtype == torch.float32 else v) for k, v in batch.items()}
+    pose = O.transformation_from_parameters if str(dev) == "cpu" else (lambda a, t, inv: None)
+    inputs, mono_outputs, outputs, leaves = to_dicts(b, pose, device=None if str(dev) == "cpu" else dev)
+    for s in range(1, sclm + 1):
+        inputs[("color", 0, s)] = cast(torch.nn.functional.avg_pool2d(batch["color0"], 2 ** s)).to(dev)
+        for name, outs in (("disp_teacher", mono_outputs), ("disp_student", outputs)):
+            leaf = cast(torch.nn.functional.avg_pool2d(batch[name], 2 ** s)).to(dev).clone().requires_grad_(True)
+            leaves["%s_s%d" % (name, s)] = leaf
+            outs[("disp", s)] = leaf
+    return inputs, mono_outputs, outputs, leaves
+
+
+def ms_run_oracle(batch, kw, nt, ns, matching, synth=None, forced=None, double=False):
+    """process_batch without --distil over scales 0..sclm on the CPU (trainer.py:573-612 calling compute_losses for both
+    networks).  ``forced``: {"teacher": [per scale], "student": [per scale], "cmask"} (oracle.mal_oracle.compute_losses)."""
+    opt = O.default_opt(**kw)
+    sclm = opt.sclm
+    cast = (lambda t: t.double()) if double else (lambda t: t)
+    inputs, mono_outputs, outputs, leaves = ms_build(batch, "cpu", sclm, double=double)
+    if not matching:
+        outputs.pop("lowest_cost")
+    ft, fs = (None, None) if forced is None else (forced["teacher"], forced["student"])
+    has_ins = O.generate_images_pred(opt, inputs, mono_outputs, synth=synth, forced=ft)
+    lt = O.compute_losses(opt, inputs, mono_outputs, is_multi=False, has_ins=has_ins, noises=[cast(n.clone()) for n in nt], forced=ft)
+    for key in list(mono_outputs.keys()):
+        if isinstance(key, tuple) and key[0] in ("depth", "disp"):
+            outputs[("mono_" + key[0],) + tuple(key[1:])] = mono_outputs[key]
+    if matching:  # trainer.py:592-593
+        outputs["consistency_mask"] = (outputs["consistency_mask"] * O.compute_matching_mask(outputs) if forced is None
+                                       else forced["cmask"].to(outputs["consistency_mask"].dtype))
+    O.generate_images_pred(opt, inputs, outputs, is_multi=True, forced=fs)
+    ls = O.compute_losses(opt, inputs, outputs, is_multi=True, noises=[cast(n.clone()) for n in ns], forced=fs)
+    (lt["loss"] + ls["loss"]).backward()
+    res = dict(teacher={k: float(v.detach()) for k, v in lt.items()}, student={k: float(v.detach()) for k, v in ls.items()},
+               total=float((lt["loss"] + ls["loss"]).detach()), consistency_mask=outputs["consistency_mask"].detach().numpy(),
+               grads={k: (t.grad if t.grad is not None else torch.zeros_like(t)).numpy() for k, t in leaves.items()}, scales=[])
+    with torch.no_grad():  # what the tie analysis needs, per scale
+        target = inputs[("color", 0, 0)]
+        I = torch.cat([O.compute_reprojection_loss(inputs[("color", f, 0)], target, opt.no_ssim) for f in (-1, 1)], 1)
+        for s in range(sclm + 1):
+            tp = [mono_outputs[("color", f, s)] for f in (-1, 1)]
+            if has_ins and opt.temporal:
+                tp += [mono_outputs[("syn", f, s)] for f in (-1, 1)]
+            sp = [outputs[("color", f, s)] for f in (-1, 1)]
+            res["scales"].append(dict(
+                t_cands=torch.cat([O.compute_reprojection_loss(c, target, opt.no_ssim) for c in tp], 1).numpy(),
+                s_cands=torch.cat([O.compute_reprojection_loss(c, target, opt.no_ssim) for c in sp], 1).numpy(),
+                ident=I.min(1, keepdim=True)[0].numpy(), t_preds=[c.numpy() for c in tp], s_preds=[c.numpy() for c in sp],
+                t_sample={f: mono_outputs[("sample", f, s)].numpy() for f in (-1, 1)},
+                s_sample={f: outputs[("sample", f, s)].numpy() for f in (-1, 1)}))
+        res["mono_depth0"] = mono_outputs[("depth", 0, 0)].numpy()
+    return res
+
+
+def _raw_smooth_signs(disp):
+    """what the kernels take: the signs of the RAW disparity's first differences at the map's own size (the positive
+    1 / (mean + 1e-7) is applied afterwards) -- exact in fp32, so a checker forms them from the inputs"""
+    return torch.sign(disp[:, :, :, :-1] - disp[:, :, :, 1:]), torch.sign(disp[:, :, :-1, :] - disp[:, :, 1:, :])
+
+
+def ms_oracle_decisions(o, batch, nt, sclm):
+    """the decisions the free-running oracle took in ``o = ms_run_oracle(...)``, in the layout its ``forced=`` expects"""
+    from oracle import aten_restated as AR
+    B, _, H, W = batch["color0"].shape
+    t = torch.from_numpy
+    out = dict(teacher=[], student=[], cmask=t(o["consistency_mask"]))
+
+    def l1_signs(preds, win):
+        pred = t(preds[0])
+        for i in range(1, len(preds)):
+            pred = torch.where(win == i, t(preds[i]), pred)
+        return torch.sign(pred - batch["color0"])
+
+    for s in range(sclm + 1):
+        sc = o["scales"][s]
+        dt = batch["disp_teacher"] if s == 0 else torch.nn.functional.avg_pool2d(batch["disp_teacher"], 2 ** s)
+        ds = batch["disp_student"] if s == 0 else torch.nn.functional.avg_pool2d(batch["disp_student"], 2 ** s)
+        win_t, win_s = t(sc["t_cands"]).argmin(1, keepdim=True), t(sc["s_cands"]).argmin(1, keepdim=True)
+        rp_t = t(sc["t_cands"]).min(1, keepdim=True)[0]
+        idn = t(sc["ident"]) + nt[s] * 0.00001
+        out["teacher"].append(dict(win=win_t, automask=(rp_t <= idn).float(), l1=l1_signs(sc["t_preds"], win_t),
+                                   smooth=_smooth_signs(dt), taps={f: AR.taps_of(t(sc["t_sample"][f]), H, W) for f in (-1, 1)}))
+        out["student"].append(dict(win=win_s, l1=l1_signs(sc["s_preds"], win_s), smooth=_smooth_signs(ds),
+                                   taps={f: AR.taps_of(t(sc["s_sample"][f]), H, W) for f in (-1, 1)}))
+    return out
+
+
+def ms_kernel_decisions(decs, consistency_mask, batch, sclm):
+    """``decs`` of mal_amd.step.loss_step_multiscale(want_decisions=True) -> the same layout"""
+    def taps(pl):
+        pl = pl.long()
+        return pl & 0xfff, (pl >> 12) & 0xfff, ((pl >> 24) & 1).bool(), ((pl >> 25) & 1).bool()
+
+    out = dict(teacher=[], student=[], cmask=torch.as_tensor(consistency_mask).cpu().float())
+    for s in range(sclm + 1):
+        for who, key, name in (("teacher", "dec_teacher", "disp_teacher"), ("student", "dec_student", "disp_student")):
+            d = decs[key][s].cpu()
+            disp = batch[name] if s == 0 else torch.nn.functional.avg_pool2d(batch[name], 2 ** s)
+            r = dict(win=(d[0].long() & 3)[:, None], taps={-1: taps(d[4]), 1: taps(d[5])},
+                     l1=torch.stack([((d[6].long() >> sh) & 3) - 1 for sh in (0, 2, 4)], 1).float(), smooth=_raw_smooth_signs(disp))
+            if who == "teacher":
+                r["automask"] = ((d[0].long() >> 2) & 1).float()[:, None]
+            out[who].append(r)
+    return out
+
+
+def ms_decision_differences(a, b, sclm):
+    """per scale and kind: bool (B,1,H,W) map of pixels where two decision sets differ (the smoothness signs are compared by
+    the caller at the map's own size)"""
+    out = []
+    for s in range(sclm + 1):
+        d = {"win_t": a["teacher"][s]["win"] != b["teacher"][s]["win"],
+             "automask": a["teacher"][s]["automask"] != b["teacher"][s]["automask"],
+             "win_s": a["student"][s]["win"] != b["student"][s]["win"]}
+        for who, k in (("teacher", "tap_t"), ("student", "tap_s")):
+            m = None
+            for f in (-1, 1):
+                for u, v in zip(a[who][s]["taps"][f], b[who][s]["taps"][f]):
+                    m = (u != v) if m is None else (m | (u != v))
+            d[k] = m[:, None]
+        for who, k in (("teacher", "l1_t"), ("student", "l1_s")):
+            d[k] = (a[who][s]["l1"] != b[who][s]["l1"]).any(1, keepdim=True)
+        out.append({k: v.numpy() for k, v in d.items()})
+    return out

@@ -46,3 +46,31 @@ def test_forcing_changes_only_the_forced_choice():
     expect = gap / float(dec["teacher"]["automask"].sum())
     got = f["mono_losses"]["reproj_loss/0"] - o["mono_losses"]["reproj_loss/0"]
     assert abs(got - expect) <= 1e-2 * expect + 1e-7, (got, expect)  # the loss itself is an fp32 number near 0.1
+
+
+@pytest.mark.parametrize("temporal", [False, True], ids=["plain", "temporal"])
+def test_four_scale_forced_with_own_decisions_reproduces_free_run(temporal):
+    """the same for the non-distil four-scale path (oracle.mal_oracle.compute_losses / generate_images_pred with one decision
+    set per scale): what tests/test_gpu_multiscale.py forces the kernels' decisions through"""
+    from mal_amd.synthetic import make_batch, fake_image_synthesis
+    B, H, W, sclm = 2, 32, 64, 2
+    batch = make_batch(B, H, W, seed=81, with_syn=temporal)
+    g = torch.Generator().manual_seed(13)
+    nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False, temporal=temporal)
+    synth = fake_image_synthesis(batch["syn_rects"]) if temporal else None
+    o = HH.ms_run_oracle(batch, kw, nt, nt, True, synth=synth)
+    dec = HH.ms_oracle_decisions(o, batch, nt, sclm)
+    f = HH.ms_run_oracle(batch, kw, nt, nt, True, synth=synth, forced=dec)
+    for who in ("teacher", "student"):
+        for k, v in o[who].items():
+            assert abs(f[who][k] - v) <= 2e-6 * abs(v) + 1e-9, (who, k, f[who][k], v)
+    for k, r in o["grads"].items():
+        a = f["grads"][k]
+        assert np.abs(a - r).max() <= 1e-4 * np.abs(r).max(), (k, np.abs(a - r).max() / np.abs(r).max())
+    d = HH.ms_decision_differences(dec, dec, sclm)
+    assert not any(v.any() for sc in d for v in sc.values())
+    # ... and in float64 it is the same function
+    f64 = HH.ms_run_oracle(batch, kw, nt, nt, True, synth=synth, forced=dec, double=True)
+    for k, r in o["grads"].items():
+        assert np.linalg.norm((f64["grads"][k] - r).ravel()) <= 2e-3 * np.linalg.norm(r.ravel()), k

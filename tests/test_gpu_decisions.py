@@ -130,10 +130,11 @@ def check_step_decision_exact(b, kw, n0, n1, w_list=(0.7, 0.3), return_runs=Fals
     od = HH.oracle_decisions(o, b, n0, no_ens=bool(kw.get("no_ens")))
     # the kernels report the L1 signs of the winning WARPED candidate; where a synthesised image won (temporal hint) its
     # signs are taken from the oracle's own
-    for who in ("teacher", "student"):  # (the student's: --main_temporal)
+    for who, preds in (("teacher", o["mono_preds"]), ("student", o["multi_preds"])):  # (the student's: --main_temporal)
         syn_won = kd[who]["win"] >= 2
-        if syn_won.any():
-            kd[who]["l1"] = torch.where(syn_won, od[who]["l1"], kd[who]["l1"])
+        if syn_won.any():  # the signs of THAT candidate's differences in the oracle's images (not of the oracle's own winner)
+            pred = torch.where(kd[who]["win"] == 3, torch.from_numpy(preds[3]), torch.from_numpy(preds[2]))
+            kd[who]["l1"] = torch.where(syn_won, torch.sign(pred - b["color0"]), kd[who]["l1"])
     counts = check_decisions_are_near_ties(HH.decision_differences(kd, od), o, b, n0, N)
     # ---- same decisions on both sides: hold everything at 1e-4
     f = HH.run_oracle(b, kw, n0, n1, w_list, forced=kd)

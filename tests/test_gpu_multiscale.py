@@ -131,48 +131,161 @@ def _build(batch, dev, sclm):
     return inputs, mono_outputs, outputs, leaves
 
 
+def _to64(d):
+    if isinstance(d, dict):
+        return {k: _to64(v) for k, v in d.items()}
+    if isinstance(d, (tuple, list)):
+        return type(d)(_to64(v) for v in d)
+    return d.double() if torch.is_tensor(d) and d.dtype == torch.float32 else d
+
+
+def _gap2(stack):
+    s_ = np.sort(stack, axis=1)
+    return s_[:, 1:2] - s_[:, 0:1]
+
+
+def _frac_dist(sample, H, W):
+    d = None
+    for f in (-1, 1):
+        g = sample[f].astype(np.float64)
+        for v in ((g[..., 0] + 1) / 2 * (W - 1), (g[..., 1] + 1) / 2 * (H - 1)):
+            dd = np.abs(v - np.round(v))
+            d = dd if d is None else np.minimum(d, dd)
+    return d[:, None]
+
+
+def check_multiscale_decision_exact(batch, kw, nt, matching, synth_of=None):
+    """tests/test_gpu_decisions.py's method on the four-scale path: (i) the kernels' per-scale decisions (winner, automask,
+    bilinear tap cell / border clip per frame, L1 signs; the matching mask; the smoothness signs are the raw disparity
+    differences' by construction) equal the free-running oracle's except at a handful of pixels, each shown to be a near-tie in
+    the oracle's own numbers; (ii) with the oracle forced to the kernels' decisions, loss scalars agree at 1e-5 and EVERY
+    gradient -- every pixel of every scale's two disparity maps, the four pose vectors -- is held against the same forced
+    oracle in fp64 within max(1e-4, 1.25 x the fp32 forced oracle's own distance from it)."""
+    from tests import hip_harness as HH
+    B, H, W, sclm, temporal = kw["batch_size"], kw["height"], kw["width"], kw["sclm"], kw.get("temporal", False)
+    N = B * H * W
+    synth_cpu = synth_of() if synth_of else None
+    o = HH.ms_run_oracle(batch, kw, nt, nt, matching, synth=synth_cpu)
+    hi, hm, ho, hl = HH.ms_build(batch, DEV, sclm)
+    if not matching:
+        ho.pop("lowest_cost")
+    from mal_amd import step, trainer
+    for f, s_ in ((-1, "m1"), (1, "p1")):
+        hm[("axisangle", 0, f)] = hl["axisangle_" + s_]
+        hm[("translation", 0, f)] = hl["translation_" + s_]
+    losses, mono_losses, decs = step.loss_step_multiscale(trainer.default_options(**kw), hi, hm, ho, noises=[n.to(DEV) for n in nt],
+                                                          image_synthesis=synth_of() if synth_of else None, want_decisions=True)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    kd = HH.ms_kernel_decisions(decs, ho["consistency_mask"], batch, sclm)
+    od = HH.ms_oracle_decisions(o, batch, nt, sclm)
+    if temporal:  # where a synthesised candidate won, the kernels report no L1 signs (theirs are a warped candidate's): take the
+        for s in range(sclm + 1):  # signs of THAT candidate's differences in the oracle's images (not of the oracle's own winner)
+            win = kd["teacher"][s]["win"]
+            preds = [torch.from_numpy(p_) for p_ in o["scales"][s]["t_preds"]]
+            if len(preds) == 4:
+                pred = torch.where(win == 3, preds[3], preds[2])
+                kd["teacher"][s]["l1"] = torch.where(win >= 2, torch.sign(pred - batch["color0"]), kd["teacher"][s]["l1"])
+    diffs = HH.ms_decision_differences(kd, od, sclm)
+    tgt = batch["color0"].numpy()
+    counts = {}
+    for s in range(sclm + 1):
+        sc = o["scales"][s]
+        idn = sc["ident"] + nt[s].numpy() * np.float32(1e-5)
+
+        def l1_gap(preds, cands):
+            win = cands.argmin(1)[:, None]
+            pred = preds[0]
+            for i in range(1, len(preds)):
+                pred = np.where(win == i, preds[i], pred)
+            return np.abs(pred - tgt).min(1, keepdims=True)
+
+        near = {"win_t": _gap2(sc["t_cands"]) <= 1e-4, "win_s": _gap2(sc["s_cands"]) <= 1e-4,
+                "automask": np.abs(sc["t_cands"].min(1, keepdims=True) - idn) <= 1e-4,
+                "tap_t": _frac_dist(sc["t_sample"], H, W) <= 1e-3, "tap_s": _frac_dist(sc["s_sample"], H, W) <= 1e-3,
+                "l1_t": (l1_gap(sc["t_preds"], sc["t_cands"]) <= 1e-4) | diffs[s]["win_t"],
+                "l1_s": (l1_gap(sc["s_preds"], sc["s_cands"]) <= 1e-4) | diffs[s]["win_s"]}
+        for k, d in diffs[s].items():
+            counts[(s, k)] = int(d.sum())
+            assert counts[(s, k)] <= 3e-4 * N + 8, ("too many differing decisions", s, k, counts[(s, k)])
+            unexplained = d & ~near[k]
+            assert not unexplained.any(), ("decision differs away from any tie", s, k, np.argwhere(unexplained)[:5].tolist())
+    if matching:
+        mono = o["mono_depth0"]
+        m_ = 1.0 / batch["lowest_cost"].numpy()[:, None]
+        ratio = np.minimum(np.abs((m_ - mono) / mono - 1.0), np.abs((mono - m_) / m_ - 1.0))
+        dc = (kd["cmask"] != od["cmask"]).numpy()[:, None]
+        assert not (dc & ~(ratio <= 1e-5)).any() and dc.sum() <= 3e-4 * N + 8
+    # the smoothness signs: the oracle's (of the mean-normalised map) differ from the raw differences' only at near-equal neighbours
+    for s in range(sclm + 1):
+        for who, name in (("teacher", "disp_teacher"), ("student", "disp_student")):
+            disp = batch[name] if s == 0 else torch.nn.functional.avg_pool2d(batch[name], 2 ** s)
+            amb = HH.smooth_sign_ambiguous(disp.numpy())
+            (kx, ky), (ox, oy) = kd[who][s]["smooth"], od[who][s]["smooth"]
+            dx, dy = (kx != ox).numpy(), (ky != oy).numpy()
+            assert not (dx & ~(amb[..., :, :-1] | amb[..., :, 1:])).any() and not (dy & ~(amb[..., :-1, :] | amb[..., 1:, :])).any(), (who, s)
+    # ---- same decisions on both sides
+    f = HH.ms_run_oracle(batch, kw, nt, nt, matching, synth=synth_of() if synth_of else None, forced=kd)
+    for k, v in f["teacher"].items():
+        assert abs(float(mono_losses[k]) - v) <= 1e-5 * abs(v) + 1e-9, ("teacher", k, float(mono_losses[k]), v)
+    for k, v in f["student"].items():
+        name = k if k.startswith("consistency") else "main/" + k
+        assert abs(float(losses[name]) - v) <= 1e-5 * abs(v) + 1e-9, ("student", k, float(losses[name]), v)
+    assert abs(float(losses["loss"].detach()) - f["total"]) <= 1e-5 * abs(f["total"])
+    f64 = HH.ms_run_oracle(batch, kw, nt, nt, matching, synth=synth_of() if synth_of else None, forced=_to64(kd), double=True)
+    report = {}
+    for key, t_ in hl.items():
+        g, r32, r64 = t_.grad.cpu().numpy(), f["grads"][key], f64["grads"][key]
+        floor = _l2rel(r32, r64)
+        report[key] = (_l2rel(g, r64), floor)
+        assert _l2rel(g, r64) <= max(1e-4, 1.25 * floor), (key, "L2 rel to the exact (fp64) forced oracle", _l2rel(g, r64), "fp32 oracle:", floor)
+        if g.ndim == 4:  # EVERY pixel of every scale's map, no exemptions
+            sc_ = np.abs(r64).max()
+            tol_px = max(1e-4, 1.25 * np.abs(r32 - r64).max() / sc_)
+            worst = np.abs(g - r64).max() / sc_
+            assert worst <= tol_px, (key, "worst pixel / map scale", worst, tol_px, np.unravel_index(np.abs(g - r64).argmax(), g.shape))
+    return counts, report
+
+
 @pytest.mark.parametrize("case", [(12, 192, 640, 3, True, False), (3, 40, 72, 2, False, False), (2, 32, 64, 0, True, False),
                                   (12, 192, 640, 3, True, True), (3, 40, 72, 2, False, True)],
                          ids=["baseline-b12-192x640-sclm3", "b3-40x72-sclm2", "b2-32x64-sclm0",
                               "baseline-b12-192x640-sclm3-temporal", "b3-40x72-sclm2-temporal"])
 def test_against_the_oracle(case):
+    """decision-exact (round 5; rounds 2-4 held the pose gradients of this route at 2e-2 and exempted up to 2 % of the pixels)"""
     from mal_amd.synthetic import fake_image_synthesis
     B, H, W, sclm, matching, temporal = case
     batch = make_batch(B, H, W, seed=79, with_syn=temporal)
     g = torch.Generator().manual_seed(12)
     nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
     kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False, temporal=temporal)
-    synth = fake_image_synthesis(batch["syn_rects"]) if temporal else None
-    oi, om, oo, ol = _build(batch, "cpu", sclm)
-    rt, rs = _oracle_step(oi, om, oo, kw, nt, nt, matching=matching, synth=synth)
-    hi, hm, ho, hl = _build(batch, DEV, sclm)
-    if not matching:
-        ho.pop("lowest_cost")
-    losses, mono_losses = _hip_step(hi, hm, ho, hl, kw, nt, synth=synth)
-    N = B * H * W
-    tie_t = 40.0 * (sclm + 1) / N
-    for k, v in rt.items():
-        assert abs(float(mono_losses[k]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + tie_t, ("teacher", k, float(mono_losses[k]), float(v))
-    for k, v in rs.items():
-        name = k if k.startswith("consistency") else "main/" + k
-        # a pixel whose matching-mask test sits at rounding distance moves the masked mean by <~ 1/N
-        assert abs(float(losses[name]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + (4.0 / N if matching else 0.0), (
-            "student", k, float(losses[name]), float(v))
-    for s in range(sclm + 1):  # process_batch's sums (trainer.py:614-616)
-        for k in ("reproj_loss/%d" % s, "loss/%d" % s):
-            assert abs(float(losses[k]) - (float(losses["main/" + k]) + float(mono_losses[k]))) <= 1e-6
-    if matching:
-        ref_mask = oo["consistency_mask"].numpy()
-        assert (ho["consistency_mask"].cpu().numpy() != ref_mask).mean() <= 1e-4
-    for k in hl:
-        gq, r = hl[k].grad.cpu().numpy(), ol[k].grad.numpy()
-        if gq.ndim == 4:
-            bad = (np.abs(gq - r) > 3e-4 * np.abs(r).max()).mean()
-            sc = int(k[-1]) if k[-1].isdigit() else 0
-            # near-tie pixels and their neighbourhoods: a few tens per map whatever its size
-            assert bad <= max(1e-3 * (1 + 4 ** sc / 8.0), 40.0 / gq.size), (k, bad)
-        else:
-            assert _l2rel(gq, r) <= 2e-2, (k, _l2rel(gq, r))
+    counts, report = check_multiscale_decision_exact(batch, kw, nt, matching,
+                                                     (lambda: fake_image_synthesis(batch["syn_rects"])) if temporal else None)
+    if B * H * W < 100000:  # at the small sizes plain 1e-4 holds for every leaf
+        assert all(v[0] <= 1e-4 for v in report.values()), report
+
+
+def test_decision_planes_do_not_change_results():
+    """the instrumented instantiations are the same kernels: losses and every gradient bit for bit with and without them"""
+    from mal_amd import step, trainer
+    from tests import hip_harness as HH
+    B, H, W, sclm = 2, 48, 96, 3
+    batch = make_batch(B, H, W, seed=9)
+    g = torch.Generator().manual_seed(3)
+    nt = [torch.randn(B, 1, H, W, generator=g).to(DEV) for _ in range(sclm + 1)]
+    kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
+    runs = []
+    for want in (False, True):
+        hi, hm, ho, hl = HH.ms_build(batch, DEV, sclm)
+        for f, s_ in ((-1, "m1"), (1, "p1")):
+            hm[("axisangle", 0, f)] = hl["axisangle_" + s_]
+            hm[("translation", 0, f)] = hl["translation_" + s_]
+        res = step.loss_step_multiscale(trainer.default_options(**kw), hi, hm, ho, noises=nt, want_decisions=want)
+        res[0]["loss"].backward()
+        runs.append((float(res[0]["loss"].detach()), {k: t.grad.clone() for k, t in hl.items()}))
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
 
 
 def test_in_kernel_noise_equals_the_same_noise_handed_in():
