@@ -505,6 +505,9 @@ typedef struct mal_dr_args {
    * copies of the three images and the identity term are taken from it instead of being formed again (a step over several
    * scales packs once).  Honoured when this call's smoothness term does not ride on that sweep (scale > 0 or n_iters > 2). */
   const void *texels_from;
+  /* parity instrumentation (tests), per iteration: the per-pixel decisions of that iteration's pass, as mal_step_args.dec_teacher
+   * (int32 (MAL_DEC_PLANES,B,H,W); MAL_DEC_WIN, _TAP0/1, _L1).  NULL: the uninstrumented kernels; bit-identical results. */
+  uint32_t *dec[MAL_DR_MAX_ITERS];
 } mal_dr_args;
 size_t mal_dr_workspace_bytes(int B, int H, int W, int n_iters);
 int mal_dr_loss_fwd(const mal_dr_args* args);

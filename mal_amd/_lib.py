@@ -166,7 +166,7 @@ class DrArgs(C.Structure):
                  ("noise_seed", C.c_uint64), ("noise_step", C.c_uint64), ("noise_counter", vp), ("losses", vp), ("loss_total", vp),
                  ("g_total", vp), ("g_disp", vp * 4), ("g_T_m1", vp * 4), ("g_T_p1", vp * 4),
                  ("ws", vp), ("ws_bytes", sz), ("stream", vp), ("scale", i32), ("color0_s", vp), ("disp_lo", vp * 4),
-                 ("g_disp_lo", vp * 4), ("texels_from", vp)])
+                 ("g_disp_lo", vp * 4), ("texels_from", vp), ("dec", vp * 4)])
 
 
 DR_MAX_ITERS = 4

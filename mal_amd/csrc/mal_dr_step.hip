@@ -351,6 +351,7 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
       p.g_cons = w.G_c[it]; p.g_distil = nullptr; p.merge_cons = merge_cons; p.merge_distil = 0.f;
       flags |= MAL_F_EPILOGUE;
     }
+    p.dbg = a->dec[it];
     rc = march_launch(p, flags, st);
     if (rc) return rc;
     per_sample = p.strips * p.segs;

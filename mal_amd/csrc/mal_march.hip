@@ -1594,6 +1594,7 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   } else if (p.dbg) {  // instrumented instantiations exist for the two gradient passes of the whole-step list
     if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
     if (grad && pose && automask && !epi) hipLaunchKernelGGL((march_kernel<true, true, true, false, true>), grid, block, 0, st, p);
+    else if (grad && pose && automask && epi) hipLaunchKernelGGL((march_kernel<true, true, true, true, true>), grid, block, 0, st, p);  // DualRefine, deq iterations > 0
     else if (grad && !pose && !automask && epi) hipLaunchKernelGGL((march_kernel<true, false, false, true, true>), grid, block, 0, st, p);
     else if (grad && !pose && !automask && !epi) hipLaunchKernelGGL((march_kernel<true, false, false, false, true>), grid, block, 0, st, p);
     else return MAL_EINVAL;

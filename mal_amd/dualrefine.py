@@ -72,6 +72,7 @@ class DrLossStepFn(Function):
         min_depth, max_depth, smooth_weight, flags, n, philox = cfg[:6]
         scale = cfg[6] if len(cfg) > 6 else 0
         texels_from = cfg[7] if len(cfg) > 7 else None  # the workspace of the step's first call (texels + identity term)
+        want_dec = len(cfg) > 8 and cfg[8]               # parity instrumentation (tests): decision planes per iteration
         req, p = ops._req, ops._p
         tens = [req(t, "leaf") for t in leaves]
         cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K)]
@@ -107,17 +108,22 @@ class DrLossStepFn(Function):
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
         if texels_from is not None:
             a.texels_from = p(texels_from)
+        decs = []
+        if want_dec:
+            decs = [torch.zeros((L.DEC_PLANES, B, H, W), dtype=torch.int32, device=dev) for _ in range(n)]
+            for it in range(n):
+                a.dec[it] = p(decs[it])
         L.check(L.load().mal_dr_loss_fwd(C.byref(a)), "mal_dr_loss_fwd")
         ctx.args, ctx.keep, ctx.n, ctx.scale, ctx.up = a, (tens, cons, cm, nz, ws, losses, total), n, int(scale), up
         ctx.texels_from = texels_from  # (kept alive: the passes of this call read it)
         ctx.ws_token = ops.claim_workspace(ws)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(losses, ws)
-        return total, losses, ws  # (ws: what a later scale's call of the same step takes the texels from)
+        ctx.mark_non_differentiable(losses, ws, *decs)
+        return (total, losses, ws, *decs)  # (ws: what a later scale's call of the same step takes the texels from)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_total, _g_losses=None, _g_ws=None):
+    def backward(ctx, g_total, _g_losses=None, _g_ws=None, *_g_decs):
         n, tens = ctx.n, ctx.keep[0]
         if g_total is None:
             return (None,) * (2 + 3 * n)
@@ -308,7 +314,7 @@ class DualRefineLossPath:
         losses["loss"] = total / self.num_scales
         return losses
 
-    def loss_step(self, inputs, outputs, noises=None):
+    def loss_step(self, inputs, outputs, noises=None, want_decisions=False):
         """``generate_images_pred`` + ``compute_losses`` (dualrefine/trainer.py:395-451,530-633) in ONE library call per
         direction AND scale of ``opt.scales`` (upstream's default list is [0,1,2,3]: scale 0 and 2 with the deq iterations
         0..n_losses, scale 1 skipped, scale 3 iteration 0 only, :403-407,536-547; a lower scale's disparities are upsampled
@@ -336,6 +342,7 @@ class DualRefineLossPath:
             else:
                 noises = [loss_utils.draw_noise((B, 1, H, W), target.device) for _ in units]  # one draw per visit (:586-587)
         losses, total, k = {}, None, 0
+        decisions = {}  # want_decisions: {(scale, it): (MAL_DEC_PLANES,B,H,W) int32}
         first_ws = None  # the first call's workspace: later scales of this step take the texels and the identity term from it
         for scale in scales:
             if scale == 1:
@@ -354,8 +361,11 @@ class DualRefineLossPath:
             k += n
             consts = (target, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)], cmask, nz,
                       inputs[("color", 0, scale)] if scale else None)
-            cfg = (opt.min_depth, opt.max_depth, opt.disparity_smoothness / (2 ** scale), flags, n, philox, scale, first_ws)
-            tot_s, v, ws_s = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1)
+            cfg = (opt.min_depth, opt.max_depth, opt.disparity_smoothness / (2 ** scale), flags, n, philox, scale, first_ws,
+                   bool(want_decisions))
+            tot_s, v, ws_s, *decs_s = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1)
+            for it, d in enumerate(decs_s):
+                decisions[(scale, it)] = d
             if first_ws is None:
                 first_ws = ws_s
             total = tot_s.reshape(()) if total is None else total + tot_s.reshape(())
@@ -365,6 +375,8 @@ class DualRefineLossPath:
                 if it > 0:
                     losses["consistency_loss/%d_%d" % (scale, it)] = v[4 * it + 1]
         losses["loss"] = total / self.num_scales if self.num_scales != 1 else total
+        if want_decisions:
+            return losses, decisions
         return losses
 
     def _weight_map(self, inputs, outputs, scale, it, ext, rp_map, noise):

@@ -61,13 +61,13 @@ def multiscale_dicts(z, pose_fn, device="cpu"):
 DUALREFINE_CASES = ["dualrefine_b2_40x72", "dualrefine_b2_40x72_scales0123"]
 
 
-def dualrefine_dicts(z, pose_fn, device="cpu"):
+def dualrefine_dicts(z, pose_fn, device="cpu", dtype=torch.float32):
     """a DualRefine fixture (oracle/gen_golden_dr.py: the reference's own Trainer methods called unbound) as that trainer's
     dicts: 4-tuple keys ("disp", scale, deq_iter); the second case carries upstream's default scales [0, 1, 2, 3]
     (scale 1 is never read, scale 3 has iteration 0 only: dualrefine/trainer.py:403-407).  Returns
     (batch, scales, units, inputs, outputs, leaves); units = the (scale, iteration) pairs in the order the loops visit them."""
     b = batch_from_golden(z)
-    mv = lambda t: t.to(device)
+    mv = lambda t: (t.to(dtype) if t.is_floating_point() else t).to(device)
     scales = [int(v) for v in z["scales"]] if "scales" in z else [0]
     inputs = {("color", f, 0): mv(b[k]) for f, k in ((0, "color0"), (-1, "color_m1"), (1, "color_p1"))}
     inputs[("K", 0)], inputs[("inv_K", 0)] = mv(b["K"]), mv(b["inv_K"])
@@ -82,11 +82,11 @@ def dualrefine_dicts(z, pose_fn, device="cpu"):
     for s in scales:
         if s == 0:
             continue
-        inputs[("color", 0, s)] = torch.nn.functional.avg_pool2d(b["color0"], 2 ** s).to(device)
+        inputs[("color", 0, s)] = mv(torch.nn.functional.avg_pool2d(b["color0"], 2 ** s))
         for it in (0, 1):
             key = "in/disp_s%d_it%d" % (s, it)
             if key in z:
-                leaf = torch.from_numpy(z[key].astype(np.float32)).to(device).requires_grad_(True)
+                leaf = mv(torch.from_numpy(z[key].astype(np.float32))).requires_grad_(True)
                 leaves["disp_s%d_it%d" % (s, it)] = leaf
                 outputs[("disp", s, it)] = leaf
                 units.append((s, it))

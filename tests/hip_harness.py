@@ -284,31 +284,43 @@ def oracle_fp64_grads(batch, opt_kw, n0, n1):
 
 
 # ------------------------------------------------------------------ the four-scale path (mal_loss_multiscale_*), decision-exact
+def _lowres(batch, name, s):
+    """scale s of a disparity leaf: ``batch["lowres"][name + "_s%d"]`` when the batch brings its own (the reference-generated
+    fixtures store fp16-rounded pooled maps), else the pooled copy of scale 0"""
+    if s == 0:
+        return batch[name]
+    lr = batch.get("lowres")
+    if lr is not None:
+        return lr["%s_s%d" % (name, s)]
+    return torch.nn.functional.avg_pool2d(batch[name], 2 ** s)
+
+
 def ms_build(batch, dev, sclm, double=False):
     """the reference's dict contract for ``sclm`` + 1 scales: lower scales are pooled copies (the shipped decoder emits scale 0
     only); leaves: disp_teacher / disp_student per scale and the four pose vectors"""
     cast = (lambda t: t.double()) if double else (lambda t: t)
-    b = {k: (cast(v) if torch.is_tensor(v) and v.dtype == torch.float32 else v) for k, v in batch.items()}
+    b = {k: (cast(v) if torch.is_tensor(v) and v.dtype == torch.float32 else v) for k, v in batch.items()}  # ("lowres" stays as it is)
     pose = O.transformation_from_parameters if str(dev) == "cpu" else (lambda a, t, inv: None)
     inputs, mono_outputs, outputs, leaves = to_dicts(b, pose, device=None if str(dev) == "cpu" else dev)
     for s in range(1, sclm + 1):
         inputs[("color", 0, s)] = cast(torch.nn.functional.avg_pool2d(batch["color0"], 2 ** s)).to(dev)
         for name, outs in (("disp_teacher", mono_outputs), ("disp_student", outputs)):
-            leaf = cast(torch.nn.functional.avg_pool2d(batch[name], 2 ** s)).to(dev).clone().requires_grad_(True)
+            leaf = cast(_lowres(batch, name, s)).to(dev).clone().requires_grad_(True)
             leaves["%s_s%d" % (name, s)] = leaf
             outs[("disp", s)] = leaf
     return inputs, mono_outputs, outputs, leaves
 
 
-def ms_run_oracle(batch, kw, nt, ns, matching, synth=None, forced=None, double=False):
+def ms_run_oracle(batch, kw, nt, ns, matching, synth=None, forced=None, double=False, builder=None):
     """process_batch without --distil over scales 0..sclm on the CPU (trainer.py:573-612 calling compute_losses for both
     networks).  ``forced``: {"teacher": [per scale], "student": [per scale], "cmask"} (oracle.mal_oracle.compute_losses)."""
     opt = O.default_opt(**kw)
     sclm = opt.sclm
     cast = (lambda t: t.double()) if double else (lambda t: t)
-    inputs, mono_outputs, outputs, leaves = ms_build(batch, "cpu", sclm, double=double)
+    # ``builder(dev, double) -> (inputs, mono_outputs, outputs, leaves)``: a test's own dict layout (e.g. one leaf shared by both networks)
+    inputs, mono_outputs, outputs, leaves = ms_build(batch, "cpu", sclm, double=double) if builder is None else builder("cpu", double)
     if not matching:
-        outputs.pop("lowest_cost")
+        outputs.pop("lowest_cost", None)
     ft, fs = (None, None) if forced is None else (forced["teacher"], forced["student"])
     has_ins = O.generate_images_pred(opt, inputs, mono_outputs, synth=synth, forced=ft)
     lt = O.compute_losses(opt, inputs, mono_outputs, is_multi=False, has_ins=has_ins, noises=[cast(n.clone()) for n in nt], forced=ft)
@@ -348,8 +360,9 @@ def _raw_smooth_signs(disp):
     return torch.sign(disp[:, :, :, :-1] - disp[:, :, :, 1:]), torch.sign(disp[:, :, :-1, :] - disp[:, :, 1:, :])
 
 
-def ms_oracle_decisions(o, batch, nt, sclm):
-    """the decisions the free-running oracle took in ``o = ms_run_oracle(...)``, in the layout its ``forced=`` expects"""
+def ms_oracle_decisions(o, batch, nt, sclm, noise_scale=0.00001):
+    """the decisions the free-running oracle took in ``o = ms_run_oracle(...)``, in the layout its ``forced=`` expects
+    (``noise_scale`` = 0 with --disable_automasking: the identity term is compared without its tie-break noise)"""
     from oracle import aten_restated as AR
     B, _, H, W = batch["color0"].shape
     t = torch.from_numpy
@@ -363,11 +376,10 @@ def ms_oracle_decisions(o, batch, nt, sclm):
 
     for s in range(sclm + 1):
         sc = o["scales"][s]
-        dt = batch["disp_teacher"] if s == 0 else torch.nn.functional.avg_pool2d(batch["disp_teacher"], 2 ** s)
-        ds = batch["disp_student"] if s == 0 else torch.nn.functional.avg_pool2d(batch["disp_student"], 2 ** s)
+        dt, ds = _lowres(batch, "disp_teacher", s), _lowres(batch, "disp_student", s)
         win_t, win_s = t(sc["t_cands"]).argmin(1, keepdim=True), t(sc["s_cands"]).argmin(1, keepdim=True)
         rp_t = t(sc["t_cands"]).min(1, keepdim=True)[0]
-        idn = t(sc["ident"]) + nt[s] * 0.00001
+        idn = t(sc["ident"]) + nt[s] * noise_scale
         out["teacher"].append(dict(win=win_t, automask=(rp_t <= idn).float(), l1=l1_signs(sc["t_preds"], win_t),
                                    smooth=_smooth_signs(dt), taps={f: AR.taps_of(t(sc["t_sample"][f]), H, W) for f in (-1, 1)}))
         out["student"].append(dict(win=win_s, l1=l1_signs(sc["s_preds"], win_s), smooth=_smooth_signs(ds),
@@ -385,7 +397,7 @@ def ms_kernel_decisions(decs, consistency_mask, batch, sclm):
     for s in range(sclm + 1):
         for who, key, name in (("teacher", "dec_teacher", "disp_teacher"), ("student", "dec_student", "disp_student")):
             d = decs[key][s].cpu()
-            disp = batch[name] if s == 0 else torch.nn.functional.avg_pool2d(batch[name], 2 ** s)
+            disp = _lowres(batch, name, s)
             r = dict(win=(d[0].long() & 3)[:, None], taps={-1: taps(d[4]), 1: taps(d[5])},
                      l1=torch.stack([((d[6].long() >> sh) & 3) - 1 for sh in (0, 2, 4)], 1).float(), smooth=_raw_smooth_signs(disp))
             if who == "teacher":
@@ -411,4 +423,43 @@ def ms_decision_differences(a, b, sclm):
         for who, k in (("teacher", "l1_t"), ("student", "l1_s")):
             d[k] = (a[who][s]["l1"] != b[who][s]["l1"]).any(1, keepdim=True)
         out.append({k: v.numpy() for k, v in d.items()})
+    return out
+
+
+def ms_explicit_route_decisions(opt, inputs, mono_outputs, outputs, nt, batch, sclm):
+    """The decisions of the EXPLICIT operator route (MALLossPath with fuse=False: materialising warp, then the materialised-
+    candidate kernels) without any instrumented kernel: everything it decides can be re-derived exactly from what it leaves in
+    the dicts -- the tap cell / border clip from its own sampling grid ("sample"), the winner and the automask weight by running
+    the same deterministic min kernel (ops.photo_fwd) on its own warped images ("color"), the L1 signs from those images (a
+    comparison of two fp32 numbers), the smoothness signs from the raw disparities."""
+    from mal_amd import _lib as L, loss_utils, ops
+    from oracle import aten_restated as AR
+    target = inputs[("color", 0, 0)]
+    B, _, H, W = target.shape
+    no_ssim = bool(getattr(opt, "no_ssim", False))
+    flags = L.F_NO_SSIM if no_ssim else 0
+    sources = [inputs[("color", f, 0)] for f in (-1, 1)]
+    out = dict(teacher=[], student=[], cmask=outputs["consistency_mask"].detach().cpu().float())
+    tgt = target.cpu()
+    for s in range(sclm + 1):
+        for who, outs, name in (("teacher", mono_outputs, "disp_teacher"), ("student", outputs, "disp_student")):
+            cands = [outs[("color", f, s)].detach() for f in (-1, 1)]
+            if who == "teacher":
+                ident = loss_utils.identity_min(target, sources, no_ssim)
+                noise = None if getattr(opt, "disable_automasking", False) else nt[s].to(target.device)
+                _, am, wt, _ = ops.photo_fwd(target, cands, ident, noise, None, flags | L.F_AUTOMASK)
+            else:
+                m = torch.ones(B, 1, H, W, dtype=torch.float32, device=target.device)
+                if not getattr(opt, "disable_motion_masking", False):
+                    m = m * outputs["consistency_mask"].unsqueeze(1)
+                if not getattr(opt, "no_matching_augmentation", False):
+                    m = m * (1 - outputs["augmentation_mask"][:B])
+                _, am, wt, _ = ops.photo_fwd(target, cands, None, None, m.contiguous(), flags)
+            win = am.long().cpu()
+            pred = torch.where(win == 1, cands[1].cpu(), cands[0].cpu())
+            r = dict(win=win, l1=torch.sign(pred - tgt), smooth=_raw_smooth_signs(outs[("disp", s)].detach().cpu()),
+                     taps={f: AR.taps_of(outs[("sample", f, s)].detach().cpu(), H, W) for f in (-1, 1)})
+            if who == "teacher":
+                r["automask"] = wt.cpu()
+            out[who].append(r)
     return out

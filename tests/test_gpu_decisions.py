@@ -347,6 +347,40 @@ def _dr_build(batch, dev, pose_fn, dtype=torch.float32):
     return inputs, outputs, leaves
 
 
+def _dr_decode(d):
+    """one (MAL_DEC_PLANES,B,H,W) block of a teacher-style pass -> the oracle's forced-decision layout"""
+    def taps(pl):
+        pl = pl.long()
+        return pl & 0xfff, (pl >> 12) & 0xfff, ((pl >> 24) & 1).bool(), ((pl >> 25) & 1).bool()
+    d = torch.as_tensor(d).cpu()
+    return dict(win=(d[0].long() & 3)[:, None], automask=((d[0].long() >> 2) & 1).float()[:, None],
+                taps={-1: taps(d[4]), 1: taps(d[5])},
+                l1=torch.stack([((d[6].long() >> s) & 3) - 1 for s in (0, 2, 4)], 1).float())
+
+
+def _dr_hold_against_forced_oracle(grads, leaf_values, f32, g32, g64, got_losses, loss_tol=2e-5):
+    """losses against the fp32 forced oracle; every gradient against the fp64 one within max(1e-4, 1.25 x the fp32 forced
+    oracle's own distance from it); per-pixel maps at every pixel whose smoothness sign is not a rounding matter (the
+    DualRefine passes export no smoothness signs)"""
+    for k, v in f32.items():
+        assert abs(got_losses[k] - float(v)) <= loss_tol * abs(float(v)) + 1e-9, (k, got_losses[k], float(v))
+    report = {}
+    for key, g in grads.items():
+        r32, r64 = g32[key], g64[key]
+        floor = _l2rel(r32, r64)
+        report[key] = (_l2rel(g, r64), floor)
+        if g.ndim == 4 and g.shape[1] == 1:
+            amb = HH.smooth_sign_ambiguous(leaf_values[key])
+            sc = np.abs(r64).max()
+            tol_px = max(1e-4, 1.25 * np.abs(r32 - r64).max() / sc)
+            worst = (np.abs(g - r64) * ~amb).max() / sc
+            assert worst <= tol_px, (key, "worst pixel / map scale", worst, tol_px)
+            assert _l2rel(g * ~amb, r64 * ~amb) <= max(1e-4, 1.25 * floor), (key, _l2rel(g * ~amb, r64 * ~amb), floor)
+        else:
+            assert _l2rel(g, r64) <= max(1e-4, 1.25 * floor), (key, "L2 rel to the exact (fp64) forced oracle", _l2rel(g, r64), floor)
+    return report
+
+
 def _dr_oracle(batch, kw, noises, forced=None, dtype=torch.float32):
     from oracle import mal_oracle as O
     inputs, outputs, leaves = _dr_build(batch, "cpu", O.transformation_from_parameters, dtype)
@@ -440,18 +474,21 @@ def test_dualrefine_decision_exact(shape):
 def test_dualrefine_upstream_default_scales_against_the_reference_fixture():
     """upstream's default scale list [0, 1, 2, 3] (dualrefine/options.py:65-69): the loops visit scale 0 and 2 with both
     iterations, skip scale 1, take iteration 0 of scale 3 (trainer.py:403-407,536-547), every disparity upsampled to full
-    resolution, smoothness at the scale's own size / 2**scale, total / 4 -- generate_images_pred + compute_losses of
-    DualRefineLossPath against the numbers the reference's own Trainer methods produced (oracle/gen_golden_dr.py)."""
+    resolution, smoothness at the scale's own size / 2**scale, total / 4 -- against the numbers the reference's own Trainer
+    methods produced (oracle/gen_golden_dr.py; the oracle reproduces them bit for bit).  The fixture is a free-running
+    evaluation: its loss scalars are held within the movement of a few near-tie pixels; the GRADIENTS are held decision-exactly
+    -- the one-call step exports every visited unit's decisions (mal_dr_args.dec), the oracle takes them, fp64 is the yardstick
+    -- and the operator route of the same class equals the step to rounding (the next tests)."""
     from mal_amd import dualrefine, layers
+    from oracle import mal_oracle as O
     z = G.load("dualrefine_b2_40x72_scales0123")
     b, scales, units, inputs, outputs, leaves = G.dualrefine_dicts(z, layers.transformation_from_parameters, "cuda:0")
     B, _, H, W = b["color0"].shape
     N = B * H * W
     torch.manual_seed(int(z["in/noise_seed"]))
-    noises = [torch.randn(B, 1, H, W).to("cuda:0") for _ in units]
+    noises = [torch.randn(B, 1, H, W) for _ in units]
     lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=B, n_losses=1, scales=scales), fuse=True)
-    lp.generate_images_pred(inputs, outputs)
-    got = lp.compute_losses(inputs, outputs, noises=noises)
+    got, decs = lp.loss_step(inputs, outputs, noises=[n.to("cuda:0") for n in noises], want_decisions=True)
     got["loss"].backward()
     torch.cuda.synchronize()
     assert set("losses/" + k for k in got) == set(k for k in z if k.startswith("losses/"))
@@ -459,13 +496,22 @@ def test_dualrefine_upstream_default_scales_against_the_reference_fixture():
         ref = float(z["losses/" + k])
         # an automask pixel at rounding distance of its threshold moves a masked mean by <~ 1/N: two allowed per visited unit
         assert abs(float(v.detach()) - ref) <= 2e-4 * abs(ref) + 1e-6 + 2.0 * len(units) / N, (k, float(v.detach()), ref)
-    for k, t in leaves.items():
-        g, r = t.grad.cpu().numpy(), z["grad/" + k].reshape(t.shape)
-        if g.ndim == 4:
-            bad = (np.abs(g - r) > (2e-4 + 4.0 / N) * np.abs(r).max()).mean()
-            assert bad <= (3e-2 if k[-3:-2].isdigit() or "_s" in k else 5e-3), (k, bad)
-        else:
-            assert _l2rel(g, r) <= 2e-2, (k, _l2rel(g, r))
+    assert set(decs) == set(units)
+    forced = {u: _dr_decode(decs[u]) for u in units}
+
+    def run(dtype):
+        _, _, _, oin, oout, ol = G.dualrefine_dicts(z, O.transformation_from_parameters, "cpu", dtype)
+        opt = O.dr_default_opt(height=H, width=W, batch_size=B, n_losses=1, scales=scales)
+        fd = forced if dtype == torch.float32 else _to64(forced)
+        O.dr_generate_images_pred(opt, oin, oout, forced=fd)
+        ref = O.dr_compute_losses(opt, oin, oout, noises=[n.clone().to(dtype) for n in noises], forced=fd)
+        ref["loss"].backward()
+        return ref, {k: t.grad.numpy() for k, t in ol.items()}
+    f32, g32 = run(torch.float32)
+    _, g64 = run(torch.float64)
+    grads = {k: t.grad.cpu().numpy() for k, t in leaves.items()}
+    _dr_hold_against_forced_oracle(grads, {k: t.detach().cpu().numpy() for k, t in leaves.items()}, f32, g32, g64,
+                                   {k: float(v.detach()) for k, v in got.items()})
 
 
 @pytest.mark.parametrize("shape,kw_extra", [((2, 40, 72), {}), ((8, 192, 640), {}), ((3, 37, 50), {"n_losses": 2}),
@@ -538,7 +584,7 @@ def test_dualrefine_one_call_step_avg_and_no_ssim(kw_extra):
             lp.generate_images_pred(inputs, outputs)
             got = lp.compute_losses(inputs, outputs, noises=nz)
         else:
-            got = lp.loss_step(inputs, outputs, noises=nz)
+            got, res["decs"] = lp.loss_step(inputs, outputs, noises=nz, want_decisions=True)
         got["loss"].backward()
         torch.cuda.synchronize()
         res[route] = ({k: float(v.detach()) for k, v in got.items()},
@@ -548,14 +594,21 @@ def test_dualrefine_one_call_step_avg_and_no_ssim(kw_extra):
         tie = 4.0 / N  # two automask pixels per iteration at rounding distance of their threshold
         assert abs(res["step"][0][k] - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + tie, (k, res["step"][0][k], float(v))
         assert abs(res["step"][0][k] - res["ops"][0][k]) <= 2e-5 * abs(float(v)) + tie, (k, res["step"][0][k], res["ops"][0][k])
+    # ---- gradients, decision-exact (round 5): the step's own decisions forced on the oracle, fp64 as the yardstick
+    forced = {u: _dr_decode(d) for u, d in res["decs"].items()}
+    if kw.get("avg_reprojection"):
+        for fd in forced.values():
+            fd.pop("l1")  # both candidates carry an L1 term with their own signs; there is no argmin to force either
+    f32, g32, _, _ = _dr_oracle(batch, kw, noises, forced=forced)
+    _, g64, _, _ = _dr_oracle(batch, kw, noises, forced=_to64(forced), dtype=torch.float64)
+    _dr_hold_against_forced_oracle(res["step"][1], {k: batch[k].numpy() for k in HH.LEAVES}, f32, g32, g64, res["step"][0])
+    # the operator route takes these options through the explicit kernels (materialising warp + materialised candidates, ATen's
+    # summation order inside SSIM): per-pixel maps against the step on all but near-tie pixels and their neighbourhoods
     for k in HH.LEAVES:
-        g, r, o = res["step"][1][k], gref[k], res["ops"][1][k]
+        g, o = res["step"][1][k], res["ops"][1][k]
         if g.ndim == 4:
-            for other, what in ((r, "oracle"), (o, "operator route")):
-                bad = (np.abs(g - other) > 3e-4 * np.abs(other).max()).mean()
-                assert bad <= max(2e-3, 40.0 / g.size), (k, what, bad)
-        else:
-            assert _l2rel(g, r) <= 2e-2 and _l2rel(g, o) <= 2e-2, (k, _l2rel(g, r), _l2rel(g, o))
+            bad = (np.abs(g - o) > 3e-4 * np.abs(o).max()).mean()
+            assert bad <= max(2e-3, 40.0 / g.size), (k, "operator route", bad)
 
 
 def test_dualrefine_one_call_step_with_upstream_default_scales():

@@ -79,20 +79,28 @@ def test_four_scales_against_the_reference_fixture(temporal):
     """sclm=3 (BASELINE configs[1]'s "4 scales"): the reference's own numbers for both networks' compute_losses over four
     disparity scales (oracle/gen_golden.py run_reference_multiscale); ``temporal``: with --temporal on this path
     (trainer.py:1161-1162,1279-1283) -- the producer once per scale between mal_loss_multiscale_warp and _fwd, the
-    synthesised candidates in every scale's min of the teacher, their gradient back through the producer in _bwd"""
+    synthesised candidates in every scale's min of the teacher, their gradient back through the producer in _bwd.
+    The fixture is the free-running reference (the oracle reproduces it bit for bit, tests/test_oracle_golden.py): the kernels
+    are held decision-exactly against the oracle on the fixture's inputs, the reference's loss scalars within the movement of the
+    pixels whose decision differs, and -- when no decision differs -- the reference's gradients at 1e-4."""
     from tests import golden_io as G
+    from tests import hip_harness as HH
     from mal_amd.synthetic import fake_image_synthesis
     z = G.load(G.MULTISCALE_TEMPORAL_CASE if temporal else G.MULTISCALE_CASE)
     b, sclm, inputs, mono_outputs, outputs, leaves = G.multiscale_dicts(z, lambda a, t, inv: None, DEV)
-    outputs.pop("lowest_cost", None)  # the fixture calls compute_losses directly: no matching mask
     B, _, H, W = b["color0"].shape
     nt, _ = G.multiscale_noises(z, (B, 1, H, W), sclm)
+    batch = dict(b)
+    batch["lowres"] = {k: t.detach().cpu() for k, t in leaves.items() if k[-1].isdigit() and "_s" in k}
     kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False, temporal=temporal)
-    losses, mono_losses = _hip_step(inputs, mono_outputs, outputs, leaves, kw, nt,
-                                    synth=fake_image_synthesis(b["syn_rects"]) if temporal else None)
+    synth_of = (lambda: fake_image_synthesis(b["syn_rects"])) if temporal else None
+    # the fixture calls compute_losses directly: no matching mask
+    counts, report, (losses, mono_losses, hl, mono_out) = check_multiscale_decision_exact(batch, kw, nt, False, synth_of, return_run=True)
+    assert all(v[0] <= 1e-4 for v in report.values()), report
     if temporal:
-        assert mono_outputs["has_ins"] is True and all(("syn", f, s_) in mono_outputs for f in (-1, 1) for s_ in range(sclm + 1))
+        assert mono_out["has_ins"] is True and all(("syn", f, s_) in mono_out for f in (-1, 1) for s_ in range(sclm + 1))
     N = B * H * W
+    n_diff = sum(counts.values())
     got = {"teacher": mono_losses, "student": {k.replace("main/", ""): v for k, v in losses.items() if k.startswith("main/")}}
     for s in range(sclm + 1):
         got["student"]["consistency_loss/%d" % s] = losses["consistency_loss/%d" % s]
@@ -103,20 +111,14 @@ def test_four_scales_against_the_reference_fixture(temporal):
             if key not in z:
                 continue
             ref = float(z[key])
-            tie = 2.0 * (sclm + 1) / N if (who == "teacher" and ("reproj" in k or k.startswith("loss"))) else 0.0
-            assert abs(float(v) - ref) <= 2e-4 * abs(ref) + 1e-6 + tie, (who, k, float(v), ref)
+            tie = 2.0 * n_diff / N  # a pixel that decides the other way moves a masked mean by <~ 2/N
+            assert abs(float(v) - ref) <= 1e-5 * abs(ref) + 1e-7 + tie, (who, k, float(v), ref, n_diff)
             checked += 1
     assert checked >= 4 * (sclm + 1) + 2
-    total = float(z["teacher/loss"]) + float(z["student/loss"])
-    assert abs(float(losses["loss"].detach()) - total) <= 2e-4 * abs(total) + 2.0 * (sclm + 1) / N
-    renorm = 4.0 / N
-    for k, t in leaves.items():
-        g, r = t.grad.cpu().numpy(), z["grad/" + k].reshape(t.shape)
-        if g.ndim == 4:
-            bad = (np.abs(g - r) > (2e-4 + renorm) * np.abs(r).max()).mean()
-            assert bad <= (2e-2 if k[-1].isdigit() else 5e-3), (k, bad)
-        else:
-            assert _l2rel(g, r) <= 2e-2, k
+    if n_diff == 0:  # the same decisions as the reference took: its gradients at the north star's tolerance
+        for k, t in hl.items():
+            g, r = t.grad.cpu().numpy(), z["grad/" + k].reshape(t.shape)
+            assert _l2rel(g, r) <= 1e-4, (k, _l2rel(g, r))
 
 
 def _build(batch, dev, sclm):
@@ -154,7 +156,7 @@ def _frac_dist(sample, H, W):
     return d[:, None]
 
 
-def check_multiscale_decision_exact(batch, kw, nt, matching, synth_of=None):
+def check_multiscale_decision_exact(batch, kw, nt, matching, synth_of=None, return_run=False):
     """tests/test_gpu_decisions.py's method on the four-scale path: (i) the kernels' per-scale decisions (winner, automask,
     bilinear tap cell / border clip per frame, L1 signs; the matching mask; the smoothness signs are the raw disparity
     differences' by construction) equal the free-running oracle's except at a handful of pixels, each shown to be a near-tie in
@@ -178,7 +180,8 @@ def check_multiscale_decision_exact(batch, kw, nt, matching, synth_of=None):
     losses["loss"].backward()
     torch.cuda.synchronize()
     kd = HH.ms_kernel_decisions(decs, ho["consistency_mask"], batch, sclm)
-    od = HH.ms_oracle_decisions(o, batch, nt, sclm)
+    noise_scale = 0.0 if kw.get("disable_automasking") else 1e-5  # (upstream still compares against the identity term, without noise)
+    od = HH.ms_oracle_decisions(o, batch, nt, sclm, noise_scale)
     if temporal:  # where a synthesised candidate won, the kernels report no L1 signs (theirs are a warped candidate's): take the
         for s in range(sclm + 1):  # signs of THAT candidate's differences in the oracle's images (not of the oracle's own winner)
             win = kd["teacher"][s]["win"]
@@ -191,7 +194,7 @@ def check_multiscale_decision_exact(batch, kw, nt, matching, synth_of=None):
     counts = {}
     for s in range(sclm + 1):
         sc = o["scales"][s]
-        idn = sc["ident"] + nt[s].numpy() * np.float32(1e-5)
+        idn = sc["ident"] + nt[s].numpy() * np.float32(noise_scale)
 
         def l1_gap(preds, cands):
             win = cands.argmin(1)[:, None]
@@ -219,7 +222,7 @@ def check_multiscale_decision_exact(batch, kw, nt, matching, synth_of=None):
     # the smoothness signs: the oracle's (of the mean-normalised map) differ from the raw differences' only at near-equal neighbours
     for s in range(sclm + 1):
         for who, name in (("teacher", "disp_teacher"), ("student", "disp_student")):
-            disp = batch[name] if s == 0 else torch.nn.functional.avg_pool2d(batch[name], 2 ** s)
+            disp = HH._lowres(batch, name, s)
             amb = HH.smooth_sign_ambiguous(disp.numpy())
             (kx, ky), (ox, oy) = kd[who][s]["smooth"], od[who][s]["smooth"]
             dx, dy = (kx != ox).numpy(), (ky != oy).numpy()
@@ -229,7 +232,7 @@ def check_multiscale_decision_exact(batch, kw, nt, matching, synth_of=None):
     for k, v in f["teacher"].items():
         assert abs(float(mono_losses[k]) - v) <= 1e-5 * abs(v) + 1e-9, ("teacher", k, float(mono_losses[k]), v)
     for k, v in f["student"].items():
-        name = k if k.startswith("consistency") else "main/" + k
+        name = k if k.startswith(("consistency", "ensemble")) else "main/" + k
         assert abs(float(losses[name]) - v) <= 1e-5 * abs(v) + 1e-9, ("student", k, float(losses[name]), v)
     assert abs(float(losses["loss"].detach()) - f["total"]) <= 1e-5 * abs(f["total"])
     f64 = HH.ms_run_oracle(batch, kw, nt, nt, matching, synth=synth_of() if synth_of else None, forced=_to64(kd), double=True)
@@ -244,6 +247,8 @@ def check_multiscale_decision_exact(batch, kw, nt, matching, synth_of=None):
             tol_px = max(1e-4, 1.25 * np.abs(r32 - r64).max() / sc_)
             worst = np.abs(g - r64).max() / sc_
             assert worst <= tol_px, (key, "worst pixel / map scale", worst, tol_px, np.unravel_index(np.abs(g - r64).argmax(), g.shape))
+    if return_run:
+        return counts, report, (losses, mono_losses, hl, hm)
     return counts, report
 
 
@@ -322,46 +327,15 @@ def test_in_kernel_noise_equals_the_same_noise_handed_in():
 @pytest.mark.parametrize("case", [(3, 40, 72, 2), (12, 192, 640, 3)], ids=["b3-40x72-sclm2", "baseline-b12-192x640-sclm3"])
 def test_no_ssim_against_the_oracle(case):
     """--no_ssim on the non-distillation route (the one upstream reads the flag on, manydepth/trainer.py:1217-1218): r = mean_c
-    |target - pred| in both networks' passes and in the identity term (MAL_STEP_NO_SSIM)"""
+    |target - pred| in both networks' passes and in the identity term (MAL_STEP_NO_SSIM).  Decision-exact (round 5): r without
+    SSIM lands within rounding of a threshold far more often than the SSIM mix does, which rounds 2-4 absorbed by not holding the
+    poses of samples with a near-tie; with the oracle taking the kernels' decisions nothing is exempted."""
     B, H, W, sclm = case
     batch = make_batch(B, H, W, seed=81)
     g = torch.Generator().manual_seed(14)
     nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
     kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False, no_ssim=True)
-    oi, om, oo, ol = _build(batch, "cpu", sclm)
-    rt, rs = _oracle_step(oi, om, oo, kw, nt, nt, matching=True)
-    hi, hm, ho, hl = _build(batch, DEV, sclm)
-    losses, mono_losses = _hip_step(hi, hm, ho, hl, kw, nt)
-    N = B * H * W
-    tie_t = 40.0 * (sclm + 1) / N
-    for k, v in rt.items():
-        assert abs(float(mono_losses[k]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + tie_t, ("teacher", k, float(mono_losses[k]), float(v))
-    for k, v in rs.items():
-        name = k if k.startswith("consistency") else "main/" + k
-        assert abs(float(losses[name]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + 4.0 / N, ("student", k, float(losses[name]), float(v))
-    # r = mean_c |t - p| lands within rounding of the automask threshold / of the other candidate far more often than the SSIM
-    # mix does: a sample where the ORACLE's own gap is below 5e-7 at some pixel of some scale may decide that pixel either way,
-    # and one flipped pixel moves a pose gradient (a sum of cancelling terms) by per cent -- those samples' poses are not held
-    tgt = oi[("color", 0, 0)]
-    with torch.no_grad():
-        I = torch.cat([O.compute_reprojection_loss(oi[("color", f, 0)], tgt, True) for f in (-1, 1)], 1).min(1, keepdim=True)[0]
-        tied = torch.zeros(B, dtype=torch.bool)
-        for sc in range(sclm + 1):
-            R = torch.cat([O.compute_reprojection_loss(om[("color", f, sc)].detach(), tgt, True) for f in (-1, 1)], 1)
-            gap = torch.minimum((R.min(1, keepdim=True)[0] - (I + nt[sc] * 1e-5)).abs(), (R[:, 0:1] - R[:, 1:2]).abs())
-            tied |= (gap.flatten(1).min(1)[0] < 5e-7)
-    keep = (~tied).numpy()
-    if H * W >= 20000:
-        keep[:] = True  # at this size one pixel is 1e-5 of a sample: every sample's poses are held, flipped pixel or not
-    assert keep.any()
-    for k in hl:
-        gq, r = hl[k].grad.cpu().numpy(), ol[k].grad.numpy()
-        if gq.ndim == 4:
-            bad = (np.abs(gq - r) > 3e-4 * np.abs(r).max()).mean()
-            sc = int(k[-1]) if k[-1].isdigit() else 0
-            assert bad <= max(2e-3 * (1 + 4 ** sc / 8.0), 40.0 / gq.size), (k, bad)
-        else:
-            assert _l2rel(gq[keep], r[keep]) <= 2e-2, (k, _l2rel(gq[keep], r[keep]), keep)
+    check_multiscale_decision_exact(batch, kw, nt, True)
 
 
 @pytest.mark.parametrize("kw_extra", [{"disable_automasking": True}, {"disable_motion_masking": True},
@@ -373,7 +347,7 @@ def test_mask_switches_against_the_oracle(kw_extra):
     """--disable_automasking (upstream still compares against the identity term, trainer.py:1296-1311: only the noise goes),
     --disable_motion_masking, --no_matching_augmentation (:1321-1326: the student's weight leaves the consistency mask / the
     (1 - augmentation) factor out), --ensemble (:1346-1351: + mean |(mono + multi)/2 - multi| * mask for the student) on the
-    four-scale path"""
+    four-scale path; decision-exact"""
     B, H, W, sclm = 3, 40, 72, 2
     batch = make_batch(B, H, W, seed=85)
     batch["augmentation_mask"][0] = 1.0  # one augmented sample, so that the switch shows
@@ -381,25 +355,8 @@ def test_mask_switches_against_the_oracle(kw_extra):
     nt = [torch.randn(B, 1, H, W, generator=g) for _ in range(sclm + 1)]
     kw = dict(height=H, width=W, batch_size=B, sclm=sclm, distil=False)
     kw.update(kw_extra)
-    oi, om, oo, ol = _build(batch, "cpu", sclm)
-    rt, rs = _oracle_step(oi, om, oo, kw, nt, nt, matching=True)
-    hi, hm, ho, hl = _build(batch, DEV, sclm)
-    losses, mono_losses = _hip_step(hi, hm, ho, hl, kw, nt)
-    N = B * H * W
-    for k, v in rt.items():
-        assert abs(float(mono_losses[k]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + 12.0 / N, ("teacher", k, float(mono_losses[k]), float(v))
-    for k, v in rs.items():
-        name = k if k.startswith(("consistency", "ensemble")) else "main/" + k
-        assert abs(float(losses[name]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + 4.0 / N, ("student", k, float(losses[name]), float(v))
-    assert (ho["consistency_mask"].cpu().numpy() != oo["consistency_mask"].numpy()).mean() <= 1e-3  # x matching mask, either way
-    for k in hl:
-        gq, r = hl[k].grad.cpu().numpy(), ol[k].grad.numpy()
-        if gq.ndim == 4:
-            bad = (np.abs(gq - r) > 3e-4 * np.abs(r).max()).mean()
-            sc = int(k[-1]) if k[-1].isdigit() else 0
-            assert bad <= max(2e-3 * (1 + 4 ** sc / 8.0), 40.0 / gq.size), (k, bad)
-        else:
-            assert _l2rel(gq, r) <= 3e-2, (k, _l2rel(gq, r))
+    counts, report = check_multiscale_decision_exact(batch, kw, nt, True)
+    assert all(v[0] <= 1e-4 for v in report.values()), report
 
 
 def _compare_with_operator_route(B, H, W, sclm, temporal, seed):
