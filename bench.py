@@ -978,7 +978,7 @@ def main():
     if args.mode in ("step", "distil"):
         # kernel_ms / achieved / frac: the kernel inside a REPLAYED graph (what the headline's graph-replayed step runs),
         # measured in this run; eager_kernel_ms: the same kernel bracketed by HIP events on eager launches (6-10 % longer:
-        # an eager stream's packets carry release fences, and the event pair adds packet processing)
+        # an eager stream's packets carry release fences, and the event pair adds packet processing; LABBOOK.md 5)
         have_replay = replayed is not None and len(replayed) == 2
         kernel_ms = replayed[0] if have_replay else kern_ms_plain
         frac_of = lambda ms: (ALG_BYTES_PER_PX * n_px / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS if ms and ms > 0 else 0.0

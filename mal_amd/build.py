@@ -31,7 +31,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectoriz
          "-mllvm", "-amdgpu-sched-strategy=max-ilp",
          "-Wall", "-Wno-unused-function", "-I", CSRC]
 # MAL_EXPERIMENTS=1 in the environment builds the formulations that were measured slower and are kept for same-box A/B
-# only (LDS-tiled passes, three-wave pipeline, exporting gradient pass, classified dispatch order); the
+# only (LABBOOK.md 6: LDS-tiled passes, three-wave pipeline, exporting gradient pass, classified dispatch order); the
 # default library does not contain them and mal_set_option refuses their switches
 if os.environ.get("MAL_EXPERIMENTS", "0") not in ("", "0"):
     FLAGS = FLAGS + ["-DMAL_EXPERIMENTS"]

@@ -3,7 +3,7 @@
 // The translation units are compiled with -ffp-contract=off: a fused multiply-add appears
 // only where it is written (fma_), so each formula below states its own rounding points.
 // They are chosen to follow what the reference's PyTorch-CPU path executes (probed against
-// ATen 2.10 bit for bit in the authoring container, DESIGN.md "Numerics"):
+// ATen 2.10 bit for bit in the authoring container, DESIGN.md 2 "Numerics"):
 //   * bmm / matmul rows: p0*x0, then fma per further k            (layers.py:164,187)
 //   * grid_sample bilinear blend: nw*w, then fma for ne, sw, se    (trainer.py:1122)
 //   * unnormalise: ac=True (g+1)*((S-1)/2); ac=False fma(g+1, S/2, -0.5)

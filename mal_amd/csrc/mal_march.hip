@@ -151,6 +151,9 @@ MAL_DEV void dec_store(unsigned* dbg, unsigned n, int plane, unsigned boff, unsi
   *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dbg + (size_t)plane * n) + boff) = v;
 }
 
+#ifndef MAL_PROBE_NOLOADS
+#define MAL_PROBE_NOLOADS 0
+#endif
 // projection, tap weights and the eight gathers
 // (Round 5 tried a next-row PREFETCH here for the cold regime -- one dword per frame of the source row the next iteration's taps
 // will newly touch, issued behind the gathers, dropped at the top of the next iteration: +2 vector-memory instructions per row
@@ -447,7 +450,7 @@ MAL_DEV void march_body() {
   // Measured (same box, teacher pass replayed alone, profiles/r04_hsum_variants_ab.txt): LDS for the 18 partial planes -1 %,
   // LDS for the 24 statistic planes +2 % (their results are needed at once: the LDS round trip is exposed where the DPP adds
   // pipeline), both +2.5 %, and the gathers'-shadow ordering +7 % -- although the row loop's vector-ALU pipe cycles fall by
-  // 13 %: the pass is not bound by the vector ALU's throughput.  Shipped: partial planes through LDS, the rest DPP.
+  // 13 %: the pass is not bound by the vector ALU's throughput (LABBOOK.md 6).  Shipped: partial planes through LDS, the rest DPP.
   // Build-time switches (same-box A/B with scripts/build_variant.py):
   //   MAL_HSUM_H   the 24 statistic planes:  0 = DPP blocks, 1 = LDS, three groups in flight, 2 = LDS, all groups in flight
   //   MAL_HSUM_HC  the 18 partial planes:    0 = DPP blocks, 1 = LDS, three groups in flight, 2 = LDS, all groups in flight
@@ -563,20 +566,21 @@ MAL_DEV void march_body() {
       return m ? v : absent;
     };
     a.ident = 0.f; a.noise = 0.f;
-    if (AUTOMASK && !TEMPORAL) { a.ident = ldf(pp.ident, oc); if (!NO_NOISE) a.noise = opt(pp.noise, oc, 0.f); }
+    if (AUTOMASK && !TEMPORAL) { if (!(MAL_PROBE_NOLOADS & 1)) a.ident = ldf(pp.ident, oc); else a.ident = 0.3f; if (!NO_NOISE) a.noise = opt(pp.noise, oc, 0.f); }
     if (TEMPORAL) {
       a.ident = ldf(pp.forced_w, oc);
-      a.noise = (float)*(pp.forced_arg + (oc >> 2));
+      a.noise = (MAL_PROBE_NOLOADS & 4) ? 0.f : (float)*(pp.forced_arg + (oc >> 2));
       const unsigned og = moff(min(max(rr - 2, 0), H - 1)) - (unsigned)b * (unsigned)HW * 4u;  // pixel offset inside the sample
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) a.gc[f * 3 + ch] = ldf(pp.gcol[f] + ((size_t)b * 3 + ch) * HW, og);
+        for (int ch = 0; ch < 3; ++ch) a.gc[f * 3 + ch] = (MAL_PROBE_NOLOADS & 2) ? 0.f : ldf(pp.gcol[f] + ((size_t)b * 3 + ch) * HW, og);
     }
     a.ext = 1.f; a.mono = 0.f; a.cost = 1.f;
     if (EXT_YES) a.ext = ldf(pp.ext_mask, oc);
     else if (!EXT_NO) a.ext = opt(pp.ext_mask, oc, 1.f);
-    if (COST_YES) {
+    if (COST_YES && (MAL_PROBE_NOLOADS & 8)) { a.mono = 0.5f; a.cost = 0.2f; }
+    else if (COST_YES) {
       a.mono = ldf(pp.mono_disp, oc); a.cost = ldf(pp.lowest_cost, oc);
     } else if (!COST_NO) {
       a.mono = opt(pp.lowest_cost ? pp.mono_disp : nullptr, oc, 0.f);
@@ -590,7 +594,7 @@ MAL_DEV void march_body() {
       a.e_er = opt(pp.ens_reproj, oq, 0.f);
       a.e_ensd = opt(pp.ens_disp, oq, 0.f);
     }
-    if (TEMPORAL) a.e_mono = opt(pp.fin_gn, oq, 0.f);  // the smoothness gradient of the gradient row (fin_out)
+    if (TEMPORAL && !(MAL_PROBE_NOLOADS & 16)) a.e_mono = opt(pp.fin_gn, oq, 0.f);  // the smoothness gradient of the gradient row (fin_out)
   };
   Ahead nxt;
   request(maps_of(p), r_first, nxt);
@@ -1059,7 +1063,7 @@ MAL_DEV void march_body() {
       if (!in_x) w = 0.f;  // not a pixel: contributes nothing (its statistics only served as halo)
       pi0.w = w;
       if (out_x && c >= y_lo && c < y_hi) {
-        if (p.min_reproj) stf(p.min_reproj, go, pi0.rp);
+        if (p.min_reproj && !(MAL_PROBE_NOLOADS & 32)) stf(p.min_reproj, go, pi0.rp);
         if (OUTS) {  // the pass in front of the producer: second copy of the min, the automask weight
           if (p.min_reproj2) stf(p.min_reproj2, go, pi0.rp);
           if (p.weight_out) stf(p.weight_out, go, w);
@@ -1198,7 +1202,7 @@ template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG = false, bool 
 __global__ __launch_bounds__(64, 2) void march_kernel(MarchParams p_kernarg) {
   march_body<GRAD, AUTOMASK, POSE, EPI, DBG, TEMPORAL, false>();
 }
-#ifdef MAL_EXPERIMENTS  // option "temporal_spec" (measured slower): not in the default build
+#ifdef MAL_EXPERIMENTS  // option "temporal_spec" (measured slower, LABBOOK.md 6): not in the default build
 template <bool DBG>
 __global__ __launch_bounds__(64, 2) void march_export_kernel(MarchParams p_kernarg) {
   march_body<true, true, true, false, DBG, false, true>();
@@ -1233,7 +1237,7 @@ __global__ __launch_bounds__(64, 2) void march_refine_kernel(MarchParams p_kerna
   march_body<true, true, true, true, false, false, false, kSpecRefine>();
 }
 
-#ifdef MAL_EXPERIMENTS  // option "march3" (measured slower): not in the default build
+#ifdef MAL_EXPERIMENTS  // option "march3" (measured slower, LABBOOK.md 6): not in the default build
 #include "experiments/march3.inc"
 #endif  // MAL_EXPERIMENTS
 

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
   photo_march_bwd_task<FUSED>(p, task);
 }
 
-#ifdef MAL_EXPERIMENTS  // option "syn_queue" (measured slower): not in the default build
+#ifdef MAL_EXPERIMENTS  // option "syn_queue" (measured slower, LABBOOK.md 6): not in the default build
 // one wavefront per task of the fused sweep's decomposition: the test photo_march_bwd_task<true> opens with
 __global__ __launch_bounds__(64) void photo_march_classify_kernel(PhotoMarchParams p) {
   constexpr int HALO = 2, CW = 60;

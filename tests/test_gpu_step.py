@@ -296,7 +296,7 @@ def test_a_raising_producer_leaves_the_library_usable():
 
 @pytest.mark.parametrize("option,temporal", [("march3", False), ("temporal_spec", True)], ids=["march3", "temporal_spec"])
 def test_alternative_teacher_schedules_hold_against_the_oracle(option, temporal):
-    """Two schedules of the teacher's gradient pass that were measured SLOWER and are off by default, kept
+    """Two schedules of the teacher's gradient pass that were measured SLOWER and are off by default (LABBOOK.md 6), kept
     for same-box A/B -- mal_set_option("march3", 1): three cooperating waves per strip (warp | statistics | gradient row);
     mal_set_option("temporal_spec", 1): the --temporal step's pass in front of the producer already takes the gradient and
     the sweep behind it only redoes the tasks near the region map.  Each is held against the oracle by the same
