@@ -151,9 +151,6 @@ MAL_DEV void dec_store(unsigned* dbg, unsigned n, int plane, unsigned boff, unsi
   *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dbg + (size_t)plane * n) + boff) = v;
 }
 
-#ifndef MAL_PROBE_NOLOADS
-#define MAL_PROBE_NOLOADS 0
-#endif
 // projection, tap weights and the eight gathers
 // (Round 5 tried a next-row PREFETCH here for the cold regime -- one dword per frame of the source row the next iteration's taps
 // will newly touch, issued behind the gathers, dropped at the top of the next iteration: +2 vector-memory instructions per row
@@ -311,6 +308,9 @@ enum : int {
 #define MAL_RI(j) (j)
 #define MAL_RING_POSE 24
 #define MAL_TEACHER_WAVES 2
+#endif
+#ifndef MAL_FIN_UNIFORM
+#define MAL_FIN_UNIFORM 1
 #endif
 template <bool GRAD, bool AUTOMASK, bool POSE, bool EPI, bool DBG, bool TEMPORAL, bool EXPORT, int SPEC = 0>
 MAL_DEV void march_body() {
@@ -566,21 +566,24 @@ MAL_DEV void march_body() {
       return m ? v : absent;
     };
     a.ident = 0.f; a.noise = 0.f;
-    if (AUTOMASK && !TEMPORAL) { if (!(MAL_PROBE_NOLOADS & 1)) a.ident = ldf(pp.ident, oc); else a.ident = 0.3f; if (!NO_NOISE) a.noise = opt(pp.noise, oc, 0.f); }
+    if (AUTOMASK && !TEMPORAL) { a.ident = ldf(pp.ident, oc); if (!NO_NOISE) a.noise = opt(pp.noise, oc, 0.f); }
     if (TEMPORAL) {
       a.ident = ldf(pp.forced_w, oc);
-      a.noise = (MAL_PROBE_NOLOADS & 4) ? 0.f : (float)*(pp.forced_arg + (oc >> 2));
-      const unsigned og = moff(min(max(rr - 2, 0), H - 1)) - (unsigned)b * (unsigned)HW * 4u;  // pixel offset inside the sample
+      a.noise = (float)*(pp.forced_arg + (oc >> 2));
+      // (kernel-argument pointer) + (32-bit offset holding sample and channel: a (B,3,H,W) image is below 2^32 bytes) -- with
+      // a pointer per plane the compiler, out of scalar registers, formed six 64-bit vector addresses per row and spilled
+      const unsigned og = moff(min(max(rr - 2, 0), H - 1)) + 2u * (unsigned)b * (unsigned)HW * 4u;  // pixel (b, 0, y, x) of a (B,3,H,W) image
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int ch = 0; ch < 3; ++ch) {
+        const unsigned o = og + (unsigned)ch * (unsigned)HW * 4u;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) a.gc[f * 3 + ch] = (MAL_PROBE_NOLOADS & 2) ? 0.f : ldf(pp.gcol[f] + ((size_t)b * 3 + ch) * HW, og);
+        for (int f = 0; f < 2; ++f) a.gc[f * 3 + ch] = ldf(pp.gcol[f], o);
+      }
     }
     a.ext = 1.f; a.mono = 0.f; a.cost = 1.f;
     if (EXT_YES) a.ext = ldf(pp.ext_mask, oc);
     else if (!EXT_NO) a.ext = opt(pp.ext_mask, oc, 1.f);
-    if (COST_YES && (MAL_PROBE_NOLOADS & 8)) { a.mono = 0.5f; a.cost = 0.2f; }
-    else if (COST_YES) {
+    if (COST_YES) {
       a.mono = ldf(pp.mono_disp, oc); a.cost = ldf(pp.lowest_cost, oc);
     } else if (!COST_NO) {
       a.mono = opt(pp.lowest_cost ? pp.mono_disp : nullptr, oc, 0.f);
@@ -594,7 +597,7 @@ MAL_DEV void march_body() {
       a.e_er = opt(pp.ens_reproj, oq, 0.f);
       a.e_ensd = opt(pp.ens_disp, oq, 0.f);
     }
-    if (TEMPORAL && !(MAL_PROBE_NOLOADS & 16)) a.e_mono = opt(pp.fin_gn, oq, 0.f);  // the smoothness gradient of the gradient row (fin_out)
+    if (TEMPORAL) a.e_mono = opt(pp.fin_gn, oq, 0.f);  // the smoothness gradient of the gradient row (fin_out)
   };
   Ahead nxt;
   request(maps_of(p), r_first, nxt);
@@ -604,6 +607,11 @@ MAL_DEV void march_body() {
     fin_cR = p.fin_coefs[0] * gg; fin_cS = p.fin_coefs[4] * gg;
     fin_inv = div_(1.0f, (float)p.fin_stats[b] + 1e-7f);
     fin_corr = (float)p.fin_stats[2 * p.B + b];
+#if MAL_FIN_UNIFORM
+    // wave-uniform (the sample's scalars): keep them in scalar registers -- this instantiation sits at the 256-VGPR limit
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    fin_cR = uni(fin_cR); fin_cS = uni(fin_cS); fin_inv = uni(fin_inv); fin_corr = uni(fin_corr);
+#endif
   }
   // reciprocals of the grid normalisation's divisors, once per wave (scalar registers)
   const float norm_rw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
@@ -908,15 +916,20 @@ MAL_DEV void march_body() {
       float* const c0 = p.color_out[0];
       float* const c1 = p.color_out[1];
       if (c0 && r >= y_lo && r < y_hi && out_x) {
-        const unsigned og = moff(r) - (unsigned)b * (unsigned)HW * 4u;
-        const size_t pl = (size_t)b * (p.color_out_stride ? (size_t)p.color_out_stride : 3 * (size_t)HW);
-        stf(c0 + pl, og, w0.x[0].x); stf(c0 + pl + HW, og, w0.x[0].y); stf(c0 + pl + 2 * (size_t)HW, og, w0.x[2].x);
-        stf(c1 + pl, og, w0.x[1].x); stf(c1 + pl + HW, og, w0.x[1].y); stf(c1 + pl + 2 * (size_t)HW, og, w0.x[2].y);
+        // (kernel-argument pointer) + (32-bit offset holding sample and channel plane): a pointer per plane costs the loop six
+        // 64-bit vector address computations (the scalar registers are exhausted); march_launch bounds the buffers below 2^32 bytes
+        const unsigned og = moff(r) - (unsigned)b * (unsigned)HW * 4u;  // pixel offset inside a plane
+        const unsigned hw4 = (unsigned)HW * 4u;
+        const unsigned o0 = og + (unsigned)b * (p.color_out_stride ? (unsigned)p.color_out_stride : 3u * (unsigned)HW) * 4u;
+        const unsigned o1 = o0 + hw4, o2 = o1 + hw4;
+        stf(c0, o0, w0.x[0].x); stf(c0, o1, w0.x[0].y); stf(c0, o2, w0.x[2].x);
+        stf(c1, o0, w0.x[1].x); stf(c1, o1, w0.x[1].y); stf(c1, o2, w0.x[2].y);
         if (p.color_out2[0]) {
-          float* const d0 = p.color_out2[0] + (size_t)b * 3 * (size_t)HW;
-          float* const d1 = p.color_out2[1] + (size_t)b * 3 * (size_t)HW;
-          stf(d0, og, w0.x[0].x); stf(d0 + HW, og, w0.x[0].y); stf(d0 + 2 * (size_t)HW, og, w0.x[2].x);
-          stf(d1, og, w0.x[1].x); stf(d1 + HW, og, w0.x[1].y); stf(d1 + 2 * (size_t)HW, og, w0.x[2].y);
+          float* const d0 = p.color_out2[0];
+          float* const d1 = p.color_out2[1];
+          const unsigned q0 = og + 3u * (unsigned)b * hw4, q1 = q0 + hw4, q2 = q1 + hw4;
+          stf(d0, q0, w0.x[0].x); stf(d0, q1, w0.x[0].y); stf(d0, q2, w0.x[2].x);
+          stf(d1, q0, w0.x[1].x); stf(d1, q1, w0.x[1].y); stf(d1, q2, w0.x[2].y);
         }
       }
     }
@@ -1029,9 +1042,9 @@ MAL_DEV void march_body() {
       if (OUTS) {  // ... the winner among the two warped candidates, twice: the copy the fused sweep updates
         unsigned char* const am = p.argmin_out;
         if (am && out_x && c >= y_lo && c < y_hi) {
-          am[so_c >> 2] = (unsigned char)pi0.win;
+          stb(am, so_c >> 2, (unsigned char)pi0.win);
           unsigned char* const am2 = p.argmin_out2;
-          if (am2) am2[so_c >> 2] = (unsigned char)pi0.win;
+          if (am2) stb(am2, so_c >> 2, (unsigned char)pi0.win);
         }
       }
       float w = 1.0f;
@@ -1063,7 +1076,7 @@ MAL_DEV void march_body() {
       if (!in_x) w = 0.f;  // not a pixel: contributes nothing (its statistics only served as halo)
       pi0.w = w;
       if (out_x && c >= y_lo && c < y_hi) {
-        if (p.min_reproj && !(MAL_PROBE_NOLOADS & 32)) stf(p.min_reproj, go, pi0.rp);
+        if (p.min_reproj) stf(p.min_reproj, go, pi0.rp);
         if (OUTS) {  // the pass in front of the producer: second copy of the min, the automask weight
           if (p.min_reproj2) stf(p.min_reproj2, go, pi0.rp);
           if (p.weight_out) stf(p.weight_out, go, w);
@@ -1538,6 +1551,8 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   dim3 grid(p.per_xcd * 8), block(64);
   if (!p.cam) return MAL_EINVAL;
   if ((long long)p.H * p.W >= (1ll << 24)) return MAL_ESHAPE;  // tap offsets use 24-bit multiplies
+  if (p.color_out[0] && (long long)p.B * (p.color_out_stride ? (long long)p.color_out_stride : 3ll * p.H * p.W) * 4 >= (1ll << 32))
+    return MAL_ESHAPE;  // the exported planes are addressed with 32-bit byte offsets
   if (!p.cam_ready) {
     hipLaunchKernelGGL(cam_setup_kernel, dim3(p.B), dim3(64), 0, st, p.K, p.T[0], p.T[1], p.invK, p.cam);
     p.cam_ready = 1;

@@ -98,6 +98,12 @@ MAL_DEV texel_t ldt(const float* base, unsigned boff) {
   return *reinterpret_cast<const texel_t*>(reinterpret_cast<const char*>(base) + boff);
 }
 MAL_DEV void stf(float* base, unsigned boff, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v; }
+MAL_DEV void stb(unsigned char* base, unsigned boff, unsigned char v) { *(base + boff) = v; }  // scalar base + 32-bit offset
+// A 32-bit byte offset as a value the compiler cannot trace back: used INSIDE a conditional block in front of ldf / stf there.
+// global_load/store take (scalar base) + (32-bit vector offset) only when instruction selection sees the offset's zero-extension
+// next to the access; an offset computed before a branch has its zero-extension hoisted in front of it, the block behind the
+// branch then sees a 64-bit value and the access is built from a 64-bit vector add (v_lshl_add_u64 + two VGPRs) instead.
+MAL_DEV unsigned fresh(unsigned v) { asm("" : "+v"(v)); return v; }
 // the three colour channels of pixel `pix` of sample b: planar (B,3,H,W) or packed (B,H,W,kTexel)
 MAL_DEV void load_rgb(const float* img, int packed, int b, int HW, unsigned pix, float* out) {
   if (packed) {

@@ -206,15 +206,18 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
   const int gxr = min(max(reflect1(gx, W), 0), W - 1);
   const bool out_x = in_x && lane >= HALO && lane < 64 - HALO;
   const float sL = gx == 0 ? 2.0f : 1.0f, sR = gx == W - 1 ? 2.0f : 1.0f;
-  const float* tb = p.target + (size_t)b * 3 * HW;
-  const float* ab = p.cand[0] + (size_t)b * 3 * HW;
-  const float* cb = p.cand[1] + (size_t)b * 3 * HW;
+  // Every access is (parameter-block pointer) + (32-bit per-lane byte offset that already holds the sample's and the plane's
+  // base): with a pointer per sample and plane (rounds 2-4) the sweep formed 51 of its 82 addresses as 64-bit vector adds --
+  // the scalar registers were exhausted -- in the kernel whose end gates the join of the --temporal step.  A (B,3,H,W) image
+  // stays below 2^32 bytes (check_shape bounds a (B,1,H,W) map below 2^31; photo_march_fused_more checks orig_stride).
+  const unsigned hw4 = (unsigned)HW * 4u;
+  const unsigned img_b = (unsigned)b * 3u * hw4;   // sample b of a (B,3,H,W) image / (B,H,W,3) texel image, bytes
+  const unsigned map_b4 = (unsigned)b * hw4;       // sample b of a (B,1,H,W) map, bytes
+  const unsigned map_b = (unsigned)b * (unsigned)HW;  // ... of a (B,H,W) byte map
   const bool sparse = FUSED && p.region && p.orig[0];
-  const float* oa = sparse ? p.orig[0] + (size_t)b * p.orig_stride : ab;
-  const float* ob = sparse ? p.orig[1] + (size_t)b * p.orig_stride : cb;
-  float* ga = p.g_cand[0] + (size_t)b * 3 * HW;
-  float* gb = p.g_cand[1] ? p.g_cand[1] + (size_t)b * 3 * HW : nullptr;
-  const size_t map_b = (size_t)b * HW;
+  const unsigned org_b = sparse ? (unsigned)b * (unsigned)p.orig_stride * 4u : 0u;
+  typedef __attribute__((address_space(4))) const PhotoMarchParams CPhoto;
+  CPhoto* const kp0 = (CPhoto*)__builtin_amdgcn_kernarg_segment_ptr();  // (the kernel's only argument)
   float sc = p.scale ? *p.scale : 1.0f;
   if (p.sums) sc = (float)((double)sc / (p.sums[1] + 1e-7));
   f2 hsA[9], hsB[9], hyA[2], hyB[2], hcA[9], hcB[9];
@@ -230,19 +233,19 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
   int win1 = 255;
   float acc_rw = 0.f, acc_w = 0.f;  // FUSED: sum rp*w, sum w over the pixels this task owns
   auto row_of = [&](int rr) { return min(max(reflect1(rr, H), 0), H - 1); };
-  const uint8_t* rgn = (FUSED && p.region) ? p.region + map_b : nullptr;
-  if (FUSED && rgn) {
+  const uint8_t* rgn0 = (FUSED && p.region) ? p.region + map_b : nullptr;
+  if (FUSED && rgn0) {
     // does the producer's region come within two pixels of this tile?  (owned pixel <- decisions of its 3x3 neighbours <-
     // their 3x3 windows)
     unsigned any = 0u;  // every load issued before the first use: no short-circuit
 #pragma unroll 8
-    for (int rr = max(y_lo - 2, 0); rr <= min(y_hi + 1, H - 1); ++rr) any |= rgn[rr * W + gxr];
+    for (int rr = max(y_lo - 2, 0); rr <= min(y_hi + 1, H - 1); ++rr) any |= rgn0[rr * W + gxr];
     if (!__any((any & 1u) && in_x)) {
       if (out_x)
         for (int c = y_lo; c < y_hi; ++c) {
-          const unsigned go = (unsigned)(c * W + gxr);
-          stf(ga, go * 4u, 0.f); stf(ga + HW, go * 4u, 0.f); stf(ga + 2 * (size_t)HW, go * 4u, 0.f);
-          if (gb) { stf(gb, go * 4u, 0.f); stf(gb + HW, go * 4u, 0.f); stf(gb + 2 * (size_t)HW, go * 4u, 0.f); }
+          const unsigned o0 = (unsigned)(c * W + gxr) * 4u + img_b, o1 = o0 + hw4, o2 = o1 + hw4;
+          stf(p.g_cand[0], o0, 0.f); stf(p.g_cand[0], o1, 0.f); stf(p.g_cand[0], o2, 0.f);
+          if (p.g_cand[1]) { stf(p.g_cand[1], o0, 0.f); stf(p.g_cand[1], o1, 0.f); stf(p.g_cand[1], o2, 0.f); }
         }
       if (lane == 0) { p.block_sums[(size_t)task * 2] = 0.0; p.block_sums[(size_t)task * 2 + 1] = 0.0; }
       return;
@@ -251,26 +254,50 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
   float nfA = 0.f, nfB = 0.f;  // region within one column, of rows r-2 and r-1
   const int r_first = max(y_lo - HALO, -1), r_last = y_hi - 1 + HALO;
   Px9 nxt;
-  request9(p, tb, ab, cb, HW, row_of(r_first), gxr, nxt);
-  float on_a[3] = {0.f, 0.f, 0.f}, on_c[3] = {0.f, 0.f, 0.f};  // sparse pair: the same pixel of the images it was made from
-  auto request_orig = [&](int row) {
+  auto request9o = [&](CPhoto& P, int row, Px9& q) {  // the nine planes of pixel (row, gxr) of sample b
     const unsigned bo = (unsigned)(row * W + gxr) * 4u;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) { on_a[ch] = ldf(oa + (size_t)ch * HW, bo); on_c[ch] = ldf(ob + (size_t)ch * HW, bo); }
+    const unsigned o0 = bo + img_b, o1 = o0 + hw4, o2 = o1 + hw4;
+    // (FUSED <=> the target is handed over as (B,H,W,3) texels -- the step's packed copy / a channels_last input --, checked by
+    // the launcher: as a RUN-TIME branch it split the block, the offsets' zero-extension was hoisted across it, and instruction
+    // selection no longer saw (scalar base + zext(32-bit offset)): the six candidate loads became 64-bit vector adds)
+    if (FUSED) {
+      const texel_t t = ldt(P.target, bo * (unsigned)kTexel + (unsigned)b * (unsigned)HW * (unsigned)(kTexel * 4));
+      q.t[0] = t.x; q.t[1] = t.y; q.t[2] = t.z;
+    } else {
+      q.t[0] = ldf(P.target, o0); q.t[1] = ldf(P.target, o1); q.t[2] = ldf(P.target, o2);
+    }
+    q.a[0] = ldf(P.cand[0], o0); q.a[1] = ldf(P.cand[0], o1); q.a[2] = ldf(P.cand[0], o2);
+    q.c[0] = ldf(P.cand[1], o0); q.c[1] = ldf(P.cand[1], o1); q.c[2] = ldf(P.cand[1], o2);
   };
-  if (sparse) request_orig(row_of(r_first));
-  unsigned fr_nxt = (FUSED && rgn) ? rgn[row_of(r_first) * W + gxr] : 1u;  // the region byte travels one row ahead, like the planes
+  request9o(*kp0, row_of(r_first), nxt);
+  float on_a[3] = {0.f, 0.f, 0.f}, on_c[3] = {0.f, 0.f, 0.f};  // sparse pair: the same pixel of the images it was made from
+  auto request_orig = [&](CPhoto& P, int row) {
+    const unsigned o0 = (unsigned)(row * W + gxr) * 4u + org_b, o1 = o0 + hw4, o2 = o1 + hw4;
+    on_a[0] = ldf(P.orig[0], o0); on_a[1] = ldf(P.orig[0], o1); on_a[2] = ldf(P.orig[0], o2);
+    on_c[0] = ldf(P.orig[1], o0); on_c[1] = ldf(P.orig[1], o1); on_c[2] = ldf(P.orig[1], o2);
+  };
+  if (sparse) request_orig(*kp0, row_of(r_first));
+  unsigned fr_nxt = (FUSED && rgn0) ? rgn0[row_of(r_first) * W + gxr] : 1u;  // the region byte travels one row ahead, like the planes
   unsigned fr_m0 = 0u, fr_m1 = 0u;  // region bytes of rows r-1 and r-2
   float pm_nxt = 0.f, idn_nxt = 0.f;
   int win_nxt = 255;
   if (FUSED) {  // centre row of the first iteration: r_first - 1
     const unsigned g0 = (unsigned)(min(max(r_first - 1, 0), H - 1) * W + gxr);
-    pm_nxt = ldf(p.prev_min + map_b, g0 * 4u);
-    win_nxt = p.prev_arg[map_b + g0];
-    idn_nxt = ldf(p.ident + map_b, g0 * 4u);
-    if (p.noise) idn_nxt += ldf(p.noise + map_b, g0 * 4u) * 0.00001f;
+    pm_nxt = ldf(p.prev_min, g0 * 4u + map_b4);
+    win_nxt = *(p.prev_arg + (map_b + g0));
+    idn_nxt = ldf(p.ident, g0 * 4u + map_b4);
+    if (p.noise) idn_nxt += ldf(p.noise, g0 * 4u + map_b4) * 0.00001f;
   }
   for (int r = r_first; r <= r_last; ++r) {
+    // the parameter block's pointers are re-read from the kernarg segment where they are used (scalar loads through a
+    // pointer made opaque per iteration, as in march_body): held across the loop they exhaust the scalar registers and the
+    // compiler falls back to 64-bit VECTOR addresses (two VALU instructions and two VGPRs per access)
+    CPhoto* kp = kp0;
+    asm volatile("" : "+s"(kp));
+    CPhoto& P = *kp;
+    float* const ga = P.g_cand[0];
+    float* const gb = P.g_cand[1];
+    const uint8_t* const rgn = (FUSED && P.region) ? P.region + map_b : nullptr;
     Px9 cur = nxt;
     const unsigned fr_q = fr_m1;  // region byte of the gradient row q = r-2
     fr_m1 = fr_m0; fr_m0 = fr_nxt;
@@ -279,9 +306,9 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) { cur.a[ch] = on_a[ch]; cur.c[ch] = on_c[ch]; }
     }
-    request9(p, tb, ab, cb, HW, row_of(r + 1), gxr, nxt);
-    if (sparse) request_orig(row_of(r + 1));
-    if (FUSED && rgn) fr_nxt = rgn[row_of(r + 1) * W + gxr];
+    request9o(P, row_of(r + 1), nxt);
+    if (sparse) request_orig(P, row_of(r + 1));
+    if (FUSED && P.region) fr_nxt = *(P.region + fresh(map_b + (unsigned)(row_of(r + 1) * W + gxr)));
     const int c = r - 1;
     const bool c_valid = c >= 0 && c < H && c >= y_lo - 1 && c <= y_hi;
     float w0 = 0.f;
@@ -293,15 +320,15 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
       pm = pm_nxt; win0 = win_nxt; idn = idn_nxt;
       const int cn = min(max(r, 0), H - 1);  // next iteration's centre row (clamped: unused when not valid)
       const unsigned gn = (unsigned)(cn * W + gxr);
-      pm_nxt = ldf(p.prev_min + map_b, gn * 4u);
-      win_nxt = p.prev_arg[map_b + gn];
-      idn_nxt = ldf(p.ident + map_b, gn * 4u);
-      if (p.noise) idn_nxt += ldf(p.noise + map_b, gn * 4u) * 0.00001f;
+      pm_nxt = ldf(P.prev_min, gn * 4u + map_b4);
+      win_nxt = *(P.prev_arg + (map_b + gn));
+      idn_nxt = ldf(P.ident, gn * 4u + map_b4);
+      if (P.noise) idn_nxt += ldf(P.noise, fresh(gn * 4u + map_b4)) * 0.00001f;
       if (!c_valid) { pm = 0.f; win0 = 255; idn = 0.f; }
     } else if (c_valid) {
       const unsigned go = (unsigned)(c * W + gxr);
-      w0 = in_x ? ldf(p.weight_in + map_b, go * 4u) : 0.f;  // not a pixel: contributes nothing
-      win0 = p.argmin_in[map_b + go];
+      w0 = in_x ? ldf(P.weight_in, go * 4u + map_b4) : 0.f;  // not a pixel: contributes nothing
+      win0 = *(P.argmin_in + (map_b + go));
     }
     const f2 x0[3] = {(f2){cur.a[0], cur.a[1]}, (f2){cur.c[0], cur.c[1]}, (f2){cur.a[2], cur.c[2]}};
     const f2 y0rg = (f2){cur.t[0], cur.t[1]};
@@ -351,23 +378,23 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
         const f2 rr = bc(0.85f) * div3_2(ssum) + bc(0.15f) * div3_2(lsum);
         float rp = pm;  // running min, first minimum wins (torch.min)
         if (near_c) {
-          if (rr.x < rp) { rp = rr.x; win0 = p.idx[0]; }
-          if (rr.y < rp) { rp = rr.y; win0 = p.idx[1]; }
+          if (rr.x < rp) { rp = rr.x; win0 = P.idx[0]; }
+          if (rr.y < rp) { rp = rr.y; win0 = P.idx[1]; }
         }
-        const float w = p.weight_given ? idn : ((rp <= idn) ? 1.0f : 0.0f);
+        const float w = P.weight_given ? idn : ((rp <= idn) ? 1.0f : 0.0f);
         w0 = in_x ? w : 0.f;
         if (out_x && c >= y_lo && c < y_hi) {
           const unsigned go = (unsigned)(c * W + gxr);
-          stf(p.min_reproj + map_b, go * 4u, rp);
-          p.argmin[map_b + go] = (uint8_t)win0;
-          if (!p.weight_given) stf(p.weight_out + map_b, go * 4u, w);
-          const float w_old = p.weight_given ? idn : ((pm <= idn) ? 1.0f : 0.0f);  // what the pass over the earlier candidates decided and summed
+          stf(P.min_reproj, go * 4u + map_b4, rp);
+          *(P.argmin + (map_b + go)) = (uint8_t)win0;
+          if (!P.weight_given) stf(P.weight_out, fresh(go * 4u + map_b4), w);
+          const float w_old = P.weight_given ? idn : ((pm <= idn) ? 1.0f : 0.0f);  // what the pass over the earlier candidates decided and summed
           acc_rw += rp * w - pm * w_old;
           acc_w += w - w_old;
         }
       }
       const float kk = -w0 * (0.85f / 3.0f) * 0.5f;
-      const float kk0 = win0 == p.idx[0] ? kk : 0.f, kk1 = win0 == p.idx[1] ? kk : 0.f;
+      const float kk0 = win0 == P.idx[0] ? kk : 0.f, kk1 = win0 == P.idx[1] ? kk : 0.f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         // torch.clamp passes gradient on [0,1] inclusive (clamped == raw)
@@ -389,7 +416,7 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
     if (q >= y_lo && q < y_hi) {  // wave-uniform
       const float wyd = (q == H - 2) ? 2.0f : 1.0f;
       const float lw = w1 * (0.15f / 3.0f);
-      const float lw0 = win1 == p.idx[0] ? lw : 0.f, lw1 = win1 == p.idx[1] ? lw : 0.f;
+      const float lw0 = win1 == P.idx[0] ? lw : 0.f, lw1 = win1 == P.idx[1] ? lw : 0.f;
       const f2 lwk[3] = {bc(lw0), bc(lw1), (f2){lw0, lw1}};
       f2 g[3];
 #pragma unroll
@@ -403,14 +430,15 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
         g[k] = fma2(lwk[k], sg, fma2(SC, yq, fma2(SB, xq, SA))) * bc(sc);
       }
       if (out_x) {
-        const unsigned bo = (unsigned)(q * W + gxr) * 4u;
-        stf(ga, bo, g[0].x); stf(ga + HW, bo, g[0].y); stf(ga + 2 * (size_t)HW, bo, g[2].x);
-        if (gb) { stf(gb, bo, g[1].x); stf(gb + HW, bo, g[1].y); stf(gb + 2 * (size_t)HW, bo, g[2].y); }
-        if (FUSED && p.g_region[0] && (fr_q & 1u)) {
-          float* ra = p.g_region[0] + (size_t)b * 3 * HW;
-          float* rb = p.g_region[1] + (size_t)b * 3 * HW;
-          stf(ra, bo, g[0].x); stf(ra + HW, bo, g[0].y); stf(ra + 2 * (size_t)HW, bo, g[2].x);
-          stf(rb, bo, g[1].x); stf(rb + HW, bo, g[1].y); stf(rb + 2 * (size_t)HW, bo, g[2].y);
+        const unsigned o0 = (unsigned)(q * W + gxr) * 4u + img_b, o1 = o0 + hw4, o2 = o1 + hw4;
+        stf(ga, o0, g[0].x); stf(ga, o1, g[0].y); stf(ga, o2, g[2].x);
+        if (gb) { const unsigned q0 = fresh(o0), q1 = fresh(o1), q2 = fresh(o2); stf(gb, q0, g[1].x); stf(gb, q1, g[1].y); stf(gb, q2, g[2].y); }
+        if (FUSED && P.g_region[0] && (fr_q & 1u)) {
+          float* const ra = P.g_region[0];
+          float* const rb = P.g_region[1];
+          const unsigned q0 = fresh(o0), q1 = fresh(o1), q2 = fresh(o2);
+          stf(ra, q0, g[0].x); stf(ra, q1, g[0].y); stf(ra, q2, g[2].x);
+          stf(rb, q0, g[1].x); stf(rb, q1, g[1].y); stf(rb, q2, g[2].y);
         }
       }
     }
@@ -716,6 +744,8 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
   if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
   if (weight_given && noise) return MAL_EINVAL;
   if ((orig0 == nullptr) != (orig1 == nullptr) || (orig0 && !region)) return MAL_EINVAL;
+  if (!target_texels) return MAL_EINVAL;  // the fused sweep reads the target as texels (compile-time in the kernel)
+  if (orig0 && (long long)B * (long long)(orig_stride ? orig_stride : (size_t)3 * H * W) * 4 >= (1ll << 32)) return MAL_ESHAPE;  // 32-bit byte offsets
   PhotoMarchParams p = {};
   p.target = target; p.target_texels = target_texels; p.weight_given = weight_given; p.B = B; p.H = H; p.W = W;
   p.cand[0] = cand0; p.cand[1] = cand1; p.idx[0] = idx0; p.idx[1] = idx0 + 1;
