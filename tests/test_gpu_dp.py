@@ -90,7 +90,7 @@ def _overlap_worker(rank, world, port, out_dir):
         opt = harness.default_options(batch_size=2, height=64, width=128, no_matching_augmentation=True)
         inputs = harness.synthetic_inputs(opt, dev, seed=21 + rank)
         res = {}
-        for segs in (1, 4):
+        for key, segs in (("warm", 1), (1, 1), ("again", 1), (4, 4)):  # "warm": MIOpen settles its solver choice; "again": run-to-run noise
             torch.manual_seed(0)
             random.seed(0)
             h = harness.TrainHarness(opt, dev, exchange_segments=segs)
@@ -106,7 +106,7 @@ def _overlap_worker(rank, world, port, out_dir):
                     first = h.bucket.flat.detach().cpu()
             torch.cuda.synchronize()
             assert h.bucket.check_views()
-            res[segs] = {"flat": first, "inside": inside, "pieces": len(h.bucket.bounds)}
+            res[key] = {"flat": first, "inside": inside, "pieces": len(h.bucket.bounds)}
         torch.save(res, os.path.join(out_dir, "rank%d.pt" % rank))
     finally:
         dist.destroy_process_group()
@@ -129,8 +129,11 @@ def test_exchange_from_inside_the_backward_equals_the_single_all_reduce(tmp_path
     assert torch.equal(r[0][4]["flat"], r[1][4]["flat"])  # every rank holds the same mean
     scale = float(r[0][1]["flat"].abs().max())
     assert scale > 0
-    # one piece against four: the same sums up to MIOpen's run-to-run noise (4e-5 in the norm, 1.2e-4 on single elements per
-    # step: profiles/r03_determinism_probe.txt)
-    d = r[0][4]["flat"].double() - r[0][1]["flat"].double()
-    assert float(d.norm()) <= 5e-4 * float(r[0][1]["flat"].double().norm())
-    assert float(d.abs().max()) <= 2e-3 * scale
+    # one piece against four: the same sums up to MIOpen's run-to-run noise (typically 4e-5 in the norm, 1.2e-4 on single elements
+    # per step: profiles/r03_determinism_probe.txt -- but a box whose MIOpen picks another solver between two runs has shown 3e-3),
+    # so the yardstick is measured in the same process: the one-piece configuration run twice ("again")
+    ref = r[0][1]["flat"].double()
+    noise = r[0]["again"]["flat"].double() - ref
+    d = r[0][4]["flat"].double() - ref
+    assert float(d.norm()) <= max(5e-4 * float(ref.norm()), 3.0 * float(noise.norm())), (float(d.norm()), float(noise.norm()), float(ref.norm()))
+    assert float(d.abs().max()) <= max(2e-3 * scale, 3.0 * float(noise.abs().max())), (float(d.abs().max()), float(noise.abs().max()), scale)
