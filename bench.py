@@ -827,7 +827,7 @@ def main():
     kern_ms_plain = kern_ms
     replayed = replayed_warm = None
     if args.mode in ("step", "distil"):
-        R_k = 8 if cold else 1
+        R_k = (8 if R >= 6 else R) if cold else 1  # (a reduced --rotate, as the quick tests use, reduces this rotation too)
         plains = Rotation(dev, 1234 + rank + 104729, "distil", R_k, slot_base=300, graph=False)
         pev = []
         for i in range(60):  # back to back (no host sync in between: the clocks stay where the timed region had them)
@@ -992,12 +992,13 @@ def main():
                 traffic, traffic_temporal = tj.get("pass_kernel_teacher_bytes_per_launch"), tj.get("pass_kernel_teacher_temporal_bytes_per_launch")
             except Exception:
                 traffic = traffic_temporal = None
-        n_b = 8 if cold else 1
+        n_b = (8 if R >= 6 else R) if cold else 1
         how_replay = ("a HIP graph holding ONLY 64 back-to-back launches of this kernel, launch i with the argument block of a "
                       "--distil step of batch i %% %d (mal_loss_step_teacher_replay; %s), replayed 10x after 2 warm-up replays, two "
                       "events outside the graph, / 640; includes the gaps between consecutive graph nodes"
-                      % (n_b, ("8 batches x ~77 MB of operands: 540 MB pass through the 256 MiB Infinity Cache between two launches "
-                               "on the same batch, so every operand comes from HBM") if cold else
+                      % (n_b, ("%d batches x ~77 MB of operands: %d MB pass through the 256 MiB Infinity Cache between two launches "
+                               "on the same batch%s" % (n_b, 77 * (n_b - 1), ", so every operand comes from HBM" if n_b >= 5 else
+                                                        " -- NOT enough to evict it: a reduced --rotate")) if cold else
                               "one batch: its operands stay in the Infinity Cache"))
         out["roofline"] = {"bound": "hbm", "kernel": "mal::march_teacher_kernel<false> (teacher pass: warp+SSIM+L1+"
                                                      "min+automask fwd+bwd, one launch = the whole B=12 pass)",

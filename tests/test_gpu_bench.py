@@ -76,7 +76,7 @@ def test_driver_command_default_flags():
                                           (["--mode", "distil"], "--distil")],
                          ids=["dualrefine", "cityscapes_width", "distil"])
 def test_other_bench_modes_print_a_line(extra, expect):
-    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--train-steps", "0", "--loss-blc"] + extra)
+    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--train-steps", "0", "--loss-blc", "--rotate", "2"] + extra)
     _contract(d, 2, 1)
     if extra == ["--mode", "distil"]:  # the reference's own command adds --loss_blc (README.md:22): timed as its own block
         b = d["loss_blc"]
@@ -98,7 +98,8 @@ def test_two_ranks_over_gloo_print_the_multi_gpu_line():
     env = dict(os.environ, MAL_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rotate", "2",
+                        "--train-steps", "4"],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
@@ -113,7 +114,7 @@ def test_two_ranks_over_gloo_print_the_multi_gpu_line():
     assert d["breakdown_ms"]["grad_all_reduce"] > 0 and "error" not in d["exchange_overlapped"]
     t = d["train_step"]
     assert "error" not in t, t
-    assert t["n_gpus"] == 2 and t["world_size"] == 2 and t["value"] > 0 and t["steps"] == 20
+    assert t["n_gpus"] == 2 and t["world_size"] == 2 and t["value"] > 0 and t["steps"] == 4
     assert "4 piece(s)" in t["exchange"] and "world size 2" in t["exchange"] and t["exchange_pieces"] == 4
     assert 0 <= t["pieces_issued_inside_backward"] <= 4
     assert abs(t["value"] - 24 / (t["ms_per_step"] * 1e-3)) <= 1e-6 * t["value"]
