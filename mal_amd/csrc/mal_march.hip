@@ -1553,6 +1553,7 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
   if ((long long)p.H * p.W >= (1ll << 24)) return MAL_ESHAPE;  // tap offsets use 24-bit multiplies
   if (p.color_out[0] && (long long)p.B * (p.color_out_stride ? (long long)p.color_out_stride : 3ll * p.H * p.W) * 4 >= (1ll << 32))
     return MAL_ESHAPE;  // the exported planes are addressed with 32-bit byte offsets
+  if (p.forced_w && (long long)p.B * 3 * p.H * p.W * 4 >= (1ll << 32)) return MAL_ESHAPE;  // ... and so are the (B,3,H,W) colour cotangents
   if (!p.cam_ready) {
     hipLaunchKernelGGL(cam_setup_kernel, dim3(p.B), dim3(64), 0, st, p.K, p.T[0], p.T[1], p.invK, p.cam);
     p.cam_ready = 1;

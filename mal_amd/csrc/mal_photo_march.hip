@@ -714,6 +714,7 @@ int photo_march_fwd(const float* target, const float* const* cand, int n_cand, c
 
 int photo_march_bwd(const float* target, const float* const* cand, int n_cand, const uint8_t* argmin, const float* weight,
                     const float* scale, const double* sums, int B, int H, int W, float* const* g_cand, hipStream_t st) {
+  if ((long long)B * 3 * H * W * 4 >= (1ll << 32)) return MAL_ESHAPE;  // the sweep addresses (B,3,H,W) images with 32-bit byte offsets
   for (int pr = 0; pr < (n_cand + 1) / 2; ++pr) {
     PhotoMarchParams p = {};
     p.target = target; p.B = B; p.H = H; p.W = W;
@@ -745,6 +746,7 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
   if (weight_given && noise) return MAL_EINVAL;
   if ((orig0 == nullptr) != (orig1 == nullptr) || (orig0 && !region)) return MAL_EINVAL;
   if (!target_texels) return MAL_EINVAL;  // the fused sweep reads the target as texels (compile-time in the kernel)
+  if ((long long)B * 3 * H * W * 4 >= (1ll << 32)) return MAL_ESHAPE;  // (B,3,H,W) images are addressed with 32-bit byte offsets
   if (orig0 && (long long)B * (long long)(orig_stride ? orig_stride : (size_t)3 * H * W) * 4 >= (1ll << 32)) return MAL_ESHAPE;  // 32-bit byte offsets
   PhotoMarchParams p = {};
   p.target = target; p.target_texels = target_texels; p.weight_given = weight_given; p.B = B; p.H = H; p.W = W;

@@ -324,7 +324,7 @@ def test_in_kernel_noise_equals_the_same_noise_handed_in():
         config.noise_source, config.noise_seed = old
 
 
-@pytest.mark.parametrize("case", [(3, 40, 72, 2), (4, 192, 640, 3)], ids=["b3-40x72-sclm2", "b4-192x640-sclm3"])
+@pytest.mark.parametrize("case", [(3, 40, 72, 2), (12, 192, 640, 3)], ids=["b3-40x72-sclm2", "baseline-b12-192x640-sclm3"])
 def test_no_ssim_against_the_oracle(case):
     """--no_ssim on the non-distillation route (the one upstream reads the flag on, manydepth/trainer.py:1217-1218): r = mean_c
     |target - pred| in both networks' passes and in the identity term (MAL_STEP_NO_SSIM).  Decision-exact (round 5): r without
