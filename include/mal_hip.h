@@ -460,16 +460,26 @@ int mal_loss_multiscale_bwd(const mal_ms_args* args);
  * and it > 0, ...); which of them are detached is the caller's business: a NULL g_T_* output is a detached pose.
  * losses: [4*it + {0 reproj, 1 consistency, 2 smooth, 3 running loss after it}], [4*MAL_DR_MAX_ITERS] total,
  * [4*MAL_DR_MAX_ITERS + 1] the final running loss (what every "loss/0_it" entry reads upstream).
- * One call = the iterations of ONE scale (`scale`, below); --avg_reprojection / --no_ssim: MAL_DR_AVG / MAL_DR_NO_SSIM; the
- * pose-update losses (:699-767) stay on the operator-level API. */
+ * One call = the iterations of ONE scale (`scale`, below); --avg_reprojection / --no_ssim: MAL_DR_AVG / MAL_DR_NO_SSIM.
+ * MAL_DR_POSE_UPDATE (scale 0 only): the same call also evaluates the pose-update losses (:457-480 pose_update_generate_images_pred,
+ * :699-767 compute_pose_update_losses) in ONE more marching pass whose two candidates are warped with two different
+ * disparities: frame -1 with pu_disp_m1 (the last iteration's disparity -- or iteration 0's, detached, with --Tstar_D0_pair)
+ * under the refined pose pu_T_m1 = ("cam_T_cam", 0, -1, 1); frame +1 as ("color", 1, 0, 0) was: pu_disp_p1 = iteration 0's
+ * disparity under pu_T_p1 = ("cam_T_cam", 0, 1).  min (or mean) over the two, automask against the identity term + 1e-5 pu_noise,
+ * no consistency mask, no smoothness: losses[4*MAL_DR_MAX_ITERS + 2] = sum(rp mask) / (sum mask + 1e-7).  It is NOT part of
+ * losses[4*MAL_DR_MAX_ITERS] / loss_total (upstream adds it after the division by len(scales), :337-343): the caller adds it,
+ * and hands its cotangent in g_pu_total. */
 enum { MAL_DR_MAX_ITERS = 4 };
 enum { MAL_DR_AVG = 8,      /* --avg_reprojection (dualrefine/trainer.py:569-583): the MEAN over the two frames of r and of the
                                identity term instead of their min; both frames take half of every gradient */
        MAL_DR_NO_SSIM = 16, /* --no_ssim (:493-494): r = mean_c |target - pred| */
        MAL_DR_NO_AUTOMASK = 1, MAL_DR_NO_MOTION_MASK = 2,
-       MAL_DR_NOISE_PHILOX = 4 /* the tie-break noise of every iteration is drawn in the step's first launch (Philox4x32-10
+       MAL_DR_NOISE_PHILOX = 4, /* the tie-break noise of every iteration is drawn in the step's first launch (Philox4x32-10
                                   keyed by noise_seed, step number = step * MAL_DR_MAX_ITERS + it: mal_tiebreak_noise with
-                                  that step number reproduces iteration it's map); every noise[it] must be NULL */ };
+                                  that step number reproduces iteration it's map); every noise[it] must be NULL.  The
+                                  pose-update pass's map: key noise_seed ^ MAL_DR_POSE_NOISE_KEY, step number step * MAL_DR_MAX_ITERS */
+       MAL_DR_POSE_UPDATE = 32 /* the pose-update losses ride on this call (see above) */ };
+#define MAL_DR_POSE_NOISE_KEY 0x706f73655f757064ull /* "pose_upd" */
 typedef struct mal_dr_args {
   int B, H, W, n_iters;
   float min_depth, max_depth, smooth_weight;
@@ -508,6 +518,15 @@ typedef struct mal_dr_args {
   /* parity instrumentation (tests), per iteration: the per-pixel decisions of that iteration's pass, as mal_step_args.dec_teacher
    * (int32 (MAL_DEC_PLANES,B,H,W); MAL_DEC_WIN, _TAP0/1, _L1).  NULL: the uninstrumented kernels; bit-identical results. */
   uint32_t *dec[MAL_DR_MAX_ITERS];
+  /* MAL_DR_POSE_UPDATE */
+  const float *pu_disp_m1, *pu_disp_p1;           /* (B,1,H,W) */
+  const float *pu_T_m1, *pu_T_p1;                 /* (B,16) */
+  const float *pu_noise;                          /* (B,1,H,W) N(0,1), nullable; must be NULL with MAL_DR_NOISE_PHILOX */
+  const float *g_pu_total;                        /* backward: device scalar, nullable = 1 */
+  float *g_pu_disp_m1, *g_pu_disp_p1;             /* backward outputs, nullable each (a NULL output is a detached operand) */
+  float *g_pu_T_m1, *g_pu_T_p1;
+  uint32_t *pu_dec;                               /* parity instrumentation, as dec[] */
+  float *pu_loss_total;                           /* nullable: receives the pose-update loss (= losses[4*MAL_DR_MAX_ITERS + 2]) */
 } mal_dr_args;
 size_t mal_dr_workspace_bytes(int B, int H, int W, int n_iters);
 int mal_dr_loss_fwd(const mal_dr_args* args);

@@ -166,11 +166,14 @@ class DrArgs(C.Structure):
                  ("noise_seed", C.c_uint64), ("noise_step", C.c_uint64), ("noise_counter", vp), ("losses", vp), ("loss_total", vp),
                  ("g_total", vp), ("g_disp", vp * 4), ("g_T_m1", vp * 4), ("g_T_p1", vp * 4),
                  ("ws", vp), ("ws_bytes", sz), ("stream", vp), ("scale", i32), ("color0_s", vp), ("disp_lo", vp * 4),
-                 ("g_disp_lo", vp * 4), ("texels_from", vp), ("dec", vp * 4)])
+                 ("g_disp_lo", vp * 4), ("texels_from", vp), ("dec", vp * 4)] +
+                [(n, vp) for n in ("pu_disp_m1", "pu_disp_p1", "pu_T_m1", "pu_T_p1", "pu_noise", "g_pu_total", "g_pu_disp_m1",
+                                   "g_pu_disp_p1", "g_pu_T_m1", "g_pu_T_p1", "pu_dec", "pu_loss_total")])
 
 
 DR_MAX_ITERS = 4
-DR_NO_AUTOMASK, DR_NO_MOTION_MASK, DR_NOISE_PHILOX, DR_AVG, DR_NO_SSIM = 1, 2, 4, 8, 16
+DR_NO_AUTOMASK, DR_NO_MOTION_MASK, DR_NOISE_PHILOX, DR_AVG, DR_NO_SSIM, DR_POSE_UPDATE = 1, 2, 4, 8, 16, 32
+DR_POSE_NOISE_KEY = 0x706f73655f757064
 MS_MAX_SCALES = 4
 STEP_NO_ENS, STEP_AUG_MASK, STEP_NOISE_PHILOX, STEP_TEMPORAL, STEP_SYN_SPARSE, STEP_DUAL_DISTIL, STEP_TEXEL_INPUTS = 1, 2, 4, 8, 16, 32, 64
 STEP_MAIN_TEMPORAL, STEP_SYN_S_SPARSE, STEP_NO_SSIM, STEP_NO_MOTION_MASK, STEP_NO_AUG, STEP_ENSEMBLE = 128, 256, 512, 1024, 2048, 4096

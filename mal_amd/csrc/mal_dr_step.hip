@@ -14,6 +14,11 @@
 //               iteration, so iteration it weighs (n - it), :624-631), coefficients of the backward
 //   backward  1 assembly: d total / d disp_it, d total / d T (the 4x4 matrices the trainer hands in: refined or not,
 //             detached or not is the caller's business -- a NULL output pointer is a detached pose)
+// MAL_DR_POSE_UPDATE (round 5): the pose-update losses (dualrefine/trainer.py:457-480,699-767) as ONE more marching pass of
+// the same call -- slot n_iters of every per-iteration array below.  Its two candidates are warped with two different
+// disparities (MarchParams::framed: frame -1 with the last iteration's disparity under the refined pose, frame +1 as
+// ("color", 1, 0, 0) was, with iteration 0's), so it leaves two gradient maps; no consistency mask, no smoothness, its own
+// tie-break noise, its own cotangent (g_pu_total: upstream adds the term after the division by len(scales), :337-343).
 #include "mal_march.h"
 #include "mal_device.h"
 
@@ -24,16 +29,18 @@ int smooth_march_sweep_batch(int n, const float* const* disp, const float* const
                              float* const* gn, double* const* partial, hipStream_t st, int* per_sample);
 
 constexpr int kDrIt = MAL_DR_MAX_ITERS;
+constexpr int kDrSlots = kDrIt + 1;  // + the pose-update pass (slot n_iters)
 
 struct DrWs {
-  float* packed[3]; float* ident; float* cam[kDrIt];
-  float* G_r[kDrIt]; float* G_c[kDrIt]; float* gn[kDrIt]; float* bnd[kDrIt];
-  double* bs[kDrIt]; float* bgP[kDrIt]; double* sm[kDrIt];
-  double* ps;      // [it][B][8]
+  float* packed[3]; float* ident; float* cam[kDrSlots];
+  float* G_r[kDrSlots]; float* G_c[kDrIt]; float* gn[kDrIt]; float* bnd[kDrSlots];
+  double* bs[kDrSlots]; float* bgP[kDrSlots]; double* sm[kDrIt];
+  float* G_r2; float* bnd2;  // pose-update pass: d / d (frame +1's disparity)
+  double* ps;      // [slot][B][8]
   double* stats;   // [2][it][B]: mean, mean-coupling term of the smoothness
-  float* gT;       // [it][2][B*16]
-  float* coefs;    // [it][4]: cR, cC, cS, weight
-  float* noise[kDrIt];  // MAL_DR_NOISE_PHILOX: the iteration's N(0,1) map
+  float* gT;       // [slot][2][B*16]
+  float* coefs;    // [slot][4]: cR, cC, cS, weight
+  float* noise[kDrSlots];  // MAL_DR_NOISE_PHILOX: the iteration's N(0,1) map
   unsigned* ticket;
   size_t bytes;
 };
@@ -53,22 +60,30 @@ static DrWs carve_dr(void* base, int B, int H, int W, int n) {
     w.bs[it] = (double*)take(nb * 8 * 8); w.bgP[it] = (float*)take(nb * 24 * 4); w.sm[it] = (double*)take(nb * 8 * 8);
     w.noise[it] = (float*)take(map);
   }
-  w.ps = (double*)take((size_t)kDrIt * B * 8 * 8);
+  w.ps = (double*)take((size_t)kDrSlots * B * 8 * 8);
   w.stats = (double*)take((size_t)2 * kDrIt * B * 8);
-  w.gT = (float*)take((size_t)kDrIt * 2 * B * 16 * 4);
-  w.coefs = (float*)take(kDrIt * 4 * 4);
+  w.gT = (float*)take((size_t)kDrSlots * 2 * B * 16 * 4);
+  w.coefs = (float*)take(kDrSlots * 4 * 4);
   w.ticket = (unsigned*)take(16);
+  for (int it = n; it < n + 1; ++it) {  // the pose-update pass's slot (behind everything an earlier layout had: texels_from)
+    w.cam[it] = (float*)take((size_t)B * kCamFloats * 4);
+    w.G_r[it] = (float*)take(map); w.G_r2 = (float*)take(map);
+    w.bnd[it] = (float*)take(march_bnd_floats(B, H, W) * sizeof(float)); w.bnd2 = (float*)take(march_bnd_floats(B, H, W) * sizeof(float));
+    w.bs[it] = (double*)take(nb * 8 * 8); w.bgP[it] = (float*)take(nb * 24 * 4);
+    w.noise[it] = (float*)take(map);
+  }
   w.bytes = o;
   return w;
 }
 
 struct DrFinal {
-  const double* bs[kDrIt]; const float* bgP[kDrIt]; const double* sm[kDrIt];
+  const double* bs[kDrSlots]; const float* bgP[kDrSlots]; const double* sm[kDrIt];
   const float* K;
   int per_sample, per_sample_sm, sm_stride, B, H, W, n;
+  int pu;  // 1: slot n holds the pose-update pass (sums and pose partials only)
   int hs, ws;  // size of the maps the smoothness term is taken on (H >> scale, W >> scale)
   float smooth_weight;
-  double* ps; double* stats; float* gT; float* losses; float* coefs; float* loss_total; unsigned* ticket;
+  double* ps; double* stats; float* gT; float* losses; float* coefs; float* loss_total; float* pu_loss_total; unsigned* ticket;
   unsigned long long* noise_counter;  // nullable: advanced by one when every reader of this step has finished
 };
 
@@ -77,9 +92,10 @@ struct DrFinal {
 // mal_tiebreak_noise reproduces a map); the B workgroups after them: the camera block (K T)[:3,:] of both frames +
 // inv_K[:3,:3] of sample b for that iteration's poses; workgroup (0,0) also clears the completion ticket.
 struct DrPrologue {
-  const float* K; const float* invK; const float* T[kDrIt][2]; float* cam[kDrIt]; float* noise[kDrIt];
+  const float* K; const float* invK; const float* T[kDrSlots][2]; float* cam[kDrSlots]; float* noise[kDrSlots];
   unsigned long long seed, step; const unsigned long long* counter;
   int noise_blocks, B, H, W; unsigned* ticket;
+  int pu_slot;  // >= 0: that slot is the pose-update pass (its noise: key seed ^ MAL_DR_POSE_NOISE_KEY, step number step * kDrIt)
 };
 __global__ __launch_bounds__(256) void dr_prologue_kernel(DrPrologue p) {
   const int it = blockIdx.y, tid = threadIdx.x;
@@ -92,9 +108,10 @@ __global__ __launch_bounds__(256) void dr_prologue_kernel(DrPrologue p) {
   const size_t i = blockIdx.x * (size_t)256 + tid;
   if (i >= (size_t)p.B * H4 * W) return;
   const int x = (int)(i % W), row = (int)(i / W), y4 = row % H4, b = row / H4, y0 = y4 * 4;
-  const unsigned long long st = (p.counter ? *p.counter : p.step) * (unsigned long long)kDrIt + it;
+  const bool pu = it == p.pu_slot;
+  const unsigned long long st = (p.counter ? *p.counter : p.step) * (unsigned long long)kDrIt + (pu ? 0 : it);
   float n[4];
-  tie_noise4(p.seed, st, (unsigned)(b * H * W + y0 * W + x), n);
+  tie_noise4(pu ? p.seed ^ MAL_DR_POSE_NOISE_KEY : p.seed, st, (unsigned)(b * H * W + y0 * W + x), n);
   float* o = p.noise[it] + (size_t)b * H * W + (size_t)y0 * W + x;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -108,7 +125,7 @@ __global__ __launch_bounds__(256) void dr_final_kernel(DrFinal p) {
   __shared__ double s_part[256];
   __shared__ double s_gP[24];
   __shared__ unsigned s_last;
-  const int tid = threadIdx.x, B = p.B, HW = p.H * p.W, nB = p.n * B;
+  const int tid = threadIdx.x, B = p.B, HW = p.H * p.W, nB = (p.n + p.pu) * B;
   if ((int)blockIdx.x < nB) {
     const int it = blockIdx.x / B, b = blockIdx.x - it * B;
     const int j = tid & 7, sub = tid >> 3;
@@ -117,7 +134,7 @@ __global__ __launch_bounds__(256) void dr_final_kernel(DrFinal p) {
       const double* q = p.bs[it] + (size_t)b * p.per_sample * 8 + j;
 #pragma unroll 8
       for (int t = sub; t < p.per_sample; t += 32) acc += q[(size_t)t * 8];
-    } else {
+    } else if (it < p.n) {
       const double* q = p.sm[it] + (size_t)b * p.per_sample_sm * p.sm_stride + (j - 4);
 #pragma unroll 8
       for (int t = sub; t < p.per_sample_sm; t += 32) acc += q[(size_t)t * p.sm_stride];
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(256) void dr_final_kernel(DrFinal p) {
   __threadfence();
   // per-sample statistics of the smoothness gradient (mean and the mean-coupling term), then the scalars: thread it
   const int HWs = p.hs * p.ws;
-  for (int s = tid; s < nB; s += 256) {
+  for (int s = tid; s < p.n * B; s += 256) {
     const double* q = p.ps + (size_t)s * 8;
     const double mean = q[7] / (double)HWs;
     const double m = (double)((float)mean + 1e-7f);
@@ -190,6 +207,16 @@ __global__ __launch_bounds__(256) void dr_final_kernel(DrFinal p) {
     p.coefs[it * 4 + 2] = wt * p.smooth_weight;
     p.coefs[it * 4 + 3] = wt;
   }
+  if (p.pu && tid == p.n) {  // the pose-update term: masked mean over its own pass, weight 1 (dualrefine/trainer.py:750-758)
+    double t0 = 0.0, t1 = 0.0;
+    for (int b = 0; b < B; ++b) {
+      const double* q = p.ps + ((size_t)p.n * B + b) * 8;
+      t0 += q[0]; t1 += q[1];
+    }
+    p.losses[4 * kDrIt + 2] = (float)(t0 / (t1 + 1e-7));
+    if (p.pu_loss_total) *p.pu_loss_total = p.losses[4 * kDrIt + 2];
+    p.coefs[p.n * 4 + 0] = (float)(1.0 / (t1 + 1e-7));
+  }
   __threadfence();
   __syncthreads();
   if (tid != 0) return;
@@ -208,8 +235,9 @@ __global__ __launch_bounds__(256) void dr_final_kernel(DrFinal p) {
 }
 
 struct DrAssemble {
-  const float* G_r[kDrIt]; const float* G_c[kDrIt]; const float* gn[kDrIt]; const float* bnd[kDrIt];
-  float* g_disp[kDrIt]; float* g_T[kDrIt][2];
+  const float* G_r[kDrSlots]; const float* G_c[kDrIt]; const float* gn[kDrIt]; const float* bnd[kDrSlots];
+  float* g_disp[kDrSlots]; float* g_T[kDrSlots][2];
+  const float* G_r2; const float* bnd2; float* g_disp2; const float* g_pu_total;  // pose-update pass (slot n, grid y = n)
   float* g_disp_lo[kDrIt];  // scale > 0: the smoothness term's gradient at the scale's own size (then not part of g_disp)
   const float* gT; const float* coefs; const double* stats; const float* g_total;
   int B, H, W, n, rows, segs, hs, ws;
@@ -219,8 +247,9 @@ struct DrAssemble {
 // workgroup 0 of each iteration also scales the pose gradients
 __global__ __launch_bounds__(256) void dr_assemble_kernel(DrAssemble p) {
   const int it = blockIdx.y, B = p.B, H = p.H, W = p.W;
-  const float g = p.g_total ? *p.g_total : 1.0f;
-  const float cR = p.coefs[it * 4 + 0] * g, cC = p.coefs[it * 4 + 1] * g, cS = p.coefs[it * 4 + 2] * g;
+  const bool pu = it == p.n;
+  const float g = pu ? (p.g_pu_total ? *p.g_pu_total : 1.0f) : (p.g_total ? *p.g_total : 1.0f);
+  const float cR = p.coefs[it * 4 + 0] * g, cC = pu ? 0.f : p.coefs[it * 4 + 1] * g, cS = pu ? 0.f : p.coefs[it * 4 + 2] * g;
   if (blockIdx.x == 0) {
     for (int f = 0; f < 2; ++f) {
       float* out = p.g_T[it][f];
@@ -228,6 +257,21 @@ __global__ __launch_bounds__(256) void dr_assemble_kernel(DrAssemble p) {
       const float* in = p.gT + ((size_t)it * 2 + f) * B * 16;
       for (int i = threadIdx.x; i < B * 16; i += 256) out[i] = in[i] * cR;
     }
+  }
+  if (pu) {  // two maps, the reprojection term only: d / d (frame -1's disparity), d / d (frame +1's)
+    for (int m = 0; m < 2; ++m) {
+      float* o2 = m ? p.g_disp2 : p.g_disp[it];
+      if (!o2) continue;
+      const float* G = m ? p.G_r2 : p.G_r[it];
+      const float* bn = m ? p.bnd2 : p.bnd[it];
+      for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+        const int b = row / H, y = row - b * H;
+        const float* brow = bn ? march_boundary_row(bn, b, y, H, W, p.rows, p.segs) : nullptr;
+        const size_t r0 = (size_t)row * W;
+        for (int x = threadIdx.x; x < W; x += 256) o2[r0 + x] = cR * (brow ? G[r0 + x] + brow[x] : G[r0 + x]);
+      }
+    }
+    return;
   }
   float* out = p.g_disp[it];
   float* lo = p.g_disp_lo[it];
@@ -284,6 +328,10 @@ static int dr_check(const mal_dr_args* a) {
   if (a->flags & MAL_DR_NOISE_PHILOX)
     for (int it = 0; it < a->n_iters; ++it)
       if (a->noise[it]) return MAL_EINVAL;
+  if (a->flags & MAL_DR_POSE_UPDATE) {  // rides on the full-resolution call
+    if (a->scale != 0 || !a->pu_disp_m1 || !a->pu_disp_p1 || !a->pu_T_m1 || !a->pu_T_p1) return MAL_EINVAL;
+    if ((a->flags & MAL_DR_NOISE_PHILOX) && a->pu_noise) return MAL_EINVAL;
+  }
   if (a->ws_bytes < carve_dr(nullptr, a->B, a->H, a->W, a->n_iters).bytes) return MAL_EWORKSPACE;
   return MAL_OK;
 }
@@ -300,6 +348,7 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
   DrWs w = carve_dr(a->ws, B, H, W, n);
   hipStream_t st = (hipStream_t)a->stream;
   const bool automask = !(a->flags & MAL_DR_NO_AUTOMASK);
+  const int pu = (a->flags & MAL_DR_POSE_UPDATE) ? 1 : 0;
   // identity term + texel packing (no noise here: every iteration adds its own).  Up to two iterations (the shipped
   // n_losses = 1): their edge-aware smoothness rides on this sweep, which holds the target rows anyway; more: one batched
   // smoothness sweep below
@@ -328,7 +377,9 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
     q.B = B; q.H = H; q.W = W; q.ticket = w.ticket;
     q.noise_blocks = philox ? (int)(((size_t)B * ((H + 3) / 4) * W + 255) / 256) : 0;
     for (int it = 0; it < n; ++it) { q.T[it][0] = a->T_m1[it]; q.T[it][1] = a->T_p1[it]; q.cam[it] = w.cam[it]; q.noise[it] = w.noise[it]; }
-    hipLaunchKernelGGL(dr_prologue_kernel, dim3((unsigned)(q.noise_blocks + B), (unsigned)n), dim3(256), 0, st, q);
+    q.pu_slot = pu ? n : -1;
+    if (pu) { q.T[n][0] = a->pu_T_m1; q.T[n][1] = a->pu_T_p1; q.cam[n] = w.cam[n]; q.noise[n] = w.noise[n]; }
+    hipLaunchKernelGGL(dr_prologue_kernel, dim3((unsigned)(q.noise_blocks + B), (unsigned)(n + pu)), dim3(256), 0, st, q);
     rc = launch_status();
     if (rc) return rc;
   }
@@ -356,6 +407,23 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
     if (rc) return rc;
     per_sample = p.strips * p.segs;
   }
+  if (pu) {
+    // the pose-update losses (dualrefine/trainer.py:457-480,699-767): min over {frame -1 under the refined pose with the last
+    // iteration's disparity, frame +1 as iteration 0 warped it}, automask with a noise draw of its own, no mask, no epilogue
+    MarchParams p = march_params(B, H, W, a->min_depth, a->max_depth, 1e-7f, 1);
+    p.disp = a->pu_disp_m1; p.disp2 = a->pu_disp_p1; p.framed = 1;
+    p.K = a->K; p.invK = a->inv_K; p.T[0] = a->pu_T_m1; p.T[1] = a->pu_T_p1;
+    p.src[0] = w.packed[1]; p.src[1] = w.packed[2]; p.target = w.packed[0];
+    p.ident = w.ident; p.noise = automask ? (philox ? w.noise[n] : a->pu_noise) : nullptr;
+    p.g_reproj = w.G_r[n]; p.g_reproj2 = w.G_r2; p.block_sums = w.bs[n]; p.block_gP = w.bgP[n];
+    p.bnd = g_march_halo1 ? w.bnd[n] : nullptr; p.bnd2 = g_march_halo1 ? w.bnd2 : nullptr;
+    p.cam = w.cam[n]; p.cam_ready = 1;
+    p.avg = (a->flags & MAL_DR_AVG) ? 1 : 0; p.no_ssim = (a->flags & MAL_DR_NO_SSIM) ? 1 : 0;
+    p.dbg = a->pu_dec;
+    rc = march_launch(p, MAL_F_GRAD | MAL_F_POSE_GRAD | (automask ? MAL_F_AUTOMASK : 0) | packed, st);
+    if (rc) return rc;
+    per_sample = p.strips * p.segs;
+  }
   DrFinal fin = {};
   if (!smooth_fused) {
     const float *sd[kDrIt], *si[kDrIt];
@@ -374,13 +442,14 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
     fin.per_sample_sm = per_sample_sm; fin.sm_stride = 8;   // [task][map][4] of the first sweep
     for (int it = 0; it < n; ++it) fin.sm[it] = w.sm[0] + it * 4;
   }
-  for (int it = 0; it < n; ++it) { fin.bs[it] = w.bs[it]; fin.bgP[it] = w.bgP[it]; }
+  for (int it = 0; it < n + pu; ++it) { fin.bs[it] = w.bs[it]; fin.bgP[it] = w.bgP[it]; }
+  fin.pu = pu; fin.pu_loss_total = pu ? a->pu_loss_total : nullptr;
   fin.K = a->K; fin.per_sample = per_sample; fin.B = B; fin.H = H; fin.W = W; fin.n = n; fin.smooth_weight = a->smooth_weight;
   fin.hs = hs; fin.ws = wsz;
   fin.ps = w.ps; fin.stats = w.stats; fin.gT = w.gT; fin.losses = a->losses; fin.coefs = w.coefs; fin.loss_total = a->loss_total;
   fin.ticket = w.ticket;
   fin.noise_counter = philox ? (unsigned long long*)a->noise_counter : nullptr;
-  hipLaunchKernelGGL(dr_final_kernel, dim3(2 * n * B), dim3(256), 0, st, fin);
+  hipLaunchKernelGGL(dr_final_kernel, dim3(2 * (n + pu) * B), dim3(256), 0, st, fin);
   return launch_status();
 }
 
@@ -395,12 +464,18 @@ extern "C" int mal_dr_loss_bwd(const mal_dr_args* a) {
     p.g_disp[it] = a->g_disp[it]; p.g_T[it][0] = a->g_T_m1[it]; p.g_T[it][1] = a->g_T_p1[it];
     p.g_disp_lo[it] = a->scale ? a->g_disp_lo[it] : nullptr;
   }
+  const int pu = (a->flags & MAL_DR_POSE_UPDATE) ? 1 : 0;
+  if (pu) {
+    p.G_r[n] = w.G_r[n]; p.G_r2 = w.G_r2; p.bnd[n] = g_march_halo1 ? w.bnd[n] : nullptr; p.bnd2 = g_march_halo1 ? w.bnd2 : nullptr;
+    p.g_disp[n] = a->g_pu_disp_m1; p.g_disp2 = a->g_pu_disp_p1; p.g_T[n][0] = a->g_pu_T_m1; p.g_T[n][1] = a->g_pu_T_p1;
+    p.g_pu_total = a->g_pu_total;
+  }
   p.hs = H >> a->scale; p.ws = W >> a->scale;
   p.gT = w.gT; p.coefs = w.coefs; p.stats = w.stats; p.g_total = a->g_total;
   p.B = B; p.H = H; p.W = W; p.n = n;
   march_geometry(B, H, W, MAL_F_GRAD, nullptr, &p.segs, &p.rows);
   unsigned rowsg = (unsigned)(B * H);
   if (rowsg > 4096) rowsg = 4096;
-  hipLaunchKernelGGL(dr_assemble_kernel, dim3(rowsg, (unsigned)n), dim3(256), 0, (hipStream_t)a->stream, p);
+  hipLaunchKernelGGL(dr_assemble_kernel, dim3(rowsg, (unsigned)(n + pu)), dim3(256), 0, (hipStream_t)a->stream, p);
   return launch_status();
 }

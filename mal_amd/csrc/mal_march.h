@@ -71,6 +71,10 @@ struct MarchParams {
   // Parity instrumentation (tests only; DBG instantiations of the gradient passes): the per-pixel DECISIONS the pass
   // took, as kDecPlanes uint32 planes of B*H*W each (include/mal_hip.h, MAL_DEC_*).  nullptr = the production kernels.
   unsigned* dbg;
+  // FRAMED gradient pass (DualRefine's pose-update losses, dualrefine/trainer.py:457-480,699-767: the two candidates of the
+  // min are warped with two DIFFERENT disparities -- frame -1 with disp, frame +1 with disp2): g_reproj receives d / d disp
+  // (what frame -1's candidate contributes), g_reproj2 d / d disp2 (frame +1's); bnd2 = the boundary scratch rows of g_reproj2
+  int framed; float* g_reproj2; float* bnd2;
 };
 constexpr int kDecPlanes = MAL_DEC_PLANES;
 

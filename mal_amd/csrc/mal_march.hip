@@ -90,9 +90,9 @@ MAL_DEV float refined_rcp(float b) {
 }
 
 // rw, rh: refined reciprocals of the grid normalisation's divisors (W-1, H-1 for convention 0; W, H for 1)
+MAL_DEV Sample2 project2_tail(const f2 (&c)[3], float eps, int W, int H, int convention, float rw, float rh);
 MAL_DEV Sample2 project2(const f2 (&P)[12], const float (&X)[3], float eps, int W, int H, int convention, float rw,
                          float rh) {
-  Sample2 s;
   f2 c[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -101,6 +101,22 @@ MAL_DEV Sample2 project2(const f2 (&P)[12], const float (&X)[3], float eps, int 
     acc = fma2(P[4 * i + 2], bc(X[2]), acc);
     c[i] = acc + P[4 * i + 3];  // == fma(P, 1, acc)
   }
+  return project2_tail(c, eps, W, H, convention, rw, rh);
+}
+// ... with a point per frame (FRAMED passes: the two frames' candidates are warped with two different disparities)
+MAL_DEV Sample2 project2(const f2 (&P)[12], const f2 (&X)[3], float eps, int W, int H, int convention, float rw, float rh) {
+  f2 c[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f2 acc = P[4 * i] * X[0];
+    acc = fma2(P[4 * i + 1], X[1], acc);
+    acc = fma2(P[4 * i + 2], X[2], acc);
+    c[i] = acc + P[4 * i + 3];
+  }
+  return project2_tail(c, eps, W, H, convention, rw, rh);
+}
+MAL_DEV Sample2 project2_tail(const f2 (&c)[3], float eps, int W, int H, int convention, float rw, float rh) {
+  Sample2 s;
   const f2 zp = c[2] + bc(eps);
   s.u = div_safe2_(c[0], zp);
   s.v = div_safe2_(c[1], zp);
@@ -158,15 +174,22 @@ MAL_DEV void dec_store(unsigned* dbg, unsigned n, int plane, unsigned boff, unsi
 // LEAN (the specialised passes of the whole-step lists: packed texels, H*W*12 < 2^24 checked by march_launch): the byte
 // offsets of the four taps are formed in fp32 -- every product and sum below 2^24 is exact -- instead of with 32-bit integer
 // multiplies (v_mul_lo_u32 is quarter rate: the compiler does not keep __umul24 for operands it cannot bound)
-template <bool DERIV, bool POSE, bool DBG, bool LEAN, class BeforeGathers>
+// FRAMED: frame 1's candidate is warped with its own disparity, dispv1 (frame 0's with dispv)
+template <bool DERIV, bool POSE, bool DBG, bool LEAN, bool FRAMED = false, class BeforeGathers>
 MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik)[9], int b, int gyr, int gxr,
-                        float dispv, PendingWarp& w, BeforeGathers before_gathers) {
+                        float dispv, PendingWarp& w, BeforeGathers before_gathers, float dispv1 = 0.f) {
+  static_assert(!FRAMED || (POSE && !LEAN), "FRAMED: pose variants of the generic passes only");
   const int W = p.W, H = p.H, HW = H * W, pix = gyr * W + gxr;
   const float depth = depth_of(dispv, p.min_disp, p.range);
   float ray[3], X[3];
   ray_of(ik, (float)gxr, (float)gyr, ray);
   X[0] = depth * ray[0]; X[1] = depth * ray[1]; X[2] = depth * ray[2];
-  const Sample2 s = project2(P, X, p.eps, W, H, p.convention, p.rw, p.rh);
+  Sample2 s;
+  if (FRAMED) {
+    const float depth1 = depth_of(dispv1, p.min_disp, p.range);
+    const f2 X2[3] = {(f2){X[0], depth1 * ray[0]}, (f2){X[1], depth1 * ray[1]}, (f2){X[2], depth1 * ray[2]}};
+    s = project2(P, X2, p.eps, W, H, p.convention, p.rw, p.rh);
+  } else s = project2(P, X, p.eps, W, H, p.convention, p.rw, p.rh);
   MAL_MARK(10);  // projection done; taps, operand requests, gathers follow
   // make_taps of mal_device.h for both frames
   const f2 x0f = (f2){floorf(s.ix.x), floorf(s.ix.y)}, y0f = (f2){floorf(s.iy.x), floorf(s.iy.y)};
@@ -287,6 +310,7 @@ enum : int {
   kSpecMonoYes = 64,                    // the teacher's disparity is given as disparity (epilogue)
   kSpecNoScale = 128,                   // no per-sample scale
   kSpecNoNoise = 256,                   // no tie-break noise map (the whole-step lists fold it into the identity map: Philox)
+  kSpecFramed = 2048,                   // a disparity per frame (MarchParams::framed; not a LEAN specialisation)
   kSpecConvA = 512, kSpecConvB = 1024,  // Project3D convention 0 (ManyDepth, align_corners=True) / 1 (DualRefine) known at compile time
   kSpecTeacher = kSpecLean | kSpecNoDisp2 | kSpecExtNo | kSpecCostNo | kSpecNoScale | kSpecConvA,
   kSpecStudent = kSpecLean | kSpecNoDisp2 | kSpecExtYes | kSpecCostYes | kSpecMonoYes | kSpecConvA,      // whole-step list, scale 0
@@ -322,6 +346,8 @@ MAL_DEV void march_body() {
   constexpr bool COST_NO = (SPEC & kSpecCostNo) != 0, COST_YES = (SPEC & kSpecCostYes) != 0;
   constexpr bool MONO_YES = (SPEC & kSpecMonoYes) != 0, NO_SCALE = (SPEC & kSpecNoScale) != 0;
   constexpr bool NO_NOISE = (SPEC & kSpecNoNoise) != 0;
+  constexpr bool FRAMED = (SPEC & kSpecFramed) != 0;  // frame -1 warped with disp, frame +1 with disp2; two gradient maps
+  static_assert(!FRAMED || (GRAD && POSE && !LEAN && !NO_DISP2 && !EPI && !TEMPORAL && !EXPORT), "FRAMED: generic pose-gradient pass");
 #ifdef MAL_CONV_FIXED  // A/B: Project3D's convention fixed at compile time in the specialised passes (measured 1 % SLOWER than the
   constexpr int CONV = (SPEC & kSpecConvA) ? 0 : ((SPEC & kSpecConvB) ? 1 : -1);  // scalar branch: profiles/r04_hsum_variants_ab.txt)
 #else
@@ -498,7 +524,7 @@ MAL_DEV void march_body() {
   constexpr bool SHADOW = MAL_SHADOW && H_MODE != 0 && GRAD;
   // ... the pose re-derivation only where its seven results fit next to the rest (the temporal and epilogue variants spill)
   constexpr bool SHADOW_POSE = SHADOW && POSE && !TEMPORAL && !EPI && !DBG;
-  struct PosePrep { f2 alq, beq; float X[3]; };
+  struct PosePrep { f2 alq, beq; float X[3]; f2 Xf[FRAMED ? 3 : 1]; };  // Xf: the point per frame (FRAMED)
   int it = 0;
   // One-row halo (p.bnd != nullptr, gradient passes of the whole-step list): a task warps ONE row beyond each end of its
   // segment and evaluates the statistics / decisions of its OWN rows only.  The gradient of a boundary row then lacks
@@ -626,6 +652,7 @@ MAL_DEV void march_body() {
   f2 y2rg = bc(0.f);
   float y2b = 0.f;  // target pixel of row r-2
   float dv_1 = 0.f, dv_2 = 0.f;  // disparity of rows r-1, r-2 (the pose terms of the gradient row re-project it)
+  float dw_1 = 0.f, dw_2 = 0.f;  // FRAMED: frame 1's
   // ================= epilogue terms of output row (EPI): row q = r-2 with GRAD, c without ===
   auto epilogue = [&](CParams& p, int r, const PixInfo& pq, float le_disp, float le_mono, float le_mr, float le_er,
                       unsigned so_c, unsigned so_q, bool has_mdisp, bool has_er, float le_ensd) __attribute__((always_inline)) {
@@ -686,8 +713,15 @@ MAL_DEV void march_body() {
     const f2 c0 = P[0] * bc(ray[0]) + P[1] * bc(ray[1]) + P[2] * bc(ray[2]);
     const f2 c1 = P[4] * bc(ray[0]) + P[5] * bc(ray[1]) + P[6] * bc(ray[2]);
     const f2 c2 = P[8] * bc(ray[0]) + P[9] * bc(ray[1]) + P[10] * bc(ray[2]);
-    o.alq = (c0 - pq_u * c2) * pq_rz * bc(ddepth);  // d u / d disp (the clip gate is inside du, dv)
-    o.beq = (c1 - pq_v * c2) * pq_rz * bc(ddepth);
+    f2 dd = bc(ddepth);
+    if (FRAMED) {  // frame 1's point and depth derivative come from its own disparity
+      const float depth1 = depth_of(dw_2, p.min_disp, p.range);
+      dd = (f2){ddepth, -(depth1 * depth1) * p.range};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o.Xf[j] = (f2){o.X[j], depth1 * ray[j]};
+    }
+    o.alq = (c0 - pq_u * c2) * pq_rz * dd;  // d u / d disp (the clip gate is inside du, dv)
+    o.beq = (c1 - pq_v * c2) * pq_rz * dd;
   };
   auto gradient_row = [&](CParams& p, int r, int it, const f2* hc, const Ahead& cur, unsigned so_q,
                           float le_mono, const PosePrep* prep) __attribute__((always_inline)) {
@@ -755,7 +789,7 @@ MAL_DEV void march_body() {
       g[2] = fma2((f2){cur.gc[2], cur.gc[5]}, ownf, g[2]);
     }
     MAL_MARK(61);  // ring read, L1 term, vertical adjoint sums, d loss / d warped colour done
-    float gdisp;
+    float gdisp, gdisp1 = 0.f;
     if (POSE) {
       PosePrep here;
       if (!prep) pose_prep(q, it, here);  // (the drain iterations; the row loop hands in what it formed in the gathers' shadow)
@@ -768,6 +802,7 @@ MAL_DEV void march_body() {
       const f2 gv = (f2){(tv0.x + tv0.y) + tv2.x, (tv1.x + tv1.y) + tv2.y};
       const f2 gd = gu * alq + gv * beq;
       gdisp = gd.x + gd.y;
+      if (FRAMED) { gdisp = gd.x; gdisp1 = gd.y; }  // each frame's candidate has its own disparity map
       MAL_MARK(62);  // chain rule to the disparity done; pose partials follow
       if (out_x) {
         const f2 a0 = gu * pq_rz, a1 = gv * pq_rz, a2 = -(gu * pq_u + gv * pq_v) * pq_rz;
@@ -775,7 +810,7 @@ MAL_DEV void march_body() {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
-          for (int j = 0; j < 3; ++j) gP[i * 4 + j] = fma2(a[i], bc(X[j]), gP[i * 4 + j]);
+          for (int j = 0; j < 3; ++j) gP[i * 4 + j] = fma2(a[i], FRAMED ? pp.Xf[j] : bc(X[j]), gP[i * 4 + j]);
           gP[i * 4 + 3] += a[i];
         }
       }
@@ -789,8 +824,12 @@ MAL_DEV void march_body() {
         const int py = prow(q), sq = py / p.rows;
         const unsigned which = (py == sq * p.rows) ? 0u : 1u;
         stf(p.bnd, ((unsigned)((b * p.segs + sq) * 2) + which) * (unsigned)W * 4u + (unsigned)gxr * 4u, gdisp);
+        if (FRAMED) stf(p.bnd2, ((unsigned)((b * p.segs + sq) * 2) + which) * (unsigned)W * 4u + (unsigned)gxr * 4u, gdisp1);
       } else if (TEMPORAL && p.fin_out) stf(p.fin_out, so_q, fma_(fin_cR, gdisp, fin_cS * (le_mono * fin_inv - fin_corr)));
-      else stf(p.g_reproj, so_q, gdisp);
+      else {
+        stf(p.g_reproj, so_q, gdisp);
+        if (FRAMED) stf(p.g_reproj2, so_q, gdisp1);
+      }
     }
   }
   MAL_MARK(63);  // gradient row stored
@@ -839,7 +878,8 @@ MAL_DEV void march_body() {
     // ================= stage W: warp row r (reflected if outside the image) ==================
     const int gyr = prow(row_of(r));  // physical row: addresses and the ray
     WarpRow w0;
-    const float dv_ = disp2_b ? (cur.disp + cur.disp2) / 2.0f : cur.disp;
+    const float dv_ = (!FRAMED && disp2_b) ? (cur.disp + cur.disp2) / 2.0f : cur.disp;
+    const float dw_ = FRAMED ? cur.disp2 : 0.f;
     w0.yrg = (f2){cur.y[0], cur.y[1]}; w0.yb = cur.y[2];
     // the issue phase (projection, operand requests, gathers) is what the rest of the iteration waits for:
     // run it at raised wave priority so the sibling wave's arithmetic does not delay it (measured -1.7 %)
@@ -854,7 +894,7 @@ MAL_DEV void march_body() {
 #ifdef MAL_TAPS_INT  // A/B: integer tap offsets (round 3) in the specialised passes too
       warp_issue<GRAD, POSE, DBG, false>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
 #else
-      warp_issue<GRAD, POSE, DBG, LEAN && !DBG>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
+      warp_issue<GRAD, POSE, DBG, LEAN && !DBG, FRAMED>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); }, dw_);
 #endif
     }
     __builtin_amdgcn_s_setprio(0);
@@ -1167,6 +1207,7 @@ MAL_DEV void march_body() {
     w1 = w0;
     if (GRAD) pi1 = pi0;
     dv_2 = dv_1; dv_1 = dv_;
+    if (FRAMED) { dw_2 = dw_1; dw_1 = dw_; }
     tick(7); MAL_MARK(7);  // rolls
   }
   // ---- one-row halo: nothing is left to warp, two gradient rows are -- the segment's last own row (its window row below
@@ -1188,6 +1229,7 @@ MAL_DEV void march_body() {
       y2rg = w1.yrg; y2b = w1.yb;
       pi1.rp = 0.f; pi1.w = 0.f; pi1.win = 0;
       dv_2 = dv_1;
+      if (FRAMED) dw_2 = dw_1;
     }
   }
 #ifdef MAL_STAGE_TIMERS
@@ -1248,6 +1290,12 @@ __global__ __launch_bounds__(64, 2) void march_student_temporal_kernel(MarchPara
 // DualRefine's passes of the deq iterations > 0: teacher-style pass (automask, pose gradients) with the consistency epilogue
 __global__ __launch_bounds__(64, 2) void march_refine_kernel(MarchParams p_kernarg) {
   march_body<true, true, true, true, false, false, false, kSpecRefine>();
+}
+// DualRefine's pose-update losses (dualrefine/trainer.py:457-480,699-767): teacher-style pass whose two candidates are warped
+// with two different disparities (MarchParams::framed)
+template <bool AUTOMASK, bool DBG>
+__global__ __launch_bounds__(64, 2) void march_framed_kernel(MarchParams p_kernarg) {
+  march_body<true, AUTOMASK, true, false, DBG, false, false, kSpecFramed>();
 }
 
 #ifdef MAL_EXPERIMENTS  // option "march3" (measured slower, LABBOOK.md 6): not in the default build
@@ -1592,7 +1640,19 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
 #else
   if (grad && p.color_out[0]) return MAL_EINVAL;  // an exporting gradient pass exists in -DMAL_EXPERIMENTS builds only
 #endif
-  if (p.forced_w && grad && !pose && !automask && !epi) {
+  if (p.framed) {  // a disparity per frame: gradient + pose-gradient pass without epilogue, two gradient maps
+    if (!(grad && pose && !epi) || !p.disp2 || !p.g_reproj || !p.g_reproj2 || (p.bnd != nullptr) != (p.bnd2 != nullptr) ||
+        p.forced_w || p.color_out[0] || p.lowest_cost || p.depth_out)
+      return MAL_EINVAL;
+    if (p.dbg && (p.H >= 4096 || p.W >= 4096)) return MAL_EINVAL;
+    if (automask) {
+      if (p.dbg) hipLaunchKernelGGL((march_framed_kernel<true, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((march_framed_kernel<true, false>), grid, block, 0, st, p);
+    } else {
+      if (p.dbg) hipLaunchKernelGGL((march_framed_kernel<false, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((march_framed_kernel<false, false>), grid, block, 0, st, p);
+    }
+  } else if (p.forced_w && grad && !pose && !automask && !epi) {
     // TEMPORAL student pass (--main_temporal): forced_w is the pass's whole weight (consistency x matching x (1 - augmentation),
     // as the forward pass in front of the producer formed it), so no mask operand is read again
     if (!p.forced_arg || !p.g_color[0] || !p.g_color[1] || p.ext_mask || p.lowest_cost || p.sample_scale) return MAL_EINVAL;
@@ -1615,6 +1675,8 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
     if (p.H >= 4096 || p.W >= 4096) return MAL_EINVAL;
     if (grad && pose && automask && !epi) hipLaunchKernelGGL((march_kernel<true, true, true, false, true>), grid, block, 0, st, p);
     else if (grad && pose && automask && epi) hipLaunchKernelGGL((march_kernel<true, true, true, true, true>), grid, block, 0, st, p);  // DualRefine, deq iterations > 0
+    else if (grad && pose && !automask && !epi) hipLaunchKernelGGL((march_kernel<true, false, true, false, true>), grid, block, 0, st, p);  // DualRefine, --disable_automasking
+    else if (grad && pose && !automask && epi) hipLaunchKernelGGL((march_kernel<true, false, true, true, true>), grid, block, 0, st, p);
     else if (grad && !pose && !automask && epi) hipLaunchKernelGGL((march_kernel<true, false, false, true, true>), grid, block, 0, st, p);
     else if (grad && !pose && !automask && !epi) hipLaunchKernelGGL((march_kernel<true, false, false, false, true>), grid, block, 0, st, p);
     else return MAL_EINVAL;

@@ -40,7 +40,10 @@ def default_options(**kw):
     Pass ``scales=[0, 1, 2, 3]`` for upstream's list: ``generate_images_pred`` + ``compute_losses`` take any."""
     o = dict(height=192, width=640, batch_size=8, min_depth=0.1, max_depth=100.0, frame_ids=[0, -1, 1], scales=[0],
              n_losses=1, v1_multiscale=False, disable_automasking=False, no_ssim=False, disparity_smoothness=1e-3,
-             avg_reprojection=False, disable_motion_masking=False, Dstar_T0_pair=False, Tstar_D0_pair=False)
+             avg_reprojection=False, disable_motion_masking=False, Dstar_T0_pair=False, Tstar_D0_pair=False,
+             # upstream's default is False (options.py:160-162) -- and its shipped branch then ends the process (exit(0),
+             # trainer.py:484); the default here is the configuration upstream can run.  False: loss_step adds the pose-update losses
+             disable_pose_updates=True)
     o.update(kw)
     return SimpleNamespace(**o)
 
@@ -63,7 +66,11 @@ class DrLossStepFn(Function):
     """generate_images_pred + compute_losses of DualRefine's trainer over the deq iterations of ONE scale as one library call
     per direction (``mal_dr_loss_fwd/_bwd``).  Leaves: ``disp[it]`` (n of them, at the scale's own size), then ``T_m1[it]``,
     then ``T_p1[it]`` ((B,4,4) each; a pose the trainer detaches simply arrives without ``requires_grad``).  For a scale > 0
-    the disparities are upsampled here (trainer.py:411-412) and the adjoint is applied to what the library hands back."""
+    the disparities are upsampled here (trainer.py:411-412) and the adjoint is applied to what the library hands back.
+    ``cfg[9]`` (a dict, scale 0 only): the pose-update losses (trainer.py:457-480,699-767) ride on the call as one more marching
+    pass -- four more leaves follow: the disparity paired with the refined pose for frame -1, iteration 0's disparity (frame
+    +1's candidate is ("color", 1, 0, 0)), ("cam_T_cam", 0, -1, 1), ("cam_T_cam", 0, 1); the term is the SECOND output (its own
+    cotangent: upstream adds it after the division by len(scales))."""
 
     @staticmethod
     def forward(ctx, consts, cfg, *leaves):
@@ -73,6 +80,7 @@ class DrLossStepFn(Function):
         scale = cfg[6] if len(cfg) > 6 else 0
         texels_from = cfg[7] if len(cfg) > 7 else None  # the workspace of the step's first call (texels + identity term)
         want_dec = len(cfg) > 8 and cfg[8]               # parity instrumentation (tests): decision planes per iteration
+        pu = cfg[9] if len(cfg) > 9 else None            # the pose-update losses: {"noise": (B,1,H,W) N(0,1) or None}
         req, p = ops._req, ops._p
         tens = [req(t, "leaf") for t in leaves]
         cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K)]
@@ -104,6 +112,15 @@ class DrLossStepFn(Function):
         losses = torch.empty(4 * L.DR_MAX_ITERS + 4, dtype=torch.float32, device=dev)
         total = torch.empty(1, dtype=torch.float32, device=dev)
         a.losses, a.loss_total = p(losses), p(total)
+        pu_total, pu_nz = None, None
+        if pu is not None:
+            if scale or len(tens) != 3 * n + 4:
+                raise L.MalError("DrLossStepFn: the pose-update losses ride on the scale-0 call, with four more leaves")
+            pu_total = torch.empty(1, dtype=torch.float32, device=dev)
+            pu_nz = None if pu.get("noise") is None else req(pu["noise"], "pose-update noise")
+            a.flags |= L.DR_POSE_UPDATE
+            a.pu_disp_m1, a.pu_disp_p1, a.pu_T_m1, a.pu_T_p1 = (p(t) for t in tens[3 * n:3 * n + 4])
+            a.pu_noise, a.pu_loss_total = p(pu_nz), p(pu_total)
         ws = _dr_workspace(dev, B, H, W, n, slot=int(scale))
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
         if texels_from is not None:
@@ -113,25 +130,34 @@ class DrLossStepFn(Function):
             decs = [torch.zeros((L.DEC_PLANES, B, H, W), dtype=torch.int32, device=dev) for _ in range(n)]
             for it in range(n):
                 a.dec[it] = p(decs[it])
+            if pu is not None:
+                decs.append(torch.zeros((L.DEC_PLANES, B, H, W), dtype=torch.int32, device=dev))
+                a.pu_dec = p(decs[-1])
         L.check(L.load().mal_dr_loss_fwd(C.byref(a)), "mal_dr_loss_fwd")
-        ctx.args, ctx.keep, ctx.n, ctx.scale, ctx.up = a, (tens, cons, cm, nz, ws, losses, total), n, int(scale), up
+        ctx.args, ctx.keep, ctx.n, ctx.scale, ctx.up = a, (tens, cons, cm, nz, ws, losses, total, pu_total, pu_nz), n, int(scale), up
+        ctx.pu = pu is not None
         ctx.texels_from = texels_from  # (kept alive: the passes of this call read it)
         ctx.ws_token = ops.claim_workspace(ws)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(losses, ws, *decs)
-        return (total, losses, ws, *decs)  # (ws: what a later scale's call of the same step takes the texels from)
+        return (total, pu_total, losses, ws, *decs)  # (ws: what a later scale's call of the same step takes the texels from)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_total, _g_losses=None, _g_ws=None, *_g_decs):
+    def backward(ctx, g_total, g_pu=None, _g_losses=None, _g_ws=None, *_g_decs):
         n, tens = ctx.n, ctx.keep[0]
-        if g_total is None:
-            return (None,) * (2 + 3 * n)
+        if g_total is None and (g_pu is None or not ctx.pu):
+            return (None,) * (2 + len(tens))
         ops.check_workspace(ctx.keep[4], ctx.ws_token, "DualRefineLossPath.loss_step backward")
-        g_total = g_total.reshape(1).contiguous()
+        zero = lambda g: torch.zeros(1, dtype=torch.float32, device=tens[0].device) if g is None else g.reshape(1).contiguous()
+        g_total = zero(g_total)
         a = ctx.args
         grads = [torch.empty_like(t) if ctx.needs_input_grad[2 + i] else None for i, t in enumerate(tens)]
         a.g_total = ops._p(g_total)
+        if ctx.pu:
+            g_pu = zero(g_pu)
+            a.g_pu_total = ops._p(g_pu)
+            a.g_pu_disp_m1, a.g_pu_disp_p1, a.g_pu_T_m1, a.g_pu_T_p1 = (ops._p(g) for g in grads[3 * n:3 * n + 4])
         full = [None] * n  # scale > 0: d total / d (upsampled disparity) without the smoothness term, which arrives in grads[it]
         for it in range(n):
             if ctx.scale and grads[it] is not None:
@@ -314,15 +340,24 @@ class DualRefineLossPath:
         losses["loss"] = total / self.num_scales
         return losses
 
-    def loss_step(self, inputs, outputs, noises=None, want_decisions=False):
+    def loss_step(self, inputs, outputs, noises=None, want_decisions=False, pose_update=None, pose_noise=None):
         """``generate_images_pred`` + ``compute_losses`` (dualrefine/trainer.py:395-451,530-633) in ONE library call per
         direction AND scale of ``opt.scales`` (upstream's default list is [0,1,2,3]: scale 0 and 2 with the deq iterations
         0..n_losses, scale 1 skipped, scale 3 iteration 0 only, :403-407,536-547; a lower scale's disparities are upsampled
         around the call), with --avg_reprojection / --no_ssim when set; same ``losses`` keys and values as the two methods
         called one after the other (they remain the route for --v1_multiscale and for the ("color", ...) / ("sample", ...)
         outputs, which this call does not materialise).  ``noises``: one (B,1,H,W) N(0,1) map per visited
-        (scale, iteration), in loop order (default: drawn as ``config.noise_source`` says)."""
+        (scale, iteration), in loop order (default: drawn as ``config.noise_source`` says).
+        ``pose_update`` (default: ``not opt.disable_pose_updates``): the pose-update losses of ``process_batch`` (:337-343;
+        ``pose_update_generate_images_pred`` + ``compute_pose_update_losses``, :457-480,699-767) ride on the scale-0 call as one
+        more marching pass -- "reproj_loss/pose_0" / "loss/pose_0_0" appear and "loss" includes the term, as upstream's merged
+        dictionary has them; ``pose_noise``: its (B,1,H,W) N(0,1) map (default: drawn like the others)."""
         opt = self.opt
+        if pose_update is None:
+            pose_update = not getattr(opt, "disable_pose_updates", True)
+        if pose_update and 0 not in opt.scales:
+            raise L.MalError("loss_step: the pose-update losses ride on the scale-0 call; use pose_update_generate_images_pred + "
+                             "compute_pose_update_losses for a scale list without scale 0")
         n_full = opt.n_losses + 1
         scales = list(opt.scales)
         if any(s_ not in (0, 1, 2, 3) for s_ in scales) or len(set(scales)) != len(scales) or not scales \
@@ -341,7 +376,10 @@ class DualRefineLossPath:
                 philox = config.noise_seed
             else:
                 noises = [loss_utils.draw_noise((B, 1, H, W), target.device) for _ in units]  # one draw per visit (:586-587)
+        if pose_update and pose_noise is None and not opt.disable_automasking and philox is None:
+            pose_noise = loss_utils.draw_noise((B, 1, H, W), target.device)
         losses, total, k = {}, None, 0
+        pu_total = None
         decisions = {}  # want_decisions: {(scale, it): (MAL_DEC_PLANES,B,H,W) int32}
         first_ws = None  # the first call's workspace: later scales of this step take the texels and the identity term from it
         for scale in scales:
@@ -361,11 +399,22 @@ class DualRefineLossPath:
             k += n
             consts = (target, inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("K", 0)], inputs[("inv_K", 0)], cmask, nz,
                       inputs[("color", 0, scale)] if scale else None)
+            pu, pu_leaves = None, ()
+            if pose_update and scale == 0:
+                # frame -1: the refined pose paired with the last iteration's depth -- or iteration 0's, detached (:463-469);
+                # frame +1: ("color", 1, 0, 0), i.e. iteration 0's depth under ("cam_T_cam", 0, 1) with its graph (:420-423)
+                d_m1 = outputs[("disp", 0, 0)].detach() if opt.Tstar_D0_pair else outputs[("disp", 0, opt.n_losses)]
+                pu_leaves = (d_m1, outputs[("disp", 0, 0)], outputs[("cam_T_cam", 0, -1, 1)], outputs[("cam_T_cam", 0, 1)])
+                if philox is not None and pose_noise is not None:
+                    raise L.MalError("loss_step: pose_noise given while the other maps are drawn in the kernels (pass `noises` too)")
+                pu = {"noise": None if opt.disable_automasking else pose_noise}
             cfg = (opt.min_depth, opt.max_depth, opt.disparity_smoothness / (2 ** scale), flags, n, philox, scale, first_ws,
-                   bool(want_decisions))
-            tot_s, v, ws_s, *decs_s = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1)
+                   bool(want_decisions), pu)
+            tot_s, pu_s, v, ws_s, *decs_s = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1, *pu_leaves)
             for it, d in enumerate(decs_s):
-                decisions[(scale, it)] = d
+                decisions[(scale, it) if it < n else ("pose", 0)] = d
+            if pu is not None:
+                pu_total = pu_s.reshape(())
             if first_ws is None:
                 first_ws = ws_s
             total = tot_s.reshape(()) if total is None else total + tot_s.reshape(())
@@ -375,6 +424,9 @@ class DualRefineLossPath:
                 if it > 0:
                     losses["consistency_loss/%d_%d" % (scale, it)] = v[4 * it + 1]
         losses["loss"] = total / self.num_scales if self.num_scales != 1 else total
+        if pu_total is not None:  # process_batch merges the two dictionaries: "loss" is in both and is summed (:337-343)
+            losses["reproj_loss/pose_0"] = losses["loss/pose_0_0"] = pu_total
+            losses["loss"] = losses["loss"] + pu_total
         if want_decisions:
             return losses, decisions
         return losses

@@ -678,10 +678,10 @@ def dr_compute_losses(opt, inputs, outputs, noises=None, aten=True, forced=None)
     return losses
 
 
-def dr_pose_update_generate_images_pred(opt, inputs, outputs, aten=True):
+def dr_pose_update_generate_images_pred(opt, inputs, outputs, aten=True, forced=None):
     """dualrefine/trainer.py:457-480: frame -1 warped once more with the refined pose ``("cam_T_cam", 0, -1, 1)`` and the
     last iteration's depth (the iteration-0 depth, detached, with --Tstar_D0_pair).  The debug prints and ``exit(0)`` of
-    :481-484 are not behaviour."""
+    :481-484 are not behaviour.  ``forced`` (decision-forced parity tests): {"taps": {-1: (x0, y0, clipx, clipy)}, ...}."""
     if getattr(opt, "Tstar_D0_pair", False):
         depth = outputs[("depth", 0, 0, 0)].clone().detach()
     else:
@@ -689,17 +689,23 @@ def dr_pose_update_generate_images_pred(opt, inputs, outputs, aten=True):
     H, W = depth.shape[-2:]
     pts = backproject_depth(depth, inputs[("inv_K", 0)])
     grid = project_3d(pts, inputs[("K", 0)], outputs[("cam_T_cam", 0, -1, 1)], H, W, convention="dualrefine")
-    outputs[("color", -1, 0, 0, 1)] = grid_sample_border(inputs[("color", -1, 0)], grid, convention="dualrefine", aten=aten)
+    outputs[("sample", -1, 0, 0, 1)] = grid
+    if forced is not None:
+        outputs[("color", -1, 0, 0, 1)] = AR.grid_sample_forced_taps(inputs[("color", -1, 0)], grid, *forced["taps"][-1],
+                                                                     align_corners=False)
+    else:
+        outputs[("color", -1, 0, 0, 1)] = grid_sample_border(inputs[("color", -1, 0)], grid, convention="dualrefine", aten=aten)
 
 
-def dr_compute_pose_update_losses(opt, inputs, outputs, noise=None, aten=True):
+def dr_compute_pose_update_losses(opt, inputs, outputs, noise=None, aten=True, forced=None):
     """dualrefine/trainer.py:699-767: min (or mean, --avg_reprojection) over {frame -1 under the refined pose,
-    frame +1 of iteration 0}, automask against the raw sources, masked mean; no smoothness / consistency term."""
+    frame +1 of iteration 0}, automask against the raw sources, masked mean; no smoothness / consistency term.
+    ``forced`` (decision-forced parity tests): {"win", "automask", "l1"} as in dr_compute_losses."""
     target = inputs[("color", 0, 0)]
     R = []
     for f in opt.frame_ids[1:]:
         pred = outputs[("color", -1, 0, 0, 1)] if f == -1 else outputs[("color", f, 0, 0)]
-        R.append(compute_reprojection_loss(pred, target, opt.no_ssim, aten))
+        R.append(compute_reprojection_loss(pred, target, opt.no_ssim, aten, None if forced is None else forced.get("l1")))
     R = torch.cat(R, 1)
     ident = None
     if not opt.disable_automasking:
@@ -707,8 +713,10 @@ def dr_compute_pose_update_losses(opt, inputs, outputs, noise=None, aten=True):
                        for f in opt.frame_ids[1:]], 1)
         ident = I.mean(1, keepdim=True) if opt.avg_reprojection else torch.min(I, dim=1, keepdim=True)[0]
     rp = R.mean(1, keepdim=True) if opt.avg_reprojection else torch.min(R, dim=1, keepdim=True)[0]
+    if forced is not None and not opt.avg_reprojection:
+        rp = torch.gather(R, 1, forced["win"])
     if not opt.disable_automasking:
         ident = ident + _draw_noise(ident.shape, noise) * 0.00001
-    mask = compute_loss_masks(rp, ident)
+    mask = compute_loss_masks(rp, ident) if forced is None else forced["automask"].to(rp.dtype)
     reproj = (rp * mask).sum() / (mask.sum() + 1e-7)
     return {"reproj_loss/pose_0": reproj, "loss/pose_0_0": reproj, "loss": reproj}

@@ -692,6 +692,137 @@ def test_dualrefine_scales_sweep_against_the_operator_route():
             assert np.abs(res["step"][1][k] - g).max() <= 2e-5 * max(sc, 1e-12), (tag, k, np.abs(res["step"][1][k] - g).max() / max(sc, 1e-12))
 
 
+# ------------------------------------------------------------------ a17: the pose-update losses in the one-call step
+def _dr_build_pu(batch, dev, pose_fn, dtype=torch.float32):
+    """_dr_build with a refined pose of its own -- a function of the same leaves, which then collect both poses' gradients"""
+    inputs, outputs, leaves = _dr_build(batch, dev, pose_fn, dtype)
+    outputs[("cam_T_cam", 0, -1, 1)] = pose_fn(leaves["axisangle_m1"] * 1.05 + 0.002, leaves["translation_m1"] * 0.95 - 0.003, True)
+    return inputs, outputs, leaves
+
+
+def _dr_oracle_pu(batch, kw, noises, nz_pose, forced=None, forced_pose=None, dtype=torch.float32, build=_dr_build_pu):
+    """process_batch's loss half with the pose updates on (dualrefine/trainer.py:335-343): the two dictionaries merged"""
+    from oracle import mal_oracle as O
+    inputs, outputs, leaves = build(batch, "cpu", O.transformation_from_parameters, dtype)
+    opt = O.dr_default_opt(**kw)
+    O.dr_generate_images_pred(opt, inputs, outputs, forced=forced)
+    ref = O.dr_compute_losses(opt, inputs, outputs, noises=[n.clone().to(dtype) for n in noises], forced=forced)
+    O.dr_pose_update_generate_images_pred(opt, inputs, outputs, forced=forced_pose)
+    pl = O.dr_compute_pose_update_losses(opt, inputs, outputs, noise=nz_pose.clone().to(dtype), forced=forced_pose)
+    for k, v in pl.items():
+        ref[k] = ref[k] + v if k in ref else v
+    ref["loss"].backward()
+    return ref, {k: (t.grad if t.grad is not None else torch.zeros_like(t)).numpy() for k, t in leaves.items()}, inputs, outputs
+
+
+@pytest.mark.parametrize("shape,kw_extra", [((2, 40, 72), {}), ((8, 192, 640), {}), ((3, 37, 50), {"Tstar_D0_pair": True}),
+                                            ((2, 40, 72), {"Dstar_T0_pair": True}), ((2, 40, 72), {"avg_reprojection": True}),
+                                            ((2, 40, 72), {"no_ssim": True}), ((2, 40, 72), {"disable_automasking": True})],
+                         ids=["b2_40x72", "b8_192x640", "Tstar_D0_ragged", "Dstar_T0", "avg", "no_ssim", "no_automask"])
+def test_dualrefine_pose_update_losses_in_the_one_call_step(shape, kw_extra):
+    """dualrefine/trainer.py:335-343,457-480,699-767 (round 5): with pose updates on, process_batch adds a second loss
+    dictionary -- min over {frame -1 under the REFINED pose with the last iteration's depth, frame +1 as iteration 0 warped
+    it}, automask with its own noise draw, masked mean.  In the one-call step that is one more marching pass whose two
+    candidates carry two different disparities (MarchParams::framed).  Decision-exact against the oracle's restatement of
+    those lines: the pass exports its decisions, they differ from the free-running oracle's at a handful of near-tie pixels,
+    and with the oracle taking them every loss agrees at 2e-5 and every gradient -- the leaves collect the main loops' and the
+    pose-update term's -- within max(1e-4, 1.25 x the fp32 oracle's own distance from fp64)."""
+    from mal_amd import dualrefine, layers
+    from mal_amd.synthetic import make_batch
+    from oracle import aten_restated as AR
+    from oracle import mal_oracle as O
+    B, H, W = shape
+    N = B * H * W
+    batch = make_batch(B, H, W, seed=324)
+    kw = dict(height=H, width=W, batch_size=B, n_losses=1)
+    kw.update(kw_extra)
+    torch.manual_seed(12)
+    noises = [torch.randn(B, 1, H, W) for _ in range(2)]
+    nz_pose = torch.randn(B, 1, H, W)
+    inputs, outputs, gl = _dr_build_pu(batch, "cuda:0", layers.transformation_from_parameters)
+    lp = dualrefine.DualRefineLossPath(dualrefine.default_options(disable_pose_updates=False, **kw), fuse=True)
+    got, decs = lp.loss_step(inputs, outputs, noises=[n.to("cuda:0") for n in noises], want_decisions=True,
+                             pose_noise=nz_pose.to("cuda:0"))
+    got["loss"].backward()
+    torch.cuda.synchronize()
+    assert set(decs) == {(0, 0), (0, 1), ("pose", 0)}
+    got_l = {k: float(v.detach()) for k, v in got.items()}
+    grads = {k: (t.grad if t.grad is not None else torch.zeros_like(t)).cpu().numpy() for k, t in gl.items()}
+    forced = {u: _dr_decode(decs[u]) for u in ((0, 0), (0, 1))}
+    fpose = _dr_decode(decs[("pose", 0)])
+    # frame +1's candidate IS ("color", 1, 0, 0): the pass re-warps it with iteration 0's disparity and pose -- same taps
+    for u, v in zip(fpose["taps"][1], forced[(0, 0)]["taps"][1]):
+        assert torch.equal(u, v)
+    # ---- free-running oracle: same keys, losses within the movement of near-tie pixels, decisions a handful apart
+    ref, _, oin, oout = _dr_oracle_pu(batch, kw, noises, nz_pose)
+    assert set(got_l) == set(ref), (sorted(got_l), sorted(ref))
+    for k, v in ref.items():
+        assert abs(got_l[k] - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + 6.0 / N, (k, got_l[k], float(v))
+    mine = AR.taps_of(oout[("sample", -1, 0, 0, 1)], H, W, align_corners=False)
+    diff = None
+    for u, v in zip(fpose["taps"][-1], mine):
+        diff = (u != v) if diff is None else (diff | (u != v))
+    counts = {"tap": int(diff.sum())}
+    if not kw.get("avg_reprojection"):
+        R = torch.cat([O.compute_reprojection_loss(oout[k], oin[("color", 0, 0)], kw.get("no_ssim", False))
+                       for k in (("color", -1, 0, 0, 1), ("color", 1, 0, 0))], 1)
+        counts["win"] = int((R.argmin(1, keepdim=True) != fpose["win"]).sum())
+    assert all(v <= 3e-4 * N + 8 for v in counts.values()), counts
+    # ---- the kernels' decisions on both sides
+    if kw.get("avg_reprojection"):
+        for fd in list(forced.values()) + [fpose]:
+            fd.pop("l1")  # both candidates carry an L1 term with their own signs; no argmin to force either
+    f32, g32, _, _ = _dr_oracle_pu(batch, kw, noises, nz_pose, forced=forced, forced_pose=fpose)
+    _, g64, _, _ = _dr_oracle_pu(batch, kw, noises, nz_pose, forced=_to64(forced), forced_pose=_to64(fpose), dtype=torch.float64)
+    _dr_hold_against_forced_oracle(grads, {k: batch[k].numpy() for k in HH.LEAVES}, f32, g32, g64, got_l)
+    # the refined pose and the pairing options really matter here: the term moves the leaves
+    assert abs(got_l["loss/pose_0_0"]) > 1e-3 and got_l["reproj_loss/pose_0"] == got_l["loss/pose_0_0"]
+
+
+def test_dualrefine_pose_update_one_call_against_the_operator_route_and_the_reference_fixture():
+    """the same term through pose_update_generate_images_pred + compute_pose_update_losses (materialised candidates, other
+    kernels) and against the values the reference's own Trainer methods produced for the fixture batch
+    (tests/golden/dualrefine_b2_40x72*.npz, "pose_losses/*": noise seed + 1; free-running, so near-tie pixels may move them)."""
+    from mal_amd import dualrefine, layers
+    for tag in G.DUALREFINE_CASES:
+        z = G.load(tag)
+        res = {}
+        for route in ("ops", "step"):
+            b, scales, units, inputs, outputs, leaves = G.dualrefine_dicts(z, layers.transformation_from_parameters, "cuda:0")
+            B, _, H, W = b["color0"].shape
+            N = B * H * W
+            torch.manual_seed(int(z["in/noise_seed"]))
+            noises = [torch.randn(B, 1, H, W).to("cuda:0") for _ in units]
+            torch.manual_seed(int(z["in/noise_seed"]) + 1)
+            nz_pose = torch.randn(B, 1, H, W).to("cuda:0")
+            lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=B, n_losses=1, scales=scales,
+                                                                          disable_pose_updates=False), fuse=True)
+            if route == "ops":
+                lp.generate_images_pred(inputs, outputs)
+                got = lp.compute_losses(inputs, outputs, noises=noises)
+                lp.pose_update_generate_images_pred(inputs, outputs)
+                for k, v in lp.compute_pose_update_losses(inputs, outputs, noise=nz_pose).items():
+                    got[k] = got[k] + v if k in got else v
+            else:
+                got = lp.loss_step(inputs, outputs, noises=noises, pose_noise=nz_pose)
+            got["loss"].backward()
+            torch.cuda.synchronize()
+            res[route] = ({k: float(v.detach()) for k, v in got.items()}, {k: t.grad.cpu().numpy() for k, t in leaves.items()})
+        assert set(res["ops"][0]) == set(res["step"][0])
+        for k in ("reproj_loss/pose_0", "loss/pose_0_0"):
+            ref = float(z["pose_losses/" + k])
+            assert abs(res["step"][0][k] - ref) <= 2e-4 * abs(ref) + 1e-6 + 4.0 / N, (tag, k, res["step"][0][k], ref)
+        ref = float(z["losses/loss"]) + float(z["pose_losses/loss"])
+        assert abs(res["step"][0]["loss"] - ref) <= 2e-4 * abs(ref) + 1e-6 + 2.0 * (len(units) + 2) / N, (tag, res["step"][0]["loss"], ref)
+        for k, v in res["ops"][0].items():
+            assert abs(res["step"][0][k] - v) <= 2e-5 * abs(v) + 4.0 / N, (tag, k, res["step"][0][k], v)
+        for k, g in res["ops"][1].items():  # materialised candidates, ATen's summation order inside SSIM: all but near-tie pixels
+            o = res["step"][1][k]
+            if g.ndim == 4:
+                bad = (np.abs(g - o) > 3e-4 * np.abs(o).max()).mean()
+                assert bad <= max(2e-3, 40.0 / g.size), (tag, k, "operator route", bad)
+
+
 def test_dualrefine_step_in_kernel_noise_equals_the_same_noise_handed_in():
     """MAL_DR_NOISE_PHILOX: iteration it's map is mal_tiebreak_noise(seed, step * MAL_DR_MAX_ITERS + it); the step with the
     maps drawn in its first launch and the step handed those maps agree to the bit, and the device counter advances once."""
