@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--dr-default-scales", action="store_true",
                     help="--mode dualrefine / dualrefine_ops with upstream's default scale list [0,1,2,3] (dualrefine/options.py:65-69: "
                          "scale 0 and 2 with both deq iterations, scale 1 skipped, scale 3 iteration 0) instead of [0]; a variant run")
+    ap.add_argument("--dr-pose-update", action="store_true",
+                    help="--mode dualrefine / dualrefine_ops with the pose updates on (dualrefine/trainer.py:335-343,457-480,699-767): "
+                         "the pose-update losses ride on the one-call step as one more marching pass (MAL_DR_POSE_UPDATE); a variant run")
     ap.add_argument("--ms-temporal", action="store_true",
                     help="--mode multiscale with --temporal (trainer.py:1161-1162,1279-1283): the producer once per scale between "
                          "mal_loss_multiscale_warp and _fwd; a variant run")
@@ -188,7 +191,8 @@ class TrainStep:
 class Step:
     """Everything a step needs, resident on the device."""
 
-    def __init__(self, dev, seed, mode="step", channels_last=False, main_temporal=False, ms_temporal=False, dr_scales=None):
+    def __init__(self, dev, seed, mode="step", channels_last=False, main_temporal=False, ms_temporal=False, dr_scales=None,
+                 dr_pose_update=False):
         from mal_amd import config, layers, trainer, step as step_mod
         self.mode, self.step_mod = mode, step_mod
         from mal_amd.synthetic import make_batch
@@ -231,8 +235,10 @@ class Step:
         elif mode == "dualrefine":
             from mal_amd import dualrefine
             self.dr_scales = list(dr_scales or [0])
+            self.dr_pose_update = bool(dr_pose_update)
             self.lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=self.B, n_losses=1,
-                                                                               scales=self.dr_scales), fuse=True)
+                                                                               scales=self.dr_scales,
+                                                                               disable_pose_updates=not dr_pose_update), fuse=True)
             self.cmask4 = self.cmask.unsqueeze(1)
             for sc in self.dr_scales:  # lower scales: pooled copies (the DEQ decoder is not part of this package)
                 if sc in (0, 1):
@@ -302,6 +308,10 @@ class Step:
             if self.dr_ops:  # the operator-level route (two fused passes + glue: ~75 launches)
                 self.lp.generate_images_pred(self.inputs, outputs)
                 losses = self.lp.compute_losses(self.inputs, outputs)
+                if self.dr_pose_update:  # process_batch's second dictionary, merged as upstream merges it (:337-343)
+                    self.lp.pose_update_generate_images_pred(self.inputs, outputs)
+                    for k, v in self.lp.compute_pose_update_losses(self.inputs, outputs).items():
+                        losses[k] = losses[k] + v if k in losses else v
             else:            # mal_dr_loss_fwd/_bwd: one library call per direction
                 losses = self.lp.loss_step(self.inputs, outputs)
             losses["loss"].backward(gradient=self.one)
@@ -666,7 +676,7 @@ def main():
     else:
         rot = Rotation(dev, 1234 + rank, args.mode, R, graph=bool(args.graph), channels_last=args.channels_last,
                        main_temporal=args.main_temporal, ms_temporal=args.ms_temporal,
-                       dr_scales=[0, 1, 2, 3] if args.dr_default_scales else None)
+                       dr_scales=[0, 1, 2, 3] if args.dr_default_scales else None, dr_pose_update=args.dr_pose_update)
         step = rot.steps[0]
     batch_cpu = step.batch_cpu
     step_B = getattr(step, "B", B)  # images per rank and step (read here: the train_step block below frees `step`)
@@ -1050,6 +1060,10 @@ def main():
                                 else "operator-level (DualRefineLossPath.generate_images_pred + compute_losses)")
         out["config"]["global_batch"] = step_B * n_ranks
         out["metric"] = "train images/sec at B=8 192x640 KITTI-shaped (DualRefine+MAL loss loops, fwd+bwd)"
+        if args.dr_pose_update:
+            out["config"]["pose_updates"] = ("on: compute_pose_update_losses (dualrefine/trainer.py:457-480,699-767) as one more marching pass "
+                                             "of the same call (MAL_DR_POSE_UPDATE)" if args.mode == "dualrefine" else
+                                             "on: pose_update_generate_images_pred + compute_pose_update_losses through the operators")
         if args.dr_default_scales:
             out["config"]["variant"] = ("upstream's default scale list [0,1,2,3]: scale 0 and 2 with deq iterations 0..1, scale 1 skipped, "
                                         "scale 3 iteration 0 (one mal_dr_loss call per visited scale on the one-call route)")

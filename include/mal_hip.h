@@ -527,6 +527,11 @@ typedef struct mal_dr_args {
   float *g_pu_T_m1, *g_pu_T_p1;
   uint32_t *pu_dec;                               /* parity instrumentation, as dec[] */
   float *pu_loss_total;                           /* nullable: receives the pose-update loss (= losses[4*MAL_DR_MAX_ITERS + 2]) */
+  /* An operand of the pose-update pass that IS an iteration's operand (upstream's default pairing: pu_disp_m1 = disp[n_iters-1],
+   * pu_disp_p1 = disp[0], pu_T_m1 = T_m1[n_iters-1], pu_T_p1 = T_p1[0]) can have its pose-update gradient ADDED into that
+   * iteration's output by the assembly launch instead of leaving as an output of its own that the caller then adds:
+   * k + 1 = "add into iteration k's g_disp / g_T_m1 / g_T_p1" (the matching g_pu_* must then be NULL), 0 = separate output. */
+  int pu_disp_m1_into, pu_disp_p1_into, pu_T_m1_into, pu_T_p1_into;
 } mal_dr_args;
 size_t mal_dr_workspace_bytes(int B, int H, int W, int n_iters);
 int mal_dr_loss_fwd(const mal_dr_args* args);

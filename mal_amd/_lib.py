@@ -168,7 +168,8 @@ class DrArgs(C.Structure):
                  ("ws", vp), ("ws_bytes", sz), ("stream", vp), ("scale", i32), ("color0_s", vp), ("disp_lo", vp * 4),
                  ("g_disp_lo", vp * 4), ("texels_from", vp), ("dec", vp * 4)] +
                 [(n, vp) for n in ("pu_disp_m1", "pu_disp_p1", "pu_T_m1", "pu_T_p1", "pu_noise", "g_pu_total", "g_pu_disp_m1",
-                                   "g_pu_disp_p1", "g_pu_T_m1", "g_pu_T_p1", "pu_dec", "pu_loss_total")])
+                                   "g_pu_disp_p1", "g_pu_T_m1", "g_pu_T_p1", "pu_dec", "pu_loss_total")] +
+                [(n, i32) for n in ("pu_disp_m1_into", "pu_disp_p1_into", "pu_T_m1_into", "pu_T_p1_into")])
 
 
 DR_MAX_ITERS = 4

@@ -238,6 +238,8 @@ struct DrAssemble {
   const float* G_r[kDrSlots]; const float* G_c[kDrIt]; const float* gn[kDrIt]; const float* bnd[kDrSlots];
   float* g_disp[kDrSlots]; float* g_T[kDrSlots][2];
   const float* G_r2; const float* bnd2; float* g_disp2; const float* g_pu_total;  // pose-update pass (slot n, grid y = n)
+  int pu_on;          // the pose-update pass ran
+  int pu_into[4];     // its gradient w.r.t. {frame -1's disparity, frame +1's, T_m1, T_p1} joins iteration k's output: k + 1 (0: own output)
   float* g_disp_lo[kDrIt];  // scale > 0: the smoothness term's gradient at the scale's own size (then not part of g_disp)
   const float* gT; const float* coefs; const double* stats; const float* g_total;
   int B, H, W, n, rows, segs, hs, ws;
@@ -250,12 +252,15 @@ __global__ __launch_bounds__(256) void dr_assemble_kernel(DrAssemble p) {
   const bool pu = it == p.n;
   const float g = pu ? (p.g_pu_total ? *p.g_pu_total : 1.0f) : (p.g_total ? *p.g_total : 1.0f);
   const float cR = p.coefs[it * 4 + 0] * g, cC = pu ? 0.f : p.coefs[it * 4 + 1] * g, cS = pu ? 0.f : p.coefs[it * 4 + 2] * g;
+  // the pose-update term's coefficient, for what it adds into THIS iteration's outputs (pu_into)
+  const float cP = (p.pu_on && !pu) ? p.coefs[p.n * 4 + 0] * (p.g_pu_total ? *p.g_pu_total : 1.0f) : 0.f;
   if (blockIdx.x == 0) {
     for (int f = 0; f < 2; ++f) {
       float* out = p.g_T[it][f];
       if (!out) continue;
       const float* in = p.gT + ((size_t)it * 2 + f) * B * 16;
-      for (int i = threadIdx.x; i < B * 16; i += 256) out[i] = in[i] * cR;
+      const float* inP = (p.pu_on && !pu && p.pu_into[2 + f] == it + 1) ? p.gT + ((size_t)p.n * 2 + f) * B * 16 : nullptr;
+      for (int i = threadIdx.x; i < B * 16; i += 256) out[i] = inP ? fma_(inP[i], cP, in[i] * cR) : in[i] * cR;
     }
   }
   if (pu) {  // two maps, the reprojection term only: d / d (frame -1's disparity), d / d (frame +1's)
@@ -288,17 +293,24 @@ __global__ __launch_bounds__(256) void dr_assemble_kernel(DrAssemble p) {
   const bool with_smooth = p.hs == H && p.ws == W;  // scale 0: all three terms live on the same map
   const float* G_r = p.G_r[it];
   const float* G_c = it > 0 ? p.G_c[it] : nullptr;
+  // the pose-update pass's maps that are gradients w.r.t. THIS iteration's disparity (wave-uniform)
+  const bool pa = p.pu_on && p.pu_into[0] == it + 1, pb = p.pu_on && p.pu_into[1] == it + 1;
   for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
     const int b = row / H, y = row - b * H;
     const float inv = div_(1.0f, (float)p.stats[it * B + b] + 1e-7f), corr = (float)p.stats[kDrIt * B + it * B + b];
     const float* brow = p.bnd[it] ? march_boundary_row(p.bnd[it], b, y, H, W, p.rows, p.segs) : nullptr;
+    const float* browA = (pa && p.bnd[p.n]) ? march_boundary_row(p.bnd[p.n], b, y, H, W, p.rows, p.segs) : nullptr;
+    const float* browB = (pb && p.bnd2) ? march_boundary_row(p.bnd2, b, y, H, W, p.rows, p.segs) : nullptr;
     const size_t r0 = (size_t)row * W;
     for (int x = threadIdx.x; x < W; x += 256) {
       const size_t i = r0 + x;
       const float G = brow ? G_r[i] + brow[x] : G_r[i];
       float v = with_smooth ? cS * (gn[i] * inv - corr) : 0.f;
       if (G_c) v = fma_(cC, G_c[i], v);
-      out[i] = fma_(cR, G, v);
+      v = fma_(cR, G, v);
+      if (pa) v = fma_(cP, browA ? p.G_r[p.n][i] + browA[x] : p.G_r[p.n][i], v);
+      if (pb) v = fma_(cP, browB ? p.G_r2[i] + browB[x] : p.G_r2[i], v);
+      out[i] = v;
     }
   }
 }
@@ -469,6 +481,14 @@ extern "C" int mal_dr_loss_bwd(const mal_dr_args* a) {
     p.G_r[n] = w.G_r[n]; p.G_r2 = w.G_r2; p.bnd[n] = g_march_halo1 ? w.bnd[n] : nullptr; p.bnd2 = g_march_halo1 ? w.bnd2 : nullptr;
     p.g_disp[n] = a->g_pu_disp_m1; p.g_disp2 = a->g_pu_disp_p1; p.g_T[n][0] = a->g_pu_T_m1; p.g_T[n][1] = a->g_pu_T_p1;
     p.g_pu_total = a->g_pu_total;
+    p.pu_on = 1;
+    const int into[4] = {a->pu_disp_m1_into, a->pu_disp_p1_into, a->pu_T_m1_into, a->pu_T_p1_into};
+    float* const own[4] = {a->g_pu_disp_m1, a->g_pu_disp_p1, a->g_pu_T_m1, a->g_pu_T_p1};
+    for (int k = 0; k < 4; ++k) {
+      if (into[k] < 0 || into[k] > n || (into[k] && own[k])) return MAL_EINVAL;  // one destination per gradient
+      if (into[k] && a->scale) return MAL_EINVAL;
+      p.pu_into[k] = into[k];
+    }
   }
   p.hs = H >> a->scale; p.ws = W >> a->scale;
   p.gT = w.gT; p.coefs = w.coefs; p.stats = w.stats; p.g_total = a->g_total;

@@ -82,7 +82,7 @@ class DrLossStepFn(Function):
         want_dec = len(cfg) > 8 and cfg[8]               # parity instrumentation (tests): decision planes per iteration
         pu = cfg[9] if len(cfg) > 9 else None            # the pose-update losses: {"noise": (B,1,H,W) N(0,1) or None}
         req, p = ops._req, ops._p
-        tens = [req(t, "leaf") for t in leaves]
+        tens = [None if t is None else req(t, "leaf") for t in leaves]  # (None: a pose-update operand that IS an iteration's)
         cons = [req(t, "input") for t in (color0, color_m1, color_p1, K, inv_K)]
         cm = None if cmask is None else req(cmask, "consistency_mask")
         nz = [None if t is None else req(t, "noise") for t in (noises or [None] * n)]
@@ -119,7 +119,17 @@ class DrLossStepFn(Function):
             pu_total = torch.empty(1, dtype=torch.float32, device=dev)
             pu_nz = None if pu.get("noise") is None else req(pu["noise"], "pose-update noise")
             a.flags |= L.DR_POSE_UPDATE
-            a.pu_disp_m1, a.pu_disp_p1, a.pu_T_m1, a.pu_T_p1 = (p(t) for t in tens[3 * n:3 * n + 4])
+            # an operand that is one of the iterations' own (pu["into"][k] = that iteration, else None) arrives as None: its
+            # pose-update gradient is added into the iteration's output by the assembly launch, not by autograd afterwards
+            into = pu.get("into") or (None,) * 4
+            ops_ = []
+            for k, base in enumerate((0, 0, n, 2 * n)):
+                t = tens[3 * n + k]
+                if (t is None) != (into[k] is not None):
+                    raise L.MalError("DrLossStepFn: a pose-update operand is either a leaf of its own or one of the iterations'")
+                ops_.append(tens[base + into[k]] if t is None else t)
+            a.pu_disp_m1, a.pu_disp_p1, a.pu_T_m1, a.pu_T_p1 = (p(t) for t in ops_)
+            a.pu_disp_m1_into, a.pu_disp_p1_into, a.pu_T_m1_into, a.pu_T_p1_into = (0 if i is None else i + 1 for i in into)
             a.pu_noise, a.pu_loss_total = p(pu_nz), p(pu_total)
         ws = _dr_workspace(dev, B, H, W, n, slot=int(scale))
         a.ws, a.ws_bytes, a.stream = p(ws), ws.numel(), ops._stream()
@@ -152,7 +162,7 @@ class DrLossStepFn(Function):
         zero = lambda g: torch.zeros(1, dtype=torch.float32, device=tens[0].device) if g is None else g.reshape(1).contiguous()
         g_total = zero(g_total)
         a = ctx.args
-        grads = [torch.empty_like(t) if ctx.needs_input_grad[2 + i] else None for i, t in enumerate(tens)]
+        grads = [torch.empty_like(t) if (t is not None and ctx.needs_input_grad[2 + i]) else None for i, t in enumerate(tens)]
         a.g_total = ops._p(g_total)
         if ctx.pu:
             g_pu = zero(g_pu)
@@ -404,10 +414,18 @@ class DualRefineLossPath:
                 # frame -1: the refined pose paired with the last iteration's depth -- or iteration 0's, detached (:463-469);
                 # frame +1: ("color", 1, 0, 0), i.e. iteration 0's depth under ("cam_T_cam", 0, 1) with its graph (:420-423)
                 d_m1 = outputs[("disp", 0, 0)].detach() if opt.Tstar_D0_pair else outputs[("disp", 0, opt.n_losses)]
-                pu_leaves = (d_m1, outputs[("disp", 0, 0)], outputs[("cam_T_cam", 0, -1, 1)], outputs[("cam_T_cam", 0, 1)])
+                pu_leaves = [d_m1, outputs[("disp", 0, 0)], outputs[("cam_T_cam", 0, -1, 1)], outputs[("cam_T_cam", 0, 1)]]
                 if philox is not None and pose_noise is not None:
                     raise L.MalError("loss_step: pose_noise given while the other maps are drawn in the kernels (pass `noises` too)")
-                pu = {"noise": None if opt.disable_automasking else pose_noise}
+                # upstream's default pairing re-uses the iterations' own tensors (the last disparity, the refined pose, frame
+                # +1's pose of iteration 0): their pose-update gradients then join the iteration's inside the assembly launch
+                into = []
+                for k, own in enumerate((disps, disps, T_m1, T_p1)):
+                    hit = [i for i, t in enumerate(own) if t is pu_leaves[k]]
+                    into.append(hit[0] if hit else None)
+                    if hit:
+                        pu_leaves[k] = None
+                pu = {"noise": None if opt.disable_automasking else pose_noise, "into": tuple(into)}
             cfg = (opt.min_depth, opt.max_depth, opt.disparity_smoothness / (2 ** scale), flags, n, philox, scale, first_ws,
                    bool(want_decisions), pu)
             tot_s, pu_s, v, ws_s, *decs_s = DrLossStepFn.apply(consts, cfg, *disps, *T_m1, *T_p1, *pu_leaves)

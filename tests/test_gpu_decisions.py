@@ -757,7 +757,8 @@ def test_dualrefine_pose_update_losses_in_the_one_call_step(shape, kw_extra):
     ref, _, oin, oout = _dr_oracle_pu(batch, kw, noises, nz_pose)
     assert set(got_l) == set(ref), (sorted(got_l), sorted(ref))
     for k, v in ref.items():
-        assert abs(got_l[k] - float(v)) <= 1e-4 * abs(float(v)) + 1e-6 + 6.0 / N, (k, got_l[k], float(v))
+        v = float(v.detach())
+        assert abs(got_l[k] - v) <= 1e-4 * abs(v) + 1e-6 + 6.0 / N, (k, got_l[k], v)
     mine = AR.taps_of(oout[("sample", -1, 0, 0, 1)], H, W, align_corners=False)
     diff = None
     for u, v in zip(fpose["taps"][-1], mine):
@@ -854,6 +855,47 @@ def test_dualrefine_step_in_kernel_noise_equals_the_same_noise_handed_in():
             assert int(ctr.item()) == c0 + 1
             res.append((float(got["loss"].detach()), {k: t.grad.clone() for k, t in gl.items() if t.grad is not None}))
         assert res[0][0] == res[1][0]
+        for k, g in res[0][1].items():
+            assert torch.equal(g, res[1][1][k]), k
+    finally:
+        config.noise_source, config.noise_seed = old
+
+
+def test_dualrefine_pose_update_in_kernel_noise_equals_the_same_noise_handed_in():
+    """MAL_DR_NOISE_PHILOX with MAL_DR_POSE_UPDATE: the pose-update pass's map is mal_tiebreak_noise(seed ^ MAL_DR_POSE_NOISE_KEY,
+    step * MAL_DR_MAX_ITERS) -- a draw of its own (upstream: another torch.randn, dualrefine/trainer.py:744-746), reproducible;
+    the step handed the maps agrees with the step that draws them to the bit."""
+    import ctypes as C
+    from mal_amd import _lib, config, dualrefine, layers, ops, step
+    from mal_amd.synthetic import make_batch
+    B, H, W = 2, 40, 72
+    batch = make_batch(B, H, W, seed=12)
+    old = config.noise_source, config.noise_seed
+    config.noise_source, config.noise_seed = "philox", 778
+    try:
+        ctr = step.noise_counter(torch.device("cuda:0"))
+        c0 = int(ctr.item())
+        res = []
+        for mode in ("drawn", "same"):
+            noises = pose_noise = None
+            if mode == "same":
+                def draw(seed, st):
+                    out = torch.empty(B, 1, H, W, device="cuda:0")
+                    _lib.check(_lib.load().mal_tiebreak_noise(C.c_uint64(seed), C.c_uint64(st), B, H, W, out.data_ptr(), ops._stream()),
+                               "mal_tiebreak_noise")
+                    return out
+                noises = [draw(778, c0 * _lib.DR_MAX_ITERS + it) for it in range(2)]
+                pose_noise = draw(778 ^ _lib.DR_POSE_NOISE_KEY, c0 * _lib.DR_MAX_ITERS)
+                assert not torch.equal(pose_noise, noises[0])
+            inputs, outputs, gl = _dr_build_pu(batch, "cuda:0", layers.transformation_from_parameters)
+            lp = dualrefine.DualRefineLossPath(dualrefine.default_options(height=H, width=W, batch_size=B, n_losses=1,
+                                                                          disable_pose_updates=False), fuse=True)
+            got = lp.loss_step(inputs, outputs, noises=noises, pose_noise=pose_noise)
+            got["loss"].backward()
+            torch.cuda.synchronize()
+            assert int(ctr.item()) == c0 + 1  # the drawing step advanced it once; the step handed its maps leaves it
+            res.append(({k: float(v.detach()) for k, v in got.items()}, {k: t.grad.clone() for k, t in gl.items() if t.grad is not None}))
+        assert res[0][0] == res[1][0], (res[0][0], res[1][0])
         for k, g in res[0][1].items():
             assert torch.equal(g, res[1][1][k]), k
     finally:
