@@ -3,9 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/mal_hip.h"
 
 namespace mal {
+// A process-wide option (mal_set_option): written under a mutex, read by the launch functions of any thread -- an atomic, so
+// that a concurrent mal_set_option is a defined (if ill-advised) thing to do.  They are same-box A/B switches, not per-call
+// state: set them before the first launch (a step reads some of them in both of its calls).
+typedef std::atomic<int> opt_t;
 
 // tile geometry of the fused / photometric kernels: 64x16 output pixels per 256-thread
 // workgroup; one wave owns one 64-pixel row segment per step, so every global access of the

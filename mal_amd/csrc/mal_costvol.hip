@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void costvol_finish_kernel(CostVolParams p) {
 
 using namespace mal;
 
-namespace mal { int g_costvol_impl = 1; }  // 1 = planar features, lane = pixel (default); 0 = channel-last, lane = channel
+namespace mal { opt_t g_costvol_impl{1}; }  // 1 = planar features, lane = pixel (default); 0 = channel-last, lane = channel
 
 extern "C" int mal_costvol_channel_last(void) { return g_costvol_impl == 0; }
 

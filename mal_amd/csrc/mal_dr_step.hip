@@ -24,7 +24,7 @@
 
 namespace mal {
 
-extern int g_march_halo1;  // mal_step.hip
+extern opt_t g_march_halo1;  // mal_step.hip
 int smooth_march_sweep_batch(int n, const float* const* disp, const float* const* img, int B, const int* H, const int* W,
                              float* const* gn, double* const* partial, hipStream_t st, int* per_sample);
 

@@ -21,8 +21,8 @@ constexpr int kEpiMaxLevels = 4;
 #define MAL_EPI_G 3  // 2-3: 0.70 ms, 4: 0.77, 6: 0.73 at B=8, 128 channels, 48x160, 51 hypotheses
 #endif
 constexpr int kEpiG = MAL_EPI_G;  // hypotheses per wavefront
-int g_epi_bwd_planes = 2;  // 2: two channel planes per workgroup where they fit (round 4); 1: one (round 3); 0: global atomics
-int g_epi_probe = 0;  // option "epi_probe": timing experiments of the plane kernel (wrong results), see EpiSampleBwdParams::probe         // option "epi_bwd_planes": 0 = the global-atomic scatter everywhere (A/B)
+opt_t g_epi_bwd_planes{2};  // 2: two channel planes per workgroup where they fit (round 4); 1: one (round 3); 0: global atomics
+opt_t g_epi_probe{0};  // option "epi_probe": timing experiments of the plane kernel (wrong results), see EpiSampleBwdParams::probe         // option "epi_bwd_planes": 0 = the global-atomic scatter everywhere (A/B)
 
 struct EpiCoordParams {
   const float* depth; const float* poses; const float* K;

@@ -1520,27 +1520,27 @@ __global__ __launch_bounds__(64, 3) void pack_identity_kernel(IdentParams p) {
   }
 }
 
-int g_pass_impl = 1;   // 1 = marching (this file, fastest); 0 = LDS-tiled v1 (mal_pass.hip); 2 = LDS-tiled, 512 threads (mal_tile2.hip)
-extern int g_costvol_impl;  // mal_costvol.hip
-int g_march_flip = 1;  // odd segments bottom-up (mal_set_option("march_flip", 0|1))
-int g_march_rows = 0;  // output rows per wave task; 0 = pick so that one round of tasks fills the chip
-int g_pack_rows = 10;  // rows per task of the identity / packing sweep: 20 segments x 11 strips x 12 samples = 2640 tasks <= 3072 (three waves per SIMD); same-box steps, round 3: 10: 0.2010 / 0.3270 ms (--distil / headline), 9: 0.2019 / 0.3290, 11: 0.2043 / 0.3291, 12: 0.329 (headline)
-int g_march_rows_fwd = 0;  // the same for the forward-only passes (<= 168 VGPRs: three waves per SIMD); 0 = automatic
-int g_debug = 0;
+opt_t g_pass_impl{1};   // 1 = marching (this file, fastest); 0 = LDS-tiled v1 (mal_pass.hip); 2 = LDS-tiled, 512 threads (mal_tile2.hip)
+extern opt_t g_costvol_impl;  // mal_costvol.hip
+opt_t g_march_flip{1};  // odd segments bottom-up (mal_set_option("march_flip", 0|1))
+opt_t g_march_rows{0};  // output rows per wave task; 0 = pick so that one round of tasks fills the chip
+opt_t g_pack_rows{10};  // rows per task of the identity / packing sweep: 20 segments x 11 strips x 12 samples = 2640 tasks <= 3072 (three waves per SIMD); same-box steps, round 3: 10: 0.2010 / 0.3270 ms (--distil / headline), 9: 0.2019 / 0.3290, 11: 0.2043 / 0.3291, 12: 0.329 (headline)
+opt_t g_march_rows_fwd{0};  // the same for the forward-only passes (<= 168 VGPRs: three waves per SIMD); 0 = automatic
+opt_t g_debug{0};
 std::atomic<unsigned*> g_dec_next{nullptr};  // mal_decisions_next_pass (one-shot, taken with an atomic exchange): decision planes for the next instrumentable gradient pass
-extern int g_photo_impl;  // mal_photo_march.hip
-extern int g_epi_bwd_planes;  // mal_epipolar.hip
-extern int g_epi_probe;       // mal_epipolar.hip
-extern int g_syn_rows;        // mal_photo_march.hip
-extern int g_syn_queue;       // mal_photo_march.hip
-extern int g_step_overlap;    // mal_step.hip
-extern int g_student_overlap; // mal_step.hip
-extern int g_side_priority;   // mal_step.hip
-extern int g_side_order;      // mal_step.hip
-extern int g_march_halo1;     // mal_step.hip
-extern int g_temporal_spec;   // mal_step.hip
-int g_march_lean = 1;         // option "march_lean": the teacher's passes without the optional operands' code (0: generic, A/B)
-int g_march3 = 0;             // option "march3": the teacher's gradient pass as a three-wave pipeline (0: one wave per strip)
+extern opt_t g_photo_impl;  // mal_photo_march.hip
+extern opt_t g_epi_bwd_planes;  // mal_epipolar.hip
+extern opt_t g_epi_probe;       // mal_epipolar.hip
+extern opt_t g_syn_rows;        // mal_photo_march.hip
+extern opt_t g_syn_queue;       // mal_photo_march.hip
+extern opt_t g_step_overlap;    // mal_step.hip
+extern opt_t g_student_overlap; // mal_step.hip
+extern opt_t g_side_priority;   // mal_step.hip
+extern opt_t g_side_order;      // mal_step.hip
+extern opt_t g_march_halo1;     // mal_step.hip
+extern opt_t g_temporal_spec;   // mal_step.hip
+opt_t g_march_lean{1};         // option "march_lean": the teacher's passes without the optional operands' code (0: generic, A/B)
+opt_t g_march3{0};             // option "march3": the teacher's gradient pass as a three-wave pipeline (0: one wave per strip)
 
 MarchParams march_params(int B, int H, int W, float min_depth, float max_depth, float eps, int convention) {
   MarchParams p = {};

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void reproj_bwd_kernel(const float* pred, cons
 
 // ---------------------------------------------------------------- photo fwd / bwd
 // marching formulation (mal_photo_march.hip), the default for SSIM + min
-extern int g_photo_impl;
+extern opt_t g_photo_impl;
 int photo_march_fwd(const float* target, const float* const* cand, int n_cand, const float* ident, const float* noise,
                     const float* ext_mask, int B, int H, int W, int automask, float* min_reproj, uint8_t* argmin,
                     float* weight_out, double* block_sums, int* ntasks_out, hipStream_t st);

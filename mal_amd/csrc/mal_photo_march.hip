@@ -659,7 +659,7 @@ int smooth_march(const float* disp, const float* img, int B, int H, int W, int n
   return launch_status();
 }
 
-int g_photo_impl = 1;  // 1 = marching kernels of this file; 0 = one-pixel-per-thread kernels of mal_photo.hip
+opt_t g_photo_impl{1};  // 1 = marching kernels of this file; 0 = one-pixel-per-thread kernels of mal_photo.hip
 
 static int device_slots() {
   static int slots = 0;
@@ -675,8 +675,8 @@ static int device_slots() {
 // MI355X (B=12 192x640, 19 % of the 4-row tasks active): the sweep itself 33.8 -> 21.3 us, but the classification launch
 // costs 76 us (6336 atomics on two addresses) and even a free one would gain ~6 us: the sweep runs beside the ensemble
 // pass, which then waits for the wave slots the expensive tasks hold from the start (0.347 -> 0.417 ms per step).  Off.
-int g_syn_queue = 0;
-int g_syn_rows = 4;  // option "syn_rows": rows per task of the fused sweep when a region map makes most tasks leave early
+opt_t g_syn_queue{0};
+opt_t g_syn_rows{4};  // option "syn_rows": rows per task of the fused sweep when a region map makes most tasks leave early
 static void decompose(PhotoMarchParams& p, int cw, int waves_per_simd, int rows_min = 8) {
   p.strips = (p.W + cw - 1) / cw;
   int rows = rows_min;

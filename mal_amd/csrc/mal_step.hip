@@ -573,7 +573,7 @@ static int first_sweep(const mal_step_args* a, const StepWs& w, hipStream_t st, 
                               tex ? nullptr : w.packed[0], w.ident, st, &sp, &tn, &sm, per_sample_p, tex);
 }
 
-namespace mal { int g_march_halo1 = 1; }   // option "march_halo1": one-row halo of the step's gradient passes (0: two rows, A/B)
+namespace mal { opt_t g_march_halo1{1}; }   // option "march_halo1": one-row halo of the step's gradient passes (0: two rows, A/B)
 
 static MarchParams teacher_params(const mal_step_args* a, const StepWs& w, float* mono_reproj) {
   MarchParams p = march_params(a->B, a->H, a->W, a->min_depth, a->max_depth, 1e-7f, 0);
@@ -680,11 +680,11 @@ static EpiParams epilogue_params(const mal_step_args* a, const StepWs& w, const 
 // (and whatever the segmenter does) -- the ensemble pass depends on none of it.  It is forked onto a side stream AFTER the
 // warp pass (beside it, two ALU-bound passes only slow each other down: measured) and joined before the student pass,
 // which reads its map.  Fork / join through events: capturable into the caller's HIP graph.
-namespace mal { int g_step_overlap = 1; }  // option "step_overlap"
+namespace mal { opt_t g_step_overlap{1}; }  // option "step_overlap"
 // option "temporal_spec" (--temporal step): 1 = the pass in front of the producer is the teacher's GRADIENT pass (it
 // exports the warped images as well) and the sweep after the producer's backward only corrects the tasks near the region
 // map; 0 = forward-only pass in front, full gradient sweep behind (rounds 2-3, kept for same-box A/B)
-namespace mal { int g_temporal_spec = 0; }  // settable in -DMAL_EXPERIMENTS builds only (mal_set_option refuses it otherwise)
+namespace mal { opt_t g_temporal_spec{0}; }  // settable in -DMAL_EXPERIMENTS builds only (mal_set_option refuses it otherwise)
 // One side stream (with its fork / join events) per (device, caller stream): two steps in flight on different streams of a
 // device -- each with its own workspace -- then cannot consume or overwrite each other's pending join (round 3 kept one
 // `pending` flag per device: step B's _warp cleared A's, and B's _fwd could return without waiting for its own ensemble
@@ -694,7 +694,7 @@ namespace mal { int g_temporal_spec = 0; }  // settable in -DMAL_EXPERIMENTS bui
 // launches themselves are the caller's (one thread per stream, as for every HIP stream).
 // option "side_priority": 1 = the side stream is created with the device's LOWEST priority.  Measured: every kernel of the
 // replayed step slows down -- 0.566 ms per step against 0.323 (profiles/r04_step_timelines.txt) --, so the default stays 0.
-namespace mal { int g_side_priority = 0; }
+namespace mal { opt_t g_side_priority{0}; }
 struct SideStream { hipStream_t caller; hipStream_t s; hipEvent_t fork, join, mid; bool ok, init, pending; int dev; };
 static SideStream* side_stream(hipStream_t caller) {
   constexpr int kSlots = 64;
@@ -764,7 +764,7 @@ int side_wait(hipStream_t st, bool always) { return join_side(st, always); }
 }
 // what is forked beside the producer: the ensemble pass (unless --no_ens) and, with option "student_overlap" (default), the
 // student's marching pass without its epilogue
-namespace mal { int g_student_overlap = 1; int g_side_order = 0; }  // side_order 1 (student first) measured slower: 0.3265 vs 0.3200 ms -- the producer's small kernels starve beside a pass that holds every wave slot and all of the LDS
+namespace mal { opt_t g_student_overlap{1}; opt_t g_side_order{0}; }  // side_order 1 (student first) measured slower: 0.3265 vs 0.3200 ms -- the producer's small kernels starve beside a pass that holds every wave slot and all of the LDS
 static bool side_forked(const mal_step_args* a) {
   return g_step_overlap && (a->flags & (MAL_STEP_TEMPORAL | MAL_STEP_MAIN_TEMPORAL)) && side_stream((hipStream_t)a->stream) != nullptr;
 }

@@ -18,7 +18,7 @@
 #include "mal_pose.h"
 
 namespace mal {
-extern int g_march_halo1;  // mal_step.hip
+extern opt_t g_march_halo1;  // mal_step.hip
 
 // mal_photo_march.hip / mal_step.hip
 int smooth_march_sweep_batch(int n, const float* const* disp, const float* const* img, int B, const int* H, const int* W,
