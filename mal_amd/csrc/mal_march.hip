@@ -155,7 +155,6 @@ struct PendingWarp {
   f2 ex, ey, tx, ty;           // DERIV
   f2 mx, my, du_ddisp, dv_ddisp;
   f2 u, v, rz;                 // POSE: the projection, kept for the pose terms of the gradient row
-  unsigned off[2][4];          // DEFER: byte offsets of the taps inside the sample's texel image (the caller issues the gathers)
 };
 
 // the parameter-block fields the warp needs, read together at the top of an iteration (one scalar-load wait)
@@ -176,12 +175,10 @@ MAL_DEV void dec_store(unsigned* dbg, unsigned n, int plane, unsigned boff, unsi
 // offsets of the four taps are formed in fp32 -- every product and sum below 2^24 is exact -- instead of with 32-bit integer
 // multiplies (v_mul_lo_u32 is quarter rate: the compiler does not keep __umul24 for operands it cannot bound)
 // FRAMED: frame 1's candidate is warped with its own disparity, dispv1 (frame 0's with dispv)
-// DEFER (LEAN only): the gathers are NOT issued here -- their offsets are left in w.off for the caller to place
-template <bool DERIV, bool POSE, bool DBG, bool LEAN, bool FRAMED = false, bool DEFER = false, class BeforeGathers>
+template <bool DERIV, bool POSE, bool DBG, bool LEAN, bool FRAMED = false, class BeforeGathers>
 MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik)[9], int b, int gyr, int gxr,
                         float dispv, PendingWarp& w, BeforeGathers before_gathers, float dispv1 = 0.f) {
   static_assert(!FRAMED || (POSE && !LEAN), "FRAMED: pose variants of the generic passes only");
-  static_assert(!DEFER || LEAN, "DEFER: the specialised passes only");
   const int W = p.W, H = p.H, HW = H * W, pix = gyr * W + gxr;
   const float depth = depth_of(dispv, p.min_disp, p.range);
   float ray[3], X[3];
@@ -225,10 +222,7 @@ MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int (&o)[4] = oo[f];
-    if (LEAN && DEFER) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) w.off[f][k] = bo12[f][k];
-    } else if (LEAN) {
+    if (LEAN) {
       const float* sp = p.src[f] + (size_t)b * HW * kTexel;
 #pragma unroll
       for (int k = 0; k < 4; ++k) w.t[f][k] = ldt(sp, bo12[f][k]);
@@ -360,20 +354,6 @@ MAL_DEV void march_body() {
   constexpr int CONV = -1;
 #endif
   constexpr bool OUTS = EXPORT || (!GRAD && !EPI);  // the outputs the producer / the fused sweep read
-  // PIPE (round 5; the forward-only passes without epilogue: the ensemble pass, the pass in front of the temporal hint's
-  // producer): the eight gathers of row r+1 are issued in iteration r, right after row r's blend -- they have the rest of the
-  // iteration to arrive instead of being waited for a few instructions after their issue.  These passes hold ~145 VGPRs and
-  // run at two waves per SIMD anyway (1980 tasks on 2048 slots), so the second set of tap weights is free; the gradient
-  // passes (251 VGPRs) cannot afford it.  -DMAL_FWD_PIPE=0: the round-4 loop (A/B).
-#ifndef MAL_FWD_PIPE
-#define MAL_FWD_PIPE 0
-#endif
-  constexpr bool PIPE = MAL_FWD_PIPE && !GRAD && !EPI && !DBG;
-  // SPREAD (MAL_FWD_PIPE 2, the specialised forward passes): the eight gathers of row r+1 are not issued in one burst behind
-  // the projection but one by one between the stages of iteration r.  Every wave of a pass starts at the same time and runs
-  // the same code, so bursts arrive at the CU's one address unit together (8 waves x 9 x ~32 cycles) while the vector ALU
-  // idles, and then all waves compute while the address unit idles; spreading the gathers lets the two overlap.
-  constexpr bool SPREAD = PIPE && LEAN && MAL_FWD_PIPE >= 2;
   constexpr int HALO = GRAD ? 2 : 1;
   constexpr int CW = 64 - 2 * HALO;
   // The ~30 pointers and sizes of the parameter block do not fit in scalar registers next to the loop
@@ -598,7 +578,7 @@ MAL_DEV void march_body() {
     // of the sample instead (a valid address, L2-resident) and the value is dropped.
     const bool packed_t = (pp.packed & 2) != 0;
     const unsigned pix = (unsigned)(prow(row_of(rr)) * W + gxr);
-    const unsigned od = moff(row_of(PIPE ? rr + 1 : rr));  // PIPE: iteration rr projects (and gathers for) row rr + 1
+    const unsigned od = moff(row_of(rr));
     a.disp = ldf(disp_b, od);
     a.disp2 = 0.f;
     if (!NO_DISP2) {
@@ -863,28 +843,6 @@ MAL_DEV void march_body() {
     }
   }
   };
-  // the fields of the parameter block the warp reads (DBG members: per iteration, below)
-  auto warp_consts = [&](CParams& p, const Maps& mp) __attribute__((always_inline)) {
-    WarpConsts wc;
-    wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = mp.packed; wc.debug = LEAN ? 0 : p.debug; wc.W = W; wc.H = H;
-    wc.convention = CONV >= 0 ? CONV : p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
-    wc.rw = norm_rw; wc.rh = norm_rh;
-    wc.dbg = DBG ? p.dbg : nullptr; wc.dbg_n = (unsigned)(p.B * HW);
-    wc.dbg_off = 0; wc.dbg_on = false;
-    return wc;
-  };
-  PendingWarp pw_ahead;  // PIPE: the taps of the row the NEXT iteration blends
-  if (PIPE) {            // ... of the first row: issued here (its disparity is the one load of the task that is waited for at once)
-    const Maps mp = maps_of(p);
-    const WarpConsts wc = warp_consts(p, mp);
-    f2 P[12];
-    float ik[9];
-    load_cam(cam_b, P, ik);
-    const unsigned od = moff(row_of(r_first));
-    float d0 = ldf(disp_b, od);
-    if (!NO_DISP2 && disp2_b) d0 = (d0 + ldf(disp2_b, od)) / 2.0f;
-    warp_issue<false, false, false, false>(wc, P, ik, b, prow(row_of(r_first)), gxr, d0, pw_ahead, []() {});
-  }
   for (int r = r_first; r <= r_warp_last; ++r, ++it) {
     CParams* kp = kp0;
     asm volatile("" : "+s"(kp));
@@ -895,7 +853,12 @@ MAL_DEV void march_body() {
     const bool has_noise = mp.noise != nullptr, has_ext = EXT_YES || mp.ext_mask != nullptr,
                has_cost = COST_YES || mp.lowest_cost != nullptr, has_mdisp = MONO_YES || mp.mono_disp != nullptr,
                has_er = mp.ens_reproj != nullptr;
-    WarpConsts wc = warp_consts(p, mp);
+    WarpConsts wc;
+    wc.src[0] = p.src[0]; wc.src[1] = p.src[1]; wc.packed = mp.packed; wc.debug = LEAN ? 0 : p.debug; wc.W = W; wc.H = H;
+    wc.convention = CONV >= 0 ? CONV : p.convention; wc.min_disp = p.min_disp; wc.range = p.range; wc.eps = p.eps;
+    wc.rw = norm_rw; wc.rh = norm_rh;
+    wc.dbg = DBG ? p.dbg : nullptr; wc.dbg_n = (unsigned)(p.B * HW);
+    wc.dbg_off = 0; wc.dbg_on = false;
     if (DBG) { wc.dbg_on = r >= y_lo && r < y_hi && out_x; wc.dbg_off = moff(row_of(r)); }
 #ifdef MAL_STAGE_TIMERS
     auto tick = [&](int i) {
@@ -913,20 +876,15 @@ MAL_DEV void march_body() {
     const float le_disp = GRAD ? dv_2 : dv_1;  // the epilogue row's own disparity (rows r-2 / r-1 of this sweep)
     const float le_mono = cur.e_mono, le_mr = cur.e_mr, le_er = cur.e_er;
     // ================= stage W: warp row r (reflected if outside the image) ==================
-    const int gyr = prow(row_of(PIPE ? r + 1 : r));  // physical row: addresses and the ray (PIPE: of the row gathered for, r + 1)
+    const int gyr = prow(row_of(r));  // physical row: addresses and the ray
     WarpRow w0;
     const float dv_ = (!FRAMED && disp2_b) ? (cur.disp + cur.disp2) / 2.0f : cur.disp;
     const float dw_ = FRAMED ? cur.disp2 : 0.f;
     w0.yrg = (f2){cur.y[0], cur.y[1]}; w0.yb = cur.y[2];
     // the issue phase (projection, operand requests, gathers) is what the rest of the iteration waits for:
     // run it at raised wave priority so the sibling wave's arithmetic does not delay it (measured -1.7 %)
-    PendingWarp pw_here;
-    PendingWarp& pw = PIPE ? pw_ahead : pw_here;
-    if (PIPE) {  // row r: its taps were requested one iteration ago; the blend frees their registers for row r + 1's
-      DerivRow d0;
-      warp_finish<false, false>(pw, w0.x, d0);
-    }
     __builtin_amdgcn_s_setprio(3);
+    PendingWarp pw;
     {
       f2 P[12];
       float ik[9];
@@ -936,21 +894,10 @@ MAL_DEV void march_body() {
 #ifdef MAL_TAPS_INT  // A/B: integer tap offsets (round 3) in the specialised passes too
       warp_issue<GRAD, POSE, DBG, false>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); });
 #else
-      warp_issue<GRAD, POSE, DBG, LEAN && !DBG, FRAMED, SPREAD>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); }, dw_);
+      warp_issue<GRAD, POSE, DBG, LEAN && !DBG, FRAMED>(wc, P, ik, b, gyr, gxr, dv_, pw, [&]() { request(mp, r + 1, nxt); }, dw_);
 #endif
     }
     __builtin_amdgcn_s_setprio(0);
-    // SPREAD: tap i (frame i >> 2, corner i & 3) of row r+1, placed by the caller between two stages
-    const float* const tap_src0 = SPREAD ? wc.src[0] + (size_t)b * HW * kTexel : nullptr;
-    const float* const tap_src1 = SPREAD ? wc.src[1] + (size_t)b * HW * kTexel : nullptr;
-    auto taps = [&](int i0, int i1) __attribute__((always_inline)) {
-      if (!SPREAD) return;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = i0; i < i1; ++i) pw.t[i >> 2][i & 3] = ldt((i >> 2) ? tap_src1 : tap_src0, pw.off[i >> 2][i & 3]);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    taps(0, 3);
     tick(1); MAL_MARK(1);  // small loads, prefetch, projection, gathers issued
     // ---- in the shadow of the gathers (see SHADOW above)
     f2 sh_hy[2] = {bc(0.f), bc(0.f)}, sh_l15 = bc(0.f);
@@ -1003,7 +950,7 @@ MAL_DEV void march_body() {
 
     if (EPI && GRAD) epilogue(p, r, pi1, le_disp, le_mono, le_mr, le_er, so_c, so_q, has_mdisp, has_er, cur.e_ensd);
     tick(2); MAL_MARK(2);  // epilogue terms
-    if (!PIPE) finish_warp();
+    finish_warp();
     tick(3); MAL_MARK(3);  // gather wait, blend, ring write
     if (OUTS) {  // the pass in front of the temporal-hint producer: the warped images, planar
       float* const c0 = p.color_out[0];
@@ -1027,7 +974,6 @@ MAL_DEV void march_body() {
       }
     }
 
-    taps(3, 6);
     // ================= stage H: horizontal 3-sums of row r ====================================
     f2 h[9], hy[2];
     float hz[2];
@@ -1097,7 +1043,6 @@ MAL_DEV void march_body() {
     }
 
     tick(4); MAL_MARK(4);  // horizontal sums
-    taps(6, 8);  // (the statistics stage below is a wave-uniform branch: no loads inside it)
     // ================= stage S: statistics of centre row c = r-1 ==============================
     const int c = r - 1;
     const bool c_valid = c >= 0 && c < H && c >= y_lo - (HALO - 1) + h1e && c <= y_hi - 1 + (HALO - 1) - h1e;
@@ -1345,16 +1290,6 @@ __global__ __launch_bounds__(64, 2) void march_student_temporal_kernel(MarchPara
 // DualRefine's passes of the deq iterations > 0: teacher-style pass (automask, pose gradients) with the consistency epilogue
 __global__ __launch_bounds__(64, 2) void march_refine_kernel(MarchParams p_kernarg) {
   march_body<true, true, true, true, false, false, false, kSpecRefine>();
-}
-// The forward-only passes of the whole-step lists (round 5): the ensemble pass (no automask; the averaged disparity is formed
-// from two maps) and the pass in front of the temporal hint's producer (automask, exports).  The generic instantiations carry
-// BOTH load paths of every image operand (texels / planes, decided per launch) and the compiler waits for memory between them
-// -- three full round trips per row (the target texel, the taps of frame 0, the taps of frame 1); with the layout known at
-// compile time there is one path, and with PIPE (march_body) the taps are requested a whole iteration ahead.
-template <bool AUTOMASK>
-__global__ __launch_bounds__(64, 2) void march_forward_kernel(MarchParams p_kernarg) {
-  march_body<false, AUTOMASK, false, false, false, false, false,
-             kSpecLean | kSpecExtNo | kSpecCostNo | kSpecNoScale | kSpecConvA | (AUTOMASK ? kSpecNoDisp2 : 0)>();
 }
 // DualRefine's pose-update losses (dualrefine/trainer.py:457-480,699-767): teacher-style pass whose two candidates are warped
 // with two different disparities (MarchParams::framed)
@@ -1604,7 +1539,6 @@ extern opt_t g_side_priority;   // mal_step.hip
 extern opt_t g_side_order;      // mal_step.hip
 extern opt_t g_march_halo1;     // mal_step.hip
 extern opt_t g_temporal_spec;   // mal_step.hip
-opt_t g_fwd_lean{0};           // option "fwd_lean": the forward-only passes of the whole-step lists as march_forward_kernel (0: generic, A/B)
 opt_t g_march_lean{1};         // option "march_lean": the teacher's passes without the optional operands' code (0: generic, A/B)
 opt_t g_march3{0};             // option "march3": the teacher's gradient pass as a three-wave pipeline (0: one wave per strip)
 
@@ -1754,9 +1688,6 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
     hipLaunchKernelGGL(march_student_kernel<kSpecStudentNoCost>, grid, block, 0, st, p);
   } else if (lean_refine && grad && pose && automask && epi && !p.forced_w) {
     hipLaunchKernelGGL(march_refine_kernel, grid, block, 0, st, p);
-  } else if (!grad && !epi && lean0 && conv_a && no_maps && !(automask && p.disp2) && g_fwd_lean) {
-    if (automask) hipLaunchKernelGGL(march_forward_kernel<true>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(march_forward_kernel<false>, grid, block, 0, st, p);
   } else if (!grad) {
     if (automask) { if (epi) MAL_LAUNCH(false, true, false, true); else MAL_LAUNCH(false, true, false, false); }
     else          { if (epi) MAL_LAUNCH(false, false, false, true); else MAL_LAUNCH(false, false, false, false); }
@@ -1847,8 +1778,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("debug")) { g_debug = value; return MAL_OK; }
   if (eq("photo_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_photo_impl = value; return MAL_OK; }
   if (eq("costvol_impl")) { if (value < 0 || value > 1) return MAL_EINVAL; g_costvol_impl = value; return MAL_OK; }
-  if (eq("fwd_lean")) { g_fwd_lean = value != 0; return MAL_OK; }
-  if (eq("step_overlap")) { if (value < 0 || value > 3) return MAL_EINVAL; g_step_overlap = value; return MAL_OK; }
+  if (eq("step_overlap")) { if (value < 0 || value > 2) return MAL_EINVAL; g_step_overlap = value; return MAL_OK; }
   if (eq("march_halo1")) { g_march_halo1 = value != 0; return MAL_OK; }
   if (eq("student_overlap")) { g_student_overlap = value != 0; return MAL_OK; }
   if (eq("side_order")) { g_side_order = value != 0; return MAL_OK; }

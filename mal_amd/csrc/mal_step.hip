@@ -781,12 +781,10 @@ static bool student_warp_forked(const mal_step_args* a) {
   return side_forked(a) && g_step_overlap == 1 && (a->flags & MAL_STEP_TEMPORAL) && (a->flags & MAL_STEP_MAIN_TEMPORAL);
 }
 
-// `record` false (option "step_overlap" 3): the fork event was recorded earlier -- behind the warp pass, by mal_loss_step_warp --
-// and only the launches are enqueued now
-static int fork_ensemble(const mal_step_args* a, const StepWs& w, hipStream_t st, bool record = true) {
+static int fork_ensemble(const mal_step_args* a, const StepWs& w, hipStream_t st) {
   SideStream* ss = side_stream(st);
   if (!ss) return MAL_ELAUNCH;
-  if ((record && hipEventRecord(ss->fork, st) != hipSuccess) || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return MAL_ELAUNCH;
+  if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return MAL_ELAUNCH;
   int rc = MAL_OK;
   if (student_warp_forked(a)) {
     rc = launch_student_warp(a, w, ss->s);
@@ -871,13 +869,6 @@ extern "C" int mal_loss_step_warp(const mal_step_args* a) {
     rc = fork_ensemble(a, w, st);
     if (rc) return rc;
   }
-  if (g_step_overlap == 3 && ensemble_forked(a)) {
-    // option "step_overlap" 3: the ensemble pass depends on what precedes THIS point, but is enqueued by mal_loss_step_fwd --
-    // behind the producer's kernels in enqueue order, so that in a captured graph the producer chain is the warp pass's first
-    // successor (the graph runtime keeps a node's first successor on its queue and the rest pay a cross-queue wake-up)
-    SideStream* ss = side_stream(st);
-    if (!ss || hipEventRecord(ss->fork, st) != hipSuccess) return MAL_ELAUNCH;
-  }
   return MAL_OK;
 }
 
@@ -901,8 +892,8 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     march_geometry(B, H, W, temporal && !g_temporal_spec ? 0 : MAL_F_GRAD, &strips, &segs, nullptr);
     per_sample_t = strips * segs;
   }
-  if (hinted && ensemble_forked(a) && g_step_overlap >= 2) {  // option "step_overlap" 2: the ensemble pass beside the sweeps of this call
-    rc = fork_ensemble(a, w, st, g_step_overlap == 2);          // (3: forked behind the warp pass, enqueued here)
+  if (hinted && ensemble_forked(a) && g_step_overlap == 2) {  // option "step_overlap" 2: the ensemble pass beside the sweeps of this call
+    rc = fork_ensemble(a, w, st);
     if (rc) return rc;
   }
   if (!temporal) {

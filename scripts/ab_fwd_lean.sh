@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the formulations this script compares lost: their code is in commit 1f05471 only -- check that commit out to re-run)
 # A/B: the forward-only passes of the whole-step lists as march_forward_kernel (one load path + taps requested one iteration ahead)
 set -e
 mkdir -p gpurun_out/r05e

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the formulations this script compares lost: their code is in commit 1f05471 only -- check that commit out to re-run)
 # same-box A/B of the forward-only passes' formulations: library variants pipe0 (-DMAL_FWD_PIPE=0, the round-4 loop), pipe1 (taps of
 # row r+1 issued together after row r's blend), default (pipe 2: spread between the stages) x option fwd_lean (0: generic instantiation)
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r05e; mkdir -p $O

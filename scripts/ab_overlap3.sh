@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the formulations this script compares lost: their code is in commit 1f05471 only -- check that commit out to re-run)
 # A/B: option step_overlap 3 (the producer chain as the warp pass's first successor in the captured graph) against the default
 set -e
 mkdir -p gpurun_out/r05e

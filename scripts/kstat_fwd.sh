@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the formulations this script compares lost: their code is in commit 1f05471 only -- check that commit out to re-run)
 set -e
 mkdir -p gpurun_out/r05e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
