@@ -352,6 +352,14 @@ int mal_loss_step_warp(const mal_step_args* args);
  * pass that _warp forked onto the library's side stream back into args->stream (no-op when nothing is pending), so the
  * next step cannot overwrite buffers that pass still reads and a stream capture does not end with unjoined work. */
 int mal_loss_step_abort(const mal_step_args* args);
+/* Option "tail_overlap" (mal_set_option; --temporal steps): call between the step's forward and the producer's backward.
+ * *stream receives the stream the producer's backward is to be enqueued on: the library's side stream -- made to wait for
+ * the fused sweep, the producer of d loss / d syn -- when the option applies, args->stream otherwise.  mal_loss_step_bwd
+ * then runs the teacher's gradient sweep behind it on that stream (beside the epilogue and the reduction of the forward, which
+ * args->stream may still be running) and joins it back in front of the assembly.  _cancel: the caller enqueued nothing there
+ * after all (its producer is not one whose backward can be redirected); the side stream is joined back at once. */
+int mal_loss_step_tail_begin(const mal_step_args* args, void** stream);
+int mal_loss_step_tail_cancel(const mal_step_args* args);
 /* MAL_STEP_MAIN_TEMPORAL: call after mal_loss_step_warp (and after the teacher's producer, with MAL_STEP_TEMPORAL) and BEFORE the
  * student's producer reads warp_s_*: with both hints the student's forward pass runs on the library's side stream beside the
  * teacher's producer chain, and args->stream waits for it here (a no-op when the pass ran on args->stream itself). */

@@ -89,6 +89,8 @@ SIGNATURES = {
     "mal_loss_step_warp": (i32, [vp]),
     "mal_loss_step_student_ready": (i32, [vp]),
     "mal_loss_step_abort": (i32, [vp]),
+    "mal_loss_step_tail_begin": (i32, [vp, vp]),
+    "mal_loss_step_tail_cancel": (i32, [vp]),
     "mal_loss_step_teacher_replay": (i32, [vp, i32]),
     "mal_tiebreak_noise": (i32, [C.c_uint64, C.c_uint64, i32, i32, i32, c_fp, vp]),
     "mal_ms_workspace_bytes": (sz, [i32, i32, i32, i32]),

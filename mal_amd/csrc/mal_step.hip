@@ -695,7 +695,13 @@ namespace mal { opt_t g_temporal_spec{0}; }  // settable in -DMAL_EXPERIMENTS bu
 // option "side_priority": 1 = the side stream is created with the device's LOWEST priority.  Measured: every kernel of the
 // replayed step slows down -- 0.566 ms per step against 0.323 (profiles/r04_step_timelines.txt) --, so the default stays 0.
 namespace mal { opt_t g_side_priority{0}; }
-struct SideStream { hipStream_t caller; hipStream_t s; hipEvent_t fork, join, mid; bool ok, init, pending; int dev; };
+// sweep / tail (option "tail_overlap"): `sweep` is recorded on the caller's stream behind the fused sweep of a --temporal step;
+// the producer's backward and the teacher's gradient sweep then run on the side stream behind it -- beside the epilogue and the
+// reduction, which the caller's stream runs meanwhile -- and `tail` joins them back in front of the assembly
+// (Measured, profiles/r05_tail_overlap.txt: a stream of its own for the chain, an anchor kernel behind the sweep that the chain
+// then continues, the assembly on the chain's stream -- the graph runtime places the nodes on hardware queues by its own rules
+// and none of these beat the plain form: the chain on the side stream, the assembly back on the caller's.)
+struct SideStream { hipStream_t caller; hipStream_t s; hipEvent_t fork, join, mid, sweep, tail; bool ok, init, pending, sweep_valid, tail_pending; int dev; };
 static SideStream* side_stream(hipStream_t caller) {
   constexpr int kSlots = 64;
   static SideStream all[kSlots] = {};
@@ -729,7 +735,10 @@ static SideStream* side_stream(hipStream_t caller) {
                                   : hipStreamCreateWithFlags(&slot->s, hipStreamNonBlocking)) == hipSuccess &&
                  hipEventCreateWithFlags(&slot->fork, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&slot->join, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&slot->mid, hipEventDisableTiming) == hipSuccess;
+                 hipEventCreateWithFlags(&slot->mid, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&slot->sweep, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&slot->tail, hipEventDisableTiming) == hipSuccess;
+      slot->sweep_valid = slot->tail_pending = false;
       (void)hipGetLastError();
     }
   if (!slot) slot = first_of_dev;  // table full: share this device's first slot
@@ -738,8 +747,17 @@ static SideStream* side_stream(hipStream_t caller) {
 // the caller's stream waits for the forked ensemble pass; every path that leaves a step after the fork goes through here.
 // `always`: the step KNOWS it forked (mal_loss_step_fwd of a forked step): wait for the slot's last recorded join even if
 // another step that shares the slot has consumed the flag meanwhile.
+// a tail that was begun (mal_loss_step_tail_begin) and never finished by mal_loss_step_bwd: whatever runs on the side stream
+// is joined back, so that nothing of an abandoned backward is left in flight (or outside a stream capture)
+static int join_tail(SideStream* ss, hipStream_t st) {
+  if (!ss || !ss->tail_pending) return MAL_OK;
+  ss->tail_pending = false;
+  if (hipEventRecord(ss->tail, ss->s) != hipSuccess || hipStreamWaitEvent(st, ss->tail, 0) != hipSuccess) return MAL_ELAUNCH;
+  return MAL_OK;
+}
 static int join_side(hipStream_t st, bool always = false) {
   SideStream* ss = side_stream(st);
+  if (ss) { const int rc = join_tail(ss, st); if (rc) return rc; }
   if (!ss || (!ss->pending && !always)) return MAL_OK;
   ss->pending = false;
   return hipStreamWaitEvent(st, ss->join, 0) == hipSuccess ? MAL_OK : MAL_ELAUNCH;
@@ -764,7 +782,35 @@ int side_wait(hipStream_t st, bool always) { return join_side(st, always); }
 }
 // what is forked beside the producer: the ensemble pass (unless --no_ens) and, with option "student_overlap" (default), the
 // student's marching pass without its epilogue
-namespace mal { opt_t g_student_overlap{1}; opt_t g_side_order{0}; }  // side_order 1 (student first) measured slower: 0.3265 vs 0.3200 ms -- the producer's small kernels starve beside a pass that holds every wave slot and all of the LDS
+namespace mal { opt_t g_student_overlap{1}; opt_t g_side_order{0}; }
+// option "tail_overlap": 1 = a --temporal step's backward chain (producer's backward -> teacher's gradient sweep) runs on the
+// library's side stream behind the FUSED SWEEP only, beside the epilogue and the reduction of the forward (in a captured graph
+// the two chains are independent; eager: the same order as before, the side stream simply has nothing to wait for)
+namespace mal { opt_t g_tail_overlap{1}; }
+static bool tail_applies(const mal_step_args* a) {
+  return g_tail_overlap && g_step_overlap == 1 && !g_temporal_spec && (a->flags & MAL_STEP_TEMPORAL) && !(a->flags & MAL_STEP_MAIN_TEMPORAL) &&
+         side_stream((hipStream_t)a->stream) != nullptr;
+}
+// Call between a --temporal step's forward and the producer's backward: *stream receives the stream the producer's backward
+// should be enqueued on -- the library's side stream, made to wait for the fused sweep (the producer of d loss / d syn), when
+// the option applies; args->stream otherwise.  mal_loss_step_bwd then enqueues the teacher's gradient sweep behind it on that
+// stream and joins it back in front of the assembly.  mal_loss_step_tail_cancel: the caller did not use the stream after all.
+extern "C" int mal_loss_step_tail_begin(const mal_step_args* a, void** stream) {
+  if (!a || !stream) return MAL_EINVAL;
+  *stream = a->stream;
+  if (!tail_applies(a)) return MAL_OK;
+  SideStream* ss = side_stream((hipStream_t)a->stream);
+  if (!ss || !ss->sweep_valid || ss->tail_pending) return MAL_OK;
+  if (hipStreamWaitEvent(ss->s, ss->sweep, 0) != hipSuccess) { (void)hipGetLastError(); return MAL_OK; }
+  ss->tail_pending = true;
+  *stream = ss->s;
+  return MAL_OK;
+}
+extern "C" int mal_loss_step_tail_cancel(const mal_step_args* a) {
+  if (!a) return MAL_EINVAL;
+  SideStream* ss = side_stream((hipStream_t)a->stream);
+  return join_tail(ss, (hipStream_t)a->stream);
+}  // side_order 1 (student first) measured slower: 0.3265 vs 0.3200 ms -- the producer's small kernels starve beside a pass that holds every wave slot and all of the LDS
 static bool side_forked(const mal_step_args* a) {
   return g_step_overlap && (a->flags & (MAL_STEP_TEMPORAL | MAL_STEP_MAIN_TEMPORAL)) && side_stream((hipStream_t)a->stream) != nullptr;
 }
@@ -920,6 +966,11 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
                                 sparse ? a->warp_m1 : nullptr, sparse ? a->warp_p1 : nullptr, (size_t)a->warp_sample_stride,
                                 1 /* the target as texels: one 12-byte load instead of three planes */, 0);
     if (rc) { (void)join_side(st); return rc; }
+    if (tail_applies(a)) {  // what the backward chain waits for (mal_loss_step_tail_begin)
+      SideStream* ss = side_stream(st);
+      ss->sweep_valid = ss && hipEventRecord(ss->sweep, st) == hipSuccess;
+      (void)hipGetLastError();
+    }
   }
   int per_sample_sh = 0;
   if (main_t) {
@@ -999,6 +1050,11 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   hipStream_t st = (hipStream_t)a->stream;
   int per_sample_t = 0;
   bool teacher_done = false;
+  SideStream* tail = nullptr;  // option "tail_overlap": the sweep below runs on the side stream, behind the producer's backward
+  if ((a->flags & MAL_STEP_TEMPORAL) && tail_applies(a)) {
+    SideStream* ss = side_stream(st);
+    if (ss && ss->tail_pending) tail = ss;
+  }
   if (a->flags & MAL_STEP_TEMPORAL) {
     // the teacher's gradient sweep, with the decisions of the four-way min taken from _fwd and the gradient that
     // reaches the warped images through syn added before the chain rule through the warp
@@ -1012,6 +1068,10 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
       // map are redone (all of them without a map); the assembly finishes the teacher's gradient as in the plain step.
       // The sums of the redone tasks are not the step's (those are the pass's in front + the fused sweep's differences)
       p.region = a->syn_region; p.block_sums = w.bs_e;
+    } else if (tail) {
+      // beside the reduction: the loss scalars may not exist yet -- the sweep leaves the unnormalised map (the assembly finishes
+      // it, as in the step without the hint) and its sums go to a scratch of their own (the reduction reads bs_t meanwhile)
+      p.block_sums = w.bs_e;
     } else {
       // the loss scalars exist already: the sweep writes d total / d disp_teacher itself (the assembly does the student's)
       p.fin_gn = w.gn_t; p.fin_coefs = w.coefs; p.fin_stats = w.sm_stats; p.fin_g_total = a->g_total; p.fin_out = a->g_disp_teacher;
@@ -1019,7 +1079,8 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
     }
     p.bnd = g_march_halo1 ? w.bnd_t : nullptr;
     p.dbg = a->dec_teacher;
-    rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, st);
+    rc = march_launch(p, MAL_F_AUTOMASK | MAL_F_GRAD | MAL_F_POSE_GRAD | MAL_F_SRC_PACKED | MAL_F_TGT_PACKED, tail ? tail->s : st);
+    if (tail && rc) (void)join_tail(tail, st);  // (nothing may be left outside the caller's stream)
     if (rc) return rc;
     per_sample_t = p.strips * p.segs;
   }
@@ -1042,6 +1103,10 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   pp.g_axisangle[0] = a->g_axisangle_m1; pp.g_axisangle[1] = a->g_axisangle_p1;
   pp.g_translation[0] = a->g_translation_m1; pp.g_translation[1] = a->g_translation_p1;
   const int pose_bwd = (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) ? 1 : 0;
+  if (tail) {  // the sweep's results (and the producer's backward in front of it) come back to the caller's stream
+    rc = join_tail(tail, st);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.gn_t,
                      w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
                      teacher_done ? nullptr : a->g_disp_teacher, a->g_disp_student, pp, pose_bwd, per_sample_t ? w.bgP : nullptr,

@@ -86,6 +86,11 @@ def _as_u8(mask, dev):
 # writes one when it has the region map): the backward then gathers from the snapshot and writes the region pixels of the
 # registered buffer in one launch, without scratch.
 INPLACE_COTANGENTS = {}
+# The whole-step API (mal_amd.step, option "tail_overlap") may ask for this node's backward launch on another stream: a raw
+# stream handle that already waits for the producer of the cotangents.  Honoured only by the in-place, region-only backward
+# (ONE launch, no torch operation -- nothing the caching allocator or the autograd engine would have to know about), which then
+# says so in BACKWARD_STREAM["used"]; the caller makes its own stream wait for that stream before it reads the result.
+BACKWARD_STREAM = {"handle": None, "used": False}
 
 
 class BatchSynthesisFn(Function):
@@ -234,7 +239,10 @@ class BatchSynthesisFn(Function):
                 a.g_ori_last, a.g_ori_next, a.region_only = q_sl + b * s_sl, q_sn + b * s_sn, 1
             elif inplace:
                 a.g_tmp_last, a.g_tmp_next = q_tl + b * s_tl, q_tn + b * s_tn
-        L.check(lib.mal_dyn_batch_bwd(arr, len(ctx.saved), C, H, W, ops._stream()), "mal_dyn_batch_bwd")
+        stream = ops._stream()
+        if BACKWARD_STREAM["handle"] and snap_l is not None:
+            stream, BACKWARD_STREAM["used"] = BACKWARD_STREAM["handle"], True
+        L.check(lib.mal_dyn_batch_bwd(arr, len(ctx.saved), C, H, W, stream), "mal_dyn_batch_bwd")
         return gl, gn, None, None, None
 
 

@@ -287,23 +287,35 @@ class _Hint:
                 out[("syn", -1, sc)], out[("syn", 1, sc)] = self.syn_data
         out["multi_has_ins" if self.student else "has_ins"] = self.has_ins
 
-    def backward(self):
-        """the producer's own backward (linear): g_syn -> g_warp, handed to mal_loss_step_bwd"""
+    def backward(self, stream=None):
+        """the producer's own backward (linear): g_syn -> g_warp, handed to mal_loss_step_bwd.  ``stream`` (option
+        "tail_overlap"): a raw stream handle that already waits for the cotangents' producer; a producer whose backward is
+        ONE launch on buffers it was handed (mal_amd.dyn_utils, in place, region-only) enqueues it there.  Returns whether
+        everything this call enqueued went to that stream (the caller cancels the overlap otherwise)."""
+        on_stream = False
         if self.syn is None:
             g_warp = self.g_syn  # the identity producer
+            on_stream = stream is not None  # (nothing was enqueued at all)
         else:
             from . import dyn_utils
             # mal_amd.dyn_utils.image_synthesis turns the cotangent buffers into its result in place
             reg = {g.data_ptr(): (self.snap[i] if self.snap is not None else None) for i, g in enumerate(self.g_syn)}
             dyn_utils.INPLACE_COTANGENTS.update(reg)
+            dyn_utils.BACKWARD_STREAM["handle"], dyn_utils.BACKWARD_STREAM["used"] = stream, False
             try:
                 g_warp = torch.autograd.grad(self.syn, self.leaf, self.g_syn, allow_unused=True)
             finally:
                 for k in reg:
                     dyn_utils.INPLACE_COTANGENTS.pop(k, None)
+                used = dyn_utils.BACKWARD_STREAM["used"]
+                dyn_utils.BACKWARD_STREAM["handle"], dyn_utils.BACKWARD_STREAM["used"] = None, False
+            # ... and only if the result IS those buffers (no further operation of the autograd engine on the caller's stream)
+            on_stream = bool(used) and all(g is not None and g.data_ptr() == q.data_ptr() and g.is_contiguous()
+                                           for g, q in zip(g_warp, self.g_syn))
             g_warp = [torch.zeros_like(w) if g is None else g.contiguous() for g, w in zip(g_warp, self.warp)]
         self.g_warp = g_warp
         self._set("g_warp", g_warp)
+        return on_stream
 
 
 class TemporalLossStepFn(Function):
@@ -351,8 +363,19 @@ class TemporalLossStepFn(Function):
     def backward(ctx, g_total, *_):
         if g_total is None:
             return (None,) * 13
-        for h in ctx.hints:
-            h.backward()
+        # option "tail_overlap": the backward chain (producer's backward -> teacher's gradient sweep) on the library's side
+        # stream, behind the fused sweep only -- beside the epilogue and the reduction the forward left on this stream
+        lib, a = L.load(), ctx.args
+        side = C.c_void_p(0)
+        L.check(lib.mal_loss_step_tail_begin(C.byref(a), C.byref(side)), "mal_loss_step_tail_begin")
+        overlap = len(ctx.hints) == 1 and side.value is not None and side.value != a.stream
+        ok = True
+        try:
+            for h in ctx.hints:
+                ok = h.backward(stream=side.value if overlap else None) and ok
+        finally:
+            if side.value != a.stream and not (overlap and ok):  # nothing (or not everything) went there: join it back now
+                L.check(lib.mal_loss_step_tail_cancel(C.byref(a)), "mal_loss_step_tail_cancel")
         grads = _run_bwd(ctx, g_total)
         return (*grads, None, None, None, None, None, None, ctx.g_ens)
 

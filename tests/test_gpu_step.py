@@ -442,3 +442,54 @@ def test_channels_last_inputs_are_the_texels(temporal):
         assert torch.equal(ga[k], gb[k]), k
     for k in ma:
         assert torch.equal(ma[k], mb[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_tail_overlap_equals_the_serial_backward(graph):
+    """option "tail_overlap" (default 1, round 5): a --temporal step's backward chain -- the producer's backward, then the teacher's
+    gradient sweep -- runs on the library's side stream behind the fused sweep only, beside the epilogue and the reduction that
+    the forward left on the caller's stream; the sweep then leaves the unnormalised map and the assembly finishes it (as in the
+    step without the hint).  Same losses to the bit, the teacher's disparity gradient to rounding (one fused multiply-add
+    association), every other gradient to the bit -- eagerly and replayed from a captured graph, three steps in a row."""
+    import bench
+    from mal_amd import _lib, config
+    from mal_amd import step as step_mod
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    res = {}
+    old_noise = config.noise_source, config.noise_seed
+    try:
+        for opt in (0, 1):
+            assert lib.mal_set_option(b"tail_overlap", opt) == 0
+            step = bench.Step(dev, 4321, "step")
+            step_mod.noise_counter(dev).zero_()  # the in-kernel tie-break noise: the same draws for both runs
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                runs = []
+                if graph:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
+                        loss = step()
+                for _ in range(3):
+                    if graph:
+                        g.replay()
+                    else:
+                        loss = step()
+                    torch.cuda.synchronize()
+                    runs.append((float(loss.detach()), {k: t.grad.detach().clone() for k, t in step.leaves.items() if t.grad is not None}))
+                res[opt] = runs
+    finally:
+        lib.mal_set_option(b"tail_overlap", 1)
+        config.noise_source, config.noise_seed = old_noise  # (bench.Step switches the noise source)
+    for (l0, g0), (l1, g1) in zip(res[0], res[1]):
+        assert l0 == l1
+        assert set(g0) == set(g1)
+        for k in g0:
+            if k == "disp_teacher":
+                sc = float(g0[k].abs().max())
+                assert float((g0[k] - g1[k]).abs().max()) <= 2e-6 * sc, (k, float((g0[k] - g1[k]).abs().max()) / sc)
+            else:
+                assert torch.equal(g0[k], g1[k]), k
