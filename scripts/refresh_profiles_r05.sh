@@ -20,5 +20,5 @@ for regime in cold warm; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_distil_$regime -o s -- python3 $R/bench.py --mode distil --regime $regime --no-cpu-baseline --train-steps 0 > $O/stats_distil_$regime.log 2>&1 || exit 1
   echo "stats $regime done" >> $O/progress.log
 done
-cd $R && bash scripts/r05_pmc.sh > $O/pmc.txt 2>&1
+[ -n "$SKIP_PMC" ] || { cd $R && bash scripts/r05_pmc.sh > $O/pmc.txt 2>&1; }
 echo "pmc done" >> $O/progress.log
