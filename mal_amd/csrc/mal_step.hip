@@ -788,7 +788,7 @@ namespace mal { opt_t g_student_overlap{1}; opt_t g_side_order{0}; }
 // the two chains are independent; eager: the same order as before, the side stream simply has nothing to wait for)
 namespace mal { opt_t g_tail_overlap{1}; }
 static bool tail_applies(const mal_step_args* a) {
-  return g_tail_overlap && g_step_overlap == 1 && !g_temporal_spec && (a->flags & MAL_STEP_TEMPORAL) && !(a->flags & MAL_STEP_MAIN_TEMPORAL) &&
+  return g_tail_overlap && g_step_overlap == 1 && !g_temporal_spec && (a->flags & (MAL_STEP_TEMPORAL | MAL_STEP_MAIN_TEMPORAL)) &&
          side_stream((hipStream_t)a->stream) != nullptr;
 }
 // Call between a --temporal step's forward and the producer's backward: *stream receives the stream the producer's backward
@@ -966,11 +966,6 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
                                 sparse ? a->warp_m1 : nullptr, sparse ? a->warp_p1 : nullptr, (size_t)a->warp_sample_stride,
                                 1 /* the target as texels: one 12-byte load instead of three planes */, 0);
     if (rc) { (void)join_side(st); return rc; }
-    if (tail_applies(a)) {  // what the backward chain waits for (mal_loss_step_tail_begin)
-      SideStream* ss = side_stream(st);
-      ss->sweep_valid = ss && hipEventRecord(ss->sweep, st) == hipSuccess;
-      (void)hipGetLastError();
-    }
   }
   int per_sample_sh = 0;
   if (main_t) {
@@ -984,6 +979,11 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
                                 nullptr, nullptr, sparse ? a->warp_s_m1 : nullptr, sparse ? a->warp_s_p1 : nullptr,
                                 (size_t)a->warp_sample_stride, 1, 1 /* `ident` is the weight */);
     if (rc) { (void)join_side(st); return rc; }
+  }
+  if (hinted && tail_applies(a)) {  // what the backward chain waits for (mal_loss_step_tail_begin): the last fused sweep
+    SideStream* ss = side_stream(st);
+    ss->sweep_valid = ss && hipEventRecord(ss->sweep, st) == hipSuccess;
+    (void)hipGetLastError();
   }
   // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp -- and so
   // was the student's marching pass (without its epilogue)
@@ -1050,15 +1050,15 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   hipStream_t st = (hipStream_t)a->stream;
   int per_sample_t = 0;
   bool teacher_done = false;
-  SideStream* tail = nullptr;  // option "tail_overlap": the sweep below runs on the side stream, behind the producer's backward
-  if ((a->flags & MAL_STEP_TEMPORAL) && tail_applies(a)) {
+  SideStream* tail = nullptr;  // option "tail_overlap": the sweeps below run on the side stream, behind the producers' backwards
+  if (tail_applies(a)) {
     SideStream* ss = side_stream(st);
     if (ss && ss->tail_pending) tail = ss;
   }
   if (a->flags & MAL_STEP_TEMPORAL) {
     // the teacher's gradient sweep, with the decisions of the four-way min taken from _fwd and the gradient that
     // reaches the warped images through syn added before the chain rule through the warp
-    if (!a->g_warp_m1 || !a->g_warp_p1) return MAL_EINVAL;
+    if (!a->g_warp_m1 || !a->g_warp_p1) { if (tail) (void)join_tail(tail, st); return MAL_EINVAL; }
     MarchParams p = teacher_params(a, w, nullptr);
     p.g_reproj = w.G_r_t; p.block_sums = w.bs_t;
     p.ident = w.ident;  // unused by the TEMPORAL instantiation (the launch checks the flag combination only)
@@ -1085,8 +1085,9 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
     per_sample_t = p.strips * p.segs;
   }
   if (a->flags & MAL_STEP_MAIN_TEMPORAL) {
-    if (!a->g_warp_s_m1 || !a->g_warp_s_p1) return MAL_EINVAL;
-    rc = launch_student_temporal(a, w, st);
+    if (!a->g_warp_s_m1 || !a->g_warp_s_p1) { if (tail) (void)join_tail(tail, st); return MAL_EINVAL; }
+    rc = launch_student_temporal(a, w, tail ? tail->s : st);
+    if (tail && rc) (void)join_tail(tail, st);
     if (rc) return rc;
   }
   size_t g = (size_t)B * H;  // a workgroup per image row

@@ -368,7 +368,7 @@ class TemporalLossStepFn(Function):
         lib, a = L.load(), ctx.args
         side = C.c_void_p(0)
         L.check(lib.mal_loss_step_tail_begin(C.byref(a), C.byref(side)), "mal_loss_step_tail_begin")
-        overlap = len(ctx.hints) == 1 and side.value is not None and side.value != a.stream
+        overlap = side.value is not None and side.value != a.stream
         ok = True
         try:
             for h in ctx.hints:

@@ -445,8 +445,9 @@ def test_channels_last_inputs_are_the_texels(temporal):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("main_temporal", [False, True], ids=["temporal", "temporal+main_temporal"])
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
-def test_tail_overlap_equals_the_serial_backward(graph):
+def test_tail_overlap_equals_the_serial_backward(graph, main_temporal):
     """option "tail_overlap" (default 1, round 5): a --temporal step's backward chain -- the producer's backward, then the teacher's
     gradient sweep -- runs on the library's side stream behind the fused sweep only, beside the epilogue and the reduction that
     the forward left on the caller's stream; the sweep then leaves the unnormalised map and the assembly finishes it (as in the
@@ -462,7 +463,7 @@ def test_tail_overlap_equals_the_serial_backward(graph):
     try:
         for opt in (0, 1):
             assert lib.mal_set_option(b"tail_overlap", opt) == 0
-            step = bench.Step(dev, 4321, "step")
+            step = bench.Step(dev, 4321, "step", main_temporal=main_temporal)
             step_mod.noise_counter(dev).zero_()  # the in-kernel tie-break noise: the same draws for both runs
             with torch.cuda.stream(torch.cuda.Stream()):
                 for _ in range(2):
@@ -488,7 +489,7 @@ def test_tail_overlap_equals_the_serial_backward(graph):
         assert l0 == l1
         assert set(g0) == set(g1)
         for k in g0:
-            if k == "disp_teacher":
+            if k == "disp_teacher":  # (with --main_temporal the student's sweep left the unnormalised map before, too)
                 sc = float(g0[k].abs().max())
                 assert float((g0[k] - g1[k]).abs().max()) <= 2e-6 * sc, (k, float((g0[k] - g1[k]).abs().max()) / sc)
             else:
