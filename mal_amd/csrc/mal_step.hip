@@ -381,10 +381,16 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(const float* G_r_t, 
                                                             PoseParams pp, int pose_bwd, const float* bgP, const float* K,
                                                             int per_sample, int W, const float* bnd_t, const float* bnd_s,
                                                             int rows, int segs, float* fix_t, const float* G_e, float* g_ens,
-                                                            const float* G_dual) {
+                                                            const float* G_dual, int parts) {
+  // parts (option "tail_overlap": the student's half is launched while the teacher's sweep still runs, the rest behind it):
+  // bit 0 = the teacher's map, bit 1 = the student's map (and the ensemble head's), bit 2 = the pose gradients; 7 = everything
   const float g = g_total ? *g_total : 1.0f;
   const float cRt = coefs[0] * g, cRs = coefs[1] * g, cS = coefs[4] * g;  // coefs[2], [3] are already inside G_cd
-  if (bgP) {
+  if (!(parts & 1)) { g_disp_t = nullptr; fix_t = nullptr; }
+  if (!(parts & 2)) { g_disp_s = nullptr; g_ens = nullptr; }
+  if (!(parts & 4)) {
+    // (no pose work in this launch)
+  } else if (bgP) {
     // temporal hint: the teacher's sweep ran in this backward call, its pose partials are still per task: workgroup b
     // reduces sample b's (step_final_kernel's pose branch), scales and runs that sample's pose backward
     if ((int)blockIdx.x < B) {
@@ -1104,16 +1110,26 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   pp.g_axisangle[0] = a->g_axisangle_m1; pp.g_axisangle[1] = a->g_axisangle_p1;
   pp.g_translation[0] = a->g_translation_m1; pp.g_translation[1] = a->g_translation_p1;
   const int pose_bwd = (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) ? 1 : 0;
-  if (tail) {  // the sweep's results (and the producer's backward in front of it) come back to the caller's stream
-    rc = join_tail(tail, st);
+  auto assemble = [&](int parts) {
+    hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.gn_t,
+                       w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
+                       teacher_done ? nullptr : a->g_disp_teacher, a->g_disp_student, pp, pose_bwd, per_sample_t ? w.bgP : nullptr,
+                       a->K, per_sample_t, W, g_march_halo1 ? w.bnd_t : nullptr, g_march_halo1 ? w.bnd_s : nullptr, rows, segs,
+                       teacher_done ? a->g_disp_teacher : nullptr, a->ens_disp ? w.G_e : nullptr,
+                       a->ens_disp ? a->g_ens_disp : nullptr, (a->flags & MAL_STEP_DUAL_DISTIL) ? w.G_e : nullptr, parts);
+    return launch_status();
+  };
+  if (tail) {
+    // the student's half needs nothing of the side stream's chain (unless its own sweep runs there: --main_temporal; and
+    // --dual_distil adds a term of the epilogue to the TEACHER's map only): it goes out now, beside the teacher's sweep
+    const bool split = !(a->flags & MAL_STEP_MAIN_TEMPORAL) && a->g_disp_student != nullptr;
+    if (split) {
+      rc = assemble(2);
+      if (rc) { (void)join_tail(tail, st); return rc; }
+    }
+    rc = join_tail(tail, st);  // the sweep's results (and the producer's backward in front of it) come back to the caller's stream
     if (rc) return rc;
+    return assemble(split ? 5 : 7);
   }
-  hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.gn_t,
-                     w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
-                     teacher_done ? nullptr : a->g_disp_teacher, a->g_disp_student, pp, pose_bwd, per_sample_t ? w.bgP : nullptr,
-                     a->K, per_sample_t, W, g_march_halo1 ? w.bnd_t : nullptr, g_march_halo1 ? w.bnd_s : nullptr, rows, segs,
-                     teacher_done ? a->g_disp_teacher : nullptr, a->ens_disp ? w.G_e : nullptr,
-                     a->ens_disp ? a->g_ens_disp : nullptr, (a->flags & MAL_STEP_DUAL_DISTIL) ? w.G_e : nullptr);
-  rc = launch_status();
-  return rc;
+  return assemble(7);
 }
