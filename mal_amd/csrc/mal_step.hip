@@ -706,7 +706,8 @@ namespace mal { opt_t g_side_priority{0}; }
 // reduction, which the caller's stream runs meanwhile -- and `tail` joins them back in front of the assembly
 // (Measured, profiles/r05_tail_overlap.txt: a stream of its own for the chain, an anchor kernel behind the sweep that the chain
 // then continues, the assembly on the chain's stream -- the graph runtime places the nodes on hardware queues by its own rules
-// and none of these beat the plain form: the chain on the side stream, the assembly back on the caller's.)
+// and none of these beat the plain form: the chain on the side stream, the assembly back on the caller's.  Nor does the rest
+// of the assembly on the chain's stream: it then follows the sweep 5 us sooner, and the graph ends 19 us later.)
 struct SideStream { hipStream_t caller; hipStream_t s; hipEvent_t fork, join, mid, sweep, tail; bool ok, init, pending, sweep_valid, tail_pending; int dev; };
 static SideStream* side_stream(hipStream_t caller) {
   constexpr int kSlots = 64;
@@ -1110,8 +1111,8 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
   pp.g_axisangle[0] = a->g_axisangle_m1; pp.g_axisangle[1] = a->g_axisangle_p1;
   pp.g_translation[0] = a->g_translation_m1; pp.g_translation[1] = a->g_translation_p1;
   const int pose_bwd = (a->g_axisangle_m1 || a->g_translation_m1 || a->g_axisangle_p1 || a->g_translation_p1) ? 1 : 0;
-  auto assemble = [&](int parts) {
-    hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, st, w.G_r_t, w.G_r_s, w.G_c, w.gn_t,
+  auto assemble = [&](int parts, hipStream_t on) {
+    hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)g), dim3(256), 0, on, w.G_r_t, w.G_r_s, w.G_c, w.gn_t,
                        w.gn_s, w.coefs, w.sm_stats, a->g_total, B, HW, w.gT[0], w.gT[1], w.gTs[0], w.gTs[1],
                        teacher_done ? nullptr : a->g_disp_teacher, a->g_disp_student, pp, pose_bwd, per_sample_t ? w.bgP : nullptr,
                        a->K, per_sample_t, W, g_march_halo1 ? w.bnd_t : nullptr, g_march_halo1 ? w.bnd_s : nullptr, rows, segs,
@@ -1124,12 +1125,12 @@ extern "C" int mal_loss_step_bwd(const mal_step_args* a) {
     // --dual_distil adds a term of the epilogue to the TEACHER's map only): it goes out now, beside the teacher's sweep
     const bool split = !(a->flags & MAL_STEP_MAIN_TEMPORAL) && a->g_disp_student != nullptr;
     if (split) {
-      rc = assemble(2);
+      rc = assemble(2, st);
       if (rc) { (void)join_tail(tail, st); return rc; }
     }
     rc = join_tail(tail, st);  // the sweep's results (and the producer's backward in front of it) come back to the caller's stream
     if (rc) return rc;
-    return assemble(split ? 5 : 7);
+    return assemble(split ? 5 : 7, st);
   }
-  return assemble(7);
+  return assemble(7, st);
 }
