@@ -808,6 +808,7 @@ extern "C" int mal_loss_step_tail_begin(const mal_step_args* a, void** stream) {
   if (!tail_applies(a)) return MAL_OK;
   SideStream* ss = side_stream((hipStream_t)a->stream);
   if (!ss || !ss->sweep_valid || ss->tail_pending) return MAL_OK;
+  ss->sweep_valid = false;  // one forward, one chain: a second backward of the same step (or an option switched on in between) runs in order
   if (hipStreamWaitEvent(ss->s, ss->sweep, 0) != hipSuccess) { (void)hipGetLastError(); return MAL_OK; }
   ss->tail_pending = true;
   *stream = ss->s;
@@ -987,9 +988,9 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
                                 (size_t)a->warp_sample_stride, 1, 1 /* `ident` is the weight */);
     if (rc) { (void)join_side(st); return rc; }
   }
-  if (hinted && tail_applies(a)) {  // what the backward chain waits for (mal_loss_step_tail_begin): the last fused sweep
-    SideStream* ss = side_stream(st);
-    ss->sweep_valid = ss && hipEventRecord(ss->sweep, st) == hipSuccess;
+  if (hinted) {  // what the backward chain waits for (mal_loss_step_tail_begin): the last fused sweep
+    SideStream* ss = g_step_overlap ? side_stream(st) : nullptr;
+    if (ss) ss->sweep_valid = tail_applies(a) && hipEventRecord(ss->sweep, st) == hipSuccess;
     (void)hipGetLastError();
   }
   // ensemble pass (no gradient); with the temporal hint it was forked beside the producer by mal_loss_step_warp -- and so
