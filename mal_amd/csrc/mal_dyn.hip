@@ -118,7 +118,7 @@ __global__ __launch_bounds__(1024) void dyn_extents16_kernel(DynBatch bt) {
   const uint4* m16 = reinterpret_cast<const uint4*>((which ? p.mask_next : p.mask_last) +
                                                     dyn_row(sel, i, which ? p.rows_next : p.rows_last) * ((size_t)H * W));
   int rmax = 0, rmin = 0x7fffffff, cmax = 0, cmin = 0x7fffffff;
-  for (int k = r_lo * W16 + tid; k < max(r_hi, r_lo) * W16; k += 1024) {
+  for (int k = r_lo * W16 + tid; k < max(r_hi, r_lo) * W16; k += (int)blockDim.x) {
     const uint4 v = m16[k];
     const unsigned w4[4] = {v.x, v.y, v.z, v.w};
     unsigned m = 0u;
@@ -502,6 +502,7 @@ __global__ __launch_bounds__(256) void dyn_apply_region4_kernel(DynBatch bt) {
 }
 
 }  // namespace mal
+namespace mal { opt_t g_dyn_small_blocks{1}; }  // option "dyn_small_blocks" (A/B): 0 = 1024-thread workgroups in dyn_extents16_kernel
 
 using namespace mal;
 
@@ -538,8 +539,10 @@ static int dyn_fwd_chunk(const mal_dyn_item* it, int n, int C, int H, int W, int
   }
   bool wide = (W & 15) == 0;
   for (int k = 0; k < n && wide; ++k) wide = aligned_to(bt.s[k].mask_last, 16) && aligned_to(bt.s[k].mask_next, 16);
+  // (256 threads: one wave per SIMD -- a 1024-thread workgroup needs four slots of 32 VGPRs on EVERY SIMD of a CU at once
+  // and waited for a whole marching pass beside which the --temporal step runs it: 45 us instead of 13)
   if (wide)
-    hipLaunchKernelGGL(dyn_extents16_kernel, dim3(max_num, 2 * kExtChunks, n), dim3(1024), 0, st, bt);
+    hipLaunchKernelGGL(dyn_extents16_kernel, dim3(max_num, 2 * kExtChunks, n), dim3(g_dyn_small_blocks ? 256 : 1024), 0, st, bt);
   else
     hipLaunchKernelGGL(dyn_extents_kernel, dim3(max_num, 2 * kExtChunks, n), dim3(1024), (size_t)(H + W + 4) * sizeof(int), st, bt);
   bool quad = (W & 3) == 0 && C == 3;

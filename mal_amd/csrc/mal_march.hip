@@ -1536,6 +1536,7 @@ extern opt_t g_syn_queue;       // mal_photo_march.hip
 extern opt_t g_step_overlap;    // mal_step.hip
 extern opt_t g_student_overlap; // mal_step.hip
 extern opt_t g_tail_overlap;    // mal_step.hip
+extern opt_t g_dyn_small_blocks; // mal_dyn.hip
 extern opt_t g_side_priority;   // mal_step.hip
 extern opt_t g_side_order;      // mal_step.hip
 extern opt_t g_march_halo1;     // mal_step.hip
@@ -1783,6 +1784,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("march_halo1")) { g_march_halo1 = value != 0; return MAL_OK; }
   if (eq("student_overlap")) { g_student_overlap = value != 0; return MAL_OK; }
   if (eq("tail_overlap")) { g_tail_overlap = value != 0; return MAL_OK; }
+  if (eq("dyn_small_blocks")) { g_dyn_small_blocks = value != 0; return MAL_OK; }
   if (eq("side_order")) { g_side_order = value != 0; return MAL_OK; }
   if (eq("side_priority")) { g_side_priority = value != 0; return MAL_OK; }  // read when a side stream is first created
   if (eq("temporal_spec")) { if (!kExp && value) return MAL_EINVAL; g_temporal_spec = value != 0; return MAL_OK; }
