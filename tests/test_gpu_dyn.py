@@ -34,10 +34,19 @@ def test_golden_bit_exact(tag, replace):
     assert np.array_equal(gn.cpu().numpy(), z["out/g_img_next" + sfx])
 
 
-def test_full_size_against_the_cpu_checker():
-    from mal_amd import dyn_utils
+@pytest.mark.parametrize("small_blocks", [1, 0], ids=["256-thread extents (default)", "1024-thread extents"])
+def test_full_size_against_the_cpu_checker(small_blocks):
+    from mal_amd import _lib, dyn_utils
     from oracle import dyn_oracle as D
     from oracle.gen_golden_dyn import make_masks
+    assert _lib.load().mal_set_option(b"dyn_small_blocks", small_blocks) == 0  # (same bits either way: the extents' band reduction)
+    try:
+        _full_size_against_the_cpu_checker(dyn_utils, D, make_masks)
+    finally:
+        _lib.load().mal_set_option(b"dyn_small_blocks", 1)
+
+
+def _full_size_against_the_cpu_checker(dyn_utils, D, make_masks):
     num, H, W = 12, 192, 640
     ml, mn = make_masks(num, H, W, seed=9)
     g = torch.Generator().manual_seed(4)
