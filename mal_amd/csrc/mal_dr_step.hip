@@ -361,6 +361,7 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
   hipStream_t st = (hipStream_t)a->stream;
   const bool automask = !(a->flags & MAL_DR_NO_AUTOMASK);
   const int pu = (a->flags & MAL_DR_POSE_UPDATE) ? 1 : 0;
+  const bool philox = automask && (a->flags & MAL_DR_NOISE_PHILOX);
   // identity term + texel packing (no noise here: every iteration adds its own).  Up to two iterations (the shipped
   // n_losses = 1): their edge-aware smoothness rides on this sweep, which holds the target rows anyway; more: one batched
   // smoothness sweep below
@@ -377,12 +378,19 @@ extern "C" int mal_dr_loss_fwd(const mal_dr_args* a) {
     SmoothParams sm = {};
     sm.n = n; sm.partials = w.sm[0];
     for (int it = 0; it < n && smooth_fused; ++it) { sm.disp[it] = a->disp[it]; sm.gn[it] = w.gn[it]; }
+    // ... and the prologue (camera blocks, noise maps: nothing the sweep reads or writes) as the same launch's last workgroups
+    DrExtra x = {};
+    x.K = a->K; x.invK = a->inv_K; x.seed = a->noise_seed; x.step = a->noise_step;
+    x.counter = (const unsigned long long*)a->noise_counter;
+    x.B = B; x.H = H; x.W = W; x.ticket = w.ticket; x.slots = n + pu; x.pu_slot = pu ? n : -1;
+    x.noise_blocks = philox ? (int)(((size_t)B * ((H + 3) / 4) * W + 63) / 64) : 0;
+    for (int it = 0; it < n; ++it) { x.T[it][0] = a->T_m1[it]; x.T[it][1] = a->T_p1[it]; x.cam[it] = w.cam[it]; x.noise[it] = w.noise[it]; }
+    if (pu) { x.T[n][0] = a->pu_T_m1; x.T[n][1] = a->pu_T_p1; x.cam[n] = w.cam[n]; x.noise[n] = w.noise[n]; }
     rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
-                              nullptr, nullptr, smooth_fused ? &sm : nullptr, &per_sample_sm, false, variant);
+                              nullptr, nullptr, smooth_fused ? &sm : nullptr, &per_sample_sm, false, variant, &x);
     if (rc) return rc;
   }
-  const bool philox = automask && (a->flags & MAL_DR_NOISE_PHILOX);
-  {
+  if (reuse) {  // (no sweep in this call: the prologue is a launch of its own)
     DrPrologue q = {};
     q.K = a->K; q.invK = a->inv_K; q.seed = a->noise_seed; q.step = a->noise_step;
     q.counter = (const unsigned long long*)a->noise_counter;

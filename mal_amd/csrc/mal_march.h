@@ -142,11 +142,22 @@ struct TieNoise { int on; unsigned long long seed, step; const unsigned long lon
 // the sample's 1/(mean+1e-7)), partials [task][m][4] = sum |dx d| w, sum |dy d| w, sum gn*disp, sum disp;
 // dec[m] (tests, nullable): decision planes receiving the signs taken (MAL_DEC_SMOOTH_X / _Y).
 struct SmoothParams { int n; const float* disp[2]; float* gn[2]; double* partials; unsigned* dec[2]; };
+// DualRefine's one-call step (mal_dr_step.hip): what its prologue does -- the camera block (K T)[:3,:] of both frames + inv_K of
+// sample b for every slot's poses (slot = deq iteration; pu_slot: the pose-update pass) and, with MAL_DR_NOISE_PHILOX, every
+// slot's N(0,1) map -- as extra workgroups of the identity / packing sweep instead of a launch of its own behind it (neither
+// needs the other).  noise_blocks: 64-pixel-group workgroups per slot (0: no noise), then B camera workgroups per slot.
+constexpr int kDrSlotsMax = 5;  // MAL_DR_MAX_ITERS + the pose-update pass
+struct DrExtra {
+  const float* K; const float* invK; const float* T[kDrSlotsMax][2]; float* cam[kDrSlotsMax]; float* noise[kDrSlotsMax];
+  unsigned long long seed, step; const unsigned long long* counter;
+  int slots, pu_slot, noise_blocks, B, H, W; unsigned* ticket;
+};
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
                          const StepPoses* poses = nullptr, const TieNoise* noise = nullptr,
                          const SmoothParams* smooth = nullptr, int* tasks_per_sample = nullptr, bool texel_in = false,
-                         int variant = 0 /* bit 0 --no_ssim, bit 1 --avg_reprojection: the identity term follows */);
+                         int variant = 0 /* bit 0 --no_ssim, bit 1 --avg_reprojection: the identity term follows */,
+                         const DrExtra* dr = nullptr);
 
 // Philox4x32-10 (Salmon et al., SC'11; the generator behind torch's device randn), one block of four 32-bit words
 MAL_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
@@ -173,6 +184,30 @@ MAL_DEV void tie_noise4(unsigned long long seed, unsigned long long step, unsign
     n[2 * h] = r * __cosf(6.283185307179586f * u2);
     n[2 * h + 1] = r * __sinf(6.283185307179586f * u2);
   }
+}
+
+// workgroup e (64 threads) of a DrExtra: slot e / (noise_blocks + B); the slot's noise groups first, then its camera blocks.
+// MAL_DR_NOISE_PHILOX's numbering: key seed (the pose-update pass: seed ^ MAL_DR_POSE_NOISE_KEY), step number
+// (counter ? *counter : step) * MAL_DR_MAX_ITERS + slot (the pose-update pass: + 0), value layout of tiebreak_noise_kernel
+MAL_DEV void dr_extra_block(const DrExtra& p, int e, int tid) {
+  const int per = p.noise_blocks + p.B, it = e / per, r = e - it * per;
+  if (e == 0 && tid < 4) p.ticket[tid] = 0u;
+  if (r >= p.noise_blocks) {
+    cam_fill(p.K, p.T[it][0], p.T[it][1], p.invK, p.cam[it], r - p.noise_blocks, tid);
+    return;
+  }
+  const int H = p.H, W = p.W, H4 = (H + 3) >> 2;
+  const size_t i = (size_t)r * 64 + tid;
+  if (i >= (size_t)p.B * H4 * W) return;
+  const int x = (int)(i % W), row = (int)(i / W), y4 = row % H4, b = row / H4, y0 = y4 * 4;
+  const bool pu = it == p.pu_slot;
+  const unsigned long long st = (p.counter ? *p.counter : p.step) * (unsigned long long)MAL_DR_MAX_ITERS + (pu ? 0 : it);
+  float n[4];
+  tie_noise4(pu ? p.seed ^ MAL_DR_POSE_NOISE_KEY : p.seed, st, (unsigned)(b * H * W + y0 * W + x), n);
+  float* o = p.noise[it] + (size_t)b * H * W + (size_t)y0 * W + x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (y0 + j < H) o[(size_t)j * W] = n[j];
 }
 
 }  // namespace mal

@@ -1316,6 +1316,7 @@ struct IdentParams {
   TieNoise tn;                                // ident += 1e-5 * N(0,1) (Philox), see mal_march.h
   SmoothParams sm;                            // edge-aware smoothness of up to two disparity maps in the same sweep
   int variant;                                // VARIANTS instantiation only: bit 0 --no_ssim, bit 1 --avg_reprojection
+  int dr_blocks; DrExtra dr;                  // DualRefine's one-call step: its prologue as the launch's last dr_blocks workgroups
 };
 
 // TEXIN: the three images arrive as (B,H,W,3) texels already -- a (B,3,H,W) tensor in torch.channels_last IS that layout --:
@@ -1325,6 +1326,10 @@ template <bool TEXIN, bool VARIANTS = false>
 __global__ __launch_bounds__(64, 3) void pack_identity_kernel(IdentParams p) {
   constexpr int HALO = 1, CW = 62;
   const int id = blockIdx.x;
+  if (id >= p.per_xcd * 8 + p.pose_blocks) {  // DualRefine's one-call step: camera blocks and noise maps of every slot
+    dr_extra_block(p.dr, id - p.per_xcd * 8 - p.pose_blocks, threadIdx.x);
+    return;
+  }
   if (id >= p.per_xcd * 8) {  // whole-step list: poses of both frames and the camera block of sample b
     const int b = id - p.per_xcd * 8, tid = threadIdx.x;
     if (b == 0 && tid < 3) p.sp.ticket[tid] = 0u;  // completion counter of step_final_kernel, [1..2]: counts of the fused sweep's task order
@@ -1710,9 +1715,10 @@ int pack_identity_tasks_per_sample(int H, int W) { return ((W + 61) / 62) * ((H 
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
                          const StepPoses* poses, const TieNoise* noise, const SmoothParams* smooth, int* tasks_per_sample,
-                         bool texel_in, int variant) {
+                         bool texel_in, int variant, const DrExtra* dr) {
   IdentParams p = {};
   p.variant = variant;
+  if (dr) { p.dr = *dr; p.dr_blocks = dr->slots * (dr->noise_blocks + dr->B); }
   if (noise) p.tn = *noise;
   if (smooth) p.sm = *smooth;
   p.pose_blocks = poses ? B : 0;
@@ -1727,12 +1733,12 @@ int pack_identity_launch(const float* target, const float* src0, const float* sr
   if (tasks_per_sample) *tasks_per_sample = p.strips * p.segs;
   if (variant) {  // --no_ssim / --avg_reprojection identity term: its own instantiation (the default one stays as it is)
     if (texel_in) return MAL_EINVAL;
-    hipLaunchKernelGGL((pack_identity_kernel<false, true>), dim3(p.per_xcd * 8 + p.pose_blocks), dim3(64), 0, st, p);
+    hipLaunchKernelGGL((pack_identity_kernel<false, true>), dim3(p.per_xcd * 8 + p.pose_blocks + p.dr_blocks), dim3(64), 0, st, p);
   } else if (texel_in) {
     if (packed0 || packed1 || packed_target) return MAL_EINVAL;  // nothing to repack: the inputs are the texels
-    hipLaunchKernelGGL(pack_identity_kernel<true>, dim3(p.per_xcd * 8 + p.pose_blocks), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(pack_identity_kernel<true>, dim3(p.per_xcd * 8 + p.pose_blocks + p.dr_blocks), dim3(64), 0, st, p);
   } else
-  hipLaunchKernelGGL(pack_identity_kernel<false>, dim3(p.per_xcd * 8 + p.pose_blocks), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(pack_identity_kernel<false>, dim3(p.per_xcd * 8 + p.pose_blocks + p.dr_blocks), dim3(64), 0, st, p);
   return launch_status();
 }
 
