@@ -152,12 +152,21 @@ struct DrExtra {
   unsigned long long seed, step; const unsigned long long* counter;
   int slots, pu_slot, noise_blocks, B, H, W; unsigned* ticket;
 };
+// The four-scale step (mal_step_ms.hip): its per-scale tie-break noise maps (MAL_STEP_NOISE_PHILOX) and the bilinear
+// upsampling of the lower scales' disparities to full resolution (trainer.py:1094-1096) -- neither reads anything the
+// identity / packing sweep writes -- as extra workgroups of that sweep's launch instead of two launches behind it.
+struct UpMaps { const float* src[2 * MAL_MS_MAX_SCALES]; float* dst[2 * MAL_MS_MAX_SCALES]; int h[2 * MAL_MS_MAX_SCALES], w[2 * MAL_MS_MAX_SCALES]; };
+struct MsExtra {
+  unsigned long long seed, step; const unsigned long long* counter; unsigned mult; int n_noise; float* noise[MAL_MS_MAX_SCALES];
+  UpMaps up; int n_up;            // maps to upsample, four output pixels per thread (W % 4 == 0, 16-byte aligned destinations)
+  int B, H, W, noise_blocks, up_blocks;  // 64-thread workgroups per noise map / per upsampled map
+};
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
                          const StepPoses* poses = nullptr, const TieNoise* noise = nullptr,
                          const SmoothParams* smooth = nullptr, int* tasks_per_sample = nullptr, bool texel_in = false,
                          int variant = 0 /* bit 0 --no_ssim, bit 1 --avg_reprojection: the identity term follows */,
-                         const DrExtra* dr = nullptr);
+                         const DrExtra* dr = nullptr, const MsExtra* ms = nullptr);
 
 // Philox4x32-10 (Salmon et al., SC'11; the generator behind torch's device randn), one block of four 32-bit words
 MAL_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
@@ -184,6 +193,71 @@ MAL_DEV void tie_noise4(unsigned long long seed, unsigned long long step, unsign
     n[2 * h] = r * __cosf(6.283185307179586f * u2);
     n[2 * h + 1] = r * __sinf(6.283185307179586f * u2);
   }
+}
+
+// ---- bilinear upsampling (align_corners=False), as mal_step_ms.hip applies it
+// ATen's area_pixel_compute_source_index: src = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out (float);
+// i0 = (int)src, i1 = i0 + (i0 < in - 1), lambda1 = src - i0, lambda0 = 1 - lambda1.
+struct Tap { int i0, i1; float l0, l1; };
+MAL_DEV Tap tap_of(int dst, float scale, int n_in) {
+  float src = fma_(scale, (float)dst + 0.5f, -0.5f);  // contracted in ATen's builds (exact either way for power-of-two factors)
+  src = src < 0.f ? 0.f : src;
+  Tap t;
+  t.i0 = (int)src;
+  t.i1 = t.i0 + (t.i0 < n_in - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.0f - t.l1;
+  return t;
+}
+// h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d) as ATen's builds contract it (device and host kernels alike, measured
+// bit for bit by scripts/upsample_probe.py): the first product of each sum becomes the fused multiply-add
+MAL_DEV float bilinear_value(float h0, float h1, float w0, float w1, float a, float b, float c, float d) {
+  const float top = fma_(w0, a, w1 * b), bot = fma_(w0, c, w1 * d);
+  return fma_(h0, top, h1 * bot);
+}
+// V consecutive output pixels (row `row` = b * H + y, columns x0 ..) of map k
+template <int V>
+MAL_DEV void upsample_pixels(const UpMaps& m, int k, int row, int x0, int H, int W) {
+  const int h = m.h[k], w = m.w[k];
+  const int b = row / H, y = row - b * H;
+  const Tap ty = tap_of(y, (float)h / (float)H, h);
+  const float* s0 = m.src[k] + (size_t)b * h * w + ty.i0 * w;
+  const float* s1 = m.src[k] + (size_t)b * h * w + ty.i1 * w;
+  float o[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const Tap tx = tap_of(x0 + v, (float)w / (float)W, w);
+    o[v] = bilinear_value(ty.l0, ty.l1, tx.l0, tx.l1, s0[tx.i0], s0[tx.i1], s1[tx.i0], s1[tx.i1]);
+  }
+  float* d = m.dst[k] + (size_t)row * W + x0;
+  if (V == 4) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+  else d[0] = o[0];
+}
+// workgroup e (64 threads) of an MsExtra: the noise maps' groups first (map e / noise_blocks; numbering of
+// tiebreak_noise_kernel: step number (counter ? *counter : step) * mult + map), then the upsampled maps' quads
+MAL_DEV void ms_extra_block(const MsExtra& p, int e, int tid) {
+  const int nb = p.n_noise * p.noise_blocks;
+  if (e < nb) {
+    const int k = e / p.noise_blocks, r = e - k * p.noise_blocks;
+    const int H = p.H, W = p.W, H4 = (H + 3) >> 2;
+    const size_t i = (size_t)r * 64 + tid;
+    if (i >= (size_t)p.B * H4 * W) return;
+    const int x = (int)(i % W), row = (int)(i / W), y4 = row % H4, b = row / H4, y0 = y4 * 4;
+    const unsigned long long st = (p.counter ? *p.counter : p.step) * p.mult + (unsigned)k;
+    float n[4];
+    tie_noise4(p.seed, st, (unsigned)(b * H * W + y0 * W + x), n);
+    float* o = p.noise[k] + (size_t)b * H * W + (size_t)y0 * W + x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (y0 + j < H) o[(size_t)j * W] = n[j];
+    return;
+  }
+  e -= nb;
+  const int k = e / p.up_blocks, r = e - k * p.up_blocks;
+  const int W4 = p.W >> 2;
+  const size_t q = (size_t)r * 64 + tid;  // quad index inside the map: row-major over (B*H, W/4)
+  if (q >= (size_t)p.B * p.H * W4) return;
+  upsample_pixels<4>(p.up, k, (int)(q / W4), (int)(q % W4) * 4, p.H, p.W);
 }
 
 // workgroup e (64 threads) of a DrExtra: slot e / (noise_blocks + B); the slot's noise groups first, then its camera blocks.

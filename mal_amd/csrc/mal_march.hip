@@ -1317,6 +1317,7 @@ struct IdentParams {
   SmoothParams sm;                            // edge-aware smoothness of up to two disparity maps in the same sweep
   int variant;                                // VARIANTS instantiation only: bit 0 --no_ssim, bit 1 --avg_reprojection
   int dr_blocks; DrExtra dr;                  // DualRefine's one-call step: its prologue as the launch's last dr_blocks workgroups
+  int ms_blocks; MsExtra ms;                  // the four-scale step: noise maps + upsampled disparities, behind those
 };
 
 // TEXIN: the three images arrive as (B,H,W,3) texels already -- a (B,3,H,W) tensor in torch.channels_last IS that layout --:
@@ -1326,6 +1327,10 @@ template <bool TEXIN, bool VARIANTS = false>
 __global__ __launch_bounds__(64, 3) void pack_identity_kernel(IdentParams p) {
   constexpr int HALO = 1, CW = 62;
   const int id = blockIdx.x;
+  if (id >= p.per_xcd * 8 + p.pose_blocks + p.dr_blocks) {  // the four-scale step: noise maps, upsampled disparities
+    ms_extra_block(p.ms, id - p.per_xcd * 8 - p.pose_blocks - p.dr_blocks, threadIdx.x);
+    return;
+  }
   if (id >= p.per_xcd * 8 + p.pose_blocks) {  // DualRefine's one-call step: camera blocks and noise maps of every slot
     dr_extra_block(p.dr, id - p.per_xcd * 8 - p.pose_blocks, threadIdx.x);
     return;
@@ -1541,6 +1546,7 @@ extern opt_t g_syn_queue;       // mal_photo_march.hip
 extern opt_t g_step_overlap;    // mal_step.hip
 extern opt_t g_student_overlap; // mal_step.hip
 extern opt_t g_tail_overlap;    // mal_step.hip
+extern opt_t g_ms_fold;         // mal_step_ms.hip
 extern opt_t g_dyn_small_blocks; // mal_dyn.hip
 extern opt_t g_side_priority;   // mal_step.hip
 extern opt_t g_side_order;      // mal_step.hip
@@ -1715,10 +1721,11 @@ int pack_identity_tasks_per_sample(int H, int W) { return ((W + 61) / 62) * ((H 
 int pack_identity_launch(const float* target, const float* src0, const float* src1, int B, int H, int W,
                          float* packed0, float* packed1, float* packed_target, float* ident, hipStream_t st,
                          const StepPoses* poses, const TieNoise* noise, const SmoothParams* smooth, int* tasks_per_sample,
-                         bool texel_in, int variant, const DrExtra* dr) {
+                         bool texel_in, int variant, const DrExtra* dr, const MsExtra* ms) {
   IdentParams p = {};
   p.variant = variant;
   if (dr) { p.dr = *dr; p.dr_blocks = dr->slots * (dr->noise_blocks + dr->B); }
+  if (ms) { p.ms = *ms; p.ms_blocks = ms->n_noise * ms->noise_blocks + ms->n_up * ms->up_blocks; }
   if (noise) p.tn = *noise;
   if (smooth) p.sm = *smooth;
   p.pose_blocks = poses ? B : 0;
@@ -1733,12 +1740,12 @@ int pack_identity_launch(const float* target, const float* src0, const float* sr
   if (tasks_per_sample) *tasks_per_sample = p.strips * p.segs;
   if (variant) {  // --no_ssim / --avg_reprojection identity term: its own instantiation (the default one stays as it is)
     if (texel_in) return MAL_EINVAL;
-    hipLaunchKernelGGL((pack_identity_kernel<false, true>), dim3(p.per_xcd * 8 + p.pose_blocks + p.dr_blocks), dim3(64), 0, st, p);
+    hipLaunchKernelGGL((pack_identity_kernel<false, true>), dim3(p.per_xcd * 8 + p.pose_blocks + p.dr_blocks + p.ms_blocks), dim3(64), 0, st, p);
   } else if (texel_in) {
     if (packed0 || packed1 || packed_target) return MAL_EINVAL;  // nothing to repack: the inputs are the texels
-    hipLaunchKernelGGL(pack_identity_kernel<true>, dim3(p.per_xcd * 8 + p.pose_blocks + p.dr_blocks), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(pack_identity_kernel<true>, dim3(p.per_xcd * 8 + p.pose_blocks + p.dr_blocks + p.ms_blocks), dim3(64), 0, st, p);
   } else
-  hipLaunchKernelGGL(pack_identity_kernel<false>, dim3(p.per_xcd * 8 + p.pose_blocks + p.dr_blocks), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(pack_identity_kernel<false>, dim3(p.per_xcd * 8 + p.pose_blocks + p.dr_blocks + p.ms_blocks), dim3(64), 0, st, p);
   return launch_status();
 }
 
@@ -1789,6 +1796,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("step_overlap")) { if (value < 0 || value > 2) return MAL_EINVAL; g_step_overlap = value; return MAL_OK; }
   if (eq("march_halo1")) { g_march_halo1 = value != 0; return MAL_OK; }
   if (eq("student_overlap")) { g_student_overlap = value != 0; return MAL_OK; }
+  if (eq("ms_fold")) { g_ms_fold = value != 0; return MAL_OK; }
   if (eq("tail_overlap")) { g_tail_overlap = value != 0; return MAL_OK; }
   if (eq("dyn_small_blocks")) { g_dyn_small_blocks = value != 0; return MAL_OK; }
   if (eq("side_order")) { g_side_order = value != 0; return MAL_OK; }

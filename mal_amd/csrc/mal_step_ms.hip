@@ -38,6 +38,10 @@ int tiebreak_noise_launch(unsigned long long seed, unsigned long long step, cons
                           int n, int B, int H, int W, float* const* out, hipStream_t st);
 
 constexpr int kMsS = MAL_MS_MAX_SCALES;
+// option "ms_fold" (A/B): 0 = the noise maps and the upsampling as launches of their own behind the first sweep.  Worth 0.6 %
+// only (0.5937 -> 0.5903 ms; the noise maps alone 0.5888, the upsampling alone 0.5914): the riders inherit the sweep's 152
+// VGPRs per wave, i.e. three waves per SIMD for 160 000 tiny workgroups that as launches of their own run at eight
+opt_t g_ms_fold{1};
 constexpr int kMsLossSlots = 48;
 
 struct MsWs {
@@ -102,54 +106,21 @@ static MsWs carve_ms(void* base, int B, int H, int W, int sclm) {
   return w;
 }
 
-// ---------------------------------------------------------------- bilinear upsampling (align_corners=False) + adjoint
-// ATen's area_pixel_compute_source_index: src = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out (float);
-// i0 = (int)src, i1 = i0 + (i0 < in - 1), lambda1 = src - i0, lambda0 = 1 - lambda1.
-struct Tap { int i0, i1; float l0, l1; };
-MAL_DEV Tap tap_of(int dst, float scale, int n_in) {
-  float src = fma_(scale, (float)dst + 0.5f, -0.5f);  // contracted in ATen's builds (exact either way for power-of-two factors)
-  src = src < 0.f ? 0.f : src;
-  Tap t;
-  t.i0 = (int)src;
-  t.i1 = t.i0 + (t.i0 < n_in - 1 ? 1 : 0);
-  t.l1 = src - (float)t.i0;
-  t.l0 = 1.0f - t.l1;
-  return t;
-}
+// ---------------------------------------------------------------- bilinear upsampling (align_corners=False: Tap, tap_of,
+// bilinear_value, UpMaps, upsample_pixels in mal_march.h) + adjoint
 // weight with which output index `dst` reads input index `i`
 MAL_DEV float tap_weight(int dst, float scale, int n_in, int i) {
   const Tap t = tap_of(dst, scale, n_in);
   return (t.i0 == i ? t.l0 : 0.f) + (t.i1 == i ? t.l1 : 0.f);
 }
 
-// h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d) as ATen's builds contract it (device and host kernels alike, measured
-// bit for bit by scripts/upsample_probe.py): the first product of each sum becomes the fused multiply-add
-MAL_DEV float bilinear_value(float h0, float h1, float w0, float w1, float a, float b, float c, float d) {
-  const float top = fma_(w0, a, w1 * b), bot = fma_(w0, c, w1 * d);
-  return fma_(h0, top, h1 * bot);
-}
-
-struct UpMaps { const float* src[2 * kMsS]; float* dst[2 * kMsS]; int h[2 * kMsS], w[2 * kMsS]; };
 // grid (x chunks, B*H rows, maps); one thread per V consecutive output pixels of a row (V = 4 when W % 4 == 0: one 16-byte
 // store)
 template <int V>
 __global__ __launch_bounds__(256) void upsample_kernel(UpMaps m, int B, int H, int W) {
-  const int k = blockIdx.z, h = m.h[k], w = m.w[k];
-  const int x0 = (blockIdx.x * 256 + threadIdx.x) * V, row = blockIdx.y;
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * V;
   if (x0 >= W) return;
-  const int b = row / H, y = row - b * H;  // uniform: scalar unit
-  const Tap ty = tap_of(y, (float)h / (float)H, h);
-  const float* s0 = m.src[k] + (size_t)b * h * w + ty.i0 * w;
-  const float* s1 = m.src[k] + (size_t)b * h * w + ty.i1 * w;
-  float o[V];
-#pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const Tap tx = tap_of(x0 + v, (float)w / (float)W, w);
-    o[v] = bilinear_value(ty.l0, ty.l1, tx.l0, tx.l1, s0[tx.i0], s0[tx.i1], s1[tx.i0], s1[tx.i1]);
-  }
-  float* d = m.dst[k] + (size_t)row * W + x0;
-  if (V == 4) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
-  else d[0] = o[0];
+  upsample_pixels<V>(m, blockIdx.z, blockIdx.y, x0, H, W);
 }
 static void upsample_launch(const UpMaps& m, int n, int B, int H, int W, hipStream_t st) {
   bool vec = W % 4 == 0;
@@ -567,17 +538,9 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
     sp.pose.invert[0] = 1; sp.pose.invert[1] = 0;
     sp.pose.T[0] = w.T[0]; sp.pose.T[1] = w.T[1];
     sp.K = a->K; sp.invK = a->inv_K; sp.cam = w.cam; sp.ticket = w.ticket;
-    rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
-                              &sp, nullptr, nullptr, nullptr, false, (a->flags & MAL_STEP_NO_SSIM) ? 1 : 0);
-    if (rc) return rc;
-  }
-  if (a->flags & MAL_STEP_NOISE_PHILOX) {
-    rc = tiebreak_noise_launch(a->noise_seed, a->noise_step, (const unsigned long long*)a->noise_counter, (unsigned)S, S, B, H, W,
-                               w.noise, st);
-    if (rc) return rc;
-  }
-  // 2. every scale's disparity at full resolution (trainer.py:1094-1096)
-  if (S > 1) {
+    // 2. every scale's disparity at full resolution (trainer.py:1094-1096) and the per-scale tie-break noise maps: neither
+    // reads what the sweep writes -- they ride on its launch as extra workgroups (four pixels per thread: W % 4 == 0 and
+    // 16-byte aligned maps; launches of their own otherwise)
     UpMaps m = {};
     int k = 0;
     for (int s = 1; s < S; ++s)
@@ -585,9 +548,34 @@ static int ms_front(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool te
         m.src[k] = n ? a->disp_student[s] : a->disp_teacher[s];
         m.dst[k] = w.up[n][s]; m.h[k] = H >> s; m.w[k] = W >> s;
       }
-    upsample_launch(m, k, B, H, W, st);
-    rc = launch_status();
+    bool fold = g_ms_fold && W % 4 == 0;
+    for (int i = 0; i < k; ++i) fold = fold && ((uintptr_t)m.dst[i] % 16 == 0);
+    const bool philox = (a->flags & MAL_STEP_NOISE_PHILOX) != 0;
+    MsExtra x = {};
+    if (fold) {
+      x.seed = a->noise_seed; x.step = a->noise_step; x.counter = (const unsigned long long*)a->noise_counter; x.mult = (unsigned)S;
+      x.n_noise = philox ? S : 0;
+      for (int s = 0; s < S; ++s) x.noise[s] = w.noise[s];
+      x.up = m; x.n_up = k; x.B = B; x.H = H; x.W = W;
+      x.noise_blocks = (int)(((size_t)B * ((H + 3) / 4) * W + 63) / 64);
+      x.up_blocks = (int)(((size_t)B * H * (W / 4) + 63) / 64);
+    }
+    rc = pack_identity_launch(a->color0, a->color_m1, a->color_p1, B, H, W, w.packed[1], w.packed[2], w.packed[0], w.ident, st,
+                              &sp, nullptr, nullptr, nullptr, false, (a->flags & MAL_STEP_NO_SSIM) ? 1 : 0, nullptr,
+                              fold ? &x : nullptr);
     if (rc) return rc;
+    if (!fold) {
+      if (philox) {
+        rc = tiebreak_noise_launch(a->noise_seed, a->noise_step, (const unsigned long long*)a->noise_counter, (unsigned)S, S, B, H, W,
+                                   w.noise, st);
+        if (rc) return rc;
+      }
+      if (k > 0) {
+        upsample_launch(m, k, B, H, W, st);
+        rc = launch_status();
+        if (rc) return rc;
+      }
+    }
   }
   const int packed = MAL_F_SRC_PACKED | MAL_F_TGT_PACKED;
   const float merge_cons = (float)(1.0 / ((double)S * (double)B * H * W));
