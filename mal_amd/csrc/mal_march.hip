@@ -1630,7 +1630,12 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
                      (long long)p.H * p.W * (kTexel * 4) < (1ll << 24);  // tap byte offsets are formed in fp32 there
   const bool no_maps = !p.ext_mask && !p.lowest_cost && !p.sample_scale;
   const bool conv_a = p.convention == 0, conv_b = p.convention == 1;
-  const bool lean = lean0 && conv_a && no_maps && !p.disp2;                                                      // kSpecTeacher
+#ifdef MAL_CONV_FIXED
+  const bool conv_teacher = conv_a;  // (A/B build: the convention is compiled into the specialisations)
+#else
+  const bool conv_teacher = conv_a || conv_b;  // the specialised teacher pass reads the convention per launch: DualRefine's iteration 0 too
+#endif
+  const bool lean = lean0 && conv_teacher && no_maps && !p.disp2;                                                // kSpecTeacher
   const bool lean_student = lean0 && conv_a && !p.disp2 && p.ext_mask && p.lowest_cost && p.mono_disp;          // kSpecStudent
   const bool lean_student_nc = lean0 && conv_a && !p.disp2 && p.ext_mask && !p.lowest_cost && p.mono_disp;      // kSpecStudentNoCost
   const bool lean_refine = lean0 && conv_b && !p.disp2 && !p.lowest_cost && p.mono_disp && !p.sample_scale;     // kSpecRefine
