@@ -780,6 +780,40 @@ def test_dualrefine_pose_update_losses_in_the_one_call_step(shape, kw_extra):
     assert abs(got_l["loss/pose_0_0"]) > 1e-3 and got_l["reproj_loss/pose_0"] == got_l["loss/pose_0_0"]
 
 
+def test_dualrefine_pose_update_random_shapes_sweep():
+    """fixed-seed sweep over odd sizes and option pairs: the one-call step with the pose-update pass against the forced oracle
+    (the same gates as above), incl. widths that are no multiple of four and single-sample batches"""
+    import random
+    from mal_amd import dualrefine, layers
+    from mal_amd.synthetic import make_batch
+    rng = random.Random(977)
+    opts = [{}, {"Tstar_D0_pair": True}, {"Dstar_T0_pair": True, "disable_motion_masking": True}, {"no_ssim": True, "Tstar_D0_pair": True}, {}]
+    for i, extra in enumerate(opts):
+        B, H, W = rng.randint(1, 3), rng.randint(17, 60), rng.randint(33, 150)
+        batch = make_batch(B, H, W, seed=700 + i)
+        kw = dict(height=H, width=W, batch_size=B, n_losses=1)
+        kw.update(extra)
+        torch.manual_seed(60 + i)
+        noises = [torch.randn(B, 1, H, W) for _ in range(2)]
+        nz_pose = torch.randn(B, 1, H, W)
+        inputs, outputs, gl = _dr_build_pu(batch, "cuda:0", layers.transformation_from_parameters)
+        lp = dualrefine.DualRefineLossPath(dualrefine.default_options(disable_pose_updates=False, **kw), fuse=True)
+        got, decs = lp.loss_step(inputs, outputs, noises=[n.to("cuda:0") for n in noises], want_decisions=True,
+                                 pose_noise=nz_pose.to("cuda:0"))
+        got["loss"].backward()
+        torch.cuda.synchronize()
+        got_l = {k: float(v.detach()) for k, v in got.items()}
+        grads = {k: (t.grad if t.grad is not None else torch.zeros_like(t)).cpu().numpy() for k, t in gl.items()}
+        forced = {u: _dr_decode(decs[u]) for u in ((0, 0), (0, 1))}
+        fpose = _dr_decode(decs[("pose", 0)])
+        f32, g32, _, _ = _dr_oracle_pu(batch, kw, noises, nz_pose, forced=forced, forced_pose=fpose)
+        _, g64, _, _ = _dr_oracle_pu(batch, kw, noises, nz_pose, forced=_to64(forced), forced_pose=_to64(fpose), dtype=torch.float64)
+        try:
+            _dr_hold_against_forced_oracle(grads, {k: batch[k].numpy() for k in HH.LEAVES}, f32, g32, g64, got_l)
+        except AssertionError as e:
+            raise AssertionError(((B, H, W), extra, str(e)))
+
+
 def test_dualrefine_pose_update_one_call_against_the_operator_route_and_the_reference_fixture():
     """the same term through pose_update_generate_images_pred + compute_pose_update_losses (materialised candidates, other
     kernels) and against the values the reference's own Trainer methods produced for the fixture batch
