@@ -178,7 +178,7 @@ MAL_DEV void dec_store(unsigned* dbg, unsigned n, int plane, unsigned boff, unsi
 template <bool DERIV, bool POSE, bool DBG, bool LEAN, bool FRAMED = false, class BeforeGathers>
 MAL_DEV void warp_issue(const WarpConsts& p, const f2 (&P)[12], const float (&ik)[9], int b, int gyr, int gxr,
                         float dispv, PendingWarp& w, BeforeGathers before_gathers, float dispv1 = 0.f) {
-  static_assert(!FRAMED || (POSE && !LEAN), "FRAMED: pose variants of the generic passes only");
+  static_assert(!FRAMED || POSE, "FRAMED: pose variants only");
   const int W = p.W, H = p.H, HW = H * W, pix = gyr * W + gxr;
   const float depth = depth_of(dispv, p.min_disp, p.range);
   float ray[3], X[3];
@@ -347,7 +347,7 @@ MAL_DEV void march_body() {
   constexpr bool MONO_YES = (SPEC & kSpecMonoYes) != 0, NO_SCALE = (SPEC & kSpecNoScale) != 0;
   constexpr bool NO_NOISE = (SPEC & kSpecNoNoise) != 0;
   constexpr bool FRAMED = (SPEC & kSpecFramed) != 0;  // frame -1 warped with disp, frame +1 with disp2; two gradient maps
-  static_assert(!FRAMED || (GRAD && POSE && !LEAN && !NO_DISP2 && !EPI && !TEMPORAL && !EXPORT), "FRAMED: generic pose-gradient pass");
+  static_assert(!FRAMED || (GRAD && POSE && !NO_DISP2 && !EPI && !TEMPORAL && !EXPORT), "FRAMED: pose-gradient pass without epilogue");
 #ifdef MAL_CONV_FIXED  // A/B: Project3D's convention fixed at compile time in the specialised passes (measured 1 % SLOWER than the
   constexpr int CONV = (SPEC & kSpecConvA) ? 0 : ((SPEC & kSpecConvB) ? 1 : -1);  // scalar branch: profiles/r04_hsum_variants_ab.txt)
 #else
@@ -524,7 +524,7 @@ MAL_DEV void march_body() {
   constexpr bool SHADOW = MAL_SHADOW && H_MODE != 0 && GRAD;
   // ... the pose re-derivation only where its seven results fit next to the rest (the temporal and epilogue variants spill)
   constexpr bool SHADOW_POSE = SHADOW && POSE && !TEMPORAL && !EPI && !DBG;
-  struct PosePrep { f2 alq, beq; float X[3]; f2 Xf[FRAMED ? 3 : 1]; };  // Xf: the point per frame (FRAMED)
+  struct PosePrep { f2 alq, beq; float X[3]; f2 Xf0, Xf1, Xf2; };  // Xf*: the point per frame (FRAMED; scalars: an array member went to scratch)
   int it = 0;
   // One-row halo (p.bnd != nullptr, gradient passes of the whole-step list): a task warps ONE row beyond each end of its
   // segment and evaluates the statistics / decisions of its OWN rows only.  The gradient of a boundary row then lacks
@@ -717,8 +717,7 @@ MAL_DEV void march_body() {
     if (FRAMED) {  // frame 1's point and depth derivative come from its own disparity
       const float depth1 = depth_of(dw_2, p.min_disp, p.range);
       dd = (f2){ddepth, -(depth1 * depth1) * p.range};
-#pragma unroll
-      for (int j = 0; j < 3; ++j) o.Xf[j] = (f2){o.X[j], depth1 * ray[j]};
+      o.Xf0 = (f2){o.X[0], depth1 * ray[0]}; o.Xf1 = (f2){o.X[1], depth1 * ray[1]}; o.Xf2 = (f2){o.X[2], depth1 * ray[2]};
     }
     o.alq = (c0 - pq_u * c2) * pq_rz * dd;  // d u / d disp (the clip gate is inside du, dv)
     o.beq = (c1 - pq_v * c2) * pq_rz * dd;
@@ -807,10 +806,11 @@ MAL_DEV void march_body() {
       if (out_x) {
         const f2 a0 = gu * pq_rz, a1 = gv * pq_rz, a2 = -(gu * pq_u + gv * pq_v) * pq_rz;
         const f2 a[3] = {a0, a1, a2};
+        const f2 Xj[3] = {FRAMED ? pp.Xf0 : bc(X[0]), FRAMED ? pp.Xf1 : bc(X[1]), FRAMED ? pp.Xf2 : bc(X[2])};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
-          for (int j = 0; j < 3; ++j) gP[i * 4 + j] = fma2(a[i], FRAMED ? pp.Xf[j] : bc(X[j]), gP[i * 4 + j]);
+          for (int j = 0; j < 3; ++j) gP[i * 4 + j] = fma2(a[i], Xj[j], gP[i * 4 + j]);
           gP[i * 4 + 3] += a[i];
         }
       }
@@ -1297,6 +1297,10 @@ template <bool AUTOMASK, bool DBG>
 __global__ __launch_bounds__(64, 2) void march_framed_kernel(MarchParams p_kernarg) {
   march_body<true, AUTOMASK, true, false, DBG, false, false, kSpecFramed>();
 }
+// ... specialised like the other passes of the one-call lists (packed texels, no mask operands): what mal_dr_loss_fwd launches
+__global__ __launch_bounds__(64, 2) void march_framed_lean_kernel(MarchParams p_kernarg) {
+  march_body<true, true, true, false, false, false, false, kSpecFramed | kSpecLean | kSpecExtNo | kSpecCostNo | kSpecNoScale>();
+}
 
 #ifdef MAL_EXPERIMENTS  // option "march3" (measured slower, LABBOOK.md 6): not in the default build
 #include "experiments/march3.inc"
@@ -1663,8 +1667,11 @@ int march_launch(MarchParams& p, int flags, hipStream_t st) {
         p.forced_w || p.color_out[0] || p.lowest_cost || p.depth_out)
       return MAL_EINVAL;
     if (p.dbg && (p.H >= 4096 || p.W >= 4096)) return MAL_EINVAL;
+    const bool framed_lean = g_march_lean && p.packed == 3 && p.debug == 0 && !p.avg && !p.no_ssim && !p.ext_mask && !p.sample_scale &&
+                             (long long)p.H * p.W * (kTexel * 4) < (1ll << 24);
     if (automask) {
       if (p.dbg) hipLaunchKernelGGL((march_framed_kernel<true, true>), grid, block, 0, st, p);
+      else if (framed_lean) hipLaunchKernelGGL(march_framed_lean_kernel, grid, block, 0, st, p);
       else hipLaunchKernelGGL((march_framed_kernel<true, false>), grid, block, 0, st, p);
     } else {
       if (p.dbg) hipLaunchKernelGGL((march_framed_kernel<false, true>), grid, block, 0, st, p);
