@@ -152,6 +152,15 @@ struct DrExtra {
   unsigned long long seed, step; const unsigned long long* counter;
   int slots, pu_slot, noise_blocks, B, H, W; unsigned* ticket;
 };
+// the arguments of one fused sweep over a materialised candidate pair (photo_march_fused_more, mal_photo_march.hip), for the
+// batched launch photo_march_fused_more_n
+struct FusedMoreArgs {
+  const float* target; const float* cand0; const float* cand1; int idx0; const float* ident; const float* noise;
+  const float* prev_min; const uint8_t* prev_arg; float* min_reproj; uint8_t* argmin; float* weight_out; double* block_sums;
+  float* g_cand0; float* g_cand1; const uint8_t* region; float* g_region0; float* g_region1; const float* orig0; const float* orig1;
+  size_t orig_stride; int weight_given;
+};
+int photo_march_fused_more_n(int n, const FusedMoreArgs* a, int B, int H, int W, int* per_sample_out, hipStream_t st);
 // The four-scale step (mal_step_ms.hip): its per-scale tie-break noise maps (MAL_STEP_NOISE_PHILOX) and the bilinear
 // upsampling of the lower scales' disparities to full resolution (trainer.py:1094-1096) -- neither reads anything the
 // identity / packing sweep writes -- as extra workgroups of that sweep's launch instead of two launches behind it.

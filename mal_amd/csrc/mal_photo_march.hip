@@ -16,6 +16,7 @@
 // mal_set_option("photo_impl", 0); they also serve MAL_F_NO_SSIM / MAL_F_AVG).
 #include "mal_common.h"
 #include "mal_device.h"
+#include "mal_march.h"  // FusedMoreArgs
 #include "mal_pairs.h"
 
 namespace mal {
@@ -193,8 +194,9 @@ __global__ __launch_bounds__(64, 4) void photo_march_fwd_kernel(PhotoMarchParams
 // (the pass in front of the producer wrote them, with its sums): this sweep overwrites them only at the pixels it
 // re-decides and leaves per-task DIFFERENCES of sum(rp*w), sum(w) -- a task the producer's region does not reach
 // writes zero gradients, zero differences and nothing else.
+// slot: the parameter block's index inside the kernel's argument (the batched launch: one block per scale)
 template <bool FUSED>
-MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
+MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task, const int slot = 0) {
   constexpr int HALO = 2, CW = 60;
   const int per_b = p.strips * p.segs;
   const int b = task / per_b, tt = task - b * per_b;
@@ -217,7 +219,7 @@ MAL_DEV void photo_march_bwd_task(const PhotoMarchParams& p, const int task) {
   const bool sparse = FUSED && p.region && p.orig[0];
   const unsigned org_b = sparse ? (unsigned)b * (unsigned)p.orig_stride * 4u : 0u;
   typedef __attribute__((address_space(4))) const PhotoMarchParams CPhoto;
-  CPhoto* const kp0 = (CPhoto*)__builtin_amdgcn_kernarg_segment_ptr();  // (the kernel's only argument)
+  CPhoto* const kp0 = (CPhoto*)__builtin_amdgcn_kernarg_segment_ptr() + slot;  // (the kernel's only argument: block `slot` of it)
   float sc = p.scale ? *p.scale : 1.0f;
   if (p.sums) sc = (float)((double)sc / (p.sums[1] + 1e-7));
   f2 hsA[9], hsB[9], hyA[2], hyB[2], hcA[9], hcB[9];
@@ -475,6 +477,19 @@ __global__ __launch_bounds__(64, 2) void photo_march_bwd_kernel(PhotoMarchParams
   const int task = (id & 7) * p.per_xcd + (id >> 3);
   if (task >= p.ntasks) return;
   photo_march_bwd_task<FUSED>(p, task);
+}
+
+// The fused sweeps of several scales (the four-scale --temporal step: same shape, independent operands) as ONE launch,
+// blockIdx.y = scale: each is region-gated -- a few short tasks on an otherwise idle chip -- and four of them one behind the
+// other took 135 us where one takes 30-40.
+struct PhotoMarchBatch { PhotoMarchParams s[MAL_MS_MAX_SCALES]; };
+__global__ __launch_bounds__(64, 2) void photo_march_bwd_batch_kernel(PhotoMarchBatch q) {
+  const int slot = blockIdx.y;
+  const PhotoMarchParams& p = q.s[slot];
+  const int id = blockIdx.x;
+  const int task = (id & 7) * p.per_xcd + (id >> 3);
+  if (task >= p.ntasks) return;
+  photo_march_bwd_task<true>(p, task, slot);
 }
 
 #ifdef MAL_EXPERIMENTS  // option "syn_queue" (measured slower, LABBOOK.md 6): not in the default build
@@ -736,30 +751,22 @@ int photo_march_bwd(const float* target, const float* const* cand, int n_cand, c
 // min_reproj / argmin / weight_out arrive holding the decision over the earlier candidates and are overwritten where this
 // pair is re-decided; per-task partials [task][2] = DIFFERENCES of sum(rp*w), sum(w) against that earlier decision; and
 // d sum(rp*w) / d candidate, unnormalised.  order (nullable): >= ntasks device words, order_count: two zeroed words.
+static int fused_more_params(PhotoMarchParams& p, const float* target, const float* cand0, const float* cand1, int idx0,
+                             const float* ident, const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H,
+                             int W, float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
+                             float* g_cand1, const uint8_t* region, float* g_region0, float* g_region1, const float* orig0,
+                             const float* orig1, size_t orig_stride, int target_texels, int weight_given);
 int photo_march_fused_more(const float* target, const float* cand0, const float* cand1, int idx0, const float* ident,
                            const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H, int W,
                            float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
                            float* g_cand1, int* per_sample_out, hipStream_t st, const uint8_t* region, float* g_region0,
                            float* g_region1, unsigned* order, unsigned* order_count, const float* orig0, const float* orig1,
                            size_t orig_stride, int target_texels, int weight_given) {
-  if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
-  if (weight_given && noise) return MAL_EINVAL;
-  if ((orig0 == nullptr) != (orig1 == nullptr) || (orig0 && !region)) return MAL_EINVAL;
-  if (!target_texels) return MAL_EINVAL;  // the fused sweep reads the target as texels (compile-time in the kernel)
-  if ((long long)B * 3 * H * W * 4 >= (1ll << 32)) return MAL_ESHAPE;  // (B,3,H,W) images are addressed with 32-bit byte offsets
-  if (orig0 && (long long)B * (long long)(orig_stride ? orig_stride : (size_t)3 * H * W) * 4 >= (1ll << 32)) return MAL_ESHAPE;  // 32-bit byte offsets
   PhotoMarchParams p = {};
-  p.target = target; p.target_texels = target_texels; p.weight_given = weight_given; p.B = B; p.H = H; p.W = W;
-  p.cand[0] = cand0; p.cand[1] = cand1; p.idx[0] = idx0; p.idx[1] = idx0 + 1;
-  p.prev_min = prev_min; p.prev_arg = prev_arg; p.ident = ident; p.noise = noise;
-  p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;
-  p.g_cand[0] = g_cand0; p.g_cand[1] = g_cand1; p.region = region;
-  p.orig[0] = orig0; p.orig[1] = orig1; p.orig_stride = orig_stride ? orig_stride : (size_t)3 * H * W;
-  if (region && g_region0 && g_region1) { p.g_region[0] = g_region0; p.g_region[1] = g_region1; }
-  // with a region map the few tasks that do the full work set the kernel's duration (every task is resident at once, and
-  // a wavefront alone on its SIMD marches no faster): shorter tasks, four times as many (the workspace holds 2-row tasks)
-  if (region && g_syn_rows >= 2 && g_syn_rows < 8) decompose(p, 60, 8, g_syn_rows); else
-  decompose(p, 60, 2);
+  int rc = fused_more_params(p, target, cand0, cand1, idx0, ident, noise, prev_min, prev_arg, B, H, W, min_reproj, argmin, weight_out,
+                             block_sums, g_cand0, g_cand1, region, g_region0, g_region1, orig0, orig1, orig_stride, target_texels,
+                             weight_given);
+  if (rc) return rc;
   *per_sample_out = p.strips * p.segs;
   unsigned grid = (unsigned)p.per_xcd * 8u;
 #ifdef MAL_EXPERIMENTS
@@ -773,6 +780,58 @@ int photo_march_fused_more(const float* target, const float* cand0, const float*
 #endif
   hipLaunchKernelGGL(photo_march_bwd_kernel<true>, dim3(grid), dim3(64), 0, st, p);
   return launch_status();
+}
+
+// n <= MAL_MS_MAX_SCALES fused sweeps of one shape in ONE launch (mal_march.h: FusedMoreArgs = the arguments above)
+int photo_march_fused_more_n(int n, const FusedMoreArgs* a, int B, int H, int W, int* per_sample_out, hipStream_t st) {
+  if (n < 1 || n > MAL_MS_MAX_SCALES) return MAL_EINVAL;
+  PhotoMarchBatch q = {};
+  for (int k = 0; k < n; ++k) {
+    const FusedMoreArgs& x = a[k];
+    const int rc = fused_more_params(q.s[k], x.target, x.cand0, x.cand1, x.idx0, x.ident, x.noise, x.prev_min, x.prev_arg, B, H, W,
+                                     x.min_reproj, x.argmin, x.weight_out, x.block_sums, x.g_cand0, x.g_cand1, x.region, x.g_region0,
+                                     x.g_region1, x.orig0, x.orig1, x.orig_stride, 1, x.weight_given);
+    if (rc) return rc;
+    if (q.s[k].ntasks != q.s[0].ntasks) return MAL_EINVAL;  // (a scale without a region map decomposes differently: not batched)
+  }
+  *per_sample_out = q.s[0].strips * q.s[0].segs;
+  hipLaunchKernelGGL(photo_march_bwd_batch_kernel, dim3((unsigned)q.s[0].per_xcd * 8u, (unsigned)n), dim3(64), 0, st, q);
+  return launch_status();
+}
+
+static int fused_more_params_impl(PhotoMarchParams& p, const float* target, const float* cand0, const float* cand1, int idx0,
+                                  const float* ident, const float* noise, const float* prev_min, const uint8_t* prev_arg, int B,
+                                  int H, int W, float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums,
+                                  float* g_cand0, float* g_cand1, const uint8_t* region, float* g_region0, float* g_region1,
+                                  const float* orig0, const float* orig1, size_t orig_stride, int target_texels, int weight_given) {
+  if (prev_min == min_reproj || prev_arg == argmin) return MAL_EINVAL;
+  if (weight_given && noise) return MAL_EINVAL;
+  if ((orig0 == nullptr) != (orig1 == nullptr) || (orig0 && !region)) return MAL_EINVAL;
+  if (!target_texels) return MAL_EINVAL;  // the fused sweep reads the target as texels (compile-time in the kernel)
+  if ((long long)B * 3 * H * W * 4 >= (1ll << 32)) return MAL_ESHAPE;  // (B,3,H,W) images are addressed with 32-bit byte offsets
+  if (orig0 && (long long)B * (long long)(orig_stride ? orig_stride : (size_t)3 * H * W) * 4 >= (1ll << 32)) return MAL_ESHAPE;  // 32-bit byte offsets
+  p = PhotoMarchParams{};
+  p.target = target; p.target_texels = target_texels; p.weight_given = weight_given; p.B = B; p.H = H; p.W = W;
+  p.cand[0] = cand0; p.cand[1] = cand1; p.idx[0] = idx0; p.idx[1] = idx0 + 1;
+  p.prev_min = prev_min; p.prev_arg = prev_arg; p.ident = ident; p.noise = noise;
+  p.min_reproj = min_reproj; p.argmin = argmin; p.weight_out = weight_out; p.block_sums = block_sums;
+  p.g_cand[0] = g_cand0; p.g_cand[1] = g_cand1; p.region = region;
+  p.orig[0] = orig0; p.orig[1] = orig1; p.orig_stride = orig_stride ? orig_stride : (size_t)3 * H * W;
+  if (region && g_region0 && g_region1) { p.g_region[0] = g_region0; p.g_region[1] = g_region1; }
+  // with a region map the few tasks that do the full work set the kernel's duration (every task is resident at once, and
+  // a wavefront alone on its SIMD marches no faster): shorter tasks, four times as many (the workspace holds 2-row tasks)
+  if (region && g_syn_rows >= 2 && g_syn_rows < 8) decompose(p, 60, 8, g_syn_rows); else
+  decompose(p, 60, 2);
+  return MAL_OK;
+}
+static int fused_more_params(PhotoMarchParams& p, const float* target, const float* cand0, const float* cand1, int idx0,
+                             const float* ident, const float* noise, const float* prev_min, const uint8_t* prev_arg, int B, int H,
+                             int W, float* min_reproj, uint8_t* argmin, float* weight_out, double* block_sums, float* g_cand0,
+                             float* g_cand1, const uint8_t* region, float* g_region0, float* g_region1, const float* orig0,
+                             const float* orig1, size_t orig_stride, int target_texels, int weight_given) {
+  return fused_more_params_impl(p, target, cand0, cand1, idx0, ident, noise, prev_min, prev_arg, B, H, W, min_reproj, argmin,
+                                weight_out, block_sums, g_cand0, g_cand1, region, g_region0, g_region1, orig0, orig1, orig_stride,
+                                target_texels, weight_given);
 }
 
 }  // namespace mal

@@ -686,10 +686,25 @@ static int ms_back(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool tem
   if (temporal) {
     march_geometry(B, H, W, 0, &strips, &segs, nullptr);
     fin.per_sample_t = strips * segs;
+    // every scale's sweep in ONE launch when all of them have a region map (same decomposition): each is a few short tasks
+    bool batch = g_ms_fold && S > 1;
+    for (int s = 0; s < S; ++s) batch = batch && a->syn_region[s] != nullptr;
+    FusedMoreArgs fa[kMsS] = {};
     for (int s = 0; s < S; ++s) {
       if (!a->syn_m1[s] || !a->syn_p1[s] || !a->g_syn_m1[s] || !a->g_syn_p1[s]) { (void)side_wait(st, false); return MAL_EINVAL; }
       const bool sparse = (a->syn_sparse >> s) & 1;
       if (sparse && (!a->syn_region[s] || !a->warp_m1[s] || !a->warp_p1[s])) { (void)side_wait(st, false); return MAL_EINVAL; }
+      if (batch) {
+        FusedMoreArgs& x = fa[s];
+        x.target = w.packed[0]; x.cand0 = a->syn_m1[s]; x.cand1 = a->syn_p1[s]; x.idx0 = 2; x.ident = w.ident; x.noise = ms_noise(a, w, s);
+        x.prev_min = w.rp_warp[s]; x.prev_arg = w.arg_warp[s]; x.min_reproj = w.rp4[s]; x.argmin = w.arg_t[s]; x.weight_out = w.w_t[s];
+        x.block_sums = w.bs_ph[s]; x.g_cand0 = a->g_syn_m1[s]; x.g_cand1 = a->g_syn_p1[s]; x.region = a->syn_region[s];
+        x.g_region0 = a->g_syn_region_m1[s]; x.g_region1 = a->g_syn_region_p1[s];
+        x.orig0 = sparse ? a->warp_m1[s] : nullptr; x.orig1 = sparse ? a->warp_p1[s] : nullptr;
+        x.orig_stride = (size_t)a->warp_sample_stride; x.weight_given = 0;
+        fin.bs_ph[s] = w.bs_ph[s];
+        continue;
+      }
       int rc = photo_march_fused_more(w.packed[0], a->syn_m1[s], a->syn_p1[s], 2, w.ident, ms_noise(a, w, s), w.rp_warp[s],
                                       w.arg_warp[s], B, H, W, w.rp4[s], w.arg_t[s], w.w_t[s], w.bs_ph[s], a->g_syn_m1[s],
                                       a->g_syn_p1[s], &fin.per_sample_ph[s], st, a->syn_region[s], a->g_syn_region_m1[s],
@@ -697,6 +712,12 @@ static int ms_back(const mal_ms_args* a, const MsWs& w, hipStream_t st, bool tem
                                       sparse ? a->warp_p1[s] : nullptr, (size_t)a->warp_sample_stride, 1, 0);
       if (rc) { (void)side_wait(st, false); return rc; }
       fin.bs_ph[s] = w.bs_ph[s];
+    }
+    if (batch) {
+      int per = 0;
+      const int rc = photo_march_fused_more_n(S, fa, B, H, W, &per, st);
+      if (rc) { (void)side_wait(st, false); return rc; }
+      for (int s = 0; s < S; ++s) fin.per_sample_ph[s] = per;
     }
     // the students' passes and the smoothness sweeps ran on the side stream beside the producers (mal_loss_multiscale_warp)
     int rc = side_wait(st, false);
