@@ -1550,6 +1550,7 @@ extern opt_t g_syn_queue;       // mal_photo_march.hip
 extern opt_t g_step_overlap;    // mal_step.hip
 extern opt_t g_student_overlap; // mal_step.hip
 extern opt_t g_tail_overlap;    // mal_step.hip
+extern opt_t g_sweeps_batched;  // mal_step.hip
 extern opt_t g_ms_fold;         // mal_step_ms.hip
 extern opt_t g_dyn_small_blocks; // mal_dyn.hip
 extern opt_t g_side_priority;   // mal_step.hip
@@ -1809,6 +1810,7 @@ extern "C" int mal_set_option(const char* name, int value) {
   if (eq("march_halo1")) { g_march_halo1 = value != 0; return MAL_OK; }
   if (eq("student_overlap")) { g_student_overlap = value != 0; return MAL_OK; }
   if (eq("ms_fold")) { g_ms_fold = value != 0; return MAL_OK; }
+  if (eq("sweeps_batched")) { g_sweeps_batched = value != 0; return MAL_OK; }
   if (eq("tail_overlap")) { g_tail_overlap = value != 0; return MAL_OK; }
   if (eq("dyn_small_blocks")) { g_dyn_small_blocks = value != 0; return MAL_OK; }
   if (eq("side_order")) { g_side_order = value != 0; return MAL_OK; }

@@ -794,6 +794,8 @@ namespace mal { opt_t g_student_overlap{1}; opt_t g_side_order{0}; }
 // library's side stream behind the FUSED SWEEP only, beside the epilogue and the reduction of the forward (in a captured graph
 // the two chains are independent; eager: the same order as before, the side stream simply has nothing to wait for)
 namespace mal { opt_t g_tail_overlap{1}; }
+// option "sweeps_batched" (A/B): --temporal --main_temporal: the teacher's and the student's fused sweep as one launch
+namespace mal { opt_t g_sweeps_batched{1}; }
 static bool tail_applies(const mal_step_args* a) {
   return g_tail_overlap && g_step_overlap == 1 && !g_temporal_spec && (a->flags & (MAL_STEP_TEMPORAL | MAL_STEP_MAIN_TEMPORAL)) &&
          side_stream((hipStream_t)a->stream) != nullptr;
@@ -941,6 +943,7 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
 
   int per_sample_p = 1, per_sample_ph = 0;
   int per_sample = 1, per_sample_t = 0;
+  bool both_sweeps = false;
   {  // tasks per sample of the teacher's sums: its gradient pass, or (temporal hint) the forward pass in front of the producer
     int strips = 0, segs = 0;
     march_geometry(B, H, W, temporal && !g_temporal_spec ? 0 : MAL_F_GRAD, &strips, &segs, nullptr);
@@ -968,6 +971,9 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     const bool sparse = (a->flags & MAL_STEP_SYN_SPARSE) != 0;
     if (sparse && (!a->syn_region || !a->warp_m1 || !a->warp_p1)) { (void)join_side(st); return MAL_EINVAL; }
     per_sample_p = pack_identity_tasks_per_sample(H, W);
+    // with --main_temporal too, both passes' sweeps (region-gated: a few short tasks each) go out as ONE launch, below
+    both_sweeps = main_t && g_sweeps_batched && a->syn_region && a->syn_s_region;
+    if (!both_sweeps)
     rc = photo_march_fused_more(w.packed[0], a->syn_m1, a->syn_p1, 2, w.ident, a->noise, w.rp_warp, w.arg_warp, B, H, W,
                                 mono_reproj, w.arg_t, w.w_t, w.bs_ph, a->g_syn_m1, a->g_syn_p1, &per_sample_ph, st, a->syn_region,
                                 a->g_syn_region_m1, a->g_syn_region_p1, w.order, w.ticket + 1,
@@ -976,7 +982,27 @@ extern "C" int mal_loss_step_fwd(const mal_step_args* a) {
     if (rc) { (void)join_side(st); return rc; }
   }
   int per_sample_sh = 0;
-  if (main_t) {
+  if (main_t && both_sweeps) {
+    if (!a->syn_s_m1 || !a->syn_s_p1 || !a->g_syn_s_m1 || !a->g_syn_s_p1) { (void)join_side(st); return MAL_EINVAL; }
+    const bool sp_t = (a->flags & MAL_STEP_SYN_SPARSE) != 0, sp_s = (a->flags & MAL_STEP_SYN_S_SPARSE) != 0;
+    if (sp_s && (!a->warp_s_m1 || !a->warp_s_p1)) { (void)join_side(st); return MAL_EINVAL; }
+    FusedMoreArgs fa[2] = {};
+    fa[0].target = w.packed[0]; fa[0].cand0 = a->syn_m1; fa[0].cand1 = a->syn_p1; fa[0].idx0 = 2; fa[0].ident = w.ident; fa[0].noise = a->noise;
+    fa[0].prev_min = w.rp_warp; fa[0].prev_arg = w.arg_warp; fa[0].min_reproj = mono_reproj; fa[0].argmin = w.arg_t; fa[0].weight_out = w.w_t;
+    fa[0].block_sums = w.bs_ph; fa[0].g_cand0 = a->g_syn_m1; fa[0].g_cand1 = a->g_syn_p1; fa[0].region = a->syn_region;
+    fa[0].g_region0 = a->g_syn_region_m1; fa[0].g_region1 = a->g_syn_region_p1;
+    fa[0].orig0 = sp_t ? a->warp_m1 : nullptr; fa[0].orig1 = sp_t ? a->warp_p1 : nullptr; fa[0].orig_stride = (size_t)a->warp_sample_stride;
+    fa[1].target = w.packed[0]; fa[1].cand0 = a->syn_s_m1; fa[1].cand1 = a->syn_s_p1; fa[1].idx0 = 2; fa[1].ident = w.w_s; fa[1].noise = nullptr;
+    fa[1].prev_min = w.rp_warp_s; fa[1].prev_arg = w.arg_warp_s; fa[1].min_reproj = a->multi_reproj ? a->multi_reproj : w.multi_reproj;
+    fa[1].argmin = w.arg_s; fa[1].weight_out = w.w_s; fa[1].block_sums = w.bs_sh; fa[1].g_cand0 = a->g_syn_s_m1; fa[1].g_cand1 = a->g_syn_s_p1;
+    fa[1].region = a->syn_s_region; fa[1].g_region0 = a->g_syn_s_region_m1; fa[1].g_region1 = a->g_syn_s_region_p1;
+    fa[1].orig0 = sp_s ? a->warp_s_m1 : nullptr; fa[1].orig1 = sp_s ? a->warp_s_p1 : nullptr; fa[1].orig_stride = (size_t)a->warp_sample_stride;
+    fa[1].weight_given = 1;  // `ident` is the weight
+    int per = 0;
+    rc = photo_march_fused_more_n(2, fa, B, H, W, &per, st);
+    if (rc) { (void)join_side(st); return rc; }
+    per_sample_ph = per_sample_sh = per;
+  } else if (main_t) {
     // --main_temporal: the student's pair joins ITS running min the same way; the weight is the pass's mask (w_s), whatever wins
     if (!a->syn_s_m1 || !a->syn_s_p1 || !a->g_syn_s_m1 || !a->g_syn_s_p1) { (void)join_side(st); return MAL_EINVAL; }
     const bool sparse = (a->flags & MAL_STEP_SYN_S_SPARSE) != 0;
